@@ -1,0 +1,474 @@
+// bsw -- banded Smith-Waterman seed extension on gfx950.
+//
+// Semantics: BandedPairWiseSW::scalarBandedSWA
+//   (/root/reference/benchmarks/bsw/src/bandedSWA.cpp:132-253), which is what the
+//   reference's inter-sequence SIMD path (getScores16, bandedSWA.cpp:1128-1835) emulates
+//   lane by lane.  The CPU vectorises ACROSS pairs (one pair per 16-bit SIMD lane) because
+//   the adaptive band, the z-drop exit and the first/last-max tie rules make the rows of
+//   one pair strictly sequential.  The MI355X equivalent of that idea is one pair per
+//   wavefront lane:
+//
+//   1. bucket  -- counting sort of the pairs by (query length, reference length / 8) so
+//                 that the 64 lanes of a wave carry near-identical work and diverge little
+//                 (the reference sorts by len1 for the same reason, bandedSWA.cpp:372-407);
+//   2. bsw_dp  -- one wave (= one workgroup) per 64 sorted pairs.  The H/E row of every
+//                 lane lives in LDS as [column][lane] dwords (bank = lane, conflict-free
+//                 for any per-lane column), H and E packed as two u16 in one dword when
+//                 max(h0) + 256*max(mat) fits 15 bits (the reference's own int16 lanes),
+//                 else two dwords.  LDS is sized per launch from the query-length class, so
+//                 short queries get up to 8 waves/CU and 256-base queries still fit.
+//   Results are scattered back by pair id, so the output order is the input order.
+//
+// Roofline: integer-VALU / LDS bound (~20 VALU + 1 LDS read + 1 LDS write per DP cell,
+// ~7.4 k cells per ~210 input bytes); HBM traffic is the algorithmic minimum
+// len1 + len2 + 12 B per pair plus the 4-byte permutation entry.
+#include "gab_internal.h"
+#include <new>
+#include <string.h>
+
+namespace {
+
+constexpr int kQBuckets = 256;            // query length 1..256 -> 0..255
+constexpr int kTBuckets = 256;            // min(tlen >> 3, 255)
+constexpr int kNumKeys = kQBuckets * kTBuckets;
+constexpr int kClassStep = 16;            // query-length classes for LDS sizing
+constexpr int kNumClasses = kQBuckets / kClassStep;
+
+struct BswConst {
+    int32_t o_del, e_del, o_ins, e_ins, zdrop, end_bonus, w, max_sc;
+    uint32_t row_lo[5];   // biased (+128) scores mat[t][0..3], one byte each
+    uint32_t row_hi[5];   // biased score mat[t][4] in byte 0
+};
+
+struct BswStats {          // device-side, zeroed per run
+    unsigned long long cells;
+    int32_t max_h0;
+    int32_t bad;           // number of pairs that failed validation
+    int32_t first_bad;     // smallest failing index + 1
+    int32_t pad;
+};
+
+struct BswIO {
+    const uint8_t *ref; const int64_t *ref_off;
+    const uint8_t *qry; const int64_t *qry_off;
+    const int32_t *len1, *len2, *h0;
+    int64_t ref_bytes, qry_bytes, n;
+};
+
+__device__ __forceinline__ int bsw_key(int qlen, int tlen) {
+    int tb = tlen >> 3; if (tb > kTBuckets - 1) tb = kTBuckets - 1;
+    return (qlen - 1) * kTBuckets + tb;
+}
+
+// ---- pass 1: validate + histogram ------------------------------------------------------
+__global__ __launch_bounds__(256) void bsw_hist(BswIO io, uint32_t *hist, BswStats *st) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    int mh = 0;
+    for (; i < io.n; i += stride) {
+        int ql = io.len2[i], tl = io.len1[i], h = io.h0[i];
+        int64_t ro = io.ref_off[i], qo = io.qry_off[i];
+        bool ok = ql >= 1 && ql <= GAB_BSW_MAX_QLEN && tl >= 1 && tl <= GAB_BSW_MAX_TLEN && h >= 0 &&
+                  h <= (1 << 29) && ro >= 0 && qo >= 0 &&
+                  ((ro + tl + 3) & ~3ll) <= io.ref_bytes && ((qo + ql + 3) & ~3ll) <= io.qry_bytes;
+        if (!ok) {
+            atomicAdd(&st->bad, 1);
+            atomicMin((unsigned int *)&st->first_bad, (unsigned int)(i + 1 > 0x7fffffff ? 0x7fffffff : i + 1));
+            continue;
+        }
+        mh = h > mh ? h : mh;
+        atomicAdd(&hist[bsw_key(ql, tl)], 1u);
+    }
+    // wave max of h0, one atomic per wave
+    for (int o = 32; o > 0; o >>= 1) { int v = __shfl_xor(mh, o); mh = v > mh ? v : mh; }
+    if ((threadIdx.x & 63) == 0 && mh > 0) atomicMax(&st->max_h0, mh);
+}
+
+// ---- pass 2: exclusive scan of the 65536 bins (single workgroup) ---------------------------
+__global__ __launch_bounds__(1024) void bsw_scan(const uint32_t *hist, uint32_t *start, uint32_t *cursor,
+                                                 uint32_t *qstart) {
+    __shared__ uint32_t part[1024];
+    const int t = threadIdx.x;
+    constexpr int per = kNumKeys / 1024;   // 64 consecutive bins per thread
+    uint32_t s = 0;
+    for (int k = 0; k < per; k++) s += hist[t * per + k];
+    part[t] = s;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        uint32_t v = t >= o ? part[t - o] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    uint32_t run = part[t] - s;
+    for (int k = 0; k < per; k++) {
+        int b = t * per + k;
+        start[b] = run; cursor[b] = run;
+        if ((b % kTBuckets) == 0) qstart[b / kTBuckets] = run;
+        run += hist[b];
+    }
+    if (t == 1023) { start[kNumKeys] = run; qstart[kQBuckets] = run; }
+}
+
+// ---- pass 3: scatter pair ids into bucket order -------------------------------------------
+__global__ __launch_bounds__(256) void bsw_scatter(BswIO io, uint32_t *cursor, uint32_t *perm) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < io.n; i += stride) {
+        int ql = io.len2[i], tl = io.len1[i];
+        if (ql < 1 || ql > GAB_BSW_MAX_QLEN || tl < 1 || tl > GAB_BSW_MAX_TLEN) continue;
+        uint32_t pos = atomicAdd(&cursor[bsw_key(ql, tl)], 1u);
+        perm[pos] = (uint32_t)i;
+    }
+}
+
+// ---- pass 4: the DP ------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t load_u32_unaligned(const uint8_t *p) {
+    uint32_t w;
+    __builtin_memcpy(&w, p, 4);
+    return w;
+}
+
+// WIDE = false: H and E packed as (E << 16) | H in one dword per column (both < 2^15).
+// WIDE = true : H at lds[j*64+lane], E at lds[(qcap+1+j)*64+lane].
+template <bool WIDE>
+__global__ __launch_bounds__(64) void bsw_dp(BswIO io, BswConst c, const uint32_t *__restrict__ perm,
+                                            int64_t kbeg, int64_t kend, int qcap,
+                                            int32_t *__restrict__ score_out,
+                                            gab_bsw_result *__restrict__ result_out, BswStats *st) {
+    extern __shared__ uint32_t lds[];
+    const int lane = threadIdx.x;
+    const int64_t k = kbeg + (int64_t)blockIdx.x * 64 + lane;
+    const bool valid = k < kend;
+    const uint32_t id = valid ? perm[k] : 0u;
+
+    uint32_t *const H = lds + lane;                                   // [j*64]
+    uint32_t *const E = lds + (size_t)(qcap + 1) * 64 + lane;         // WIDE only
+    uint8_t *const QC = reinterpret_cast<uint8_t *>(lds + (size_t)(WIDE ? 2 : 1) * (qcap + 1) * 64) + lane * 4;
+    // query code j of this lane: QC[(j >> 2) * 256 + (j & 3)]
+
+    unsigned long long cells = 0;
+    if (valid) {
+        const int qlen = io.len2[id], tlen = io.len1[id], h0 = io.h0[id];
+        const uint8_t *q = io.qry + io.qry_off[id];
+        const uint8_t *t = io.ref + io.ref_off[id];
+        const int oe_del = c.o_del + c.e_del, oe_ins = c.o_ins + c.e_ins;
+        const int e_del = c.e_del, e_ins = c.e_ins;
+
+        for (int w4 = 0; w4 * 4 < qlen; w4++)
+            *reinterpret_cast<uint32_t *>(QC + w4 * 256) = load_u32_unaligned(q + w4 * 4);
+
+        // row -1 (bandedSWA.cpp:159-161); E starts at 0 everywhere
+        {
+            int prev = h0;
+            for (int j = 0; j <= qlen; j++) {
+                int v;
+                if (j == 0) v = h0;
+                else if (j == 1) v = h0 > oe_ins ? h0 - oe_ins : 0;
+                else v = prev > e_ins ? prev - e_ins : 0;
+                prev = v;
+                H[j * 64] = (uint32_t)v;
+                if (WIDE) E[j * 64] = 0u;
+            }
+        }
+        // band clamp (bandedSWA.cpp:164-172)
+        int w = c.w;
+        {
+            int lim = (int)((double)(qlen * c.max_sc + c.end_bonus - c.o_ins) / e_ins + 1.);
+            lim = lim > 1 ? lim : 1; w = w < lim ? w : lim;
+            lim = (int)((double)(qlen * c.max_sc + c.end_bonus - c.o_del) / e_del + 1.);
+            lim = lim > 1 ? lim : 1; w = w < lim ? w : lim;
+        }
+
+        int best = h0, best_i = -1, best_j = -1, g_i = -1, gscore = -1, max_off = 0;
+        int beg = 0, end = qlen;
+        uint32_t tw = load_u32_unaligned(t);       // 4 reference bases, refreshed every 4 rows
+        for (int i = 0; i < tlen; i++) {
+            const int tc = (tw >> ((i & 3) * 8)) & 0xff;
+            if ((i & 3) == 3 && i + 1 < tlen) tw = load_u32_unaligned(t + i + 1);
+            // biased score bytes for this reference base (codes >= 4 are N)
+            uint32_t rlo = c.row_lo[4], rhi = c.row_hi[4];
+            rlo = tc == 0 ? c.row_lo[0] : rlo; rhi = tc == 0 ? c.row_hi[0] : rhi;
+            rlo = tc == 1 ? c.row_lo[1] : rlo; rhi = tc == 1 ? c.row_hi[1] : rhi;
+            rlo = tc == 2 ? c.row_lo[2] : rlo; rhi = tc == 2 ? c.row_hi[2] : rhi;
+            rlo = tc == 3 ? c.row_lo[3] : rlo; rhi = tc == 3 ? c.row_hi[3] : rhi;
+
+            if (beg < i - w) beg = i - w;
+            if (end > i + w + 1) end = i + w + 1;
+            if (end > qlen) end = qlen;
+            int hleft = 0;
+            if (beg == 0) { hleft = h0 - (c.o_del + e_del * (i + 1)); hleft = hleft > 0 ? hleft : 0; }
+            int f = 0;
+            uint32_t rowpk = 0;           // (row max << 16) | column, max over the row; ties -> later column
+            int rowmax32 = 0, rowmax_j = -1;
+            int j = beg;
+            for (; j < end; j++) {
+                int diag, e;
+                if (WIDE) { diag = (int)H[j * 64]; e = (int)E[j * 64]; }
+                else { uint32_t v = H[j * 64]; diag = (int)(v & 0xffffu); e = (int)(v >> 16); }
+                uint32_t qc = QC[(j >> 2) * 256 + (j & 3)];
+                qc = qc > 4u ? 4u : qc;
+                int sc = (int)__builtin_amdgcn_perm(rhi, rlo, qc | 0x0c0c0c00u) - 128;
+                int M = diag ? diag + sc : 0;
+                int h = max(max(M, e), f);
+                int t1 = M - oe_del; t1 = t1 > 0 ? t1 : 0;
+                int en = e - e_del; en = en > t1 ? en : t1;
+                if (WIDE) { H[j * 64] = (uint32_t)hleft; E[j * 64] = (uint32_t)en; }
+                else H[j * 64] = (uint32_t)hleft | ((uint32_t)en << 16);
+                hleft = h;
+                if (WIDE) {
+                    if (!(rowmax32 > h)) rowmax_j = j;
+                    rowmax32 = h > rowmax32 ? h : rowmax32;
+                } else {
+                    uint32_t pk = ((uint32_t)h << 16) | (uint32_t)j;
+                    rowpk = pk > rowpk ? pk : rowpk;
+                }
+                int t2 = M - oe_ins; t2 = t2 > 0 ? t2 : 0;
+                f -= e_ins; f = f > t2 ? f : t2;
+            }
+            cells += (unsigned)(end > beg ? end - beg : 0);
+            int rowmax;
+            if (WIDE) rowmax = rowmax32;
+            else { rowmax = (int)(rowpk >> 16); rowmax_j = end > beg ? (int)(rowpk & 0xffffu) : -1; }
+            if (WIDE) { H[end * 64] = (uint32_t)hleft; E[end * 64] = 0u; }
+            else H[end * 64] = (uint32_t)hleft;
+            if (j == qlen) {
+                if (!(gscore > hleft)) g_i = i;
+                gscore = hleft > gscore ? hleft : gscore;
+            }
+            if (rowmax == 0) break;
+            if (rowmax > best) {
+                best = rowmax; best_i = i; best_j = rowmax_j;
+                int off = rowmax_j - i; off = off < 0 ? -off : off;
+                max_off = off > max_off ? off : max_off;
+            } else if (c.zdrop > 0) {
+                int di = i - best_i, dj = rowmax_j - best_j;
+                if (di > dj) { if (best - rowmax - (di - dj) * e_del > c.zdrop) break; }
+                else { if (best - rowmax - (dj - di) * e_ins > c.zdrop) break; }
+            }
+            // trim all-zero cells from both band edges (bandedSWA.cpp:234-237)
+            if (WIDE) {
+                for (j = beg; j < end && H[j * 64] == 0u && E[j * 64] == 0u; j++) {}
+                beg = j;
+                for (j = end; j >= beg && H[j * 64] == 0u && E[j * 64] == 0u; j--) {}
+            } else {
+                for (j = beg; j < end && H[j * 64] == 0u; j++) {}
+                beg = j;
+                for (j = end; j >= beg && H[j * 64] == 0u; j--) {}
+            }
+            end = j + 2 < qlen ? j + 2 : qlen;
+        }
+        score_out[id] = best;
+        if (result_out) {
+            gab_bsw_result r;
+            r.score = best; r.qle = best_j + 1; r.tle = best_i + 1;
+            r.gtle = g_i + 1; r.gscore = gscore; r.max_off = max_off;
+            result_out[id] = r;
+        }
+    }
+    // one atomic per wave for the cell counter
+    for (int o = 32; o > 0; o >>= 1) cells += __shfl_xor(cells, o);
+    if (lane == 0 && cells) atomicAdd(&st->cells, cells);
+}
+
+}  // namespace
+
+// =============================================================================== host side
+struct gab_bsw {
+    int device = 0;
+    gab_bsw_params prm;
+    BswConst cst;
+    gab_devbuf ws;          // hist | start | cursor | qstart | stats | perm
+    gab_devbuf io;          // staging for the host-pointer entry point
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};   // total begin, dp begin, dp end, total end
+    bool have_stats = false;
+    uint32_t *h_qstart = nullptr;   // pinned, kQBuckets + 1
+    BswStats *h_stats = nullptr;    // pinned
+    int64_t last_cells = 0;
+};
+
+extern "C" int gab_bsw_create(const gab_bsw_params *p, int device, gab_bsw **out) {
+    if (!p || !out) { gab_set_error("gab_bsw_create: NULL argument"); return GAB_EINVAL; }
+    *out = nullptr;
+    GAB_CHECK(p->e_del > 0 && p->e_ins > 0 && p->o_del >= 0 && p->o_ins >= 0,
+              "gab_bsw_create: gap penalties must be o>=0, e>0 (got o_del=%d e_del=%d o_ins=%d e_ins=%d)",
+              p->o_del, p->e_del, p->o_ins, p->e_ins);
+    GAB_CHECK(p->w >= 0 && p->zdrop >= 0, "gab_bsw_create: w and zdrop must be >= 0");
+    GAB_CHECK(p->o_del + p->e_del < 32768 && p->o_ins + p->e_ins < 32768 && p->end_bonus >= -32768 &&
+              p->end_bonus < 32768, "gab_bsw_create: penalties out of 16-bit range");
+    int rc = gab_check_device(device);
+    if (rc) return rc;
+    gab_device_guard g(device);
+    gab_bsw *h = new (std::nothrow) gab_bsw();
+    if (!h) { gab_set_error("out of host memory"); return GAB_ENOMEM; }
+    h->device = device; h->prm = *p;
+    BswConst &c = h->cst;
+    c.o_del = p->o_del; c.e_del = p->e_del; c.o_ins = p->o_ins; c.e_ins = p->e_ins;
+    c.zdrop = p->zdrop; c.end_bonus = p->end_bonus; c.w = p->w;
+    int mx = 0;
+    for (int k = 0; k < 25; k++) mx = p->mat[k] > mx ? p->mat[k] : mx;
+    c.max_sc = mx;
+    for (int t = 0; t < 5; t++) {
+        uint32_t lo = 0;
+        for (int q = 0; q < 4; q++) lo |= (uint32_t)(uint8_t)(p->mat[t * 5 + q] + 128) << (8 * q);
+        c.row_lo[t] = lo;
+        c.row_hi[t] = (uint32_t)(uint8_t)(p->mat[t * 5 + 4] + 128);
+    }
+    for (int k = 0; k < 4; k++)
+        if (hipEventCreate(&h->ev[k]) != hipSuccess) { gab_set_error("hipEventCreate failed"); delete h; return GAB_EDEVICE; }
+    // the 256-base class needs more than the default 64 KiB of dynamic LDS
+    if (hipFuncSetAttribute((const void *)bsw_dp<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+        hipFuncSetAttribute((const void *)bsw_dp<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+        gab_set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed"); delete h; return GAB_EDEVICE;
+    }
+    if (hipHostMalloc((void **)&h->h_qstart, sizeof(uint32_t) * (kQBuckets + 1)) != hipSuccess ||
+        hipHostMalloc((void **)&h->h_stats, sizeof(BswStats)) != hipSuccess) {
+        gab_set_error("hipHostMalloc failed"); delete h; return GAB_ENOMEM;
+    }
+    *out = h;
+    return GAB_OK;
+}
+
+extern "C" void gab_bsw_destroy(gab_bsw *h) {
+    if (!h) return;
+    gab_device_guard g(h->device);
+    h->ws.release(); h->io.release();
+    for (int k = 0; k < 4; k++) if (h->ev[k]) (void)hipEventDestroy(h->ev[k]);
+    if (h->h_qstart) (void)hipHostFree(h->h_qstart);
+    if (h->h_stats) (void)hipHostFree(h->h_stats);
+    delete h;
+}
+
+extern "C" int gab_bsw_run_device(gab_bsw *h, const uint8_t *ref, int64_t ref_bytes, const int64_t *ref_off,
+                                  const uint8_t *qry, int64_t qry_bytes, const int64_t *qry_off,
+                                  const int32_t *len1, const int32_t *len2, const int32_t *h0, int64_t n,
+                                  int32_t *score_out, gab_bsw_result *result_out, void *stream_) {
+    GAB_CHECK(h, "gab_bsw_run_device: NULL handle");
+    GAB_CHECK(n >= 0 && n < (1ll << 31), "gab_bsw_run_device: n=%lld out of range", (long long)n);
+    h->have_stats = false;
+    if (n == 0) return GAB_OK;
+    GAB_CHECK(ref && ref_off && qry && qry_off && len1 && len2 && h0 && score_out,
+              "gab_bsw_run_device: NULL buffer");
+    gab_device_guard g(h->device);
+    hipStream_t s = (hipStream_t)stream_;
+
+    // workspace carve-up
+    const size_t o_hist = 0;
+    const size_t o_start = o_hist + sizeof(uint32_t) * kNumKeys;
+    const size_t o_cursor = o_start + sizeof(uint32_t) * (kNumKeys + 1);
+    const size_t o_qstart = o_cursor + sizeof(uint32_t) * (kNumKeys + 1);
+    const size_t o_stats = (o_qstart + sizeof(uint32_t) * (kQBuckets + 1) + 15) & ~(size_t)15;
+    const size_t o_perm = (o_stats + sizeof(BswStats) + 255) & ~(size_t)255;
+    int rc = h->ws.reserve(o_perm + sizeof(uint32_t) * (size_t)n);
+    if (rc) return rc;
+    char *base = h->ws.as<char>();
+    uint32_t *d_hist = (uint32_t *)(base + o_hist), *d_start = (uint32_t *)(base + o_start);
+    uint32_t *d_cursor = (uint32_t *)(base + o_cursor), *d_qstart = (uint32_t *)(base + o_qstart);
+    BswStats *d_stats = (BswStats *)(base + o_stats);
+    uint32_t *d_perm = (uint32_t *)(base + o_perm);
+
+    BswIO io{ref, ref_off, qry, qry_off, len1, len2, h0, ref_bytes, qry_bytes, n};
+    GAB_HIP(hipEventRecord(h->ev[0], s));
+    GAB_HIP(hipMemsetAsync(base, 0, o_perm, s));
+    {
+        BswStats init; memset(&init, 0, sizeof(init)); init.first_bad = 0x7fffffff;
+        // first_bad uses atomicMin, so it starts at INT_MAX (set by a tiny H2D after the memset)
+        *h->h_stats = init;
+        GAB_HIP(hipMemcpyAsync(d_stats, h->h_stats, sizeof(BswStats), hipMemcpyHostToDevice, s));
+    }
+    int grid = (int)(gab_ceil_div(n, 256) < 4096 ? gab_ceil_div(n, 256) : 4096);
+    hipLaunchKernelGGL(bsw_hist, dim3(grid), dim3(256), 0, s, io, d_hist, d_stats);
+    hipLaunchKernelGGL(bsw_scan, dim3(1), dim3(1024), 0, s, d_hist, d_start, d_cursor, d_qstart);
+    hipLaunchKernelGGL(bsw_scatter, dim3(grid), dim3(256), 0, s, io, d_cursor, d_perm);
+    GAB_HIP(hipMemcpyAsync(h->h_qstart, d_qstart, sizeof(uint32_t) * (kQBuckets + 1), hipMemcpyDeviceToHost, s));
+    GAB_HIP(hipMemcpyAsync(h->h_stats, d_stats, sizeof(BswStats), hipMemcpyDeviceToHost, s));
+    GAB_HIP(hipStreamSynchronize(s));   // launch geometry of the DP depends on the class sizes
+    if (h->h_stats->bad) {
+        gab_set_error("gab_bsw_run_device: %d pair(s) violate the limits (first: pair %d): need 1<=len2<=%d, "
+                      "1<=len1<=%d, 0<=h0, offsets inside the slabs (readable to a multiple of 4 bytes)",
+                      h->h_stats->bad, h->h_stats->first_bad - 1, GAB_BSW_MAX_QLEN, GAB_BSW_MAX_TLEN);
+        return GAB_EINVAL;
+    }
+    // 16-bit packing is valid iff every H/E value < 2^15: H <= h0 + qlen * max_sc
+    const bool wide = (int64_t)h->h_stats->max_h0 + (int64_t)GAB_BSW_MAX_QLEN * h->cst.max_sc > 32767;
+
+    GAB_HIP(hipEventRecord(h->ev[1], s));
+    for (int cls = 0; cls < kNumClasses; cls++) {
+        const int64_t kb = h->h_qstart[cls * kClassStep], ke = h->h_qstart[(cls + 1) * kClassStep];
+        if (ke <= kb) continue;
+        const int qcap = (cls + 1) * kClassStep;
+        const size_t lds = sizeof(uint32_t) * 64 * ((size_t)(wide ? 2 : 1) * (qcap + 1) + (size_t)(qcap + 3) / 4);
+        const int blocks = (int)gab_ceil_div(ke - kb, 64);
+        if (wide)
+            hipLaunchKernelGGL(bsw_dp<true>, dim3(blocks), dim3(64), lds, s, io, h->cst, d_perm, kb, ke, qcap,
+                               score_out, result_out, d_stats);
+        else
+            hipLaunchKernelGGL(bsw_dp<false>, dim3(blocks), dim3(64), lds, s, io, h->cst, d_perm, kb, ke, qcap,
+                               score_out, result_out, d_stats);
+    }
+    GAB_HIP(hipGetLastError());
+    GAB_HIP(hipEventRecord(h->ev[2], s));
+    GAB_HIP(hipMemcpyAsync(h->h_stats, d_stats, sizeof(BswStats), hipMemcpyDeviceToHost, s));
+    GAB_HIP(hipEventRecord(h->ev[3], s));
+    h->have_stats = true;
+    return GAB_OK;
+}
+
+extern "C" int gab_bsw_run(gab_bsw *h, const uint8_t *ref, const int64_t *ref_off, const uint8_t *qry,
+                           const int64_t *qry_off, const int32_t *len1, const int32_t *len2,
+                           const int32_t *h0, int64_t n, int32_t *score_out) {
+    GAB_CHECK(h, "gab_bsw_run: NULL handle");
+    GAB_CHECK(n >= 0 && n < (1ll << 31), "gab_bsw_run: n=%lld out of range", (long long)n);
+    if (n == 0) return GAB_OK;
+    GAB_CHECK(ref && ref_off && qry && qry_off && len1 && len2 && h0 && score_out, "gab_bsw_run: NULL buffer");
+    gab_device_guard g(h->device);
+    // extent of the two slabs actually referenced
+    int64_t rb = 0, qb = 0;
+    for (int64_t i = 0; i < n; i++) {
+        GAB_CHECK(ref_off[i] >= 0 && qry_off[i] >= 0 && len1[i] >= 0 && len2[i] >= 0,
+                  "gab_bsw_run: negative offset/length at pair %lld", (long long)i);
+        int64_t r = ref_off[i] + len1[i], q = qry_off[i] + len2[i];
+        rb = r > rb ? r : rb; qb = q > qb ? q : qb;
+    }
+    const size_t rpad = ((size_t)rb + 3 + 255) & ~(size_t)255, qpad = ((size_t)qb + 3 + 255) & ~(size_t)255;
+    const size_t nn = (size_t)n;
+    size_t o = 0;
+    const size_t o_ref = o; o += rpad;
+    const size_t o_qry = o; o += qpad;
+    const size_t o_roff = o; o += 8 * nn;
+    const size_t o_qoff = o; o += 8 * nn;
+    const size_t o_l1 = o; o += 4 * nn;
+    const size_t o_l2 = o; o += 4 * nn;
+    const size_t o_h0 = o; o += 4 * nn;
+    const size_t o_sc = o; o += 4 * nn;
+    int rc = h->io.reserve(o);
+    if (rc) return rc;
+    char *b = h->io.as<char>();
+    hipStream_t s = nullptr;
+    GAB_HIP(hipMemcpyAsync(b + o_ref, ref, (size_t)rb, hipMemcpyHostToDevice, s));
+    GAB_HIP(hipMemcpyAsync(b + o_qry, qry, (size_t)qb, hipMemcpyHostToDevice, s));
+    GAB_HIP(hipMemcpyAsync(b + o_roff, ref_off, 8 * nn, hipMemcpyHostToDevice, s));
+    GAB_HIP(hipMemcpyAsync(b + o_qoff, qry_off, 8 * nn, hipMemcpyHostToDevice, s));
+    GAB_HIP(hipMemcpyAsync(b + o_l1, len1, 4 * nn, hipMemcpyHostToDevice, s));
+    GAB_HIP(hipMemcpyAsync(b + o_l2, len2, 4 * nn, hipMemcpyHostToDevice, s));
+    GAB_HIP(hipMemcpyAsync(b + o_h0, h0, 4 * nn, hipMemcpyHostToDevice, s));
+    rc = gab_bsw_run_device(h, (const uint8_t *)(b + o_ref), (int64_t)rpad, (const int64_t *)(b + o_roff),
+                            (const uint8_t *)(b + o_qry), (int64_t)qpad, (const int64_t *)(b + o_qoff),
+                            (const int32_t *)(b + o_l1), (const int32_t *)(b + o_l2), (const int32_t *)(b + o_h0),
+                            n, (int32_t *)(b + o_sc), nullptr, s);
+    if (rc) return rc;
+    GAB_HIP(hipMemcpyAsync(score_out, b + o_sc, 4 * nn, hipMemcpyDeviceToHost, s));
+    GAB_HIP(hipStreamSynchronize(s));
+    return GAB_OK;
+}
+
+extern "C" int gab_bsw_last_stats(gab_bsw *h, int64_t *cells, float *kernel_ms, float *total_ms) {
+    GAB_CHECK(h, "gab_bsw_last_stats: NULL handle");
+    GAB_CHECK(h->have_stats, "gab_bsw_last_stats: no completed run on this handle");
+    gab_device_guard g(h->device);
+    GAB_HIP(hipEventSynchronize(h->ev[3]));
+    if (cells) *cells = (int64_t)h->h_stats->cells;
+    if (kernel_ms) GAB_HIP(hipEventElapsedTime(kernel_ms, h->ev[1], h->ev[2]));
+    if (total_ms) GAB_HIP(hipEventElapsedTime(total_ms, h->ev[0], h->ev[3]));
+    return GAB_OK;
+}

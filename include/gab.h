@@ -1,0 +1,92 @@
+/* gab.h -- C ABI of libgab_hip.so: the MI355X (gfx950) engine for the GenArchBench
+ * banded-DP / seed-chaining hot path.
+ *
+ * The reference has no plugin/FFI layer: each kernel library is linked straight into
+ * its benchmark's main().  Every entry point below therefore replaces one *call site*
+ * of a reference driver (cited per function, paths relative to
+ * /root/reference/benchmarks/).  INTEGRATION.md shows the few lines a maintainer
+ * changes in each driver to call this library instead.
+ *
+ * Conventions
+ *   - plain C, no C++/torch types; every function returns 0 on success or a negative
+ *     GAB_E* code and never calls exit(); gab_last_error() gives the message for the
+ *     calling thread.
+ *   - the caller owns every buffer.  "_run" variants take HOST pointers and do
+ *     H2D + kernels + D2H synchronously; "_run_device" variants take DEVICE pointers
+ *     (hipMalloc'ed or a torch tensor's data_ptr) and enqueue asynchronously on `stream`
+ *     (a hipStream_t passed as void*, NULL = the default stream).
+ *   - a handle is bound to one GPU; calls on distinct handles are thread-safe, so the
+ *     multi-GPU drivers run one host thread (or one process) per GPU with no collective.
+ */
+#ifndef GAB_H
+#define GAB_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GAB_OK 0
+#define GAB_EINVAL (-22)   /* bad argument / unsupported size  */
+#define GAB_ENOMEM (-12)   /* host or device allocation failed */
+#define GAB_EDEVICE (-5)   /* HIP runtime error                */
+#define GAB_ENODEV (-19)   /* no usable gfx950 device          */
+
+/* ---- library ------------------------------------------------------------------- */
+const char *gab_version(void);
+const char *gab_last_error(void);
+int gab_device_count(void);
+
+/* ---- bsw: banded Smith-Waterman seed extension ------------------------------------
+ * Replaces  bsw[tid]->getScores16(SeqPair*, ref, qer, nPairsBatch, 1, w)
+ *           bsw/src/main_banded.cpp:338-350  (class: bsw/src/bandedSWA.h:240-245;
+ *           semantics: scalarBandedSWA, bsw/src/bandedSWA.cpp:132-253).
+ * Instead of T threads x batches of B pairs, the GPU driver makes ONE call over all
+ * pairs inside the same region of interest.
+ */
+typedef struct gab_bsw gab_bsw;
+typedef struct {
+    int32_t o_del, e_del, o_ins, e_ins; /* BandedPairWiseSW ctor, bandedSWA.cpp:48-66    */
+    int32_t zdrop, end_bonus;           /* main_banded.cpp:268                            */
+    int32_t w;                          /* band width passed to getScores16 (100)         */
+    int8_t mat[25];                     /* 5x5 scores, codes 0..3 = ACGT, 4 = N           */
+} gab_bsw_params;
+
+/* Limits (same as the reference driver's slabs, main_banded.cpp:76-79): query length
+ * 1..256, reference length 1..32767, 0 <= h0, and h0 + qlen * max(mat) <= 2^30. */
+#define GAB_BSW_MAX_QLEN 256
+#define GAB_BSW_MAX_TLEN 32767
+
+/* full extension result, as scalarBandedSWA returns it (bandedSWA.cpp:241-252) */
+typedef struct {
+    int32_t score, qle, tle, gtle, gscore, max_off;
+} gab_bsw_result;
+
+int gab_bsw_create(const gab_bsw_params *params, int device, gab_bsw **out);
+void gab_bsw_destroy(gab_bsw *h);
+
+/* Host buffers.  Pair i: reference (target) = ref[ref_off[i] .. +len1[i]), query =
+ * qry[qry_off[i] .. +len2[i]), base codes 0..4 one byte each (what loadPairs produces,
+ * main_banded.cpp:164-206), seed score h0[i].  score_out[i] = SeqPair.score. */
+int gab_bsw_run(gab_bsw *h, const uint8_t *ref, const int64_t *ref_off, const uint8_t *qry,
+                const int64_t *qry_off, const int32_t *len1, const int32_t *len2,
+                const int32_t *h0, int64_t n, int32_t *score_out);
+
+/* Device buffers, asynchronous on `stream`.  ref_bytes / qry_bytes = sizes of the two
+ * sequence slabs (used for bounds validation of 4-byte reads: both slabs must be
+ * readable up to a multiple of 4 bytes past the last base).  result_out may be NULL;
+ * when given it receives all six result fields per pair. */
+int gab_bsw_run_device(gab_bsw *h, const uint8_t *ref, int64_t ref_bytes, const int64_t *ref_off,
+                       const uint8_t *qry, int64_t qry_bytes, const int64_t *qry_off,
+                       const int32_t *len1, const int32_t *len2, const int32_t *h0, int64_t n,
+                       int32_t *score_out, gab_bsw_result *result_out, void *stream);
+
+/* Counters of the last run on this handle (for the roofline report): number of DP
+ * cells evaluated (sum over rows of band width) and device time of the dominant kernel
+ * as measured with HIP events on the run's stream (ms). */
+int gab_bsw_last_stats(gab_bsw *h, int64_t *cells, float *kernel_ms, float *total_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GAB_H */

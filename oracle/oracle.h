@@ -1,0 +1,43 @@
+/* CPU ORACLE -- TEST INFRASTRUCTURE ONLY.
+ *
+ * Plain-C restatements of the reference algorithms on the hot path.  Only
+ * tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may link or
+ * call anything in this directory; the product (libgab_hip.so and the drivers
+ * under benchmarks/) never does.
+ *
+ * Parity status: PINNED.  Every function here is checked bit-for-bit against
+ * (a) golden vectors under tests/golden/ produced by the reference itself,
+ * compiled from /root/reference by oracle/Makefile into oracle/_ref/, and
+ * (b) that compiled reference run live when oracle/_ref/ is present.
+ */
+#ifndef GAB_ORACLE_H
+#define GAB_ORACLE_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- bsw: follows BandedPairWiseSW::scalarBandedSWA,
+ *      /root/reference/benchmarks/bsw/src/bandedSWA.cpp:132-253 ------------- */
+typedef struct {
+    int32_t o_del, e_del, o_ins, e_ins, zdrop, end_bonus, w;
+    int8_t mat[25];
+} oracle_bsw_params;
+typedef struct {
+    int32_t score, qle, tle, gtle, gscore, max_off;
+} oracle_bsw_result;
+/* fills the 5x5 matrix the way bsw/src/main_banded.cpp:94-102 does */
+void oracle_bsw_fill_scmat(int a, int b, int ambig, int8_t mat[25]);
+void oracle_bsw_one(const oracle_bsw_params *p, int qlen, const uint8_t *query,
+                    int tlen, const uint8_t *target, int h0, oracle_bsw_result *out);
+/* batch over n pairs, OpenMP over pairs; also returns the number of DP cells
+ * evaluated (sum over rows of end-beg) when cells != NULL */
+void oracle_bsw_batch(const oracle_bsw_params *p, const uint8_t *ref, const int64_t *ref_off,
+                      const uint8_t *qry, const int64_t *qry_off, const int32_t *len1,
+                      const int32_t *len2, const int32_t *h0, int64_t n, int threads,
+                      oracle_bsw_result *out, int64_t *cells);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

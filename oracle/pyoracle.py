@@ -1,0 +1,69 @@
+"""ctypes front-end for the CPU ORACLE (oracle/*.c) -- TEST INFRASTRUCTURE ONLY.
+
+Importable only from tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.
+The product path (genarchbench_amd/, benchmarks/) must never import this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_lib = None
+
+
+def build(force=False, with_ref=True):
+    """compile liboracle.so and, when /root/reference is present, oracle/_ref/*"""
+    targets = ["all"] + (["ref"] if with_ref else [])
+    so = os.path.join(_HERE, "liboracle.so")
+    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith((".c", ".h"))]
+    stale = (not os.path.exists(so)) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs)
+    if force or stale or (with_ref and os.path.isdir("/root/reference")):
+        subprocess.check_call(["make", "-C", _HERE, "-s"] + targets)
+    return so
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = C.CDLL(build(with_ref=False))
+    return _lib
+
+
+def ref_path(name):
+    """path of a compiled-reference binary under oracle/_ref, or None if it was not built"""
+    p = os.path.join(_HERE, "_ref", name)
+    return p if os.path.exists(p) else None
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+# ------------------------------------------------------------------ bsw
+class BswParams(C.Structure):
+    _fields_ = [("o_del", C.c_int32), ("e_del", C.c_int32), ("o_ins", C.c_int32),
+                ("e_ins", C.c_int32), ("zdrop", C.c_int32), ("end_bonus", C.c_int32),
+                ("w", C.c_int32), ("mat", C.c_int8 * 25)]
+
+
+BSW_RESULT_FIELDS = ("score", "qle", "tle", "gtle", "gscore", "max_off")
+
+
+def bsw_params(match=1, mismatch=4, gapo=6, gape=1, ambig=-1, zdrop=100, end_bonus=5, w=100):
+    """defaults of the reference driver: bsw/src/main_banded.cpp:70-74,266-276"""
+    p = BswParams(gapo, gape, gapo, gape, zdrop, end_bonus, w)
+    lib().oracle_bsw_fill_scmat(C.c_int(match), C.c_int(mismatch), C.c_int(ambig), p.mat)
+    return p
+
+
+def bsw(batch, params=None, threads=0, want_cells=False):
+    """returns int32 array [n, 6] = (score, qle, tle, gtle, gscore, max_off)"""
+    params = params or bsw_params()
+    out = np.zeros((batch.n, 6), np.int32)
+    cells = C.c_int64(0)
+    lib().oracle_bsw_batch(C.byref(params), _p(batch.ref), _p(batch.ref_off), _p(batch.qry),
+                           _p(batch.qry_off), _p(batch.len1), _p(batch.len2), _p(batch.h0),
+                           C.c_int64(batch.n), C.c_int(threads), _p(out), C.byref(cells))
+    return (out, cells.value) if want_cells else out

@@ -1,0 +1,26 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _built():
+    """build the generators, the CPU oracle and (in the build container) libgab_hip.so once per session"""
+    from tools import gabgen
+    from oracle import pyoracle
+    gabgen.build()
+    pyoracle.build(with_ref=False)
+    import genarchbench_amd
+    so = os.path.join(ROOT, "genarchbench_amd", "libgab_hip.so")
+    if not os.path.exists(so):
+        genarchbench_amd.build()
+    yield

@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""Regenerates the golden vectors under tests/golden/ from THE REFERENCE ITSELF.
+
+Runs only in the build container: needs /root/reference (compiled in place into
+oracle/_ref/ by `make -C oracle ref`).  Inputs come from the seeded generators in
+tools/gen; expected outputs are what the reference binaries print.  Nothing from
+the reference's sources is stored here -- only inputs and the outputs it produced.
+
+    python tests/golden/make_golden.py [bsw ...]
+"""
+import json
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+from oracle import pyoracle  # noqa: E402
+from tools import gabgen  # noqa: E402
+
+MANIFEST = os.path.join(HERE, "MANIFEST.json")
+
+
+def _manifest():
+    if os.path.exists(MANIFEST):
+        return json.load(open(MANIFEST))
+    return {}
+
+
+def _save(m):
+    json.dump(m, open(MANIFEST, "w"), indent=1, sort_keys=True)
+
+
+def make_bsw(m):
+    # (name, seed, n, mode): n is a multiple of 32 so no padded pair is printed
+    # (bsw/src/main_banded.cpp:254,407-409)
+    for name, seed, n, mode in [("bsw_bench", 101, 2048, 0), ("bsw_adv", 102, 1536, 1)]:
+        inp = os.path.join(HERE, name + ".in.txt")
+        gabgen.write_text("bsw", inp, seed, n, mode)
+        outs = {}
+        for isa in ("avx512", "avx2", "sse41"):
+            exe = pyoracle.ref_path("bsw_ref_" + isa)
+            r = subprocess.run([exe, "-pairs", inp, "-t", "1", "-b", "512"], capture_output=True, text=True, check=True)
+            outs[isa] = [l for l in r.stderr.splitlines() if "score=" in l][:n]
+        assert outs["avx512"] == outs["avx2"] == outs["sse41"], "reference ISA variants disagree"
+        with open(os.path.join(HERE, name + ".expected.txt"), "w") as f:
+            f.write("\n".join(outs["avx2"]) + "\n")
+        m[name] = {"generator": "tools/gen gabgen bsw", "seed": seed, "n": n, "mode": mode,
+                   "reference": "bsw/src/{main_banded,bandedSWA}.cpp built by oracle/Makefile "
+                                "(-mavx512bw, -mavx2, -msse4.1: identical output)",
+                   "command": "bsw_ref_<isa> -pairs <in> -t 1 -b 512 ; grep score= stderr"}
+
+
+MAKERS = {"bsw": make_bsw}
+
+if __name__ == "__main__":
+    pyoracle.build(with_ref=True)
+    which = sys.argv[1:] or list(MAKERS)
+    m = _manifest()
+    for w in which:
+        MAKERS[w](m)
+    _save(m)
+    print("golden vectors written:", ", ".join(sorted(m)))

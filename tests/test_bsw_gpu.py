@@ -1,0 +1,93 @@
+"""GPU parity: the bsw HIP path (through the C ABI) against the CPU oracle and the golden vectors."""
+import numpy as np
+import pytest
+
+from oracle import pyoracle
+from tools import gabgen
+from tests.util import GOLDEN, read_bsw_input, read_scores
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def sw():
+    from genarchbench_amd.bsw import BandedPairWiseSW
+    s = BandedPairWiseSW()
+    yield s
+    s.close()
+
+
+@pytest.mark.parametrize("name", ["bsw_bench", "bsw_adv"])
+def test_golden(sw, name):
+    batch = read_bsw_input(f"{GOLDEN}/{name}.in.txt")
+    want = read_scores(f"{GOLDEN}/{name}.expected.txt")
+    np.testing.assert_array_equal(sw.getScores16(batch), want)
+
+
+@pytest.mark.parametrize("seed,n,mode", [(11, 100000, 0), (12, 50000, 1), (13, 63, 0), (14, 65, 1), (15, 1, 0)])
+def test_vs_oracle(sw, seed, n, mode):
+    batch = gabgen.bsw(seed, n, mode)
+    want = pyoracle.bsw(batch)[:, 0]
+    np.testing.assert_array_equal(sw.getScores16(batch), want)
+
+
+def test_full_result_and_cells(sw):
+    """all six result fields + the DP cell counter, device-resident entry point"""
+    import torch
+    batch = gabgen.bsw(21, 20000, 1)
+    want, cells = pyoracle.bsw(batch, want_cells=True)
+    dev = torch.device("cuda:0")
+    t = lambda a: torch.from_numpy(a).to(dev)
+    ref, qry = t(batch.ref), t(batch.qry)
+    score = torch.full((batch.n,), -7, dtype=torch.int32, device=dev)
+    res = torch.full((batch.n, 6), -7, dtype=torch.int32, device=dev)
+    sw.run_device(ref, t(batch.ref_off), qry, t(batch.qry_off), t(batch.len1), t(batch.len2), t(batch.h0),
+                  score, res, stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(res.cpu().numpy(), want)
+    np.testing.assert_array_equal(score.cpu().numpy(), want[:, 0])
+    assert sw.last_stats()["cells"] == cells
+
+
+def test_wide_mode_large_h0(sw):
+    """h0 beyond the 15-bit packed range switches to the 32-bit cell kernel"""
+    batch = gabgen.bsw(31, 3000, 1)
+    batch.h0[::7] = 40000
+    batch.h0[1::7] = 32767 - 200
+    want = pyoracle.bsw(batch)[:, 0]
+    np.testing.assert_array_equal(sw.getScores16(batch), want)
+
+
+def test_max_lengths(sw):
+    """query 256 (the LDS-heaviest class) and a long reference"""
+    rng = np.random.default_rng(3)
+    qrys = [rng.integers(0, 4, 256).astype(np.uint8) for _ in range(70)]
+    refs = []
+    for q in qrys:
+        r = q.copy()
+        r[rng.integers(0, 256, 10)] = rng.integers(0, 4, 10)
+        refs.append(np.concatenate([r, rng.integers(0, 4, rng.integers(0, 1700)).astype(np.uint8)]))
+    batch = gabgen.bsw_from_arrays(refs, qrys, [int(x) for x in rng.integers(0, 300, 70)])
+    want = pyoracle.bsw(batch)[:, 0]
+    np.testing.assert_array_equal(sw.getScores16(batch), want)
+
+
+def test_other_penalties():
+    from genarchbench_amd.bsw import BandedPairWiseSW, bwa_fill_scmat
+    batch = gabgen.bsw(41, 5000, 1)
+    for (a, b, go, ge, amb, zd, w) in [(2, 3, 5, 2, -2, 50, 30), (1, 1, 0, 1, 0, 0, 100), (3, 5, 7, 3, -1, 200, 5)]:
+        s = BandedPairWiseSW(go, ge, go + 1, ge, zd, 5, bwa_fill_scmat(a, b, amb), w)
+        p = pyoracle.bsw_params(a, b, go, ge, amb, zd, 5, w)
+        p.o_ins = go + 1
+        np.testing.assert_array_equal(s.getScores16(batch), pyoracle.bsw(batch, p)[:, 0])
+        s.close()
+
+
+def test_rejects_bad_input(sw):
+    from genarchbench_amd._lib import GabError
+    A = lambda *x: np.array(x, np.uint8)
+    batch = gabgen.bsw_from_arrays([A(0, 1)], [np.zeros(257, np.uint8)], [5])
+    with pytest.raises(GabError):
+        sw.getScores16(batch)
+    empty = gabgen.bsw_from_arrays([], [], [])
+    assert len(sw.getScores16(empty)) == 0

@@ -1,0 +1,40 @@
+"""helpers shared by the tests: golden-vector readers for the reference's text formats"""
+import os
+import re
+
+import numpy as np
+
+from tools import gabgen
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def read_bsw_input(path):
+    """reference bsw input format (bsw/src/main_banded.cpp:152-206): h0 / ref digits / query digits"""
+    with open(path, "rb") as f:
+        lines = f.read().split(b"\n")
+    n = len(lines) // 3
+    refs, qrys, h0s = [], [], []
+    for i in range(n):
+        h0s.append(int(lines[3 * i]))
+        refs.append(np.frombuffer(lines[3 * i + 1], np.uint8) - 48)
+        qrys.append(np.frombuffer(lines[3 * i + 2], np.uint8) - 48)
+    return gabgen.bsw_from_arrays(refs, qrys, h0s)
+
+
+def read_scores(path):
+    """'[i] score=s' lines -> int32 array indexed by i"""
+    out = {}
+    for line in open(path):
+        m = re.match(r"\[(\d+)\] score=(-?\d+)", line)
+        if m:
+            out[int(m.group(1))] = int(m.group(2))
+    return np.array([out[i] for i in range(len(out))], np.int32)
+
+
+def has_gpu():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False

@@ -1,0 +1,103 @@
+"""ctypes front-end for the seeded input generators in tools/gen (test/bench infrastructure)."""
+import ctypes as C
+import os
+import subprocess
+from dataclasses import dataclass
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_GEN_DIR = os.path.join(_HERE, "gen")
+_lib = None
+
+
+def build(force=False):
+    so = os.path.join(_GEN_DIR, "libgabgen.so")
+    if force or not os.path.exists(so) or not os.path.exists(os.path.join(_GEN_DIR, "gabgen")):
+        subprocess.check_call(["make", "-C", _GEN_DIR, "-s"])
+    return so
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = C.CDLL(build())
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _offsets(lens, align=1):
+    """exclusive prefix sum of lens (each rounded up to `align`) -> int64 offsets, total"""
+    l = lens.astype(np.int64)
+    if align > 1:
+        l = (l + align - 1) // align * align
+    off = np.zeros(len(l), dtype=np.int64)
+    if len(l) > 1:
+        np.cumsum(l[:-1], out=off[1:])
+    total = int(off[-1] + l[-1]) if len(l) else 0
+    return off, total
+
+
+@dataclass
+class BswBatch:
+    """Packed bsw input: codes 0..4, one byte per base, variable-length, back to back."""
+    ref: np.ndarray
+    ref_off: np.ndarray
+    qry: np.ndarray
+    qry_off: np.ndarray
+    len1: np.ndarray  # reference (target) lengths
+    len2: np.ndarray  # query lengths
+    h0: np.ndarray
+
+    @property
+    def n(self):
+        return len(self.len1)
+
+    def pair(self, i):
+        r = self.ref[self.ref_off[i]:self.ref_off[i] + self.len1[i]]
+        q = self.qry[self.qry_off[i]:self.qry_off[i] + self.len2[i]]
+        return r, q, int(self.h0[i])
+
+    def write_text(self, path):
+        """reference input format: bsw/src/main_banded.cpp:152-206"""
+        with open(path, "wb") as f:
+            for i in range(self.n):
+                r, q, h = self.pair(i)
+                f.write(b"%d\n" % h)
+                f.write((r + 48).astype(np.uint8).tobytes() + b"\n")
+                f.write((q + 48).astype(np.uint8).tobytes() + b"\n")
+
+
+def bsw(seed, n, mode=0, first=0):
+    L = lib()
+    len1 = np.empty(n, np.int32); len2 = np.empty(n, np.int32); h0 = np.empty(n, np.int32)
+    L.gab_gen_bsw_lens(C.c_uint64(seed), C.c_int(mode), C.c_int64(first), C.c_int64(n),
+                       _p(len1), _p(len2), _p(h0))
+    ref_off, rt = _offsets(len1)
+    qry_off, qt = _offsets(len2)
+    # 16 bytes of slack so device-side vector loads past the last base stay in bounds
+    ref = np.zeros(rt + 16, np.uint8); qry = np.zeros(qt + 16, np.uint8)
+    L.gab_gen_bsw_fill(C.c_uint64(seed), C.c_int(mode), C.c_int64(first), C.c_int64(n),
+                       _p(ref), _p(ref_off), _p(qry), _p(qry_off))
+    return BswBatch(ref, ref_off, qry, qry_off, len1, len2, h0)
+
+
+def bsw_from_arrays(refs, qrys, h0s):
+    """build a batch from python lists of uint8 code arrays (hand-made edge cases)"""
+    len1 = np.array([len(r) for r in refs], np.int32)
+    len2 = np.array([len(q) for q in qrys], np.int32)
+    ref_off, rt = _offsets(len1); qry_off, qt = _offsets(len2)
+    ref = np.zeros(rt + 16, np.uint8); qry = np.zeros(qt + 16, np.uint8)
+    for i, (r, q) in enumerate(zip(refs, qrys)):
+        ref[ref_off[i]:ref_off[i] + len(r)] = r
+        qry[qry_off[i]:qry_off[i] + len(q)] = q
+    return BswBatch(ref, ref_off, qry, qry_off, len1, len2, np.array(h0s, np.int32))
+
+
+def write_text(bench, path, seed, n, mode=0, *extra):
+    build()
+    subprocess.check_call([os.path.join(_GEN_DIR, "gabgen"), bench, path, str(seed), str(n), str(mode)]
+                          + [str(e) for e in extra])

@@ -1,0 +1,180 @@
+/* Seeded synthetic-input generators (see gabgen.h).  Test/bench infrastructure. */
+#include "gabgen.h"
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+
+/* ---------------------------------------------------------------- rng ---- */
+typedef struct { uint64_t s; } rng_t;
+static inline uint64_t sm64(uint64_t *s) {
+    uint64_t z = (*s += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+static inline rng_t rng_for(uint64_t seed, uint64_t stream, uint64_t item) {
+    uint64_t s = seed * 0xD1342543DE82EF95ull + stream * 0x2545F4914F6CDD1Dull;
+    (void)sm64(&s);
+    s ^= item * 0x9E3779B97F4A7C15ull;
+    rng_t r; r.s = sm64(&s); return r;
+}
+static inline uint64_t rnd(rng_t *r) { return sm64(&r->s); }
+/* uniform integer in [lo, hi] */
+static inline int64_t rnd_range(rng_t *r, int64_t lo, int64_t hi) {
+    return lo + (int64_t)(rnd(r) % (uint64_t)(hi - lo + 1));
+}
+/* true with probability num/10000 */
+static inline int rnd_pm(rng_t *r, int num) { return (int)(rnd(r) % 10000u) < num; }
+
+/* ================================================================= bsw === */
+/* Generates one pair into q[] / t[] (capacity 256 / 2048); returns lengths. */
+static void bsw_item(uint64_t seed, int mode, int64_t idx, uint8_t *q, int *qlen_out,
+                     uint8_t *t, int *tlen_out, int *h0_out) {
+    rng_t r = rng_for(seed, 1, (uint64_t)idx);
+    int qlen, tlen = 0, h0;
+    if (mode == 0) {
+        qlen = (int)rnd_range(&r, 20, 131);
+        h0 = (int)rnd_range(&r, 19, 100);
+        for (int i = 0; i < qlen; i++) q[i] = rnd_pm(&r, 100) ? 4 : (uint8_t)(rnd(&r) & 3);
+        for (int i = 0; i < qlen; i++) {
+            if (rnd_pm(&r, 100)) continue;                       /* deletion   */
+            if (rnd_pm(&r, 100)) t[tlen++] = (uint8_t)(rnd(&r) & 3); /* insertion */
+            uint8_t c = q[i];
+            if (rnd_pm(&r, 500)) c = (uint8_t)(rnd(&r) & 3);     /* substitution */
+            t[tlen++] = c;
+        }
+        int tail = (int)rnd_range(&r, 0, 100);
+        for (int i = 0; i < tail; i++) t[tlen++] = rnd_pm(&r, 100) ? 4 : (uint8_t)(rnd(&r) & 3);
+        if (tlen == 0) t[tlen++] = 0;
+    } else {
+        static const int h0s[7] = {0, 1, 5, 19, 50, 200, 1000};
+        qlen = (int)rnd_range(&r, 1, 250);
+        h0 = h0s[rnd(&r) % 7];
+        for (int i = 0; i < qlen; i++) q[i] = rnd_pm(&r, 300) ? 4 : (uint8_t)(rnd(&r) & 3);
+        int i = 0;
+        while (i < qlen && tlen < 540) {
+            if (rnd_pm(&r, 150)) { i += (int)rnd_range(&r, 1, 12); continue; }      /* del burst */
+            if (rnd_pm(&r, 150)) {
+                int b = (int)rnd_range(&r, 1, 12);
+                for (int k = 0; k < b && tlen < 540; k++) t[tlen++] = (uint8_t)(rnd(&r) & 3);
+            }
+            uint8_t c = q[i++];
+            if (rnd_pm(&r, 800)) c = (uint8_t)(rnd(&r) & 3);
+            if (rnd_pm(&r, 300)) c = 4;
+            if (tlen < 540) t[tlen++] = c;
+        }
+        /* one in eight pairs: unrelated reference (exercises m==0 / z-drop exits) */
+        if ((rnd(&r) & 7) == 0) { tlen = 0; }
+        int tail = (int)rnd_range(&r, 0, 300);
+        if (tlen + tail > 549) tail = 549 - tlen;
+        for (int k = 0; k < tail; k++) t[tlen++] = rnd_pm(&r, 300) ? 4 : (uint8_t)(rnd(&r) & 3);
+        if (tlen == 0) t[tlen++] = (uint8_t)(rnd(&r) & 3);
+    }
+    *qlen_out = qlen; *tlen_out = tlen; *h0_out = h0;
+}
+
+void gab_gen_bsw_lens(uint64_t seed, int mode, int64_t first, int64_t n,
+                      int32_t *len1, int32_t *len2, int32_t *h0) {
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; i++) {
+        uint8_t q[256], t[2048]; int ql, tl, h;
+        bsw_item(seed, mode, first + i, q, &ql, t, &tl, &h);
+        len1[i] = tl; len2[i] = ql; h0[i] = h;
+    }
+}
+
+void gab_gen_bsw_fill(uint64_t seed, int mode, int64_t first, int64_t n,
+                      uint8_t *ref, const int64_t *ref_off,
+                      uint8_t *qry, const int64_t *qry_off) {
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; i++) {
+        uint8_t q[256], t[2048]; int ql, tl, h;
+        bsw_item(seed, mode, first + i, q, &ql, t, &tl, &h);
+        memcpy(ref + ref_off[i], t, (size_t)tl);
+        memcpy(qry + qry_off[i], q, (size_t)ql);
+    }
+}
+
+int gab_gen_bsw_write(const char *path, uint64_t seed, int mode, int64_t n) {
+    FILE *f = fopen(path, "w");
+    if (!f) return -1;
+    char line[2100];
+    for (int64_t i = 0; i < n; i++) {
+        uint8_t q[256], t[2048]; int ql, tl, h;
+        bsw_item(seed, mode, i, q, &ql, t, &tl, &h);
+        fprintf(f, "%d\n", h);
+        for (int k = 0; k < tl; k++) line[k] = (char)('0' + t[k]);
+        line[tl] = '\n'; fwrite(line, 1, (size_t)tl + 1, f);
+        for (int k = 0; k < ql; k++) line[k] = (char)('0' + q[k]);
+        line[ql] = '\n'; fwrite(line, 1, (size_t)ql + 1, f);
+    }
+    return fclose(f);
+}
+
+/* ============================================================ bpm / wfa === */
+#define PAIRS_MAXLEN 4096
+static void pairs_item(uint64_t seed, int mode, int plen, int64_t idx,
+                       char *p, int *pl_out, char *t, int *tl_out) {
+    static const char B[4] = {'A', 'C', 'G', 'T'};
+    rng_t r = rng_for(seed, 2, (uint64_t)idx);
+    int pl = plen, tl = 0;
+    int pN = 10, pS = 200, pI = 50, pD = 50, pLow = 0;
+    if (mode == 1) {
+        pl = (int)rnd_range(&r, 1, plen);
+        pN = 200; pS = 500; pI = 200; pD = 200; pLow = 30;
+    }
+    for (int i = 0; i < pl; i++) {
+        char c = B[rnd(&r) & 3];
+        if (rnd_pm(&r, pN)) c = 'N';
+        if (pLow && rnd_pm(&r, pLow)) c = (char)(c | 0x20);
+        p[i] = c;
+    }
+    for (int i = 0; i < pl && tl < PAIRS_MAXLEN - 2; i++) {
+        if (rnd_pm(&r, pD)) continue;
+        if (rnd_pm(&r, pI)) t[tl++] = B[rnd(&r) & 3];
+        char c = p[i];
+        if (rnd_pm(&r, pS)) c = B[rnd(&r) & 3];
+        t[tl++] = c;
+    }
+    if (mode == 1 && (rnd(&r) & 15) == 0) {          /* unrelated text, other length */
+        tl = (int)rnd_range(&r, 1, plen);
+        for (int i = 0; i < tl; i++) t[i] = B[rnd(&r) & 3];
+    }
+    if (tl == 0) t[tl++] = B[rnd(&r) & 3];
+    *pl_out = pl; *tl_out = tl;
+}
+
+void gab_gen_pairs_lens(uint64_t seed, int mode, int plen, int64_t first, int64_t n,
+                        int32_t *pat_len, int32_t *txt_len) {
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; i++) {
+        char p[PAIRS_MAXLEN], t[PAIRS_MAXLEN]; int pl, tl;
+        pairs_item(seed, mode, plen, first + i, p, &pl, t, &tl);
+        pat_len[i] = pl; txt_len[i] = tl;
+    }
+}
+
+void gab_gen_pairs_fill(uint64_t seed, int mode, int plen, int64_t first, int64_t n,
+                        char *pat, const int64_t *pat_off,
+                        char *txt, const int64_t *txt_off) {
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; i++) {
+        char p[PAIRS_MAXLEN], t[PAIRS_MAXLEN]; int pl, tl;
+        pairs_item(seed, mode, plen, first + i, p, &pl, t, &tl);
+        memcpy(pat + pat_off[i], p, (size_t)pl);
+        memcpy(txt + txt_off[i], t, (size_t)tl);
+    }
+}
+
+int gab_gen_pairs_write(const char *path, uint64_t seed, int mode, int plen, int64_t n) {
+    FILE *f = fopen(path, "w");
+    if (!f) return -1;
+    for (int64_t i = 0; i < n; i++) {
+        char p[PAIRS_MAXLEN], t[PAIRS_MAXLEN]; int pl, tl;
+        pairs_item(seed, mode, plen, i, p, &pl, t, &tl);
+        fputc('>', f); fwrite(p, 1, (size_t)pl, f); fputc('\n', f);
+        fputc('<', f); fwrite(t, 1, (size_t)tl, f); fputc('\n', f);
+    }
+    return fclose(f);
+}
