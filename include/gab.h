@@ -86,6 +86,38 @@ int gab_bsw_run_device(gab_bsw *h, const uint8_t *ref, int64_t ref_bytes, const 
  * as measured with HIP events on the run's stream (ms). */
 int gab_bsw_last_stats(gab_bsw *h, int64_t *cells, float *kernel_ms, float *total_ms);
 
+/* ---- chain / fast-chain: minimap2 seed chaining ------------------------------------
+ * Replaces  host_chain_kernel(std::vector<call_t>&, std::vector<return_t>&, numThreads)
+ *           chain/src/main.cpp:154 and fast-chain/src/main.cpp:154 (declared in each src/host_kernel.h:6;
+ *           kernels chain/src/host_kernel.cpp:30-108, fast-chain/src/host_kernel.cpp:135-865).
+ * The reference call is already a whole-input batch call; so is this one.
+ * Anchors of all calls lie back to back: call c owns x/y/score/parent[call_off[c] ..
+ * call_off[c] + hdr[c].n).  x, y are minimap2's mm128_t words (chain/src/host_data.h:18-21):
+ * x = ref id/strand/pos (ascending), y = seg_id << 48 | q_span << 32 | query_pos.
+ * Outputs are return_t.scores / return_t.parents (host_data.h:30-36).
+ */
+#define GAB_CHAIN 0      /* chain:      max_skip / max_iter heuristics, 64-bit coordinates   */
+#define GAB_FASTCHAIN 1  /* fast-chain: no max_skip, 32-bit coordinates, AVX2/AVX-512 rounding */
+typedef struct gab_chain gab_chain;
+typedef struct {           /* call_t header, chain/src/host_data.h:23-28 */
+    int64_t n;
+    float avg_qspan;
+    int32_t max_dist_x, max_dist_y, bw, n_segs;
+} gab_chain_hdr;
+
+int gab_chain_create(int device, gab_chain **out);
+void gab_chain_destroy(gab_chain *h);
+/* everything on the host */
+int gab_chain_run(gab_chain *h, int mode, const uint64_t *x, const uint64_t *y, const int64_t *call_off,
+                  const gab_chain_hdr *hdr, int64_t ncalls, int32_t *score_out, int32_t *parent_out);
+/* anchors and results on the device; the small call table (call_off, hdr) stays on the host.
+ * Returns after the kernel has completed on `stream`. */
+int gab_chain_run_device(gab_chain *h, int mode, const uint64_t *d_x, const uint64_t *d_y,
+                         const int64_t *call_off, const gab_chain_hdr *hdr, int64_t ncalls,
+                         int32_t *d_score, int32_t *d_parent, void *stream);
+/* predecessor evaluations (inner-loop iterations) and kernel time (HIP events) of the last run */
+int gab_chain_last_stats(gab_chain *h, int64_t *evals, float *kernel_ms);
+
 #ifdef __cplusplus
 }
 #endif

@@ -37,6 +37,23 @@ void oracle_bsw_batch(const oracle_bsw_params *p, const uint8_t *ref, const int6
                       const int32_t *len2, const int32_t *h0, int64_t n, int threads,
                       oracle_bsw_result *out, int64_t *cells);
 
+/* ---- chain / fast-chain: see chain.c ---------------------------------------------- */
+typedef struct {
+    int64_t n;
+    float avg_qspan;
+    int32_t max_dist_x, max_dist_y, bw, n_segs;
+} oracle_chain_hdr;
+/* both return the number of predecessor evaluations (inner-loop iterations) */
+int64_t oracle_chain_call(const oracle_chain_hdr *h, const uint64_t *x, const uint64_t *y,
+                          int32_t *score, int32_t *parent);
+int64_t oracle_fastchain_call(const oracle_chain_hdr *h, const uint64_t *x, const uint64_t *y,
+                              int32_t *score, int32_t *parent);
+/* mode 0 = chain, 1 = fast-chain; OpenMP dynamic over calls like host_chain_kernel
+ * (chain/src/host_kernel.cpp:96-108) */
+void oracle_chain_batch(int mode, const oracle_chain_hdr *hdr, const int64_t *call_off, int64_t ncalls,
+                        const uint64_t *x, const uint64_t *y, int threads,
+                        int32_t *score, int32_t *parent, int64_t *evals);
+
 #ifdef __cplusplus
 }
 #endif

@@ -67,3 +67,14 @@ def bsw(batch, params=None, threads=0, want_cells=False):
                            _p(batch.qry_off), _p(batch.len1), _p(batch.len2), _p(batch.h0),
                            C.c_int64(batch.n), C.c_int(threads), _p(out), C.byref(cells))
     return (out, cells.value) if want_cells else out
+
+
+# ------------------------------------------------------------------ chain / fast-chain
+def chain(batch, mode=0, threads=0, want_evals=False):
+    """mode 0 = chain (max_skip heuristics), 1 = fast-chain (AVX2/AVX-512 arithmetic).
+    returns (score, parent) int32 arrays over all anchors of all calls"""
+    score = np.zeros(batch.nanchors, np.int32); parent = np.zeros(batch.nanchors, np.int32)
+    ev = C.c_int64(0)
+    lib().oracle_chain_batch(C.c_int(mode), _p(batch.hdr), _p(batch.call_off), C.c_int64(batch.ncalls),
+                             _p(batch.x), _p(batch.y), C.c_int(threads), _p(score), _p(parent), C.byref(ev))
+    return (score, parent, ev.value) if want_evals else (score, parent)

@@ -52,7 +52,29 @@ def make_bsw(m):
                    "command": "bsw_ref_<isa> -pairs <in> -t 1 -b 512 ; grep score= stderr"}
 
 
-MAKERS = {"bsw": make_bsw}
+def make_chain(m):
+    # one input serves both benchmarks (fast-chain reads chain's files: fast-chain/scripts/regression_small.sh:4)
+    for name, seed, ncalls, mode, nmin, nmax in [("chain_bench", 201, 24, 0, 50, 2000),
+                                                 ("chain_dense", 202, 5, 1, 1500, 6000)]:
+        inp = os.path.join(HERE, name + ".in.txt")
+        gabgen.write_text("chain", inp, seed, ncalls, mode, nmin, nmax)
+        outs = {}
+        for exe in ("chain_ref", "fastchain_ref_avx2", "fastchain_ref_avx512"):
+            out = os.path.join(HERE, name + "." + exe + ".tmp")
+            subprocess.run([pyoracle.ref_path(exe), "-i", inp, "-o", out, "-t", "1"], capture_output=True, check=True)
+            outs[exe] = open(out).read()
+            os.remove(out)
+        assert outs["fastchain_ref_avx2"] == outs["fastchain_ref_avx512"], "fast-chain AVX2 != AVX-512"
+        open(os.path.join(HERE, name + ".chain.expected.txt"), "w").write(outs["chain_ref"])
+        open(os.path.join(HERE, name + ".fastchain.expected.txt"), "w").write(outs["fastchain_ref_avx2"])
+        m[name] = {"generator": "tools/gen gabgen chain", "seed": seed, "ncalls": ncalls, "mode": mode,
+                   "nmin": nmin, "nmax": nmax,
+                   "reference": "chain/src/*.cpp and fast-chain/src/*.cpp built by oracle/Makefile "
+                                "(fast-chain: -mavx2 and -mavx512bw builds, identical output)",
+                   "command": "<exe> -i <in> -o <out> -t 1"}
+
+
+MAKERS = {"bsw": make_bsw, "chain": make_chain}
 
 if __name__ == "__main__":
     pyoracle.build(with_ref=True)

@@ -1,0 +1,76 @@
+"""GPU parity: chain / fast-chain HIP kernels (through the C ABI) vs the oracle and the golden vectors."""
+import numpy as np
+import pytest
+
+from oracle import pyoracle
+from tools import gabgen
+from tests.util import GOLDEN, read_chain_output
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from genarchbench_amd.chain import ChainEngine
+    e = ChainEngine()
+    yield e
+    e.close()
+
+
+@pytest.mark.parametrize("name", ["chain_bench", "chain_dense"])
+@pytest.mark.parametrize("mode,tag", [(0, "chain"), (1, "fastchain")])
+def test_golden(eng, name, mode, tag):
+    batch = gabgen.read_chain_text(f"{GOLDEN}/{name}.in.txt")
+    ws, wp = read_chain_output(f"{GOLDEN}/{name}.{tag}.expected.txt")
+    s, p = eng.host_chain_kernel(batch, mode)
+    np.testing.assert_array_equal(s, ws)
+    np.testing.assert_array_equal(p, wp)
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("seed,ncalls,gmode,nmin,nmax", [(31, 200, 0, 50, 20000), (32, 30, 1, 500, 9000),
+                                                         (33, 3, 1, 40000, 70000), (34, 64, 0, 1, 70)])
+def test_vs_oracle(eng, mode, seed, ncalls, gmode, nmin, nmax):
+    batch = gabgen.chain(seed, ncalls, gmode, nmin, nmax)
+    ws, wp, ev = pyoracle.chain(batch, mode, want_evals=True)
+    s, p = eng.host_chain_kernel(batch, mode)
+    np.testing.assert_array_equal(s, ws)
+    np.testing.assert_array_equal(p, wp)
+    assert eng.last_stats()["evals"] == ev
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_edge_calls(eng, mode):
+    """empty call, single anchor, duplicates, unsorted x, window clamp (max_iter), huge max_dist"""
+    rng = np.random.default_rng(5)
+    Y = lambda q, span=15, seg=0: (np.uint64(seg) << np.uint64(48)) | (np.uint64(span) << np.uint64(32)) | np.uint64(q)
+    calls = []
+    calls.append((15.0, 5000, 5000, 500, 1, np.array([], np.uint64), np.array([], np.uint64)))
+    calls.append((15.0, 5000, 5000, 500, 1, np.array([7], np.uint64), np.array([Y(3)], np.uint64)))
+    x = np.sort(rng.integers(0, 50, 300)).astype(np.uint64)
+    calls.append((15.0, 5000, 5000, 500, 1, x, np.array([Y(int(q)) for q in rng.integers(0, 60, 300)], np.uint64)))
+    x = rng.integers(0, 4000, 500).astype(np.uint64)  # NOT sorted
+    calls.append((14.5, 5000, 5000, 500, 1, x, np.array([Y(int(q), int(s)) for q, s in zip(rng.integers(0, 4000, 500), rng.integers(1, 40, 500))], np.uint64)))
+    # 12000 anchors inside one max_dist_x window: the 5000-predecessor clamp applies
+    x = np.sort(rng.integers(0, 3000, 12000)).astype(np.uint64)
+    q = (x.astype(np.int64) + rng.integers(-20, 20, 12000)).clip(0)
+    calls.append((15.0, 1000000, 1000000, 100000, 1, x, np.array([Y(int(v)) for v in q], np.uint64)))
+    batch = gabgen.chain_from_calls(calls)
+    ws, wp = pyoracle.chain(batch, mode)
+    s, p = eng.host_chain_kernel(batch, mode)
+    np.testing.assert_array_equal(s, ws)
+    np.testing.assert_array_equal(p, wp)
+
+
+def test_device_resident(eng):
+    import torch
+    batch = gabgen.chain(41, 50, 0, 50, 5000)
+    dev = torch.device("cuda:0")
+    x = torch.from_numpy(batch.x.view(np.int64)).to(dev); y = torch.from_numpy(batch.y.view(np.int64)).to(dev)
+    sc = torch.zeros(batch.nanchors, dtype=torch.int32, device=dev); pa = torch.zeros_like(sc)
+    for mode in (0, 1):
+        eng.run_device(mode, x, y, batch.call_off, batch.hdr, sc, pa, stream=torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        ws, wp = pyoracle.chain(batch, mode)
+        np.testing.assert_array_equal(sc.cpu().numpy(), ws)
+        np.testing.assert_array_equal(pa.cpu().numpy(), wp)

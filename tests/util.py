@@ -38,3 +38,13 @@ def has_gpu():
         return torch.cuda.is_available()
     except Exception:
         return False
+
+
+def read_chain_output(path):
+    """reference chain output (chain/src/host_data_io.cpp:53-60): n / score<TAB>parent x n / EOR"""
+    sc, pa = [], []
+    for line in open(path):
+        f = line.split()
+        if len(f) == 2:
+            sc.append(int(f[0])); pa.append(int(f[1]))
+    return np.array(sc, np.int32), np.array(pa, np.int32)

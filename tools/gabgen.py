@@ -101,3 +101,78 @@ def write_text(bench, path, seed, n, mode=0, *extra):
     build()
     subprocess.check_call([os.path.join(_GEN_DIR, "gabgen"), bench, path, str(seed), str(n), str(mode)]
                           + [str(e) for e in extra])
+
+
+# ------------------------------------------------------------------ chain / fast-chain
+CHAIN_HDR = np.dtype([("n", np.int64), ("avg_qspan", np.float32), ("max_dist_x", np.int32),
+                      ("max_dist_y", np.int32), ("bw", np.int32), ("n_segs", np.int32)], align=True)
+assert CHAIN_HDR.itemsize == 32
+
+
+@dataclass
+class ChainBatch:
+    """all calls of one input file, anchors back to back: call c owns [call_off[c], call_off[c]+hdr[c].n)"""
+    hdr: np.ndarray       # CHAIN_HDR records
+    call_off: np.ndarray  # int64
+    x: np.ndarray         # uint64
+    y: np.ndarray         # uint64
+
+    @property
+    def ncalls(self):
+        return len(self.hdr)
+
+    @property
+    def nanchors(self):
+        return len(self.x)
+
+    def write_text(self, path):
+        """reference input format: chain/src/host_data_io.cpp:13-51"""
+        with open(path, "w") as f:
+            for c in range(self.ncalls):
+                h = self.hdr[c]; o = int(self.call_off[c])
+                f.write("%d\t%f\t%d\t%d\t%d\t%d\n" % (h["n"], h["avg_qspan"], h["max_dist_x"], h["max_dist_y"],
+                                                     h["bw"], h["n_segs"]))
+                for i in range(int(h["n"])):
+                    f.write("%d\t%d\n" % (self.x[o + i], self.y[o + i]))
+                f.write("EOR\n")
+
+
+def chain(seed, ncalls, mode=0, nmin=50, nmax=60000, first=0):
+    L = lib()
+    hdr = np.zeros(ncalls, CHAIN_HDR)
+    L.gab_gen_chain_hdrs(C.c_uint64(seed), C.c_int(mode), C.c_int64(nmin), C.c_int64(nmax), C.c_int64(first),
+                         C.c_int64(ncalls), _p(hdr))
+    call_off, total = _offsets(hdr["n"])
+    x = np.zeros(total, np.uint64); y = np.zeros(total, np.uint64)
+    L.gab_gen_chain_fill(C.c_uint64(seed), C.c_int(mode), C.c_int64(nmin), C.c_int64(nmax), C.c_int64(first),
+                         C.c_int64(ncalls), _p(hdr), _p(call_off), _p(x), _p(y))
+    return ChainBatch(hdr, call_off, x, y)
+
+
+def chain_from_calls(calls):
+    """calls: list of (avg_qspan, max_dist_x, max_dist_y, bw, n_segs, x_array, y_array)"""
+    hdr = np.zeros(len(calls), CHAIN_HDR)
+    for c, (aq, mdx, mdy, bw, ns, x, y) in enumerate(calls):
+        hdr[c] = (len(x), aq, mdx, mdy, bw, ns)
+    call_off, total = _offsets(hdr["n"])
+    X = np.zeros(total, np.uint64); Y = np.zeros(total, np.uint64)
+    for c, call in enumerate(calls):
+        o = int(call_off[c]); n = len(call[5])
+        X[o:o + n] = call[5]; Y[o:o + n] = call[6]
+    return ChainBatch(hdr, call_off, X, Y)
+
+
+def read_chain_text(path):
+    """parse the reference's chain input format into a ChainBatch (tests only; the C driver has its own parser)"""
+    toks = open(path).read().split()
+    calls, p = [], 0
+    while p + 6 <= len(toks):
+        n = int(toks[p]); aq = np.float32(toks[p + 1])
+        mdx, mdy, bw, ns = (int(t) for t in toks[p + 2:p + 6])
+        p += 6
+        xy = np.array(toks[p:p + 2 * n], dtype=np.uint64).reshape(n, 2)
+        p += 2 * n
+        assert toks[p] == "EOR"
+        p += 1
+        calls.append((aq, mdx, mdy, bw, ns, xy[:, 0].copy(), xy[:, 1].copy()))
+    return chain_from_calls(calls)

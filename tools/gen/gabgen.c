@@ -178,3 +178,122 @@ int gab_gen_pairs_write(const char *path, uint64_t seed, int mode, int plen, int
     }
     return fclose(f);
 }
+
+/* ================================================================ chain === */
+/* Anchor (minimap2 mm128_t):  x = rid << 32 | ref_pos  (sorted ascending),
+ * y = seg_id << 48 | q_span << 32 | query_pos   (chain/src/host_kernel.cpp:27-28,53-55). */
+static int64_t chain_n(uint64_t seed, int64_t nmin, int64_t nmax, int64_t idx) {
+    rng_t r = rng_for(seed, 3, (uint64_t)idx);
+    double u = (double)(rnd(&r) >> 11) / 9007199254740992.0;
+    double v = exp(log((double)nmin) + u * (log((double)nmax) - log((double)nmin)));
+    int64_t n = (int64_t)(v + 0.5);
+    if (n < nmin) n = nmin;
+    if (n > nmax) n = nmax;
+    return n;
+}
+
+typedef struct { uint64_t x, y; } gen_anchor;
+static int cmp_anchor(const void *a, const void *b) {
+    const gen_anchor *p = (const gen_anchor *)a, *q = (const gen_anchor *)b;
+    if (p->x != q->x) return p->x < q->x ? -1 : 1;
+    if (p->y != q->y) return p->y < q->y ? -1 : 1;
+    return 0;
+}
+
+/* fills anchors[n]; returns the mean q_span */
+static float chain_item(uint64_t seed, int mode, int64_t idx, int64_t n, gen_anchor *a) {
+    rng_t r = rng_for(seed, 4, (uint64_t)idx);
+    double span_sum = 0;
+    if (mode == 0) {
+        /* reference extent grows with n so anchor density (and the window) stays realistic */
+        int64_t extent = n * (int64_t)rnd_range(&r, 8, 40) + 2000;
+        int ndiag = (int)rnd_range(&r, 1, 5);
+        int64_t dq0[5], dr0[5];
+        for (int d = 0; d < ndiag; d++) { dr0[d] = rnd_range(&r, 0, extent / 4); dq0[d] = rnd_range(&r, 0, extent / 4); }
+        for (int64_t i = 0; i < n; i++) {
+            int64_t rp, qp;
+            if (rnd_pm(&r, 7000)) {
+                int d = (int)(rnd(&r) % (uint64_t)ndiag);
+                int64_t t = rnd_range(&r, 0, extent);
+                rp = dr0[d] + t; qp = dq0[d] + t + rnd_range(&r, -40, 40);
+                if (qp < 0) qp = 0;
+            } else { rp = rnd_range(&r, 0, extent * 5 / 4); qp = rnd_range(&r, 0, extent * 5 / 4); }
+            int span = rnd_pm(&r, 9000) ? 15 : (int)rnd_range(&r, 1, 30);
+            span_sum += span;
+            a[i].x = (uint64_t)rp;
+            a[i].y = ((uint64_t)span << 32) | (uint64_t)(qp & 0x7fffffff);
+        }
+    } else {
+        /* dense: tiny coordinate range -> windows of thousands of predecessors, many ties,
+         * multiple reference ids (x above 2^32), multi-segment ids, duplicate positions */
+        int64_t extent = (int64_t)rnd_range(&r, 300, 6000);
+        int nrid = (int)rnd_range(&r, 1, 3);
+        int nseg = (idx % 3 == 0) ? 2 : 1;
+        for (int64_t i = 0; i < n; i++) {
+            uint64_t rid = rnd(&r) % (uint64_t)nrid;
+            int64_t t = rnd_range(&r, 0, extent);
+            int64_t rp = t, qp = t + rnd_range(&r, -25, 25);
+            if (rnd_pm(&r, 2000)) qp = rnd_range(&r, 0, extent);
+            if (qp < 0) qp = 0;
+            int span = rnd_pm(&r, 8000) ? 15 : (int)rnd_range(&r, 1, 40);
+            uint64_t seg = (uint64_t)(rnd(&r) % (uint64_t)nseg);
+            span_sum += span;
+            a[i].x = (rid * 5 + 1) << 32 | (uint64_t)rp;   /* rid 1,6,11: above 2^32 */
+            a[i].y = seg << 48 | ((uint64_t)span << 32) | (uint64_t)qp;
+        }
+    }
+    qsort(a, (size_t)n, sizeof(gen_anchor), cmp_anchor);
+    return (float)(span_sum / (double)n);
+}
+
+void gab_gen_chain_hdrs(uint64_t seed, int mode, int64_t nmin, int64_t nmax,
+                        int64_t first, int64_t ncalls, gabgen_chain_hdr *hdr) {
+    for (int64_t c = 0; c < ncalls; c++) {
+        int64_t idx = first + c;
+        int64_t n = chain_n(seed, nmin, nmax, idx);
+        hdr[c].n = n;
+        hdr[c].max_dist_x = 5000; hdr[c].max_dist_y = 5000; hdr[c].bw = 500;
+        hdr[c].n_segs = (mode == 1 && idx % 3 == 0) ? 2 : 1;
+        hdr[c].avg_qspan = 0.f;   /* filled by gab_gen_chain_fill */
+    }
+}
+
+void gab_gen_chain_fill(uint64_t seed, int mode, int64_t nmin, int64_t nmax,
+                        int64_t first, int64_t ncalls, const gabgen_chain_hdr *hdr_in,
+                        const int64_t *call_off, uint64_t *x, uint64_t *y) {
+    (void)nmin; (void)nmax;
+    gabgen_chain_hdr *hdr = (gabgen_chain_hdr *)hdr_in;
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int64_t c = 0; c < ncalls; c++) {
+        int64_t n = hdr[c].n;
+        gen_anchor *a = (gen_anchor *)malloc(sizeof(gen_anchor) * (size_t)n);
+        float avg = chain_item(seed, mode, first + c, n, a);
+        /* mode 1 uses integer avg_qspan on two thirds of the calls: separates the fp32
+         * and fp64 gap-cost paths of fast-chain */
+        if (mode == 1 && (first + c) % 3 != 2) avg = (float)(int)(avg + 0.5f);
+        /* the text format prints avg_qspan with %.6g-like precision; round-trip it */
+        char buf[64]; snprintf(buf, sizeof buf, "%f", avg); avg = strtof(buf, 0);
+        hdr[c].avg_qspan = avg;
+        for (int64_t i = 0; i < n; i++) { x[call_off[c] + i] = a[i].x; y[call_off[c] + i] = a[i].y; }
+        free(a);
+    }
+}
+
+int gab_gen_chain_write(const char *path, uint64_t seed, int mode, int64_t nmin,
+                        int64_t nmax, int64_t ncalls) {
+    FILE *f = fopen(path, "w");
+    if (!f) return -1;
+    for (int64_t c = 0; c < ncalls; c++) {
+        gabgen_chain_hdr h; int64_t off = 0;
+        gab_gen_chain_hdrs(seed, mode, nmin, nmax, c, 1, &h);
+        uint64_t *x = (uint64_t *)malloc(16 * (size_t)h.n), *y = x + h.n;
+        gab_gen_chain_fill(seed, mode, nmin, nmax, c, 1, &h, &off, x, y);
+        fprintf(f, "%lld\t%f\t%d\t%d\t%d\t%d\n", (long long)h.n, h.avg_qspan, h.max_dist_x,
+                h.max_dist_y, h.bw, h.n_segs);
+        for (int64_t i = 0; i < h.n; i++)
+            fprintf(f, "%llu\t%llu\n", (unsigned long long)x[i], (unsigned long long)y[i]);
+        fprintf(f, "EOR\n");
+        free(x);
+    }
+    return fclose(f);
+}

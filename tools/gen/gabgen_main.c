@@ -6,7 +6,7 @@
 #include <string.h>
 int main(int argc, char **argv) {
     if (argc < 5) {
-        fprintf(stderr, "usage: gabgen bsw|bpm|wfa <out> <seed> <n> [mode] [plen]\n");
+        fprintf(stderr, "usage: gabgen bsw|bpm|wfa|chain <out> <seed> <n> [mode] [plen | nmin nmax]\n");
         return 2;
     }
     const char *b = argv[1], *out = argv[2];
@@ -17,6 +17,10 @@ int main(int argc, char **argv) {
     if (!strcmp(b, "bpm") || !strcmp(b, "wfa")) {
         int plen = argc > 6 ? atoi(argv[6]) : 151;
         return gab_gen_pairs_write(out, seed, mode, plen, n) ? 1 : 0;
+    }
+    if (!strcmp(b, "chain")) {
+        int64_t nmin = argc > 6 ? atoll(argv[6]) : 50, nmax = argc > 7 ? atoll(argv[7]) : 60000;
+        return gab_gen_chain_write(out, seed, mode, nmin, nmax, n) ? 1 : 0;
     }
     fprintf(stderr, "unknown benchmark %s\n", b);
     return 2;
