@@ -1,0 +1,486 @@
+// bpm -- bit-parallel Myers global edit distance (+ backtrace-derived score) on gfx950.
+//
+// Semantics: benchmark_edit_bpm, /root/reference/benchmarks/bpm/benchmark/benchmark_edit.c:31-56
+//   = edit_bpm_pattern_compile (bpm/edit/edit_bpm.c:70-136) + edit_bpm_compute_matrix (:190-275,
+//   block step BPM_ADVANCE_BLOCK :47-66) + edit_bpm_backtrace_matrix (:276-316) and
+//   score = -edit_cigar_score_edit (bpm/edit/edit_cigar.c:103-116), called with
+//   max_distance = pattern_length and text_length <= pattern_length (the driver's swap,
+//   bpm/tools/align_benchmark.c:177-181), so no block is ever cut off.
+//
+// The reference stores Pv/Mv of EVERY column (7.3 KB per 151-bp pair) only to backtrace, and the
+// printed score is the number of non-match backtrace operations.  When both sequences consist of
+// upper-case A/C/G/T only, the match predicate of the bit-vectors equals raw byte equality and
+// every backtrace step follows an optimal DP move, so the count is exactly the DP distance
+// (bpm) -- no matrix needed.  Otherwise two reference quirks can make the count differ
+// (code 4 aliases onto the next block's 'A' mask; diagonal steps are classified by raw bytes), and
+// the pair takes the full path.  Hence two kernels, one pair per lane in both:
+//
+//   bpm_score<W>   all pairs, bucketed by W = ceil(plen/64) in 1..4: Pv/Mv in registers, the
+//                  4W+1 match masks of each lane in LDS as [mask][lane] (conflict-free b64 reads),
+//                  built with ds_or; writes -distance for clean pairs, queues the rest.
+//   bpm_full<W>    queued pairs (and every pair with W > 4, W = 0 instantiation): same recurrence,
+//                  but each column's Pv/Mv is stored to a global scratch laid out [column][block][slot]
+//                  (coalesced across lanes), followed by the reference's backtrace on that scratch.
+//
+// Roofline: ~36 VALU per (text char x 64-row block); 306 B of input per 151-bp pair.  The score
+// path is integer-VALU bound at about 16 k VALU per pair; its HBM traffic is the algorithmic
+// plen + tlen + 4 B per pair.  The full path adds 16 B x W x (tlen+1) of scratch per queued pair.
+#include "gab_internal.h"
+#include <algorithm>
+#include <new>
+#include <vector>
+#include <string.h>
+
+namespace {
+
+constexpr int kMaxRegW = 4;                 // W classes kept in registers
+constexpr int kClasses = kMaxRegW + 1;      // class c = W for W <= 4, class 0 = W > 4
+constexpr int kBlock = 256;
+
+struct BpmIO {
+    const char *pat; const int64_t *pat_off; const int32_t *pat_len;
+    const char *txt; const int64_t *txt_off; const int32_t *txt_len;
+    int64_t pat_bytes, txt_bytes, n;
+};
+
+struct BpmCounters {        // device-side, zeroed per run
+    uint32_t cls_count[8];  // pairs per W class (index = class)
+    uint32_t cls_cursor[8];
+    uint32_t wl_count[8];   // queued (unclean) pairs per class
+    int32_t bad, first_bad;
+    unsigned long long steps;   // block steps executed by bpm_score (m * W summed)
+    unsigned long long full_steps;
+};
+
+__device__ __forceinline__ int bpm_class(int n) {
+    const int W = (n + 63) >> 6;
+    return W <= kMaxRegW ? W : 0;
+}
+
+// code 0..3 for ACGT/acgt, 4 otherwise (bpm/utils/dna_text.c:47-51); *clean &= upper-case ACGT
+__device__ __forceinline__ int bpm_code(uint32_t ch, bool &clean) {
+    const uint32_t idx = ch & 0x1f;
+    const bool letter = (ch & 0xc0u) == 0x40u;
+    const bool acgt = letter && ((0x00100088u | 2u) >> idx & 1u);    // bits 1 (A), 3 (C), 7 (G), 20 (T)
+    const uint32_t x = (ch >> 1) & 3u;                               // A0 C1 G3 T2
+    clean = clean && acgt && !(ch & 0x20u);
+    return acgt ? (int)(x ^ (x >> 1)) : 4;
+}
+
+__device__ __forceinline__ uint32_t ld_u32(const char *p) { uint32_t w; __builtin_memcpy(&w, p, 4); return w; }
+
+// ---- pass 1: validate + count per class ---------------------------------------------------
+__global__ __launch_bounds__(256) void bpm_count(BpmIO io, BpmCounters *ct) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < io.n; i += stride) {
+        const int n = io.pat_len[i], m = io.txt_len[i];
+        const int64_t po = io.pat_off[i], to = io.txt_off[i];
+        const bool ok = n >= 1 && n <= GAB_BPM_MAX_PLEN && m >= 0 && m <= n && po >= 0 && to >= 0 &&
+                        ((po + n + 3) & ~3ll) <= io.pat_bytes && ((to + m + 3) & ~3ll) <= io.txt_bytes;
+        if (!ok) {
+            atomicAdd(&ct->bad, 1);
+            atomicMin((unsigned int *)&ct->first_bad, (unsigned int)(i + 1 > 0x7fffffff ? 0x7fffffff : i + 1));
+            continue;
+        }
+        atomicAdd(&ct->cls_count[bpm_class(n)], 1u);
+    }
+}
+
+// ---- pass 2: scatter ids by class ---------------------------------------------------------
+__global__ __launch_bounds__(256) void bpm_scatter(BpmIO io, BpmCounters *ct, uint32_t *perm) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < io.n; i += stride) {
+        const int n = io.pat_len[i];
+        perm[atomicAdd(&ct->cls_cursor[bpm_class(n)], 1u)] = (uint32_t)i;
+    }
+}
+
+// one 64-row block step (BPM_ADVANCE_BLOCK, edit_bpm.c:47-66)
+__device__ __forceinline__ void bpm_step(uint64_t Eq, uint64_t mask, uint64_t &P, uint64_t &M, uint32_t &PH,
+                                         uint32_t &MH) {
+    const uint64_t Xv = Eq | M;
+    const uint64_t Eq2 = Eq | (uint64_t)MH;
+    const uint64_t Xh = (((Eq2 & P) + P) ^ P) | Eq2;
+    uint64_t Ph = M | ~(Xh | P);
+    uint64_t Mh = P & Xh;
+    const uint32_t PHo = (Ph & mask) != 0, MHo = (Mh & mask) != 0;
+    Ph = (Ph << 1) | (uint64_t)PH;
+    Mh = (Mh << 1) | (uint64_t)MH;
+    P = Mh | ~(Xv | Ph);
+    M = Ph & Xv;
+    PH = PHo; MH = MHo;
+}
+
+// Builds the 4W+1 match masks of this lane in LDS (peq[mask * kBlock + tid]); returns cleanliness.
+template <int W>
+__device__ __forceinline__ bool bpm_build_peq(uint64_t *peq, const char *p, int n) {
+    for (int k = 0; k < 4 * W + 1; k++) peq[k * kBlock] = 0;
+    bool clean = true;
+    for (int i0 = 0; i0 < n; i0 += 4) {
+        uint32_t w = ld_u32(p + i0);
+        for (int k = 0; k < 4 && i0 + k < n; k++, w >>= 8) {
+            const int i = i0 + k;
+            const int c = bpm_code(w & 0xffu, clean);
+            atomicOr((unsigned long long *)&peq[((i >> 6) * 4 + c) * kBlock], 1ull << (i & 63));
+        }
+    }
+    // padding rows n .. 64W-1 match every code 0..3 (edit_bpm.c:106-113)
+    if (n & 63) {
+        const uint64_t pad = ~0ull << (n & 63);
+        for (int c = 0; c < 4; c++) peq[((W - 1) * 4 + c) * kBlock] |= pad;
+    }
+    return clean;
+}
+
+// ---- score path: W in 1..4 -------------------------------------------------------------------
+template <int W>
+__global__ __launch_bounds__(kBlock) void bpm_score(BpmIO io, const uint32_t *__restrict__ perm, uint32_t kbeg,
+                                                    uint32_t kend, int32_t *__restrict__ score_out,
+                                                    uint32_t *__restrict__ worklist, BpmCounters *ct) {
+    __shared__ uint64_t peq_s[(4 * W + 1) * kBlock];
+    const uint32_t k = kbeg + blockIdx.x * kBlock + threadIdx.x;
+    unsigned long long steps = 0;
+    if (k < kend) {
+        const uint32_t id = perm[k];
+        const int n = io.pat_len[id], m = io.txt_len[id];
+        const char *p = io.pat + io.pat_off[id], *t = io.txt + io.txt_off[id];
+        uint64_t *peq = peq_s + threadIdx.x;
+        bool clean = bpm_build_peq<W>(peq, p, n);
+        uint64_t P[W], M[W];
+#pragma unroll
+        for (int b = 0; b < W; b++) { P[b] = ~0ull; M[b] = 0; }
+        const uint64_t top_mask = (n & 63) ? 1ull << ((n & 63) - 1) : 1ull << 63;
+        int score = n;
+        for (int h0 = 0; h0 < m; h0 += 4) {
+            uint32_t w = ld_u32(t + h0);
+            for (int kk = 0; kk < 4 && h0 + kk < m; kk++, w >>= 8) {
+                const int c = bpm_code(w & 0xffu, clean);
+                uint32_t PH = 1, MH = 0;
+#pragma unroll
+                for (int b = 0; b < W; b++)
+                    bpm_step(peq[(b * 4 + c) * kBlock], b == W - 1 ? top_mask : 1ull << 63, P[b], M[b], PH, MH);
+                score += (int)PH - (int)MH;
+            }
+        }
+        steps = (unsigned long long)m * W;
+        if (clean) score_out[id] = -score;
+        else worklist[atomicAdd(&ct->wl_count[W], 1u)] = id;
+    }
+    for (int o = 32; o > 0; o >>= 1) steps += __shfl_xor(steps, o);
+    if ((threadIdx.x & 63) == 0 && steps) atomicAdd(&ct->steps, steps);
+}
+
+// ---- full path: history + backtrace ---------------------------------------------------------------
+// slot s of this launch works on pair list[s]; element (col, b) of its history lives at
+//   hist[base + ((col * Wd + b) * 2 + {0: P, 1: M}) * estride]       (u64 units)
+// REGW > 0: W == REGW for every slot, base = s, estride = nslots (coalesced); masks in LDS.
+// REGW == 0: any W (<= 255), base = slot_base[s], estride = 1; the 4W+1 masks sit in front of the history.
+template <int REGW>
+__global__ __launch_bounds__(kBlock) void bpm_full(BpmIO io, const uint32_t *__restrict__ list, uint32_t nslots,
+                                                   uint64_t *__restrict__ hist, const int64_t *__restrict__ slot_base,
+                                                   int32_t *__restrict__ score_out, BpmCounters *ct) {
+    __shared__ uint64_t peq_s[(REGW ? 4 * REGW + 1 : 1) * kBlock];
+    const uint32_t s = blockIdx.x * kBlock + threadIdx.x;
+    if (s >= nslots) return;
+    const uint32_t id = list[s];
+    const int n = io.pat_len[id], m = io.txt_len[id];
+    const char *p = io.pat + io.pat_off[id], *t = io.txt + io.txt_off[id];
+    const int Wd = REGW ? REGW : (n + 63) >> 6;
+    const int64_t estride = REGW ? (int64_t)nslots : 1;
+    uint64_t *H;                 // history origin of this slot
+    uint64_t *peq;               // mask k at peq[k * pstride]
+    int64_t pstride;
+    bool dummy = true;
+    if (REGW) {
+        H = hist + s;
+        peq = peq_s + threadIdx.x; pstride = kBlock;
+        bpm_build_peq<(REGW ? REGW : 1)>(peq, p, n);
+    } else {
+        peq = hist + slot_base[s]; pstride = 1;
+        H = peq + 4 * Wd + 1;
+        for (int k = 0; k < 4 * Wd + 1; k++) peq[k] = 0;
+        for (int i = 0; i < n; i++) peq[(i >> 6) * 4 + bpm_code((uint8_t)p[i], dummy)] |= 1ull << (i & 63);
+        if (n & 63) for (int c = 0; c < 4; c++) peq[(Wd - 1) * 4 + c] |= ~0ull << (n & 63);
+    }
+    const uint64_t top_mask = (n & 63) ? 1ull << ((n & 63) - 1) : 1ull << 63;
+#define HP(col, b) H[(((int64_t)(col) * Wd + (b)) * 2) * estride]
+#define HM(col, b) H[(((int64_t)(col) * Wd + (b)) * 2 + 1) * estride]
+    uint64_t P[REGW ? REGW : 1], M[REGW ? REGW : 1];
+    if (REGW) {
+#pragma unroll
+        for (int b = 0; b < REGW; b++) { P[b] = ~0ull; M[b] = 0; HP(0, b) = ~0ull; HM(0, b) = 0; }
+    } else {
+        for (int b = 0; b < Wd; b++) { HP(0, b) = ~0ull; HM(0, b) = 0; }
+    }
+    for (int h = 0; h < m; h++) {
+        const int c = bpm_code((uint8_t)t[h], dummy);
+        uint32_t PH = 1, MH = 0;
+        if (REGW) {
+#pragma unroll
+            for (int b = 0; b < REGW; b++) {
+                bpm_step(peq[(b * 4 + c) * pstride], b == REGW - 1 ? top_mask : 1ull << 63, P[b], M[b], PH, MH);
+                HP(h + 1, b) = P[b]; HM(h + 1, b) = M[b];
+            }
+        } else {
+            for (int b = 0; b < Wd; b++) {
+                uint64_t Pb = HP(h, b), Mb = HM(h, b);
+                bpm_step(peq[b * 4 + c], b == Wd - 1 ? top_mask : 1ull << 63, Pb, Mb, PH, MH);
+                HP(h + 1, b) = Pb; HM(h + 1, b) = Mb;
+            }
+        }
+    }
+    // backtrace (edit_bpm.c:289-313), counting non-match operations
+    int ops = 0, v = n - 1, h = m - 1;
+    while (v >= 0 && h >= 0) {
+        const int b = v >> 6;
+        const uint64_t bit = 1ull << (v & 63);
+        if (HP(h + 1, b) & bit) { ops++; v--; }
+        else if (HM(h, b) & bit) { ops++; h--; }
+        else { ops += t[h] != p[v]; h--; v--; }
+    }
+    ops += (h + 1) + (v + 1);
+    score_out[id] = -ops;
+    atomicAdd(&ct->full_steps, (unsigned long long)m * Wd);
+#undef HP
+#undef HM
+}
+
+}  // namespace
+
+// =============================================================================== host side
+struct gab_bpm {
+    int device = 0;
+    gab_devbuf ws;          // counters | perm | worklists
+    gab_devbuf scratch;     // history of the full path
+    gab_devbuf io;          // staging for the host-pointer entry point
+    size_t scratch_budget = (size_t)8 << 30;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    BpmCounters *h_ct = nullptr;   // pinned
+    bool have_stats = false;
+    int64_t last_full = 0;
+};
+
+extern "C" int gab_bpm_create(int device, gab_bpm **out) {
+    if (!out) { gab_set_error("gab_bpm_create: NULL argument"); return GAB_EINVAL; }
+    *out = nullptr;
+    int rc = gab_check_device(device);
+    if (rc) return rc;
+    gab_device_guard g(device);
+    gab_bpm *h = new (std::nothrow) gab_bpm();
+    if (!h) { gab_set_error("out of host memory"); return GAB_ENOMEM; }
+    h->device = device;
+    for (int k = 0; k < 4; k++)
+        if (hipEventCreate(&h->ev[k]) != hipSuccess) { gab_set_error("hipEventCreate failed"); delete h; return GAB_EDEVICE; }
+    if (hipHostMalloc((void **)&h->h_ct, sizeof(BpmCounters)) != hipSuccess) {
+        gab_set_error("hipHostMalloc failed"); delete h; return GAB_ENOMEM;
+    }
+    *out = h;
+    return GAB_OK;
+}
+
+extern "C" void gab_bpm_destroy(gab_bpm *h) {
+    if (!h) return;
+    gab_device_guard g(h->device);
+    h->ws.release(); h->scratch.release(); h->io.release();
+    for (int k = 0; k < 4; k++) if (h->ev[k]) (void)hipEventDestroy(h->ev[k]);
+    if (h->h_ct) (void)hipHostFree(h->h_ct);
+    delete h;
+}
+
+template <int W>
+static void launch_score(hipStream_t s, const BpmIO &io, const uint32_t *perm, uint32_t kb, uint32_t ke, int32_t *score,
+                         uint32_t *wl, BpmCounters *ct) {
+    if (ke <= kb) return;
+    hipLaunchKernelGGL(bpm_score<W>, dim3((ke - kb + kBlock - 1) / kBlock), dim3(kBlock), 0, s, io, perm, kb, ke, score, wl, ct);
+}
+template <int W>
+static void launch_full(hipStream_t s, const BpmIO &io, const uint32_t *list, uint32_t nslots, uint64_t *hist,
+                        const int64_t *slot_base, int32_t *score, BpmCounters *ct) {
+    hipLaunchKernelGGL(bpm_full<W>, dim3((nslots + kBlock - 1) / kBlock), dim3(kBlock), 0, s, io, list, nslots, hist,
+                       slot_base, score, ct);
+}
+
+extern "C" int gab_bpm_run_device(gab_bpm *h, const char *pat, int64_t pat_bytes, const int64_t *pat_off,
+                                  const int32_t *pat_len, const char *txt, int64_t txt_bytes, const int64_t *txt_off,
+                                  const int32_t *txt_len, int64_t n, int32_t *score_out, void *stream_) {
+    GAB_CHECK(h, "gab_bpm_run_device: NULL handle");
+    GAB_CHECK(n >= 0 && n < (1ll << 31), "gab_bpm_run_device: n=%lld out of range", (long long)n);
+    h->have_stats = false;
+    if (n == 0) return GAB_OK;
+    GAB_CHECK(pat && pat_off && pat_len && txt && txt_off && txt_len && score_out, "gab_bpm_run_device: NULL buffer");
+    gab_device_guard g(h->device);
+    hipStream_t s = (hipStream_t)stream_;
+
+    const size_t o_perm = (sizeof(BpmCounters) + 255) & ~(size_t)255;
+    const size_t o_wl = o_perm + sizeof(uint32_t) * (size_t)n;
+    int rc = h->ws.reserve(o_wl + sizeof(uint32_t) * (size_t)n);
+    if (rc) return rc;
+    char *base = h->ws.as<char>();
+    BpmCounters *d_ct = (BpmCounters *)base;
+    uint32_t *d_perm = (uint32_t *)(base + o_perm), *d_wl = (uint32_t *)(base + o_wl);
+    BpmIO io{pat, pat_off, pat_len, txt, txt_off, txt_len, pat_bytes, txt_bytes, n};
+
+    GAB_HIP(hipEventRecord(h->ev[0], s));
+    memset(h->h_ct, 0, sizeof(BpmCounters));
+    h->h_ct->first_bad = 0x7fffffff;
+    GAB_HIP(hipMemcpyAsync(d_ct, h->h_ct, sizeof(BpmCounters), hipMemcpyHostToDevice, s));
+    const int grid = (int)std::min<int64_t>(gab_ceil_div(n, 256), 4096);
+    hipLaunchKernelGGL(bpm_count, dim3(grid), dim3(256), 0, s, io, d_ct);
+    GAB_HIP(hipMemcpyAsync(h->h_ct, d_ct, sizeof(BpmCounters), hipMemcpyDeviceToHost, s));
+    GAB_HIP(hipStreamSynchronize(s));
+    if (h->h_ct->bad) {
+        gab_set_error("gab_bpm_run_device: %d pair(s) violate the limits (first: pair %d): need 1 <= pattern_length <= %d, "
+                      "0 <= text_length <= pattern_length (apply the driver's longer-is-pattern swap), offsets inside "
+                      "the slabs (readable to a multiple of 4 bytes)", h->h_ct->bad, h->h_ct->first_bad - 1,
+                      GAB_BPM_MAX_PLEN);
+        return GAB_EINVAL;
+    }
+    // class starts: perm = [class 1 | class 2 | class 3 | class 4 | class 0 (W > 4)]
+    uint32_t cstart[kClasses + 1], ccount[kClasses];
+    const int order[kClasses] = {1, 2, 3, 4, 0};
+    uint32_t run = 0;
+    for (int k = 0; k < kClasses; k++) { ccount[order[k]] = h->h_ct->cls_count[order[k]]; cstart[order[k]] = run; run += ccount[order[k]]; }
+    for (int c = 0; c < kClasses; c++) h->h_ct->cls_cursor[c] = cstart[c];
+    GAB_HIP(hipMemcpyAsync(d_ct, h->h_ct, sizeof(BpmCounters), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(bpm_scatter, dim3(grid), dim3(256), 0, s, io, d_ct, d_perm);
+
+    // score path; worklist of class W occupies d_wl[cstart[W] ..)
+    GAB_HIP(hipEventRecord(h->ev[1], s));
+    launch_score<1>(s, io, d_perm, cstart[1], cstart[1] + ccount[1], score_out, d_wl + cstart[1], d_ct);
+    launch_score<2>(s, io, d_perm, cstart[2], cstart[2] + ccount[2], score_out, d_wl + cstart[2], d_ct);
+    launch_score<3>(s, io, d_perm, cstart[3], cstart[3] + ccount[3], score_out, d_wl + cstart[3], d_ct);
+    launch_score<4>(s, io, d_perm, cstart[4], cstart[4] + ccount[4], score_out, d_wl + cstart[4], d_ct);
+    GAB_HIP(hipGetLastError());
+    GAB_HIP(hipEventRecord(h->ev[2], s));
+    GAB_HIP(hipMemcpyAsync(h->h_ct, d_ct, sizeof(BpmCounters), hipMemcpyDeviceToHost, s));
+    GAB_HIP(hipStreamSynchronize(s));
+
+    // full path for queued pairs, per class, in scratch-sized batches
+    int64_t nfull = 0;
+    {
+        // largest text length bounds the history per slot; classes 1..4 have plen <= 64 W, tlen <= plen
+        for (int W = 1; W <= kMaxRegW; W++) {
+            const uint32_t cnt = h->h_ct->wl_count[W];
+            if (!cnt) continue;
+            nfull += cnt;
+            const size_t per_slot = (size_t)(64 * W + 1) * W * 16;
+            uint32_t batch = (uint32_t)std::max<size_t>(kBlock, std::min<size_t>(cnt, h->scratch_budget / per_slot));
+            batch = (batch + kBlock - 1) / kBlock * kBlock;
+            if (batch > cnt) batch = cnt;
+            rc = h->scratch.reserve(per_slot * batch);
+            if (rc) return rc;
+            for (uint32_t b0 = 0; b0 < cnt; b0 += batch) {
+                const uint32_t nb = std::min(batch, cnt - b0);
+                const uint32_t *list = d_wl + cstart[W] + b0;
+                uint64_t *hist = h->scratch.as<uint64_t>();
+                switch (W) {
+                    case 1: launch_full<1>(s, io, list, nb, hist, nullptr, score_out, d_ct); break;
+                    case 2: launch_full<2>(s, io, list, nb, hist, nullptr, score_out, d_ct); break;
+                    case 3: launch_full<3>(s, io, list, nb, hist, nullptr, score_out, d_ct); break;
+                    default: launch_full<4>(s, io, list, nb, hist, nullptr, score_out, d_ct); break;
+                }
+            }
+        }
+        // W > 4: every pair takes the generic full path with per-slot extents
+        const uint32_t cnt0 = ccount[0];
+        if (cnt0) {
+            nfull += cnt0;
+            std::vector<uint32_t> ids(cnt0);
+            std::vector<int32_t> pl(cnt0), tl(cnt0);
+            GAB_HIP(hipMemcpyAsync(ids.data(), d_perm + cstart[0], 4 * (size_t)cnt0, hipMemcpyDeviceToHost, s));
+            GAB_HIP(hipStreamSynchronize(s));
+            // lengths of those pairs (few and far between: gather one by one through a strided copy)
+            for (uint32_t k = 0; k < cnt0; k++) {
+                GAB_HIP(hipMemcpyAsync(&pl[k], pat_len + ids[k], 4, hipMemcpyDeviceToHost, s));
+                GAB_HIP(hipMemcpyAsync(&tl[k], txt_len + ids[k], 4, hipMemcpyDeviceToHost, s));
+            }
+            GAB_HIP(hipStreamSynchronize(s));
+            uint32_t k0 = 0;
+            while (k0 < cnt0) {
+                std::vector<int64_t> sb;
+                size_t used = 0; uint32_t k1 = k0;
+                while (k1 < cnt0) {
+                    const size_t Wd = ((size_t)pl[k1] + 63) / 64;
+                    const size_t need = 4 * Wd + 1 + ((size_t)tl[k1] + 1) * Wd * 2;
+                    if (k1 > k0 && (used + need) * 8 > h->scratch_budget) break;
+                    sb.push_back((int64_t)used); used += need; k1++;
+                }
+                const size_t nb = sb.size();
+                rc = h->scratch.reserve(used * 8 + nb * 8 + 64);
+                if (rc) return rc;
+                int64_t *d_sb = (int64_t *)(h->scratch.as<char>() + ((used * 8 + 63) & ~(size_t)63));
+                rc = h->scratch.reserve(((used * 8 + 63) & ~(size_t)63) + nb * 8);
+                if (rc) return rc;
+                d_sb = (int64_t *)(h->scratch.as<char>() + ((used * 8 + 63) & ~(size_t)63));
+                GAB_HIP(hipMemcpyAsync(d_sb, sb.data(), nb * 8, hipMemcpyHostToDevice, s));
+                launch_full<0>(s, io, d_perm + cstart[0] + k0, (uint32_t)nb, h->scratch.as<uint64_t>(), d_sb, score_out, d_ct);
+                GAB_HIP(hipStreamSynchronize(s));      // sb (host) and the scratch are reused by the next batch
+                k0 = k1;
+            }
+        }
+    }
+    GAB_HIP(hipGetLastError());
+    GAB_HIP(hipMemcpyAsync(h->h_ct, d_ct, sizeof(BpmCounters), hipMemcpyDeviceToHost, s));
+    GAB_HIP(hipEventRecord(h->ev[3], s));
+    h->last_full = nfull;
+    h->have_stats = true;
+    return GAB_OK;
+}
+
+extern "C" int gab_bpm_run(gab_bpm *h, const char *pat, const int64_t *pat_off, const int32_t *pat_len,
+                           const char *txt, const int64_t *txt_off, const int32_t *txt_len, int64_t n,
+                           int32_t *score_out) {
+    GAB_CHECK(h, "gab_bpm_run: NULL handle");
+    GAB_CHECK(n >= 0 && n < (1ll << 31), "gab_bpm_run: n=%lld out of range", (long long)n);
+    if (n == 0) return GAB_OK;
+    GAB_CHECK(pat && pat_off && pat_len && txt && txt_off && txt_len && score_out, "gab_bpm_run: NULL buffer");
+    gab_device_guard g(h->device);
+    int64_t pb = 0, tb = 0;
+    for (int64_t i = 0; i < n; i++) {
+        GAB_CHECK(pat_off[i] >= 0 && txt_off[i] >= 0 && pat_len[i] >= 0 && txt_len[i] >= 0,
+                  "gab_bpm_run: negative offset/length at pair %lld", (long long)i);
+        pb = std::max(pb, pat_off[i] + pat_len[i]); tb = std::max(tb, txt_off[i] + txt_len[i]);
+    }
+    const size_t ppad = ((size_t)pb + 3 + 255) & ~(size_t)255, tpad = ((size_t)tb + 3 + 255) & ~(size_t)255;
+    const size_t nn = (size_t)n;
+    size_t o = 0;
+    const size_t o_p = o; o += ppad;
+    const size_t o_t = o; o += tpad;
+    const size_t o_po = o; o += 8 * nn;
+    const size_t o_to = o; o += 8 * nn;
+    const size_t o_pl = o; o += 4 * nn;
+    const size_t o_tl = o; o += 4 * nn;
+    const size_t o_sc = o; o += 4 * nn;
+    int rc = h->io.reserve(o);
+    if (rc) return rc;
+    char *b = h->io.as<char>();
+    hipStream_t s = nullptr;
+    GAB_HIP(hipMemcpyAsync(b + o_p, pat, (size_t)pb, hipMemcpyHostToDevice, s));
+    GAB_HIP(hipMemcpyAsync(b + o_t, txt, (size_t)tb, hipMemcpyHostToDevice, s));
+    GAB_HIP(hipMemcpyAsync(b + o_po, pat_off, 8 * nn, hipMemcpyHostToDevice, s));
+    GAB_HIP(hipMemcpyAsync(b + o_to, txt_off, 8 * nn, hipMemcpyHostToDevice, s));
+    GAB_HIP(hipMemcpyAsync(b + o_pl, pat_len, 4 * nn, hipMemcpyHostToDevice, s));
+    GAB_HIP(hipMemcpyAsync(b + o_tl, txt_len, 4 * nn, hipMemcpyHostToDevice, s));
+    rc = gab_bpm_run_device(h, b + o_p, (int64_t)ppad, (const int64_t *)(b + o_po), (const int32_t *)(b + o_pl), b + o_t,
+                            (int64_t)tpad, (const int64_t *)(b + o_to), (const int32_t *)(b + o_tl), n,
+                            (int32_t *)(b + o_sc), s);
+    if (rc) return rc;
+    GAB_HIP(hipMemcpyAsync(score_out, b + o_sc, 4 * nn, hipMemcpyDeviceToHost, s));
+    GAB_HIP(hipStreamSynchronize(s));
+    return GAB_OK;
+}
+
+extern "C" int gab_bpm_last_stats(gab_bpm *h, int64_t *block_steps, int64_t *full_pairs, float *score_kernel_ms,
+                                  float *total_ms) {
+    GAB_CHECK(h, "gab_bpm_last_stats: NULL handle");
+    GAB_CHECK(h->have_stats, "gab_bpm_last_stats: no completed run on this handle");
+    gab_device_guard g(h->device);
+    GAB_HIP(hipEventSynchronize(h->ev[3]));
+    if (block_steps) *block_steps = (int64_t)(h->h_ct->steps + h->h_ct->full_steps);
+    if (full_pairs) *full_pairs = h->last_full;
+    if (score_kernel_ms) GAB_HIP(hipEventElapsedTime(score_kernel_ms, h->ev[1], h->ev[2]));
+    if (total_ms) GAB_HIP(hipEventElapsedTime(total_ms, h->ev[0], h->ev[3]));
+    return GAB_OK;
+}

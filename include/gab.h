@@ -118,6 +118,35 @@ int gab_chain_run_device(gab_chain *h, int mode, const uint64_t *d_x, const uint
 /* predecessor evaluations (inner-loop iterations) and kernel time (HIP events) of the last run */
 int gab_chain_last_stats(gab_chain *h, int64_t *evals, float *kernel_ms);
 
+/* ---- bpm: bit-parallel Myers edit distance (+ backtrace-derived score) -----------------
+ * Replaces  it->score = benchmark_edit_bpm(&align_input)   bpm/tools/align_benchmark.c:243-257
+ *           (bpm/benchmark/benchmark_edit.c:31-56; kernel bpm/edit/edit_bpm.c:70-331).
+ * One call over all pairs instead of one call per pair.  The caller has already applied the
+ * driver's swap (the longer line is the pattern, align_benchmark.c:177-181) and stripped the
+ * leading '>' / '<' and the newline (:247-252): text_length <= pattern_length is required,
+ * exactly the condition under which the reference never cuts a block off.
+ * Sequences are raw ASCII bytes: pair i = pat[pat_off[i] .. +pat_len[i]), txt[...].
+ * score_out[i] = the value the reference prints as "[i] score=%d" (<= 0).
+ */
+#define GAB_BPM_MAX_PLEN 16320 /* 255 x 64: top_level is a uint8_t, bpm/edit/edit_bpm.c:205-206 */
+typedef struct gab_bpm gab_bpm;
+int gab_bpm_create(int device, gab_bpm **out);
+void gab_bpm_destroy(gab_bpm *h);
+int gab_bpm_run(gab_bpm *h, const char *pat, const int64_t *pat_off, const int32_t *pat_len,
+                const char *txt, const int64_t *txt_off, const int32_t *txt_len, int64_t n,
+                int32_t *score_out);
+/* device buffers; pat_bytes / txt_bytes = slab sizes (each readable to a multiple of 4 bytes
+ * past the last sequence).  Synchronises `stream` internally (the second kernel's launch
+ * geometry depends on the first one's queue length). */
+int gab_bpm_run_device(gab_bpm *h, const char *pat, int64_t pat_bytes, const int64_t *pat_off,
+                       const int32_t *pat_len, const char *txt, int64_t txt_bytes,
+                       const int64_t *txt_off, const int32_t *txt_len, int64_t n,
+                       int32_t *score_out, void *stream);
+/* last run: 64-row block steps executed, pairs that needed the history + backtrace path,
+ * device time of the score kernels and of the whole call (HIP events, ms) */
+int gab_bpm_last_stats(gab_bpm *h, int64_t *block_steps, int64_t *full_pairs,
+                       float *score_kernel_ms, float *total_ms);
+
 #ifdef __cplusplus
 }
 #endif

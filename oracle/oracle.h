@@ -54,6 +54,13 @@ void oracle_chain_batch(int mode, const oracle_chain_hdr *hdr, const int64_t *ca
                         const uint64_t *x, const uint64_t *y, int threads,
                         int32_t *score, int32_t *parent, int64_t *evals);
 
+/* ---- bpm: see bpm.c.  The caller has applied the driver's "longer sequence is the pattern"
+ * swap; returns the printed score (<= 0), INT32_MIN if text_length > pattern_length. */
+int oracle_bpm_one(const char *pattern, int n, const char *text, int m, int64_t *block_steps);
+void oracle_bpm_batch(const char *pat, const int64_t *pat_off, const int32_t *pat_len,
+                      const char *txt, const int64_t *txt_off, const int32_t *txt_len,
+                      int64_t n, int threads, int32_t *score, int64_t *block_steps);
+
 #ifdef __cplusplus
 }
 #endif

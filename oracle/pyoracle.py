@@ -78,3 +78,13 @@ def chain(batch, mode=0, threads=0, want_evals=False):
     lib().oracle_chain_batch(C.c_int(mode), _p(batch.hdr), _p(batch.call_off), C.c_int64(batch.ncalls),
                              _p(batch.x), _p(batch.y), C.c_int(threads), _p(score), _p(parent), C.byref(ev))
     return (score, parent, ev.value) if want_evals else (score, parent)
+
+
+# ------------------------------------------------------------------ bpm
+def bpm(batch, threads=0, want_steps=False):
+    """batch: PairBatch with the longer-is-pattern swap already applied -> int32 scores (<= 0)"""
+    score = np.zeros(batch.n, np.int32)
+    st = C.c_int64(0)
+    lib().oracle_bpm_batch(_p(batch.pat), _p(batch.pat_off), _p(batch.pat_len), _p(batch.txt), _p(batch.txt_off),
+                           _p(batch.txt_len), C.c_int64(batch.n), C.c_int(threads), _p(score), C.byref(st))
+    return (score, st.value) if want_steps else score

@@ -1,0 +1,75 @@
+"""GPU parity: bpm HIP kernels (through the C ABI) vs the oracle and the golden vectors."""
+import numpy as np
+import pytest
+
+from oracle import pyoracle
+from tools import gabgen
+from tests.util import GOLDEN, read_scores
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from genarchbench_amd.bpm import BpmEngine
+    e = BpmEngine()
+    yield e
+    e.close()
+
+
+@pytest.mark.parametrize("name", ["bpm_bench", "bpm_adv"])
+def test_golden(eng, name):
+    batch = gabgen.read_pairs_text(f"{GOLDEN}/{name}.in.txt").swapped_longer_first()
+    want = read_scores(f"{GOLDEN}/{name}.expected.txt")
+    np.testing.assert_array_equal(eng.benchmark_edit_bpm(batch), want)
+
+
+@pytest.mark.parametrize("seed,n,mode,plen", [(51, 200000, 0, 151), (52, 60000, 1, 256), (53, 30000, 0, 100),
+                                              (54, 3000, 1, 700), (55, 65, 1, 64), (56, 1, 0, 151)])
+def test_vs_oracle(eng, seed, n, mode, plen):
+    batch = gabgen.pairs(seed, n, mode, plen).swapped_longer_first()
+    want, steps = pyoracle.bpm(batch, want_steps=True)
+    got = eng.benchmark_edit_bpm(batch)
+    np.testing.assert_array_equal(got, want)
+    st = eng.last_stats()
+    assert st["block_steps"] >= steps          # queued pairs are stepped twice (score pass + full pass)
+
+
+def test_edge_cases(eng):
+    pats = [b"A", b"ACGT", b"NNNN", b"acgt", b"A" * 64, b"A" * 65, b"ACGTN" * 30, b"N" * 130, b"ACGT" * 64, b"T" * 257]
+    txts = [b"", b"ACGT", b"NNNN", b"ACGT", b"A" * 64, b"A" * 64, b"ACGTN" * 29, b"A" * 129, b"ACGT" * 63 + b"ACG", b"T" * 200]
+    b = gabgen.pairs_from_lists(pats, txts)
+    np.testing.assert_array_equal(eng.benchmark_edit_bpm(b), pyoracle.bpm(b))
+
+
+def test_long_patterns_generic_path(eng):
+    """W > 4 words: the generic history kernel; includes the reference maximum of 255 words"""
+    rng = np.random.default_rng(9)
+    pats, txts = [], []
+    for n in (257, 300, 1000, 5000, 16320):
+        p = rng.choice(np.frombuffer(b"ACGTN", np.uint8), n, p=[.24, .24, .24, .24, .04]).tobytes()
+        t = bytearray(p[: n - int(rng.integers(0, 40))])
+        for k in rng.integers(0, len(t), max(1, len(t) // 50)):
+            t[k] = b"ACGT"[int(rng.integers(0, 4))]
+        pats.append(p); txts.append(bytes(t))
+    b = gabgen.pairs_from_lists(pats, txts)
+    np.testing.assert_array_equal(eng.benchmark_edit_bpm(b), pyoracle.bpm(b))
+
+
+def test_rejects_text_longer_than_pattern(eng):
+    from genarchbench_amd._lib import GabError
+    b = gabgen.pairs_from_lists([b"ACG"], [b"ACGTACGT"])
+    with pytest.raises(GabError):
+        eng.benchmark_edit_bpm(b)
+
+
+def test_device_resident(eng):
+    import torch
+    batch = gabgen.pairs(57, 50000, 0, 151).swapped_longer_first()
+    dev = torch.device("cuda:0")
+    t = lambda a: torch.from_numpy(a).to(dev)
+    sc = torch.zeros(batch.n, dtype=torch.int32, device=dev)
+    eng.run_device(t(batch.pat), t(batch.pat_off), t(batch.pat_len), t(batch.txt), t(batch.txt_off), t(batch.txt_len),
+                   sc, stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(sc.cpu().numpy(), pyoracle.bpm(batch))

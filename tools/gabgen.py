@@ -176,3 +176,71 @@ def read_chain_text(path):
         p += 1
         calls.append((aq, mdx, mdy, bw, ns, xy[:, 0].copy(), xy[:, 1].copy()))
     return chain_from_calls(calls)
+
+
+# ------------------------------------------------------------------ bpm / wfa
+@dataclass
+class PairBatch:
+    """'>' pattern / '<' text pairs, ASCII, back to back"""
+    pat: np.ndarray
+    pat_off: np.ndarray
+    pat_len: np.ndarray
+    txt: np.ndarray
+    txt_off: np.ndarray
+    txt_len: np.ndarray
+
+    @property
+    def n(self):
+        return len(self.pat_len)
+
+    def pair(self, i):
+        p = self.pat[self.pat_off[i]:self.pat_off[i] + self.pat_len[i]].tobytes()
+        t = self.txt[self.txt_off[i]:self.txt_off[i] + self.txt_len[i]].tobytes()
+        return p, t
+
+    def swapped_longer_first(self):
+        """the bpm driver's swap (bpm/tools/align_benchmark.c:177-181): the longer LINE becomes the pattern"""
+        swap = self.pat_len < self.txt_len
+        if not swap.any():
+            return self
+        pats, txts = [], []
+        for i in range(self.n):
+            p, t = self.pair(i)
+            if swap[i]:
+                p, t = t, p
+            pats.append(p); txts.append(t)
+        return pairs_from_lists(pats, txts)
+
+    def write_text(self, path):
+        with open(path, "wb") as f:
+            for i in range(self.n):
+                p, t = self.pair(i)
+                f.write(b">" + p + b"\n<" + t + b"\n")
+
+
+def pairs(seed, n, mode=0, plen=151, first=0):
+    L = lib()
+    pl = np.empty(n, np.int32); tl = np.empty(n, np.int32)
+    L.gab_gen_pairs_lens(C.c_uint64(seed), C.c_int(mode), C.c_int(plen), C.c_int64(first), C.c_int64(n), _p(pl), _p(tl))
+    po, pt = _offsets(pl); to, tt = _offsets(tl)
+    pat = np.zeros(pt + 16, np.uint8); txt = np.zeros(tt + 16, np.uint8)
+    L.gab_gen_pairs_fill(C.c_uint64(seed), C.c_int(mode), C.c_int(plen), C.c_int64(first), C.c_int64(n),
+                         _p(pat), _p(po), _p(txt), _p(to))
+    return PairBatch(pat, po, pl, txt, to, tl)
+
+
+def pairs_from_lists(pats, txts):
+    pl = np.array([len(p) for p in pats], np.int32); tl = np.array([len(t) for t in txts], np.int32)
+    po, pt = _offsets(pl); to, tt = _offsets(tl)
+    pat = np.zeros(pt + 16, np.uint8); txt = np.zeros(tt + 16, np.uint8)
+    for i, (p, t) in enumerate(zip(pats, txts)):
+        pat[po[i]:po[i] + len(p)] = np.frombuffer(p, np.uint8)
+        txt[to[i]:to[i] + len(t)] = np.frombuffer(t, np.uint8)
+    return PairBatch(pat, po, pl, txt, to, tl)
+
+
+def read_pairs_text(path):
+    lines = open(path, "rb").read().split(b"\n")
+    pats = [l[1:] for l in lines[0::2] if l]
+    txts = [l[1:] for l in lines[1::2] if l]
+    return pairs_from_lists(pats, txts)
