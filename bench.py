@@ -253,7 +253,96 @@ class FastChainWorkload(ChainWorkload):
     kernel = "chain_kernel<true>"
 
 
-WORKLOADS = {"bsw": BswWorkload, "chain": ChainWorkload, "fast-chain": FastChainWorkload}
+# ------------------------------------------------------------------------------------- bpm
+class BpmWorkload:
+    name = "bpm"
+    metric = "bpm ROI M alignments/sec"
+    unit = "M alignments/s"
+    dtype = "u64"
+    default_items = 10_000_000
+    seed = 3
+    plen = 151
+
+    def __init__(self, items, rank, dev):
+        import torch
+        from tools import gabgen
+        from genarchbench_amd.bpm import BpmEngine
+        self.items = items
+        t0 = time.time()
+        raw = gabgen.pairs(self.seed, items, 0, self.plen, first=rank * items)
+        self.batch = b = raw.swapped_combined()      # the driver's longer-is-pattern swap
+        log(f"[rank {rank}] generated {items} bpm pairs in {time.time() - t0:.1f}s")
+        t = lambda a: torch.from_numpy(a).to(dev)
+        slab = t(b.pat)
+        self.d = [slab, t(b.pat_off), t(b.pat_len), slab, t(b.txt_off), t(b.txt_len)]
+        self.score = torch.empty(items, dtype=torch.int32, device=dev)
+        self.eng = BpmEngine(device=dev.index or 0)
+        self.alg_bytes = int(b.pat_len.astype(np.int64).sum() + b.txt_len.astype(np.int64).sum() + 4 * items)
+        self.kernel_ms, self.total_ms = [], []
+        self.stats = {}
+
+    def step(self, stream):
+        d = self.d
+        self.eng.run_device(d[0], d[1], d[2], d[3], d[4], d[5], self.score, stream=stream)
+
+    def after_step(self, timed):
+        st = self.eng.last_stats()
+        if timed:
+            self.kernel_ms.append(st["kernel_ms"]); self.total_ms.append(st["total_ms"])
+        self.stats = st
+
+    def check(self):
+        from oracle import pyoracle
+        from tools import gabgen
+        got = self.score.cpu().numpy()
+        b = self.batch
+        assert (got <= 0).all() and (got >= -b.pat_len).all(), "score outside [-plen, 0]"
+        assert (-got >= b.pat_len - b.txt_len).all(), "distance below the length difference"
+        n = min(50000, self.items)
+        sub = gabgen.PairBatch(b.pat, b.pat_off[:n], b.pat_len[:n], b.txt, b.txt_off[:n], b.txt_len[:n])
+        assert np.array_equal(got[:n], pyoracle.bpm(sub)), "bpm HIP output differs from the oracle"
+        return f"bit-exact vs oracle on first {n} pairs; bounds hold on all {self.items}"
+
+    def extra(self, ms_per_step):
+        return {"block_steps_per_step": self.stats.get("block_steps"), "full_path_pairs": self.stats.get("full_pairs"),
+                "g_block_steps_per_s": round(self.stats.get("block_steps", 0) / (ms_per_step * 1e6), 2),
+                "dominant_kernel": "bpm_score<3>", "dominant_kernel_ms": float(np.mean(self.kernel_ms)),
+                "device_total_ms": float(np.mean(self.total_ms))}
+
+    def roofline(self):
+        k = float(np.mean(self.kernel_ms))
+        ach = self.alg_bytes / (k * 1e-3) / 1e9
+        return {"bound": "hbm", "achieved": round(ach, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(ach / HBM_PEAK_GBS, 6), "traffic": None,
+                "note": "score kernel: plen+tlen+4 B per pair vs ~16k integer VALU per pair (VALU bound)"}
+
+    def cpu_baseline(self, cores):
+        from oracle import pyoracle
+        from tools import gabgen
+        exe = pyoracle.ref_path("bpm_ref")
+        n = min(self.items, 2_000_000)
+        if exe:
+            with tempfile.TemporaryDirectory() as td:
+                p = os.path.join(td, "bpm.txt")
+                gabgen.write_text("bpm", p, self.seed, n, 0, self.plen)
+                env = dict(os.environ, OMP_PROC_BIND="true", OMP_PLACES="cores")
+                r = subprocess.run([exe, "-a", "bpm-edit", "-i", p, "-t", str(cores)], capture_output=True, text=True, env=env)
+                m = re.search(r"Time.Benchmark\s+([\d.]+) (ms|s|us)", r.stderr)
+                if r.returncode == 0 and m:
+                    sec = float(m.group(1)) * {"s": 1.0, "ms": 1e-3, "us": 1e-6}[m.group(2)]
+                    return {"value": round(n / sec / 1e6, 4), "unit": self.unit, "cores": cores, "kind": "reference",
+                            "sample": f"first {n} pairs of the same seeded input, reference align_benchmark -a bpm-edit "
+                                      f"-t {cores}, its own Time.Benchmark ({sec:.2f} s)"}
+                log("reference binary failed, using the oracle port:", r.stderr[-200:])
+        b = self.batch
+        n = min(self.items, 1_000_000)
+        sub = gabgen.PairBatch(b.pat, b.pat_off[:n], b.pat_len[:n], b.txt, b.txt_off[:n], b.txt_len[:n])
+        t0 = time.time(); pyoracle.bpm(sub, threads=cores); sec = time.time() - t0
+        return {"value": round(n / sec / 1e6, 4), "unit": self.unit, "cores": cores, "kind": "port",
+                "sample": f"first {n} pairs, oracle/bpm.c + OpenMP ({sec:.2f} s)"}
+
+
+WORKLOADS = {"bpm": BpmWorkload, "bsw": BswWorkload, "chain": ChainWorkload, "fast-chain": FastChainWorkload}
 
 
 def main():

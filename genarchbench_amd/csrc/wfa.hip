@@ -1,0 +1,523 @@
+// wfa -- gap-affine wavefront alignment (WFA v1, complete mode) with CIGAR backtrace, on gfx950.
+//
+// Semantics: affine_wavefronts_align,
+//   /root/reference/benchmarks/wfa/gap_affine/affine_wavefront_align.c:325-361 = loop over scores of
+//   extend (affine_wavefront_extend.c:241-252) / end test (affine_wavefront_utils.c:83-102) /
+//   next wavefront (affine_wavefront_align.c:41-321), then affine_wavefronts_backtrace
+//   (affine_wavefront_backtrace.c:276-387).  Missing sources read as offset -10
+//   (affine_wavefront.h:48); the strings behave as if padded with 'X' / 'Y'
+//   (wfa/utils/string_padded.c:88-117).  Output = the un-run-length-encoded CIGAR operations the
+//   driver prints (wfa/tools/align_benchmark.c:417-437, 499-504).
+//
+// Mapping: one wavefront (64 lanes) per pair, lanes = diagonals k.  The whole O(s^2) wavefront
+// history of the pair -- needed by the backtrace -- lives in LDS as int16 offsets behind a small
+// per-score directory, together with the two sequences (padded with 'X'/'Y' exactly like the
+// reference, so the extension loop needs no length checks).  Extension compares four bases per
+// step (two aligned ds_read_b32 + v_alignbyte per string, xor, ctz).  The backtrace runs
+// wave-uniformly on the LDS history; match runs are written cooperatively.  A pair whose history
+// does not fit the LDS pool (score above ~90 in the first pass) is queued and re-run with a bigger
+// LDS pool, and finally by the same code with int32 offsets in a global scratch.
+//
+// Roofline: plen + tlen + |cigar| + 4 bytes of HBM traffic per pair; the work is latency-bound
+// LDS traffic (sum over scores of the wavefront width + the extended matches).
+#include "gab_internal.h"
+#include <algorithm>
+#include <new>
+#include <vector>
+#include <string.h>
+
+namespace {
+
+constexpr int kNull = -10;                 // AFFINE_WAVEFRONT_OFFSET_NULL
+constexpr int kNone = 0x7fffffff;          // "no wavefront" marker in the directory
+constexpr int kSeqPad = 16;                // physical 'X'/'Y' padding behind each LDS sequence
+constexpr int kLdsMaxLen = 2040;           // longest sequence the LDS kernels accept
+
+struct WfaPen { int32_t x, o, e; };
+
+struct WfaIO {
+    const char *pat; const int64_t *pat_off; const int32_t *pat_len;
+    const char *txt; const int64_t *txt_off; const int32_t *txt_len;
+    int64_t pat_bytes, txt_bytes, n;
+    char *ops; const int64_t *ops_off; int32_t *ops_len; int32_t *score;
+};
+
+struct WfaCounters {
+    int32_t bad, first_bad;
+    int32_t max_plen, max_tlen;       // over the pairs eligible for the LDS kernels
+    uint32_t n_lds, n_big;            // eligible pairs / pairs too long for LDS
+    uint32_t n_over;                  // pairs queued by the current pass
+    uint32_t pad;
+    unsigned long long work;          // wavefront cells computed + bases extended
+};
+
+// Per-score directory entry.  lo/hi as in affine_wavefront_t; bases index the offset pool.
+struct WfDir { int lo, hi, m, i, d; };
+
+template <typename OffT>
+struct WfStore {
+    OffT *pool;           // offsets
+    int *dir;             // 5 ints per score: lo, hi, baseM, baseI, baseD
+    int pool_cap, dir_cap, used;
+    __device__ __forceinline__ WfDir get(int s) const {
+        WfDir w;
+        if (s < 0) { w.lo = 1; w.hi = -1; w.m = w.i = w.d = kNone; return w; }
+        const int *p = dir + 5 * s;
+        w.lo = p[0]; w.hi = p[1]; w.m = p[2]; w.i = p[3]; w.d = p[4];
+        return w;
+    }
+    __device__ __forceinline__ int at(int base, int lo, int hi, int k) const {
+        return (base != kNone && lo <= k && k <= hi) ? (int)pool[base + (k - lo)] : kNull;
+    }
+};
+
+__device__ __forceinline__ uint32_t lds_ld4(const uint8_t *base, int byte_off) {
+    const uint32_t *w = reinterpret_cast<const uint32_t *>(base + (byte_off & ~3));
+    return __builtin_amdgcn_alignbyte(w[1], w[0], (uint32_t)(byte_off & 3));
+}
+__device__ __forceinline__ uint32_t glb_ld4(const char *p) { uint32_t w; __builtin_memcpy(&w, p, 4); return w; }
+
+// One pair, one wave.  LDSSEQ: P/T are LDS copies padded with kSeqPad bytes of 'X'/'Y';
+// otherwise they are the global sequences (readable to a multiple of 4 bytes past the end).
+// Returns false if the history did not fit (nothing has been written to the outputs then).
+template <typename OffT, bool LDSSEQ>
+__device__ bool wfa_pair(WfStore<OffT> &st, const WfaPen pen, const uint8_t *P, int plen, const uint8_t *T, int tlen,
+                         char *ops, int32_t *ops_len_out, int32_t *score_out, unsigned long long &work) {
+    const int lane = threadIdx.x;
+    const int x = pen.x, oe = pen.o + pen.e, e = pen.e;
+    const int ak = tlen - plen;
+    auto pch = [&](int v) -> int { return (v >= 0 && v < plen) ? (int)P[v] : (int)'X'; };
+    auto tch = [&](int h) -> int { return (h >= 0 && h < tlen) ? (int)T[h] : (int)'Y'; };
+
+    // score 0: M = {k = 0 -> offset 0}
+    st.used = 0;
+    if (st.dir_cap < 1 || st.pool_cap < 1) return false;
+    if (lane == 0) { st.dir[0] = 0; st.dir[1] = 0; st.dir[2] = 0; st.dir[3] = kNone; st.dir[4] = kNone; st.pool[0] = (OffT)0; }
+    st.used = 1;
+    __syncthreads();
+    int score = 0;
+    for (;;) {
+        WfDir cur = st.get(score);
+        if (cur.m != kNone) {
+            // ---- extend every diagonal of M[score]
+            for (int k = cur.lo + lane; k <= cur.hi; k += 64) {
+                int o = (int)st.pool[cur.m + (k - cur.lo)];
+                int v = o - k, h = o;
+                for (;;) {
+                    if (v >= 0 && v <= plen && h >= 0 && h <= tlen) {
+                        uint32_t a, b;
+                        if (LDSSEQ) { a = lds_ld4(P, v); b = lds_ld4(T, h); }
+                        else {
+                            // global strings have no physical padding: build the padded view
+                            if (v + 4 <= plen && h + 4 <= tlen) { a = glb_ld4((const char *)P + v); b = glb_ld4((const char *)T + h); }
+                            else {
+                                a = (uint32_t)pch(v) | (uint32_t)pch(v + 1) << 8 | (uint32_t)pch(v + 2) << 16 | (uint32_t)pch(v + 3) << 24;
+                                b = (uint32_t)tch(h) | (uint32_t)tch(h + 1) << 8 | (uint32_t)tch(h + 2) << 16 | (uint32_t)tch(h + 3) << 24;
+                            }
+                        }
+                        const uint32_t d = a ^ b;
+                        if (d == 0) { o += 4; v += 4; h += 4; work += 4; continue; }
+                        const int c = __builtin_ctz(d) >> 3;
+                        o += c; work += c;
+                        break;
+                    }
+                    if (pch(v) == tch(h)) { o++; v++; h++; work++; continue; }
+                    break;
+                }
+                st.pool[cur.m + (k - cur.lo)] = (OffT)o;
+            }
+            __syncthreads();
+            // ---- end reached?
+            if (cur.lo <= ak && ak <= cur.hi && (int)st.pool[cur.m + (ak - cur.lo)] >= tlen) break;
+        }
+        // ---- next wavefront
+        score++;
+        if (score >= st.dir_cap) return false;
+        const WfDir ms = st.get(score - x), mg = st.get(score - oe), ie = st.get(score - e);
+        const int de_base = ie.d, ie_base = ie.i;              // I and D of score-e share lo/hi
+        const bool n_ms = ms.m == kNone, n_mg = mg.m == kNone, n_ie = ie_base == kNone, n_de = de_base == kNone;
+        int *dd = st.dir + 5 * score;
+        if (n_ms && n_mg && n_ie && n_de) {
+            if (lane == 0) { dd[0] = 1; dd[1] = -1; dd[2] = kNone; dd[3] = kNone; dd[4] = kNone; }
+            __syncthreads();
+            continue;
+        }
+        // a null source counts as lo = 1, hi = -1 (affine_wavefront.c:44-50)
+        const int lo = min(min(n_ms ? 1 : ms.lo, n_mg ? 1 : mg.lo), min(n_ie ? 1 : ie.lo, n_de ? 1 : ie.lo)) - 1;
+        const int hi = max(max(n_ms ? -1 : ms.hi, n_mg ? -1 : mg.hi), max(n_ie ? -1 : ie.hi, n_de ? -1 : ie.hi)) + 1;
+        const int width = hi - lo + 1;
+        const bool has_i = !n_mg || !n_ie, has_d = !n_mg || !n_de;
+        const int need = width * (1 + (has_i ? 1 : 0) + (has_d ? 1 : 0));
+        if (st.used + need > st.pool_cap) return false;
+        const int bM = st.used, bI = has_i ? bM + width : kNone, bD = has_d ? bM + width * (has_i ? 2 : 1) : kNone;
+        st.used += need;
+        if (lane == 0) { dd[0] = lo; dd[1] = hi; dd[2] = bM; dd[3] = bI; dd[4] = bD; }
+        for (int k = lo + lane; k <= hi; k += 64) {
+            int best = (!n_ms && ms.lo <= k && k <= ms.hi) ? (int)st.pool[ms.m + (k - ms.lo)] + 1 : kNull;
+            if (has_i) {
+                const int ins = max(st.at(mg.m, mg.lo, mg.hi, k - 1), st.at(ie_base, ie.lo, ie.hi, k - 1)) + 1;
+                st.pool[bI + (k - lo)] = (OffT)ins;
+                best = max(best, ins);
+            }
+            if (has_d) {
+                const int del = max(st.at(mg.m, mg.lo, mg.hi, k + 1), st.at(de_base, ie.lo, ie.hi, k + 1));
+                st.pool[bD + (k - lo)] = (OffT)del;
+                best = max(best, del);
+            }
+            st.pool[bM + (k - lo)] = (OffT)best;
+        }
+        work += (lane == 0) ? (unsigned)width : 0u;
+        __syncthreads();
+    }
+
+    // ---- backtrace (wave-uniform): ops written right-aligned into [0, cap), then shifted left
+    const int cap = plen + tlen;
+    int pos = cap - 1;
+    int s = score, k = ak;
+    {
+        const WfDir w = st.get(s);
+        int offset = (int)st.pool[w.m + (k - w.lo)];
+        int type = 0;                                           // 0 = M, 1 = I, 2 = D
+        auto valid_loc = [&](int kk, int oo) { return oo - kk > 0 && oo - kk <= plen && oo > 0 && oo <= tlen; };
+        bool valid = valid_loc(k, offset);
+        int v = offset - k, h = offset;
+        auto put = [&](char c) { if (lane == 0) ops[pos] = c; pos--; };
+        auto put_run = [&](char c, int cnt) {
+            for (int i = lane; i < cnt; i += 64) ops[pos - i] = c;
+            pos -= cnt > 0 ? cnt : 0;
+        };
+        while (v > 0 && h > 0 && s > 0) {
+            if (!valid) {
+                valid = valid_loc(k, offset);
+                if (valid) {
+                    if (k < ak) put_run('I', ak - k);
+                    else if (k > ak) put_run('D', k - ak);
+                }
+            }
+            const int s_go = s - oe, s_ge = s - e, s_mm = s - x;
+            const WfDir wgo = st.get(s_go), wge = st.get(s_ge), wmm = st.get(s_mm);
+            const int del_ext = type == 1 ? kNull : st.at(wge.d, wge.lo, wge.hi, k + 1);
+            const int del_open = type == 1 ? kNull : st.at(wgo.m, wgo.lo, wgo.hi, k + 1);
+            const int ie_raw = st.at(wge.i, wge.lo, wge.hi, k - 1), io_raw = st.at(wgo.m, wgo.lo, wgo.hi, k - 1);
+            const bool ie_ok = wge.i != kNone && wge.lo <= k - 1 && k - 1 <= wge.hi;
+            const bool io_ok = wgo.m != kNone && wgo.lo <= k - 1 && k - 1 <= wgo.hi;
+            const bool mm_ok = wmm.m != kNone && wmm.lo <= k && k <= wmm.hi;
+            const int ins_ext = (type == 2 || !ie_ok) ? kNull : ie_raw + 1;
+            const int ins_open = (type == 2 || !io_ok) ? kNull : io_raw + 1;
+            const int misms = (type != 0 || !mm_ok) ? kNull : st.at(wmm.m, wmm.lo, wmm.hi, k) + 1;
+            const int max_all = max(misms, max(max(ins_ext, ins_open), max(del_ext, del_open)));
+            if (type == 0) { put_run('M', offset - max_all); offset = max_all; }
+            if (max_all == del_ext) { if (valid) put('D'); s = s_ge; k++; type = 2; }
+            else if (max_all == del_open) { if (valid) put('D'); s = s_go; k++; type = 0; }
+            else if (max_all == ins_ext) { if (valid) put('I'); s = s_ge; k--; offset--; type = 1; }
+            else if (max_all == ins_open) { if (valid) put('I'); s = s_go; k--; offset--; type = 0; }
+            else { if (valid) put('X'); s = s_mm; offset--; }
+            v = offset - k; h = offset;
+        }
+        if (s == 0) put_run('M', offset);
+        else { put_run('D', v); put_run('I', h); }
+    }
+    pos++;
+    const int nops = cap - pos;
+    __syncthreads();
+    // shift left by `pos` bytes, 64 bytes per step (sources of a step are read before its stores)
+    if (pos > 0) {
+        for (int c0 = 0; c0 < nops; c0 += 64) {
+            const int i = c0 + lane;
+            char c = 0;
+            if (i < nops) c = ops[pos + i];
+            __syncthreads();
+            if (i < nops) ops[i] = c;
+            __syncthreads();
+        }
+    }
+    if (lane == 0) { *ops_len_out = nops; *score_out = score; }
+    return true;
+}
+
+// ---- pass 0: validate, classify ------------------------------------------------------------
+__global__ __launch_bounds__(256) void wfa_classify(WfaIO io, WfaCounters *ct, uint32_t *list_lds, uint32_t *list_big) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    int mp = 0, mt = 0;
+    for (; i < io.n; i += stride) {
+        const int pl = io.pat_len[i], tl = io.txt_len[i];
+        const int64_t po = io.pat_off[i], to = io.txt_off[i];
+        const bool ok = pl >= 0 && tl >= 0 && pl <= GAB_WFA_MAX_LEN && tl <= GAB_WFA_MAX_LEN && po >= 0 && to >= 0 &&
+                        io.ops_off[i] >= 0 && ((po + pl + 3) & ~3ll) <= io.pat_bytes && ((to + tl + 3) & ~3ll) <= io.txt_bytes;
+        if (!ok) {
+            atomicAdd(&ct->bad, 1);
+            atomicMin((unsigned int *)&ct->first_bad, (unsigned int)(i + 1 > 0x7fffffff ? 0x7fffffff : i + 1));
+            continue;
+        }
+        if (pl <= kLdsMaxLen && tl <= kLdsMaxLen) {
+            list_lds[atomicAdd(&ct->n_lds, 1u)] = (uint32_t)i;
+            mp = max(mp, pl); mt = max(mt, tl);
+        } else list_big[atomicAdd(&ct->n_big, 1u)] = (uint32_t)i;
+    }
+    for (int o = 32; o > 0; o >>= 1) { mp = max(mp, __shfl_xor(mp, o)); mt = max(mt, __shfl_xor(mt, o)); }
+    if ((threadIdx.x & 63) == 0) { atomicMax(&ct->max_plen, mp); atomicMax(&ct->max_tlen, mt); }
+}
+
+// ---- LDS kernel: one wave per pair ---------------------------------------------------------------
+// dynamic LDS: [dir: 5*dir_cap ints][P: seqp bytes][T: seqt bytes][pool: pool_cap int16]
+__global__ __launch_bounds__(64) void wfa_lds(WfaIO io, WfaPen pen, const uint32_t *__restrict__ list, uint32_t count,
+                                              int dir_cap, int seqp, int seqt, int pool_cap, uint32_t *over_list,
+                                              WfaCounters *ct) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const uint32_t b = blockIdx.x;
+    if (b >= count) return;
+    const uint32_t id = list[b];
+    const int lane = threadIdx.x;
+    int *dir = reinterpret_cast<int *>(smem);
+    uint8_t *P = smem + (size_t)dir_cap * 20;
+    uint8_t *T = P + seqp;
+    int16_t *pool = reinterpret_cast<int16_t *>(T + seqt);
+    const int plen = io.pat_len[id], tlen = io.txt_len[id];
+    const char *gp = io.pat + io.pat_off[id], *gt = io.txt + io.txt_off[id];
+    for (int i = lane; i < plen + kSeqPad; i += 64) P[i] = i < plen ? (uint8_t)gp[i] : (uint8_t)'X';
+    for (int i = lane; i < tlen + kSeqPad; i += 64) T[i] = i < tlen ? (uint8_t)gt[i] : (uint8_t)'Y';
+    __syncthreads();
+    WfStore<int16_t> st;
+    st.pool = pool; st.dir = dir; st.pool_cap = pool_cap; st.dir_cap = dir_cap; st.used = 0;
+    unsigned long long work = 0;
+    const bool ok = wfa_pair<int16_t, true>(st, pen, P, plen, T, tlen, io.ops + io.ops_off[id], io.ops_len + id,
+                                            io.score + id, work);
+    if (!ok && lane == 0) over_list[atomicAdd(&ct->n_over, 1u)] = id;
+    for (int o = 32; o > 0; o >>= 1) work += __shfl_xor(work, o);
+    if (lane == 0 && ok) atomicAdd(&ct->work, work);
+}
+
+// ---- global kernel: int32 history in a scratch slab, any length ------------------------------
+__global__ __launch_bounds__(64) void wfa_global(WfaIO io, WfaPen pen, const uint32_t *__restrict__ list, uint32_t count,
+                                                 int32_t *scratch, int64_t per_block, int dir_cap, int pool_cap,
+                                                 uint32_t *over_list, WfaCounters *ct) {
+    const int lane = threadIdx.x;
+    int32_t *mine = scratch + (int64_t)blockIdx.x * per_block;
+    for (uint32_t b = blockIdx.x; b < count; b += gridDim.x) {
+        const uint32_t id = list[b];
+        const int plen = io.pat_len[id], tlen = io.txt_len[id];
+        WfStore<int32_t> st;
+        st.dir = mine; st.pool = mine + (int64_t)dir_cap * 5; st.pool_cap = pool_cap; st.dir_cap = dir_cap; st.used = 0;
+        unsigned long long work = 0;
+        const bool ok = wfa_pair<int32_t, false>(st, pen, (const uint8_t *)(io.pat + io.pat_off[id]), plen,
+                                                 (const uint8_t *)(io.txt + io.txt_off[id]), tlen,
+                                                 io.ops + io.ops_off[id], io.ops_len + id, io.score + id, work);
+        if (!ok && lane == 0) over_list[atomicAdd(&ct->n_over, 1u)] = id;
+        for (int o = 32; o > 0; o >>= 1) work += __shfl_xor(work, o);
+        if (lane == 0 && ok) atomicAdd(&ct->work, work);
+        __syncthreads();
+    }
+}
+
+}  // namespace
+
+// =============================================================================== host side
+struct gab_wfa {
+    int device = 0;
+    WfaPen pen;
+    gab_devbuf ws;          // counters | 3 id lists
+    gab_devbuf scratch;     // global-kernel history
+    gab_devbuf io;          // staging for the host-pointer entry point
+    size_t scratch_budget = (size_t)8 << 30;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    WfaCounters *h_ct = nullptr;
+    bool have_stats = false;
+    int64_t last_requeued = 0;
+};
+
+extern "C" int gab_wfa_create(const gab_wfa_penalties *p, int device, gab_wfa **out) {
+    if (!p || !out) { gab_set_error("gab_wfa_create: NULL argument"); return GAB_EINVAL; }
+    *out = nullptr;
+    GAB_CHECK(p->mismatch > 0 && p->gap_opening > 0 && p->gap_extension > 0 && p->mismatch < 4096 &&
+              p->gap_opening < 4096 && p->gap_extension < 4096,
+              "gab_wfa_create: penalties must be strictly positive (X=%d,O=%d,E=%d), as affine_penalties_mzero demands",
+              p->mismatch, p->gap_opening, p->gap_extension);
+    int rc = gab_check_device(device);
+    if (rc) return rc;
+    gab_device_guard g(device);
+    gab_wfa *h = new (std::nothrow) gab_wfa();
+    if (!h) { gab_set_error("out of host memory"); return GAB_ENOMEM; }
+    h->device = device;
+    h->pen.x = p->mismatch; h->pen.o = p->gap_opening; h->pen.e = p->gap_extension;
+    for (int k = 0; k < 4; k++)
+        if (hipEventCreate(&h->ev[k]) != hipSuccess) { gab_set_error("hipEventCreate failed"); delete h; return GAB_EDEVICE; }
+    if (hipHostMalloc((void **)&h->h_ct, sizeof(WfaCounters)) != hipSuccess ||
+        hipFuncSetAttribute((const void *)wfa_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+        gab_set_error("gab_wfa_create: pinned allocation / LDS attribute failed"); delete h; return GAB_EDEVICE;
+    }
+    *out = h;
+    return GAB_OK;
+}
+
+extern "C" void gab_wfa_destroy(gab_wfa *h) {
+    if (!h) return;
+    gab_device_guard g(h->device);
+    h->ws.release(); h->scratch.release(); h->io.release();
+    for (int k = 0; k < 4; k++) if (h->ev[k]) (void)hipEventDestroy(h->ev[k]);
+    if (h->h_ct) (void)hipHostFree(h->h_ct);
+    delete h;
+}
+
+extern "C" int gab_wfa_run_device(gab_wfa *h, const char *pat, int64_t pat_bytes, const int64_t *pat_off,
+                                  const int32_t *pat_len, const char *txt, int64_t txt_bytes, const int64_t *txt_off,
+                                  const int32_t *txt_len, int64_t n, char *ops_out, const int64_t *ops_off,
+                                  int32_t *ops_len_out, int32_t *score_out, void *stream_) {
+    GAB_CHECK(h, "gab_wfa_run_device: NULL handle");
+    GAB_CHECK(n >= 0 && n < (1ll << 31), "gab_wfa_run_device: n=%lld out of range", (long long)n);
+    h->have_stats = false;
+    if (n == 0) return GAB_OK;
+    GAB_CHECK(pat && pat_off && pat_len && txt && txt_off && txt_len && ops_out && ops_off && ops_len_out && score_out,
+              "gab_wfa_run_device: NULL buffer");
+    gab_device_guard g(h->device);
+    hipStream_t s = (hipStream_t)stream_;
+    const size_t o_l0 = 256, o_l1 = o_l0 + 4 * (size_t)n, o_l2 = o_l1 + 4 * (size_t)n;
+    int rc = h->ws.reserve(o_l2 + 4 * (size_t)n);
+    if (rc) return rc;
+    char *base = h->ws.as<char>();
+    WfaCounters *d_ct = (WfaCounters *)base;
+    uint32_t *l_a = (uint32_t *)(base + o_l0), *l_b = (uint32_t *)(base + o_l1), *l_big = (uint32_t *)(base + o_l2);
+    WfaIO io{pat, pat_off, pat_len, txt, txt_off, txt_len, pat_bytes, txt_bytes, n, ops_out, ops_off, ops_len_out, score_out};
+
+    GAB_HIP(hipEventRecord(h->ev[0], s));
+    memset(h->h_ct, 0, sizeof(WfaCounters));
+    h->h_ct->first_bad = 0x7fffffff;
+    GAB_HIP(hipMemcpyAsync(d_ct, h->h_ct, sizeof(WfaCounters), hipMemcpyHostToDevice, s));
+    const int grid = (int)std::min<int64_t>(gab_ceil_div(n, 256), 4096);
+    hipLaunchKernelGGL(wfa_classify, dim3(grid), dim3(256), 0, s, io, d_ct, l_a, l_big);
+    GAB_HIP(hipMemcpyAsync(h->h_ct, d_ct, sizeof(WfaCounters), hipMemcpyDeviceToHost, s));
+    GAB_HIP(hipStreamSynchronize(s));
+    if (h->h_ct->bad) {
+        gab_set_error("gab_wfa_run_device: %d pair(s) violate the limits (first: pair %d): need 0 <= length <= %d and "
+                      "offsets inside the slabs (readable to a multiple of 4 bytes)", h->h_ct->bad,
+                      h->h_ct->first_bad - 1, GAB_WFA_MAX_LEN);
+        return GAB_EINVAL;
+    }
+    const uint32_t n_lds = h->h_ct->n_lds, n_big = h->h_ct->n_big;
+    const int seqp = ((h->h_ct->max_plen + kSeqPad + 8) + 15) & ~15, seqt = ((h->h_ct->max_tlen + kSeqPad + 8) + 15) & ~15;
+    int64_t requeued = 0;
+
+    GAB_HIP(hipEventRecord(h->ev[1], s));
+    // pass 1 / pass 2: LDS kernels with a small, then a large, history pool
+    uint32_t *cur = l_a, *nxt = l_b;
+    uint32_t cnt = n_lds;
+    bool ev2 = false;
+    const int pool_bytes[2] = {12 * 1024, 96 * 1024};
+    const int dir_caps[2] = {128, 640};
+    for (int pass = 0; pass < 2 && cnt; pass++) {
+        const int dir_cap = dir_caps[pass];
+        const size_t fixed = (size_t)dir_cap * 20 + seqp + seqt;
+        const size_t lds = fixed + pool_bytes[pass];
+        if (lds > 160 * 1024 - 512) continue;            // sequences too long for this pool: let the next stage take them
+        h->h_ct->n_over = 0;
+        GAB_HIP(hipMemsetAsync(&d_ct->n_over, 0, 4, s));
+        hipLaunchKernelGGL(wfa_lds, dim3(cnt), dim3(64), lds, s, io, h->pen, cur, cnt, dir_cap, seqp, seqt,
+                           pool_bytes[pass] / 2, nxt, d_ct);
+        GAB_HIP(hipGetLastError());
+        if (!ev2) { GAB_HIP(hipEventRecord(h->ev[2], s)); ev2 = true; }
+        GAB_HIP(hipMemcpyAsync(h->h_ct, d_ct, sizeof(WfaCounters), hipMemcpyDeviceToHost, s));
+        GAB_HIP(hipStreamSynchronize(s));
+        cnt = h->h_ct->n_over;
+        requeued += cnt;
+        std::swap(cur, nxt);
+    }
+    if (!ev2) GAB_HIP(hipEventRecord(h->ev[2], s));
+    // pass 3+: global history; first the LDS leftovers, then the long pairs; pool grows on overflow
+    for (int which = 0; which < 2; which++) {
+        uint32_t *list = which == 0 ? cur : l_big;
+        uint32_t *spill = which == 0 ? nxt : (cur == l_a ? l_b : l_a);
+        uint32_t c = which == 0 ? cnt : n_big;
+        int64_t pool_cap = 1 << 20;                       // int32 elements per block
+        int64_t dir_cap = 4096;
+        while (c) {
+            int64_t per_block = dir_cap * 5 + pool_cap;
+            int blocks = (int)std::min<int64_t>(c, std::max<int64_t>(1, (int64_t)(h->scratch_budget / 4) / per_block));
+            blocks = std::min(blocks, 2048);
+            if ((size_t)per_block * 4 > h->scratch_budget) {
+                gab_set_error("gab_wfa_run_device: a pair needs more than %zu bytes of wavefront history", h->scratch_budget);
+                return GAB_ENOMEM;
+            }
+            rc = h->scratch.reserve((size_t)per_block * 4 * blocks);
+            if (rc) return rc;
+            GAB_HIP(hipMemsetAsync(&d_ct->n_over, 0, 4, s));
+            hipLaunchKernelGGL(wfa_global, dim3(blocks), dim3(64), 0, s, io, h->pen, list, c, h->scratch.as<int32_t>(),
+                               per_block, (int)dir_cap, (int)pool_cap, spill, d_ct);
+            GAB_HIP(hipGetLastError());
+            GAB_HIP(hipMemcpyAsync(h->h_ct, d_ct, sizeof(WfaCounters), hipMemcpyDeviceToHost, s));
+            GAB_HIP(hipStreamSynchronize(s));
+            c = h->h_ct->n_over;
+            requeued += c;
+            std::swap(list, spill);
+            pool_cap *= 8; dir_cap *= 4;
+            if (dir_cap > (1 << 22)) dir_cap = 1 << 22;
+        }
+    }
+    GAB_HIP(hipEventRecord(h->ev[3], s));
+    GAB_HIP(hipStreamSynchronize(s));
+    h->last_requeued = requeued;
+    h->have_stats = true;
+    return GAB_OK;
+}
+
+extern "C" int gab_wfa_run(gab_wfa *h, const char *pat, const int64_t *pat_off, const int32_t *pat_len, const char *txt,
+                           const int64_t *txt_off, const int32_t *txt_len, int64_t n, char *ops_out,
+                           const int64_t *ops_off, int32_t *ops_len_out, int32_t *score_out) {
+    GAB_CHECK(h, "gab_wfa_run: NULL handle");
+    GAB_CHECK(n >= 0 && n < (1ll << 31), "gab_wfa_run: n=%lld out of range", (long long)n);
+    if (n == 0) return GAB_OK;
+    GAB_CHECK(pat && pat_off && pat_len && txt && txt_off && txt_len && ops_out && ops_off && ops_len_out && score_out,
+              "gab_wfa_run: NULL buffer");
+    gab_device_guard g(h->device);
+    int64_t pb = 0, tb = 0, ob = 0;
+    for (int64_t i = 0; i < n; i++) {
+        GAB_CHECK(pat_off[i] >= 0 && txt_off[i] >= 0 && ops_off[i] >= 0 && pat_len[i] >= 0 && txt_len[i] >= 0,
+                  "gab_wfa_run: negative offset/length at pair %lld", (long long)i);
+        pb = std::max(pb, pat_off[i] + pat_len[i]); tb = std::max(tb, txt_off[i] + txt_len[i]);
+        ob = std::max(ob, ops_off[i] + pat_len[i] + txt_len[i]);
+    }
+    const size_t ppad = ((size_t)pb + 3 + 255) & ~(size_t)255, tpad = ((size_t)tb + 3 + 255) & ~(size_t)255;
+    const size_t opad = ((size_t)ob + 255) & ~(size_t)255, nn = (size_t)n;
+    size_t o = 0;
+    const size_t o_p = o; o += ppad;
+    const size_t o_t = o; o += tpad;
+    const size_t o_ops = o; o += opad;
+    const size_t o_po = o; o += 8 * nn;
+    const size_t o_to = o; o += 8 * nn;
+    const size_t o_oo = o; o += 8 * nn;
+    const size_t o_pl = o; o += 4 * nn;
+    const size_t o_tl = o; o += 4 * nn;
+    const size_t o_ol = o; o += 4 * nn;
+    const size_t o_sc = o; o += 4 * nn;
+    int rc = h->io.reserve(o);
+    if (rc) return rc;
+    char *b = h->io.as<char>();
+    hipStream_t s = nullptr;
+    GAB_HIP(hipMemcpyAsync(b + o_p, pat, (size_t)pb, hipMemcpyHostToDevice, s));
+    GAB_HIP(hipMemcpyAsync(b + o_t, txt, (size_t)tb, hipMemcpyHostToDevice, s));
+    GAB_HIP(hipMemcpyAsync(b + o_po, pat_off, 8 * nn, hipMemcpyHostToDevice, s));
+    GAB_HIP(hipMemcpyAsync(b + o_to, txt_off, 8 * nn, hipMemcpyHostToDevice, s));
+    GAB_HIP(hipMemcpyAsync(b + o_oo, ops_off, 8 * nn, hipMemcpyHostToDevice, s));
+    GAB_HIP(hipMemcpyAsync(b + o_pl, pat_len, 4 * nn, hipMemcpyHostToDevice, s));
+    GAB_HIP(hipMemcpyAsync(b + o_tl, txt_len, 4 * nn, hipMemcpyHostToDevice, s));
+    rc = gab_wfa_run_device(h, b + o_p, (int64_t)ppad, (const int64_t *)(b + o_po), (const int32_t *)(b + o_pl), b + o_t,
+                            (int64_t)tpad, (const int64_t *)(b + o_to), (const int32_t *)(b + o_tl), n, b + o_ops,
+                            (const int64_t *)(b + o_oo), (int32_t *)(b + o_ol), (int32_t *)(b + o_sc), s);
+    if (rc) return rc;
+    GAB_HIP(hipMemcpyAsync(ops_out, b + o_ops, (size_t)ob, hipMemcpyDeviceToHost, s));
+    GAB_HIP(hipMemcpyAsync(ops_len_out, b + o_ol, 4 * nn, hipMemcpyDeviceToHost, s));
+    GAB_HIP(hipMemcpyAsync(score_out, b + o_sc, 4 * nn, hipMemcpyDeviceToHost, s));
+    GAB_HIP(hipStreamSynchronize(s));
+    return GAB_OK;
+}
+
+extern "C" int gab_wfa_last_stats(gab_wfa *h, int64_t *work, int64_t *requeued, float *first_pass_ms, float *total_ms) {
+    GAB_CHECK(h, "gab_wfa_last_stats: NULL handle");
+    GAB_CHECK(h->have_stats, "gab_wfa_last_stats: no completed run on this handle");
+    gab_device_guard g(h->device);
+    GAB_HIP(hipEventSynchronize(h->ev[3]));
+    if (work) *work = (int64_t)h->h_ct->work;
+    if (requeued) *requeued = h->last_requeued;
+    if (first_pass_ms) GAB_HIP(hipEventElapsedTime(first_pass_ms, h->ev[1], h->ev[2]));
+    if (total_ms) GAB_HIP(hipEventElapsedTime(total_ms, h->ev[0], h->ev[3]));
+    return GAB_OK;
+}

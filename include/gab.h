@@ -147,6 +147,38 @@ int gab_bpm_run_device(gab_bpm *h, const char *pat, int64_t pat_bytes, const int
 int gab_bpm_last_stats(gab_bpm *h, int64_t *block_steps, int64_t *full_pairs,
                        float *score_kernel_ms, float *total_ms);
 
+/* ---- wfa: gap-affine wavefront alignment with CIGAR ---------------------------------------
+ * Replaces  affine_wavefronts_clear(wf); affine_wavefronts_align(wf, pattern, plen, text, tlen);
+ *           + the copy of wf->edit_cigar            wfa/tools/align_benchmark.c:415-437
+ *           (kernel: wfa/gap_affine/affine_wavefront_align.c:325-361 and the files it calls).
+ * One call over all pairs.  No swap: the '>' line is the pattern, the '<' line the text
+ * (align_benchmark.c:152-160).  Complete mode only (no wavefront reduction), i.e. the
+ * driver's default min_wavefront_length = -1 (align_benchmark.c:91,359-363).
+ * ops_out receives, for pair i, ops_len_out[i] operations 'M','X','I','D' starting at
+ * ops_out[ops_off[i]]; the caller provides pattern_length + text_length bytes of room per pair
+ * (edit_cigar_allocate, wfa/gap_affine/edit_cigar.c:38-47) and run-length encodes them when
+ * printing (edit_cigar_print, :184-200).  score_out[i] = the alignment penalty.
+ */
+#define GAB_WFA_MAX_LEN 100000 /* MAX_SEQUENCE_LENGTH, wfa/tools/align_benchmark.c:62 */
+typedef struct gab_wfa gab_wfa;
+typedef struct {
+    int32_t mismatch, gap_opening, gap_extension; /* defaults 4, 6, 2 (align_benchmark.c:85-90); match = 0 */
+} gab_wfa_penalties;
+int gab_wfa_create(const gab_wfa_penalties *penalties, int device, gab_wfa **out);
+void gab_wfa_destroy(gab_wfa *h);
+int gab_wfa_run(gab_wfa *h, const char *pat, const int64_t *pat_off, const int32_t *pat_len,
+                const char *txt, const int64_t *txt_off, const int32_t *txt_len, int64_t n,
+                char *ops_out, const int64_t *ops_off, int32_t *ops_len_out, int32_t *score_out);
+/* device buffers (sequence slabs readable to a multiple of 4 bytes past the last base);
+ * synchronises `stream` internally between its passes */
+int gab_wfa_run_device(gab_wfa *h, const char *pat, int64_t pat_bytes, const int64_t *pat_off,
+                       const int32_t *pat_len, const char *txt, int64_t txt_bytes,
+                       const int64_t *txt_off, const int32_t *txt_len, int64_t n, char *ops_out,
+                       const int64_t *ops_off, int32_t *ops_len_out, int32_t *score_out, void *stream);
+/* last run: wavefront cells computed + bases extended, pairs re-run with a larger history,
+ * device time of the first (LDS) pass and of the whole call (HIP events, ms) */
+int gab_wfa_last_stats(gab_wfa *h, int64_t *work, int64_t *requeued, float *first_pass_ms, float *total_ms);
+
 #ifdef __cplusplus
 }
 #endif

@@ -61,6 +61,15 @@ void oracle_bpm_batch(const char *pat, const int64_t *pat_off, const int32_t *pa
                       const char *txt, const int64_t *txt_off, const int32_t *txt_len,
                       int64_t n, int threads, int32_t *score, int64_t *block_steps);
 
+/* ---- wfa: see wfa.c.  ops = un-run-length-encoded CIGAR ('M','X','I','D'), capacity
+ * pattern_length + text_length per pair; returns the number of operations. */
+typedef struct { int32_t mismatch, gap_opening, gap_extension; } oracle_wfa_penalties;
+int oracle_wfa_one(const oracle_wfa_penalties *pen, const char *pattern, int plen, const char *text, int tlen,
+                   char *ops_out, int *score_out, int64_t *cells);
+void oracle_wfa_batch(const oracle_wfa_penalties *pen, const char *pat, const int64_t *pat_off, const int32_t *pat_len,
+                      const char *txt, const int64_t *txt_off, const int32_t *txt_len, int64_t n, int threads,
+                      char *ops, const int64_t *ops_off, int32_t *ops_len, int32_t *score, int64_t *cells);
+
 #ifdef __cplusplus
 }
 #endif

@@ -88,3 +88,41 @@ def bpm(batch, threads=0, want_steps=False):
     lib().oracle_bpm_batch(_p(batch.pat), _p(batch.pat_off), _p(batch.pat_len), _p(batch.txt), _p(batch.txt_off),
                            _p(batch.txt_len), C.c_int64(batch.n), C.c_int(threads), _p(score), C.byref(st))
     return (score, st.value) if want_steps else score
+
+
+# ------------------------------------------------------------------ wfa
+class WfaPenalties(C.Structure):
+    _fields_ = [("mismatch", C.c_int32), ("gap_opening", C.c_int32), ("gap_extension", C.c_int32)]
+
+
+def rle(ops):
+    """edit_cigar_print (wfa/gap_affine/edit_cigar.c:184-200): run-length "%d%c" text"""
+    if len(ops) == 0:
+        return ""
+    a = np.frombuffer(ops, np.uint8) if isinstance(ops, (bytes, bytearray)) else np.asarray(ops, np.uint8)
+    cut = np.flatnonzero(np.diff(a)) + 1
+    starts = np.concatenate([[0], cut]); ends = np.concatenate([cut, [len(a)]])
+    return "".join("%d%c" % (e - s, a[s]) for s, e in zip(starts, ends))
+
+
+def wfa(batch, pen=(4, 6, 2), threads=0, want_cells=False):
+    """batch: PairBatch (no swap: '>' line is the pattern).  returns (ops slab, ops_off, ops_len, score)"""
+    p = WfaPenalties(*pen)
+    cap = batch.pat_len.astype(np.int64) + batch.txt_len.astype(np.int64)
+    ops_off = np.zeros(batch.n, np.int64)
+    if batch.n > 1:
+        np.cumsum(cap[:-1], out=ops_off[1:])
+    ops = np.zeros(int(cap.sum()) + 16, np.uint8)
+    ops_len = np.zeros(batch.n, np.int32); score = np.zeros(batch.n, np.int32)
+    cells = C.c_int64(0)
+    lib().oracle_wfa_batch(C.byref(p), _p(batch.pat), _p(batch.pat_off), _p(batch.pat_len), _p(batch.txt),
+                           _p(batch.txt_off), _p(batch.txt_len), C.c_int64(batch.n), C.c_int(threads),
+                           _p(ops), _p(ops_off), _p(ops_len), _p(score), C.byref(cells))
+    r = (ops, ops_off, ops_len, score)
+    return r + (cells.value,) if want_cells else r
+
+
+def wfa_cigars(res, idx=None):
+    ops, off, ln = res[0], res[1], res[2]
+    idx = range(len(ln)) if idx is None else idx
+    return [rle(ops[off[i]:off[i] + ln[i]]) for i in idx]

@@ -94,7 +94,26 @@ def make_bpm(m):
                    "command": "bpm_ref -a bpm-edit -i <in> -o <out> -t 1|3 ; sort by id (as regression_small.sh:94 does)"}
 
 
-MAKERS = {"bsw": make_bsw, "chain": make_chain, "bpm": make_bpm}
+def make_wfa(m):
+    import re
+    for name, seed, n, mode, plen in [("wfa_bench", 401, 1500, 0, 151), ("wfa_adv", 402, 2000, 1, 240)]:
+        inp = os.path.join(HERE, name + ".in.txt")
+        gabgen.write_text("wfa", inp, seed, n, mode, plen)
+        outs = []
+        for t in ("1", "3"):
+            out = os.path.join(HERE, name + ".tmp")
+            subprocess.run([pyoracle.ref_path("wfa_ref"), "-i", inp, "-o", out, "-t", t], capture_output=True, check=True)
+            lines = sorted(open(out).read().splitlines(), key=lambda l: int(re.match(r"id=(\d+)", l).group(1)))
+            os.remove(out)
+            outs.append(lines)
+        assert outs[0] == outs[1], "wfa reference output depends on the thread count"
+        open(os.path.join(HERE, name + ".expected.txt"), "w").write("\n".join(outs[0]) + "\n")
+        m[name] = {"generator": "tools/gen gabgen wfa", "seed": seed, "n": n, "mode": mode, "plen": plen,
+                   "reference": "wfa/tools/align_benchmark.c + wfa/{gap_affine,utils}/*.c built by oracle/Makefile",
+                   "command": "wfa_ref -i <in> -o <out> -t 1|3 ; sort by id (as regression_small.sh:94 does)"}
+
+
+MAKERS = {"bsw": make_bsw, "chain": make_chain, "bpm": make_bpm, "wfa": make_wfa}
 
 if __name__ == "__main__":
     pyoracle.build(with_ref=True)

@@ -1,0 +1,97 @@
+"""GPU parity: wfa HIP kernels (through the C ABI) vs the oracle and the golden CIGARs."""
+import numpy as np
+import pytest
+
+from oracle import pyoracle
+from tools import gabgen
+from tests.util import GOLDEN, read_cigars
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from genarchbench_amd.wfa import AffineWavefronts
+    e = AffineWavefronts()
+    yield e
+    e.close()
+
+
+def same(res_gpu, res_cpu):
+    go, goff, gl, gs = res_gpu[:4]
+    co, coff, cl, cs = res_cpu[:4]
+    np.testing.assert_array_equal(gs, cs)
+    np.testing.assert_array_equal(gl, cl)
+    np.testing.assert_array_equal(goff, coff)
+    # ops slabs: compare only the bytes each pair owns
+    mask = np.zeros(len(co), bool)
+    for o, l in zip(coff, cl):
+        mask[o:o + l] = True
+    np.testing.assert_array_equal(go[:len(co)][mask], co[mask])
+
+
+@pytest.mark.parametrize("name", ["wfa_bench", "wfa_adv"])
+def test_golden(eng, name):
+    batch = gabgen.read_pairs_text(f"{GOLDEN}/{name}.in.txt")
+    want = read_cigars(f"{GOLDEN}/{name}.expected.txt")
+    assert pyoracle.wfa_cigars(eng.align(batch)) == want
+
+
+@pytest.mark.parametrize("seed,n,mode,plen", [(61, 100000, 0, 151), (62, 20000, 1, 300), (63, 20000, 0, 100),
+                                              (64, 3000, 1, 900), (65, 65, 1, 40), (66, 1, 0, 151)])
+def test_vs_oracle(eng, seed, n, mode, plen):
+    batch = gabgen.pairs(seed, n, mode, plen)
+    want = pyoracle.wfa(batch, want_cells=True)
+    got = eng.align(batch)
+    same(got, want)
+    assert eng.last_stats()["work"] == want[4]
+
+
+def test_edge_and_padding_chars(eng):
+    """empty strings, X/Y bytes that collide with the reference's padding characters, long indels"""
+    pats = [b"A", b"ACGT", b"", b"ACGT", b"AAAA", b"ACGTACGT", b"XXYY", b"ACGTXX", b"YYACGT", b"A" * 200, b"ACGT" * 50]
+    txts = [b"A", b"", b"ACGT", b"AGGT", b"AAAAAAAA", b"ACGT", b"YYXX", b"ACGTXXXXXX", b"ACGT", b"A" * 120, b"TGCA" * 50]
+    b = gabgen.pairs_from_lists(pats, txts)
+    same(eng.align(b), pyoracle.wfa(b))
+
+
+def test_long_sequences_global_path(eng):
+    """sequences beyond the LDS limit and scores beyond the LDS pools -> global-history kernel"""
+    rng = np.random.default_rng(11)
+    pats, txts = [], []
+    for n, err in ((2500, 0.01), (6000, 0.03), (1500, 0.25), (300, 0.6)):
+        p = rng.choice(np.frombuffer(b"ACGT", np.uint8), n).tobytes()
+        t = bytearray()
+        for c in p:
+            r = rng.random()
+            if r < err / 3: continue
+            if r < 2 * err / 3: t.append(b"ACGT"[int(rng.integers(0, 4))])
+            t.append(c if r > err else b"ACGT"[int(rng.integers(0, 4))])
+        pats.append(p); txts.append(bytes(t))
+    b = gabgen.pairs_from_lists(pats, txts)
+    same(eng.align(b), pyoracle.wfa(b))
+    assert eng.last_stats()["requeued"] >= 1
+
+
+def test_other_penalties():
+    from genarchbench_amd.wfa import AffineWavefronts
+    b = gabgen.pairs(67, 5000, 1, 120)
+    for pen in [(1, 1, 1), (2, 3, 1), (5, 8, 3), (3, 1, 4)]:
+        e = AffineWavefronts(*pen)
+        same(e.align(b), pyoracle.wfa(b, pen))
+        e.close()
+
+
+def test_device_resident(eng):
+    import torch
+    from genarchbench_amd.wfa import ops_layout
+    batch = gabgen.pairs(68, 30000, 0, 151)
+    dev = torch.device("cuda:0")
+    t = lambda a: torch.from_numpy(a).to(dev)
+    off, total = ops_layout(batch)
+    ops = torch.zeros(total + 16, dtype=torch.uint8, device=dev)
+    ln = torch.zeros(batch.n, dtype=torch.int32, device=dev); sc = torch.zeros_like(ln)
+    eng.run_device(t(batch.pat), t(batch.pat_off), t(batch.pat_len), t(batch.txt), t(batch.txt_off), t(batch.txt_len),
+                   ops, t(off), ln, sc, stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    same((ops.cpu().numpy(), off, ln.cpu().numpy(), sc.cpu().numpy()), pyoracle.wfa(batch))

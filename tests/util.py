@@ -48,3 +48,13 @@ def read_chain_output(path):
         if len(f) == 2:
             sc.append(int(f[0])); pa.append(int(f[1]))
     return np.array(sc, np.int32), np.array(pa, np.int32)
+
+
+def read_cigars(path):
+    """'id=N CIGAR' lines -> list indexed by id"""
+    out = {}
+    for line in open(path):
+        m = re.match(r"id=(\d+) (\S*)", line)
+        if m:
+            out[int(m.group(1))] = m.group(2)
+    return [out[i] for i in range(len(out))]

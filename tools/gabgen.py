@@ -211,6 +211,18 @@ class PairBatch:
             pats.append(p); txts.append(t)
         return pairs_from_lists(pats, txts)
 
+    def swapped_combined(self):
+        """vectorised form of the swap for big batches: ONE slab holding [patterns | texts] and
+        offset/length arrays pointing into it, roles exchanged where the text line is longer"""
+        slab = np.concatenate([self.pat, self.txt])
+        base = np.int64(len(self.pat))
+        swap = self.pat_len < self.txt_len
+        po = np.where(swap, self.txt_off + base, self.pat_off).astype(np.int64)
+        to = np.where(swap, self.pat_off, self.txt_off + base).astype(np.int64)
+        pl = np.where(swap, self.txt_len, self.pat_len).astype(np.int32)
+        tl = np.where(swap, self.pat_len, self.txt_len).astype(np.int32)
+        return PairBatch(slab, po, pl, slab, to, tl)
+
     def write_text(self, path):
         with open(path, "wb") as f:
             for i in range(self.n):
