@@ -342,7 +342,104 @@ class BpmWorkload:
                 "sample": f"first {n} pairs, oracle/bpm.c + OpenMP ({sec:.2f} s)"}
 
 
-WORKLOADS = {"bpm": BpmWorkload, "bsw": BswWorkload, "chain": ChainWorkload, "fast-chain": FastChainWorkload}
+# ------------------------------------------------------------------------------------- wfa
+class WfaWorkload:
+    name = "wfa"
+    metric = "wfa ROI M alignments/sec"
+    unit = "M alignments/s"
+    dtype = "i16"
+    default_items = 1_000_000
+    seed = 4
+    plen = 151
+
+    def __init__(self, items, rank, dev):
+        import torch
+        from tools import gabgen
+        from genarchbench_amd.wfa import AffineWavefronts, ops_layout
+        self.items = items
+        t0 = time.time()
+        self.batch = b = gabgen.pairs(self.seed, items, 0, self.plen, first=rank * items)
+        log(f"[rank {rank}] generated {items} wfa pairs in {time.time() - t0:.1f}s")
+        t = lambda a: torch.from_numpy(a).to(dev)
+        self.off, total = ops_layout(b)
+        self.d = [t(b.pat), t(b.pat_off), t(b.pat_len), t(b.txt), t(b.txt_off), t(b.txt_len)]
+        self.ops = torch.zeros(total + 16, dtype=torch.uint8, device=dev)
+        self.d_off = t(self.off)
+        self.ops_len = torch.zeros(items, dtype=torch.int32, device=dev)
+        self.score = torch.zeros(items, dtype=torch.int32, device=dev)
+        self.eng = AffineWavefronts(device=dev.index or 0)
+        self.in_bytes = int(b.pat_len.astype(np.int64).sum() + b.txt_len.astype(np.int64).sum() + 4 * items)
+        self.alg_bytes = self.in_bytes
+        self.kernel_ms, self.total_ms = [], []
+        self.stats = {}
+
+    def step(self, stream):
+        d = self.d
+        self.eng.run_device(d[0], d[1], d[2], d[3], d[4], d[5], self.ops, self.d_off, self.ops_len, self.score, stream=stream)
+
+    def after_step(self, timed):
+        st = self.eng.last_stats()
+        if timed:
+            self.kernel_ms.append(st["kernel_ms"]); self.total_ms.append(st["total_ms"])
+        self.stats = st
+
+    def check(self):
+        from oracle import pyoracle
+        from tools import gabgen
+        b = self.batch
+        ln = self.ops_len.cpu().numpy(); sc = self.score.cpu().numpy()
+        self.alg_bytes = self.in_bytes + int(ln.astype(np.int64).sum())     # + cigar bytes
+        assert (ln >= np.maximum(b.pat_len, b.txt_len)).all() and (ln <= b.pat_len + b.txt_len).all(), "cigar length out of range"
+        assert (sc >= 0).all()
+        n = min(20000, self.items)
+        sub = gabgen.PairBatch(b.pat, b.pat_off[:n], b.pat_len[:n], b.txt, b.txt_off[:n], b.txt_len[:n])
+        wo, woff, wl, ws = pyoracle.wfa(sub)
+        assert np.array_equal(sc[:n], ws) and np.array_equal(ln[:n], wl), "wfa score / cigar length differ from the oracle"
+        end = int(woff[n - 1] + b.pat_len[n - 1] + b.txt_len[n - 1])
+        go = self.ops[:end].cpu().numpy()
+        for i in range(0, n, 3):
+            assert np.array_equal(go[woff[i]:woff[i] + wl[i]], wo[woff[i]:woff[i] + wl[i]]), f"cigar {i} differs"
+        return f"bit-exact CIGARs vs oracle on {n // 3} of the first {n} pairs (+ all their scores); bounds on all {self.items}"
+
+    def extra(self, ms_per_step):
+        return {"work_units_per_step": self.stats.get("work"), "requeued_pairs": self.stats.get("requeued"),
+                "dominant_kernel": "wfa_lds", "dominant_kernel_ms": float(np.mean(self.kernel_ms)),
+                "device_total_ms": float(np.mean(self.total_ms))}
+
+    def roofline(self):
+        k = float(np.mean(self.kernel_ms))
+        ach = self.alg_bytes / (k * 1e-3) / 1e9
+        return {"bound": "hbm", "achieved": round(ach, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(ach / HBM_PEAK_GBS, 6), "traffic": None,
+                "note": "plen+tlen+cigar+4 B per pair; the kernel is LDS-latency bound (wave per pair)"}
+
+    def cpu_baseline(self, cores):
+        from oracle import pyoracle
+        from tools import gabgen
+        exe = pyoracle.ref_path("wfa_ref")
+        n = min(self.items, 1_000_000)
+        if exe:
+            with tempfile.TemporaryDirectory() as td:
+                p = os.path.join(td, "wfa.txt")
+                gabgen.write_text("wfa", p, self.seed, n, 0, self.plen)
+                env = dict(os.environ, OMP_PROC_BIND="true", OMP_PLACES="cores")
+                r = subprocess.run([exe, "-i", p, "-t", str(cores)], capture_output=True, text=True, env=env)
+                m = re.search(r"Time.Alignment:\s+([\d.]+) s", r.stdout)
+                if r.returncode == 0 and m and float(m.group(1)) > 0:
+                    sec = float(m.group(1))
+                    return {"value": round(n / sec / 1e6, 4), "unit": self.unit, "cores": cores, "kind": "reference",
+                            "sample": f"first {n} pairs of the same seeded input, reference align_benchmark -t {cores}, "
+                                      f"its own Time.Alignment ({sec:.3f} s)"}
+                log("reference binary failed, using the oracle port:", r.stderr[-200:])
+        b = self.batch
+        n = min(self.items, 300_000)
+        sub = gabgen.PairBatch(b.pat, b.pat_off[:n], b.pat_len[:n], b.txt, b.txt_off[:n], b.txt_len[:n])
+        t0 = time.time(); pyoracle.wfa(sub, threads=cores); sec = time.time() - t0
+        return {"value": round(n / sec / 1e6, 4), "unit": self.unit, "cores": cores, "kind": "port",
+                "sample": f"first {n} pairs, oracle/wfa.c + OpenMP ({sec:.2f} s)"}
+
+
+WORKLOADS = {"wfa": WfaWorkload, "bpm": BpmWorkload, "bsw": BswWorkload, "chain": ChainWorkload, "fast-chain": FastChainWorkload}
 
 
 def main():

@@ -19,8 +19,8 @@
 //                  4W+1 match masks of each lane in LDS as [mask][lane] (conflict-free b64 reads),
 //                  built with ds_or; writes -distance for clean pairs, queues the rest.
 //   bpm_full<W>    queued pairs (and every pair with W > 4, W = 0 instantiation): same recurrence,
-//                  but each column's Pv/Mv is stored to a global scratch laid out [column][block][slot]
-//                  (coalesced across lanes), followed by the reference's backtrace on that scratch.
+//                  but each column's Pv/Mv is stored to a per-pair region of a global scratch,
+//                  followed by the reference's backtrace on that region.
 //
 // Roofline: ~36 VALU per (text char x 64-row block); 306 B of input per 151-bp pair.  The score
 // path is integer-VALU bound at about 16 k VALU per pair; its HBM traffic is the algorithmic
@@ -175,8 +175,10 @@ __global__ __launch_bounds__(kBlock) void bpm_score(BpmIO io, const uint32_t *__
 // ---- full path: history + backtrace ---------------------------------------------------------------
 // slot s of this launch works on pair list[s]; element (col, b) of its history lives at
 //   hist[base + ((col * Wd + b) * 2 + {0: P, 1: M}) * estride]       (u64 units)
-// REGW > 0: W == REGW for every slot, base = s, estride = nslots (coalesced); masks in LDS.
-// REGW == 0: any W (<= 255), base = slot_base[s], estride = 1; the 4W+1 masks sit in front of the history.
+// REGW > 0: W == REGW for every slot, each slot owns a contiguous (64W+1) x W x 2 region (its 16-byte
+//           column records merge into full lines in the write-back L2, and the backtrace of a lane
+//           stays inside its own few KB instead of striding across the whole scratch); masks in LDS.
+// REGW == 0: any W (<= 255), base = slot_base[s]; the 4W+1 masks sit in front of the history.
 template <int REGW>
 __global__ __launch_bounds__(kBlock) void bpm_full(BpmIO io, const uint32_t *__restrict__ list, uint32_t nslots,
                                                    uint64_t *__restrict__ hist, const int64_t *__restrict__ slot_base,
@@ -188,13 +190,13 @@ __global__ __launch_bounds__(kBlock) void bpm_full(BpmIO io, const uint32_t *__r
     const int n = io.pat_len[id], m = io.txt_len[id];
     const char *p = io.pat + io.pat_off[id], *t = io.txt + io.txt_off[id];
     const int Wd = REGW ? REGW : (n + 63) >> 6;
-    const int64_t estride = REGW ? (int64_t)nslots : 1;
+    const int64_t estride = 1;
     uint64_t *H;                 // history origin of this slot
     uint64_t *peq;               // mask k at peq[k * pstride]
     int64_t pstride;
     bool dummy = true;
     if (REGW) {
-        H = hist + s;
+        H = hist + (int64_t)s * ((64 * REGW + 1) * REGW * 2);
         peq = peq_s + threadIdx.x; pstride = kBlock;
         bpm_build_peq<(REGW ? REGW : 1)>(peq, p, n);
     } else {

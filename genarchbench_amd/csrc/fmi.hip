@@ -1,0 +1,582 @@
+// fmi -- FM-index SMEM seeding (three passes per read) on gfx950.
+//
+// Semantics: the per-batch body of the fmi driver, /root/reference/benchmarks/fmi/fmi.cpp:288-348, on
+// BWA-MEM2's FMI_search (/root/reference/benchmarks/fmi/bwa-mem2/x86_64/src/FMI_search.cpp):
+//   pass 1  getSMEMsAllPosOneThread(min_intv = 1)                    :672-724 -> :496-670
+//   pass 2  getSMEMsOnePosOneThread at the midpoint of every pass-1 SMEM with length >=
+//           (int)(minSeedLen*1.5+.499) and s <= 10, min_intv = s + 1  fmi.cpp:300-324
+//   pass 3  bwtSeedStrategyAllPosOneThread(max_intv = 20, minSeedLen+1) :726-812
+//   sortSMEMs (rid, m ascending, n descending)                         :986-1022
+// every extension = backwardExt :1025-1052 = two CP_OCC look-ups (GET_OCC, FMI_search.h:66-73).
+// The index is the reference's own ".bwt.2bit.64" file (load_index :384-494), uploaded unchanged:
+// 64-byte CP_OCC records, one per 64 BWT rows.
+//
+// Mapping.  The reference interleaves reads in lock-step rounds inside a thread to overlap cache
+// misses; every read is nevertheless independent in all three passes.  Here one lane owns one read
+// and runs the three passes back to back; hundreds of thousands of lanes in flight hide the latency
+// of the two dependent 64-byte index reads per extension, which is what bounds the kernel: random
+// 64-B HBM transactions (a 0.5+ GB index does not fit the 256 MiB Infinity Cache).  Both records of
+// an extension are fetched with four 16-byte loads each before either is used; when both interval
+// ends fall into the same record it is fetched once.  The per-read list of forward intervals
+// (prev[]) lives in a global scratch laid out [entry][lane] (coalesced); the SMEMs of a read are
+// collected in a per-read slot, insertion-sorted by the owning lane, and compacted to the final
+// array with a three-kernel exclusive scan, so the output is already in the reference's order.
+//
+// Roofline: readlen + 40 B per SMEM of streaming traffic + 128 B per extension of random index
+// traffic (the extension count is returned by gab_fmi_last_stats).
+#include "gab_internal.h"
+#include <algorithm>
+#include <new>
+#include <vector>
+#include <stdio.h>
+#include <string.h>
+
+namespace {
+
+struct CpOcc { int64_t cp_count[4]; uint64_t bits[4]; };   // CP_OCC, FMI_search.h:54-58
+static_assert(sizeof(CpOcc) == 64, "CP_OCC must be 64 bytes");
+
+struct FmiIdx {
+    const CpOcc *cp_occ;
+    int64_t count[5];          // already +1 (FMI_search.cpp:433-436)
+    int64_t sentinel;
+    int64_t ref_seq_len;
+};
+
+struct Iv { uint32_t m, n; int64_t k, l, s; };            // SMEM without rid
+struct PrevRec { int64_t n, k, l, s; };                    // 32 bytes, [entry][lane]
+struct OutRec { uint32_t m, n; int64_t k, l, s; };         // 32 bytes, per-read slot
+
+struct FmiCounters {
+    unsigned long long ext_calls;
+    unsigned long long total;      // SMEMs found in this batch
+    int32_t max_per_read;
+    int32_t bad, first_bad, pad;
+};
+
+__device__ __forceinline__ void load_rec(const CpOcc *p, int64_t (&cnt)[4], uint64_t (&bits)[4]) {
+    const ulonglong2 *q = reinterpret_cast<const ulonglong2 *>(p);
+    const ulonglong2 a = q[0], b = q[1], c = q[2], d = q[3];
+    cnt[0] = (int64_t)a.x; cnt[1] = (int64_t)a.y; cnt[2] = (int64_t)b.x; cnt[3] = (int64_t)b.y;
+    bits[0] = c.x; bits[1] = c.y; bits[2] = d.x; bits[3] = d.y;
+}
+
+// backwardExt (FMI_search.cpp:1025-1052)
+__device__ __forceinline__ void backward_ext(const FmiIdx &ix, int64_t k, int64_t l, int64_t s, int a, int64_t &ko,
+                                             int64_t &lo, int64_t &so, unsigned long long &calls) {
+    calls++;
+    const int64_t sp = k, ep = k + s;
+    int64_t c_sp[4], c_ep[4]; uint64_t b_sp[4], b_ep[4];
+    const CpOcc *r_sp = ix.cp_occ + (sp >> 6), *r_ep = ix.cp_occ + (ep >> 6);
+    load_rec(r_sp, c_sp, b_sp);
+    if (r_sp == r_ep) {
+#pragma unroll
+        for (int b = 0; b < 4; b++) { c_ep[b] = c_sp[b]; b_ep[b] = b_sp[b]; }
+    } else load_rec(r_ep, c_ep, b_ep);
+    const int y_sp = (int)(sp & 63), y_ep = (int)(ep & 63);
+    const uint64_t m_sp = y_sp ? ~0ull << (64 - y_sp) : 0ull, m_ep = y_ep ? ~0ull << (64 - y_ep) : 0ull;
+    int64_t kk[4], ss[4];
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+        const int64_t o_sp = c_sp[b] + __popcll(b_sp[b] & m_sp);
+        const int64_t o_ep = c_ep[b] + __popcll(b_ep[b] & m_ep);
+        kk[b] = ix.count[b] + o_sp;
+        ss[b] = o_ep - o_sp;
+    }
+    const int64_t sent = (k <= ix.sentinel && k + s > ix.sentinel) ? 1 : 0;
+    const int64_t l3 = l + sent, l2 = l3 + ss[3], l1 = l2 + ss[2], l0 = l1 + ss[1];
+    ko = a == 0 ? kk[0] : a == 1 ? kk[1] : a == 2 ? kk[2] : kk[3];
+    so = a == 0 ? ss[0] : a == 1 ? ss[1] : a == 2 ? ss[2] : ss[3];
+    lo = a == 0 ? l0 : a == 1 ? l1 : a == 2 ? l2 : l3;
+}
+// forward extension = backward extension on the reverse-complement strand (FMI_search.cpp:549-557)
+__device__ __forceinline__ void forward_ext(const FmiIdx &ix, Iv &sm, int a, unsigned long long &calls) {
+    int64_t ko, lo, so;
+    backward_ext(ix, sm.l, sm.k, sm.s, 3 - a, ko, lo, so, calls);
+    sm.k = lo; sm.l = ko; sm.s = so;
+}
+
+struct ReadCtx {
+    const uint8_t *q; int len;
+    PrevRec *prev; int64_t pstride;        // prev[p * pstride]
+    OutRec *out; int cap; int nout;        // out[j], j < cap stored; nout counts all
+    int min_seed_len;
+};
+
+__device__ __forceinline__ void emit(ReadCtx &rc, uint32_t m, uint32_t n, int64_t k, int64_t l, int64_t s) {
+    if (rc.nout < rc.cap) { OutRec o; o.m = m; o.n = n; o.k = k; o.l = l; o.s = s; rc.out[rc.nout] = o; }
+    rc.nout++;
+}
+
+// body of getSMEMsOnePosOneThread for one (read, x, min_intv); returns next_x
+__device__ int smem_one_pos(const FmiIdx &ix, ReadCtx &rc, int x, int64_t min_intv, unsigned long long &calls) {
+    const uint8_t *q = rc.q;
+    const int len = rc.len;
+    int next_x = x + 1;
+    int a = q[x];
+    if (a >= 4) return next_x;
+    Iv sm;
+    sm.m = (uint32_t)x; sm.n = (uint32_t)x;
+    sm.k = ix.count[a]; sm.l = ix.count[3 - a]; sm.s = ix.count[a + 1] - ix.count[a];
+    int nprev = 0;
+    for (int j = x + 1; j < len; j++) {
+        a = q[j];
+        next_x = j + 1;
+        if (a >= 4) break;
+        Iv nw = sm;
+        forward_ext(ix, nw, a, calls);
+        nw.n = (uint32_t)j;
+        if (nw.s != sm.s) { PrevRec p; p.n = sm.n; p.k = sm.k; p.l = sm.l; p.s = sm.s; rc.prev[nprev * rc.pstride] = p; nprev++; }
+        if (nw.s < min_intv) { next_x = j; break; }
+        sm = nw;
+    }
+    if (sm.s >= min_intv) { PrevRec p; p.n = sm.n; p.k = sm.k; p.l = sm.l; p.s = sm.s; rc.prev[nprev * rc.pstride] = p; nprev++; }
+    // reverse (longest match first)
+    for (int p = 0; p < nprev / 2; p++) {
+        PrevRec t0 = rc.prev[p * rc.pstride], t1 = rc.prev[(nprev - 1 - p) * rc.pstride];
+        rc.prev[p * rc.pstride] = t1; rc.prev[(nprev - 1 - p) * rc.pstride] = t0;
+    }
+    // every prev entry starts at m = x; m is tracked per backward column instead of per entry
+    uint32_t cur_m = (uint32_t)x;
+    for (int j = x - 1; j >= 0; j--) {
+        a = q[j];
+        if (a > 3) break;
+        int ncur = 0;
+        int curr_s = -1;                                     // int, as in the reference
+        bool first_phase = true;
+        for (int p = 0; p < nprev; p++) {
+            const PrevRec s0 = rc.prev[p * rc.pstride];
+            int64_t ko, lo, so;
+            backward_ext(ix, s0.k, s0.l, s0.s, a, ko, lo, so, calls);
+            if (first_phase) {
+                if (so < min_intv && (int)((int64_t)s0.n - (int64_t)cur_m + 1) >= rc.min_seed_len) {
+                    emit(rc, cur_m, (uint32_t)s0.n, s0.k, s0.l, s0.s);
+                    first_phase = false;
+                    continue;
+                }
+                if (so >= min_intv && so != (int64_t)curr_s) {
+                    curr_s = (int)so;
+                    PrevRec nw; nw.n = s0.n; nw.k = ko; nw.l = lo; nw.s = so;
+                    rc.prev[ncur * rc.pstride] = nw; ncur++;
+                    first_phase = false;
+                }
+            } else if (so >= min_intv && so != (int64_t)curr_s) {
+                curr_s = (int)so;
+                PrevRec nw; nw.n = s0.n; nw.k = ko; nw.l = lo; nw.s = so;
+                rc.prev[ncur * rc.pstride] = nw; ncur++;
+            }
+        }
+        nprev = ncur;
+        if (ncur == 0) break;
+        cur_m = (uint32_t)j;
+    }
+    if (nprev != 0) {
+        const PrevRec s0 = rc.prev[0];
+        if ((int)((int64_t)s0.n - (int64_t)cur_m + 1) >= rc.min_seed_len) emit(rc, cur_m, (uint32_t)s0.n, s0.k, s0.l, s0.s);
+    }
+    return next_x;
+}
+
+__device__ __forceinline__ bool rec_less(const OutRec &a, const OutRec &b) {
+    if (a.m != b.m) return a.m < b.m;
+    if (a.n != b.n) return a.n > b.n;            // compare_smem: n descending
+    if (a.s != b.s) return a.s < b.s;            // tie-break (unspecified in the reference)
+    return a.k < b.k;
+}
+
+__global__ __launch_bounds__(256) void fmi_seed_kernel(FmiIdx ix, const uint8_t *__restrict__ enc, int32_t stride,
+                                                       const int32_t *__restrict__ len, int64_t first, int32_t nbatch,
+                                                       int min_seed_len, PrevRec *prev, OutRec *out, int cap,
+                                                       int32_t *counts, FmiCounters *ct) {
+    const int32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long calls = 0;
+    int nout = 0;
+    if (t < nbatch) {
+        const int64_t r = first + t;
+        ReadCtx rc;
+        rc.q = enc + r * (int64_t)stride; rc.len = len[r];
+        rc.prev = prev + t; rc.pstride = nbatch;
+        rc.out = out + (int64_t)t * cap; rc.cap = cap; rc.nout = 0; rc.min_seed_len = min_seed_len;
+        // pass 1
+        for (int x = 0; x < rc.len;) x = smem_one_pos(ix, rc, x, 1, calls);
+        // pass 2: re-seed (only stored records can be re-read; a truncated list is re-run with a bigger slot)
+        const int n1 = rc.nout;
+        const int split_len = (int)(min_seed_len * 1.5 + .499);
+        if (n1 <= cap) {
+            for (int j = 0; j < n1; j++) {
+                const OutRec o = rc.out[j];
+                const int start = (int)o.m, end = (int)o.n + 1;
+                if (end - start < split_len || o.s > 10) continue;
+                smem_one_pos(ix, rc, (end + start) >> 1, o.s + 1, calls);
+            }
+        }
+        // pass 3
+        const int msl = min_seed_len + 1;
+        for (int x = 0; x < rc.len;) {
+            int next_x = x + 1;
+            int a = rc.q[x];
+            if (a < 4) {
+                Iv sm;
+                sm.m = (uint32_t)x; sm.n = (uint32_t)x;
+                sm.k = ix.count[a]; sm.l = ix.count[3 - a]; sm.s = ix.count[a + 1] - ix.count[a];
+                for (int j = x + 1; j < rc.len; j++) {
+                    next_x = j + 1;
+                    a = rc.q[j];
+                    if (a >= 4) break;
+                    forward_ext(ix, sm, a, calls);
+                    sm.n = (uint32_t)j;
+                    if (sm.s < 20 && (int)(sm.n - sm.m + 1) >= msl) {
+                        if (sm.s > 0) emit(rc, sm.m, sm.n, sm.k, sm.l, sm.s);
+                        break;
+                    }
+                }
+            }
+            x = next_x;
+        }
+        nout = rc.nout;
+        // insertion sort of this read's records
+        if (nout <= cap) {
+            for (int i = 1; i < nout; i++) {
+                const OutRec key = rc.out[i];
+                int j = i - 1;
+                while (j >= 0) {
+                    const OutRec o = rc.out[j];
+                    if (!rec_less(key, o)) break;
+                    rc.out[j + 1] = o;
+                    j--;
+                }
+                rc.out[j + 1] = key;
+            }
+        }
+        counts[t] = nout;
+    }
+    // statistics: one atomic per wave
+    int mx = nout;
+    unsigned long long tot = (unsigned long long)nout;
+    for (int o = 32; o > 0; o >>= 1) {
+        calls += __shfl_xor(calls, o); tot += __shfl_xor(tot, o);
+        const int v = __shfl_xor(mx, o); mx = v > mx ? v : mx;
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (calls) atomicAdd(&ct->ext_calls, calls);
+        if (tot) atomicAdd(&ct->total, tot);
+        if (mx) atomicMax(&ct->max_per_read, mx);
+    }
+}
+
+// ---- exclusive scan of the per-read counts and compaction ------------------------------------------
+__global__ __launch_bounds__(256) void fmi_block_sums(const int32_t *counts, int32_t n, int64_t *block_sums) {
+    __shared__ int64_t sh[256];
+    const int32_t t = blockIdx.x * 256 + threadIdx.x;
+    sh[threadIdx.x] = t < n ? counts[t] : 0;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o]; __syncthreads(); }
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = sh[0];
+}
+__global__ __launch_bounds__(1024) void fmi_scan_blocks(int64_t *block_sums, int32_t nblocks, int64_t base) {
+    // single workgroup, serial over chunks of 1024
+    __shared__ int64_t sh[1024];
+    int64_t carry = base;
+    for (int32_t c0 = 0; c0 < nblocks; c0 += 1024) {
+        const int32_t i = c0 + threadIdx.x;
+        const int64_t v = i < nblocks ? block_sums[i] : 0;
+        sh[threadIdx.x] = v;
+        __syncthreads();
+        for (int o = 1; o < 1024; o <<= 1) {
+            const int64_t add = (int)threadIdx.x >= o ? sh[threadIdx.x - o] : 0;
+            __syncthreads();
+            sh[threadIdx.x] += add;
+            __syncthreads();
+        }
+        if (i < nblocks) block_sums[i] = carry + sh[threadIdx.x] - v;
+        const int64_t total = sh[1023];
+        __syncthreads();
+        carry += total;
+    }
+}
+__global__ __launch_bounds__(256) void fmi_compact(const int32_t *counts, int32_t n, const int64_t *block_off,
+                                                   const OutRec *slots, int cap, int64_t first, int64_t *read_off,
+                                                   gab_smem *out) {
+    __shared__ int64_t sh[256];
+    const int32_t t = blockIdx.x * 256 + threadIdx.x;
+    const int c = t < n ? counts[t] : 0;
+    sh[threadIdx.x] = c;
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {
+        const int64_t add = (int)threadIdx.x >= o ? sh[threadIdx.x - o] : 0;
+        __syncthreads();
+        sh[threadIdx.x] += add;
+        __syncthreads();
+    }
+    if (t >= n) return;
+    const int64_t off = block_off[blockIdx.x] + sh[threadIdx.x] - c;
+    read_off[first + t] = off;
+    const OutRec *src = slots + (int64_t)t * cap;
+    for (int j = 0; j < c; j++) {
+        const OutRec o = src[j];
+        gab_smem g;
+        g.rid = (uint32_t)(first + t); g.m = o.m; g.n = o.n; g.pad = 0; g.k = o.k; g.l = o.l; g.s = o.s;
+        out[off + j] = g;
+    }
+}
+
+__global__ __launch_bounds__(256) void fmi_validate(const int32_t *len, int64_t n, int32_t stride, FmiCounters *ct) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t s = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += s) {
+        const int l = len[i];
+        if (l < 0 || l > stride || l >= GAB_FMI_MAX_READLEN) {
+            atomicAdd(&ct->bad, 1);
+            atomicMin((unsigned int *)&ct->first_bad, (unsigned int)(i + 1 > 0x7fffffff ? 0x7fffffff : i + 1));
+        }
+    }
+}
+
+}  // namespace
+
+// =============================================================================== host side
+struct gab_fmi {
+    int device = 0;
+    FmiIdx ix;
+    gab_devbuf index;       // CP_OCC array
+    gab_devbuf ws;          // counters, counts, block sums
+    gab_devbuf prev;        // prev[] scratch
+    gab_devbuf slots;       // per-read output slots
+    gab_devbuf out;         // compacted SMEMs
+    gab_devbuf roff;        // read_off (nreads + 1)
+    gab_devbuf io;          // staging for the host entry point
+    size_t scratch_budget = (size_t)6 << 30;
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    FmiCounters *h_ct = nullptr;
+    bool have_stats = false;
+    int64_t ext_calls = 0, nsmem = 0;
+    float kernel_ms = 0;
+};
+
+static int fmi_new_handle(int device, gab_fmi **out) {
+    int rc = gab_check_device(device);
+    if (rc) return rc;
+    gab_fmi *h = new (std::nothrow) gab_fmi();
+    if (!h) { gab_set_error("out of host memory"); return GAB_ENOMEM; }
+    h->device = device;
+    if (hipEventCreate(&h->ev[0]) != hipSuccess || hipEventCreate(&h->ev[1]) != hipSuccess ||
+        hipHostMalloc((void **)&h->h_ct, sizeof(FmiCounters)) != hipSuccess) {
+        gab_set_error("gab_fmi: event / pinned allocation failed"); delete h; return GAB_EDEVICE;
+    }
+    *out = h;
+    return GAB_OK;
+}
+
+extern "C" int gab_fmi_create(int device, int64_t ref_seq_len, const int64_t count_file[5], const void *cp_occ,
+                              int64_t sentinel_index, gab_fmi **out) {
+    if (!out || !count_file || !cp_occ) { gab_set_error("gab_fmi_create: NULL argument"); return GAB_EINVAL; }
+    *out = nullptr;
+    GAB_CHECK(ref_seq_len > 0 && ref_seq_len <= 0x7fffffffffll, "gab_fmi_create: reference_seq_len out of range");
+    GAB_CHECK(sentinel_index >= 0 && sentinel_index < ref_seq_len, "gab_fmi_create: sentinel index out of range");
+    gab_fmi *h = nullptr;
+    int rc = fmi_new_handle(device, &h);
+    if (rc) return rc;
+    gab_device_guard g(device);
+    const size_t bytes = sizeof(CpOcc) * (size_t)((ref_seq_len >> 6) + 1);
+    rc = h->index.reserve(bytes);
+    if (rc) { gab_fmi_destroy(h); return rc; }
+    if (hipMemcpy(h->index.p, cp_occ, bytes, hipMemcpyHostToDevice) != hipSuccess) {
+        gab_set_error("gab_fmi_create: index upload failed"); gab_fmi_destroy(h); return GAB_EDEVICE;
+    }
+    h->ix.cp_occ = h->index.as<CpOcc>();
+    for (int i = 0; i < 5; i++) h->ix.count[i] = count_file[i] + 1;     // FMI_search.cpp:433-436
+    h->ix.sentinel = sentinel_index;
+    h->ix.ref_seq_len = ref_seq_len;
+    *out = h;
+    return GAB_OK;
+}
+
+extern "C" int gab_fmi_load(int device, const char *prefix, gab_fmi **out) {
+    if (!out || !prefix) { gab_set_error("gab_fmi_load: NULL argument"); return GAB_EINVAL; }
+    *out = nullptr;
+    char name[4096];
+    snprintf(name, sizeof name, "%s.bwt.2bit.64", prefix);
+    FILE *f = fopen(name, "rb");
+    if (!f) { gab_set_error("gab_fmi_load: cannot open %s", name); return GAB_EINVAL; }
+    int64_t ref_seq_len = 0, count[5], sentinel = -1;
+    int rc = GAB_OK;
+    void *host = nullptr;
+    do {
+        if (fread(&ref_seq_len, 8, 1, f) != 1 || fread(count, 8, 5, f) != 5 || ref_seq_len <= 0 ||
+            ref_seq_len > 0x7fffffffffll) { gab_set_error("gab_fmi_load: %s: bad header", name); rc = GAB_EINVAL; break; }
+        const size_t n_occ = (size_t)((ref_seq_len >> 6) + 1), bytes = n_occ * sizeof(CpOcc);
+        host = malloc(bytes);
+        if (!host) { gab_set_error("gab_fmi_load: out of host memory (%zu bytes)", bytes); rc = GAB_ENOMEM; break; }
+        if (fread(host, sizeof(CpOcc), n_occ, f) != n_occ) { gab_set_error("gab_fmi_load: %s: truncated", name); rc = GAB_EINVAL; break; }
+        // skip the sampled suffix array (SA_COMPX = 3: one int8 + one uint32 per 8 rows), FMI_search.cpp:439-447
+        const int64_t n_sa = (ref_seq_len >> 3) + 1;
+        if (fseek(f, (long)(n_sa * 5), SEEK_CUR) != 0 || fread(&sentinel, 8, 1, f) != 1) {
+            gab_set_error("gab_fmi_load: %s: truncated (sentinel index)", name); rc = GAB_EINVAL; break;
+        }
+        rc = gab_fmi_create(device, ref_seq_len, count, host, sentinel, out);
+    } while (0);
+    free(host);
+    fclose(f);
+    return rc;
+}
+
+extern "C" void gab_fmi_destroy(gab_fmi *h) {
+    if (!h) return;
+    gab_device_guard g(h->device);
+    h->index.release(); h->ws.release(); h->prev.release(); h->slots.release(); h->out.release(); h->roff.release();
+    h->io.release();
+    for (int k = 0; k < 2; k++) if (h->ev[k]) (void)hipEventDestroy(h->ev[k]);
+    if (h->h_ct) (void)hipHostFree(h->h_ct);
+    delete h;
+}
+
+extern "C" int gab_fmi_seed_device(gab_fmi *h, const uint8_t *d_enc, int32_t stride, const int32_t *d_len, int64_t nreads,
+                                   int32_t min_seed_len, const gab_smem **d_out, const int64_t **d_read_off,
+                                   int64_t *nout, void *stream_) {
+    GAB_CHECK(h, "gab_fmi_seed_device: NULL handle");
+    GAB_CHECK(nreads >= 0 && nreads < (1ll << 31), "gab_fmi_seed_device: nreads out of range");
+    GAB_CHECK(stride > 0 && stride < GAB_FMI_MAX_READLEN, "gab_fmi_seed_device: stride (max read length) must be in 1..%d",
+              GAB_FMI_MAX_READLEN - 1);
+    GAB_CHECK(min_seed_len >= 1, "gab_fmi_seed_device: minSeedLen must be >= 1");
+    GAB_CHECK(nout, "gab_fmi_seed_device: NULL nout");
+    h->have_stats = false;
+    *nout = 0;
+    gab_device_guard g(h->device);
+    hipStream_t s = (hipStream_t)stream_;
+    int rc = h->roff.reserve(8 * (size_t)(nreads + 1));
+    if (rc) return rc;
+    if (d_read_off) *d_read_off = h->roff.as<int64_t>();
+    if (d_out) *d_out = nullptr;
+    if (nreads == 0) { GAB_HIP(hipMemsetAsync(h->roff.p, 0, 8, s)); return GAB_OK; }
+    GAB_CHECK(d_enc && d_len, "gab_fmi_seed_device: NULL buffer");
+
+    // batch size from the scratch budget: prev needs stride x 32 B per read, slots cap x 32 B
+    int cap = 48;
+    const size_t per_read = (size_t)stride * sizeof(PrevRec) + (size_t)3 * stride * 0;   // slots sized below
+    int64_t B = (int64_t)std::min<size_t>((size_t)nreads, std::max<size_t>(1024, h->scratch_budget / (per_read + 64 * sizeof(OutRec))));
+    B = std::min<int64_t>(B, 1 << 20);
+    const int64_t nb_blocks = gab_ceil_div(B, 256);
+    const size_t o_counts = 256, o_bs = o_counts + 4 * (size_t)B + 64;
+    rc = h->ws.reserve(o_bs + 8 * (size_t)nb_blocks + 64);
+    if (rc) return rc;
+    rc = h->prev.reserve(sizeof(PrevRec) * (size_t)stride * (size_t)B);
+    if (rc) return rc;
+    char *wb = h->ws.as<char>();
+    FmiCounters *d_ct = (FmiCounters *)wb;
+    int32_t *d_counts = (int32_t *)(wb + o_counts);
+    int64_t *d_bs = (int64_t *)(wb + ((o_bs + 7) & ~(size_t)7));
+
+    memset(h->h_ct, 0, sizeof(FmiCounters));
+    h->h_ct->first_bad = 0x7fffffff;
+    GAB_HIP(hipMemcpyAsync(d_ct, h->h_ct, sizeof(FmiCounters), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(fmi_validate, dim3((unsigned)std::min<int64_t>(gab_ceil_div(nreads, 256), 2048)), dim3(256), 0, s,
+                       d_len, nreads, stride, d_ct);
+    GAB_HIP(hipMemcpyAsync(h->h_ct, d_ct, sizeof(FmiCounters), hipMemcpyDeviceToHost, s));
+    GAB_HIP(hipStreamSynchronize(s));
+    if (h->h_ct->bad) {
+        gab_set_error("gab_fmi_seed_device: %d read(s) have a length outside 0..stride (first: read %d)", h->h_ct->bad,
+                      h->h_ct->first_bad - 1);
+        return GAB_EINVAL;
+    }
+
+    // output grows geometrically; batches append
+    size_t out_cap = std::max<size_t>((size_t)nreads * 16, 1024);
+    rc = h->out.reserve(out_cap * sizeof(gab_smem));
+    if (rc) return rc;
+    int64_t total = 0;
+    unsigned long long ext_total = 0;
+    float kms = 0;
+    for (int64_t first = 0; first < nreads; first += B) {
+        const int32_t nb = (int32_t)std::min<int64_t>(B, nreads - first);
+        const int blocks = (int)gab_ceil_div(nb, 256);
+        for (;;) {                                        // at most two rounds: second with the exact slot size
+            rc = h->slots.reserve(sizeof(OutRec) * (size_t)cap * (size_t)nb);
+            if (rc) return rc;
+            h->h_ct->ext_calls = 0; h->h_ct->total = 0; h->h_ct->max_per_read = 0;
+            GAB_HIP(hipMemcpyAsync(d_ct, h->h_ct, sizeof(FmiCounters), hipMemcpyHostToDevice, s));
+            GAB_HIP(hipEventRecord(h->ev[0], s));
+            hipLaunchKernelGGL(fmi_seed_kernel, dim3(blocks), dim3(256), 0, s, h->ix, d_enc, stride, d_len, first, nb,
+                               min_seed_len, h->prev.as<PrevRec>(), h->slots.as<OutRec>(), cap, d_counts, d_ct);
+            GAB_HIP(hipGetLastError());
+            GAB_HIP(hipEventRecord(h->ev[1], s));
+            GAB_HIP(hipMemcpyAsync(h->h_ct, d_ct, sizeof(FmiCounters), hipMemcpyDeviceToHost, s));
+            GAB_HIP(hipStreamSynchronize(s));
+            if (h->h_ct->max_per_read <= cap) break;
+            cap = h->h_ct->max_per_read + 8;              // some read overflowed its slot: redo the batch
+        }
+        float ms = 0;
+        GAB_HIP(hipEventElapsedTime(&ms, h->ev[0], h->ev[1]));
+        kms += ms;
+        ext_total += h->h_ct->ext_calls;
+        const int64_t add = (int64_t)h->h_ct->total;
+        if ((size_t)(total + add) > out_cap) {
+            // grow, keeping what earlier batches wrote
+            size_t ncap = std::max<size_t>(out_cap * 2, (size_t)(total + add));
+            gab_devbuf bigger;
+            rc = bigger.reserve(ncap * sizeof(gab_smem));
+            if (rc) return rc;
+            GAB_HIP(hipMemcpyAsync(bigger.p, h->out.p, (size_t)total * sizeof(gab_smem), hipMemcpyDeviceToDevice, s));
+            GAB_HIP(hipStreamSynchronize(s));
+            h->out.release();
+            h->out = bigger;
+            out_cap = ncap;
+        }
+        hipLaunchKernelGGL(fmi_block_sums, dim3(blocks), dim3(256), 0, s, d_counts, nb, d_bs);
+        hipLaunchKernelGGL(fmi_scan_blocks, dim3(1), dim3(1024), 0, s, d_bs, blocks, total);
+        hipLaunchKernelGGL(fmi_compact, dim3(blocks), dim3(256), 0, s, d_counts, nb, d_bs, h->slots.as<OutRec>(), cap, first,
+                           h->roff.as<int64_t>(), h->out.as<gab_smem>());
+        GAB_HIP(hipGetLastError());
+        total += add;
+    }
+    GAB_HIP(hipMemcpyAsync(h->roff.as<int64_t>() + nreads, &total, 8, hipMemcpyHostToDevice, s));
+    GAB_HIP(hipStreamSynchronize(s));
+    *nout = total;
+    if (d_out) *d_out = h->out.as<gab_smem>();
+    h->ext_calls = (int64_t)ext_total; h->nsmem = total; h->kernel_ms = kms;
+    h->have_stats = true;
+    return GAB_OK;
+}
+
+extern "C" int gab_fmi_seed(gab_fmi *h, const uint8_t *enc, int32_t stride, const int32_t *len, int64_t nreads,
+                            int32_t min_seed_len, gab_smem **out, int64_t *nout) {
+    GAB_CHECK(h, "gab_fmi_seed: NULL handle");
+    GAB_CHECK(out && nout, "gab_fmi_seed: NULL output argument");
+    *out = nullptr; *nout = 0;
+    GAB_CHECK(nreads >= 0 && nreads < (1ll << 31), "gab_fmi_seed: nreads out of range");
+    if (nreads == 0) return GAB_OK;
+    GAB_CHECK(enc && len && stride > 0, "gab_fmi_seed: NULL buffer");
+    gab_device_guard g(h->device);
+    const size_t eb = (size_t)nreads * (size_t)stride;
+    const size_t o_len = (eb + 255) & ~(size_t)255;
+    int rc = h->io.reserve(o_len + 4 * (size_t)nreads);
+    if (rc) return rc;
+    hipStream_t s = nullptr;
+    char *b = h->io.as<char>();
+    GAB_HIP(hipMemcpyAsync(b, enc, eb, hipMemcpyHostToDevice, s));
+    GAB_HIP(hipMemcpyAsync(b + o_len, len, 4 * (size_t)nreads, hipMemcpyHostToDevice, s));
+    const gab_smem *d_out = nullptr;
+    int64_t n = 0;
+    rc = gab_fmi_seed_device(h, (const uint8_t *)b, stride, (const int32_t *)(b + o_len), nreads, min_seed_len, &d_out,
+                             nullptr, &n, s);
+    if (rc) return rc;
+    gab_smem *host = (gab_smem *)malloc(sizeof(gab_smem) * (size_t)(n > 0 ? n : 1));
+    if (!host) { gab_set_error("gab_fmi_seed: out of host memory"); return GAB_ENOMEM; }
+    if (n) {
+        if (hipMemcpy(host, d_out, sizeof(gab_smem) * (size_t)n, hipMemcpyDeviceToHost) != hipSuccess) {
+            free(host); gab_set_error("gab_fmi_seed: D2H copy failed"); return GAB_EDEVICE;
+        }
+    }
+    *out = host; *nout = n;
+    return GAB_OK;
+}
+
+extern "C" void gab_fmi_free(gab_smem *p) { free(p); }
+
+extern "C" int gab_fmi_last_stats(gab_fmi *h, int64_t *ext_calls, int64_t *nsmem, float *kernel_ms) {
+    GAB_CHECK(h, "gab_fmi_last_stats: NULL handle");
+    GAB_CHECK(h->have_stats, "gab_fmi_last_stats: no completed run on this handle");
+    if (ext_calls) *ext_calls = h->ext_calls;
+    if (nsmem) *nsmem = h->nsmem;
+    if (kernel_ms) *kernel_ms = h->kernel_ms;
+    return GAB_OK;
+}

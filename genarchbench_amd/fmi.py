@@ -1,0 +1,59 @@
+"""Host-side mirror of FMI_search (load_index + the three seeding passes of fmi/fmi.cpp:288-348)."""
+import ctypes as C
+
+import numpy as np
+
+from ._lib import check, lib
+
+SMEM_DTYPE = np.dtype([("rid", np.uint32), ("m", np.uint32), ("n", np.uint32), ("pad", np.uint32),
+                       ("k", np.int64), ("l", np.int64), ("s", np.int64)])
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class FMI_search:
+    def __init__(self, prefix=None, device=0, arrays=None):
+        """prefix: path prefix of a BWA-MEM2 index (<prefix>.bwt.2bit.64), or arrays=(ref_seq_len, count[5],
+        cp_occ bytes, sentinel_index) for an index built in memory"""
+        self._h = C.c_void_p()
+        if arrays is not None:
+            n, count, occ, sent = arrays
+            count = np.ascontiguousarray(count, np.int64)
+            check(lib().gab_fmi_create(C.c_int(device), C.c_int64(n), _p(count), _p(occ), C.c_int64(sent), C.byref(self._h)))
+        else:
+            check(lib().gab_fmi_load(C.c_int(device), prefix.encode(), C.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().gab_fmi_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def seed(self, reads, min_seed_len=19):
+        """reads: .enc [n, stride] uint8, .len int32 -> (smems structured array sorted by rid/m/n desc, read_off)"""
+        out = C.c_void_p(); n = C.c_int64(0)
+        check(lib().gab_fmi_seed(self._h, _p(reads.enc), C.c_int32(reads.stride), _p(reads.len), C.c_int64(reads.n),
+                                 C.c_int32(min_seed_len), C.byref(out), C.byref(n)))
+        cnt = n.value
+        arr = np.ctypeslib.as_array(C.cast(out, C.POINTER(C.c_uint8)), shape=(max(cnt, 1) * 40,))[:cnt * 40].copy().view(SMEM_DTYPE)
+        lib().gab_fmi_free(out)
+        off = np.zeros(reads.n + 1, np.int64)
+        np.cumsum(np.bincount(arr["rid"], minlength=reads.n), out=off[1:])
+        return arr, off
+
+    def seed_device(self, enc, length, min_seed_len=19, stream=0):
+        """torch CUDA tensors enc [n, stride] uint8, length int32 -> (device ptr of gab_smem[], device ptr of
+        read_off[], count); the pointers stay valid until the next call"""
+        d_out = C.c_void_p(); d_off = C.c_void_p(); n = C.c_int64(0)
+        check(lib().gab_fmi_seed_device(self._h, C.c_void_p(enc.data_ptr()), C.c_int32(enc.shape[1]),
+                                        C.c_void_p(length.data_ptr()), C.c_int64(enc.shape[0]), C.c_int32(min_seed_len),
+                                        C.byref(d_out), C.byref(d_off), C.byref(n), C.c_void_p(stream)))
+        return d_out.value, d_off.value, n.value
+
+    def last_stats(self):
+        e = C.c_int64(0); n = C.c_int64(0); k = C.c_float(0)
+        check(lib().gab_fmi_last_stats(self._h, C.byref(e), C.byref(n), C.byref(k)))
+        return {"ext_calls": e.value, "smems": n.value, "kernel_ms": k.value}

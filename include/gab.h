@@ -179,6 +179,44 @@ int gab_wfa_run_device(gab_wfa *h, const char *pat, int64_t pat_bytes, const int
  * device time of the first (LDS) pass and of the whole call (HIP events, ms) */
 int gab_wfa_last_stats(gab_wfa *h, int64_t *work, int64_t *requeued, float *first_pass_ms, float *total_ms);
 
+/* ---- fmi: FM-index SMEM seeding --------------------------------------------------------------
+ * Replaces, per batch of reads, the sequence
+ *     getSMEMsAllPosOneThread -> select -> getSMEMsOnePosOneThread -> bwtSeedStrategyAllPosOneThread
+ *     -> rid += batch offset -> sortSMEMs                          fmi/fmi.cpp:288-348
+ * on a shared read-only FMI_search (fmi/bwa-mem2/x86_64/src/FMI_search.h:101-...), and
+ *     new FMI_search(prefix); load_index()                         fmi/fmi.cpp:102-103
+ * by gab_fmi_load (outside the region of interest, as in the reference).  The index file is the
+ * reference's own <prefix>.bwt.2bit.64 (FMI_search.cpp:144-304), read unchanged; only the count[],
+ * CP_OCC[] and sentinel_index parts are used by seeding.
+ * Reads are the driver's dense code matrix (fmi.cpp:121-151): read r = enc[r*stride .. +len[r]),
+ * codes 0..3 = ACGT, anything above 3 = N.  Constants of the driver are fixed: re-seed width 10,
+ * split factor 1.5, third-pass interval 20 (fmi.cpp:162-164).
+ * Output: SMEM records (FMI_search.h:75-83) of ALL reads sorted by (rid, m ascending, n descending)
+ * -- the order the driver prints -- as [m, n] inclusive query interval and the bi-interval k, l, s.
+ */
+#define GAB_FMI_MAX_READLEN 10000 /* assert(max_readlength < 10000), fmi/fmi.cpp:117 */
+typedef struct gab_fmi gab_fmi;
+typedef struct {
+    uint32_t rid, m, n, pad;
+    int64_t k, l, s;
+} gab_smem; /* 40 bytes, layout of SMEM */
+int gab_fmi_load(int device, const char *prefix, gab_fmi **out);
+/* same, from memory: the three parts of the file as the reference writes them (count[] NOT yet +1) */
+int gab_fmi_create(int device, int64_t reference_seq_len, const int64_t count[5], const void *cp_occ,
+                   int64_t sentinel_index, gab_fmi **out);
+void gab_fmi_destroy(gab_fmi *h);
+/* host buffers; *out is malloc'ed by the library, release it with gab_fmi_free */
+int gab_fmi_seed(gab_fmi *h, const uint8_t *enc, int32_t stride, const int32_t *len, int64_t nreads,
+                 int32_t min_seed_len, gab_smem **out, int64_t *nout);
+void gab_fmi_free(gab_smem *p);
+/* device buffers; *d_out / *d_read_off (nreads + 1 offsets into d_out) point into memory owned by the
+ * handle and stay valid until the next call on it.  Synchronises `stream` internally. */
+int gab_fmi_seed_device(gab_fmi *h, const uint8_t *d_enc, int32_t stride, const int32_t *d_len,
+                        int64_t nreads, int32_t min_seed_len, const gab_smem **d_out,
+                        const int64_t **d_read_off, int64_t *nout, void *stream);
+/* last run: backwardExt calls (= 2 random 64-byte index reads each), SMEMs found, seeding-kernel ms */
+int gab_fmi_last_stats(gab_fmi *h, int64_t *ext_calls, int64_t *nsmem, float *kernel_ms);
+
 #ifdef __cplusplus
 }
 #endif

@@ -70,6 +70,25 @@ void oracle_wfa_batch(const oracle_wfa_penalties *pen, const char *pat, const in
                       const char *txt, const int64_t *txt_off, const int32_t *txt_len, int64_t n, int threads,
                       char *ops, const int64_t *ops_off, int32_t *ops_len, int32_t *score, int64_t *cells);
 
+/* ---- fmi: see fmi.c ------------------------------------------------------------------ */
+typedef struct { int64_t cp_count[4]; uint64_t one_hot_bwt_str[4]; } oracle_cp_occ;   /* CP_OCC */
+typedef struct {
+    int64_t ref_seq_len, count[5] /* already +1 */, cp_occ_size, sentinel_index;
+    oracle_cp_occ *cp_occ;
+} oracle_fmindex;
+typedef struct { uint32_t rid, m, n, pad; int64_t k, l, s; } oracle_smem;              /* SMEM, 40 bytes */
+int oracle_fmi_load(const char *prefix, oracle_fmindex *idx);                          /* <prefix>.bwt.2bit.64 */
+void oracle_fmi_from_arrays(oracle_fmindex *idx, int64_t ref_seq_len, const int64_t *file_count,
+                            const void *cp_occ, int64_t sentinel_index);
+void oracle_fmi_free(oracle_fmindex *idx);
+int64_t oracle_fmi_read(const oracle_fmindex *idx, const uint8_t *q, int len, uint32_t rid, int min_seed_len,
+                        oracle_smem *out, int64_t *ext_calls);
+/* all reads; *out_p receives a malloc'ed array sorted by (rid, m, n desc); read_off[nreads+1] */
+int64_t oracle_fmi_batch(const oracle_fmindex *idx, const uint8_t *enc, int32_t stride, const int32_t *len,
+                         int64_t nreads, int min_seed_len, int threads, oracle_smem **out_p, int64_t *read_off,
+                         int64_t *ext_calls);
+void oracle_fmi_release(oracle_smem *p);
+
 #ifdef __cplusplus
 }
 #endif

@@ -126,3 +126,51 @@ def wfa_cigars(res, idx=None):
     ops, off, ln = res[0], res[1], res[2]
     idx = range(len(ln)) if idx is None else idx
     return [rle(ops[off[i]:off[i] + ln[i]]) for i in idx]
+
+
+# ------------------------------------------------------------------ fmi
+class FmIndex(C.Structure):
+    _fields_ = [("ref_seq_len", C.c_int64), ("count", C.c_int64 * 5), ("cp_occ_size", C.c_int64),
+                ("sentinel_index", C.c_int64), ("cp_occ", C.c_void_p)]
+
+
+SMEM_DTYPE = np.dtype([("rid", np.uint32), ("m", np.uint32), ("n", np.uint32), ("pad", np.uint32),
+                       ("k", np.int64), ("l", np.int64), ("s", np.int64)])
+assert SMEM_DTYPE.itemsize == 40
+
+
+def fmi_load(prefix):
+    idx = FmIndex()
+    rc = lib().oracle_fmi_load(prefix.encode(), C.byref(idx))
+    if rc:
+        raise IOError(f"cannot load {prefix}.bwt.2bit.64 ({rc})")
+    return idx
+
+
+def fmi(idx, reads, min_seed_len=19, threads=0, want_calls=False):
+    """returns (smems structured array sorted by rid/m/n desc, read_off int64[n+1])"""
+    L = lib()
+    L.oracle_fmi_batch.restype = C.c_int64
+    out = C.c_void_p(); off = np.zeros(reads.n + 1, np.int64); calls = C.c_int64(0)
+    n = L.oracle_fmi_batch(C.byref(idx), _p(reads.enc), C.c_int32(reads.stride), _p(reads.len), C.c_int64(reads.n),
+                           C.c_int(min_seed_len), C.c_int(threads), C.byref(out), _p(off), C.byref(calls))
+    arr = np.ctypeslib.as_array(C.cast(out, C.POINTER(C.c_uint8)), shape=(max(n, 1) * 40,))[:n * 40].copy().view(SMEM_DTYPE)
+    L.oracle_fmi_release(out)
+    return (arr, off, calls.value) if want_calls else (arr, off)
+
+
+def fmi_text(smems, read_off):
+    """the data part of the reference's stdout (fmi.cpp:430-460): "rid:" then "[m,n+1]" per SMEM, for every
+    read id up to the last read that has a seed"""
+    lines = []
+    last = 0
+    for r in range(len(read_off) - 1):
+        if read_off[r + 1] > read_off[r]:
+            last = r
+    if len(smems) == 0:
+        return ""
+    for r in range(last + 1):
+        lines.append(f"{r}:")
+        for j in range(read_off[r], read_off[r + 1]):
+            lines.append(f"[{smems['m'][j]},{smems['n'][j] + 1}]")
+    return "\n".join(lines) + "\n"

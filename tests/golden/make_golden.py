@@ -113,7 +113,35 @@ def make_wfa(m):
                    "command": "wfa_ref -i <in> -o <out> -t 1|3 ; sort by id (as regression_small.sh:94 does)"}
 
 
-MAKERS = {"bsw": make_bsw, "chain": make_chain, "bpm": make_bpm, "wfa": make_wfa}
+def make_fmi(m):
+    # 100 kb reference with planted repeats, 1200 reads of 60..151 bp (2 % substitutions, N's, both strands).
+    # batch 64 keeps the reference clear of its realloc / dangling-pointer path.
+    name, rseed, qseed, L, n = "fmi_small", 501, 502, 100000, 1200
+    ref = gabgen.fmi_ref(rseed, L, 5)
+    reads = gabgen.fmi_reads(qseed, ref, n, 60, 151)
+    fa = os.path.join(HERE, name + ".ref.fa"); fq = os.path.join(HERE, name + ".reads.fq")
+    gabgen.fmi_write_fasta(fa, ref); gabgen.fmi_write_fastq(fq, reads)
+    subprocess.run([pyoracle.ref_path("bwa_mem2_index_ref"), "index", fa], capture_output=True, check=True)
+    outs = []
+    for batch, t in (("64", "1"), ("32", "2")):
+        r = subprocess.run([pyoracle.ref_path("fmi_ref"), fa, fq, batch, "19", t], capture_output=True, text=True, check=True)
+        lines = r.stdout.splitlines()
+        assert not any("realloc" in l for l in lines[:8]), "reference hit its realloc path"
+        outs.append("\n".join(lines[6:]) + "\n")          # the harness also drops the 6 header lines
+    assert outs[0] == outs[1], "fmi reference output depends on batch size / threads"
+    open(os.path.join(HERE, name + ".expected.txt"), "w").write(outs[0])
+    # keep only the index header words as a fixture for the index builder (the full file is rebuilt in tests)
+    import hashlib
+    idx = open(fa + ".bwt.2bit.64", "rb").read()
+    m[name] = {"generator": "tools/gen gab_gen_fmi_ref/_reads", "ref_seed": rseed, "read_seed": qseed, "ref_len": L, "n": n,
+               "rl_min": 60, "rl_max": 151, "index_sha256": hashlib.sha256(idx).hexdigest(), "index_bytes": len(idx),
+               "reference": "fmi/fmi.cpp + bwa-mem2 library, and bwa-mem2 index, built by oracle/Makefile (clang++)",
+               "command": "bwa_mem2_index_ref index <fa>; fmi_ref <fa> <fq> 64 19 1 ; drop 6 header lines"}
+    for ext in (".0123", ".amb", ".ann", ".pac", ".bwt.2bit.64"):
+        os.remove(fa + ext)
+
+
+MAKERS = {"bsw": make_bsw, "chain": make_chain, "bpm": make_bpm, "wfa": make_wfa, "fmi": make_fmi}
 
 if __name__ == "__main__":
     pyoracle.build(with_ref=True)

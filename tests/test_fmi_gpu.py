@@ -1,0 +1,104 @@
+"""GPU parity: fmi HIP kernel (through the C ABI) vs the oracle and the golden output."""
+import numpy as np
+import pytest
+
+from oracle import pyoracle
+from tools import gabgen, mkindex
+from tests.util import GOLDEN, read_fasta_codes, read_fastq_reads
+
+pytestmark = pytest.mark.gpu
+
+
+def build(ref, tmp):
+    idx = mkindex.FmIndex(ref)
+    prefix = str(tmp / "ref")
+    idx.write(prefix)
+    return idx, prefix
+
+
+def same(got, want):
+    (g, goff), (w, woff) = got, want
+    np.testing.assert_array_equal(goff, woff)
+    assert len(g) == len(w)
+    for f in ("rid", "m", "n", "k", "l", "s"):
+        np.testing.assert_array_equal(g[f], w[f], err_msg=f)
+
+
+def test_golden(tmp_path):
+    from genarchbench_amd.fmi import FMI_search
+    ref = read_fasta_codes(f"{GOLDEN}/fmi_small.ref.fa")
+    idx, prefix = build(ref, tmp_path)
+    reads = read_fastq_reads(f"{GOLDEN}/fmi_small.reads.fq")
+    f = FMI_search(prefix)                      # load_index path: the .bwt.2bit.64 file
+    sm, off = f.seed(reads, 19)
+    assert pyoracle.fmi_text(sm, off) == open(f"{GOLDEN}/fmi_small.expected.txt").read()
+    f.close()
+
+
+@pytest.mark.parametrize("rseed,L,n,lo,hi,msl", [(81, 2_000_000, 60000, 151, 151, 19), (82, 300_000, 20000, 30, 250, 19),
+                                                 (83, 50_000, 5000, 100, 151, 12), (84, 5_000, 3000, 20, 100, 25),
+                                                 (85, 100_000, 1, 151, 151, 19)])
+def test_vs_oracle(tmp_path, rseed, L, n, lo, hi, msl):
+    from genarchbench_amd.fmi import FMI_search
+    ref = gabgen.fmi_ref(rseed, L, 10)
+    idx, prefix = build(ref, tmp_path)
+    reads = gabgen.fmi_reads(rseed + 100, ref, n, lo, hi)
+    f = FMI_search(arrays=(idx.ref_seq_len, idx.count, idx.cp_occ, idx.sentinel_index))   # in-memory path
+    got = f.seed(reads, msl)
+    oidx = pyoracle.fmi_load(prefix)
+    w, woff, calls = pyoracle.fmi(oidx, reads, msl, want_calls=True)
+    same(got, (w, woff))
+    st = f.last_stats()
+    assert st["ext_calls"] == calls and st["smems"] == len(w)
+    f.close()
+
+
+def test_repetitive_reads_overflow_slots(tmp_path):
+    """a highly repetitive reference makes some reads produce more SMEMs than the first-pass slot holds"""
+    from genarchbench_amd.fmi import FMI_search
+    rng = np.random.default_rng(4)
+    unit = rng.integers(0, 4, 37).astype(np.uint8)
+    ref = np.concatenate([np.tile(unit, 300), rng.integers(0, 4, 20000).astype(np.uint8), np.tile(unit[::-1], 200)])
+    idx, prefix = build(ref, tmp_path)
+    reads = gabgen.fmi_reads(9, ref, 3000, 300, 900)
+    f = FMI_search(prefix)
+    got = f.seed(reads, 10)
+    w, woff = pyoracle.fmi(pyoracle.fmi_load(prefix), reads, 10)
+    same(got, (w, woff))
+    assert np.diff(woff).max() > 48
+    f.close()
+
+
+def test_all_n_and_short_reads(tmp_path):
+    from genarchbench_amd.fmi import FMI_search
+    ref = gabgen.fmi_ref(5, 20000, 5)
+    idx, prefix = build(ref, tmp_path)
+    enc = np.full((6, 40), 4, np.uint8)
+    enc[1, :40] = ref[100:140]; enc[2, :5] = ref[7:12]; enc[3, :40] = ref[300:340]; enc[3, 20] = 4
+    enc[4, :1] = 2; enc[5, :40] = 3 - ref[500:540][::-1]
+    reads = gabgen.ReadBatch(enc, np.array([40, 40, 5, 40, 1, 40], np.int32))
+    f = FMI_search(prefix)
+    same(f.seed(reads, 19), pyoracle.fmi(pyoracle.fmi_load(prefix), reads, 19))
+    f.close()
+
+
+def test_device_resident(tmp_path):
+    import ctypes as C
+    import torch
+    from genarchbench_amd.fmi import FMI_search, SMEM_DTYPE
+    ref = gabgen.fmi_ref(91, 400000, 5)
+    idx, prefix = build(ref, tmp_path)
+    reads = gabgen.fmi_reads(92, ref, 30000, 151, 151)
+    f = FMI_search(prefix)
+    dev = torch.device("cuda:0")
+    enc = torch.from_numpy(reads.enc).to(dev); ln = torch.from_numpy(reads.len).to(dev)
+    d_out, d_off, n = f.seed_device(enc, ln, 19, stream=torch.cuda.current_stream().cuda_stream)
+    w, woff = pyoracle.fmi(pyoracle.fmi_load(prefix), reads, 19)
+    assert n == len(w)
+    host = np.zeros(n * 40, np.uint8)
+    hip = C.CDLL("libamdhip64.so")
+    assert hip.hipMemcpy(host.ctypes.data_as(C.c_void_p), C.c_void_p(d_out), C.c_size_t(n * 40), C.c_int(2)) == 0
+    off = np.zeros(reads.n + 1, np.int64)
+    assert hip.hipMemcpy(off.ctypes.data_as(C.c_void_p), C.c_void_p(d_off), C.c_size_t(8 * (reads.n + 1)), C.c_int(2)) == 0
+    same((host.view(SMEM_DTYPE), off), (w, woff))
+    f.close()

@@ -58,3 +58,25 @@ def read_cigars(path):
         if m:
             out[int(m.group(1))] = m.group(2)
     return [out[i] for i in range(len(out))]
+
+
+def read_fasta_codes(path):
+    seq = b"".join(l.strip() for l in open(path, "rb") if not l.startswith(b">"))
+    lut = np.full(256, 4, np.uint8)
+    for i, c in enumerate(b"ACGT"):
+        lut[c] = i
+    return lut[np.frombuffer(seq, np.uint8)]
+
+
+def read_fastq_reads(path):
+    """FASTQ -> ReadBatch the way fmi.cpp:121-151 encodes it (row stride = longest read, A C G T -> 0..3, else 4)"""
+    lines = open(path, "rb").read().split(b"\n")
+    seqs = [lines[i] for i in range(1, len(lines), 4) if i < len(lines) and lines[i - 1].startswith(b"@")]
+    lut = np.full(256, 4, np.uint8)
+    for i, c in enumerate(b"ACGT"):
+        lut[c] = i
+    stride = max(len(s) for s in seqs)
+    enc = np.full((len(seqs), stride), 4, np.uint8)
+    for r, s in enumerate(seqs):
+        enc[r, :len(s)] = lut[np.frombuffer(s, np.uint8)]
+    return gabgen.ReadBatch(enc, np.array([len(s) for s in seqs], np.int32))

@@ -256,3 +256,40 @@ def read_pairs_text(path):
     pats = [l[1:] for l in lines[0::2] if l]
     txts = [l[1:] for l in lines[1::2] if l]
     return pairs_from_lists(pats, txts)
+
+
+# ------------------------------------------------------------------ fmi
+def fmi_ref(seed, ref_len, rep_pct=5):
+    ref = np.zeros(ref_len, np.uint8)
+    lib().gab_gen_fmi_ref(C.c_uint64(seed), C.c_int64(ref_len), C.c_int(rep_pct), _p(ref))
+    return ref
+
+
+@dataclass
+class ReadBatch:
+    enc: np.ndarray     # [n, stride] uint8 codes 0..4 (what fmi.cpp:121-151 builds)
+    len: np.ndarray     # int32
+
+    @property
+    def n(self):
+        return len(self.len)
+
+    @property
+    def stride(self):
+        return self.enc.shape[1]
+
+
+def fmi_reads(seed, ref, n, rl_min=151, rl_max=151, first=0):
+    enc = np.zeros((n, rl_max), np.uint8); ln = np.zeros(n, np.int32)
+    lib().gab_gen_fmi_reads(C.c_uint64(seed), _p(ref), C.c_int64(len(ref)), C.c_int(rl_min), C.c_int(rl_max),
+                            C.c_int64(first), C.c_int64(n), _p(enc), C.c_int32(rl_max), _p(ln))
+    return ReadBatch(enc, ln)
+
+
+def fmi_write_fasta(path, ref):
+    assert lib().gab_gen_fmi_write_fasta(path.encode(), _p(ref), C.c_int64(len(ref))) == 0
+
+
+def fmi_write_fastq(path, reads):
+    assert lib().gab_gen_fmi_write_fastq(path.encode(), _p(reads.enc), C.c_int32(reads.stride), _p(reads.len),
+                                         C.c_int64(reads.n)) == 0

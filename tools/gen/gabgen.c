@@ -297,3 +297,79 @@ int gab_gen_chain_write(const char *path, uint64_t seed, int mode, int64_t nmin,
     }
     return fclose(f);
 }
+
+/* ================================================================== fmi === */
+void gab_gen_fmi_ref(uint64_t seed, int64_t ref_len, int rep_pct, uint8_t *ref) {
+    /* random bases in blocks (one rng stream per 64 Ki bases -> parallel, order independent) */
+    const int64_t B = 65536;
+#pragma omp parallel for schedule(static)
+    for (int64_t b = 0; b < (ref_len + B - 1) / B; b++) {
+        rng_t r = rng_for(seed, 5, (uint64_t)b);
+        int64_t end = (b + 1) * B < ref_len ? (b + 1) * B : ref_len;
+        for (int64_t i = b * B; i < end; i += 32) {
+            uint64_t w = rnd(&r);
+            for (int k = 0; k < 32 && i + k < end; k++, w >>= 2) ref[i + k] = (uint8_t)(w & 3);
+        }
+    }
+    /* planted repeats: a family of 16 templates of 300 bp copied (with 1% divergence) over rep_pct % */
+    if (rep_pct > 0 && ref_len > 4000) {
+        rng_t r = rng_for(seed, 6, 0);
+        uint8_t tmpl[16][300];
+        for (int f = 0; f < 16; f++) for (int i = 0; i < 300; i++) tmpl[f][i] = (uint8_t)(rnd(&r) & 3);
+        int64_t copies = ref_len / 100 * rep_pct / 300;
+        for (int64_t c = 0; c < copies; c++) {
+            int f = (int)(rnd(&r) & 15);
+            int64_t pos = rnd_range(&r, 0, ref_len - 301);
+            for (int i = 0; i < 300; i++) ref[pos + i] = rnd_pm(&r, 100) ? (uint8_t)(rnd(&r) & 3) : tmpl[f][i];
+        }
+    }
+}
+
+void gab_gen_fmi_reads(uint64_t seed, const uint8_t *ref, int64_t ref_len, int rl_min, int rl_max,
+                       int64_t first, int64_t n, uint8_t *enc, int32_t stride, int32_t *len) {
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; i++) {
+        rng_t r = rng_for(seed, 7, (uint64_t)(first + i));
+        int L = (int)rnd_range(&r, rl_min, rl_max);
+        if (L > ref_len) L = (int)ref_len;
+        int64_t pos = rnd_range(&r, 0, ref_len - L);
+        int rev = (int)(rnd(&r) & 1);
+        uint8_t *o = enc + (int64_t)i * stride;
+        for (int k = 0; k < L; k++) {
+            uint8_t c = rev ? (uint8_t)(3 - ref[pos + L - 1 - k]) : ref[pos + k];
+            if (rnd_pm(&r, 200)) c = (uint8_t)(rnd(&r) & 3);
+            if (rnd_pm(&r, 20)) c = 4;
+            o[k] = c;
+        }
+        for (int k = L; k < stride; k++) o[k] = 4;
+        len[i] = L;
+    }
+}
+
+int gab_gen_fmi_write_fasta(const char *path, const uint8_t *ref, int64_t ref_len) {
+    FILE *f = fopen(path, "w");
+    if (!f) return -1;
+    fprintf(f, ">synthetic\n");
+    char line[81];
+    for (int64_t i = 0; i < ref_len; i += 80) {
+        int k = 0;
+        for (; k < 80 && i + k < ref_len; k++) line[k] = "ACGT"[ref[i + k] & 3];
+        line[k] = '\n';
+        fwrite(line, 1, (size_t)k + 1, f);
+    }
+    return fclose(f);
+}
+
+int gab_gen_fmi_write_fastq(const char *path, const uint8_t *enc, int32_t stride, const int32_t *len, int64_t n) {
+    FILE *f = fopen(path, "w");
+    if (!f) return -1;
+    char *s = (char *)malloc((size_t)stride + 2), *q = (char *)malloc((size_t)stride + 2);
+    for (int64_t i = 0; i < n; i++) {
+        int L = len[i];
+        for (int k = 0; k < L; k++) { s[k] = "ACGTN"[enc[i * stride + k] > 4 ? 4 : enc[i * stride + k]]; q[k] = 'I'; }
+        s[L] = q[L] = 0;
+        fprintf(f, "@r%lld\n%s\n+\n%s\n", (long long)i, s, q);
+    }
+    free(s); free(q);
+    return fclose(f);
+}

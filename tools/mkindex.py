@@ -1,0 +1,56 @@
+"""ctypes front-end of tools/mkindex (FM-index builder in the BWA-MEM2 .bwt.2bit.64 layout)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "mkindex")
+_lib = None
+
+
+class GabFmIndex(C.Structure):
+    _fields_ = [("ref_seq_len", C.c_int64), ("count", C.c_int64 * 5), ("cp_occ_size", C.c_int64),
+                ("cp_occ", C.c_void_p), ("sentinel_index", C.c_int64), ("n_sa", C.c_int64),
+                ("sa_ms_byte", C.c_void_p), ("sa_ls_word", C.c_void_p)]
+
+
+def build_tools():
+    so = os.path.join(_DIR, "libgabmkindex.so")
+    if not os.path.exists(so) or not os.path.exists(os.path.join(_DIR, "gab-mkindex")):
+        subprocess.check_call(["make", "-C", _DIR, "-s"])
+    return so
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = C.CDLL(build_tools())
+    return _lib
+
+
+class FmIndex:
+    """in-memory index: ref_seq_len, count[5] (file convention, not yet +1), cp_occ bytes, sentinel_index"""
+
+    def __init__(self, fwd_codes):
+        fwd = np.ascontiguousarray(fwd_codes, np.uint8)
+        self._raw = GabFmIndex()
+        rc = lib().gab_mkindex_build(fwd.ctypes.data_as(C.c_void_p), C.c_int64(len(fwd)), C.byref(self._raw))
+        if rc:
+            raise RuntimeError(f"gab_mkindex_build failed ({rc})")
+        r = self._raw
+        self.ref_seq_len = r.ref_seq_len
+        self.count = np.array(list(r.count), np.int64)
+        self.sentinel_index = r.sentinel_index
+        self.cp_occ = np.ctypeslib.as_array(C.cast(r.cp_occ, C.POINTER(C.c_uint8)), shape=(r.cp_occ_size * 64,))
+
+    def write(self, prefix):
+        if lib().gab_mkindex_write(C.byref(self._raw), prefix.encode()):
+            raise IOError(f"cannot write {prefix}.bwt.2bit.64")
+
+    def close(self):
+        if self._raw.cp_occ:
+            lib().gab_mkindex_free(C.byref(self._raw))
+            self.cp_occ = None
+
+    __del__ = close
