@@ -439,7 +439,123 @@ class WfaWorkload:
                 "sample": f"first {n} pairs, oracle/wfa.c + OpenMP ({sec:.2f} s)"}
 
 
-WORKLOADS = {"wfa": WfaWorkload, "bpm": BpmWorkload, "bsw": BswWorkload, "chain": ChainWorkload, "fast-chain": FastChainWorkload}
+# ------------------------------------------------------------------------------------- fmi
+class FmiWorkload:
+    name = "fmi"
+    metric = "fmi ROI M reads/sec"
+    unit = "M reads/s"
+    dtype = "i64"
+    default_items = 10_000_000
+    seed = 6
+    ref_mbp = int(os.environ.get("GAB_FMI_REF_MBP", "256"))   # synthetic reference size (>= 256 Mbp)
+    readlen = 151
+    min_seed_len = 19
+
+    def __init__(self, items, rank, dev):
+        import torch
+        from tools import gabgen, mkindex
+        from genarchbench_amd.fmi import FMI_search
+        self.items = items
+        t0 = time.time()
+        self.ref = gabgen.fmi_ref(self.seed, self.ref_mbp * 1_000_000, 5)
+        self.reads = gabgen.fmi_reads(self.seed + 1, self.ref, items, self.readlen, self.readlen, first=rank * items)
+        log(f"[rank {rank}] generated {self.ref_mbp} Mbp reference + {items} reads in {time.time() - t0:.1f}s")
+        t0 = time.time()
+        self.index = mkindex.FmIndex(self.ref)          # outside the ROI, like load_index in the reference
+        log(f"[rank {rank}] built the FM-index ({self.index.ref_seq_len} rows, "
+            f"{len(self.index.cp_occ) / 2**20:.0f} MiB of CP_OCC) in {time.time() - t0:.1f}s")
+        self.eng = FMI_search(arrays=(self.index.ref_seq_len, self.index.count, self.index.cp_occ, self.index.sentinel_index),
+                              device=dev.index or 0)
+        self.enc = torch.from_numpy(self.reads.enc).to(dev)
+        self.len = torch.from_numpy(self.reads.len).to(dev)
+        self.kernel_ms = []
+        self.stats = {}
+        self.result = None
+
+    def step(self, stream):
+        self.result = self.eng.seed_device(self.enc, self.len, self.min_seed_len, stream=stream)
+
+    def after_step(self, timed):
+        st = self.eng.last_stats()
+        if timed:
+            self.kernel_ms.append(st["kernel_ms"])
+        self.stats = st
+
+    def check(self):
+        import ctypes as C
+        from oracle import pyoracle
+        from tools import gabgen
+        from genarchbench_amd.fmi import SMEM_DTYPE
+        d_out, d_off, n = self.result
+        hip = C.CDLL("libamdhip64.so")
+        off = np.zeros(self.items + 1, np.int64)
+        assert hip.hipMemcpy(off.ctypes.data_as(C.c_void_p), C.c_void_p(d_off), C.c_size_t(8 * (self.items + 1)), C.c_int(2)) == 0
+        assert off[-1] == n and (np.diff(off) >= 0).all(), "read offsets are not a prefix sum"
+        nr = min(20000, self.items)
+        k = int(off[nr])
+        host = np.zeros(max(k, 1) * 40, np.uint8)
+        assert hip.hipMemcpy(host.ctypes.data_as(C.c_void_p), C.c_void_p(d_out), C.c_size_t(k * 40), C.c_int(2)) == 0
+        got = host[:k * 40].view(SMEM_DTYPE)
+        oidx = pyoracle.FmIndex()
+        cnt = (C.c_int64 * 5)(*[int(x) for x in self.index.count])
+        pyoracle.lib().oracle_fmi_from_arrays(C.byref(oidx), C.c_int64(self.index.ref_seq_len), cnt,
+                                              self.index.cp_occ.ctypes.data_as(C.c_void_p), C.c_int64(self.index.sentinel_index))
+        sub = gabgen.ReadBatch(self.reads.enc[:nr], self.reads.len[:nr])
+        w, woff = pyoracle.fmi(oidx, sub, self.min_seed_len)
+        assert np.array_equal(off[:nr + 1], woff) and all(np.array_equal(got[f], w[f]) for f in ("rid", "m", "n", "k", "l", "s")), \
+            "fmi HIP output differs from the oracle"
+        return f"bit-exact SMEM records vs oracle on the first {nr} reads ({k} SMEMs); offsets consistent on all {self.items}"
+
+    def extra(self, ms_per_step):
+        e = self.stats.get("ext_calls", 0)
+        k = float(np.mean(self.kernel_ms))
+        return {"backward_ext_per_step": e, "smems_per_step": self.stats.get("smems"),
+                "index_bytes": int(len(self.index.cp_occ)), "ref_mbp": self.ref_mbp,
+                "g_ext_per_s": round(e / (k * 1e6), 3), "dominant_kernel": "fmi_seed_kernel", "dominant_kernel_ms": k}
+
+    def roofline(self):
+        k = float(np.mean(self.kernel_ms))
+        e = self.stats.get("ext_calls", 0)
+        # readlen + 40 B x SMEMs streaming + 128 B x backwardExt calls of random index traffic
+        alg = self.items * self.readlen + 40 * self.stats.get("smems", 0) + 128 * e
+        ach = alg / (k * 1e-3) / 1e9
+        return {"bound": "hbm", "achieved": round(ach, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(ach / HBM_PEAK_GBS, 6), "traffic": None,
+                "note": "dominated by 2 random 64-B CP_OCC reads per backwardExt (index >> 256 MiB Infinity Cache)"}
+
+    def cpu_baseline(self, cores):
+        import ctypes as C
+        from oracle import pyoracle
+        from tools import gabgen
+        exe = pyoracle.ref_path("fmi_ref")
+        n = min(self.items, 400_000)
+        sub = gabgen.ReadBatch(self.reads.enc[:n], self.reads.len[:n])
+        if exe:
+            with tempfile.TemporaryDirectory() as td:
+                prefix = os.path.join(td, "ref")
+                self.index.write(prefix, with_bns=True)
+                fq = os.path.join(td, "reads.fq")
+                gabgen.fmi_write_fastq(fq, sub)
+                env = dict(os.environ, OMP_PROC_BIND="true", OMP_PLACES="cores")
+                r = subprocess.run([exe, prefix, fq, "512", str(self.min_seed_len), str(cores)], capture_output=True,
+                                   text=True, env=env)
+                m = re.search(r"Computing time: ([\d.eE+-]+) s", r.stdout)
+                if r.returncode == 0 and m and "realloc" not in r.stdout.split("totalSmems")[0]:
+                    sec = float(m.group(1))
+                    return {"value": round(n / sec / 1e6, 4), "unit": self.unit, "cores": cores, "kind": "reference",
+                            "sample": f"first {n} reads of the same seeded input against the same index, reference fmi "
+                                      f"<idx> <fq> 512 {self.min_seed_len} {cores}, its own Computing time ({sec:.2f} s)"}
+                log("reference binary failed / hit its realloc path, using the oracle port:", r.stderr[-200:])
+        oidx = pyoracle.FmIndex()
+        cnt = (C.c_int64 * 5)(*[int(x) for x in self.index.count])
+        pyoracle.lib().oracle_fmi_from_arrays(C.byref(oidx), C.c_int64(self.index.ref_seq_len), cnt,
+                                              self.index.cp_occ.ctypes.data_as(C.c_void_p), C.c_int64(self.index.sentinel_index))
+        t0 = time.time(); pyoracle.fmi(oidx, sub, self.min_seed_len, threads=cores); sec = time.time() - t0
+        return {"value": round(n / sec / 1e6, 4), "unit": self.unit, "cores": cores, "kind": "port",
+                "sample": f"first {n} reads, oracle/fmi.c + OpenMP ({sec:.2f} s)"}
+
+
+WORKLOADS = {"fmi": FmiWorkload, "wfa": WfaWorkload, "bpm": BpmWorkload, "bsw": BswWorkload, "chain": ChainWorkload, "fast-chain": FastChainWorkload}
 
 
 def main():

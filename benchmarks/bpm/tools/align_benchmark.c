@@ -1,0 +1,100 @@
+/* align_benchmark (bpm) -- drop-in driver of the bpm benchmark on MI355X.
+ *
+ * Command line, input format, output lines and the timing line the harness greps are those of
+ * /root/reference/benchmarks/bpm/tools/align_benchmark.c:
+ *     align_benchmark -a bpm-edit -i <input> [-o <output>] [-t <threads>] [-g <gpus>]
+ * output "[id] score=%d" per pair (the harness sorts by id, bpm/scripts/regression_small.sh:94), stderr
+ * "[Benchmark]", "=> Total.reads", "=> Time.Benchmark" formatted like timer_print
+ * (bpm/system/profiler_timer.c:110-175).  Only -a bpm-edit is implemented (the regression scripts use
+ * nothing else); the BitPAl variants are reported as unsupported.
+ * The per-pair ROI call benchmark_edit_bpm (align_benchmark.c:243-257) becomes gab_bpm_run on chunks of
+ * pairs, one host thread per GPU.  The driver applies the reference's swap: the longer line is the pattern.
+ */
+#include "../../common/gab_pairs.h"
+#include <getopt.h>
+
+#define CHUNK_PAIRS (1 << 20)
+typedef struct {
+    const gab_pairs *p;
+    int64_t *poff, *toff; int32_t *plen, *tlen;
+    int32_t *score;
+} bpm_ctx;
+static void *gpu_init(int gpu, void *c) { (void)c; gab_bpm *h = NULL; GAB_DIE_IF(gab_bpm_create(gpu, &h), "gab_bpm_create"); return h; }
+static void gpu_fini(int gpu, void *c, void *st) { (void)gpu; (void)c; gab_bpm_destroy((gab_bpm *)st); }
+static void run_chunk(int gpu, int64_t chunk, void *vctx, void *st) {
+    (void)gpu;
+    bpm_ctx *c = (bpm_ctx *)vctx;
+    const int64_t b = chunk * CHUNK_PAIRS, e = b + CHUNK_PAIRS < c->p->n ? b + CHUNK_PAIRS : c->p->n;
+    GAB_DIE_IF(gab_bpm_run((gab_bpm *)st, c->p->slab, c->poff + b, c->plen + b, c->p->slab, c->toff + b, c->tlen + b, e - b,
+                           c->score + b), "gab_bpm_run");
+}
+static void timer_print_like(FILE *f, double sec) {
+    const double ns = sec * 1e9;
+    if (ns >= 60e9) fprintf(f, "%7.2f m ", sec / 60.0);
+    else if (ns >= 1e9) fprintf(f, "%7.2f s ", sec);
+    else if (ns >= 1e6) fprintf(f, "%7.2f ms", sec * 1e3);
+    else if (ns >= 1e3) fprintf(f, "%7.2f us", sec * 1e6);
+    else fprintf(f, "%7.0f ns", ns);
+    fprintf(f, " (    1   call,");
+    if (ns > 1e9) fprintf(f, "%7.2f  s/call {min%.2fs,Max%.2fs})\n", sec, sec, sec);
+    else if (ns > 1e6) fprintf(f, "%7.2f ms/call {min%.2fms,Max%.2fms})\n", sec * 1e3, sec * 1e3, sec * 1e3);
+    else fprintf(f, "%7.2f us/call {min%.2fus,Max%.2fus})\n", sec * 1e6, sec * 1e6, sec * 1e6);
+}
+int main(int argc, char **argv) {
+    const char *algo = NULL, *input = NULL, *output = NULL;
+    int threads = 1, gpus = 0, c;
+    static struct option lo[] = {{"algorithm", required_argument, 0, 'a'}, {"input", required_argument, 0, 'i'},
+                                 {"output", required_argument, 0, 'o'}, {"threads", required_argument, 0, 't'},
+                                 {"gpus", required_argument, 0, 'g'}, {"progress", required_argument, 0, 'P'},
+                                 {"verbose", no_argument, 0, 'v'}, {"help", no_argument, 0, 'h'}, {0, 0, 0, 0}};
+    if (argc <= 1) { fprintf(stderr, "USE: ./align_benchmark -a <algorithm> -i <input> [-o <output>] [-t <threads>] [-g <gpus>]\n"); exit(0); }
+    while ((c = getopt_long(argc, argv, "a:i:o:t:g:P:vh", lo, NULL)) != -1) {
+        switch (c) {
+            case 'a': algo = optarg; break;
+            case 'i': input = optarg; break;
+            case 'o': output = optarg; break;
+            case 't': threads = atoi(optarg); break;
+            case 'g': gpus = atoi(optarg); break;
+            case 'P': case 'v': break;
+            case 'h': fprintf(stderr, "USE: ./align_benchmark -a bpm-edit -i <input> [-o <output>] [-t <threads>] [-g <gpus>]\n"); exit(1);
+            default: fprintf(stderr, "Option not recognized\n"); exit(1);
+        }
+    }
+    (void)threads;
+    if (!algo) { fprintf(stderr, "Option --algorithm is required \n"); exit(1); }
+    if (strcmp(algo, "bpm-edit") != 0) { fprintf(stderr, "Algorithm '%s' is not available in the MI355X driver (only bpm-edit)\n", algo); exit(1); }
+    if (!input) { fprintf(stderr, "Option --input is required \n"); exit(1); }
+    FILE *in = fopen(input, "r");
+    if (!in) { fprintf(stderr, "Input file '%s' couldn't be opened\n", input); exit(1); }
+    FILE *out = output ? fopen(output, "w") : NULL;
+    gab_pairs p;
+    gab_pairs_read(in, &p);
+    fclose(in);
+    bpm_ctx ctx;
+    ctx.p = &p;
+    ctx.poff = (int64_t *)malloc(8 * (size_t)p.n + 8); ctx.toff = (int64_t *)malloc(8 * (size_t)p.n + 8);
+    ctx.plen = (int32_t *)malloc(4 * (size_t)p.n + 4); ctx.tlen = (int32_t *)malloc(4 * (size_t)p.n + 4);
+    ctx.score = (int32_t *)malloc(4 * (size_t)p.n + 4);
+    for (int64_t i = 0; i < p.n; i++) {          /* swap: the longer LINE is the pattern (align_benchmark.c:177-181) */
+        const int sw = p.len1[i] < p.len2[i];
+        ctx.poff[i] = sw ? p.off2[i] : p.off1[i]; ctx.plen[i] = sw ? p.len2[i] : p.len1[i];
+        ctx.toff[i] = sw ? p.off1[i] : p.off2[i]; ctx.tlen[i] = sw ? p.len1[i] : p.len2[i];
+    }
+    const int ngpus = gab_pick_gpus(gpus);
+    gab_queue q;
+    gab_queue_open(&q, ngpus, gpu_init, run_chunk, gpu_fini, &ctx);
+    const double t0 = gab_now();                 /* ROI: align_benchmark.c:213-337 */
+    gab_roi_begin();
+    gab_queue_run(&q, (p.n + CHUNK_PAIRS - 1) / CHUNK_PAIRS);
+    gab_roi_end();
+    const double sec = gab_now() - t0;
+    gab_queue_close(&q);
+    if (out) { for (int64_t i = 0; i < p.n; i++) fprintf(out, "[%ld] score=%d\n", (long)i, ctx.score[i]); fclose(out); }
+    fprintf(stderr, "[Benchmark]\n");
+    fprintf(stderr, "=> Total.reads            %ld\n", (long)p.n);
+    fprintf(stderr, "=> Time.Benchmark      ");
+    timer_print_like(stderr, sec);
+    free(ctx.poff); free(ctx.toff); free(ctx.plen); free(ctx.tlen); free(ctx.score);
+    gab_pairs_free(&p);
+    return 0;
+}

@@ -1,0 +1,27 @@
+#!/bin/bash
+# BSW regression on the small input: runs the MI355X driver at 1 GPU (and at $GAB_REGRESSION_GPUS if set) and
+# diffs its output with the expected file of the data set, exactly like the reference's script of the same name.
+inputs_path="$GENARCH_BENCH_INPUTS_ROOT/bsw/small"
+if [[ -z "$GENARCH_BENCH_INPUTS_ROOT" || ! -d "$inputs_path" ]]; then
+    echo "ERROR: You have not set a valid input folder $inputs_path"
+    exit 1
+fi
+scriptfolder="$(dirname "$(realpath "$0")")"
+binaries_path="$(dirname "$scriptfolder")"
+clean=1
+job="BSW-REGRESSION-SMALL"
+before_command=""
+commands=( "$binaries_path/main_bsw" )
+parallelism=( 'nodes=1, mpi=1, omp=1, gpus=1' )
+[[ -n "$GAB_REGRESSION_GPUS" ]] && parallelism+=( "nodes=1, mpi=1, omp=1, gpus=$GAB_REGRESSION_GPUS" )
+command_opts="-pairs \"$inputs_path/bandedSWA_SRR7733443_100k_input.txt\" -t \$OMP_NUM_THREADS -b 512"
+before_run() ( job_name="$1" )
+after_run() (
+    job_name="$1"
+    kernel_time="$(grep "Overall SW cycles" "$job_name.out" | cut -d " " -f 6)"
+    if [[ -f "$inputs_path/output-reference.file" ]]; then
+        grep "score=" "$job_name.err" | diff --brief - "$inputs_path/output-reference.file" >/dev/null 2>&1 || { echo "The output file is not identical to the reference file"; return 1; }
+    fi
+    echo "Kernel execution time $kernel_time s"; return 0
+)
+source "$scriptfolder/../../run_wrapper.sh"

@@ -1,0 +1,155 @@
+/* chain / fast-chain -- drop-in driver of the two seed-chaining benchmarks on MI355X.
+ *
+ * Same command line (-i in -o out -t threads [-h]), input/output format and timing line as
+ * /root/reference/benchmarks/chain/src/main.cpp and fast-chain/src/main.cpp (the two are byte-identical);
+ * text I/O as chain/src/host_data_io.cpp:13-60.  The harness compares out.txt and greps "Time in kernel"
+ * (chain/scripts/regression_small.sh:89,94).
+ * The ROI call host_chain_kernel(calls, rets, numThreads) (main.cpp:154) becomes gab_chain_run over chunks
+ * of calls pulled by one host thread per GPU.  Built twice: -DGAB_CHAIN_MODE=0 (chain) and =1 (fast-chain).
+ * Extra flag: -g <gpus> (or $GAB_GPUS).  -t is accepted and ignored.
+ */
+#include "../../common/gab_driver.h"
+#include <getopt.h>
+
+#ifndef GAB_CHAIN_MODE
+#define GAB_CHAIN_MODE GAB_CHAIN
+#endif
+
+typedef struct {
+    const uint64_t *x, *y;
+    const int64_t *call_off;
+    const gab_chain_hdr *hdr;
+    int32_t *score, *parent;
+    int64_t ncalls;
+    int64_t *chunk_beg;      /* chunk c = calls [chunk_beg[c], chunk_beg[c+1]) */
+} chain_ctx;
+
+static void *gpu_init(int gpu, void *vctx) {
+    (void)vctx;
+    gab_chain *h = NULL;
+    GAB_DIE_IF(gab_chain_create(gpu, &h), "gab_chain_create");
+    return h;
+}
+static void gpu_fini(int gpu, void *vctx, void *st) { (void)gpu; (void)vctx; gab_chain_destroy((gab_chain *)st); }
+static void run_chunk(int gpu, int64_t chunk, void *vctx, void *st) {
+    (void)gpu;
+    chain_ctx *c = (chain_ctx *)vctx;
+    const int64_t b = c->chunk_beg[chunk], e = c->chunk_beg[chunk + 1];
+    if (e <= b) return;
+    /* window of the anchor arrays owned by these calls; offsets re-based to the window */
+    const int64_t a0 = c->call_off[b], a1 = c->call_off[e - 1] + c->hdr[e - 1].n;
+    int64_t *off = (int64_t *)malloc(8 * (size_t)(e - b));
+    for (int64_t k = b; k < e; k++) off[k - b] = c->call_off[k] - a0;
+    (void)a1;
+    GAB_DIE_IF(gab_chain_run((gab_chain *)st, GAB_CHAIN_MODE, c->x + a0, c->y + a0, off, c->hdr + b, e - b,
+                             c->score + a0, c->parent + a0), "gab_chain_run");
+    free(off);
+}
+
+static void help(void) {
+    fprintf(stderr,
+        "Usage: chain [OPTION]...\n"
+        "Options:\n"
+        "        -i <file>\n"
+        "            input file\n"
+        "        -o <file>\n"
+        "            output file\n"
+        "        -t <int>\n"
+        "            number of CPU threads (ignored: the kernel runs on the GPU)\n"
+        "        -g <int>\n"
+        "            number of GPUs (default $GAB_GPUS or 1)\n"
+        "        -h \n"
+        "            prints the usage\n");
+}
+
+static void skip_to_EOR(FILE *fp) {
+    const char *loc = "EOR";
+    int ch;
+    while (*loc != '\0' && (ch = fgetc(fp)) != EOF)
+        if (ch == *loc) loc++;
+}
+
+int main(int argc, char **argv) {
+    const char *in_name = "", *out_name = "";
+    int opt, numThreads = 1, gpus = 0;
+    while ((opt = getopt(argc, argv, ":i:o:t:g:h")) != -1) {
+        switch (opt) {
+            case 'i': in_name = optarg; break;
+            case 'o': out_name = optarg; break;
+            case 't': numThreads = atoi(optarg); break;
+            case 'g': gpus = atoi(optarg); break;
+            case 'h': help(); return 0;
+            default: help(); return 1;
+        }
+    }
+    if (argc == 1 || argc != optind) { help(); exit(EXIT_FAILURE); }
+    fprintf(stderr, "Input file: %s\n", in_name);
+    fprintf(stderr, "Output file: %s\n", out_name);
+    FILE *in = fopen(in_name, "r"), *out = fopen(out_name, "w");
+    if (!in || !out) { fprintf(stderr, "ERROR: cannot open %s\n", !in ? in_name : out_name); exit(EXIT_FAILURE); }
+
+    /* read_call (host_data_io.cpp:13-51): 6 header fields, n x "x y", then everything up to "EOR" */
+    size_t ccap = 1024, acap = 1 << 20, ncalls = 0, na = 0;
+    gab_chain_hdr *hdr = (gab_chain_hdr *)malloc(ccap * sizeof(*hdr));
+    int64_t *call_off = (int64_t *)malloc(ccap * 8);
+    uint64_t *x = (uint64_t *)malloc(acap * 8), *y = (uint64_t *)malloc(acap * 8);
+    for (;;) {
+        long long n; float avg; int mdx, mdy, bw, nsegs;
+        if (fscanf(in, "%lld%f%d%d%d%d", &n, &avg, &mdx, &mdy, &bw, &nsegs) != 6) break;
+        if (ncalls == ccap) { ccap *= 2; hdr = (gab_chain_hdr *)realloc(hdr, ccap * sizeof(*hdr)); call_off = (int64_t *)realloc(call_off, ccap * 8); }
+        while (na + (size_t)n > acap) { acap *= 2; x = (uint64_t *)realloc(x, acap * 8); y = (uint64_t *)realloc(y, acap * 8); }
+        hdr[ncalls].n = n; hdr[ncalls].avg_qspan = avg; hdr[ncalls].max_dist_x = mdx; hdr[ncalls].max_dist_y = mdy;
+        hdr[ncalls].bw = bw; hdr[ncalls].n_segs = nsegs;
+        call_off[ncalls] = (int64_t)na;
+        for (long long i = 0; i < n; i++) {
+            unsigned long long xx = 0, yy = 0;
+            if (fscanf(in, "%llu%llu", &xx, &yy) != 2) { xx = 0; yy = 0; }
+            x[na + (size_t)i] = xx; y[na + (size_t)i] = yy;
+        }
+        na += (size_t)n;
+        ncalls++;
+        skip_to_EOR(in);
+    }
+    fprintf(stderr, "Running with threads: %d\n", numThreads);
+
+    chain_ctx ctx;
+    ctx.x = x; ctx.y = y; ctx.call_off = call_off; ctx.hdr = hdr; ctx.ncalls = (int64_t)ncalls;
+    ctx.score = (int32_t *)malloc(4 * (na + 1)); ctx.parent = (int32_t *)malloc(4 * (na + 1));
+    const int ngpus = gab_pick_gpus(gpus);
+    /* chunks of ~equal anchor count; with one GPU everything is one call (longest-call-first inside) */
+    const int64_t nchunks_want = ngpus == 1 ? 1 : 8 * ngpus;
+    ctx.chunk_beg = (int64_t *)malloc(8 * (size_t)(nchunks_want + 2));
+    int64_t nchunks = 0;
+    {
+        const size_t per = na / (size_t)nchunks_want + 1;
+        size_t acc = 0;
+        ctx.chunk_beg[0] = 0;
+        for (size_t c = 0; c < ncalls; c++) {
+            acc += (size_t)hdr[c].n;
+            if (acc >= per && nchunks + 1 < nchunks_want) { ctx.chunk_beg[++nchunks] = (int64_t)c + 1; acc = 0; }
+        }
+        ctx.chunk_beg[++nchunks] = (int64_t)ncalls;
+    }
+    gab_queue q;
+    gab_queue_open(&q, ngpus, gpu_init, run_chunk, gpu_fini, &ctx);
+
+    /* ---- region of interest (main.cpp:111-193) ---- */
+    const double t0 = gab_now();
+    gab_roi_begin();
+    gab_queue_run(&q, nchunks);
+    gab_roi_end();
+    const double runtime = gab_now() - t0;
+    gab_queue_close(&q);
+
+    /* print_return (host_data_io.cpp:53-60) */
+    for (size_t c = 0; c < ncalls; c++) {
+        fprintf(out, "%lld\n", (long long)hdr[c].n);
+        const int64_t o = call_off[c];
+        for (int64_t i = 0; i < hdr[c].n; i++) fprintf(out, "%d\t%d\n", ctx.score[o + i], ctx.parent[o + i]);
+        fprintf(out, "EOR\n");
+    }
+    fprintf(stderr, "Time in kernel: %.2f sec\n", runtime);
+    fclose(in); fclose(out);
+    free(hdr); free(call_off); free(x); free(y); free(ctx.score); free(ctx.parent); free(ctx.chunk_beg);
+    return 0;
+}

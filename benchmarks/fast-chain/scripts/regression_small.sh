@@ -1,0 +1,25 @@
+#!/bin/bash
+# FAST-CHAIN regression on the small input: runs the MI355X driver at 1 GPU (and at $GAB_REGRESSION_GPUS if set) and
+# diffs its output with the expected file of the data set, exactly like the reference's script of the same name.
+inputs_path="$GENARCH_BENCH_INPUTS_ROOT/chain/small"
+if [[ -z "$GENARCH_BENCH_INPUTS_ROOT" || ! -d "$inputs_path" ]]; then
+    echo "ERROR: You have not set a valid input folder $inputs_path"
+    exit 1
+fi
+scriptfolder="$(dirname "$(realpath "$0")")"
+binaries_path="$(dirname "$scriptfolder")"
+clean=1
+job="FAST-CHAIN-REGRESSION-SMALL"
+before_command=""
+commands=( "$binaries_path/chain" )
+parallelism=( 'nodes=1, mpi=1, omp=1, gpus=1' )
+[[ -n "$GAB_REGRESSION_GPUS" ]] && parallelism+=( "nodes=1, mpi=1, omp=1, gpus=$GAB_REGRESSION_GPUS" )
+command_opts="-i \"$inputs_path/in-1k.txt\" -o out.txt -t \$OMP_NUM_THREADS"
+before_run() ( job_name="$1" )
+after_run() (
+    job_name="$1"
+    kernel_time="$(grep "Time in kernel" "$job_name.err" | cut -d " " -f 4)"
+    diff --brief out.txt "$inputs_path/out-reference-no-heuristics-32b.txt" >/dev/null 2>&1 || { echo "The output file is not identical to the reference file"; return 1; }
+    echo "Kernel execution time $kernel_time s"; return 0
+)
+source "$scriptfolder/../../run_wrapper.sh"

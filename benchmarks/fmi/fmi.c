@@ -1,0 +1,111 @@
+/* fmi -- drop-in driver of the fmi benchmark on MI355X.
+ *
+ *     fmi <ref_prefix> <reads.fastq[.gz]> <batch_size> <minSeedLen> <n_threads>       [$GAB_GPUS = gpus]
+ *
+ * Positional arguments, the six stdout header lines and the "rid:" / "[m,n+1]" data lines are those of
+ * /root/reference/benchmarks/fmi/fmi.cpp:74-475 (the harness drops the six header lines and diffs the rest,
+ * fmi/scripts/regression_small.sh:91,97-98).  <ref_prefix>.bwt.2bit.64 is BWA-MEM2's own index file; it is
+ * loaded and replicated on every GPU before the ROI, as load_index precedes begin_computing in the reference.
+ * The per-batch ROI body (getSMEMsAllPos -> re-seed -> bwtSeedStrategy -> sortSMEMs, fmi.cpp:288-348) becomes
+ * gab_fmi_seed on chunks of reads, one host thread per GPU; batch_size and n_threads only shaped the CPU
+ * scheduling and are accepted and ignored.
+ */
+#include "../common/gab_driver.h"
+#include <zlib.h>
+
+#define CHUNK_READS (1 << 20)
+typedef struct {
+    const char *prefix; const uint8_t *enc; int32_t stride; const int32_t *len; int64_t n; int32_t msl;
+    gab_smem **out; int64_t *nout;      /* per chunk */
+} fmi_ctx;
+static void *gpu_init(int gpu, void *c) { gab_fmi *h = NULL; GAB_DIE_IF(gab_fmi_load(gpu, ((fmi_ctx *)c)->prefix, &h), "gab_fmi_load"); return h; }
+static void gpu_fini(int gpu, void *c, void *st) { (void)gpu; (void)c; gab_fmi_destroy((gab_fmi *)st); }
+static void run_chunk(int gpu, int64_t chunk, void *vctx, void *st) {
+    (void)gpu;
+    fmi_ctx *c = (fmi_ctx *)vctx;
+    const int64_t b = chunk * CHUNK_READS, e = b + CHUNK_READS < c->n ? b + CHUNK_READS : c->n;
+    GAB_DIE_IF(gab_fmi_seed((gab_fmi *)st, c->enc + b * c->stride, c->stride, c->len + b, e - b, c->msl, &c->out[chunk],
+                            &c->nout[chunk]), "gab_fmi_seed");
+    for (int64_t i = 0; i < c->nout[chunk]; i++) c->out[chunk][i].rid += (uint32_t)b;      /* rid += batch offset, fmi.cpp:340-343 */
+}
+int main(int argc, char **argv) {
+    if (argc != 6) { printf("Need five arguments : ref_file query_set batch_size minSeedLen n_threads\n"); return 1; }
+    gzFile fp = gzopen(argv[2], "r");
+    if (fp == 0) { fprintf(stderr, "[E::%s] fail to open file `%s'.\n", __func__, argv[2]); exit(EXIT_FAILURE); }
+    printf("before reading sequences\n");
+    const double tr0 = gab_now();
+    /* FASTA / FASTQ records (what kseq yields): sequence = the line(s) after the header up to '+' or the next header */
+    size_t cap = 1 << 20, used = 0, rcap = 1 << 16;
+    char *seqs = (char *)malloc(cap);
+    int64_t *soff = (int64_t *)malloc(8 * rcap); int32_t *len = (int32_t *)malloc(4 * rcap);
+    int64_t n = 0;
+    {
+        char *line = (char *)malloc(1 << 20);
+        int state = 0;            /* 0: expect header, 1: in sequence, 2: in quality */
+        int64_t qleft = 0;
+        while (gzgets(fp, line, 1 << 20)) {
+            size_t l = strlen(line);
+            while (l && (line[l - 1] == '\n' || line[l - 1] == '\r')) line[--l] = 0;
+            if (state == 2) { qleft -= (int64_t)l; if (qleft <= 0) state = 0; continue; }
+            if ((line[0] == '>' || line[0] == '@') && state != 1) {
+                if ((size_t)n == rcap) { rcap *= 2; soff = (int64_t *)realloc(soff, 8 * rcap); len = (int32_t *)realloc(len, 4 * rcap); }
+                soff[n] = (int64_t)used; len[n] = 0; n++; state = 1; continue;
+            }
+            if (state == 1 && line[0] == '+') { state = 2; qleft = len[n - 1]; if (qleft == 0) state = 0; continue; }
+            if (state == 1 && (line[0] == '>' || line[0] == '@')) {   /* FASTA: next record */
+                if ((size_t)n == rcap) { rcap *= 2; soff = (int64_t *)realloc(soff, 8 * rcap); len = (int32_t *)realloc(len, 4 * rcap); }
+                soff[n] = (int64_t)used; len[n] = 0; n++; continue;
+            }
+            if (state == 1) {
+                while (used + l + 8 > cap) { cap *= 2; seqs = (char *)realloc(seqs, cap); }
+                memcpy(seqs + used, line, l); used += l; len[n - 1] += (int32_t)l;
+            }
+        }
+        free(line);
+        gzclose(fp);
+    }
+    if (n == 0) { printf("ERROR! seqs = NULL\n"); exit(EXIT_FAILURE); }
+    int max_rl = len[0], min_rl = len[0];
+    for (int64_t i = 1; i < n; i++) { if (len[i] > max_rl) max_rl = len[i]; if (len[i] < min_rl) min_rl = len[i]; }
+    if (max_rl <= 0 || max_rl >= GAB_FMI_MAX_READLEN) { fprintf(stderr, "ERROR: read length out of range (max %d)\n", max_rl); exit(EXIT_FAILURE); }
+    /* dense code matrix, fmi.cpp:121-151 */
+    uint8_t *enc = (uint8_t *)malloc((size_t)n * (size_t)max_rl);
+    for (int64_t r = 0; r < n; r++)
+        for (int k = 0; k < max_rl; k++) {
+            uint8_t code = 4;
+            if (k < len[r]) switch (seqs[soff[r] + k]) { case 'A': code = 0; break; case 'C': code = 1; break; case 'G': code = 2; break; case 'T': code = 3; break; default: code = 4; }
+            enc[r * max_rl + k] = code;
+        }
+    const int ngpus = gab_pick_gpus(0);
+    fmi_ctx ctx;
+    ctx.prefix = argv[1]; ctx.enc = enc; ctx.stride = max_rl; ctx.len = len; ctx.n = n; ctx.msl = atoi(argv[4]);
+    const int64_t nchunks = (n + CHUNK_READS - 1) / CHUNK_READS;
+    ctx.out = (gab_smem **)calloc((size_t)nchunks, sizeof(gab_smem *)); ctx.nout = (int64_t *)calloc((size_t)nchunks, 8);
+    gab_queue q;
+    gab_queue_open(&q, ngpus, gpu_init, run_chunk, gpu_fini, &ctx);       /* index load: before the ROI (fmi.cpp:102-105) */
+    const double tr1 = gab_now();
+    printf("numReads = %ld, max_readlength = %d, min_readlength = %d\n", (long)n, max_rl, min_rl);
+    printf("Running %d threads\n", atoi(argv[5]));
+    const double t0 = gab_now();                 /* ROI: fmi.cpp:236-362 */
+    gab_roi_begin();
+    gab_queue_run(&q, nchunks);
+    gab_roi_end();
+    const double t1 = gab_now();
+    gab_queue_close(&q);
+    int64_t total = 0;
+    for (int64_t c = 0; c < nchunks; c++) total += ctx.nout[c];
+    printf("totalSmems = %ld\n", (long)total);
+    printf("Reading time: %g s\n", tr1 - tr0);
+    printf("Computing time: %g s\n", t1 - t0);
+    int64_t prevRid = -1;                          /* fmi.cpp:430-460 */
+    for (int64_t c = 0; c < nchunks; c++)
+        for (int64_t i = 0; i < ctx.nout[c]; i++) {
+            const gab_smem s = ctx.out[c][i];
+            if ((int64_t)s.rid != prevRid) for (int64_t j = prevRid + 1; j <= (int64_t)s.rid; j++) printf("%u:\n", (unsigned)j);
+            prevRid = (int64_t)s.rid;
+            printf("[%u,%u]\n", s.m, s.n + 1);
+        }
+    for (int64_t c = 0; c < nchunks; c++) gab_fmi_free(ctx.out[c]);
+    free(ctx.out); free(ctx.nout); free(enc); free(seqs); free(soff); free(len);
+    return 0;
+}

@@ -1,0 +1,104 @@
+/* align_benchmark (wfa) -- drop-in driver of the wfa benchmark on MI355X.
+ *
+ * Command line, input format and output of /root/reference/benchmarks/wfa/tools/align_benchmark.c:
+ *     align_benchmark -i <input> [-o <output>] [-p M,X,O,E] [-t <threads>] [-g <gpus>]
+ * output "id=%d <run-length CIGAR>" per pair (edit_cigar_print, wfa/gap_affine/edit_cigar.c:184-200; the
+ * harness sorts by id, wfa/scripts/regression_small.sh:94); stdout "Total.reads:", "Time.Benchmark:",
+ * "Time.Alignment:" (align_benchmark.c:529-533).  Complete mode only: --minimum-wavefront-length /
+ * --maximum-difference-distance (adaptive reduction) are rejected.
+ * The per-pair ROI call affine_wavefronts_align (align_benchmark.c:415-437) becomes gab_wfa_run on chunks.
+ */
+#include "../../common/gab_pairs.h"
+#include <getopt.h>
+#include <sys/time.h>
+
+#define CHUNK_PAIRS (1 << 18)
+typedef struct { const gab_pairs *p; gab_wfa_penalties pen; char *ops; int64_t *ops_off; int32_t *ops_len, *score; } wfa_ctx;
+static void *gpu_init(int gpu, void *c) { gab_wfa *h = NULL; GAB_DIE_IF(gab_wfa_create(&((wfa_ctx *)c)->pen, gpu, &h), "gab_wfa_create"); return h; }
+static void gpu_fini(int gpu, void *c, void *st) { (void)gpu; (void)c; gab_wfa_destroy((gab_wfa *)st); }
+static void run_chunk(int gpu, int64_t chunk, void *vctx, void *st) {
+    (void)gpu;
+    wfa_ctx *c = (wfa_ctx *)vctx;
+    const int64_t b = chunk * CHUNK_PAIRS, e = b + CHUNK_PAIRS < c->p->n ? b + CHUNK_PAIRS : c->p->n;
+    GAB_DIE_IF(gab_wfa_run((gab_wfa *)st, c->p->slab, c->p->off1 + b, c->p->len1 + b, c->p->slab, c->p->off2 + b, c->p->len2 + b,
+                           e - b, c->ops, c->ops_off + b, c->ops_len + b, c->score + b), "gab_wfa_run");
+}
+static double tv_now(void) { struct timeval tv; gettimeofday(&tv, NULL); return (double)tv.tv_sec + 1e-6 * (double)tv.tv_usec; }
+int main(int argc, char **argv) {
+    const char *input = NULL, *output = NULL;
+    int threads = 1, gpus = 0, c;
+    wfa_ctx ctx;
+    ctx.pen.mismatch = 4; ctx.pen.gap_opening = 6; ctx.pen.gap_extension = 2;      /* align_benchmark.c:85-90 */
+    int match = 0;
+    static struct option lo[] = {{"input", required_argument, 0, 'i'}, {"output", required_argument, 0, 'o'},
+                                 {"affine-penalties", required_argument, 0, 'p'},
+                                 {"minimum-wavefront-length", required_argument, 0, 1000},
+                                 {"maximum-difference-distance", required_argument, 0, 1001},
+                                 {"nthreads", required_argument, 0, 't'}, {"gpus", required_argument, 0, 'g'},
+                                 {"progress", required_argument, 0, 'P'}, {"verbose", no_argument, 0, 'v'},
+                                 {"help", no_argument, 0, 'h'}, {0, 0, 0, 0}};
+    if (argc <= 1) { fprintf(stderr, "USE: ./align_benchmark -i <input> [-o <output>] [-p M,X,O,E] [-t <threads>] [-g <gpus>]\n"); exit(0); }
+    while ((c = getopt_long(argc, argv, "i:o:p:t:g:P:vh", lo, NULL)) != -1) {
+        switch (c) {
+            case 'i': input = optarg; break;
+            case 'o': output = optarg; break;
+            case 'p': {
+                char *s = strtok(optarg, ","); match = s ? atoi(s) : 0;
+                s = strtok(NULL, ","); if (s) ctx.pen.mismatch = atoi(s);
+                s = strtok(NULL, ","); if (s) ctx.pen.gap_opening = atoi(s);
+                s = strtok(NULL, ","); if (s) ctx.pen.gap_extension = atoi(s);
+                break;
+            }
+            case 1000: case 1001:
+                if (atoi(optarg) >= 0 || c == 1001) { fprintf(stderr, "Adaptive wavefront reduction is not available in the MI355X driver (complete mode only)\n"); exit(1); }
+                break;
+            case 't': threads = atoi(optarg); break;
+            case 'g': gpus = atoi(optarg); break;
+            case 'P': case 'v': break;
+            case 'h': fprintf(stderr, "USE: ./align_benchmark -i <input> [-o <output>] [-p M,X,O,E] [-t <threads>] [-g <gpus>]\n"); exit(1);
+            default: fprintf(stderr, "Option not recognized\n"); exit(1);
+        }
+    }
+    (void)threads;
+    if (match > 0) { fprintf(stderr, "Match score must be negative or zero (M=%d)\n", match); exit(1); }
+    if (!input) { fprintf(stderr, "Option --input is required \n"); exit(1); }
+    const double bench0 = tv_now();
+    FILE *in = fopen(input, "r");
+    if (!in) { fprintf(stderr, "Input file '%s' couldn't be opened\n", input); exit(1); }
+    FILE *out = output ? fopen(output, "w") : NULL;
+    gab_pairs p;
+    gab_pairs_read(in, &p);
+    fclose(in);
+    ctx.p = &p;
+    ctx.ops_off = (int64_t *)malloc(8 * (size_t)p.n + 8);
+    ctx.ops_len = (int32_t *)malloc(4 * (size_t)p.n + 4); ctx.score = (int32_t *)malloc(4 * (size_t)p.n + 4);
+    int64_t tot = 0;
+    for (int64_t i = 0; i < p.n; i++) { ctx.ops_off[i] = tot; tot += (int64_t)p.len1[i] + p.len2[i]; }
+    ctx.ops = (char *)malloc((size_t)tot + 16);
+    const int ngpus = gab_pick_gpus(gpus);
+    gab_queue q;
+    gab_queue_open(&q, ngpus, gpu_init, run_chunk, gpu_fini, &ctx);
+    const double t0 = tv_now();                  /* ROI: align_benchmark.c:378-491 */
+    gab_roi_begin();
+    gab_queue_run(&q, (p.n + CHUNK_PAIRS - 1) / CHUNK_PAIRS);
+    gab_roi_end();
+    const double t1 = tv_now();
+    gab_queue_close(&q);
+    if (out) {
+        for (int64_t i = 0; i < p.n; i++) {
+            fprintf(out, "id=%ld ", (long)i);
+            const char *o = ctx.ops + ctx.ops_off[i];
+            const int n = ctx.ops_len[i];
+            /* edit_cigar_print reads operations[begin] even when the CIGAR is empty; an empty pair prints nothing here */
+            for (int k = 0; k < n;) { int r = k; while (r < n && o[r] == o[k]) r++; fprintf(out, "%d%c", r - k, o[k]); k = r; }
+            fprintf(out, "\n");
+        }
+        fclose(out);
+    }
+    printf("Total.reads: %ld\n", (long)p.n);
+    printf("Time.Benchmark: %f s\n", tv_now() - bench0);
+    printf("Time.Alignment: %f s\n", t1 - t0);
+    free(ctx.ops); free(ctx.ops_off); free(ctx.ops_len); free(ctx.score);
+    gab_pairs_free(&p);
+    return 0;
+}

@@ -69,31 +69,57 @@ __device__ __forceinline__ int bpm_code(uint32_t ch, bool &clean) {
 
 __device__ __forceinline__ uint32_t ld_u32(const char *p) { uint32_t w; __builtin_memcpy(&w, p, 4); return w; }
 
+// Wave-aggregated "counters[cls] += 1" returning each lane's slot: one atomic per (wave, class present)
+// instead of one per lane (all 10 M pairs of the 151-bp workload share one class, i.e. one address).
+__device__ __forceinline__ uint32_t wave_class_add(uint32_t *counters, int cls, bool active) {
+    uint32_t slot = 0;
+    unsigned long long todo = __ballot(active);
+    const unsigned long long lt = (1ull << (threadIdx.x & 63)) - 1;
+    while (todo) {
+        const int leader = __builtin_ctzll(todo);
+        const int c = __shfl(cls, leader);
+        const unsigned long long same = __ballot(active && cls == c) & todo;
+        uint32_t base = 0;
+        if ((int)(threadIdx.x & 63) == leader) base = atomicAdd(&counters[c], (uint32_t)__popcll(same));
+        base = __shfl(base, leader);
+        if (active && cls == c) slot = base + (uint32_t)__popcll(same & lt);
+        todo &= ~same;
+    }
+    return slot;
+}
+
 // ---- pass 1: validate + count per class ---------------------------------------------------
 __global__ __launch_bounds__(256) void bpm_count(BpmIO io, BpmCounters *ct) {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (; i < io.n; i += stride) {
-        const int n = io.pat_len[i], m = io.txt_len[i];
-        const int64_t po = io.pat_off[i], to = io.txt_off[i];
-        const bool ok = n >= 1 && n <= GAB_BPM_MAX_PLEN && m >= 0 && m <= n && po >= 0 && to >= 0 &&
-                        ((po + n + 3) & ~3ll) <= io.pat_bytes && ((to + m + 3) & ~3ll) <= io.txt_bytes;
-        if (!ok) {
-            atomicAdd(&ct->bad, 1);
-            atomicMin((unsigned int *)&ct->first_bad, (unsigned int)(i + 1 > 0x7fffffff ? 0x7fffffff : i + 1));
-            continue;
+    // wave-uniform trip count so that the ballots inside wave_class_add see every lane
+    for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x; i0 < io.n; i0 += stride) {
+        const int64_t i = i0 + threadIdx.x;
+        bool ok = false;
+        int n = 1;
+        if (i < io.n) {
+            n = io.pat_len[i];
+            const int m = io.txt_len[i];
+            const int64_t po = io.pat_off[i], to = io.txt_off[i];
+            ok = n >= 1 && n <= GAB_BPM_MAX_PLEN && m >= 0 && m <= n && po >= 0 && to >= 0 &&
+                 ((po + n + 3) & ~3ll) <= io.pat_bytes && ((to + m + 3) & ~3ll) <= io.txt_bytes;
+            if (!ok) {
+                atomicAdd(&ct->bad, 1);
+                atomicMin((unsigned int *)&ct->first_bad, (unsigned int)(i + 1 > 0x7fffffff ? 0x7fffffff : i + 1));
+            }
         }
-        atomicAdd(&ct->cls_count[bpm_class(n)], 1u);
+        (void)wave_class_add(ct->cls_count, bpm_class(n), ok);
     }
 }
 
 // ---- pass 2: scatter ids by class ---------------------------------------------------------
 __global__ __launch_bounds__(256) void bpm_scatter(BpmIO io, BpmCounters *ct, uint32_t *perm) {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (; i < io.n; i += stride) {
-        const int n = io.pat_len[i];
-        perm[atomicAdd(&ct->cls_cursor[bpm_class(n)], 1u)] = (uint32_t)i;
+    for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x; i0 < io.n; i0 += stride) {
+        const int64_t i = i0 + threadIdx.x;
+        const bool in = i < io.n;
+        const int n = in ? io.pat_len[i] : 1;
+        const uint32_t slot = wave_class_add(ct->cls_cursor, bpm_class(n), in);
+        if (in) perm[slot] = (uint32_t)i;
     }
 }
 
@@ -142,6 +168,7 @@ __global__ __launch_bounds__(kBlock) void bpm_score(BpmIO io, const uint32_t *__
     __shared__ uint64_t peq_s[(4 * W + 1) * kBlock];
     const uint32_t k = kbeg + blockIdx.x * kBlock + threadIdx.x;
     unsigned long long steps = 0;
+    int64_t queue_id = -1;
     if (k < kend) {
         const uint32_t id = perm[k];
         const int n = io.pat_len[id], m = io.txt_len[id];
@@ -166,7 +193,18 @@ __global__ __launch_bounds__(kBlock) void bpm_score(BpmIO io, const uint32_t *__
         }
         steps = (unsigned long long)m * W;
         if (clean) score_out[id] = -score;
-        else worklist[atomicAdd(&ct->wl_count[W], 1u)] = id;
+        else queue_id = (int64_t)id;
+    }
+    {
+        // append the unclean pairs of this wave with one atomic
+        const unsigned long long q = __ballot(queue_id >= 0);
+        if (q) {
+            const int leader = __builtin_ctzll(q);
+            uint32_t base = 0;
+            if ((int)(threadIdx.x & 63) == leader) base = atomicAdd(&ct->wl_count[W], (uint32_t)__popcll(q));
+            base = __shfl(base, leader);
+            if (queue_id >= 0) worklist[base + (uint32_t)__popcll(q & ((1ull << (threadIdx.x & 63)) - 1))] = (uint32_t)queue_id;
+        }
     }
     for (int o = 32; o > 0; o >>= 1) steps += __shfl_xor(steps, o);
     if ((threadIdx.x & 63) == 0 && steps) atomicAdd(&ct->steps, steps);
@@ -185,7 +223,7 @@ __global__ __launch_bounds__(kBlock) void bpm_full(BpmIO io, const uint32_t *__r
                                                    int32_t *__restrict__ score_out, BpmCounters *ct) {
     __shared__ uint64_t peq_s[(REGW ? 4 * REGW + 1 : 1) * kBlock];
     const uint32_t s = blockIdx.x * kBlock + threadIdx.x;
-    if (s >= nslots) return;
+    if (s >= nslots) return;          // (no wave-level operation below needs the exited lanes)
     const uint32_t id = list[s];
     const int n = io.pat_len[id], m = io.txt_len[id];
     const char *p = io.pat + io.pat_off[id], *t = io.txt + io.txt_off[id];
@@ -244,7 +282,15 @@ __global__ __launch_bounds__(kBlock) void bpm_full(BpmIO io, const uint32_t *__r
     }
     ops += (h + 1) + (v + 1);
     score_out[id] = -ops;
-    atomicAdd(&ct->full_steps, (unsigned long long)m * Wd);
+    {
+        // one atomic per wave for the step counter (exec mask = lanes with a slot)
+        unsigned long long st = (unsigned long long)m * Wd;
+        const unsigned long long act = __ballot(true);
+        const int leader = __builtin_ctzll(act);
+        unsigned long long sum = 0;
+        for (unsigned long long r = act; r; r &= r - 1) sum += __shfl(st, __builtin_ctzll(r));
+        if ((int)(threadIdx.x & 63) == leader) atomicAdd(&ct->full_steps, sum);
+    }
 #undef HP
 #undef HM
 }
@@ -439,13 +485,15 @@ extern "C" int gab_bpm_run(gab_bpm *h, const char *pat, const int64_t *pat_off, 
     if (n == 0) return GAB_OK;
     GAB_CHECK(pat && pat_off && pat_len && txt && txt_off && txt_len && score_out, "gab_bpm_run: NULL buffer");
     gab_device_guard g(h->device);
-    int64_t pb = 0, tb = 0;
+    int64_t pb = 0, tb = 0, pa = INT64_MAX, ta = INT64_MAX;
     for (int64_t i = 0; i < n; i++) {
         GAB_CHECK(pat_off[i] >= 0 && txt_off[i] >= 0 && pat_len[i] >= 0 && txt_len[i] >= 0,
                   "gab_bpm_run: negative offset/length at pair %lld", (long long)i);
         pb = std::max(pb, pat_off[i] + pat_len[i]); tb = std::max(tb, txt_off[i] + txt_len[i]);
+        pa = std::min(pa, pat_off[i]); ta = std::min(ta, txt_off[i]);
     }
-    const size_t ppad = ((size_t)pb + 3 + 255) & ~(size_t)255, tpad = ((size_t)tb + 3 + 255) & ~(size_t)255;
+    pa &= ~(int64_t)255; ta &= ~(int64_t)255;      // stage only the referenced window [min, max) of each slab
+    const size_t ppad = ((size_t)(pb - pa) + 3 + 255) & ~(size_t)255, tpad = ((size_t)(tb - ta) + 3 + 255) & ~(size_t)255;
     const size_t nn = (size_t)n;
     size_t o = 0;
     const size_t o_p = o; o += ppad;
@@ -459,14 +507,14 @@ extern "C" int gab_bpm_run(gab_bpm *h, const char *pat, const int64_t *pat_off, 
     if (rc) return rc;
     char *b = h->io.as<char>();
     hipStream_t s = nullptr;
-    GAB_HIP(hipMemcpyAsync(b + o_p, pat, (size_t)pb, hipMemcpyHostToDevice, s));
-    GAB_HIP(hipMemcpyAsync(b + o_t, txt, (size_t)tb, hipMemcpyHostToDevice, s));
+    GAB_HIP(hipMemcpyAsync(b + o_p, pat + pa, (size_t)(pb - pa), hipMemcpyHostToDevice, s));
+    GAB_HIP(hipMemcpyAsync(b + o_t, txt + ta, (size_t)(tb - ta), hipMemcpyHostToDevice, s));
     GAB_HIP(hipMemcpyAsync(b + o_po, pat_off, 8 * nn, hipMemcpyHostToDevice, s));
     GAB_HIP(hipMemcpyAsync(b + o_to, txt_off, 8 * nn, hipMemcpyHostToDevice, s));
     GAB_HIP(hipMemcpyAsync(b + o_pl, pat_len, 4 * nn, hipMemcpyHostToDevice, s));
     GAB_HIP(hipMemcpyAsync(b + o_tl, txt_len, 4 * nn, hipMemcpyHostToDevice, s));
-    rc = gab_bpm_run_device(h, b + o_p, (int64_t)ppad, (const int64_t *)(b + o_po), (const int32_t *)(b + o_pl), b + o_t,
-                            (int64_t)tpad, (const int64_t *)(b + o_to), (const int32_t *)(b + o_tl), n,
+    rc = gab_bpm_run_device(h, b + o_p - pa, pa + (int64_t)ppad, (const int64_t *)(b + o_po), (const int32_t *)(b + o_pl),
+                            b + o_t - ta, ta + (int64_t)tpad, (const int64_t *)(b + o_to), (const int32_t *)(b + o_tl), n,
                             (int32_t *)(b + o_sc), s);
     if (rc) return rc;
     GAB_HIP(hipMemcpyAsync(score_out, b + o_sc, 4 * nn, hipMemcpyDeviceToHost, s));

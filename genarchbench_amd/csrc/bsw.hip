@@ -422,15 +422,18 @@ extern "C" int gab_bsw_run(gab_bsw *h, const uint8_t *ref, const int64_t *ref_of
     if (n == 0) return GAB_OK;
     GAB_CHECK(ref && ref_off && qry && qry_off && len1 && len2 && h0 && score_out, "gab_bsw_run: NULL buffer");
     gab_device_guard g(h->device);
-    // extent of the two slabs actually referenced
-    int64_t rb = 0, qb = 0;
+    // extent of the two slabs actually referenced: only [min, max) is staged, so a driver can hand a window
+    // of a big input (absolute offsets) to each GPU without re-basing its offset arrays
+    int64_t rb = 0, qb = 0, ra = INT64_MAX, qa = INT64_MAX;
     for (int64_t i = 0; i < n; i++) {
         GAB_CHECK(ref_off[i] >= 0 && qry_off[i] >= 0 && len1[i] >= 0 && len2[i] >= 0,
                   "gab_bsw_run: negative offset/length at pair %lld", (long long)i);
         int64_t r = ref_off[i] + len1[i], q = qry_off[i] + len2[i];
         rb = r > rb ? r : rb; qb = q > qb ? q : qb;
+        ra = ref_off[i] < ra ? ref_off[i] : ra; qa = qry_off[i] < qa ? qry_off[i] : qa;
     }
-    const size_t rpad = ((size_t)rb + 3 + 255) & ~(size_t)255, qpad = ((size_t)qb + 3 + 255) & ~(size_t)255;
+    ra &= ~(int64_t)255; qa &= ~(int64_t)255;          // keep the device alignment of the slab origin
+    const size_t rpad = ((size_t)(rb - ra) + 3 + 255) & ~(size_t)255, qpad = ((size_t)(qb - qa) + 3 + 255) & ~(size_t)255;
     const size_t nn = (size_t)n;
     size_t o = 0;
     const size_t o_ref = o; o += rpad;
@@ -445,15 +448,16 @@ extern "C" int gab_bsw_run(gab_bsw *h, const uint8_t *ref, const int64_t *ref_of
     if (rc) return rc;
     char *b = h->io.as<char>();
     hipStream_t s = nullptr;
-    GAB_HIP(hipMemcpyAsync(b + o_ref, ref, (size_t)rb, hipMemcpyHostToDevice, s));
-    GAB_HIP(hipMemcpyAsync(b + o_qry, qry, (size_t)qb, hipMemcpyHostToDevice, s));
+    GAB_HIP(hipMemcpyAsync(b + o_ref, ref + ra, (size_t)(rb - ra), hipMemcpyHostToDevice, s));
+    GAB_HIP(hipMemcpyAsync(b + o_qry, qry + qa, (size_t)(qb - qa), hipMemcpyHostToDevice, s));
     GAB_HIP(hipMemcpyAsync(b + o_roff, ref_off, 8 * nn, hipMemcpyHostToDevice, s));
     GAB_HIP(hipMemcpyAsync(b + o_qoff, qry_off, 8 * nn, hipMemcpyHostToDevice, s));
     GAB_HIP(hipMemcpyAsync(b + o_l1, len1, 4 * nn, hipMemcpyHostToDevice, s));
     GAB_HIP(hipMemcpyAsync(b + o_l2, len2, 4 * nn, hipMemcpyHostToDevice, s));
     GAB_HIP(hipMemcpyAsync(b + o_h0, h0, 4 * nn, hipMemcpyHostToDevice, s));
-    rc = gab_bsw_run_device(h, (const uint8_t *)(b + o_ref), (int64_t)rpad, (const int64_t *)(b + o_roff),
-                            (const uint8_t *)(b + o_qry), (int64_t)qpad, (const int64_t *)(b + o_qoff),
+    // virtual slab origins: device address of byte 0 of the caller's slabs
+    rc = gab_bsw_run_device(h, (const uint8_t *)(b + o_ref) - ra, ra + (int64_t)rpad, (const int64_t *)(b + o_roff),
+                            (const uint8_t *)(b + o_qry) - qa, qa + (int64_t)qpad, (const int64_t *)(b + o_qoff),
                             (const int32_t *)(b + o_l1), (const int32_t *)(b + o_l2), (const int32_t *)(b + o_h0),
                             n, (int32_t *)(b + o_sc), nullptr, s);
     if (rc) return rc;

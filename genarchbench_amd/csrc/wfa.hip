@@ -468,15 +468,17 @@ extern "C" int gab_wfa_run(gab_wfa *h, const char *pat, const int64_t *pat_off, 
     GAB_CHECK(pat && pat_off && pat_len && txt && txt_off && txt_len && ops_out && ops_off && ops_len_out && score_out,
               "gab_wfa_run: NULL buffer");
     gab_device_guard g(h->device);
-    int64_t pb = 0, tb = 0, ob = 0;
+    int64_t pb = 0, tb = 0, ob = 0, pa = INT64_MAX, ta = INT64_MAX, oa = INT64_MAX;
     for (int64_t i = 0; i < n; i++) {
         GAB_CHECK(pat_off[i] >= 0 && txt_off[i] >= 0 && ops_off[i] >= 0 && pat_len[i] >= 0 && txt_len[i] >= 0,
                   "gab_wfa_run: negative offset/length at pair %lld", (long long)i);
         pb = std::max(pb, pat_off[i] + pat_len[i]); tb = std::max(tb, txt_off[i] + txt_len[i]);
         ob = std::max(ob, ops_off[i] + pat_len[i] + txt_len[i]);
+        pa = std::min(pa, pat_off[i]); ta = std::min(ta, txt_off[i]); oa = std::min(oa, ops_off[i]);
     }
-    const size_t ppad = ((size_t)pb + 3 + 255) & ~(size_t)255, tpad = ((size_t)tb + 3 + 255) & ~(size_t)255;
-    const size_t opad = ((size_t)ob + 255) & ~(size_t)255, nn = (size_t)n;
+    pa &= ~(int64_t)255; ta &= ~(int64_t)255;   // stage only the referenced windows (oa stays exact: it is written back)
+    const size_t ppad = ((size_t)(pb - pa) + 3 + 255) & ~(size_t)255, tpad = ((size_t)(tb - ta) + 3 + 255) & ~(size_t)255;
+    const size_t opad = ((size_t)(ob - oa) + 255) & ~(size_t)255, nn = (size_t)n;
     size_t o = 0;
     const size_t o_p = o; o += ppad;
     const size_t o_t = o; o += tpad;
@@ -492,18 +494,19 @@ extern "C" int gab_wfa_run(gab_wfa *h, const char *pat, const int64_t *pat_off, 
     if (rc) return rc;
     char *b = h->io.as<char>();
     hipStream_t s = nullptr;
-    GAB_HIP(hipMemcpyAsync(b + o_p, pat, (size_t)pb, hipMemcpyHostToDevice, s));
-    GAB_HIP(hipMemcpyAsync(b + o_t, txt, (size_t)tb, hipMemcpyHostToDevice, s));
+    GAB_HIP(hipMemcpyAsync(b + o_p, pat + pa, (size_t)(pb - pa), hipMemcpyHostToDevice, s));
+    GAB_HIP(hipMemcpyAsync(b + o_t, txt + ta, (size_t)(tb - ta), hipMemcpyHostToDevice, s));
     GAB_HIP(hipMemcpyAsync(b + o_po, pat_off, 8 * nn, hipMemcpyHostToDevice, s));
     GAB_HIP(hipMemcpyAsync(b + o_to, txt_off, 8 * nn, hipMemcpyHostToDevice, s));
     GAB_HIP(hipMemcpyAsync(b + o_oo, ops_off, 8 * nn, hipMemcpyHostToDevice, s));
     GAB_HIP(hipMemcpyAsync(b + o_pl, pat_len, 4 * nn, hipMemcpyHostToDevice, s));
     GAB_HIP(hipMemcpyAsync(b + o_tl, txt_len, 4 * nn, hipMemcpyHostToDevice, s));
-    rc = gab_wfa_run_device(h, b + o_p, (int64_t)ppad, (const int64_t *)(b + o_po), (const int32_t *)(b + o_pl), b + o_t,
-                            (int64_t)tpad, (const int64_t *)(b + o_to), (const int32_t *)(b + o_tl), n, b + o_ops,
+    rc = gab_wfa_run_device(h, b + o_p - pa, pa + (int64_t)ppad, (const int64_t *)(b + o_po), (const int32_t *)(b + o_pl),
+                            b + o_t - ta, ta + (int64_t)tpad, (const int64_t *)(b + o_to), (const int32_t *)(b + o_tl), n, b + o_ops - oa,
                             (const int64_t *)(b + o_oo), (int32_t *)(b + o_ol), (int32_t *)(b + o_sc), s);
     if (rc) return rc;
-    GAB_HIP(hipMemcpyAsync(ops_out, b + o_ops, (size_t)ob, hipMemcpyDeviceToHost, s));
+    // only each pair's own operations are defined; copy the window back and let the caller read ops_len[i] bytes per pair
+    GAB_HIP(hipMemcpyAsync(ops_out + oa, b + o_ops, (size_t)(ob - oa), hipMemcpyDeviceToHost, s));
     GAB_HIP(hipMemcpyAsync(ops_len_out, b + o_ol, 4 * nn, hipMemcpyDeviceToHost, s));
     GAB_HIP(hipMemcpyAsync(score_out, b + o_sc, 4 * nn, hipMemcpyDeviceToHost, s));
     GAB_HIP(hipStreamSynchronize(s));

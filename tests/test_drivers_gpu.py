@@ -1,0 +1,47 @@
+"""GPU: the drop-in C drivers end to end -- reference CLI, reference file formats, reference regression
+scripts (benchmarks/*/scripts/regression_small.sh through benchmarks/run_wrapper.sh) against golden outputs."""
+import os
+import subprocess
+
+import pytest
+
+from tests.make_inputs import make
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def inputs(tmp_path_factory):
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "benchmarks"), "-s"])
+    return make(str(tmp_path_factory.mktemp("genarch-inputs")))
+
+
+@pytest.mark.parametrize("bench", ["bsw", "chain", "fast-chain", "bpm", "wfa", "fmi"])
+def test_regression_small(inputs, bench, tmp_path):
+    env = dict(os.environ, GENARCH_BENCH_INPUTS_ROOT=inputs)
+    r = subprocess.run(["bash", os.path.join(ROOT, "benchmarks", bench, "scripts", "regression_small.sh")], cwd=tmp_path,
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "OK" in r.stdout and "FAILED" not in r.stdout, r.stdout
+    assert "Kernel execution time" in r.stdout
+
+
+def test_bsw_driver_output_lines(inputs, tmp_path):
+    """the lines the reference harness parses are present and well-formed"""
+    exe = os.path.join(ROOT, "benchmarks", "bsw", "main_bsw")
+    r = subprocess.run([exe, "-pairs", f"{inputs}/bsw/small/bandedSWA_SRR7733443_100k_input.txt", "-t", "1", "-b", "512"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-500:]
+    assert r.stdout.startswith("Number of input pairs: 2048\n")
+    line = [l for l in r.stdout.splitlines() if l.startswith("Overall SW cycles")][0]
+    assert float(line.split(" ")[5]) >= 0          # field 6, as `cut -d ' ' -f 6` takes it
+    assert r.stderr.splitlines()[0].startswith("[0] score=")
+
+
+def test_driver_errors_like_the_reference(tmp_path):
+    exe = os.path.join(ROOT, "benchmarks", "bsw", "main_bsw")
+    r = subprocess.run([exe, "-t", "1", "-b", "512"], capture_output=True, text=True)
+    assert r.returncode != 0 and "pairFileName not specified" in r.stderr
+    r = subprocess.run([os.path.join(ROOT, "benchmarks", "fmi", "fmi"), "a", "b"], capture_output=True, text=True)
+    assert r.returncode == 1 and "Need five arguments" in r.stdout

@@ -34,6 +34,7 @@ class FmIndex:
 
     def __init__(self, fwd_codes):
         fwd = np.ascontiguousarray(fwd_codes, np.uint8)
+        self._fwd = fwd
         self._raw = GabFmIndex()
         rc = lib().gab_mkindex_build(fwd.ctypes.data_as(C.c_void_p), C.c_int64(len(fwd)), C.byref(self._raw))
         if rc:
@@ -44,9 +45,14 @@ class FmIndex:
         self.sentinel_index = r.sentinel_index
         self.cp_occ = np.ctypeslib.as_array(C.cast(r.cp_occ, C.POINTER(C.c_uint8)), shape=(r.cp_occ_size * 64,))
 
-    def write(self, prefix):
+    def write(self, prefix, with_bns=False, name="synthetic"):
+        """<prefix>.bwt.2bit.64; with_bns also writes the .ann/.amb/.pac files the reference's loader needs"""
         if lib().gab_mkindex_write(C.byref(self._raw), prefix.encode()):
             raise IOError(f"cannot write {prefix}.bwt.2bit.64")
+        if with_bns:
+            if lib().gab_mkindex_write_bns(prefix.encode(), self._fwd.ctypes.data_as(C.c_void_p), C.c_int64(len(self._fwd)),
+                                           name.encode()):
+                raise IOError(f"cannot write {prefix}.ann/.amb/.pac")
 
     def close(self):
         if self._raw.cp_occ:

@@ -166,3 +166,32 @@ int gab_mkindex_write(const gab_fmindex *idx, const char *prefix) {
              fwrite(&idx->sentinel_index, 8, 1, f) == 1;
     return fclose(f) == 0 && ok ? 0 : -1;
 }
+
+/* Companion files the reference's loader insists on (bwa_idx_load_ele -> bns_restore, bntseq.cpp:73-101,
+ * 113-180, 336-352): <prefix>.ann, <prefix>.amb (no holes: the reference is N-free) and the 2-bit <prefix>.pac. */
+int gab_mkindex_write_bns(const char *prefix, const uint8_t *fwd, int64_t L, const char *seq_name) {
+    char name[4096];
+    snprintf(name, sizeof name, "%s.ann", prefix);
+    FILE *f = fopen(name, "w");
+    if (!f) return -1;
+    fprintf(f, "%lld 1 11\n0 %s (null)\n0 %lld 0\n", (long long)L, seq_name, (long long)L);
+    if (fclose(f)) return -1;
+    snprintf(name, sizeof name, "%s.amb", prefix);
+    f = fopen(name, "w");
+    if (!f) return -1;
+    fprintf(f, "%lld 1 0\n", (long long)L);
+    if (fclose(f)) return -1;
+    snprintf(name, sizeof name, "%s.pac", prefix);
+    f = fopen(name, "wb");
+    if (!f) return -1;
+    const int64_t nbytes = (L >> 2) + ((L & 3) ? 1 : 0);
+    uint8_t *pac = (uint8_t *)calloc((size_t)nbytes + 2, 1);
+    if (!pac) { fclose(f); return -2; }
+    for (int64_t i = 0; i < L; i++) pac[i >> 2] |= (uint8_t)((fwd[i] & 3) << ((3 - (i & 3)) << 1));
+    int64_t total = nbytes;
+    if ((L & 3) == 0) pac[total++] = 0;
+    pac[total++] = (uint8_t)(L & 3);
+    const int ok = fwrite(pac, 1, (size_t)total, f) == (size_t)total;
+    free(pac);
+    return fclose(f) == 0 && ok ? 0 : -1;
+}

@@ -34,6 +34,8 @@ int gab_mkindex_build(const uint8_t *fwd, int64_t ref_len, gab_fmindex *out);
 void gab_mkindex_free(gab_fmindex *idx);
 /* writes <prefix>.bwt.2bit.64 */
 int gab_mkindex_write(const gab_fmindex *idx, const char *prefix);
+/* writes <prefix>.ann / .amb / .pac so that the reference's own loader accepts the index too */
+int gab_mkindex_write_bns(const char *prefix, const uint8_t *fwd, int64_t ref_len, const char *seq_name);
 /* suffix array of s[0..n) (symbols < K, s[n-1] must be the unique smallest symbol) */
 int gab_sais_i32(const int32_t *s, int32_t *SA, int32_t n, int32_t K);
 int gab_sais_u8(const uint8_t *s, int32_t *SA, int32_t n, int32_t K);
