@@ -607,22 +607,13 @@ def main():
         wl.after_step(True)          # reads the step's HIP events (waits for the step, as the ROI does)
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    from genarchbench_amd.shard import aggregate
+    elapsed, total_units = aggregate(elapsed, getattr(wl, "items", items), dist if world > 1 else None, dev)
 
     verdict = None if args.no_check else wl.check()
     if rank == 0:
         ms = elapsed / args.steps * 1e3
-        units = getattr(wl, "items", items)      # metric units processed per rank per step
-        if world > 1:
-            tu = torch.tensor([units], dtype=torch.float64, device=dev)
-            dist.all_reduce(tu)
-            total_units = float(tu.item())
-        else:
-            total_units = float(units)
-        value = total_units / (ms * 1e-3) / 1e6
+        value = total_units / (ms * 1e-3) / 1e6       # units of all ranks / max-over-ranks time
         out = {
             "metric": W.metric, "value": round(value, 4), "unit": W.unit, "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4),
