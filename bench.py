@@ -218,7 +218,7 @@ class ChainWorkload:
     def cpu_baseline(self, cores):
         from oracle import pyoracle
         from tools import gabgen
-        c = min(self.calls, 3000)
+        c = min(self.calls, 1500)
         exe = pyoracle.ref_path(self.ref_exe if self.mode == 0 else
                                 ("fastchain_ref_avx512" if " avx512bw" in open("/proc/cpuinfo").read() else "fastchain_ref_avx2"))
         b = self.batch

@@ -4,7 +4,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "libgab_hip.so")
+_SO = os.environ.get("GAB_LIB_PATH") or os.path.join(_HERE, "libgab_hip.so")   # override: A/B builds while tuning
 _lib = None
 
 
@@ -31,6 +31,13 @@ def lib():
             raise ImportError(
                 f"{_SO} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(or make -C genarchbench_amd/csrc).  There is no CPU fallback.")
+        # PyTorch wheels bundle their own libamdhip64.so.7; a process must hold ONE HIP runtime.  When torch is
+        # installed, load it first so that libgab_hip.so binds to the runtime torch uses (same soname) -- otherwise
+        # a later `torch.cuda` initialisation in the same process finds no GPU.  The C drivers never see torch.
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
         _lib = C.CDLL(_SO)
         _lib.gab_version.restype = C.c_char_p
         _lib.gab_last_error.restype = C.c_char_p

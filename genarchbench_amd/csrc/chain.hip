@@ -9,22 +9,24 @@
 //                    than six predecessors, double otherwise.
 //
 // Mapping.  The scores along i are a true recurrence (score[i] needs score[i-1]), so a call is
-// walked sequentially by ONE wavefront; the parallelism is (a) the 64 predecessors of a window
-// chunk, one per lane, and (b) thousands of independent calls, one workgroup (= one wave) each,
-// longest call first.  Per anchor i:
+// walked sequentially by ONE workgroup of four waves; the parallelism is (a) the 256 predecessors of
+// a window super-chunk, one per lane, and (b) thousands of independent calls, longest call first.
+// The latency of that sequential walk is the bound, so everything on the i-1 -> i dependence stays
+// on the CU: the last 1024 anchors (x, y, score, parent) live in an LDS ring.  Per anchor i:
 //   * the window start `st` is advanced with one 64-wide compare + ballot against a cached block of
 //     x values instead of the reference's scalar while-loop;
-//   * the window [st, i-1] is swept in descending 64-anchor chunks.  Chunk 0 (the 64 most recent
-//     anchors, which carry the RAW dependence on score[i-1]) lives in registers and is shifted by
-//     one lane per anchor with a DPP wave_shr; older chunks are coalesced global loads (x, y,
-//     score, parent) that hit L1/L2, issued one chunk ahead;
-//   * FASTCHAIN: wave max-reduction of the chunk scores (DPP), ties -> larger j;
-//   * CHAIN: the sequential max_skip logic is reproduced exactly in three wave-parallel steps
+//   * the window [st, i-1] is swept in descending 256-anchor super-chunks read from the LDS ring
+//     (anchors older than the ring come from global memory with agent-scope loads);
+//   * FASTCHAIN: per-wave DPP max-reduction, the four maxima combined through LDS (one barrier),
+//     ties -> larger j;
+//   * CHAIN: the sequential max_skip logic is reproduced exactly in three parallel steps
 //     (SURVEY.md App. B8): every unfiltered lane first scatters its mark targets[parent[j]] = i
-//     into a 16-bit LDS ring, then reads its own mark; an exclusive prefix-max (DPP scan) gives
-//     the "sc > max_f" improvement flags; the n_skip counter with its > 25 break is a scalar walk
-//     over the two ballot masks.  Marks scattered by lanes past the break point are harmless
-//     because a mark value i is only ever compared with the current i.
+//     into a 16-bit LDS ring and publishes its chunk maximum (barrier), then reads its own mark and
+//     derives the "sc > max_f" improvement flag from an exclusive prefix-max (DPP scan + the earlier
+//     chunks' maxima) and publishes the ballot masks (barrier); finally every wave walks the masks
+//     of the four chunks in order for the saturating n_skip counter and its > 25 break.  Marks
+//     scattered by lanes past the break point are harmless because a mark value i is only ever
+//     compared with the current i.
 //
 // Roofline: 24 B of HBM traffic per anchor (16 B in, 8 B out) against ~130-200 predecessor
 // evaluations per anchor: latency/VALU bound by construction; the window re-reads are served by
@@ -39,7 +41,7 @@ namespace {
 
 constexpr int kMaxIter = 5000;
 constexpr int kMaxSkip = 25;
-constexpr int kMarkRing = 8192;           // >= kMaxIter + 64, power of two
+constexpr int kMarkRing = 1024;           // LDS ring of mark tags for the newest anchors; older marks go to global memory
 
 struct ChainWork {                        // one call, device-side descriptor
     int64_t off, n;
@@ -60,6 +62,26 @@ __device__ __forceinline__ int wave_incl_max(int v) {
     v = max(v, GAB_DPP(id, v, 0x143, 0xc));   // row_bcast:31 -> rows 2,3
     return v;
 }
+// inclusive add-scan / min-scan, same DPP network
+__device__ __forceinline__ int wave_incl_sum(int v) {
+    v += GAB_DPP(0, v, 0x111, 0xf);
+    v += GAB_DPP(0, v, 0x112, 0xf);
+    v += GAB_DPP(0, v, 0x114, 0xf);
+    v += GAB_DPP(0, v, 0x118, 0xf);
+    v += GAB_DPP(0, v, 0x142, 0xa);
+    v += GAB_DPP(0, v, 0x143, 0xc);
+    return v;
+}
+__device__ __forceinline__ int wave_incl_min(int v) {
+    const int id = 0x7fffffff;
+    v = min(v, GAB_DPP(id, v, 0x111, 0xf));
+    v = min(v, GAB_DPP(id, v, 0x112, 0xf));
+    v = min(v, GAB_DPP(id, v, 0x114, 0xf));
+    v = min(v, GAB_DPP(id, v, 0x118, 0xf));
+    v = min(v, GAB_DPP(id, v, 0x142, 0xa));
+    v = min(v, GAB_DPP(id, v, 0x143, 0xc));
+    return v;
+}
 __device__ __forceinline__ int wave_shr1(int v, int fill) { return GAB_DPP(fill, v, 0x138, 0xf); }
 __device__ __forceinline__ uint64_t wave_shr1_u64(uint64_t v) {
     uint32_t lo = (uint32_t)wave_shr1((int)(uint32_t)v, 0), hi = (uint32_t)wave_shr1((int)(uint32_t)(v >> 32), 0);
@@ -68,17 +90,49 @@ __device__ __forceinline__ uint64_t wave_shr1_u64(uint64_t v) {
 
 __device__ __forceinline__ int ilog2_u32(uint32_t v) { return 31 - __clz((int)v); }
 
+#ifndef GAB_CHAIN_WAVES
+#define GAB_CHAIN_WAVES 4
+#endif
+constexpr int kWaves = GAB_CHAIN_WAVES;   // waves per call (one workgroup)
+constexpr int kThreads = kWaves * 64;
+constexpr int kRing = 512;                // anchors kept in the LDS window ring
+constexpr int kRingSafe = kRing - 8;      // entries younger than this are read from the ring
+
+// One workgroup (4 waves) walks one call.  Per anchor i the predecessor window [st, i-1] is swept in
+// "super-chunks" of 256 predecessors, wave w taking chunk 4*s + w.  The last kRing anchors (x, y, seg id,
+// score, parent) live in an LDS ring, so the RAW dependence score[i-1] -> score[i] never leaves the CU;
+// predecessors older than the ring (windows > ~1000 anchors) are read back from global memory.
+// Workgroup barrier that waits for LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it would wait for
+// the global store of score[i] / parent[i] (a ~2 us write acknowledgement) on every anchor of the sequential walk.
+// Nothing crossing these barriers goes through global memory: the window ring, the marks and the publish slots are
+// all LDS.  (Global loads are waited for by the compiler at their first use, as always.)
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 template <bool FAST>
-__global__ __launch_bounds__(64) void chain_kernel(const ChainWork *__restrict__ work,
-                                                   const uint64_t *__restrict__ xs,
-                                                   const uint64_t *__restrict__ ys,
-                                                   int32_t *score_out, int32_t *parent_out,
-                                                   unsigned long long *evals_out) {
-    __shared__ uint16_t marks[FAST ? 64 : kMarkRing];
+__global__ __launch_bounds__(kThreads) void chain_kernel(const ChainWork *__restrict__ work,
+                                                         const uint64_t *__restrict__ xs,
+                                                         const uint64_t *__restrict__ ys,
+                                                         int32_t *score_out, int32_t *parent_out,
+                                                         int32_t *gmarks_all, unsigned long long *evals_out) {
+    __shared__ uint64_t ring_x[kRing];
+    __shared__ uint32_t ring_y[kRing];
+    __shared__ int32_t ring_sc[kRing];
+    __shared__ int32_t ring_par[kRing];
+    __shared__ uint8_t ring_sid[FAST ? 1 : kRing];
+    __shared__ uint16_t marks[FAST ? 1 : kMarkRing];
+    __shared__ uint64_t stage_x[kThreads], stage_y[kThreads];
+    __shared__ int32_t pub_max[2][kWaves], pub_j[2][kWaves];          // FAST: per-wave maxima (double-buffered)
+    // CHAIN: per-chunk maxima, scores and ballot masks; double-buffered by super-chunk parity so that a wave
+    // already in the next super-chunk's phase A never overwrites what a slower wave still reads in phase C
+    __shared__ int32_t pub_cmax[2][kWaves];
+    __shared__ int32_t pub_sc[2][kWaves][64];
+    __shared__ unsigned long long pub_imp[2][kWaves], pub_hit[2][kWaves], pub_valid[2][kWaves];
+
     const ChainWork w = work[blockIdx.x];
-    const int lane = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint64_t *X = xs + w.off, *Y = ys + w.off;
     int32_t *S = score_out + w.off, *P = parent_out + w.off;
+    int32_t *GM = FAST ? nullptr : gmarks_all + w.off;     // targets[] of the reference, used only beyond the LDS mark ring
     const int64_t n = w.n;
     const int32_t mdx = w.max_dist_x, mdy = w.max_dist_y, bw = w.bw;
     const uint64_t mdx64 = (uint64_t)(int64_t)mdx;
@@ -86,28 +140,36 @@ __global__ __launch_bounds__(64) void chain_kernel(const ChainWork *__restrict__
     const float k32 = (float)(0.01 * (double)w.avg_qspan);
     const bool multi_seg = w.n_segs > 1;
 
-    // chunk 0 registers: lane l <-> anchor i-1-l
-    uint64_t rx = 0; uint32_t ry = 0; int rsid = 0, rsc = 0, rpar = -1;
-    // cached block of x for the window-start search
+    // cached block of x for the window-start search (every wave keeps its own copy: no barrier needed)
     int64_t st = 0, sb = 0;
     uint64_t XS = (lane < n) ? X[lane] : 0;
     unsigned long long evals = 0;
+    int pub_phase = 0;
 
     for (int64_t i = 0; i < n; i++) {
-        const uint64_t xi = X[i], yi = Y[i];             // wave-uniform
-        if (!FAST && (i & 0x7fff) == 0) {
-            // mark tags are 0x8000 | (i mod 2^15): wipe the ring once per tag epoch (and at call
-            // start, the LDS still holds the previous workgroup's bytes) so a stale tag can never match
-            for (int k = lane; k < kMarkRing; k += 64) marks[k] = 0;
-            __syncthreads();
+        if ((i & (kThreads - 1)) == 0) {
+            // stage the next 256 anchors (coalesced) -- the previous block is no longer needed by anyone
+            lds_barrier();
+            // results leave the CU in coalesced blocks of 256 taken from the ring -- a store per anchor would put a
+            // ~2 us write acknowledgement (s_waitcnt vmcnt) on the sequential path of every anchor
+            if (i > 0) {
+                const int64_t jo = i - kThreads + tid;
+                S[jo] = ring_sc[jo & (kRing - 1)]; P[jo] = ring_par[jo & (kRing - 1)];
+            }
+            if (i + tid < n) { stage_x[tid] = X[i + tid]; stage_y[tid] = Y[i + tid]; }
+            if (!FAST && (i & 0x7fff) == 0)
+                for (int k = tid; k < kMarkRing; k += kThreads) marks[k] = 0;   // new tag epoch (see tag below)
+            __syncthreads();     // full barrier (once per 256 anchors): the flushed results are acknowledged by L2
+                                 // before any wave may read them back through the deep-window path
         }
+        const uint64_t xi = stage_x[i & (kThreads - 1)], yi = stage_y[i & (kThreads - 1)];     // workgroup-uniform
         const int32_t qi = (int32_t)yi, q_span = (int32_t)(yi >> 32 & 0xff), sidi = (int32_t)(yi >> 48 & 0xff);
         // ---- window start (host_kernel.cpp:56-57 / fast :200-207)
         for (;;) {
             const int64_t cand = sb + lane;
-            bool far = FAST ? ((xi - XS) > mdx64) : (xi > XS + mdx64);
-            bool pass = cand < st || (cand < i && far);
-            unsigned long long m = __ballot(pass);
+            const bool far = FAST ? ((xi - XS) > mdx64) : (xi > XS + mdx64);
+            const bool pass = cand < st || (cand < i && far);
+            const unsigned long long m = __ballot(pass);
             if (m == ~0ull) {
                 sb += 64; st = sb;
                 XS = (sb + lane < n) ? X[sb + lane] : 0;
@@ -120,27 +182,28 @@ __global__ __launch_bounds__(64) void chain_kernel(const ChainWork *__restrict__
         if (st - sb >= 64) { sb = st & ~63ll; XS = (sb + lane < n) ? X[sb + lane] : 0; }
 
         int32_t best = q_span, best_j = -1;
-        const int64_t count = i - st;                    // window size
+        const int64_t count = i - st;
         const bool wide = !((i - 1) - st <= 5);          // FAST only (:211/:440)
         int n_skip = 0;
         bool broke = false;
+        const uint16_t tag = (uint16_t)(0x8000 | (i & 0x7fff));
 
-        // prefetch registers for the next global chunk
-        uint64_t nx = 0, ny = 0; int nsc = 0, npar = -1;
-        if (count > 64) {
-            const int64_t j = i - 1 - 64 - lane;
-            if (j >= st) { nx = X[j]; ny = Y[j]; nsc = S[j]; npar = FAST ? -1 : P[j]; }
-        }
-        for (int64_t c0 = 0; c0 < count && !broke; c0 += 64) {
-            const int64_t j = i - 1 - c0 - lane;
+        for (int64_t c0 = 0; c0 < count && !broke; c0 += kThreads) {
+            const int64_t j = i - 1 - c0 - tid;           // wave w owns lanes [64w, 64w+64) of the super-chunk
             const bool valid = j >= st;
-            uint64_t xj; uint32_t yj; int sidj, scj, parj;
-            if (c0 == 0) { xj = rx; yj = ry; sidj = rsid; scj = rsc; parj = rpar; }
-            else {
-                xj = nx; yj = (uint32_t)ny; sidj = (int)(ny >> 48 & 0xff); scj = nsc; parj = npar;
-                if (c0 + 64 < count) {                   // issue the following chunk now
-                    const int64_t j2 = j - 64;
-                    if (j2 >= st) { nx = X[j2]; ny = Y[j2]; nsc = S[j2]; npar = FAST ? -1 : P[j2]; }
+            uint64_t xj = 0; uint32_t yj = 0; int sidj = 0, scj = 0, parj = -1;
+            if (valid) {
+                if (i - j <= kRingSafe) {
+                    const int r = (int)(j & (kRing - 1));
+                    xj = ring_x[r]; yj = ring_y[r]; scj = ring_sc[r];
+                    if (!FAST) { sidj = ring_sid[r]; parj = ring_par[r]; }
+                } else {
+                    // older than the LDS ring: L2-coherent loads (the values were stored by another wave of this CU)
+                    xj = X[j];
+                    const uint64_t yy = Y[j];
+                    yj = (uint32_t)yy; sidj = (int)(yy >> 48 & 0xff);
+                    scj = __hip_atomic_load(&S[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (!FAST) parj = __hip_atomic_load(&P[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
             bool ok = valid;
@@ -151,28 +214,35 @@ __global__ __launch_bounds__(64) void chain_kernel(const ChainWork *__restrict__
                 const uint32_t diff = (uint32_t)ddr - (uint32_t)ddq;
                 const int32_t dd = (int32_t)((int32_t)diff < 0 ? 0u - diff : diff);
                 ok = ok && !(dd > bw || ddr == 0 || ddq <= 0 || ddq > mdy || ddq > mdx);
-                int32_t oc = min(min(ddr, ddq), q_span);
+                const int32_t oc = min(min(ddr, ddq), q_span);
                 const int32_t lg = dd ? ilog2_u32((uint32_t)dd) : 0;
                 int32_t gc;
                 if (wide) gc = (int32_t)floorf(__fmul_rn((float)dd, k32)) + (lg >> 1);
                 else gc = (int32_t)__dmul_rn(__dmul_rn((double)dd, .01), avg_d) + (lg >> 1);
                 sc = (int32_t)((uint32_t)scj + (uint32_t)oc - (uint32_t)gc);
                 evals += valid ? 1 : 0;
-                // wave max, ties -> larger j (= lower lane)
-                int v = ok ? sc : (int)0x80000000;
-                int mx = __builtin_amdgcn_readlane(wave_incl_max(v), 63);
-                if (mx > best) {
-                    unsigned long long who = __ballot(ok && sc == mx);
-                    best = mx;
-                    best_j = (int32_t)(i - 1 - c0 - __builtin_ctzll(who));
+                // per-wave max (ties -> larger j = lower lane), then combine the four waves through LDS
+                const int v = ok ? sc : (int)0x80000000;
+                const int mx = __builtin_amdgcn_readlane(wave_incl_max(v), 63);
+                const unsigned long long who = __ballot(ok && sc == mx);
+                if (lane == 0) {
+                    pub_max[pub_phase][wave] = mx;
+                    pub_j[pub_phase][wave] = who ? (int32_t)(i - 1 - c0 - 64 * wave - __builtin_ctzll(who)) : -1;
                 }
+                lds_barrier();
+#pragma unroll
+                for (int ww = 0; ww < kWaves; ww++) {       // wave order = descending j: strict > keeps the larger j
+                    const int m2 = pub_max[pub_phase][ww];
+                    if (m2 > best) { best = m2; best_j = pub_j[pub_phase][ww]; }
+                }
+                pub_phase ^= 1;
             } else {
                 const int64_t dr = (int64_t)(xi - xj);
                 const int32_t dq = qi - (int32_t)yj;
                 const bool same = sidi == sidj;
                 const int32_t dd = (int32_t)(dr > dq ? dr - dq : dq - dr);
-                bool skip = (same && dr == 0) || dq <= 0 || (same && dq > mdy) || dq > mdx || (same && dd > bw) ||
-                            (multi_seg && same && dr > mdy);
+                const bool skip = (same && dr == 0) || dq <= 0 || (same && dq > mdy) || dq > mdx || (same && dd > bw) ||
+                                  (multi_seg && same && dr > mdy);
                 ok = ok && !skip;
                 const int32_t min_d = (int32_t)(dq < dr ? (int64_t)dq : dr);
                 sc = min_d > q_span ? q_span : min_d;
@@ -185,48 +255,83 @@ __global__ __launch_bounds__(64) void chain_kernel(const ChainWork *__restrict__
                 } else gap = c_lin + (lg >> 1);
                 sc -= (int32_t)(__dadd_rn((double)gap, .499));     // (int)((double)gap_cost * 1.0f + .499)
                 sc += scj;
-                // marks: scatter first, then read
-                const uint16_t tag = (uint16_t)(0x8000 | (i & 0x7fff));
-                if (ok && parj >= 0 && parj >= st) marks[parj & (kMarkRing - 1)] = tag;
-                __syncthreads();
-                const bool hit_raw = ok && marks[j & (kMarkRing - 1)] == tag;
-                // improvement flags: strict > against everything visited before this lane
+                // phase A: scatter marks, publish the chunk maximum and the scores.  Marks of parents inside the LDS
+                // ring window go to LDS; a super-chunk that reaches further back (window > ~500 anchors) also uses the
+                // global targets[] array, and then needs full barriers (global stores must be acknowledged).
+                const bool deep = c0 + kThreads > kRingSafe;           // workgroup-uniform
+                if (ok && parj >= 0 && parj >= st) {
+                    if (i - parj <= kRingSafe) marks[parj & (kMarkRing - 1)] = tag;
+                    else __hip_atomic_store(&GM[parj], (int32_t)(i + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
                 const int v = ok ? sc : (int)0x80000000;
                 const int incl = wave_incl_max(v);
+                if (lane == 63) pub_cmax[pub_phase][wave] = incl;
+                pub_sc[pub_phase][wave][lane] = sc;
+                if (deep) __syncthreads(); else lds_barrier();
+                // phase B: marks of ALL chunks of this super-chunk are visible
+                bool hit_raw = false;
+                if (ok) {
+                    if (i - j <= kRingSafe) hit_raw = marks[j & (kMarkRing - 1)] == tag;
+                    else hit_raw = __hip_atomic_load(&GM[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int32_t)(i + 1);
+                }
                 int before = wave_shr1(incl, (int)0x80000000);
                 before = max(before, best);
+#pragma unroll
+                for (int ww = 0; ww < kWaves; ww++) if (ww < wave) before = max(before, pub_cmax[pub_phase][ww]);
                 const bool imp = ok && sc > before;
-                const unsigned long long imp_m = __ballot(imp), hit_m = __ballot(hit_raw && !imp);
-                const unsigned long long valid_m = __ballot(valid);
-                int brk = 64;
-                if (hit_m == 0) {
-                    n_skip -= __popcll(imp_m);
-                    n_skip = n_skip < 0 ? 0 : n_skip;
-                } else {
-                    unsigned long long ev = imp_m | hit_m;
-                    while (ev) {
-                        const int b = __builtin_ctzll(ev);
-                        ev &= ev - 1;
-                        if ((imp_m >> b) & 1) { if (n_skip > 0) --n_skip; }
-                        else if (++n_skip > kMaxSkip) { brk = b; break; }
+                const unsigned long long imp_m = __ballot(imp), hit_m = __ballot(hit_raw && !imp), valid_m = __ballot(valid);
+                if (lane == 0) { pub_imp[pub_phase][wave] = imp_m; pub_hit[pub_phase][wave] = hit_m; pub_valid[pub_phase][wave] = valid_m; }
+                lds_barrier();
+                // phase C: every wave walks the four chunks in order (identical scalar work, no further barrier)
+                unsigned long long visited = 0;
+                for (int ww = 0; ww < kWaves && !broke; ww++) {
+                    const unsigned long long im = pub_imp[pub_phase][ww], hm = pub_hit[pub_phase][ww], vm = pub_valid[pub_phase][ww];
+                    int brk = 64;
+                    if (hm == 0) {
+                        n_skip -= __popcll(im);
+                        n_skip = n_skip < 0 ? 0 : n_skip;
+                    } else {
+                        // n_skip is a counter reflected at 0: c_l = max(c_{l-1} + d_l, 0) with d = +1 on a hit, -1 on an
+                        // improvement.  Closed form over the chunk: c_l = P_l - min(-c_in, min_{t<=l} P_t), P = prefix sums
+                        // of d -- two DPP scans instead of a scalar walk over up to 64 events.
+                        const int d = (int)((hm >> lane) & 1) - (int)((im >> lane) & 1);
+                        const int pre = wave_incl_sum(d);
+                        const int mn = wave_incl_min(pre);
+                        const int cnt = pre - min(-n_skip, mn);
+                        const unsigned long long over = __ballot(((hm >> lane) & 1) && cnt > kMaxSkip);
+                        if (over) brk = __builtin_ctzll(over);
+                        else n_skip = __builtin_amdgcn_readlane(cnt, 63);
                     }
+                    const unsigned long long rec = im & (brk >= 64 ? ~0ull : ((1ull << brk) - 1));
+                    if (rec) {
+                        const int l = 63 - __builtin_clzll(rec);
+                        best = pub_sc[pub_phase][ww][l];
+                        best_j = (int32_t)(i - 1 - c0 - 64 * ww - l);
+                    }
+                    visited += (unsigned long long)__popcll(vm & (brk >= 64 ? ~0ull : ((2ull << brk) - 1)));
+                    broke = brk < 64;
                 }
-                const unsigned long long upto = brk >= 64 ? ~0ull : ((1ull << brk) - 1);
-                const unsigned long long rec = imp_m & upto;
-                if (rec) {
-                    const int l = 63 - __builtin_clzll(rec);      // last record before the break
-                    best = __builtin_amdgcn_readlane(sc, l);
-                    best_j = (int32_t)(i - 1 - c0 - l);
-                }
-                if (lane == 0) evals += __popcll(valid_m & (brk >= 64 ? ~0ull : ((2ull << brk) - 1)));
-                broke = brk < 64;
+                if (tid == 0) evals += visited;
+                pub_phase ^= 1;
             }
         }
-        if (lane == 0) { S[i] = best; P[i] = best_j; }
-        // slide chunk 0 by one anchor; lane 0 <- anchor i
-        rx = wave_shr1_u64(rx); ry = (uint32_t)wave_shr1((int)ry, 0); rsid = wave_shr1(rsid, 0);
-        rsc = wave_shr1(rsc, 0); rpar = wave_shr1(rpar, -1);
-        if (lane == 0) { rx = xi; ry = (uint32_t)yi; rsid = sidi; rsc = best; rpar = best_j; }
+                // Every wave keeps the ring up to date by itself (lane 0 of each wave stores the same values), so a wave
+        // only ever reads ring entries it has written: no barrier is needed to publish anchor i.  The barriers of the
+        // super-chunks keep the four waves within one anchor of each other, which is what protects a slot from being
+        // recycled (1024 anchors later) while a slower wave could still read it (it reads at most kRingSafe back);
+        // an anchor with an empty window has no super-chunk, so it takes an explicit barrier.
+        if (lane == 0) {
+            const int r = (int)(i & (kRing - 1));
+            ring_x[r] = xi; ring_y[r] = (uint32_t)yi; ring_sc[r] = best; ring_par[r] = best_j;
+            if (!FAST) ring_sid[r] = (uint8_t)sidi;
+        }
+        if (count <= 0) lds_barrier();
+    }
+    lds_barrier();
+    {   // flush the tail: anchors [n - rem, n) with rem = n mod 256 (or 256)
+        const int64_t done = n > 0 ? ((n - 1) & ~(int64_t)(kThreads - 1)) : 0;
+        const int64_t jo = done + tid;
+        if (jo < n) { S[jo] = ring_sc[jo & (kRing - 1)]; P[jo] = ring_par[jo & (kRing - 1)]; }
     }
     if (FAST) { for (int o = 32; o > 0; o >>= 1) evals += __shfl_xor(evals, o); }
     if (lane == 0 && evals) atomicAdd(evals_out, evals);
@@ -238,6 +343,7 @@ __global__ __launch_bounds__(64) void chain_kernel(const ChainWork *__restrict__
 struct gab_chain {
     int device = 0;
     gab_devbuf work;       // ChainWork[ncalls] + evals counter
+    gab_devbuf gmarks;     // chain mode: targets[] for windows deeper than the LDS mark ring (one int32 per anchor)
     gab_devbuf io;         // staging for the host-pointer entry point
     hipEvent_t ev[2] = {nullptr, nullptr};
     unsigned long long *h_evals = nullptr;   // pinned
@@ -264,7 +370,7 @@ extern "C" int gab_chain_create(int device, gab_chain **out) {
 extern "C" void gab_chain_destroy(gab_chain *h) {
     if (!h) return;
     gab_device_guard g(h->device);
-    h->work.release(); h->io.release();
+    h->work.release(); h->io.release(); h->gmarks.release();
     for (int k = 0; k < 2; k++) if (h->ev[k]) (void)hipEventDestroy(h->ev[k]);
     if (h->h_evals) (void)hipHostFree(h->h_evals);
     delete h;
@@ -321,11 +427,18 @@ extern "C" int gab_chain_run_device(gab_chain *h, int mode, const uint64_t *d_x,
     // caller's stack frame being reused (hipMemcpyAsync from pageable memory stages synchronously)
     GAB_HIP(hipMemcpyAsync(d_work, wk.data(), sizeof(ChainWork) * nw, hipMemcpyHostToDevice, s));
     GAB_HIP(hipMemsetAsync(d_ev, 0, 16, s));
+    int32_t *d_gm = nullptr;
+    if (mode == GAB_CHAIN) {
+        rc = h->gmarks.reserve(sizeof(int32_t) * (size_t)total);
+        if (rc) return rc;
+        d_gm = h->gmarks.as<int32_t>();
+        GAB_HIP(hipMemsetAsync(d_gm, 0, sizeof(int32_t) * (size_t)total, s));      // vector::resize zero-fills targets
+    }
     GAB_HIP(hipEventRecord(h->ev[0], s));
     if (mode == GAB_FASTCHAIN)
-        hipLaunchKernelGGL(chain_kernel<true>, dim3((unsigned)nw), dim3(64), 0, s, d_work, d_x, d_y, d_score, d_parent, d_ev);
+        hipLaunchKernelGGL(chain_kernel<true>, dim3((unsigned)nw), dim3(kThreads), 0, s, d_work, d_x, d_y, d_score, d_parent, d_gm, d_ev);
     else
-        hipLaunchKernelGGL(chain_kernel<false>, dim3((unsigned)nw), dim3(64), 0, s, d_work, d_x, d_y, d_score, d_parent, d_ev);
+        hipLaunchKernelGGL(chain_kernel<false>, dim3((unsigned)nw), dim3(kThreads), 0, s, d_work, d_x, d_y, d_score, d_parent, d_gm, d_ev);
     GAB_HIP(hipGetLastError());
     GAB_HIP(hipEventRecord(h->ev[1], s));
     GAB_HIP(hipMemcpyAsync(h->h_evals, d_ev, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
