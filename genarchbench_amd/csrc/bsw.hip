@@ -271,6 +271,178 @@ __global__ __launch_bounds__(64) void bsw_dp(BswIO io, BswConst c, const uint32_
     if (lane == 0 && cells) atomicAdd(&st->cells, cells);
 }
 
+
+// ---- pass 4b: the DP with 8-bit cells, two columns per step ---------------------------------------------------
+// Used for a query-length class when max(h0) + qcap * max(mat) <= 255 (true for the whole 151-bp read workload):
+// every H/E value then fits a byte, a column is a u16 (E << 8 | H) and TWO columns share one LDS dword, so the
+// row needs half the LDS (7 waves per CU at 128 columns instead of 3) and the inner loop one LDS read and one
+// LDS write per two cells.  Query codes are nibbles, two per byte.  The band may start or end in the middle of a
+// dword: those single cells are handled with 16-bit LDS accesses so that cells outside the band keep their stale
+// contents, which later rows may read when the band grows (bandedSWA.cpp:217,234-237).
+//   lds layout: [ (qcap + 2) / 2 dwords of cells ][ ((qcap + 1) / 2 + 3) / 4 dwords of query nibbles ]  x 64 lanes
+struct BswCellOut { int h, en, f; };
+__device__ __forceinline__ BswCellOut bsw_cell(int diag, int e, int f, uint32_t qc, uint32_t rlo, uint32_t rhi, int oe_del,
+                                               int e_del, int oe_ins, int e_ins) {
+    const int sc = (int)__builtin_amdgcn_perm(rhi, rlo, qc | 0x0c0c0c00u) - 128;
+    const int M = diag ? diag + sc : 0;
+    BswCellOut o;
+    o.h = max(max(M, e), f);
+    o.en = max(max(M - oe_del, e - e_del), 0);
+    o.f = max(max(M - oe_ins, f - e_ins), 0);
+    return o;
+}
+
+__global__ __launch_bounds__(64) void bsw_dp8(BswIO io, BswConst c, const uint32_t *__restrict__ perm, int64_t kbeg,
+                                              int64_t kend, int qcap, int32_t *__restrict__ score_out,
+                                              gab_bsw_result *__restrict__ result_out, BswStats *st) {
+    extern __shared__ uint32_t lds[];
+    const int lane = threadIdx.x;
+    const int64_t k = kbeg + (int64_t)blockIdx.x * 64 + lane;
+    const bool valid = k < kend;
+    const uint32_t id = valid ? perm[k] : 0u;
+    const int ncell_dw = (qcap + 2) / 2;
+    // cell j of this lane: 16 bits at byte address ((j >> 1) * 64 + lane) * 4 + (j & 1) * 2
+    uint8_t *const CB = reinterpret_cast<uint8_t *>(lds + lane);
+    uint32_t *const CW = lds + lane;                                   // pair p = columns 2p, 2p+1 at CW[p * 64]
+    uint8_t *const QN = reinterpret_cast<uint8_t *>(lds + (size_t)ncell_dw * 64) + lane * 4;   // nibble pair p at QN[(p >> 2) * 256 + (p & 3)]
+#define CELL16(j) (*reinterpret_cast<uint16_t *>(CB + ((j) >> 1) * 256 + ((j) & 1) * 2))
+#define QPAIR(p) (QN[((p) >> 2) * 256 + ((p) & 3)])
+
+    unsigned long long cells = 0;
+    if (valid) {
+        const int qlen = io.len2[id], tlen = io.len1[id], h0 = io.h0[id];
+        const uint8_t *q = io.qry + io.qry_off[id];
+        const uint8_t *t = io.ref + io.ref_off[id];
+        const int oe_del = c.o_del + c.e_del, oe_ins = c.o_ins + c.e_ins;
+        const int e_del = c.e_del, e_ins = c.e_ins;
+
+        // query -> nibbles (codes above 4 count as N)
+        for (int p0 = 0; p0 * 2 < qlen; p0 += 4) {             // 8 bases -> 4 nibble bytes -> one dword
+            const uint32_t w0 = load_u32_unaligned(q + p0 * 2);
+            const uint32_t w1 = p0 * 2 + 4 < qlen ? load_u32_unaligned(q + p0 * 2 + 4) : 0u;
+            uint32_t packed = 0;
+            for (int b = 0; b < 4; b++) {
+                const uint32_t src = b < 2 ? w0 : w1;
+                uint32_t lo = (src >> ((b & 1) * 16)) & 0xff, hi = (src >> ((b & 1) * 16 + 8)) & 0xff;
+                lo = lo > 4u ? 4u : lo; hi = hi > 4u ? 4u : hi;
+                packed |= (lo | hi << 4) << (8 * b);
+            }
+            *reinterpret_cast<uint32_t *>(QN + (p0 >> 2) * 256) = packed;
+        }
+        // row -1 (bandedSWA.cpp:159-161); E = 0
+        {
+            int prev = h0;
+            for (int j = 0; j <= qlen; j++) {
+                int v;
+                if (j == 0) v = h0;
+                else if (j == 1) v = h0 > oe_ins ? h0 - oe_ins : 0;
+                else v = prev > e_ins ? prev - e_ins : 0;
+                prev = v;
+                CELL16(j) = (uint16_t)v;
+            }
+        }
+        int w = c.w;
+        {
+            int lim = (int)((double)(qlen * c.max_sc + c.end_bonus - c.o_ins) / e_ins + 1.);
+            lim = lim > 1 ? lim : 1; w = w < lim ? w : lim;
+            lim = (int)((double)(qlen * c.max_sc + c.end_bonus - c.o_del) / e_del + 1.);
+            lim = lim > 1 ? lim : 1; w = w < lim ? w : lim;
+        }
+        int best = h0, best_i = -1, best_j = -1, g_i = -1, gscore = -1, max_off = 0;
+        int beg = 0, end = qlen;
+        uint32_t tw = load_u32_unaligned(t);
+        for (int i = 0; i < tlen; i++) {
+            const int tc = (tw >> ((i & 3) * 8)) & 0xff;
+            if ((i & 3) == 3 && i + 1 < tlen) tw = load_u32_unaligned(t + i + 1);
+            uint32_t rlo = c.row_lo[4], rhi = c.row_hi[4];
+            rlo = tc == 0 ? c.row_lo[0] : rlo; rhi = tc == 0 ? c.row_hi[0] : rhi;
+            rlo = tc == 1 ? c.row_lo[1] : rlo; rhi = tc == 1 ? c.row_hi[1] : rhi;
+            rlo = tc == 2 ? c.row_lo[2] : rlo; rhi = tc == 2 ? c.row_hi[2] : rhi;
+            rlo = tc == 3 ? c.row_lo[3] : rlo; rhi = tc == 3 ? c.row_hi[3] : rhi;
+            if (beg < i - w) beg = i - w;
+            if (end > i + w + 1) end = i + w + 1;
+            if (end > qlen) end = qlen;
+            int hleft = 0;
+            if (beg == 0) { hleft = h0 - (c.o_del + e_del * (i + 1)); hleft = hleft > 0 ? hleft : 0; }
+            int f = 0;
+            uint32_t rowpk = 0;                   // (row max << 16) | column; ties -> later column
+            int j = beg;
+            if ((j & 1) && j < end) {             // band starts on the upper half of a pair
+                const uint32_t v = CELL16(j);
+                const BswCellOut o = bsw_cell((int)(v & 0xff), (int)(v >> 8), f, (uint32_t)(QPAIR(j >> 1) >> 4), rlo, rhi, oe_del,
+                                              e_del, oe_ins, e_ins);
+                CELL16(j) = (uint16_t)(hleft | o.en << 8);
+                hleft = o.h; f = o.f;
+                const uint32_t pk = ((uint32_t)o.h << 16) | (uint32_t)j;
+                rowpk = pk > rowpk ? pk : rowpk;
+                j++;
+            }
+            if (j + 1 < end) {
+                // software pipeline: the next pair's words are in flight while this pair is computed
+                uint32_t v = CW[(j >> 1) * 64];
+                uint32_t qb = QPAIR(j >> 1);
+                for (; j + 1 < end; j += 2) {
+                    const int p = j >> 1;
+                    const uint32_t vn = CW[(p + 1) * 64];            // always inside the (qcap + 2) / 2 dwords
+                    const uint32_t qn = QPAIR(p + 1);
+                    const BswCellOut a = bsw_cell((int)(v & 0xff), (int)(v >> 8 & 0xff), f, qb & 0xfu, rlo, rhi, oe_del, e_del,
+                                                  oe_ins, e_ins);
+                    const BswCellOut b = bsw_cell((int)(v >> 16 & 0xff), (int)(v >> 24), a.f, qb >> 4, rlo, rhi, oe_del, e_del,
+                                                  oe_ins, e_ins);
+                    CW[p * 64] = (uint32_t)hleft | (uint32_t)a.en << 8 | (uint32_t)a.h << 16 | (uint32_t)b.en << 24;
+                    const uint32_t pa = ((uint32_t)a.h << 16) | (uint32_t)j, pb = ((uint32_t)b.h << 16) | (uint32_t)(j + 1);
+                    rowpk = max(max(rowpk, pa), pb);
+                    hleft = b.h; f = b.f;
+                    v = vn; qb = qn;
+                }
+            }
+            if (j < end) {                        // band ends on the lower half of a pair
+                const uint32_t v = CELL16(j);
+                const BswCellOut o = bsw_cell((int)(v & 0xff), (int)(v >> 8), f, (uint32_t)(QPAIR(j >> 1) & 0xfu), rlo, rhi, oe_del,
+                                              e_del, oe_ins, e_ins);
+                CELL16(j) = (uint16_t)(hleft | o.en << 8);
+                hleft = o.h; f = o.f;
+                const uint32_t pk = ((uint32_t)o.h << 16) | (uint32_t)j;
+                rowpk = pk > rowpk ? pk : rowpk;
+                j++;
+            }
+            cells += (unsigned)(end > beg ? end - beg : 0);
+            const int rowmax = (int)(rowpk >> 16);
+            const int rowmax_j = end > beg ? (int)(rowpk & 0xffffu) : -1;
+            CELL16(end) = (uint16_t)hleft;        // eh[end].h = h1, eh[end].e = 0
+            if (j == qlen) {
+                if (!(gscore > hleft)) g_i = i;
+                gscore = hleft > gscore ? hleft : gscore;
+            }
+            if (rowmax == 0) break;
+            if (rowmax > best) {
+                best = rowmax; best_i = i; best_j = rowmax_j;
+                int off = rowmax_j - i; off = off < 0 ? -off : off;
+                max_off = off > max_off ? off : max_off;
+            } else if (c.zdrop > 0) {
+                int di = i - best_i, dj = rowmax_j - best_j;
+                if (di > dj) { if (best - rowmax - (di - dj) * e_del > c.zdrop) break; }
+                else { if (best - rowmax - (dj - di) * e_ins > c.zdrop) break; }
+            }
+            for (j = beg; j < end && CELL16(j) == 0; j++) {}
+            beg = j;
+            for (j = end; j >= beg && CELL16(j) == 0; j--) {}
+            end = j + 2 < qlen ? j + 2 : qlen;
+        }
+        score_out[id] = best;
+        if (result_out) {
+            gab_bsw_result r;
+            r.score = best; r.qle = best_j + 1; r.tle = best_i + 1;
+            r.gtle = g_i + 1; r.gscore = gscore; r.max_off = max_off;
+            result_out[id] = r;
+        }
+    }
+#undef CELL16
+#undef QPAIR
+    for (int o = 32; o > 0; o >>= 1) cells += __shfl_xor(cells, o);
+    if (lane == 0 && cells) atomicAdd(&st->cells, cells);
+}
+
 }  // namespace
 
 // =============================================================================== host side
@@ -318,7 +490,8 @@ extern "C" int gab_bsw_create(const gab_bsw_params *p, int device, gab_bsw **out
         if (hipEventCreate(&h->ev[k]) != hipSuccess) { gab_set_error("hipEventCreate failed"); delete h; return GAB_EDEVICE; }
     // the 256-base class needs more than the default 64 KiB of dynamic LDS
     if (hipFuncSetAttribute((const void *)bsw_dp<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
-        hipFuncSetAttribute((const void *)bsw_dp<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+        hipFuncSetAttribute((const void *)bsw_dp<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+        hipFuncSetAttribute((const void *)bsw_dp8, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
         gab_set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed"); delete h; return GAB_EDEVICE;
     }
     if (hipHostMalloc((void **)&h->h_qstart, sizeof(uint32_t) * (kQBuckets + 1)) != hipSuccess ||
@@ -397,8 +570,15 @@ extern "C" int gab_bsw_run_device(gab_bsw *h, const uint8_t *ref, int64_t ref_by
         const int64_t kb = h->h_qstart[cls * kClassStep], ke = h->h_qstart[(cls + 1) * kClassStep];
         if (ke <= kb) continue;
         const int qcap = (cls + 1) * kClassStep;
-        const size_t lds = sizeof(uint32_t) * 64 * ((size_t)(wide ? 2 : 1) * (qcap + 1) + (size_t)(qcap + 3) / 4);
         const int blocks = (int)gab_ceil_div(ke - kb, 64);
+        // 8-bit cells when every H/E value of this class fits a byte: H <= h0 + qlen * max_sc
+        if ((int64_t)h->h_stats->max_h0 + (int64_t)qcap * h->cst.max_sc <= 255 && h->cst.max_sc >= 0) {
+            const size_t lds8 = sizeof(uint32_t) * 64 * ((size_t)(qcap + 2) / 2 + ((size_t)(qcap + 1) / 2 + 3) / 4 + 1);
+            hipLaunchKernelGGL(bsw_dp8, dim3(blocks), dim3(64), lds8, s, io, h->cst, d_perm, kb, ke, qcap, score_out, result_out,
+                               d_stats);
+            continue;
+        }
+        const size_t lds = sizeof(uint32_t) * 64 * ((size_t)(wide ? 2 : 1) * (qcap + 1) + (size_t)(qcap + 3) / 4);
         if (wide)
             hipLaunchKernelGGL(bsw_dp<true>, dim3(blocks), dim3(64), lds, s, io, h->cst, d_perm, kb, ke, qcap,
                                score_out, result_out, d_stats);
