@@ -80,10 +80,15 @@ __device__ __forceinline__ uint32_t glb_ld4(const char *p) { uint32_t w; __built
 // One pair, one wave.  LDSSEQ: P/T are LDS copies padded with kSeqPad bytes of 'X'/'Y';
 // otherwise they are the global sequences (readable to a multiple of 4 bytes past the end).
 // Returns false if the history did not fit (nothing has been written to the outputs then).
-template <typename OffT, bool LDSSEQ>
+// G = lanes cooperating on the pair (64 = a whole wave, 16 = four pairs per wave); all G lanes run this function
+// with identical control flow, other groups of the same wave may take different branches (SIMT divergence).
+template <typename OffT, bool LDSSEQ, int G>
 __device__ bool wfa_pair(WfStore<OffT> &st, const WfaPen pen, const uint8_t *P, int plen, const uint8_t *T, int tlen,
-                         char *ops, int32_t *ops_len_out, int32_t *score_out, unsigned long long &work) {
-    const int lane = threadIdx.x;
+                         char *ops_global, char *ops_lds, int32_t *ops_len_out, int32_t *score_out, unsigned long long &work) {
+    // the backtrace writes right-aligned into `ops`: an LDS buffer when the caller has one (then the CIGAR leaves the CU
+    // once, left-aligned and coalesced), else the pair's own output region (shifted in place afterwards)
+    char *ops = ops_lds ? ops_lds : ops_global;
+    const int lane = threadIdx.x & (G - 1);
     const int x = pen.x, oe = pen.o + pen.e, e = pen.e;
     const int ak = tlen - plen;
     auto pch = [&](int v) -> int { return (v >= 0 && v < plen) ? (int)P[v] : (int)'X'; };
@@ -100,7 +105,7 @@ __device__ bool wfa_pair(WfStore<OffT> &st, const WfaPen pen, const uint8_t *P, 
         WfDir cur = st.get(score);
         if (cur.m != kNone) {
             // ---- extend every diagonal of M[score]
-            for (int k = cur.lo + lane; k <= cur.hi; k += 64) {
+            for (int k = cur.lo + lane; k <= cur.hi; k += G) {
                 int o = (int)st.pool[cur.m + (k - cur.lo)];
                 int v = o - k, h = o;
                 for (;;) {
@@ -152,7 +157,7 @@ __device__ bool wfa_pair(WfStore<OffT> &st, const WfaPen pen, const uint8_t *P, 
         const int bM = st.used, bI = has_i ? bM + width : kNone, bD = has_d ? bM + width * (has_i ? 2 : 1) : kNone;
         st.used += need;
         if (lane == 0) { dd[0] = lo; dd[1] = hi; dd[2] = bM; dd[3] = bI; dd[4] = bD; }
-        for (int k = lo + lane; k <= hi; k += 64) {
+        for (int k = lo + lane; k <= hi; k += G) {
             int best = (!n_ms && ms.lo <= k && k <= ms.hi) ? (int)st.pool[ms.m + (k - ms.lo)] + 1 : kNull;
             if (has_i) {
                 const int ins = max(st.at(mg.m, mg.lo, mg.hi, k - 1), st.at(ie_base, ie.lo, ie.hi, k - 1)) + 1;
@@ -183,7 +188,7 @@ __device__ bool wfa_pair(WfStore<OffT> &st, const WfaPen pen, const uint8_t *P, 
         int v = offset - k, h = offset;
         auto put = [&](char c) { if (lane == 0) ops[pos] = c; pos--; };
         auto put_run = [&](char c, int cnt) {
-            for (int i = lane; i < cnt; i += 64) ops[pos - i] = c;
+            for (int i = lane; i < cnt; i += G) ops[pos - i] = c;
             pos -= cnt > 0 ? cnt : 0;
         };
         while (v > 0 && h > 0 && s > 0) {
@@ -220,9 +225,11 @@ __device__ bool wfa_pair(WfStore<OffT> &st, const WfaPen pen, const uint8_t *P, 
     pos++;
     const int nops = cap - pos;
     __syncthreads();
-    // shift left by `pos` bytes, 64 bytes per step (sources of a step are read before its stores)
-    if (pos > 0) {
-        for (int c0 = 0; c0 < nops; c0 += 64) {
+    if (ops_lds) {
+        for (int i = lane; i < nops; i += G) ops_global[i] = ops_lds[pos + i];
+    } else if (pos > 0) {
+        // shift left by `pos` bytes, G bytes per step (sources of a step are read before its stores)
+        for (int c0 = 0; c0 < nops; c0 += G) {
             const int i = c0 + lane;
             char c = 0;
             if (i < nops) c = ops[pos + i];
@@ -259,33 +266,42 @@ __global__ __launch_bounds__(256) void wfa_classify(WfaIO io, WfaCounters *ct, u
     if ((threadIdx.x & 63) == 0) { atomicMax(&ct->max_plen, mp); atomicMax(&ct->max_tlen, mt); }
 }
 
-// ---- LDS kernel: one wave per pair ---------------------------------------------------------------
-// dynamic LDS: [dir: 5*dir_cap ints][P: seqp bytes][T: seqt bytes][pool: pool_cap int16]
+// ---- LDS kernel: one G-lane group per pair, 64 / G pairs per wave (= per workgroup) ----------------
+// dynamic LDS per group: [dir: 5*dir_cap ints][P: seqp bytes][T: seqt bytes][pool: pool_cap int16]; the CIGAR is built over P/T
+template <int G>
 __global__ __launch_bounds__(64) void wfa_lds(WfaIO io, WfaPen pen, const uint32_t *__restrict__ list, uint32_t count,
-                                              int dir_cap, int seqp, int seqt, int pool_cap, uint32_t *over_list,
-                                              WfaCounters *ct) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const uint32_t b = blockIdx.x;
-    if (b >= count) return;
-    const uint32_t id = list[b];
-    const int lane = threadIdx.x;
-    int *dir = reinterpret_cast<int *>(smem);
-    uint8_t *P = smem + (size_t)dir_cap * 20;
-    uint8_t *T = P + seqp;
-    int16_t *pool = reinterpret_cast<int16_t *>(T + seqt);
-    const int plen = io.pat_len[id], tlen = io.txt_len[id];
-    const char *gp = io.pat + io.pat_off[id], *gt = io.txt + io.txt_off[id];
-    for (int i = lane; i < plen + kSeqPad; i += 64) P[i] = i < plen ? (uint8_t)gp[i] : (uint8_t)'X';
-    for (int i = lane; i < tlen + kSeqPad; i += 64) T[i] = i < tlen ? (uint8_t)gt[i] : (uint8_t)'Y';
-    __syncthreads();
-    WfStore<int16_t> st;
-    st.pool = pool; st.dir = dir; st.pool_cap = pool_cap; st.dir_cap = dir_cap; st.used = 0;
+                                              int dir_cap, int seqp, int seqt, int pool_cap, uint32_t group_bytes,
+                                              uint32_t *over_list, WfaCounters *ct) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem_all[];
+    constexpr int kGroups = 64 / G;
+    const int grp = threadIdx.x / G, lane = threadIdx.x & (G - 1);
+    const uint32_t b = blockIdx.x * kGroups + grp;
     unsigned long long work = 0;
-    const bool ok = wfa_pair<int16_t, true>(st, pen, P, plen, T, tlen, io.ops + io.ops_off[id], io.ops_len + id,
-                                            io.score + id, work);
-    if (!ok && lane == 0) over_list[atomicAdd(&ct->n_over, 1u)] = id;
+    bool ok = true, have = b < count;
+    uint32_t id = 0;
+    if (have) {
+        id = list[b];
+        uint8_t *smem = smem_all + (size_t)grp * group_bytes;
+        int *dir = reinterpret_cast<int *>(smem);
+        uint8_t *P = smem + (size_t)dir_cap * 20;
+        uint8_t *T = P + seqp;
+        // the backtrace never looks at the strings (affine_wavefronts_backtrace_matches__check only counts), so their
+        // LDS region doubles as the CIGAR buffer: plen + tlen <= seqp + seqt bytes
+        char *opsbuf = reinterpret_cast<char *>(P);
+        int16_t *pool = reinterpret_cast<int16_t *>(T + seqt);
+        const int plen = io.pat_len[id], tlen = io.txt_len[id];
+        const char *gp = io.pat + io.pat_off[id], *gt = io.txt + io.txt_off[id];
+        for (int i = lane; i < plen + kSeqPad; i += G) P[i] = i < plen ? (uint8_t)gp[i] : (uint8_t)'X';
+        for (int i = lane; i < tlen + kSeqPad; i += G) T[i] = i < tlen ? (uint8_t)gt[i] : (uint8_t)'Y';
+        __syncthreads();
+        WfStore<int16_t> st;
+        st.pool = pool; st.dir = dir; st.pool_cap = pool_cap; st.dir_cap = dir_cap; st.used = 0;
+        ok = wfa_pair<int16_t, true, G>(st, pen, P, plen, T, tlen, io.ops + io.ops_off[id], opsbuf, io.ops_len + id, io.score + id, work);
+        if (!ok && lane == 0) over_list[atomicAdd(&ct->n_over, 1u)] = id;
+    }
+    if (!have || !ok) work = 0;
     for (int o = 32; o > 0; o >>= 1) work += __shfl_xor(work, o);
-    if (lane == 0 && ok) atomicAdd(&ct->work, work);
+    if (threadIdx.x == 0 && work) atomicAdd(&ct->work, work);
 }
 
 // ---- global kernel: int32 history in a scratch slab, any length ------------------------------
@@ -300,9 +316,9 @@ __global__ __launch_bounds__(64) void wfa_global(WfaIO io, WfaPen pen, const uin
         WfStore<int32_t> st;
         st.dir = mine; st.pool = mine + (int64_t)dir_cap * 5; st.pool_cap = pool_cap; st.dir_cap = dir_cap; st.used = 0;
         unsigned long long work = 0;
-        const bool ok = wfa_pair<int32_t, false>(st, pen, (const uint8_t *)(io.pat + io.pat_off[id]), plen,
+        const bool ok = wfa_pair<int32_t, false, 64>(st, pen, (const uint8_t *)(io.pat + io.pat_off[id]), plen,
                                                  (const uint8_t *)(io.txt + io.txt_off[id]), tlen,
-                                                 io.ops + io.ops_off[id], io.ops_len + id, io.score + id, work);
+                                                 io.ops + io.ops_off[id], nullptr, io.ops_len + id, io.score + id, work);
         if (!ok && lane == 0) over_list[atomicAdd(&ct->n_over, 1u)] = id;
         for (int o = 32; o > 0; o >>= 1) work += __shfl_xor(work, o);
         if (lane == 0 && ok) atomicAdd(&ct->work, work);
@@ -343,7 +359,8 @@ extern "C" int gab_wfa_create(const gab_wfa_penalties *p, int device, gab_wfa **
     for (int k = 0; k < 4; k++)
         if (hipEventCreate(&h->ev[k]) != hipSuccess) { gab_set_error("hipEventCreate failed"); delete h; return GAB_EDEVICE; }
     if (hipHostMalloc((void **)&h->h_ct, sizeof(WfaCounters)) != hipSuccess ||
-        hipFuncSetAttribute((const void *)wfa_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+        hipFuncSetAttribute((const void *)wfa_lds<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+        hipFuncSetAttribute((const void *)wfa_lds<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
         gab_set_error("gab_wfa_create: pinned allocation / LDS attribute failed"); delete h; return GAB_EDEVICE;
     }
     *out = h;
@@ -398,21 +415,28 @@ extern "C" int gab_wfa_run_device(gab_wfa *h, const char *pat, int64_t pat_bytes
     int64_t requeued = 0;
 
     GAB_HIP(hipEventRecord(h->ev[1], s));
-    // pass 1 / pass 2: LDS kernels with a small, then a large, history pool
+    // LDS passes: (1) four pairs per wave with a 2 KB history each (scores up to ~35: the bulk of short-read pairs),
+    // (2) one pair per wave with 12 KB, (3) one pair per wave with 96 KB; whatever overflows goes to global memory
     uint32_t *cur = l_a, *nxt = l_b;
     uint32_t cnt = n_lds;
     bool ev2 = false;
-    const int pool_bytes[2] = {12 * 1024, 96 * 1024};
-    const int dir_caps[2] = {128, 640};
-    for (int pass = 0; pass < 2 && cnt; pass++) {
-        const int dir_cap = dir_caps[pass];
-        const size_t fixed = (size_t)dir_cap * 20 + seqp + seqt;
-        const size_t lds = fixed + pool_bytes[pass];
+    const int pool_bytes[3] = {2 * 1024, 12 * 1024, 96 * 1024};
+    const int dir_caps[3] = {48, 128, 640};
+    const int groups[3] = {16, 64, 64};
+    for (int pass = 0; pass < 3 && cnt; pass++) {
+        const int dir_cap = dir_caps[pass], G = groups[pass];
+        const size_t per_group = (((size_t)dir_cap * 20 + (size_t)(seqp + seqt) + pool_bytes[pass]) + 15) & ~(size_t)15;
+        const size_t lds = per_group * (64 / G);
         if (lds > 160 * 1024 - 512) continue;            // sequences too long for this pool: let the next stage take them
         h->h_ct->n_over = 0;
         GAB_HIP(hipMemsetAsync(&d_ct->n_over, 0, 4, s));
-        hipLaunchKernelGGL(wfa_lds, dim3(cnt), dim3(64), lds, s, io, h->pen, cur, cnt, dir_cap, seqp, seqt,
-                           pool_bytes[pass] / 2, nxt, d_ct);
+        const unsigned blocks = (cnt + (64 / G) - 1) / (64 / G);
+        if (G == 16)
+            hipLaunchKernelGGL(wfa_lds<16>, dim3(blocks), dim3(64), lds, s, io, h->pen, cur, cnt, dir_cap, seqp, seqt,
+                               pool_bytes[pass] / 2, (uint32_t)per_group, nxt, d_ct);
+        else
+            hipLaunchKernelGGL(wfa_lds<64>, dim3(blocks), dim3(64), lds, s, io, h->pen, cur, cnt, dir_cap, seqp, seqt,
+                               pool_bytes[pass] / 2, (uint32_t)per_group, nxt, d_ct);
         GAB_HIP(hipGetLastError());
         if (!ev2) { GAB_HIP(hipEventRecord(h->ev[2], s)); ev2 = true; }
         GAB_HIP(hipMemcpyAsync(h->h_ct, d_ct, sizeof(WfaCounters), hipMemcpyDeviceToHost, s));
