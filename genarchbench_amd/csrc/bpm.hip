@@ -36,6 +36,7 @@ namespace {
 constexpr int kMaxRegW = 4;                 // W classes kept in registers
 constexpr int kClasses = kMaxRegW + 1;      // class c = W for W <= 4, class 0 = W > 4
 constexpr int kBlock = 256;
+constexpr int kBandRows = 16;               // rows kept per column by the LDS band kernel
 
 struct BpmIO {
     const char *pat; const int64_t *pat_off; const int32_t *pat_len;
@@ -47,6 +48,9 @@ struct BpmCounters {        // device-side, zeroed per run
     uint32_t cls_count[8];  // pairs per W class (index = class)
     uint32_t cls_cursor[8];
     uint32_t wl_count[8];   // queued (unclean) pairs per class
+    uint32_t wl2_count[8];  // pairs whose backtrace left the 64-row window (re-run with the full history)
+    uint32_t wl1_count[8];  // pairs whose backtrace left the 16-row LDS band (re-run with the 64-row window)
+    int32_t max_tlen[8];    // longest text per class (sizes the LDS band)
     int32_t bad, first_bad;
     unsigned long long steps;   // block steps executed by bpm_score (m * W summed)
     unsigned long long full_steps;
@@ -68,6 +72,9 @@ __device__ __forceinline__ int bpm_code(uint32_t ch, bool &clean) {
 }
 
 __device__ __forceinline__ uint32_t ld_u32(const char *p) { uint32_t w; __builtin_memcpy(&w, p, 4); return w; }
+// 16 bytes per lane and load: every lane streams its own sequence, and with 4-byte loads each 64-byte line was
+// re-fetched from HBM up to 16 times (profiles/r01_hbm_traffic.md: 8.7x the algorithmic bytes, HBM-bound)
+__device__ __forceinline__ uint4 ld_u128(const char *p) { uint4 w; __builtin_memcpy(&w, p, 16); return w; }
 
 // Wave-aggregated "counters[cls] += 1" returning each lane's slot: one atomic per (wave, class present)
 // instead of one per lane (all 10 M pairs of the 151-bp workload share one class, i.e. one address).
@@ -89,37 +96,56 @@ __device__ __forceinline__ uint32_t wave_class_add(uint32_t *counters, int cls, 
 }
 
 // ---- pass 1: validate + count per class ---------------------------------------------------
+// counts are accumulated per lane over the grid-stride loop and reduced once per wave: a single atomic per class and
+// wave (with 10 M pairs in one class, an atomic per wave-iteration still serialised on one address for ~1.7 ms)
 __global__ __launch_bounds__(256) void bpm_count(BpmIO io, BpmCounters *ct) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    // wave-uniform trip count so that the ballots inside wave_class_add see every lane
-    for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x; i0 < io.n; i0 += stride) {
-        const int64_t i = i0 + threadIdx.x;
-        bool ok = false;
-        int n = 1;
-        if (i < io.n) {
-            n = io.pat_len[i];
-            const int m = io.txt_len[i];
-            const int64_t po = io.pat_off[i], to = io.txt_off[i];
-            ok = n >= 1 && n <= GAB_BPM_MAX_PLEN && m >= 0 && m <= n && po >= 0 && to >= 0 &&
-                 ((po + n + 3) & ~3ll) <= io.pat_bytes && ((to + m + 3) & ~3ll) <= io.txt_bytes;
-            if (!ok) {
-                atomicAdd(&ct->bad, 1);
-                atomicMin((unsigned int *)&ct->first_bad, (unsigned int)(i + 1 > 0x7fffffff ? 0x7fffffff : i + 1));
-            }
+    uint32_t mine[kClasses] = {0, 0, 0, 0, 0};
+    int mt[kClasses] = {0, 0, 0, 0, 0};
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < io.n; i += stride) {
+        const int n = io.pat_len[i], m = io.txt_len[i];
+        const int64_t po = io.pat_off[i], to = io.txt_off[i];
+        const bool ok = n >= 1 && n <= GAB_BPM_MAX_PLEN && m >= 0 && m <= n && po >= 0 && to >= 0 &&
+                        ((po + n + 3) & ~3ll) <= io.pat_bytes && ((to + m + 3) & ~3ll) <= io.txt_bytes;
+        if (!ok) {
+            atomicAdd(&ct->bad, 1);
+            atomicMin((unsigned int *)&ct->first_bad, (unsigned int)(i + 1 > 0x7fffffff ? 0x7fffffff : i + 1));
+            continue;
         }
-        (void)wave_class_add(ct->cls_count, bpm_class(n), ok);
+        const int cls = bpm_class(n);
+#pragma unroll
+        for (int k = 0; k < kClasses; k++) { mine[k] += cls == k; mt[k] = (cls == k && m > mt[k]) ? m : mt[k]; }
+    }
+#pragma unroll
+    for (int k = 0; k < kClasses; k++) {
+        int v = mt[k];
+        for (int o = 32; o > 0; o >>= 1) { const int u = __shfl_xor(v, o); v = u > v ? u : v; }
+        if ((threadIdx.x & 63) == 0 && v > 0) atomicMax(&ct->max_tlen[k], v);
+    }
+#pragma unroll
+    for (int k = 0; k < kClasses; k++) {
+        uint32_t v = mine[k];
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        if ((threadIdx.x & 63) == 0 && v) atomicAdd(&ct->cls_count[k], v);
     }
 }
 
-// ---- pass 2: scatter ids by class ---------------------------------------------------------
+// ---- pass 2: scatter ids by class (only when more than one class is populated) -----------------------------
+// every workgroup owns one contiguous chunk: it counts its classes in LDS, reserves its ranges with one global
+// atomic per class, then hands out slots with LDS atomics
 __global__ __launch_bounds__(256) void bpm_scatter(BpmIO io, BpmCounters *ct, uint32_t *perm) {
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x; i0 < io.n; i0 += stride) {
-        const int64_t i = i0 + threadIdx.x;
-        const bool in = i < io.n;
-        const int n = in ? io.pat_len[i] : 1;
-        const uint32_t slot = wave_class_add(ct->cls_cursor, bpm_class(n), in);
-        if (in) perm[slot] = (uint32_t)i;
+    __shared__ uint32_t cnt[kClasses], base[kClasses];
+    const int64_t per = (io.n + gridDim.x - 1) / gridDim.x;
+    const int64_t b = (int64_t)blockIdx.x * per, e = b + per < io.n ? b + per : io.n;
+    if (threadIdx.x < kClasses) cnt[threadIdx.x] = 0;
+    __syncthreads();
+    for (int64_t i = b + threadIdx.x; i < e; i += blockDim.x) atomicAdd(&cnt[bpm_class(io.pat_len[i])], 1u);
+    __syncthreads();
+    if (threadIdx.x < kClasses) { base[threadIdx.x] = cnt[threadIdx.x] ? atomicAdd(&ct->cls_cursor[threadIdx.x], cnt[threadIdx.x]) : 0; cnt[threadIdx.x] = 0; }
+    __syncthreads();
+    for (int64_t i = b + threadIdx.x; i < e; i += blockDim.x) {
+        const int cls = bpm_class(io.pat_len[i]);
+        perm[base[cls] + atomicAdd(&cnt[cls], 1u)] = (uint32_t)i;
     }
 }
 
@@ -140,11 +166,22 @@ __device__ __forceinline__ void bpm_step(uint64_t Eq, uint64_t mask, uint64_t &P
 }
 
 // Builds the 4W+1 match masks of this lane in LDS (peq[mask * kBlock + tid]); returns cleanliness.
-template <int W>
+template <int W, int kBlock = 256>
 __device__ __forceinline__ bool bpm_build_peq(uint64_t *peq, const char *p, int n) {
     for (int k = 0; k < 4 * W + 1; k++) peq[k * kBlock] = 0;
     bool clean = true;
-    for (int i0 = 0; i0 < n; i0 += 4) {
+    int i0 = 0;
+    for (; i0 + 16 <= n; i0 += 16) {
+        const uint4 q = ld_u128(p + i0);
+        const uint32_t ws[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const int i = i0 + k;
+            const int c = bpm_code((ws[k >> 2] >> ((k & 3) * 8)) & 0xffu, clean);
+            atomicOr((unsigned long long *)&peq[((i >> 6) * 4 + c) * kBlock], 1ull << (i & 63));
+        }
+    }
+    for (; i0 < n; i0 += 4) {
         uint32_t w = ld_u32(p + i0);
         for (int k = 0; k < 4 && i0 + k < n; k++, w >>= 8) {
             const int i = i0 + k;
@@ -170,7 +207,7 @@ __global__ __launch_bounds__(kBlock) void bpm_score(BpmIO io, const uint32_t *__
     unsigned long long steps = 0;
     int64_t queue_id = -1;
     if (k < kend) {
-        const uint32_t id = perm[k];
+        const uint32_t id = perm ? perm[k] : k;        // perm == nullptr: all pairs share this class, identity order
         const int n = io.pat_len[id], m = io.txt_len[id];
         const char *p = io.pat + io.pat_off[id], *t = io.txt + io.txt_off[id];
         uint64_t *peq = peq_s + threadIdx.x;
@@ -180,7 +217,21 @@ __global__ __launch_bounds__(kBlock) void bpm_score(BpmIO io, const uint32_t *__
         for (int b = 0; b < W; b++) { P[b] = ~0ull; M[b] = 0; }
         const uint64_t top_mask = (n & 63) ? 1ull << ((n & 63) - 1) : 1ull << 63;
         int score = n;
-        for (int h0 = 0; h0 < m; h0 += 4) {
+        int h0 = 0;
+        for (; h0 + 16 <= m; h0 += 16) {
+            const uint4 q = ld_u128(t + h0);
+            const uint32_t ws[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+            for (int kk = 0; kk < 16; kk++) {
+                const int c = bpm_code((ws[kk >> 2] >> ((kk & 3) * 8)) & 0xffu, clean);
+                uint32_t PH = 1, MH = 0;
+#pragma unroll
+                for (int b = 0; b < W; b++)
+                    bpm_step(peq[(b * 4 + c) * kBlock], b == W - 1 ? top_mask : 1ull << 63, P[b], M[b], PH, MH);
+                score += (int)PH - (int)MH;
+            }
+        }
+        for (; h0 < m; h0 += 4) {
             uint32_t w = ld_u32(t + h0);
             for (int kk = 0; kk < 4 && h0 + kk < m; kk++, w >>= 8) {
                 const int c = bpm_code(w & 0xffu, clean);
@@ -208,6 +259,164 @@ __global__ __launch_bounds__(kBlock) void bpm_score(BpmIO io, const uint32_t *__
     }
     for (int o = 32; o > 0; o >>= 1) steps += __shfl_xor(steps, o);
     if ((threadIdx.x & 63) == 0 && steps) atomicAdd(&ct->steps, steps);
+}
+
+// ---- LDS band path: 16 rows around the diagonal per column, history never leaves the CU -----------------------
+// First stop of a queued pair.  One pair per lane, one wave per workgroup; the column history is one dword per
+// column ({Pv, Mv} bits of the 16 rows around the diagonal) in LDS as [column][lane], so the ~300 dependent reads of
+// the backtrace cost LDS latency instead of HBM latency (the global-history kernels below spend ~20 ms of pure
+// latency on 1.4 M pairs).  A backtrace that drifts more than 7 rows off the diagonal is queued for bpm_win.
+// dynamic LDS: [ (4W+1) x 64 masks (u64) ][ (cols) x 64 dwords ]
+template <int W>
+__global__ __launch_bounds__(64) void bpm_band(BpmIO io, const uint32_t *__restrict__ list, uint32_t nslots, int cols,
+                                               int32_t *__restrict__ score_out, uint32_t *__restrict__ miss_list,
+                                               BpmCounters *ct) {
+    extern __shared__ uint64_t band_smem[];
+    const int lane = threadIdx.x;
+    const uint32_t s = blockIdx.x * 64 + lane;
+    int64_t miss_id = -1;
+    unsigned long long steps = 0;
+    if (s < nslots) {
+        const uint32_t id = list[s];
+        const int n = io.pat_len[id], m = io.txt_len[id];
+        const char *p = io.pat + io.pat_off[id], *t = io.txt + io.txt_off[id];
+        uint64_t *peq = band_smem + lane;
+        uint32_t *B = reinterpret_cast<uint32_t *>(band_smem + (4 * W + 1) * 64) + lane;      // column c at B[c * 64]
+        bpm_build_peq<W, 64>(peq, p, n);
+        const int cshift = (n - m) / 2;
+        auto start = [&](int col) { int r = col + cshift - kBandRows / 2; r = r < 0 ? 0 : r; return r > 64 * W - kBandRows ? 64 * W - kBandRows : r; };
+        const uint64_t top_mask = (n & 63) ? 1ull << ((n & 63) - 1) : 1ull << 63;
+        uint64_t P[W], M[W];
+#pragma unroll
+        for (int b = 0; b < W; b++) { P[b] = ~0ull; M[b] = 0; }
+        B[0] = 0x0000ffffu;                                       // column 0: Pv = 1..1, Mv = 0
+        bool dummy = true;
+        for (int h0 = 0; h0 < m; h0 += 4) {
+            uint32_t w4 = ld_u32(t + h0);
+            for (int kk = 0; kk < 4 && h0 + kk < m; kk++, w4 >>= 8) {
+                const int h = h0 + kk;
+                const int c = bpm_code(w4 & 0xffu, dummy);
+                uint32_t PH = 1, MH = 0;
+#pragma unroll
+                for (int b = 0; b < W; b++)
+                    bpm_step(peq[(b * 4 + c) * 64], b == W - 1 ? top_mask : 1ull << 63, P[b], M[b], PH, MH);
+                const int r0 = start(h + 1);
+                const int b0 = r0 >> 6, sh = r0 & 63;
+                uint64_t plo = P[0], phi = W > 1 ? P[W > 1 ? 1 : 0] : 0, mlo = M[0], mhi = W > 1 ? M[W > 1 ? 1 : 0] : 0;
+#pragma unroll
+                for (int b = 1; b < W; b++)
+                    if (b0 == b) { plo = P[b]; mlo = M[b]; phi = b + 1 < W ? P[b + 1 < W ? b + 1 : b] : 0; mhi = b + 1 < W ? M[b + 1 < W ? b + 1 : b] : 0; }
+                const uint32_t pw = (uint32_t)((sh ? (plo >> sh) | (phi << (64 - sh)) : plo) & 0xffffu);
+                const uint32_t mw = (uint32_t)((sh ? (mlo >> sh) | (mhi << (64 - sh)) : mlo) & 0xffffu);
+                B[(h + 1) * 64] = pw | mw << 16;
+            }
+        }
+        steps = (unsigned long long)m * W;
+        (void)cols;
+        int ops = 0, v = n - 1, h = m - 1;
+        bool miss = false;
+        while (v >= 0 && h >= 0) {
+            const int r1 = start(h + 1), rh = start(h);
+            if (v < r1 || v >= r1 + kBandRows || v < rh || v >= rh + kBandRows) { miss = true; break; }
+            if ((B[(h + 1) * 64] >> (v - r1)) & 1) { ops++; v--; }
+            else if ((B[h * 64] >> (16 + v - rh)) & 1) { ops++; h--; }
+            else { ops += t[h] != p[v]; h--; v--; }
+        }
+        if (miss) miss_id = (int64_t)id;
+        else score_out[id] = -(ops + (h + 1) + (v + 1));
+    }
+    {
+        const unsigned long long q = __ballot(miss_id >= 0);
+        if (q) {
+            const int leader = __builtin_ctzll(q);
+            uint32_t base = 0;
+            if (lane == leader) base = atomicAdd(&ct->wl1_count[W], (uint32_t)__popcll(q));
+            base = __shfl(base, leader);
+            if (miss_id >= 0) miss_list[base + (uint32_t)__popcll(q & ((1ull << lane) - 1))] = (uint32_t)miss_id;
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) steps += __shfl_xor(steps, o);
+    if (lane == 0 && steps) atomicAdd(&ct->full_steps, steps);
+}
+
+// ---- windowed path: history of a 64-row diagonal window + backtrace -----------------------------------------
+// The backtrace only ever looks at the Pv / Mv bit of the cell it stands on, and for similar sequences it stays
+// near the main diagonal.  So instead of the whole column (W words each of Pv and Mv) only the 64 rows around
+// the diagonal are kept: 16 bytes per column, four columns per 64-byte line (3x less scratch written, ~5x fewer
+// lines read back by the backtrace than with full columns).  If the walk ever steps outside the window the pair is
+// queued once more and handled by bpm_full with complete columns, so the result is exact in every case.
+template <int W>
+__device__ __forceinline__ int bpm_win_start(int col, int cshift) {
+    int r = col + cshift - 32;
+    r = r < 0 ? 0 : r;
+    return r > 64 * W - 64 ? 64 * W - 64 : r;
+}
+template <int W>
+__device__ __forceinline__ uint64_t bpm_win_take(const uint64_t (&X)[W], int r0) {
+    const int b0 = r0 >> 6, s = r0 & 63;
+    uint64_t lo = X[0], hi = W > 1 ? X[W > 1 ? 1 : 0] : 0;
+#pragma unroll
+    for (int b = 1; b < W; b++) if (b0 == b) { lo = X[b]; hi = b + 1 < W ? X[b + 1 < W ? b + 1 : b] : 0; }
+    return s ? (lo >> s) | (hi << (64 - s)) : lo;
+}
+template <int W>
+__global__ __launch_bounds__(kBlock) void bpm_win(BpmIO io, const uint32_t *__restrict__ list, uint32_t nslots,
+                                                  ulonglong2 *__restrict__ hist, int per_slot,
+                                                  int32_t *__restrict__ score_out, uint32_t *__restrict__ miss_list,
+                                                  BpmCounters *ct) {
+    __shared__ uint64_t peq_s[(4 * W + 1) * kBlock];
+    const uint32_t s = blockIdx.x * kBlock + threadIdx.x;
+    int64_t miss_id = -1;
+    unsigned long long steps = 0;
+    if (s < nslots) {
+        const uint32_t id = list[s];
+        const int n = io.pat_len[id], m = io.txt_len[id];
+        const char *p = io.pat + io.pat_off[id], *t = io.txt + io.txt_off[id];
+        uint64_t *peq = peq_s + threadIdx.x;
+        bpm_build_peq<W>(peq, p, n);
+        ulonglong2 *H = hist + (int64_t)s * per_slot;           // record of column c: {Pv window, Mv window}
+        const int cshift = (n - m) / 2;
+        const uint64_t top_mask = (n & 63) ? 1ull << ((n & 63) - 1) : 1ull << 63;
+        uint64_t P[W], M[W];
+#pragma unroll
+        for (int b = 0; b < W; b++) { P[b] = ~0ull; M[b] = 0; }
+        H[0] = make_ulonglong2(~0ull, 0ull);
+        bool dummy = true;
+        for (int h = 0; h < m; h++) {
+            const int c = bpm_code((uint8_t)t[h], dummy);
+            uint32_t PH = 1, MH = 0;
+#pragma unroll
+            for (int b = 0; b < W; b++)
+                bpm_step(peq[(b * 4 + c) * kBlock], b == W - 1 ? top_mask : 1ull << 63, P[b], M[b], PH, MH);
+            const int r0 = bpm_win_start<W>(h + 1, cshift);
+            H[h + 1] = make_ulonglong2(bpm_win_take<W>(P, r0), bpm_win_take<W>(M, r0));
+        }
+        steps = (unsigned long long)m * W;
+        // backtrace (edit_bpm.c:289-313) on the windows
+        int ops = 0, v = n - 1, h = m - 1;
+        bool miss = false;
+        while (v >= 0 && h >= 0) {
+            const int r1 = bpm_win_start<W>(h + 1, cshift), rh = bpm_win_start<W>(h, cshift);
+            if (v < r1 || v >= r1 + 64 || v < rh || v >= rh + 64) { miss = true; break; }
+            if ((H[h + 1].x >> (v - r1)) & 1) { ops++; v--; }
+            else if ((H[h].y >> (v - rh)) & 1) { ops++; h--; }
+            else { ops += t[h] != p[v]; h--; v--; }
+        }
+        if (miss) miss_id = (int64_t)id;
+        else score_out[id] = -(ops + (h + 1) + (v + 1));
+    }
+    {
+        const unsigned long long q = __ballot(miss_id >= 0);
+        if (q) {
+            const int leader = __builtin_ctzll(q);
+            uint32_t base = 0;
+            if ((int)(threadIdx.x & 63) == leader) base = atomicAdd(&ct->wl2_count[W], (uint32_t)__popcll(q));
+            base = __shfl(base, leader);
+            if (miss_id >= 0) miss_list[base + (uint32_t)__popcll(q & ((1ull << (threadIdx.x & 63)) - 1))] = (uint32_t)miss_id;
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) steps += __shfl_xor(steps, o);
+    if ((threadIdx.x & 63) == 0 && steps) atomicAdd(&ct->full_steps, steps);
 }
 
 // ---- full path: history + backtrace ---------------------------------------------------------------
@@ -321,6 +530,12 @@ extern "C" int gab_bpm_create(int device, gab_bpm **out) {
     h->device = device;
     for (int k = 0; k < 4; k++)
         if (hipEventCreate(&h->ev[k]) != hipSuccess) { gab_set_error("hipEventCreate failed"); delete h; return GAB_EDEVICE; }
+    if (hipFuncSetAttribute((const void *)bpm_band<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+        hipFuncSetAttribute((const void *)bpm_band<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+        hipFuncSetAttribute((const void *)bpm_band<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+        hipFuncSetAttribute((const void *)bpm_band<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+        gab_set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed"); delete h; return GAB_EDEVICE;
+    }
     if (hipHostMalloc((void **)&h->h_ct, sizeof(BpmCounters)) != hipSuccess) {
         gab_set_error("hipHostMalloc failed"); delete h; return GAB_ENOMEM;
     }
@@ -363,11 +578,13 @@ extern "C" int gab_bpm_run_device(gab_bpm *h, const char *pat, int64_t pat_bytes
 
     const size_t o_perm = (sizeof(BpmCounters) + 255) & ~(size_t)255;
     const size_t o_wl = o_perm + sizeof(uint32_t) * (size_t)n;
-    int rc = h->ws.reserve(o_wl + sizeof(uint32_t) * (size_t)n);
+    const size_t o_wl2 = o_wl + sizeof(uint32_t) * (size_t)n;
+    const size_t o_wl1 = o_wl2 + sizeof(uint32_t) * (size_t)n;
+    int rc = h->ws.reserve(o_wl1 + sizeof(uint32_t) * (size_t)n);
     if (rc) return rc;
     char *base = h->ws.as<char>();
     BpmCounters *d_ct = (BpmCounters *)base;
-    uint32_t *d_perm = (uint32_t *)(base + o_perm), *d_wl = (uint32_t *)(base + o_wl);
+    uint32_t *d_perm = (uint32_t *)(base + o_perm), *d_wl = (uint32_t *)(base + o_wl), *d_wl2 = (uint32_t *)(base + o_wl2), *d_wl1 = (uint32_t *)(base + o_wl1);
     BpmIO io{pat, pat_off, pat_len, txt, txt_off, txt_len, pat_bytes, txt_bytes, n};
 
     GAB_HIP(hipEventRecord(h->ev[0], s));
@@ -392,27 +609,76 @@ extern "C" int gab_bpm_run_device(gab_bpm *h, const char *pat, int64_t pat_bytes
     for (int k = 0; k < kClasses; k++) { ccount[order[k]] = h->h_ct->cls_count[order[k]]; cstart[order[k]] = run; run += ccount[order[k]]; }
     for (int c = 0; c < kClasses; c++) h->h_ct->cls_cursor[c] = cstart[c];
     GAB_HIP(hipMemcpyAsync(d_ct, h->h_ct, sizeof(BpmCounters), hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(bpm_scatter, dim3(grid), dim3(256), 0, s, io, d_ct, d_perm);
+    int populated = 0;
+    for (int c = 0; c < kClasses; c++) populated += ccount[c] != 0;
+    const bool identity = populated == 1 && ccount[0] == 0;      // one register class holds every pair: no scatter pass
+    if (!identity) hipLaunchKernelGGL(bpm_scatter, dim3(grid), dim3(256), 0, s, io, d_ct, d_perm);
+    const uint32_t *perm_arg = identity ? nullptr : d_perm;
 
     // score path; worklist of class W occupies d_wl[cstart[W] ..)
     GAB_HIP(hipEventRecord(h->ev[1], s));
-    launch_score<1>(s, io, d_perm, cstart[1], cstart[1] + ccount[1], score_out, d_wl + cstart[1], d_ct);
-    launch_score<2>(s, io, d_perm, cstart[2], cstart[2] + ccount[2], score_out, d_wl + cstart[2], d_ct);
-    launch_score<3>(s, io, d_perm, cstart[3], cstart[3] + ccount[3], score_out, d_wl + cstart[3], d_ct);
-    launch_score<4>(s, io, d_perm, cstart[4], cstart[4] + ccount[4], score_out, d_wl + cstart[4], d_ct);
+    launch_score<1>(s, io, perm_arg, cstart[1], cstart[1] + ccount[1], score_out, d_wl + cstart[1], d_ct);
+    launch_score<2>(s, io, perm_arg, cstart[2], cstart[2] + ccount[2], score_out, d_wl + cstart[2], d_ct);
+    launch_score<3>(s, io, perm_arg, cstart[3], cstart[3] + ccount[3], score_out, d_wl + cstart[3], d_ct);
+    launch_score<4>(s, io, perm_arg, cstart[4], cstart[4] + ccount[4], score_out, d_wl + cstart[4], d_ct);
     GAB_HIP(hipGetLastError());
     GAB_HIP(hipEventRecord(h->ev[2], s));
     GAB_HIP(hipMemcpyAsync(h->h_ct, d_ct, sizeof(BpmCounters), hipMemcpyDeviceToHost, s));
     GAB_HIP(hipStreamSynchronize(s));
 
-    // full path for queued pairs, per class, in scratch-sized batches
+    // queued (unclean) pairs: first the windowed history; pairs whose backtrace leaves the window are queued once
+    // more and get complete columns
     int64_t nfull = 0;
     {
-        // largest text length bounds the history per slot; classes 1..4 have plen <= 64 W, tlen <= plen
+        // stage 0: 16-row band in LDS
         for (int W = 1; W <= kMaxRegW; W++) {
             const uint32_t cnt = h->h_ct->wl_count[W];
             if (!cnt) continue;
             nfull += cnt;
+            const int cols = h->h_ct->max_tlen[W] + 1;
+            const size_t lds = sizeof(uint64_t) * 64 * (4 * W + 1) + sizeof(uint32_t) * 64 * (size_t)cols;
+            const dim3 g((cnt + 63) / 64), blk(64);
+            const uint32_t *list = d_wl + cstart[W];
+            switch (W) {
+                case 1: hipLaunchKernelGGL(bpm_band<1>, g, blk, lds, s, io, list, cnt, cols, score_out, d_wl1 + cstart[W], d_ct); break;
+                case 2: hipLaunchKernelGGL(bpm_band<2>, g, blk, lds, s, io, list, cnt, cols, score_out, d_wl1 + cstart[W], d_ct); break;
+                case 3: hipLaunchKernelGGL(bpm_band<3>, g, blk, lds, s, io, list, cnt, cols, score_out, d_wl1 + cstart[W], d_ct); break;
+                default: hipLaunchKernelGGL(bpm_band<4>, g, blk, lds, s, io, list, cnt, cols, score_out, d_wl1 + cstart[W], d_ct); break;
+            }
+        }
+        GAB_HIP(hipGetLastError());
+        GAB_HIP(hipMemcpyAsync(h->h_ct, d_ct, sizeof(BpmCounters), hipMemcpyDeviceToHost, s));
+        GAB_HIP(hipStreamSynchronize(s));
+        // stage 1: 64-row window in global memory for the pairs that left the band
+        uint32_t wcnt[kMaxRegW + 1];
+        for (int W = 1; W <= kMaxRegW; W++) wcnt[W] = h->h_ct->wl1_count[W];
+        for (int W = 1; W <= kMaxRegW; W++) {
+            const uint32_t cnt = wcnt[W];
+            if (!cnt) continue;
+            const int per_slot = 64 * W + 1;                       // columns 0 .. tlen <= 64 W, 16 bytes each
+            const size_t bytes_slot = (size_t)per_slot * 16;
+            uint32_t batch = (uint32_t)std::max<size_t>(kBlock, std::min<size_t>(cnt, h->scratch_budget / bytes_slot));
+            rc = h->scratch.reserve(bytes_slot * batch);
+            if (rc) return rc;
+            for (uint32_t b0 = 0; b0 < cnt; b0 += batch) {
+                const uint32_t nb = std::min(batch, cnt - b0);
+                const uint32_t *list = d_wl1 + cstart[W] + b0;
+                ulonglong2 *hist = h->scratch.as<ulonglong2>();
+                const dim3 g((nb + kBlock - 1) / kBlock), blk(kBlock);
+                switch (W) {
+                    case 1: hipLaunchKernelGGL(bpm_win<1>, g, blk, 0, s, io, list, nb, hist, per_slot, score_out, d_wl2 + cstart[W], d_ct); break;
+                    case 2: hipLaunchKernelGGL(bpm_win<2>, g, blk, 0, s, io, list, nb, hist, per_slot, score_out, d_wl2 + cstart[W], d_ct); break;
+                    case 3: hipLaunchKernelGGL(bpm_win<3>, g, blk, 0, s, io, list, nb, hist, per_slot, score_out, d_wl2 + cstart[W], d_ct); break;
+                    default: hipLaunchKernelGGL(bpm_win<4>, g, blk, 0, s, io, list, nb, hist, per_slot, score_out, d_wl2 + cstart[W], d_ct); break;
+                }
+            }
+        }
+        GAB_HIP(hipGetLastError());
+        GAB_HIP(hipMemcpyAsync(h->h_ct, d_ct, sizeof(BpmCounters), hipMemcpyDeviceToHost, s));
+        GAB_HIP(hipStreamSynchronize(s));
+        for (int W = 1; W <= kMaxRegW; W++) {
+            const uint32_t cnt = h->h_ct->wl2_count[W];
+            if (!cnt) continue;
             const size_t per_slot = (size_t)(64 * W + 1) * W * 16;
             uint32_t batch = (uint32_t)std::max<size_t>(kBlock, std::min<size_t>(cnt, h->scratch_budget / per_slot));
             batch = (batch + kBlock - 1) / kBlock * kBlock;
@@ -421,7 +687,7 @@ extern "C" int gab_bpm_run_device(gab_bpm *h, const char *pat, int64_t pat_bytes
             if (rc) return rc;
             for (uint32_t b0 = 0; b0 < cnt; b0 += batch) {
                 const uint32_t nb = std::min(batch, cnt - b0);
-                const uint32_t *list = d_wl + cstart[W] + b0;
+                const uint32_t *list = d_wl2 + cstart[W] + b0;
                 uint64_t *hist = h->scratch.as<uint64_t>();
                 switch (W) {
                     case 1: launch_full<1>(s, io, list, nb, hist, nullptr, score_out, d_ct); break;
