@@ -337,6 +337,168 @@ __global__ __launch_bounds__(kThreads) void chain_kernel(const ChainWork *__rest
     if (lane == 0 && evals) atomicAdd(evals_out, evals);
 }
 
+
+// ---- fast-chain: block formulation, one main wave + three helper waves per call ------------------------------------
+// Without max_skip the DP of an anchor is an order-independent maximum over its window (ties -> larger j), so the
+// sequential dependence shrinks to "anchor i needs the final score of anchors i-1, i-2, ...".  Anchors are taken in
+// blocks of 64 (lane a <-> anchor i0 + a) and every lane scores a BROADCAST predecessor against its own anchor:
+// 64 evaluations per ~45 instructions with no reduction.  Per block t:
+//   helper waves (run one block ahead, on block t+1 while the main wave is on block t):
+//     * window starts st[a] with the reference's sequential-pointer semantics (ballot search), each helper for itself;
+//     * "far" predecessors j <= i0 - 65 (final since block t-1): read 64 at a time with L2-coherent loads, broadcast
+//       with v_readlane, chunks dealt round-robin to the helpers; partial (best, argbest) per anchor go to LDS;
+//   main wave (the sequential path):
+//     * combines the helpers' partial maxima, folds in the 64 "near" predecessors (the previous block, still in its
+//       registers) and then the predecessors inside the block: anchor b is final once 0..b-1 are folded, is broadcast
+//       and folded into the lanes a > b.  A newer predecessor wins a tie against an older one.
+// One __syncthreads per block hands the results of block t to the helpers (global scores, acknowledged by L2) and the
+// partial maxima of block t+1 to the main wave (LDS).
+constexpr int kFcHelpers = 3;
+__global__ __launch_bounds__(64 * (1 + kFcHelpers)) void fastchain_kernel(const ChainWork *__restrict__ work,
+                                                                          const uint64_t *__restrict__ xs,
+                                                                          const uint64_t *__restrict__ ys, int32_t *score_out,
+                                                                          int32_t *parent_out, unsigned long long *evals_out) {
+    __shared__ int32_t part_best[2][kFcHelpers][64], part_j[2][kFcHelpers][64], part_st[2][64];
+    const ChainWork w = work[blockIdx.x];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint64_t *X = xs + w.off, *Y = ys + w.off;
+    int32_t *S = score_out + w.off, *P = parent_out + w.off;
+    const int64_t n = w.n;
+    const int32_t mdx = w.max_dist_x, mdy = w.max_dist_y, bw = w.bw;
+    const uint64_t mdx64 = (uint64_t)(int64_t)mdx;
+    const double avg_d = (double)w.avg_qspan;
+    const float k32 = (float)(0.01 * (double)w.avg_qspan);
+    const int64_t nblocks = (n + 63) / 64;
+
+    // any_narrow: wave-uniform "some lane of this block has a window of <= 6 predecessors" (only near the start of a
+    // call): only then is the double-precision gap cost evaluated at all (real branch, not a select)
+    auto score_pred = [&](int32_t xa, int32_t ya, int32_t qsa, bool wide_a, bool any_narrow, int32_t xj, int32_t yj, int32_t sj,
+                          bool &ok) -> int32_t {
+        const int32_t ddr = (int32_t)((uint32_t)xa - (uint32_t)xj);
+        const int32_t ddq = (int32_t)((uint32_t)ya - (uint32_t)yj);
+        const uint32_t diff = (uint32_t)ddr - (uint32_t)ddq;
+        const int32_t dd = (int32_t)((int32_t)diff < 0 ? 0u - diff : diff);
+        ok = !(dd > bw || ddr == 0 || ddq <= 0 || ddq > mdy || ddq > mdx);
+        const int32_t oc = min(min(ddr, ddq), qsa);
+        const int32_t lg = dd ? ilog2_u32((uint32_t)dd) : 0;
+        int32_t gc = (int32_t)floorf(__fmul_rn((float)dd, k32)) + (lg >> 1);
+        if (any_narrow) {
+            const int32_t gd = (int32_t)__dmul_rn(__dmul_rn((double)dd, .01), avg_d) + (lg >> 1);
+            gc = wide_a ? gc : gd;
+        }
+        return (int32_t)((uint32_t)sj + (uint32_t)oc - (uint32_t)gc);
+    };
+
+    // helper state: the sequential window-start pointer (each helper keeps its own identical copy)
+    int64_t st = 0, sb = 0;
+    uint64_t XS = (wave > 0 && lane < n) ? X[lane] : 0;
+    // main state: the previous block (the "near" predecessors)
+    int32_t pxa = 0, pya = 0, pbest = 0;
+    int pnb = 0;
+    unsigned long long evals = 0;
+
+    for (int64_t t = -1; t < nblocks; t++) {
+        const int par = (int)((t + 1) & 1);                  // LDS slot of block t+1; block t lives in par ^ 1
+        if (wave > 0) {
+            // ------------------------------------------------ helpers: block t + 1
+            const int64_t kb = t + 1;
+            if (kb < nblocks) {
+                const int64_t i0 = kb * 64;
+                const int nb = (int)(n - i0 < 64 ? n - i0 : 64);
+                const bool mine = lane < nb;
+                const uint64_t xa64 = mine ? X[i0 + lane] : 0, ya64 = mine ? Y[i0 + lane] : 0;
+                const int32_t xa = (int32_t)(uint32_t)xa64, ya = (int32_t)(uint32_t)ya64, qsa = (int32_t)(ya64 >> 32 & 0xff);
+                int64_t st_a = 0;
+                for (int a = 0; a < nb; a++) {               // host_kernel.cpp:200-207
+                    const int64_t i = i0 + a;
+                    const uint64_t xi = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(xa64 >> 32), a) << 32) |
+                                        (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)xa64, a);
+                    for (;;) {
+                        const int64_t cand = sb + lane;
+                        const bool pass = cand < st || (cand < i && (xi - XS) > mdx64);
+                        const unsigned long long m = __ballot(pass);
+                        if (m == ~0ull) { sb += 64; st = sb; XS = (sb + lane < n) ? X[sb + lane] : 0; continue; }
+                        st = sb + __builtin_ctzll(~m);
+                        break;
+                    }
+                    if (i - st > kMaxIter) st = i - kMaxIter;
+                    if (st - sb >= 64) { sb = st & ~63ll; XS = (sb + lane < n) ? X[sb + lane] : 0; }
+                    if (lane == a) st_a = st;
+                }
+                const int64_t ia = i0 + lane;
+                const bool wide_a = !((ia - 1) - st_a <= 5);
+                const bool any_narrow = __ballot(mine && !wide_a) != 0;
+                const int st_rel = (int)(st_a - i0);
+                int32_t best = (int32_t)0x80000000, best_j = -1;      // helpers start below any score; q_span is the main wave's floor
+                const int64_t st_lo = __builtin_amdgcn_readfirstlane((int)(uint32_t)st_a) |
+                                      ((int64_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(st_a >> 32)) << 32);
+                // far predecessors j <= i0 - 65, chunks of 64 dealt round-robin to the helpers
+                for (int64_t jb = i0 - 65 - 64 * (wave - 1); jb >= st_lo; jb -= 64 * kFcHelpers) {
+                    const int64_t jl = jb - lane;
+                    int32_t vx = 0, vy = 0, vs = 0;
+                    if (jl >= st_lo) {
+                        vx = (int32_t)(uint32_t)X[jl]; vy = (int32_t)(uint32_t)Y[jl];
+                        vs = __hip_atomic_load(&S[jl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    const int cnt = (int)(jb - st_lo + 1 < 64 ? jb - st_lo + 1 : 64);
+                    const int jrel0 = (int)(jb - i0);
+                    for (int l = 0; l < cnt; l++) {
+                        const int32_t xj = __builtin_amdgcn_readlane(vx, l), yj = __builtin_amdgcn_readlane(vy, l), sj = __builtin_amdgcn_readlane(vs, l);
+                        const int jrel = jrel0 - l;
+                        bool ok;
+                        const int32_t sc = score_pred(xa, ya, qsa, wide_a, any_narrow, xj, yj, sj, ok);
+                        if (mine && ok && jrel >= st_rel && sc > best) { best = sc; best_j = jrel; }      // descending j: strict >
+                    }
+                }
+                part_best[par][wave - 1][lane] = best; part_j[par][wave - 1][lane] = best_j;
+                if (wave == 1) part_st[par][lane] = st_rel;
+            }
+        } else if (t >= 0) {
+            // ------------------------------------------------ main wave: block t
+            const int64_t i0 = t * 64;
+            const int nb = (int)(n - i0 < 64 ? n - i0 : 64);
+            const bool mine = lane < nb;
+            const uint64_t xa64 = mine ? X[i0 + lane] : 0, ya64 = mine ? Y[i0 + lane] : 0;
+            const int32_t xa = (int32_t)(uint32_t)xa64, ya = (int32_t)(uint32_t)ya64, qsa = (int32_t)(ya64 >> 32 & 0xff);
+            const int st_rel = part_st[par ^ 1][lane];
+            const bool wide_a = !((lane - 1) - st_rel <= 5);
+            const bool any_narrow = __ballot(mine && !wide_a) != 0;
+            if (mine) evals += (unsigned long long)(lane - st_rel);
+            int32_t best = qsa, best_j = -1;                 // best_j relative to i0 for predecessors, -1 = none
+            bool have = false;
+            // helpers' partial maxima: chunks interleave, so the larger j wins a tie
+#pragma unroll
+            for (int hh = 0; hh < kFcHelpers; hh++) {
+                const int32_t b2 = part_best[par ^ 1][hh][lane], j2 = part_j[par ^ 1][hh][lane];
+                if (b2 > best || (have && b2 == best && j2 > best_j)) { best = b2; best_j = j2; have = true; }
+            }
+            // near predecessors: the previous block, newest (lane 63) first; they are newer than every far one
+            int32_t nbest = (int32_t)0x80000000, nbj = 0;
+            bool nhave = false;
+            for (int l = pnb - 1; l >= 0; l--) {
+                const int32_t xj = __builtin_amdgcn_readlane(pxa, l), yj = __builtin_amdgcn_readlane(pya, l), sj = __builtin_amdgcn_readlane(pbest, l);
+                const int jrel = l - 64;
+                bool ok;
+                const int32_t sc = score_pred(xa, ya, qsa, wide_a, any_narrow, xj, yj, sj, ok);
+                if (mine && ok && jrel >= st_rel && (!nhave || sc > nbest)) { nbest = sc; nbj = jrel; nhave = true; }
+            }
+            if (nhave && (nbest > best || (have && nbest == best))) { best = nbest; best_j = nbj; have = true; }
+            // predecessors inside the block
+            for (int b = 0; b + 1 < nb; b++) {
+                const int32_t xj = __builtin_amdgcn_readlane(xa, b), yj = __builtin_amdgcn_readlane(ya, b), sj = __builtin_amdgcn_readlane(best, b);
+                bool ok;
+                const int32_t sc = score_pred(xa, ya, qsa, wide_a, any_narrow, xj, yj, sj, ok);
+                if (mine && lane > b && ok && b >= st_rel && (sc > best || (have && sc == best))) { best = sc; best_j = b; have = true; }
+            }
+            if (mine) { S[i0 + lane] = best; P[i0 + lane] = have ? (int32_t)(i0 + best_j) : -1; }
+            pxa = xa; pya = ya; pbest = best; pnb = nb;
+        }
+        __syncthreads();       // results of block t are acknowledged by L2; partial maxima of block t+1 are in LDS
+    }
+    for (int o = 32; o > 0; o >>= 1) evals += __shfl_xor(evals, o);
+    if (lane == 0 && evals) atomicAdd(evals_out, evals);
+}
+
 }  // namespace
 
 // =============================================================================== host side
@@ -436,7 +598,7 @@ extern "C" int gab_chain_run_device(gab_chain *h, int mode, const uint64_t *d_x,
     }
     GAB_HIP(hipEventRecord(h->ev[0], s));
     if (mode == GAB_FASTCHAIN)
-        hipLaunchKernelGGL(chain_kernel<true>, dim3((unsigned)nw), dim3(kThreads), 0, s, d_work, d_x, d_y, d_score, d_parent, d_gm, d_ev);
+        hipLaunchKernelGGL(fastchain_kernel, dim3((unsigned)nw), dim3(64 * (1 + kFcHelpers)), 0, s, d_work, d_x, d_y, d_score, d_parent, d_ev);
     else
         hipLaunchKernelGGL(chain_kernel<false>, dim3((unsigned)nw), dim3(kThreads), 0, s, d_work, d_x, d_y, d_score, d_parent, d_gm, d_ev);
     GAB_HIP(hipGetLastError());
