@@ -280,6 +280,39 @@ __global__ __launch_bounds__(64) void bsw_dp(BswIO io, BswConst c, const uint32_
 // dword: those single cells are handled with 16-bit LDS accesses so that cells outside the band keep their stale
 // contents, which later rows may read when the band grows (bandedSWA.cpp:217,234-237).
 //   lds layout: [ (qcap + 2) / 2 dwords of cells ][ ((qcap + 1) / 2 + 3) / 4 dwords of query nibbles ]  x 64 lanes
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ s16x2 as_s16x2(uint32_t v) { return __builtin_bit_cast(s16x2, v); }
+__device__ __forceinline__ u16x2 as_u16x2(uint32_t v) { return __builtin_bit_cast(u16x2, v); }
+__device__ __forceinline__ uint32_t as_u32(s16x2 v) { return __builtin_bit_cast(uint32_t, v); }
+__device__ __forceinline__ uint32_t as_u32(u16x2 v) { return __builtin_bit_cast(uint32_t, v); }
+__device__ __forceinline__ s16x2 pk_splat(int v) { s16x2 r; r.x = (short)v; r.y = (short)v; return r; }
+// Packed 16-bit instructions the compiler does not form by itself: the x {0,1} product (as a C multiply it becomes
+// compare + select per half), the u16 min, and the op_sel forms that route one half of a register to the other
+// half of the result.  They are plain (non-volatile) asm so the scheduler may still move them.
+__device__ __forceinline__ uint32_t pk_mul_lo(uint32_t a, uint32_t b) {
+    uint32_t r; asm("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r;
+}
+__device__ __forceinline__ uint32_t pk_max_i16(uint32_t a, uint32_t b) {
+    uint32_t r; asm("v_pk_max_i16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r;
+}
+__device__ __forceinline__ uint32_t pk_sub_i16_k(uint32_t a, uint32_t k) {       // k: wave-uniform, stays in an SGPR
+    uint32_t r; asm("v_pk_sub_i16 %0, %1, %2" : "=v"(r) : "v"(a), "s"(k)); return r;
+}
+__device__ __forceinline__ uint32_t pk_max_i16_0(uint32_t a) {
+    uint32_t r; asm("v_pk_max_i16 %0, %1, 0" : "=v"(r) : "v"(a)); return r;
+}
+__device__ __forceinline__ uint32_t pk_min_u16_1(uint32_t a) {                    // min(half, 1) on both halves
+    uint32_t r; asm("v_pk_min_u16 %0, %1, 1 op_sel_hi:[1,0]" : "=v"(r) : "v"(a)); return r;
+}
+// result.hi = max(a.hi, b.lo); result.lo = max(a.lo, b.lo)
+__device__ __forceinline__ uint32_t pk_max_i16_hi_from_lo(uint32_t a, uint32_t b) {
+    uint32_t r; asm("v_pk_max_i16 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(r) : "v"(a), "v"(b)); return r;
+}
+// result.lo = max(a.hi, b.lo); result.hi = max(a.hi, b.hi)
+__device__ __forceinline__ uint32_t pk_max_i16_lo_from_hi(uint32_t a, uint32_t b) {
+    uint32_t r; asm("v_pk_max_i16 %0, %1, %2 op_sel:[1,0]" : "=v"(r) : "v"(a), "v"(b)); return r;
+}
 struct BswCellOut { int h, en, f; };
 __device__ __forceinline__ BswCellOut bsw_cell(int diag, int e, int f, uint32_t qc, uint32_t rlo, uint32_t rhi, int oe_del,
                                                int e_del, int oe_ins, int e_ins) {
@@ -304,9 +337,9 @@ __global__ __launch_bounds__(64) void bsw_dp8(BswIO io, BswConst c, const uint32
     // cell j of this lane: 16 bits at byte address ((j >> 1) * 64 + lane) * 4 + (j & 1) * 2
     uint8_t *const CB = reinterpret_cast<uint8_t *>(lds + lane);
     uint32_t *const CW = lds + lane;                                   // pair p = columns 2p, 2p+1 at CW[p * 64]
-    uint8_t *const QN = reinterpret_cast<uint8_t *>(lds + (size_t)ncell_dw * 64) + lane * 4;   // nibble pair p at QN[(p >> 2) * 256 + (p & 3)]
+    uint8_t *const QN = reinterpret_cast<uint8_t *>(lds + (size_t)ncell_dw * 64) + lane;   // nibble pair p at QN[p * 64]
 #define CELL16(j) (*reinterpret_cast<uint16_t *>(CB + ((j) >> 1) * 256 + ((j) & 1) * 2))
-#define QPAIR(p) (QN[((p) >> 2) * 256 + ((p) & 3)])
+#define QPAIR(p) (QN[(p) * 64])
 
     unsigned long long cells = 0;
     if (valid) {
@@ -317,17 +350,13 @@ __global__ __launch_bounds__(64) void bsw_dp8(BswIO io, BswConst c, const uint32
         const int e_del = c.e_del, e_ins = c.e_ins;
 
         // query -> nibbles (codes above 4 count as N)
-        for (int p0 = 0; p0 * 2 < qlen; p0 += 4) {             // 8 bases -> 4 nibble bytes -> one dword
-            const uint32_t w0 = load_u32_unaligned(q + p0 * 2);
-            const uint32_t w1 = p0 * 2 + 4 < qlen ? load_u32_unaligned(q + p0 * 2 + 4) : 0u;
-            uint32_t packed = 0;
-            for (int b = 0; b < 4; b++) {
-                const uint32_t src = b < 2 ? w0 : w1;
-                uint32_t lo = (src >> ((b & 1) * 16)) & 0xff, hi = (src >> ((b & 1) * 16 + 8)) & 0xff;
+        for (int p0 = 0; p0 * 2 < qlen; p0 += 2) {             // 4 bases -> 2 nibble bytes
+            const uint32_t src = load_u32_unaligned(q + p0 * 2);
+            for (int b = 0; b < 2; b++) {
+                uint32_t lo = (src >> (b * 16)) & 0xff, hi = (src >> (b * 16 + 8)) & 0xff;
                 lo = lo > 4u ? 4u : lo; hi = hi > 4u ? 4u : hi;
-                packed |= (lo | hi << 4) << (8 * b);
+                QPAIR(p0 + b) = (uint8_t)(lo | hi << 4);
             }
-            *reinterpret_cast<uint32_t *>(QN + (p0 >> 2) * 256) = packed;
         }
         // row -1 (bandedSWA.cpp:159-161); E = 0
         {
@@ -378,23 +407,46 @@ __global__ __launch_bounds__(64) void bsw_dp8(BswIO io, BswConst c, const uint32
                 j++;
             }
             if (j + 1 < end) {
-                // software pipeline: the next pair's words are in flight while this pair is computed
-                uint32_t v = CW[(j >> 1) * 64];
-                uint32_t qb = QPAIR(j >> 1);
-                for (; j + 1 < end; j += 2) {
+                // Two columns per step, the column-independent part in packed 16-bit lanes (lo = column j, hi = j+1):
+                // M, E' and the F-source of both cells come from v_pk_* instructions; only the H / F carry chain
+                // between the two cells is scalar.  The loop is unrolled by two pairs so that the software pipeline
+                // (next pair's LDS words in flight while this pair is computed) needs no register copies.
+                const uint32_t k_oe_del = as_u32(pk_splat(oe_del)), k_e_del = as_u32(pk_splat(e_del));
+                const uint32_t k_oe_ins = as_u32(pk_splat(oe_ins)), k_e_ins = as_u32(pk_splat(e_ins));
+                // carried between pairs: HB.hi = H of the previous column, FV.lo = F entering the pair (other halves unused)
+                uint32_t HB = (uint32_t)hleft << 16, FV = (uint32_t)f;
+#define BSW_PAIR(V, QB, JJ)                                                                                     \
+    {                                                                                                             \
+        const uint32_t d2 = (V) & 0x00ff00ffu;                                   /* diag of both columns */      \
+        const uint32_t e2 = __builtin_amdgcn_perm(0u, (V), 0x0c030c01u);         /* E of both columns */         \
+        const uint32_t sel = (((QB) * 0x1001u) & 0x000f000fu) | 0x0c000c00u;     /* code j -> byte 0, j+1 -> 2 */\
+        const uint32_t sc2 = __builtin_amdgcn_perm(rhi, rlo, sel);               /* biased scores per half */    \
+        const uint32_t Mraw = as_u32(as_s16x2(d2) + as_s16x2(sc2) - pk_splat(128));                              \
+        const uint32_t M = pk_mul_lo(Mraw, pk_min_u16_1(d2));         /* diag == 0 -> M = 0 */        \
+        const uint32_t EN = pk_max_i16_0(pk_max_i16(pk_sub_i16_k(M, k_oe_del), pk_sub_i16_k(e2, k_e_del)));        \
+        const uint32_t T = pk_max_i16_0(pk_sub_i16_k(M, k_oe_ins));                                              \
+        const uint32_t ME = pk_max_i16(M, e2);                                                                   \
+        const uint32_t HA = pk_max_i16(ME, FV);                                  /* lo = H[j]   */               \
+        const uint32_t FA = pk_max_i16(T, pk_sub_i16_k(FV, k_e_ins));              /* lo = F leaving column j */   \
+        const uint32_t hprev = HB;                                                                               \
+        HB = pk_max_i16_hi_from_lo(ME, FA);                                      /* hi = H[j+1] */               \
+        FV = pk_max_i16_lo_from_hi(T, pk_sub_i16_k(FA, k_e_ins));                  /* lo = F leaving column j+1 */ \
+        /* byte 0 = H[j-1] (hprev byte 2), byte 1 = E'[j], byte 2 = H[j] (HA byte 0), byte 3 = E'[j+1] */        \
+        CW[((JJ) >> 1) * 64] = (EN << 8) | __builtin_amdgcn_perm(HA, hprev, 0x0c040c02u);                        \
+        const uint32_t pa = (HA << 16) | (uint32_t)(JJ), pb = (HB & 0xffff0000u) | (uint32_t)((JJ) + 1);        \
+        rowpk = max(max(rowpk, pa), pb);                                                                         \
+    }
+                uint32_t v0 = CW[(j >> 1) * 64], q0 = QPAIR(j >> 1);
+                for (; j + 3 < end; j += 4) {
                     const int p = j >> 1;
-                    const uint32_t vn = CW[(p + 1) * 64];            // always inside the (qcap + 2) / 2 dwords
-                    const uint32_t qn = QPAIR(p + 1);
-                    const BswCellOut a = bsw_cell((int)(v & 0xff), (int)(v >> 8 & 0xff), f, qb & 0xfu, rlo, rhi, oe_del, e_del,
-                                                  oe_ins, e_ins);
-                    const BswCellOut b = bsw_cell((int)(v >> 16 & 0xff), (int)(v >> 24), a.f, qb >> 4, rlo, rhi, oe_del, e_del,
-                                                  oe_ins, e_ins);
-                    CW[p * 64] = (uint32_t)hleft | (uint32_t)a.en << 8 | (uint32_t)a.h << 16 | (uint32_t)b.en << 24;
-                    const uint32_t pa = ((uint32_t)a.h << 16) | (uint32_t)j, pb = ((uint32_t)b.h << 16) | (uint32_t)(j + 1);
-                    rowpk = max(max(rowpk, pa), pb);
-                    hleft = b.h; f = b.f;
-                    v = vn; qb = qn;
+                    const uint32_t v1 = CW[(p + 1) * 64], q1 = QPAIR(p + 1);
+                    BSW_PAIR(v0, q0, j)
+                    v0 = CW[(p + 2) * 64]; q0 = QPAIR(p + 2);        // p + 2 <= end / 2: inside the row allocation
+                    BSW_PAIR(v1, q1, j + 2)
                 }
+                if (j + 1 < end) { BSW_PAIR(v0, q0, j) j += 2; }
+                hleft = (int)(HB >> 16); f = (int)(FV & 0xffffu);
+#undef BSW_PAIR
             }
             if (j < end) {                        // band ends on the lower half of a pair
                 const uint32_t v = CELL16(j);
