@@ -299,6 +299,12 @@ __device__ __forceinline__ uint32_t pk_max_i16(uint32_t a, uint32_t b) {
 __device__ __forceinline__ uint32_t pk_sub_i16_k(uint32_t a, uint32_t k) {       // k: wave-uniform, stays in an SGPR
     uint32_t r; asm("v_pk_sub_i16 %0, %1, %2" : "=v"(r) : "v"(a), "s"(k)); return r;
 }
+__device__ __forceinline__ uint32_t pk_subsat_u16_k(uint32_t a, uint32_t k) {    // max(half - k, 0), unsigned halves
+    uint32_t r; asm("v_pk_sub_u16 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "s"(k)); return r;
+}
+__device__ __forceinline__ uint32_t and_or_b32(uint32_t a, uint32_t mask, uint32_t k) {   // (a & mask) | k, mask uniform
+    uint32_t r; asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(mask), "v"(k)); return r;
+}
 __device__ __forceinline__ uint32_t pk_max_i16_0(uint32_t a) {
     uint32_t r; asm("v_pk_max_i16 %0, %1, 0" : "=v"(r) : "v"(a)); return r;
 }
@@ -396,15 +402,21 @@ __global__ __launch_bounds__(64) void bsw_dp8(BswIO io, BswConst c, const uint32
             int f = 0;
             uint32_t rowpk = 0;                   // (row max << 16) | column; ties -> later column
             int j = beg;
-            if ((j & 1) && j < end) {             // band starts on the upper half of a pair
-                const uint32_t v = CELL16(j);
-                const BswCellOut o = bsw_cell((int)(v & 0xff), (int)(v >> 8), f, (uint32_t)(QPAIR(j >> 1) >> 4), rlo, rhi, oe_del,
-                                              e_del, oe_ins, e_ins);
-                CELL16(j) = (uint16_t)(hleft | o.en << 8);
-                hleft = o.h; f = o.f;
-                const uint32_t pk = ((uint32_t)o.h << 16) | (uint32_t)j;
-                rowpk = pk > rowpk ? pk : rowpk;
-                j++;
+            // the two pair words the row can start with and their query codes: one LDS round trip for the row start
+            uint32_t *cw = CW + (j >> 1) * 64;
+            const uint8_t *qp = QN + (j >> 1) * 64;
+            uint32_t v0 = cw[0], q0 = qp[0];
+            {
+                const uint32_t vn = cw[64], qn = qp[64];
+                if ((j & 1) && j < end) {         // band starts on the upper half of a pair
+                    const BswCellOut o = bsw_cell((int)((v0 >> 16) & 0xff), (int)(v0 >> 24), f, q0 >> 4, rlo, rhi, oe_del, e_del,
+                                                  oe_ins, e_ins);
+                    CELL16(j) = (uint16_t)(hleft | o.en << 8);
+                    hleft = o.h; f = o.f;
+                    rowpk = ((uint32_t)o.h << 16) | (uint32_t)j;
+                    j++;
+                    v0 = vn; q0 = qn; cw += 64; qp += 64;
+                }
             }
             if (j + 1 < end) {
                 // Two columns per step, the column-independent part in packed 16-bit lanes (lo = column j, hi = j+1):
@@ -413,45 +425,51 @@ __global__ __launch_bounds__(64) void bsw_dp8(BswIO io, BswConst c, const uint32
                 // (next pair's LDS words in flight while this pair is computed) needs no register copies.
                 const uint32_t k_oe_del = as_u32(pk_splat(oe_del)), k_e_del = as_u32(pk_splat(e_del));
                 const uint32_t k_oe_ins = as_u32(pk_splat(oe_ins)), k_e_ins = as_u32(pk_splat(e_ins));
+                const uint32_t k_bias = 0x00800080u, k_nib = 0x000f000fu, k_hi = 0xffff0000u;
+                uint32_t k_selz = 0x0c000c00u;                                   // per-lane copy: the third VOP3 source
+                asm volatile("" : "+v"(k_selz));
                 // carried between pairs: HB.hi = H of the previous column, FV.lo = F entering the pair (other halves unused)
                 uint32_t HB = (uint32_t)hleft << 16, FV = (uint32_t)f;
-#define BSW_PAIR(V, QB, JJ)                                                                                     \
+                // M is clamped at 0 (unsigned saturating subtract): H, E' and F all take a max with a non-negative
+                // value, so the clamp changes none of them and lets E' / F-source use saturating subtracts too.
+#define BSW_PAIR(V, QB, JJ, OUT)                                                                                \
     {                                                                                                             \
         const uint32_t d2 = (V) & 0x00ff00ffu;                                   /* diag of both columns */      \
         const uint32_t e2 = __builtin_amdgcn_perm(0u, (V), 0x0c030c01u);         /* E of both columns */         \
-        const uint32_t sel = (((QB) * 0x1001u) & 0x000f000fu) | 0x0c000c00u;     /* code j -> byte 0, j+1 -> 2 */\
+        const uint32_t sel = and_or_b32((QB) * 0x1001u, k_nib, k_selz);          /* code j -> byte 0, j+1 -> 2 */\
         const uint32_t sc2 = __builtin_amdgcn_perm(rhi, rlo, sel);               /* biased scores per half */    \
-        const uint32_t Mraw = as_u32(as_s16x2(d2) + as_s16x2(sc2) - pk_splat(128));                              \
-        const uint32_t M = pk_mul_lo(Mraw, pk_min_u16_1(d2));         /* diag == 0 -> M = 0 */        \
-        const uint32_t EN = pk_max_i16_0(pk_max_i16(pk_sub_i16_k(M, k_oe_del), pk_sub_i16_k(e2, k_e_del)));        \
-        const uint32_t T = pk_max_i16_0(pk_sub_i16_k(M, k_oe_ins));                                              \
+        const uint32_t Mc = pk_subsat_u16_k(as_u32(as_u16x2(d2) + as_u16x2(sc2)), k_bias);                       \
+        const uint32_t M = pk_mul_lo(Mc, pk_min_u16_1(d2));                      /* diag == 0 -> M = 0 */        \
+        const uint32_t EN = pk_max_i16(pk_subsat_u16_k(M, k_oe_del), pk_subsat_u16_k(e2, k_e_del));              \
+        const uint32_t T = pk_subsat_u16_k(M, k_oe_ins);                                                         \
         const uint32_t ME = pk_max_i16(M, e2);                                                                   \
         const uint32_t HA = pk_max_i16(ME, FV);                                  /* lo = H[j]   */               \
-        const uint32_t FA = pk_max_i16(T, pk_sub_i16_k(FV, k_e_ins));              /* lo = F leaving column j */   \
+        const uint32_t FA = pk_max_i16(T, pk_sub_i16_k(FV, k_e_ins));            /* lo = F leaving column j */   \
         const uint32_t hprev = HB;                                                                               \
         HB = pk_max_i16_hi_from_lo(ME, FA);                                      /* hi = H[j+1] */               \
-        FV = pk_max_i16_lo_from_hi(T, pk_sub_i16_k(FA, k_e_ins));                  /* lo = F leaving column j+1 */ \
+        FV = pk_max_i16_lo_from_hi(T, pk_sub_i16_k(FA, k_e_ins));                /* lo = F leaving column j+1 */ \
         /* byte 0 = H[j-1] (hprev byte 2), byte 1 = E'[j], byte 2 = H[j] (HA byte 0), byte 3 = E'[j+1] */        \
-        CW[((JJ) >> 1) * 64] = (EN << 8) | __builtin_amdgcn_perm(HA, hprev, 0x0c040c02u);                        \
-        const uint32_t pa = (HA << 16) | (uint32_t)(JJ), pb = (HB & 0xffff0000u) | (uint32_t)((JJ) + 1);        \
+        (OUT) = (EN << 8) | __builtin_amdgcn_perm(HA, hprev, 0x0c040c02u);                                       \
+        const uint32_t pa = (HA << 16) | (uint32_t)(JJ), pb = and_or_b32(HB, k_hi, (uint32_t)((JJ) + 1));       \
         rowpk = max(max(rowpk, pa), pb);                                                                         \
     }
-                uint32_t v0 = CW[(j >> 1) * 64], q0 = QPAIR(j >> 1);
-                for (; j + 3 < end; j += 4) {
-                    const int p = j >> 1;
-                    const uint32_t v1 = CW[(p + 1) * 64], q1 = QPAIR(p + 1);
-                    BSW_PAIR(v0, q0, j)
-                    v0 = CW[(p + 2) * 64]; q0 = QPAIR(p + 2);        // p + 2 <= end / 2: inside the row allocation
-                    BSW_PAIR(v1, q1, j + 2)
+                for (; j + 3 < end; j += 4, cw += 128, qp += 128) {
+                    const uint32_t v1 = cw[64], q1 = qp[64];
+                    BSW_PAIR(v0, q0, j, cw[0])
+                    v0 = cw[128]; q0 = qp[128];                      // pair index <= end / 2: inside the row allocation
+                    BSW_PAIR(v1, q1, j + 2, cw[64])
                 }
-                if (j + 1 < end) { BSW_PAIR(v0, q0, j) j += 2; }
+                if (j + 1 < end) {
+                    const uint32_t v1 = cw[64], q1 = qp[64];         // the word a trailing single column lives in
+                    BSW_PAIR(v0, q0, j, cw[0])
+                    j += 2; v0 = v1; q0 = q1;
+                }
                 hleft = (int)(HB >> 16); f = (int)(FV & 0xffffu);
 #undef BSW_PAIR
             }
-            if (j < end) {                        // band ends on the lower half of a pair
-                const uint32_t v = CELL16(j);
-                const BswCellOut o = bsw_cell((int)(v & 0xff), (int)(v >> 8), f, (uint32_t)(QPAIR(j >> 1) & 0xfu), rlo, rhi, oe_del,
-                                              e_del, oe_ins, e_ins);
+            if (j < end) {                        // band ends on the lower half of a pair: its word is already in v0
+                const BswCellOut o = bsw_cell((int)(v0 & 0xff), (int)((v0 >> 8) & 0xff), f, q0 & 0xfu, rlo, rhi, oe_del, e_del,
+                                              oe_ins, e_ins);
                 CELL16(j) = (uint16_t)(hleft | o.en << 8);
                 hleft = o.h; f = o.f;
                 const uint32_t pk = ((uint32_t)o.h << 16) | (uint32_t)j;
@@ -476,9 +494,26 @@ __global__ __launch_bounds__(64) void bsw_dp8(BswIO io, BswConst c, const uint32
                 if (di > dj) { if (best - rowmax - (di - dj) * e_del > c.zdrop) break; }
                 else { if (best - rowmax - (dj - di) * e_ins > c.zdrop) break; }
             }
-            for (j = beg; j < end && CELL16(j) == 0; j++) {}
-            beg = j;
-            for (j = end; j >= beg && CELL16(j) == 0; j--) {}
+            // Band trimming (bandedSWA.cpp:234-237).  The four cells next to either edge are fetched in ONE LDS round
+            // trip (whole pair words; cells outside [beg, end] only ever shorten the count and the clamps below undo
+            // that); the cell-by-cell loops of the reference run only when all four are zero.
+            {
+                const int pb = beg >> 1, pe = end >> 1;
+                const uint32_t b0 = CW[pb * 64], b1 = CW[(pb + 1) * 64], b2 = CW[(pb + 2) * 64];
+                const uint32_t e2 = CW[pe * 64], e1 = CW[(pe > 0 ? pe - 1 : 0) * 64], e0 = CW[(pe > 1 ? pe - 2 : 0) * 64];
+                uint64_t x = (uint64_t)b1 << 32 | b0;                      // cells 2pb .. 2pb+3, low half first
+                if (beg & 1) x = (x >> 16) | (uint64_t)(b2 & 0xffffu) << 48;
+                const int lz = x ? __builtin_ctzll(x) >> 4 : 4;
+                j = beg + lz;
+                if (lz == 4) for (; j < end && CELL16(j) == 0; j++) {}
+                beg = j < end ? j : end;
+                uint64_t y = (uint64_t)e2 << 32 | e1;                      // cells 2pe-2 .. 2pe+1; cell `end` goes on top
+                if (!(end & 1)) y = (y << 16) | (e0 >> 16);
+                const int tz = y ? __builtin_clzll(y) >> 4 : 4;
+                j = end - tz;
+                if (tz == 4) for (; j >= beg && CELL16(j) == 0; j--) {}
+                j = j > beg - 1 ? j : beg - 1;
+            }
             end = j + 2 < qlen ? j + 2 : qlen;
         }
         score_out[id] = best;
