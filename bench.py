@@ -514,19 +514,23 @@ class FmiWorkload:
     def extra(self, ms_per_step):
         e = self.stats.get("ext_calls", 0)
         k = float(np.mean(self.kernel_ms))
-        return {"backward_ext_per_step": e, "smems_per_step": self.stats.get("smems"),
+        return {"backward_ext_per_step": e, "cp_occ_records_per_step": self.stats.get("cp_occ_records"),
+                "smems_per_step": self.stats.get("smems"),
                 "index_bytes": int(len(self.index.cp_occ)), "ref_mbp": self.ref_mbp,
                 "g_ext_per_s": round(e / (k * 1e6), 3), "dominant_kernel": "fmi_seed_kernel", "dominant_kernel_ms": k}
 
     def roofline(self):
         k = float(np.mean(self.kernel_ms))
         e = self.stats.get("ext_calls", 0)
-        # readlen + 40 B x SMEMs streaming + 128 B x backwardExt calls of random index traffic
-        alg = self.items * self.readlen + 40 * self.stats.get("smems", 0) + 128 * e
+        # readlen + 40 B x SMEMs streaming + the random index traffic.  8d prices an extension at two
+        # 64-B CP_OCC records; GET_OCC reads ONE when both interval ends share a record (most extensions once the
+        # interval is short), so the bytes counted here are 64 B x the records the kernel really fetched.
+        recs = self.stats.get("cp_occ_records", 2 * e)
+        alg = self.items * self.readlen + 40 * self.stats.get("smems", 0) + 64 * recs
         ach = alg / (k * 1e-3) / 1e9
         return {"bound": "hbm", "achieved": round(ach, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(ach / HBM_PEAK_GBS, 6), "traffic": None,
-                "note": "dominated by 2 random 64-B CP_OCC reads per backwardExt (index >> 256 MiB Infinity Cache)"}
+                "note": "random 64-B CP_OCC records (1 or 2 per backwardExt, counted by the kernel); index >> 256 MiB Infinity Cache"}
 
     def cpu_baseline(self, cores):
         import ctypes as C

@@ -29,6 +29,7 @@
 #include <new>
 #include <vector>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 namespace {
@@ -43,12 +44,12 @@ struct FmiIdx {
     int64_t ref_seq_len;
 };
 
-struct Iv { uint32_t m, n; int64_t k, l, s; };            // SMEM without rid
 struct PrevRec { int64_t n, k, l, s; };                    // 32 bytes, [entry][lane]
 struct OutRec { uint32_t m, n; int64_t k, l, s; };         // 32 bytes, per-read slot
 
 struct FmiCounters {
     unsigned long long ext_calls;
+    unsigned long long rec_reads;  // distinct 64-byte CP_OCC records fetched (1 or 2 per extension)
     unsigned long long total;      // SMEMs found in this batch
     int32_t max_per_read;
     int32_t bad, first_bad, pad;
@@ -63,12 +64,13 @@ __device__ __forceinline__ void load_rec(const CpOcc *p, int64_t (&cnt)[4], uint
 
 // backwardExt (FMI_search.cpp:1025-1052)
 __device__ __forceinline__ void backward_ext(const FmiIdx &ix, int64_t k, int64_t l, int64_t s, int a, int64_t &ko,
-                                             int64_t &lo, int64_t &so, unsigned long long &calls) {
+                                             int64_t &lo, int64_t &so, unsigned long long &calls, unsigned long long &recs) {
     calls++;
     const int64_t sp = k, ep = k + s;
     int64_t c_sp[4], c_ep[4]; uint64_t b_sp[4], b_ep[4];
     const CpOcc *r_sp = ix.cp_occ + (sp >> 6), *r_ep = ix.cp_occ + (ep >> 6);
     load_rec(r_sp, c_sp, b_sp);
+    recs += r_sp == r_ep ? 1 : 2;
     if (r_sp == r_ep) {
 #pragma unroll
         for (int b = 0; b < 4; b++) { c_ep[b] = c_sp[b]; b_ep[b] = b_sp[b]; }
@@ -89,92 +91,211 @@ __device__ __forceinline__ void backward_ext(const FmiIdx &ix, int64_t k, int64_
     so = a == 0 ? ss[0] : a == 1 ? ss[1] : a == 2 ? ss[2] : ss[3];
     lo = a == 0 ? l0 : a == 1 ? l1 : a == 2 ? l2 : l3;
 }
-// forward extension = backward extension on the reverse-complement strand (FMI_search.cpp:549-557)
-__device__ __forceinline__ void forward_ext(const FmiIdx &ix, Iv &sm, int a, unsigned long long &calls) {
-    int64_t ko, lo, so;
-    backward_ext(ix, sm.l, sm.k, sm.s, 3 - a, ko, lo, so, calls);
-    sm.k = lo; sm.l = ko; sm.s = so;
-}
-
-struct ReadCtx {
-    const uint8_t *q; int len;
-    PrevRec *prev; int64_t pstride;        // prev[p * pstride]
-    OutRec *out; int cap; int nout;        // out[j], j < cap stored; nout counts all
-    int min_seed_len;
+// ---- the seeding kernel: one lane = one read at a time, as a state machine ------------------------------------
+// A straight transcription (one lane runs the three passes as nested loops) leaves ~13 % of the lanes active
+// (PMC, profiles/r01_fmi_pmc.md): neighbouring reads sit in different loops, so every look-up site executes with a
+// handful of lanes.  Here every lane keeps its position in the three passes as explicit state and the wave loop is
+//     A: advance the state (cheap: read a base, push / pop list entries) until the lane needs an extension
+//     B: ONE backwardExt site for the whole wave  <- the only place the index is read
+//     C: consume the result according to the state
+// so a look-up instruction serves every lane that still has work.  A lane that finishes its read takes the next
+// one of its wave's chunk (LDS counter), which evens out reads of different cost.
+enum FmiState : int {
+    ST_NEW_READ, ST_P1_NEXT, ST_START_POS, ST_FWD_STEP, ST_FWD_END, ST_BWD_COL, ST_BWD_ENT, ST_BWD_END, ST_POS_DONE,
+    ST_P2_NEXT, ST_P3_START, ST_P3_STEP, ST_READ_DONE, ST_DONE
 };
 
-__device__ __forceinline__ void emit(ReadCtx &rc, uint32_t m, uint32_t n, int64_t k, int64_t l, int64_t s) {
-    if (rc.nout < rc.cap) { OutRec o; o.m = m; o.n = n; o.k = k; o.l = l; o.s = s; rc.out[rc.nout] = o; }
-    rc.nout++;
-}
+__global__ __launch_bounds__(256) void fmi_seed_kernel(FmiIdx ix, const uint8_t *__restrict__ enc, int32_t stride,
+                                                       const int32_t *__restrict__ len_arr, int64_t first, int32_t nbatch,
+                                                       int min_seed_len, PrevRec *prev, int prev_cap, OutRec *out_all, int cap,
+                                                       int32_t *counts, FmiCounters *ct, int reads_per_wave) {
+    __shared__ int wave_next[4];
+    const int wave_in_block = threadIdx.x >> 6;
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t pstride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t wave_first = (tid >> 6) * reads_per_wave;
+    const int wave_end = (int)(wave_first + reads_per_wave < nbatch ? wave_first + reads_per_wave : nbatch);
+    if ((threadIdx.x & 63) == 0) wave_next[wave_in_block] = (int)(wave_first < nbatch ? wave_first : nbatch);
+    __syncthreads();
+    PrevRec *const prevp = prev + tid;                       // entry e of this lane at prevp[e * pstride]
+    const int split_len = (int)(min_seed_len * 1.5 + .499);
+    const int msl = min_seed_len + 1;
 
-// body of getSMEMsOnePosOneThread for one (read, x, min_intv); returns next_x
-__device__ int smem_one_pos(const FmiIdx &ix, ReadCtx &rc, int x, int64_t min_intv, unsigned long long &calls) {
-    const uint8_t *q = rc.q;
-    const int len = rc.len;
-    int next_x = x + 1;
-    int a = q[x];
-    if (a >= 4) return next_x;
-    Iv sm;
-    sm.m = (uint32_t)x; sm.n = (uint32_t)x;
-    sm.k = ix.count[a]; sm.l = ix.count[3 - a]; sm.s = ix.count[a + 1] - ix.count[a];
-    int nprev = 0;
-    for (int j = x + 1; j < len; j++) {
-        a = q[j];
-        next_x = j + 1;
-        if (a >= 4) break;
-        Iv nw = sm;
-        forward_ext(ix, nw, a, calls);
-        nw.n = (uint32_t)j;
-        if (nw.s != sm.s) { PrevRec p; p.n = sm.n; p.k = sm.k; p.l = sm.l; p.s = sm.s; rc.prev[nprev * rc.pstride] = p; nprev++; }
-        if (nw.s < min_intv) { next_x = j; break; }
-        sm = nw;
-    }
-    if (sm.s >= min_intv) { PrevRec p; p.n = sm.n; p.k = sm.k; p.l = sm.l; p.s = sm.s; rc.prev[nprev * rc.pstride] = p; nprev++; }
-    // reverse (longest match first)
-    for (int p = 0; p < nprev / 2; p++) {
-        PrevRec t0 = rc.prev[p * rc.pstride], t1 = rc.prev[(nprev - 1 - p) * rc.pstride];
-        rc.prev[p * rc.pstride] = t1; rc.prev[(nprev - 1 - p) * rc.pstride] = t0;
-    }
-    // every prev entry starts at m = x; m is tracked per backward column instead of per entry
-    uint32_t cur_m = (uint32_t)x;
-    for (int j = x - 1; j >= 0; j--) {
-        a = q[j];
-        if (a > 3) break;
-        int ncur = 0;
-        int curr_s = -1;                                     // int, as in the reference
-        bool first_phase = true;
-        for (int p = 0; p < nprev; p++) {
-            const PrevRec s0 = rc.prev[p * rc.pstride];
-            int64_t ko, lo, so;
-            backward_ext(ix, s0.k, s0.l, s0.s, a, ko, lo, so, calls);
-            if (first_phase) {
-                if (so < min_intv && (int)((int64_t)s0.n - (int64_t)cur_m + 1) >= rc.min_seed_len) {
-                    emit(rc, cur_m, (uint32_t)s0.n, s0.k, s0.l, s0.s);
-                    first_phase = false;
-                    continue;
+    unsigned long long calls = 0, recs = 0, tot = 0;
+    int mx = 0;
+    // ---- per-lane state
+    int state = ST_NEW_READ;
+    const uint8_t *q = enc; OutRec *out = out_all;
+    int t = 0, len = 0, pass = 1, x = 0, next_x = 0, j = 0, a = 0;
+    int nprev = 0, ncur = 0, p = 0, base = 0, curr_s = -1, n1 = 0, jrec = 0, nout = 0;
+    bool first_phase = true;
+    uint32_t cur_m = 0;
+    int64_t min_intv = 1, sm_k = 0, sm_l = 0, sm_s = 0;
+    int sm_n = 0;
+    PrevRec s0; s0.n = s0.k = s0.l = s0.s = 0;
+
+    auto emit = [&](uint32_t m, uint32_t n, int64_t k, int64_t l, int64_t s) {
+        if (nout < cap) { OutRec o; o.m = m; o.n = n; o.k = k; o.l = l; o.s = s; out[nout] = o; }
+        nout++;
+    };
+    auto push_fwd = [&]() {                                  // forward list, newest entry lowest: read back = longest first
+        PrevRec r; r.n = sm_n; r.k = sm_k; r.l = sm_l; r.s = sm_s;
+        prevp[(int64_t)(prev_cap - 1 - nprev) * pstride] = r; nprev++;
+    };
+
+    while (state != ST_DONE) {
+        bool need = false;
+        int64_t K = 0, L = 0, S = 0; int A = 0;
+        // ---- A: advance until an extension is needed
+        while (!need && state != ST_DONE) {
+            switch (state) {
+            case ST_NEW_READ: {
+                const int idx = atomicAdd(&wave_next[wave_in_block], 1);
+                if (idx >= wave_end) { state = ST_DONE; break; }
+                t = idx;
+                const int64_t r = first + t;
+                q = enc + r * (int64_t)stride; len = len_arr[r];
+                out = out_all + (int64_t)t * cap; nout = 0;
+                pass = 1; x = 0; min_intv = 1;
+                state = ST_P1_NEXT;
+                break;
+            }
+            case ST_P1_NEXT:                                 // getSMEMsAllPosOneThread loop, FMI_search.cpp:672-724
+                if (x < len) state = ST_START_POS;
+                else { pass = 2; n1 = nout; jrec = 0; state = ST_P2_NEXT; }
+                break;
+            case ST_START_POS: {                             // getSMEMsOnePosOneThread :496-530
+                next_x = x + 1;
+                a = q[x];
+                if (a >= 4) { state = ST_POS_DONE; break; }
+                sm_n = x; sm_k = ix.count[a]; sm_l = ix.count[3 - a]; sm_s = ix.count[a + 1] - ix.count[a];
+                nprev = 0; j = x + 1;
+                state = ST_FWD_STEP;
+                break;
+            }
+            case ST_FWD_STEP:                                // forward loop :531-575
+                if (j >= len) { state = ST_FWD_END; break; }
+                a = q[j];
+                next_x = j + 1;
+                if (a >= 4) { state = ST_FWD_END; break; }
+                K = sm_l; L = sm_k; S = sm_s; A = 3 - a; need = true;
+                break;
+            case ST_FWD_END:
+                if (sm_s >= min_intv) push_fwd();
+                base = prev_cap - nprev;                     // reversed list = entries base .. base + nprev - 1
+                cur_m = (uint32_t)x; j = x - 1;
+                state = ST_BWD_COL;
+                break;
+            case ST_BWD_COL:                                 // backward loop :589-650
+                if (j < 0) { state = ST_BWD_END; break; }
+                a = q[j];
+                if (a > 3) { state = ST_BWD_END; break; }
+                ncur = 0; curr_s = -1; first_phase = true; p = 0;
+                state = ST_BWD_ENT;
+                break;
+            case ST_BWD_ENT:
+                if (p >= nprev) {
+                    nprev = ncur; base = 0;
+                    if (ncur == 0) state = ST_BWD_END;
+                    else { cur_m = (uint32_t)j; j--; state = ST_BWD_COL; }
+                    break;
                 }
-                if (so >= min_intv && so != (int64_t)curr_s) {
-                    curr_s = (int)so;
-                    PrevRec nw; nw.n = s0.n; nw.k = ko; nw.l = lo; nw.s = so;
-                    rc.prev[ncur * rc.pstride] = nw; ncur++;
-                    first_phase = false;
+                s0 = prevp[(int64_t)(base + p) * pstride];
+                K = s0.k; L = s0.l; S = s0.s; A = a; need = true;
+                break;
+            case ST_BWD_END:
+                if (nprev != 0) {
+                    const PrevRec r0 = prevp[(int64_t)base * pstride];
+                    if ((int)((int64_t)r0.n - (int64_t)cur_m + 1) >= min_seed_len) emit(cur_m, (uint32_t)r0.n, r0.k, r0.l, r0.s);
                 }
-            } else if (so >= min_intv && so != (int64_t)curr_s) {
-                curr_s = (int)so;
-                PrevRec nw; nw.n = s0.n; nw.k = ko; nw.l = lo; nw.s = so;
-                rc.prev[ncur * rc.pstride] = nw; ncur++;
+                state = ST_POS_DONE;
+                break;
+            case ST_POS_DONE:
+                if (pass == 1) { x = next_x; state = ST_P1_NEXT; } else state = ST_P2_NEXT;
+                break;
+            case ST_P2_NEXT: {                               // re-seeding, fmi.cpp:300-324
+                bool started = false;
+                if (n1 <= cap) {
+                    while (jrec < n1) {
+                        const OutRec o = out[jrec++];
+                        const int start = (int)o.m, end = (int)o.n + 1;
+                        if (end - start < split_len || o.s > 10) continue;
+                        x = (end + start) >> 1; min_intv = o.s + 1;
+                        started = true;
+                        break;
+                    }
+                }
+                if (started) state = ST_START_POS;
+                else { pass = 3; x = 0; state = ST_P3_START; }
+                break;
+            }
+            case ST_P3_START:                                // bwtSeedStrategyAllPosOneThread :726-812
+                if (x >= len) { state = ST_READ_DONE; break; }
+                next_x = x + 1;
+                a = q[x];
+                if (a < 4) {
+                    sm_n = x; sm_k = ix.count[a]; sm_l = ix.count[3 - a]; sm_s = ix.count[a + 1] - ix.count[a];
+                    j = x + 1;
+                    state = ST_P3_STEP;
+                } else x = next_x;
+                break;
+            case ST_P3_STEP:
+                if (j >= len) { x = next_x; state = ST_P3_START; break; }
+                next_x = j + 1;
+                a = q[j];
+                if (a >= 4) { x = next_x; state = ST_P3_START; break; }
+                K = sm_l; L = sm_k; S = sm_s; A = 3 - a; need = true;
+                break;
+            case ST_READ_DONE:
+                counts[t] = nout;
+                tot += (unsigned long long)nout; mx = nout > mx ? nout : mx;
+                state = ST_NEW_READ;
+                break;
+            default: break;
             }
         }
-        nprev = ncur;
-        if (ncur == 0) break;
-        cur_m = (uint32_t)j;
+        if (!need) continue;                                 // ST_DONE: leaves the loop
+        // ---- B: the extension
+        int64_t ko, lo, so;
+        backward_ext(ix, K, L, S, A, ko, lo, so, calls, recs);
+        // ---- C: consume
+        if (state == ST_FWD_STEP) {                          // forward: result is (l, k, s) of the reverse strand
+            if (so != sm_s) push_fwd();
+            if (so < min_intv) { next_x = j; state = ST_FWD_END; }
+            else { sm_k = lo; sm_l = ko; sm_s = so; sm_n = j; j++; }
+        } else if (state == ST_BWD_ENT) {
+            bool keep = false;
+            if (first_phase && so < min_intv && (int)((int64_t)s0.n - (int64_t)cur_m + 1) >= min_seed_len) {
+                emit(cur_m, (uint32_t)s0.n, s0.k, s0.l, s0.s);
+                first_phase = false;
+            } else if (so >= min_intv && so != (int64_t)curr_s) {
+                keep = true; first_phase = false;
+            }
+            if (keep) {
+                curr_s = (int)so;                            // int, as in the reference
+                PrevRec nw; nw.n = s0.n; nw.k = ko; nw.l = lo; nw.s = so;
+                prevp[(int64_t)ncur * pstride] = nw; ncur++;
+            }
+            p++;
+        } else {                                             // ST_P3_STEP
+            sm_k = lo; sm_l = ko; sm_s = so; sm_n = j;
+            if (sm_s < 20 && sm_n - x + 1 >= msl) {
+                if (sm_s > 0) emit((uint32_t)x, (uint32_t)sm_n, sm_k, sm_l, sm_s);
+                x = next_x; state = ST_P3_START;
+            } else j++;
+        }
     }
-    if (nprev != 0) {
-        const PrevRec s0 = rc.prev[0];
-        if ((int)((int64_t)s0.n - (int64_t)cur_m + 1) >= rc.min_seed_len) emit(rc, cur_m, (uint32_t)s0.n, s0.k, s0.l, s0.s);
+    // statistics: one atomic per wave
+    for (int o = 32; o > 0; o >>= 1) {
+        calls += __shfl_xor(calls, o); tot += __shfl_xor(tot, o); recs += __shfl_xor(recs, o);
+        const int v = __shfl_xor(mx, o); mx = v > mx ? v : mx;
     }
-    return next_x;
+    if ((threadIdx.x & 63) == 0) {
+        if (calls) atomicAdd(&ct->ext_calls, calls);
+        if (recs) atomicAdd(&ct->rec_reads, recs);
+        if (tot) atomicAdd(&ct->total, tot);
+        if (mx) atomicMax(&ct->max_per_read, mx);
+    }
 }
 
 __device__ __forceinline__ bool rec_less(const OutRec &a, const OutRec &b) {
@@ -183,84 +304,23 @@ __device__ __forceinline__ bool rec_less(const OutRec &a, const OutRec &b) {
     if (a.s != b.s) return a.s < b.s;            // tie-break (unspecified in the reference)
     return a.k < b.k;
 }
-
-__global__ __launch_bounds__(256) void fmi_seed_kernel(FmiIdx ix, const uint8_t *__restrict__ enc, int32_t stride,
-                                                       const int32_t *__restrict__ len, int64_t first, int32_t nbatch,
-                                                       int min_seed_len, PrevRec *prev, OutRec *out, int cap,
-                                                       int32_t *counts, FmiCounters *ct) {
+// sortSMEMs (:986-1022) per read: insertion sort inside the read's slot (a handful of records)
+__global__ __launch_bounds__(256) void fmi_sort_slots(OutRec *out_all, int cap, const int32_t *counts, int32_t nbatch) {
     const int32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    unsigned long long calls = 0;
-    int nout = 0;
-    if (t < nbatch) {
-        const int64_t r = first + t;
-        ReadCtx rc;
-        rc.q = enc + r * (int64_t)stride; rc.len = len[r];
-        rc.prev = prev + t; rc.pstride = nbatch;
-        rc.out = out + (int64_t)t * cap; rc.cap = cap; rc.nout = 0; rc.min_seed_len = min_seed_len;
-        // pass 1
-        for (int x = 0; x < rc.len;) x = smem_one_pos(ix, rc, x, 1, calls);
-        // pass 2: re-seed (only stored records can be re-read; a truncated list is re-run with a bigger slot)
-        const int n1 = rc.nout;
-        const int split_len = (int)(min_seed_len * 1.5 + .499);
-        if (n1 <= cap) {
-            for (int j = 0; j < n1; j++) {
-                const OutRec o = rc.out[j];
-                const int start = (int)o.m, end = (int)o.n + 1;
-                if (end - start < split_len || o.s > 10) continue;
-                smem_one_pos(ix, rc, (end + start) >> 1, o.s + 1, calls);
-            }
+    if (t >= nbatch) return;
+    const int nout = counts[t];
+    if (nout > cap) return;                       // truncated slot: the batch is re-run with a bigger one
+    OutRec *out = out_all + (int64_t)t * cap;
+    for (int i = 1; i < nout; i++) {
+        const OutRec key = out[i];
+        int j = i - 1;
+        while (j >= 0) {
+            const OutRec o = out[j];
+            if (!rec_less(key, o)) break;
+            out[j + 1] = o;
+            j--;
         }
-        // pass 3
-        const int msl = min_seed_len + 1;
-        for (int x = 0; x < rc.len;) {
-            int next_x = x + 1;
-            int a = rc.q[x];
-            if (a < 4) {
-                Iv sm;
-                sm.m = (uint32_t)x; sm.n = (uint32_t)x;
-                sm.k = ix.count[a]; sm.l = ix.count[3 - a]; sm.s = ix.count[a + 1] - ix.count[a];
-                for (int j = x + 1; j < rc.len; j++) {
-                    next_x = j + 1;
-                    a = rc.q[j];
-                    if (a >= 4) break;
-                    forward_ext(ix, sm, a, calls);
-                    sm.n = (uint32_t)j;
-                    if (sm.s < 20 && (int)(sm.n - sm.m + 1) >= msl) {
-                        if (sm.s > 0) emit(rc, sm.m, sm.n, sm.k, sm.l, sm.s);
-                        break;
-                    }
-                }
-            }
-            x = next_x;
-        }
-        nout = rc.nout;
-        // insertion sort of this read's records
-        if (nout <= cap) {
-            for (int i = 1; i < nout; i++) {
-                const OutRec key = rc.out[i];
-                int j = i - 1;
-                while (j >= 0) {
-                    const OutRec o = rc.out[j];
-                    if (!rec_less(key, o)) break;
-                    rc.out[j + 1] = o;
-                    j--;
-                }
-                rc.out[j + 1] = key;
-            }
-        }
-        counts[t] = nout;
-    }
-    // statistics: one atomic per wave
-    int mx = nout;
-    unsigned long long tot = (unsigned long long)nout;
-    for (int o = 32; o > 0; o >>= 1) {
-        calls += __shfl_xor(calls, o); tot += __shfl_xor(tot, o);
-        const int v = __shfl_xor(mx, o); mx = v > mx ? v : mx;
-    }
-    if ((threadIdx.x & 63) == 0) {
-        if (calls) atomicAdd(&ct->ext_calls, calls);
-        if (tot) atomicAdd(&ct->total, tot);
-        if (mx) atomicMax(&ct->max_per_read, mx);
+        out[j + 1] = key;
     }
 }
 
@@ -349,7 +409,7 @@ struct gab_fmi {
     hipEvent_t ev[2] = {nullptr, nullptr};
     FmiCounters *h_ct = nullptr;
     bool have_stats = false;
-    int64_t ext_calls = 0, nsmem = 0;
+    int64_t ext_calls = 0, rec_reads = 0, nsmem = 0;
     float kernel_ms = 0;
 };
 
@@ -450,16 +510,18 @@ extern "C" int gab_fmi_seed_device(gab_fmi *h, const uint8_t *d_enc, int32_t str
     if (nreads == 0) { GAB_HIP(hipMemsetAsync(h->roff.p, 0, 8, s)); return GAB_OK; }
     GAB_CHECK(d_enc && d_len, "gab_fmi_seed_device: NULL buffer");
 
-    // batch size from the scratch budget: prev needs stride x 32 B per read, slots cap x 32 B
+    // A wave owns a chunk of `rpw` reads and its lanes take them one after another; the forward-interval list
+    // (prev) is per LANE (stride entries x 32 B), the output slot per READ (cap x 32 B).
     int cap = 48;
-    const size_t per_read = (size_t)stride * sizeof(PrevRec) + (size_t)3 * stride * 0;   // slots sized below
-    int64_t B = (int64_t)std::min<size_t>((size_t)nreads, std::max<size_t>(1024, h->scratch_budget / (per_read + 64 * sizeof(OutRec))));
-    B = std::min<int64_t>(B, 1 << 20);
+    static const int rpw = [] { const char *e = getenv("GAB_FMI_RPW"); const int v = e ? atoi(e) : 0; return v >= 64 ? v : 256; }();
+    int64_t B = (int64_t)std::min<size_t>((size_t)nreads, std::max<size_t>(1024, h->scratch_budget / (64 * sizeof(OutRec))));
+    B = std::min<int64_t>(B, 1 << 21);
+    const int64_t max_waves = gab_ceil_div(B, rpw), max_blocks = gab_ceil_div(max_waves, 4);
     const int64_t nb_blocks = gab_ceil_div(B, 256);
     const size_t o_counts = 256, o_bs = o_counts + 4 * (size_t)B + 64;
     rc = h->ws.reserve(o_bs + 8 * (size_t)nb_blocks + 64);
     if (rc) return rc;
-    rc = h->prev.reserve(sizeof(PrevRec) * (size_t)stride * (size_t)B);
+    rc = h->prev.reserve(sizeof(PrevRec) * (size_t)stride * (size_t)max_blocks * 256);
     if (rc) return rc;
     char *wb = h->ws.as<char>();
     FmiCounters *d_ct = (FmiCounters *)wb;
@@ -484,7 +546,7 @@ extern "C" int gab_fmi_seed_device(gab_fmi *h, const uint8_t *d_enc, int32_t str
     rc = h->out.reserve(out_cap * sizeof(gab_smem));
     if (rc) return rc;
     int64_t total = 0;
-    unsigned long long ext_total = 0;
+    unsigned long long ext_total = 0, rec_total = 0;
     float kms = 0;
     for (int64_t first = 0; first < nreads; first += B) {
         const int32_t nb = (int32_t)std::min<int64_t>(B, nreads - first);
@@ -492,11 +554,13 @@ extern "C" int gab_fmi_seed_device(gab_fmi *h, const uint8_t *d_enc, int32_t str
         for (;;) {                                        // at most two rounds: second with the exact slot size
             rc = h->slots.reserve(sizeof(OutRec) * (size_t)cap * (size_t)nb);
             if (rc) return rc;
-            h->h_ct->ext_calls = 0; h->h_ct->total = 0; h->h_ct->max_per_read = 0;
+            h->h_ct->ext_calls = 0; h->h_ct->rec_reads = 0; h->h_ct->total = 0; h->h_ct->max_per_read = 0;
             GAB_HIP(hipMemcpyAsync(d_ct, h->h_ct, sizeof(FmiCounters), hipMemcpyHostToDevice, s));
             GAB_HIP(hipEventRecord(h->ev[0], s));
-            hipLaunchKernelGGL(fmi_seed_kernel, dim3(blocks), dim3(256), 0, s, h->ix, d_enc, stride, d_len, first, nb,
-                               min_seed_len, h->prev.as<PrevRec>(), h->slots.as<OutRec>(), cap, d_counts, d_ct);
+            const int seed_blocks = (int)gab_ceil_div(gab_ceil_div((int64_t)nb, rpw), 4);
+            hipLaunchKernelGGL(fmi_seed_kernel, dim3(seed_blocks), dim3(256), 0, s, h->ix, d_enc, stride, d_len, first, nb,
+                               min_seed_len, h->prev.as<PrevRec>(), (int)stride, h->slots.as<OutRec>(), cap, d_counts, d_ct, rpw);
+            hipLaunchKernelGGL(fmi_sort_slots, dim3(blocks), dim3(256), 0, s, h->slots.as<OutRec>(), cap, d_counts, nb);
             GAB_HIP(hipGetLastError());
             GAB_HIP(hipEventRecord(h->ev[1], s));
             GAB_HIP(hipMemcpyAsync(h->h_ct, d_ct, sizeof(FmiCounters), hipMemcpyDeviceToHost, s));
@@ -507,7 +571,7 @@ extern "C" int gab_fmi_seed_device(gab_fmi *h, const uint8_t *d_enc, int32_t str
         float ms = 0;
         GAB_HIP(hipEventElapsedTime(&ms, h->ev[0], h->ev[1]));
         kms += ms;
-        ext_total += h->h_ct->ext_calls;
+        ext_total += h->h_ct->ext_calls; rec_total += h->h_ct->rec_reads;
         const int64_t add = (int64_t)h->h_ct->total;
         if ((size_t)(total + add) > out_cap) {
             // grow, keeping what earlier batches wrote
@@ -532,7 +596,7 @@ extern "C" int gab_fmi_seed_device(gab_fmi *h, const uint8_t *d_enc, int32_t str
     GAB_HIP(hipStreamSynchronize(s));
     *nout = total;
     if (d_out) *d_out = h->out.as<gab_smem>();
-    h->ext_calls = (int64_t)ext_total; h->nsmem = total; h->kernel_ms = kms;
+    h->ext_calls = (int64_t)ext_total; h->rec_reads = (int64_t)rec_total; h->nsmem = total; h->kernel_ms = kms;
     h->have_stats = true;
     return GAB_OK;
 }
@@ -578,5 +642,12 @@ extern "C" int gab_fmi_last_stats(gab_fmi *h, int64_t *ext_calls, int64_t *nsmem
     if (ext_calls) *ext_calls = h->ext_calls;
     if (nsmem) *nsmem = h->nsmem;
     if (kernel_ms) *kernel_ms = h->kernel_ms;
+    return GAB_OK;
+}
+
+extern "C" int gab_fmi_last_records(gab_fmi *h, int64_t *cp_occ_records) {
+    GAB_CHECK(h, "gab_fmi_last_records: NULL handle");
+    GAB_CHECK(h->have_stats, "gab_fmi_last_records: no completed run on this handle");
+    if (cp_occ_records) *cp_occ_records = h->rec_reads;
     return GAB_OK;
 }

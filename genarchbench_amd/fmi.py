@@ -56,4 +56,6 @@ class FMI_search:
     def last_stats(self):
         e = C.c_int64(0); n = C.c_int64(0); k = C.c_float(0)
         check(lib().gab_fmi_last_stats(self._h, C.byref(e), C.byref(n), C.byref(k)))
-        return {"ext_calls": e.value, "smems": n.value, "kernel_ms": k.value}
+        r = C.c_int64(0)
+        check(lib().gab_fmi_last_records(self._h, C.byref(r)))
+        return {"ext_calls": e.value, "smems": n.value, "kernel_ms": k.value, "cp_occ_records": r.value}

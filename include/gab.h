@@ -214,8 +214,11 @@ void gab_fmi_free(gab_smem *p);
 int gab_fmi_seed_device(gab_fmi *h, const uint8_t *d_enc, int32_t stride, const int32_t *d_len,
                         int64_t nreads, int32_t min_seed_len, const gab_smem **d_out,
                         const int64_t **d_read_off, int64_t *nout, void *stream);
-/* last run: backwardExt calls (= 2 random 64-byte index reads each), SMEMs found, seeding-kernel ms */
+/* last run: backwardExt calls, SMEMs found, seeding-kernel ms */
 int gab_fmi_last_stats(gab_fmi *h, int64_t *ext_calls, int64_t *nsmem, float *kernel_ms);
+/* last run: 64-byte CP_OCC records the extensions fetched (GET_OCC, FMI_search.h:66-73: one when both interval
+ * ends share a record, else two) -- the random index traffic of the run is 64 B x this number */
+int gab_fmi_last_records(gab_fmi *h, int64_t *cp_occ_records);
 
 #ifdef __cplusplus
 }
