@@ -105,11 +105,17 @@ enum FmiState : int {
     ST_P2_NEXT, ST_P3_START, ST_P3_STEP, ST_READ_DONE, ST_DONE
 };
 
+// LDSQ: the lane's current read sits in LDS as 4-bit codes ([word of 8 bases][lane], conflict-free), so stepping
+// along the read costs no global round trip; used whenever the read length bound fits (stride <= kLdsQMax).
+constexpr int kLdsQMax = 256;
+template <bool LDSQ>
 __global__ __launch_bounds__(256) void fmi_seed_kernel(FmiIdx ix, const uint8_t *__restrict__ enc, int32_t stride,
                                                        const int32_t *__restrict__ len_arr, int64_t first, int32_t nbatch,
                                                        int min_seed_len, PrevRec *prev, int prev_cap, OutRec *out_all, int cap,
                                                        int32_t *counts, FmiCounters *ct, int reads_per_wave) {
     __shared__ int wave_next[4];
+    extern __shared__ uint32_t lq_all[];                     // LDSQ: ((stride + 7) / 8) x 256 dwords
+    uint32_t *const lq = lq_all + threadIdx.x;
     const int wave_in_block = threadIdx.x >> 6;
     const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t pstride = (int64_t)gridDim.x * blockDim.x;
@@ -134,6 +140,12 @@ __global__ __launch_bounds__(256) void fmi_seed_kernel(FmiIdx ix, const uint8_t 
     int sm_n = 0;
     PrevRec s0; s0.n = s0.k = s0.l = s0.s = 0;
 
+    auto base_at = [&](int pos) -> int {
+        if (LDSQ) return (int)((lq[(pos >> 3) * 256] >> ((pos & 7) * 4)) & 15u);
+        return (int)q[pos];
+    };
+    PrevRec head; head.n = head.k = head.l = head.s = 0;     // entry 0 of the list the backward phase reads next
+    PrevRec nxt = head;                                      // entry p + 1, fetched while entry p is being extended
     auto emit = [&](uint32_t m, uint32_t n, int64_t k, int64_t l, int64_t s) {
         if (nout < cap) { OutRec o; o.m = m; o.n = n; o.k = k; o.l = l; o.s = s; out[nout] = o; }
         nout++;
@@ -141,6 +153,7 @@ __global__ __launch_bounds__(256) void fmi_seed_kernel(FmiIdx ix, const uint8_t 
     auto push_fwd = [&]() {                                  // forward list, newest entry lowest: read back = longest first
         PrevRec r; r.n = sm_n; r.k = sm_k; r.l = sm_l; r.s = sm_s;
         prevp[(int64_t)(prev_cap - 1 - nprev) * pstride] = r; nprev++;
+        head = r;
     };
 
     while (state != ST_DONE) {
@@ -156,6 +169,24 @@ __global__ __launch_bounds__(256) void fmi_seed_kernel(FmiIdx ix, const uint8_t 
                 const int64_t r = first + t;
                 q = enc + r * (int64_t)stride; len = len_arr[r];
                 out = out_all + (int64_t)t * cap; nout = 0;
+                if (LDSQ) {                                  // aligned dwords around the read -> 8 codes per LDS word
+                    const int mis = (int)((uintptr_t)q & 3);
+                    const uint32_t *qa = reinterpret_cast<const uint32_t *>(q - mis);
+                    const int last = (mis + len - 1) >> 2;   // last dword that overlaps the read
+                    uint32_t d0 = len > 0 ? qa[0] : 0u;
+                    for (int w = 0; w * 8 < len; w++) {
+                        const uint32_t d1 = 2 * w + 1 <= last ? qa[2 * w + 1] : 0u, d2 = 2 * w + 2 <= last ? qa[2 * w + 2] : 0u;
+                        const uint32_t lo = __builtin_amdgcn_alignbyte(d1, d0, mis), hi = __builtin_amdgcn_alignbyte(d2, d1, mis);
+                        uint32_t pk = 0;
+#pragma unroll
+                        for (int b = 0; b < 4; b++) {
+                            const uint32_t x0 = (lo >> (8 * b)) & 0xffu, x1 = (hi >> (8 * b)) & 0xffu;
+                            pk |= (x0 > 3u ? 4u : x0) << (4 * b) | (x1 > 3u ? 4u : x1) << (16 + 4 * b);
+                        }
+                        lq[w * 256] = pk;
+                        d0 = d2;
+                    }
+                }
                 pass = 1; x = 0; min_intv = 1;
                 state = ST_P1_NEXT;
                 break;
@@ -166,7 +197,7 @@ __global__ __launch_bounds__(256) void fmi_seed_kernel(FmiIdx ix, const uint8_t 
                 break;
             case ST_START_POS: {                             // getSMEMsOnePosOneThread :496-530
                 next_x = x + 1;
-                a = q[x];
+                a = base_at(x);
                 if (a >= 4) { state = ST_POS_DONE; break; }
                 sm_n = x; sm_k = ix.count[a]; sm_l = ix.count[3 - a]; sm_s = ix.count[a + 1] - ix.count[a];
                 nprev = 0; j = x + 1;
@@ -175,7 +206,7 @@ __global__ __launch_bounds__(256) void fmi_seed_kernel(FmiIdx ix, const uint8_t 
             }
             case ST_FWD_STEP:                                // forward loop :531-575
                 if (j >= len) { state = ST_FWD_END; break; }
-                a = q[j];
+                a = base_at(j);
                 next_x = j + 1;
                 if (a >= 4) { state = ST_FWD_END; break; }
                 K = sm_l; L = sm_k; S = sm_s; A = 3 - a; need = true;
@@ -188,7 +219,7 @@ __global__ __launch_bounds__(256) void fmi_seed_kernel(FmiIdx ix, const uint8_t 
                 break;
             case ST_BWD_COL:                                 // backward loop :589-650
                 if (j < 0) { state = ST_BWD_END; break; }
-                a = q[j];
+                a = base_at(j);
                 if (a > 3) { state = ST_BWD_END; break; }
                 ncur = 0; curr_s = -1; first_phase = true; p = 0;
                 state = ST_BWD_ENT;
@@ -200,12 +231,12 @@ __global__ __launch_bounds__(256) void fmi_seed_kernel(FmiIdx ix, const uint8_t 
                     else { cur_m = (uint32_t)j; j--; state = ST_BWD_COL; }
                     break;
                 }
-                s0 = prevp[(int64_t)(base + p) * pstride];
+                s0 = p == 0 ? head : nxt;
                 K = s0.k; L = s0.l; S = s0.s; A = a; need = true;
                 break;
             case ST_BWD_END:
                 if (nprev != 0) {
-                    const PrevRec r0 = prevp[(int64_t)base * pstride];
+                    const PrevRec r0 = head;
                     if ((int)((int64_t)r0.n - (int64_t)cur_m + 1) >= min_seed_len) emit(cur_m, (uint32_t)r0.n, r0.k, r0.l, r0.s);
                 }
                 state = ST_POS_DONE;
@@ -232,7 +263,7 @@ __global__ __launch_bounds__(256) void fmi_seed_kernel(FmiIdx ix, const uint8_t 
             case ST_P3_START:                                // bwtSeedStrategyAllPosOneThread :726-812
                 if (x >= len) { state = ST_READ_DONE; break; }
                 next_x = x + 1;
-                a = q[x];
+                a = base_at(x);
                 if (a < 4) {
                     sm_n = x; sm_k = ix.count[a]; sm_l = ix.count[3 - a]; sm_s = ix.count[a + 1] - ix.count[a];
                     j = x + 1;
@@ -242,7 +273,7 @@ __global__ __launch_bounds__(256) void fmi_seed_kernel(FmiIdx ix, const uint8_t 
             case ST_P3_STEP:
                 if (j >= len) { x = next_x; state = ST_P3_START; break; }
                 next_x = j + 1;
-                a = q[j];
+                a = base_at(j);
                 if (a >= 4) { x = next_x; state = ST_P3_START; break; }
                 K = sm_l; L = sm_k; S = sm_s; A = 3 - a; need = true;
                 break;
@@ -257,7 +288,11 @@ __global__ __launch_bounds__(256) void fmi_seed_kernel(FmiIdx ix, const uint8_t 
         if (!need) continue;                                 // ST_DONE: leaves the loop
         // ---- B: the extension
         int64_t ko, lo, so;
+        const bool fetch_next = state == ST_BWD_ENT && p + 1 < nprev;
+        PrevRec pre = nxt;
+        if (fetch_next) pre = prevp[(int64_t)(base + p + 1) * pstride];      // in flight together with the index records
         backward_ext(ix, K, L, S, A, ko, lo, so, calls, recs);
+        nxt = pre;
         // ---- C: consume
         if (state == ST_FWD_STEP) {                          // forward: result is (l, k, s) of the reverse strand
             if (so != sm_s) push_fwd();
@@ -274,7 +309,9 @@ __global__ __launch_bounds__(256) void fmi_seed_kernel(FmiIdx ix, const uint8_t 
             if (keep) {
                 curr_s = (int)so;                            // int, as in the reference
                 PrevRec nw; nw.n = s0.n; nw.k = ko; nw.l = lo; nw.s = so;
-                prevp[(int64_t)ncur * pstride] = nw; ncur++;
+                prevp[(int64_t)ncur * pstride] = nw;
+                if (ncur == 0) head = nw;                    // the old head was consumed at p == 0
+                ncur++;
             }
             p++;
         } else {                                             // ST_P3_STEP
@@ -558,8 +595,13 @@ extern "C" int gab_fmi_seed_device(gab_fmi *h, const uint8_t *d_enc, int32_t str
             GAB_HIP(hipMemcpyAsync(d_ct, h->h_ct, sizeof(FmiCounters), hipMemcpyHostToDevice, s));
             GAB_HIP(hipEventRecord(h->ev[0], s));
             const int seed_blocks = (int)gab_ceil_div(gab_ceil_div((int64_t)nb, rpw), 4);
-            hipLaunchKernelGGL(fmi_seed_kernel, dim3(seed_blocks), dim3(256), 0, s, h->ix, d_enc, stride, d_len, first, nb,
-                               min_seed_len, h->prev.as<PrevRec>(), (int)stride, h->slots.as<OutRec>(), cap, d_counts, d_ct, rpw);
+            if (stride <= kLdsQMax)
+                hipLaunchKernelGGL(fmi_seed_kernel<true>, dim3(seed_blocks), dim3(256), (size_t)((stride + 7) / 8) * 256 * 4, s, h->ix,
+                                   d_enc, stride, d_len, first, nb, min_seed_len, h->prev.as<PrevRec>(), (int)stride,
+                                   h->slots.as<OutRec>(), cap, d_counts, d_ct, rpw);
+            else
+                hipLaunchKernelGGL(fmi_seed_kernel<false>, dim3(seed_blocks), dim3(256), 0, s, h->ix, d_enc, stride, d_len, first, nb,
+                                   min_seed_len, h->prev.as<PrevRec>(), (int)stride, h->slots.as<OutRec>(), cap, d_counts, d_ct, rpw);
             hipLaunchKernelGGL(fmi_sort_slots, dim3(blocks), dim3(256), 0, s, h->slots.as<OutRec>(), cap, d_counts, nb);
             GAB_HIP(hipGetLastError());
             GAB_HIP(hipEventRecord(h->ev[1], s));
