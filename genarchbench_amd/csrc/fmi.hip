@@ -52,7 +52,8 @@ struct FmiCounters {
     unsigned long long rec_reads;  // distinct 64-byte CP_OCC records fetched (1 or 2 per extension)
     unsigned long long total;      // SMEMs found in this batch
     int32_t max_per_read;
-    int32_t bad, first_bad, pad;
+    int32_t bad, first_bad;
+    int32_t next_read;             // work queue of the seeding kernel
 };
 
 __device__ __forceinline__ void load_rec(const CpOcc *p, int64_t (&cnt)[4], uint64_t (&bits)[4]) {
@@ -98,8 +99,10 @@ __device__ __forceinline__ void backward_ext(const FmiIdx &ix, int64_t k, int64_
 //     A: advance the state (cheap: read a base, push / pop list entries) until the lane needs an extension
 //     B: ONE backwardExt site for the whole wave  <- the only place the index is read
 //     C: consume the result according to the state
-// so a look-up instruction serves every lane that still has work.  A lane that finishes its read takes the next
-// one of its wave's chunk (LDS counter), which evens out reads of different cost.
+// so a look-up instruction serves every lane that still has work.  A lane that finishes its read pulls the next
+// one of the batch from a global counter (a persistent grid sized to the occupancy), which evens out reads of
+// different cost.  The read itself and the interval lists stay in LDS: the only global traffic in the loop is the
+// index look-up (the global-memory lists of the first version cost as many L2 misses as the look-ups).
 enum FmiState : int {
     ST_NEW_READ, ST_P1_NEXT, ST_START_POS, ST_FWD_STEP, ST_FWD_END, ST_BWD_COL, ST_BWD_ENT, ST_BWD_END, ST_POS_DONE,
     ST_P2_NEXT, ST_P3_START, ST_P3_STEP, ST_READ_DONE, ST_DONE
@@ -109,21 +112,19 @@ enum FmiState : int {
 // along the read costs no global round trip; used whenever the read length bound fits (stride <= kLdsQMax).
 constexpr int kLdsQMax = 256;
 template <bool LDSQ>
-__global__ __launch_bounds__(256) void fmi_seed_kernel(FmiIdx ix, const uint8_t *__restrict__ enc, int32_t stride,
-                                                       const int32_t *__restrict__ len_arr, int64_t first, int32_t nbatch,
-                                                       int min_seed_len, PrevRec *prev, int prev_cap, OutRec *out_all, int cap,
-                                                       int32_t *counts, FmiCounters *ct, int reads_per_wave) {
-    __shared__ int wave_next[4];
-    extern __shared__ uint32_t lq_all[];                     // LDSQ: ((stride + 7) / 8) x 256 dwords
-    uint32_t *const lq = lq_all + threadIdx.x;
-    const int wave_in_block = threadIdx.x >> 6;
-    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t pstride = (int64_t)gridDim.x * blockDim.x;
-    const int64_t wave_first = (tid >> 6) * reads_per_wave;
-    const int wave_end = (int)(wave_first + reads_per_wave < nbatch ? wave_first + reads_per_wave : nbatch);
-    if ((threadIdx.x & 63) == 0) wave_next[wave_in_block] = (int)(wave_first < nbatch ? wave_first : nbatch);
-    __syncthreads();
-    PrevRec *const prevp = prev + tid;                       // entry e of this lane at prevp[e * pstride]
+__global__ __launch_bounds__(64) void fmi_seed_kernel(FmiIdx ix, const uint8_t *__restrict__ enc, int32_t stride,
+                                                      const int32_t *__restrict__ len_arr, int64_t first, int32_t nbatch,
+                                                      int min_seed_len, PrevRec *prev, int prev_cap, OutRec *out_all, int cap,
+                                                      int32_t *counts, FmiCounters *ct, int lds_entries) {
+    // dynamic LDS (LDSQ only): [ (stride + 7) / 8 words of read codes ][ lds_entries x 16-byte list entries ]  x 64 lanes
+    extern __shared__ uint4 lds_all[];
+    const int lane = threadIdx.x;
+    uint32_t *const lq = reinterpret_cast<uint32_t *>(lds_all) + lane;
+    uint4 *const lp = lds_all + ((stride + 7) / 8 * 64 + 3) / 4 + lane;        // entry slot e at lp[e * 64]
+    const int C = LDSQ ? lds_entries : 0;
+    const int64_t tid = (int64_t)blockIdx.x * 64 + lane;
+    const int64_t pstride = (int64_t)gridDim.x * 64;
+    PrevRec *const prevp = prev + tid;                       // overflow entry e of this lane at prevp[e * pstride]
     const int split_len = (int)(min_seed_len * 1.5 + .499);
     const int msl = min_seed_len + 1;
 
@@ -133,7 +134,7 @@ __global__ __launch_bounds__(256) void fmi_seed_kernel(FmiIdx ix, const uint8_t 
     int state = ST_NEW_READ;
     const uint8_t *q = enc; OutRec *out = out_all;
     int t = 0, len = 0, pass = 1, x = 0, next_x = 0, j = 0, a = 0;
-    int nprev = 0, ncur = 0, p = 0, base = 0, curr_s = -1, n1 = 0, jrec = 0, nout = 0;
+    int nprev = 0, ncur = 0, p = 0, curr_s = -1, n1 = 0, jrec = 0, nout = 0;
     bool first_phase = true;
     uint32_t cur_m = 0;
     int64_t min_intv = 1, sm_k = 0, sm_l = 0, sm_s = 0;
@@ -141,30 +142,81 @@ __global__ __launch_bounds__(256) void fmi_seed_kernel(FmiIdx ix, const uint8_t 
     PrevRec s0; s0.n = s0.k = s0.l = s0.s = 0;
 
     auto base_at = [&](int pos) -> int {
-        if (LDSQ) return (int)((lq[(pos >> 3) * 256] >> ((pos & 7) * 4)) & 15u);
+        if (LDSQ) return (int)((lq[(pos >> 3) * 64] >> ((pos & 7) * 4)) & 15u);
         return (int)q[pos];
     };
-    PrevRec head; head.n = head.k = head.l = head.s = 0;     // entry 0 of the list the backward phase reads next
-    PrevRec nxt = head;                                      // entry p + 1, fetched while entry p is being extended
+    // The interval lists of one seeding position (FMI_search.cpp:531-650: prev[] / curr[]) as ONE virtual array per lane:
+    // the forward loop stacks its entries downward from the top, so reading them upward gives "longest match first"
+    // without the reference's reversal, and the survivors of a backward column are written upward from entry 0 (never
+    // ahead of the read position).  The first `C` entries of either end live in LDS as 16-byte packed records
+    // (k, l, s < 2^40, n < 256); only a position with more than C forward entries spills to the global scratch.
+    bool rev = true, spill = false;
+    auto lds_put = [&](int slot, const PrevRec &r) {
+        uint4 w;
+        w.x = (uint32_t)r.k; w.y = (uint32_t)r.l; w.z = (uint32_t)r.s;
+        w.w = ((uint32_t)(r.k >> 32) & 0xffu) | ((uint32_t)(r.l >> 32) & 0xffu) << 8 | ((uint32_t)(r.s >> 32) & 0xffu) << 16 |
+              (uint32_t)r.n << 24;
+        lp[slot * 64] = w;
+    };
+    auto lds_get = [&](int slot) -> PrevRec {
+        const uint4 w = lp[slot * 64];
+        PrevRec r;
+        r.k = (int64_t)((uint64_t)(w.w & 0xffu) << 32 | w.x); r.l = (int64_t)((uint64_t)((w.w >> 8) & 0xffu) << 32 | w.y);
+        r.s = (int64_t)((uint64_t)((w.w >> 16) & 0xffu) << 32 | w.z); r.n = (int64_t)(w.w >> 24);
+        return r;
+    };
+    auto fwd_put = [&](int i, const PrevRec &r) { if (i < C) lds_put(C - 1 - i, r); else prevp[(int64_t)(prev_cap - 1 - i) * pstride] = r; };
+    auto fwd_get = [&](int i) -> PrevRec { return i < C ? lds_get(C - 1 - i) : prevp[(int64_t)(prev_cap - 1 - i) * pstride]; };
+    auto sur_put = [&](int w, const PrevRec &r) { if (!spill && w < C) lds_put(w, r); else prevp[(int64_t)w * pstride] = r; };
+    auto sur_get = [&](int w) -> PrevRec { return (!spill && w < C) ? lds_get(w) : prevp[(int64_t)w * pstride]; };
     auto emit = [&](uint32_t m, uint32_t n, int64_t k, int64_t l, int64_t s) {
         if (nout < cap) { OutRec o; o.m = m; o.n = n; o.k = k; o.l = l; o.s = s; out[nout] = o; }
         nout++;
     };
     auto push_fwd = [&]() {                                  // forward list, newest entry lowest: read back = longest first
         PrevRec r; r.n = sm_n; r.k = sm_k; r.l = sm_l; r.s = sm_s;
-        prevp[(int64_t)(prev_cap - 1 - nprev) * pstride] = r; nprev++;
-        head = r;
+        fwd_put(nprev, r); nprev++;
     };
 
+    // One wave step = one pass over the blocks below, ordered along the transitions of the three passes so that a
+    // lane normally reaches its next extension in this same pass (a lane that takes a backward edge -- end of a
+    // forward walk, an N base -- just sits out this step's extension).  Each block runs once per step for the lanes
+    // in that state instead of once per sub-transition.
     while (state != ST_DONE) {
         bool need = false;
         int64_t K = 0, L = 0, S = 0; int A = 0;
-        // ---- A: advance until an extension is needed
-        while (!need && state != ST_DONE) {
-            switch (state) {
-            case ST_NEW_READ: {
-                const int idx = atomicAdd(&wave_next[wave_in_block], 1);
-                if (idx >= wave_end) { state = ST_DONE; break; }
+        if (state == ST_FWD_END) {
+            if (sm_s >= min_intv) push_fwd();
+            rev = true; spill = nprev > C;                   // first backward column reads the forward stack
+            cur_m = (uint32_t)x; j = x - 1;
+            state = ST_BWD_COL;
+        }
+        if (state == ST_BWD_COL) {                           // backward loop :589-650
+            state = ST_BWD_END;
+            if (j >= 0) {
+                a = base_at(j);
+                if (a <= 3) { ncur = 0; curr_s = -1; first_phase = true; p = 0; state = nprev > 0 ? ST_BWD_ENT : ST_BWD_END; }
+            }
+        }
+        if (state == ST_BWD_END) {
+            if (nprev != 0) {
+                const PrevRec r0 = rev ? fwd_get(nprev - 1) : sur_get(0);
+                if ((int)((int64_t)r0.n - (int64_t)cur_m + 1) >= min_seed_len) emit(cur_m, (uint32_t)r0.n, r0.k, r0.l, r0.s);
+            }
+            state = ST_POS_DONE;
+        }
+        if (state == ST_POS_DONE) {
+            if (pass == 1) { x = next_x; state = ST_P1_NEXT; } else state = ST_P2_NEXT;
+        }
+        if (state == ST_READ_DONE) {
+            counts[t] = nout;
+            tot += (unsigned long long)nout; mx = nout > mx ? nout : mx;
+            state = ST_NEW_READ;
+        }
+        if (state == ST_NEW_READ) {
+            const int idx = atomicAdd(&ct->next_read, 1);    // every lane of the grid pulls from one queue
+            if (idx >= nbatch) state = ST_DONE;
+            else {
                 t = idx;
                 const int64_t r = first + t;
                 q = enc + r * (int64_t)stride; len = len_arr[r];
@@ -183,85 +235,46 @@ __global__ __launch_bounds__(256) void fmi_seed_kernel(FmiIdx ix, const uint8_t 
                             const uint32_t x0 = (lo >> (8 * b)) & 0xffu, x1 = (hi >> (8 * b)) & 0xffu;
                             pk |= (x0 > 3u ? 4u : x0) << (4 * b) | (x1 > 3u ? 4u : x1) << (16 + 4 * b);
                         }
-                        lq[w * 256] = pk;
+                        lq[w * 64] = pk;
                         d0 = d2;
                     }
                 }
                 pass = 1; x = 0; min_intv = 1;
                 state = ST_P1_NEXT;
-                break;
             }
-            case ST_P1_NEXT:                                 // getSMEMsAllPosOneThread loop, FMI_search.cpp:672-724
-                if (x < len) state = ST_START_POS;
-                else { pass = 2; n1 = nout; jrec = 0; state = ST_P2_NEXT; }
-                break;
-            case ST_START_POS: {                             // getSMEMsOnePosOneThread :496-530
-                next_x = x + 1;
-                a = base_at(x);
-                if (a >= 4) { state = ST_POS_DONE; break; }
+        }
+        if (state == ST_P1_NEXT) {                           // getSMEMsAllPosOneThread loop, FMI_search.cpp:672-724
+            if (x < len) state = ST_START_POS;
+            else { pass = 2; n1 = nout; jrec = 0; state = ST_P2_NEXT; }
+        }
+        if (state == ST_P2_NEXT) {                           // re-seeding, fmi.cpp:300-324
+            bool started = false;
+            if (n1 <= cap) {
+                while (jrec < n1) {
+                    const OutRec o = out[jrec++];
+                    const int start = (int)o.m, end = (int)o.n + 1;
+                    if (end - start < split_len || o.s > 10) continue;
+                    x = (end + start) >> 1; min_intv = o.s + 1;
+                    started = true;
+                    break;
+                }
+            }
+            if (started) state = ST_START_POS;
+            else { pass = 3; x = 0; state = ST_P3_START; }
+        }
+        if (state == ST_START_POS) {                         // getSMEMsOnePosOneThread :496-530
+            next_x = x + 1;
+            a = base_at(x);
+            if (a >= 4) state = ST_POS_DONE;                 // (next step)
+            else {
                 sm_n = x; sm_k = ix.count[a]; sm_l = ix.count[3 - a]; sm_s = ix.count[a + 1] - ix.count[a];
                 nprev = 0; j = x + 1;
                 state = ST_FWD_STEP;
-                break;
             }
-            case ST_FWD_STEP:                                // forward loop :531-575
-                if (j >= len) { state = ST_FWD_END; break; }
-                a = base_at(j);
-                next_x = j + 1;
-                if (a >= 4) { state = ST_FWD_END; break; }
-                K = sm_l; L = sm_k; S = sm_s; A = 3 - a; need = true;
-                break;
-            case ST_FWD_END:
-                if (sm_s >= min_intv) push_fwd();
-                base = prev_cap - nprev;                     // reversed list = entries base .. base + nprev - 1
-                cur_m = (uint32_t)x; j = x - 1;
-                state = ST_BWD_COL;
-                break;
-            case ST_BWD_COL:                                 // backward loop :589-650
-                if (j < 0) { state = ST_BWD_END; break; }
-                a = base_at(j);
-                if (a > 3) { state = ST_BWD_END; break; }
-                ncur = 0; curr_s = -1; first_phase = true; p = 0;
-                state = ST_BWD_ENT;
-                break;
-            case ST_BWD_ENT:
-                if (p >= nprev) {
-                    nprev = ncur; base = 0;
-                    if (ncur == 0) state = ST_BWD_END;
-                    else { cur_m = (uint32_t)j; j--; state = ST_BWD_COL; }
-                    break;
-                }
-                s0 = p == 0 ? head : nxt;
-                K = s0.k; L = s0.l; S = s0.s; A = a; need = true;
-                break;
-            case ST_BWD_END:
-                if (nprev != 0) {
-                    const PrevRec r0 = head;
-                    if ((int)((int64_t)r0.n - (int64_t)cur_m + 1) >= min_seed_len) emit(cur_m, (uint32_t)r0.n, r0.k, r0.l, r0.s);
-                }
-                state = ST_POS_DONE;
-                break;
-            case ST_POS_DONE:
-                if (pass == 1) { x = next_x; state = ST_P1_NEXT; } else state = ST_P2_NEXT;
-                break;
-            case ST_P2_NEXT: {                               // re-seeding, fmi.cpp:300-324
-                bool started = false;
-                if (n1 <= cap) {
-                    while (jrec < n1) {
-                        const OutRec o = out[jrec++];
-                        const int start = (int)o.m, end = (int)o.n + 1;
-                        if (end - start < split_len || o.s > 10) continue;
-                        x = (end + start) >> 1; min_intv = o.s + 1;
-                        started = true;
-                        break;
-                    }
-                }
-                if (started) state = ST_START_POS;
-                else { pass = 3; x = 0; state = ST_P3_START; }
-                break;
-            }
-            case ST_P3_START:                                // bwtSeedStrategyAllPosOneThread :726-812
-                if (x >= len) { state = ST_READ_DONE; break; }
+        }
+        if (state == ST_P3_START) {                          // bwtSeedStrategyAllPosOneThread :726-812
+            if (x >= len) state = ST_READ_DONE;              // (next step)
+            else {
                 next_x = x + 1;
                 a = base_at(x);
                 if (a < 4) {
@@ -269,31 +282,33 @@ __global__ __launch_bounds__(256) void fmi_seed_kernel(FmiIdx ix, const uint8_t 
                     j = x + 1;
                     state = ST_P3_STEP;
                 } else x = next_x;
-                break;
-            case ST_P3_STEP:
-                if (j >= len) { x = next_x; state = ST_P3_START; break; }
-                next_x = j + 1;
-                a = base_at(j);
-                if (a >= 4) { x = next_x; state = ST_P3_START; break; }
-                K = sm_l; L = sm_k; S = sm_s; A = 3 - a; need = true;
-                break;
-            case ST_READ_DONE:
-                counts[t] = nout;
-                tot += (unsigned long long)nout; mx = nout > mx ? nout : mx;
-                state = ST_NEW_READ;
-                break;
-            default: break;
             }
         }
-        if (!need) continue;                                 // ST_DONE: leaves the loop
-        // ---- B: the extension
+        if (state == ST_FWD_STEP) {                          // forward loop :531-575
+            if (j >= len) state = ST_FWD_END;
+            else {
+                a = base_at(j);
+                next_x = j + 1;
+                if (a >= 4) state = ST_FWD_END;
+                else { K = sm_l; L = sm_k; S = sm_s; A = 3 - a; need = true; }
+            }
+        } else if (state == ST_BWD_ENT) {
+            s0 = rev ? fwd_get(nprev - 1 - p) : sur_get(p);
+            K = s0.k; L = s0.l; S = s0.s; A = a; need = true;
+        } else if (state == ST_P3_STEP) {
+            if (j >= len) { x = next_x; state = ST_P3_START; }
+            else {
+                next_x = j + 1;
+                a = base_at(j);
+                if (a >= 4) { x = next_x; state = ST_P3_START; }
+                else { K = sm_l; L = sm_k; S = sm_s; A = 3 - a; need = true; }
+            }
+        }
+        if (!need) continue;
+        // ---- the extension: the only place the index is read
         int64_t ko, lo, so;
-        const bool fetch_next = state == ST_BWD_ENT && p + 1 < nprev;
-        PrevRec pre = nxt;
-        if (fetch_next) pre = prevp[(int64_t)(base + p + 1) * pstride];      // in flight together with the index records
         backward_ext(ix, K, L, S, A, ko, lo, so, calls, recs);
-        nxt = pre;
-        // ---- C: consume
+        // ---- consume
         if (state == ST_FWD_STEP) {                          // forward: result is (l, k, s) of the reverse strand
             if (so != sm_s) push_fwd();
             if (so < min_intv) { next_x = j; state = ST_FWD_END; }
@@ -309,11 +324,15 @@ __global__ __launch_bounds__(256) void fmi_seed_kernel(FmiIdx ix, const uint8_t 
             if (keep) {
                 curr_s = (int)so;                            // int, as in the reference
                 PrevRec nw; nw.n = s0.n; nw.k = ko; nw.l = lo; nw.s = so;
-                prevp[(int64_t)ncur * pstride] = nw;
-                if (ncur == 0) head = nw;                    // the old head was consumed at p == 0
+                sur_put(ncur, nw);
                 ncur++;
             }
             p++;
+            if (p >= nprev) {                                // column done
+                nprev = ncur; rev = false;
+                if (ncur == 0) state = ST_BWD_END;
+                else { cur_m = (uint32_t)j; j--; state = ST_BWD_COL; }
+            }
         } else {                                             // ST_P3_STEP
             sm_k = lo; sm_l = ko; sm_s = so; sm_n = j;
             if (sm_s < 20 && sm_n - x + 1 >= msl) {
@@ -327,7 +346,7 @@ __global__ __launch_bounds__(256) void fmi_seed_kernel(FmiIdx ix, const uint8_t 
         calls += __shfl_xor(calls, o); tot += __shfl_xor(tot, o); recs += __shfl_xor(recs, o);
         const int v = __shfl_xor(mx, o); mx = v > mx ? v : mx;
     }
-    if ((threadIdx.x & 63) == 0) {
+    if (lane == 0) {
         if (calls) atomicAdd(&ct->ext_calls, calls);
         if (recs) atomicAdd(&ct->rec_reads, recs);
         if (tot) atomicAdd(&ct->total, tot);
@@ -547,18 +566,33 @@ extern "C" int gab_fmi_seed_device(gab_fmi *h, const uint8_t *d_enc, int32_t str
     if (nreads == 0) { GAB_HIP(hipMemsetAsync(h->roff.p, 0, 8, s)); return GAB_OK; }
     GAB_CHECK(d_enc && d_len, "gab_fmi_seed_device: NULL buffer");
 
-    // A wave owns a chunk of `rpw` reads and its lanes take them one after another; the forward-interval list
-    // (prev) is per LANE (stride entries x 32 B), the output slot per READ (cap x 32 B).
+    // The seeding kernel is a persistent grid of one-wave blocks sized to the occupancy; lanes pull reads from a
+    // counter.  Scratch: a spill area for interval lists longer than the LDS part (stride entries x 32 B per LANE,
+    // touched only by the rare long list) and the output slot per READ (cap x 32 B).
     int cap = 48;
-    static const int rpw = [] { const char *e = getenv("GAB_FMI_RPW"); const int v = e ? atoi(e) : 0; return v >= 64 ? v : 256; }();
+    static const int lds_entries_env = [] { const char *e = getenv("GAB_FMI_LDS_ENTRIES"); return e ? atoi(e) : 0; }();
+    const bool ldsq = stride <= kLdsQMax;
+    const int lds_entries = ldsq ? (lds_entries_env > 0 ? lds_entries_env : 16) : 0;
+    const size_t lds_bytes = ldsq ? (((size_t)(stride + 7) / 8 * 64 + 3) / 4 + (size_t)lds_entries * 64) * 16 : 0;
+    int waves_per_cu = 0, n_cu = 0;
+    {
+        hipDeviceProp_t prop;
+        GAB_HIP(hipGetDeviceProperties(&prop, h->device));
+        n_cu = prop.multiProcessorCount;
+        if (ldsq) {
+            GAB_HIP(hipFuncSetAttribute((const void *)fmi_seed_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            GAB_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&waves_per_cu, fmi_seed_kernel<true>, 64, lds_bytes));
+        } else GAB_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&waves_per_cu, fmi_seed_kernel<false>, 64, 0));
+        GAB_CHECK(waves_per_cu > 0, "gab_fmi_seed_device: the seeding kernel does not fit a CU (stride %d)", stride);
+    }
+    const int64_t grid_waves = (int64_t)n_cu * waves_per_cu;
     int64_t B = (int64_t)std::min<size_t>((size_t)nreads, std::max<size_t>(1024, h->scratch_budget / (64 * sizeof(OutRec))));
-    B = std::min<int64_t>(B, 1 << 21);
-    const int64_t max_waves = gab_ceil_div(B, rpw), max_blocks = gab_ceil_div(max_waves, 4);
+    B = std::min<int64_t>(B, 1 << 22);
     const int64_t nb_blocks = gab_ceil_div(B, 256);
     const size_t o_counts = 256, o_bs = o_counts + 4 * (size_t)B + 64;
     rc = h->ws.reserve(o_bs + 8 * (size_t)nb_blocks + 64);
     if (rc) return rc;
-    rc = h->prev.reserve(sizeof(PrevRec) * (size_t)stride * (size_t)max_blocks * 256);
+    rc = h->prev.reserve(sizeof(PrevRec) * (size_t)stride * (size_t)grid_waves * 64);
     if (rc) return rc;
     char *wb = h->ws.as<char>();
     FmiCounters *d_ct = (FmiCounters *)wb;
@@ -591,17 +625,17 @@ extern "C" int gab_fmi_seed_device(gab_fmi *h, const uint8_t *d_enc, int32_t str
         for (;;) {                                        // at most two rounds: second with the exact slot size
             rc = h->slots.reserve(sizeof(OutRec) * (size_t)cap * (size_t)nb);
             if (rc) return rc;
-            h->h_ct->ext_calls = 0; h->h_ct->rec_reads = 0; h->h_ct->total = 0; h->h_ct->max_per_read = 0;
+            h->h_ct->ext_calls = 0; h->h_ct->rec_reads = 0; h->h_ct->total = 0; h->h_ct->max_per_read = 0; h->h_ct->next_read = 0;
             GAB_HIP(hipMemcpyAsync(d_ct, h->h_ct, sizeof(FmiCounters), hipMemcpyHostToDevice, s));
             GAB_HIP(hipEventRecord(h->ev[0], s));
-            const int seed_blocks = (int)gab_ceil_div(gab_ceil_div((int64_t)nb, rpw), 4);
-            if (stride <= kLdsQMax)
-                hipLaunchKernelGGL(fmi_seed_kernel<true>, dim3(seed_blocks), dim3(256), (size_t)((stride + 7) / 8) * 256 * 4, s, h->ix,
-                                   d_enc, stride, d_len, first, nb, min_seed_len, h->prev.as<PrevRec>(), (int)stride,
-                                   h->slots.as<OutRec>(), cap, d_counts, d_ct, rpw);
+            const int seed_blocks = (int)std::min<int64_t>(grid_waves, gab_ceil_div((int64_t)nb, 64));
+            if (ldsq)
+                hipLaunchKernelGGL(fmi_seed_kernel<true>, dim3(seed_blocks), dim3(64), lds_bytes, s, h->ix, d_enc, stride, d_len, first,
+                                   nb, min_seed_len, h->prev.as<PrevRec>(), (int)stride, h->slots.as<OutRec>(), cap, d_counts, d_ct,
+                                   lds_entries);
             else
-                hipLaunchKernelGGL(fmi_seed_kernel<false>, dim3(seed_blocks), dim3(256), 0, s, h->ix, d_enc, stride, d_len, first, nb,
-                                   min_seed_len, h->prev.as<PrevRec>(), (int)stride, h->slots.as<OutRec>(), cap, d_counts, d_ct, rpw);
+                hipLaunchKernelGGL(fmi_seed_kernel<false>, dim3(seed_blocks), dim3(64), 0, s, h->ix, d_enc, stride, d_len, first, nb,
+                                   min_seed_len, h->prev.as<PrevRec>(), (int)stride, h->slots.as<OutRec>(), cap, d_counts, d_ct, 0);
             hipLaunchKernelGGL(fmi_sort_slots, dim3(blocks), dim3(256), 0, s, h->slots.as<OutRec>(), cap, d_counts, nb);
             GAB_HIP(hipGetLastError());
             GAB_HIP(hipEventRecord(h->ev[1], s));
