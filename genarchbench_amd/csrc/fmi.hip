@@ -54,6 +54,8 @@ struct FmiCounters {
     int32_t max_per_read;
     int32_t bad, first_bad;
     int32_t next_read;             // work queue of the seeding kernel
+    unsigned long long wave_steps; // sum over waves of the steps of their longest-running lane (GAB_FMI_DEBUG)
+    unsigned long long positions, spills, list_sum;   // seeding positions, those whose list outgrew LDS, sum of list lengths
 };
 
 __device__ __forceinline__ void load_rec(const CpOcc *p, int64_t (&cnt)[4], uint64_t (&bits)[4]) {
@@ -115,7 +117,7 @@ template <bool LDSQ>
 __global__ __launch_bounds__(64) void fmi_seed_kernel(FmiIdx ix, const uint8_t *__restrict__ enc, int32_t stride,
                                                       const int32_t *__restrict__ len_arr, int64_t first, int32_t nbatch,
                                                       int min_seed_len, PrevRec *prev, int prev_cap, OutRec *out_all, int cap,
-                                                      int32_t *counts, FmiCounters *ct, int lds_entries) {
+                                                      int32_t *counts, FmiCounters *ct, int lds_entries, int64_t enc_bytes) {
     // dynamic LDS (LDSQ only): [ (stride + 7) / 8 words of read codes ][ lds_entries x 16-byte list entries ]  x 64 lanes
     extern __shared__ uint4 lds_all[];
     const int lane = threadIdx.x;
@@ -145,12 +147,16 @@ __global__ __launch_bounds__(64) void fmi_seed_kernel(FmiIdx ix, const uint8_t *
         if (LDSQ) return (int)((lq[(pos >> 3) * 64] >> ((pos & 7) * 4)) & 15u);
         return (int)q[pos];
     };
-    // The interval lists of one seeding position (FMI_search.cpp:531-650: prev[] / curr[]) as ONE virtual array per lane:
-    // the forward loop stacks its entries downward from the top, so reading them upward gives "longest match first"
-    // without the reference's reversal, and the survivors of a backward column are written upward from entry 0 (never
-    // ahead of the read position).  The first `C` entries of either end live in LDS as 16-byte packed records
-    // (k, l, s < 2^40, n < 256); only a position with more than C forward entries spills to the global scratch.
-    bool rev = true, spill = false;
+    // The interval lists of one seeding position (FMI_search.cpp:531-650: prev[] / curr[]).  Backward columns address
+    // the list by v = 0, 1, ... (0 = longest match = the NEWEST forward entry), which makes the reference's reversal
+    // implicit.  The C most recent forward entries sit in an LDS ring (16-byte packed records: k, l, s < 2^40, n < 256);
+    // entry v of the list is ring slot (Rslot - v) mod C, and a survivor written as entry w <= v reuses the slot of an
+    // entry that has already been read.  Whatever does not fit (forward entries older than the newest C, survivors
+    // beyond C) goes to the lane's global scratch: forward entries stacked down from the top, survivors up from 0, so
+    // the two never meet.  Global entries are fetched one step ahead, together with the index records.
+    bool rev = true;
+    int fslot = 0, Rslot = 0, nfwd = 0, nxt_for = -1;
+    PrevRec nxt; nxt.n = nxt.k = nxt.l = nxt.s = 0;
     auto lds_put = [&](int slot, const PrevRec &r) {
         uint4 w;
         w.x = (uint32_t)r.k; w.y = (uint32_t)r.l; w.z = (uint32_t)r.s;
@@ -165,29 +171,47 @@ __global__ __launch_bounds__(64) void fmi_seed_kernel(FmiIdx ix, const uint8_t *
         r.s = (int64_t)((uint64_t)((w.w >> 16) & 0xffu) << 32 | w.z); r.n = (int64_t)(w.w >> 24);
         return r;
     };
-    auto fwd_put = [&](int i, const PrevRec &r) { if (i < C) lds_put(C - 1 - i, r); else prevp[(int64_t)(prev_cap - 1 - i) * pstride] = r; };
-    auto fwd_get = [&](int i) -> PrevRec { return i < C ? lds_get(C - 1 - i) : prevp[(int64_t)(prev_cap - 1 - i) * pstride]; };
-    auto sur_put = [&](int w, const PrevRec &r) { if (!spill && w < C) lds_put(w, r); else prevp[(int64_t)w * pstride] = r; };
-    auto sur_get = [&](int w) -> PrevRec { return (!spill && w < C) ? lds_get(w) : prevp[(int64_t)w * pstride]; };
+    auto g_fwd = [&](int i) -> PrevRec * { return prevp + (int64_t)(prev_cap - 1 - i) * pstride; };   // forward entry i, spilled
+    auto list_slot = [&](int v) -> int { const int s = Rslot - v; return s < 0 ? s + C : s; };
+    auto list_get_g = [&](int v) -> PrevRec { return rev ? *g_fwd(nfwd - 1 - v) : prevp[(int64_t)v * pstride]; };
+    auto list_put = [&](int w, const PrevRec &r) { if (w < C) lds_put(list_slot(w), r); else prevp[(int64_t)w * pstride] = r; };
+    // Re-seeding candidates (fmi.cpp:300-324) are noted when pass 1 emits them: 12 bits each (midpoint, s + 1) in a
+    // register queue, so pass 2 does not re-read the output slot; more than kP2Max candidates (or a read longer than
+    // 255) fall back to scanning the slot.
+    constexpr int kP2Max = 10;
+    uint64_t p2q0 = 0, p2q1 = 0; int p2n = 0;
     auto emit = [&](uint32_t m, uint32_t n, int64_t k, int64_t l, int64_t s) {
         if (nout < cap) { OutRec o; o.m = m; o.n = n; o.k = k; o.l = l; o.s = s; out[nout] = o; }
         nout++;
+        if (LDSQ && pass == 1 && (int)(n + 1 - m) >= split_len && s <= 10) {
+            const uint64_t e = (uint64_t)((n + 1 + m) >> 1) | (uint64_t)(s + 1) << 8;
+            if (p2n < 5) p2q0 |= e << (12 * p2n); else if (p2n < kP2Max) p2q1 |= e << (12 * (p2n - 5));
+            p2n++;
+        }
     };
     auto push_fwd = [&]() {                                  // forward list, newest entry lowest: read back = longest first
         PrevRec r; r.n = sm_n; r.k = sm_k; r.l = sm_l; r.s = sm_s;
-        fwd_put(nprev, r); nprev++;
+        if (C > 0) {
+            if (nprev >= C) *g_fwd(nprev - C) = lds_get(fslot);        // the oldest resident entry makes room
+            lds_put(fslot, r); Rslot = fslot; fslot = fslot + 1 == C ? 0 : fslot + 1;
+        } else *g_fwd(nprev) = r;
+        nprev++;
     };
 
     // One wave step = one pass over the blocks below, ordered along the transitions of the three passes so that a
     // lane normally reaches its next extension in this same pass (a lane that takes a backward edge -- end of a
     // forward walk, an N base -- just sits out this step's extension).  Each block runs once per step for the lanes
     // in that state instead of once per sub-transition.
+    unsigned long long steps = 0;
+    unsigned dbg_pos = 0, dbg_spill = 0, dbg_list = 0;
     while (state != ST_DONE) {
+        steps++;
         bool need = false;
         int64_t K = 0, L = 0, S = 0; int A = 0;
         if (state == ST_FWD_END) {
             if (sm_s >= min_intv) push_fwd();
-            rev = true; spill = nprev > C;                   // first backward column reads the forward stack
+            rev = true; nfwd = nprev;                        // first backward column reads the forward entries
+            dbg_pos++; dbg_spill += nprev > C ? 1 : 0; dbg_list += (unsigned)nprev;
             cur_m = (uint32_t)x; j = x - 1;
             state = ST_BWD_COL;
         }
@@ -195,12 +219,12 @@ __global__ __launch_bounds__(64) void fmi_seed_kernel(FmiIdx ix, const uint8_t *
             state = ST_BWD_END;
             if (j >= 0) {
                 a = base_at(j);
-                if (a <= 3) { ncur = 0; curr_s = -1; first_phase = true; p = 0; state = nprev > 0 ? ST_BWD_ENT : ST_BWD_END; }
+                if (a <= 3) { ncur = 0; curr_s = -1; first_phase = true; p = 0; nxt_for = -1; state = nprev > 0 ? ST_BWD_ENT : ST_BWD_END; }
             }
         }
         if (state == ST_BWD_END) {
             if (nprev != 0) {
-                const PrevRec r0 = rev ? fwd_get(nprev - 1) : sur_get(0);
+                const PrevRec r0 = C > 0 ? lds_get(Rslot) : list_get_g(0);
                 if ((int)((int64_t)r0.n - (int64_t)cur_m + 1) >= min_seed_len) emit(cur_m, (uint32_t)r0.n, r0.k, r0.l, r0.s);
             }
             state = ST_POS_DONE;
@@ -213,21 +237,40 @@ __global__ __launch_bounds__(64) void fmi_seed_kernel(FmiIdx ix, const uint8_t *
             tot += (unsigned long long)nout; mx = nout > mx ? nout : mx;
             state = ST_NEW_READ;
         }
-        if (state == ST_NEW_READ) {
-            const int idx = atomicAdd(&ct->next_read, 1);    // every lane of the grid pulls from one queue
-            if (idx >= nbatch) state = ST_DONE;
-            else {
+        if (__any(state == ST_NEW_READ)) {                   // wave-uniform: the whole wave helps the lanes that start a read
+            const bool want = state == ST_NEW_READ;
+            const uint64_t wm = __ballot(want);
+            const int leader = __builtin_ctzll(wm);
+            int idx0 = 0;
+            if (lane == leader) idx0 = atomicAdd(&ct->next_read, __builtin_popcountll(wm));   // one queue for the whole grid
+            idx0 = __shfl(idx0, leader);
+            const int idx = idx0 + __builtin_popcountll(wm & ((1ull << lane) - 1ull));
+            const bool got = want && idx < nbatch;
+            if (want && !got) state = ST_DONE;
+            if (got) {
                 t = idx;
                 const int64_t r = first + t;
                 q = enc + r * (int64_t)stride; len = len_arr[r];
                 out = out_all + (int64_t)t * cap; nout = 0;
-                if (LDSQ) {                                  // aligned dwords around the read -> 8 codes per LDS word
-                    const int mis = (int)((uintptr_t)q & 3);
-                    const uint32_t *qa = reinterpret_cast<const uint32_t *>(q - mis);
-                    const int last = (mis + len - 1) >> 2;   // last dword that overlaps the read
-                    uint32_t d0 = len > 0 ? qa[0] : 0u;
-                    for (int w = 0; w * 8 < len; w++) {
-                        const uint32_t d1 = 2 * w + 1 <= last ? qa[2 * w + 1] : 0u, d2 = 2 * w + 2 <= last ? qa[2 * w + 2] : 0u;
+                pass = 1; x = 0; min_intv = 1; p2q0 = 0; p2q1 = 0; p2n = 0;
+                state = ST_P1_NEXT;
+            }
+            if (LDSQ) {
+                // read codes -> LDS column of the owning lane: lane w of the wave fetches the three aligned dwords around
+                // bases 8w .. 8w+7 (coalesced), packs them to eight 4-bit codes and stores word w of that column
+                uint64_t gm = __ballot(got);
+                while (gm) {
+                    const int src = __builtin_ctzll(gm);
+                    gm &= gm - 1;
+                    const int64_t rr = first + __shfl(t, src);
+                    const uint8_t *qq = enc + rr * (int64_t)stride;
+                    const int mis = (int)((uintptr_t)qq & 3);
+                    const uint32_t *qa = reinterpret_cast<const uint32_t *>(qq - mis);
+                    const int64_t o0 = (qq - mis - enc) + 8 * (int64_t)lane;      // byte offset of this lane's first dword
+                    if (lane * 8 < stride) {
+                        // an aligned dword that starts inside the buffer never crosses a page: safe to read whole
+                        const uint32_t d0 = o0 < enc_bytes ? qa[2 * lane] : 0u, d1 = o0 + 4 < enc_bytes ? qa[2 * lane + 1] : 0u;
+                        const uint32_t d2 = o0 + 8 < enc_bytes ? qa[2 * lane + 2] : 0u;
                         const uint32_t lo = __builtin_amdgcn_alignbyte(d1, d0, mis), hi = __builtin_amdgcn_alignbyte(d2, d1, mis);
                         uint32_t pk = 0;
 #pragma unroll
@@ -235,12 +278,9 @@ __global__ __launch_bounds__(64) void fmi_seed_kernel(FmiIdx ix, const uint8_t *
                             const uint32_t x0 = (lo >> (8 * b)) & 0xffu, x1 = (hi >> (8 * b)) & 0xffu;
                             pk |= (x0 > 3u ? 4u : x0) << (4 * b) | (x1 > 3u ? 4u : x1) << (16 + 4 * b);
                         }
-                        lq[w * 64] = pk;
-                        d0 = d2;
+                        reinterpret_cast<uint32_t *>(lds_all)[lane * 64 + src] = pk;
                     }
                 }
-                pass = 1; x = 0; min_intv = 1;
-                state = ST_P1_NEXT;
             }
         }
         if (state == ST_P1_NEXT) {                           // getSMEMsAllPosOneThread loop, FMI_search.cpp:672-724
@@ -250,13 +290,22 @@ __global__ __launch_bounds__(64) void fmi_seed_kernel(FmiIdx ix, const uint8_t *
         if (state == ST_P2_NEXT) {                           // re-seeding, fmi.cpp:300-324
             bool started = false;
             if (n1 <= cap) {
-                while (jrec < n1) {
-                    const OutRec o = out[jrec++];
-                    const int start = (int)o.m, end = (int)o.n + 1;
-                    if (end - start < split_len || o.s > 10) continue;
-                    x = (end + start) >> 1; min_intv = o.s + 1;
-                    started = true;
-                    break;
+                if (LDSQ && p2n <= kP2Max) {                 // candidates noted by emit(), in emission order
+                    if (jrec < p2n) {
+                        const uint32_t e = (uint32_t)((jrec < 5 ? p2q0 >> (12 * jrec) : p2q1 >> (12 * (jrec - 5))) & 0xfffu);
+                        jrec++;
+                        x = (int)(e & 0xffu); min_intv = (int64_t)(e >> 8);
+                        started = true;
+                    }
+                } else {
+                    while (jrec < n1) {
+                        const OutRec o = out[jrec++];
+                        const int start = (int)o.m, end = (int)o.n + 1;
+                        if (end - start < split_len || o.s > 10) continue;
+                        x = (end + start) >> 1; min_intv = o.s + 1;
+                        started = true;
+                        break;
+                    }
                 }
             }
             if (started) state = ST_START_POS;
@@ -268,7 +317,7 @@ __global__ __launch_bounds__(64) void fmi_seed_kernel(FmiIdx ix, const uint8_t *
             if (a >= 4) state = ST_POS_DONE;                 // (next step)
             else {
                 sm_n = x; sm_k = ix.count[a]; sm_l = ix.count[3 - a]; sm_s = ix.count[a + 1] - ix.count[a];
-                nprev = 0; j = x + 1;
+                nprev = 0; fslot = 0; j = x + 1;
                 state = ST_FWD_STEP;
             }
         }
@@ -293,7 +342,7 @@ __global__ __launch_bounds__(64) void fmi_seed_kernel(FmiIdx ix, const uint8_t *
                 else { K = sm_l; L = sm_k; S = sm_s; A = 3 - a; need = true; }
             }
         } else if (state == ST_BWD_ENT) {
-            s0 = rev ? fwd_get(nprev - 1 - p) : sur_get(p);
+            s0 = p < C ? lds_get(list_slot(p)) : nxt_for == p ? nxt : list_get_g(p);
             K = s0.k; L = s0.l; S = s0.s; A = a; need = true;
         } else if (state == ST_P3_STEP) {
             if (j >= len) { x = next_x; state = ST_P3_START; }
@@ -307,7 +356,11 @@ __global__ __launch_bounds__(64) void fmi_seed_kernel(FmiIdx ix, const uint8_t *
         if (!need) continue;
         // ---- the extension: the only place the index is read
         int64_t ko, lo, so;
+        const bool fetch_next = state == ST_BWD_ENT && p + 1 < nprev && p + 1 >= C;
+        PrevRec pre = nxt;
+        if (fetch_next) { pre = list_get_g(p + 1); nxt_for = p + 1; }        // in flight together with the index records
         backward_ext(ix, K, L, S, A, ko, lo, so, calls, recs);
+        nxt = pre;
         // ---- consume
         if (state == ST_FWD_STEP) {                          // forward: result is (l, k, s) of the reverse strand
             if (so != sm_s) push_fwd();
@@ -324,7 +377,7 @@ __global__ __launch_bounds__(64) void fmi_seed_kernel(FmiIdx ix, const uint8_t *
             if (keep) {
                 curr_s = (int)so;                            // int, as in the reference
                 PrevRec nw; nw.n = s0.n; nw.k = ko; nw.l = lo; nw.s = so;
-                sur_put(ncur, nw);
+                list_put(ncur, nw);
                 ncur++;
             }
             p++;
@@ -345,8 +398,12 @@ __global__ __launch_bounds__(64) void fmi_seed_kernel(FmiIdx ix, const uint8_t *
     for (int o = 32; o > 0; o >>= 1) {
         calls += __shfl_xor(calls, o); tot += __shfl_xor(tot, o); recs += __shfl_xor(recs, o);
         const int v = __shfl_xor(mx, o); mx = v > mx ? v : mx;
+        const unsigned long long sv = __shfl_xor(steps, o); steps = sv > steps ? sv : steps;
     }
+    atomicAdd(&ct->positions, (unsigned long long)dbg_pos); atomicAdd(&ct->spills, (unsigned long long)dbg_spill);
+    atomicAdd(&ct->list_sum, (unsigned long long)dbg_list);
     if (lane == 0) {
+        atomicAdd(&ct->wave_steps, steps);
         if (calls) atomicAdd(&ct->ext_calls, calls);
         if (recs) atomicAdd(&ct->rec_reads, recs);
         if (tot) atomicAdd(&ct->total, tot);
@@ -572,7 +629,7 @@ extern "C" int gab_fmi_seed_device(gab_fmi *h, const uint8_t *d_enc, int32_t str
     int cap = 48;
     static const int lds_entries_env = [] { const char *e = getenv("GAB_FMI_LDS_ENTRIES"); return e ? atoi(e) : 0; }();
     const bool ldsq = stride <= kLdsQMax;
-    const int lds_entries = ldsq ? (lds_entries_env > 0 ? lds_entries_env : 16) : 0;
+    const int lds_entries = ldsq ? (lds_entries_env > 0 ? lds_entries_env : 12) : 0;
     const size_t lds_bytes = ldsq ? (((size_t)(stride + 7) / 8 * 64 + 3) / 4 + (size_t)lds_entries * 64) * 16 : 0;
     int waves_per_cu = 0, n_cu = 0;
     {
@@ -588,6 +645,7 @@ extern "C" int gab_fmi_seed_device(gab_fmi *h, const uint8_t *d_enc, int32_t str
     const int64_t grid_waves = (int64_t)n_cu * waves_per_cu;
     int64_t B = (int64_t)std::min<size_t>((size_t)nreads, std::max<size_t>(1024, h->scratch_budget / (64 * sizeof(OutRec))));
     B = std::min<int64_t>(B, 1 << 22);
+    B = gab_ceil_div(nreads, gab_ceil_div(nreads, B));       // equal batches: no short last one
     const int64_t nb_blocks = gab_ceil_div(B, 256);
     const size_t o_counts = 256, o_bs = o_counts + 4 * (size_t)B + 64;
     rc = h->ws.reserve(o_bs + 8 * (size_t)nb_blocks + 64);
@@ -622,20 +680,23 @@ extern "C" int gab_fmi_seed_device(gab_fmi *h, const uint8_t *d_enc, int32_t str
     for (int64_t first = 0; first < nreads; first += B) {
         const int32_t nb = (int32_t)std::min<int64_t>(B, nreads - first);
         const int blocks = (int)gab_ceil_div(nb, 256);
+        int seed_blocks_dbg = 0;
         for (;;) {                                        // at most two rounds: second with the exact slot size
             rc = h->slots.reserve(sizeof(OutRec) * (size_t)cap * (size_t)nb);
             if (rc) return rc;
-            h->h_ct->ext_calls = 0; h->h_ct->rec_reads = 0; h->h_ct->total = 0; h->h_ct->max_per_read = 0; h->h_ct->next_read = 0;
+            h->h_ct->ext_calls = 0; h->h_ct->rec_reads = 0; h->h_ct->total = 0; h->h_ct->max_per_read = 0; h->h_ct->next_read = 0; h->h_ct->wave_steps = 0; h->h_ct->positions = h->h_ct->spills = h->h_ct->list_sum = 0;
             GAB_HIP(hipMemcpyAsync(d_ct, h->h_ct, sizeof(FmiCounters), hipMemcpyHostToDevice, s));
             GAB_HIP(hipEventRecord(h->ev[0], s));
             const int seed_blocks = (int)std::min<int64_t>(grid_waves, gab_ceil_div((int64_t)nb, 64));
+            seed_blocks_dbg = seed_blocks;
             if (ldsq)
                 hipLaunchKernelGGL(fmi_seed_kernel<true>, dim3(seed_blocks), dim3(64), lds_bytes, s, h->ix, d_enc, stride, d_len, first,
                                    nb, min_seed_len, h->prev.as<PrevRec>(), (int)stride, h->slots.as<OutRec>(), cap, d_counts, d_ct,
-                                   lds_entries);
+                                   lds_entries, (int64_t)nreads * stride);
             else
                 hipLaunchKernelGGL(fmi_seed_kernel<false>, dim3(seed_blocks), dim3(64), 0, s, h->ix, d_enc, stride, d_len, first, nb,
-                                   min_seed_len, h->prev.as<PrevRec>(), (int)stride, h->slots.as<OutRec>(), cap, d_counts, d_ct, 0);
+                                   min_seed_len, h->prev.as<PrevRec>(), (int)stride, h->slots.as<OutRec>(), cap, d_counts, d_ct, 0,
+                                   (int64_t)nreads * stride);
             hipLaunchKernelGGL(fmi_sort_slots, dim3(blocks), dim3(256), 0, s, h->slots.as<OutRec>(), cap, d_counts, nb);
             GAB_HIP(hipGetLastError());
             GAB_HIP(hipEventRecord(h->ev[1], s));
@@ -648,6 +709,11 @@ extern "C" int gab_fmi_seed_device(gab_fmi *h, const uint8_t *d_enc, int32_t str
         GAB_HIP(hipEventElapsedTime(&ms, h->ev[0], h->ev[1]));
         kms += ms;
         ext_total += h->h_ct->ext_calls; rec_total += h->h_ct->rec_reads;
+        if (getenv("GAB_FMI_DEBUG"))
+            fprintf(stderr, "[gab_fmi] batch of %d reads: %d waves (%d per CU), %.3f ms, %llu extensions, %llu wave steps -> %.1f extensions per step; %llu positions, %llu spilled, mean list %.2f\n",
+                    nb, seed_blocks_dbg, waves_per_cu, ms, h->h_ct->ext_calls, h->h_ct->wave_steps,
+                    (double)h->h_ct->ext_calls / (double)(h->h_ct->wave_steps ? h->h_ct->wave_steps : 1), h->h_ct->positions,
+                    h->h_ct->spills, (double)h->h_ct->list_sum / (double)(h->h_ct->positions ? h->h_ct->positions : 1));
         const int64_t add = (int64_t)h->h_ct->total;
         if ((size_t)(total + add) > out_cap) {
             // grow, keeping what earlier batches wrote
