@@ -42,6 +42,8 @@ struct FmiIdx {
     int64_t count[5];          // already +1 (FMI_search.cpp:433-436)
     int64_t sentinel;
     int64_t ref_seq_len;
+    const uint4 *kmer_tab;     // bi-intervals of every pattern of 1 .. kmer_depth bases (packed like the LDS entries)
+    int kmer_depth;
 };
 
 struct PrevRec { int64_t n, k, l, s; };                    // 32 bytes, [entry][lane]
@@ -50,6 +52,7 @@ struct OutRec { uint32_t m, n; int64_t k, l, s; };         // 32 bytes, per-read
 struct FmiCounters {
     unsigned long long ext_calls;
     unsigned long long rec_reads;  // distinct 64-byte CP_OCC records fetched (1 or 2 per extension)
+    unsigned long long tab_reads;  // extensions answered by the short-pattern table
     unsigned long long total;      // SMEMs found in this batch
     int32_t max_per_read;
     int32_t bad, first_bad;
@@ -94,6 +97,79 @@ __device__ __forceinline__ void backward_ext(const FmiIdx &ix, int64_t k, int64_
     so = a == 0 ? ss[0] : a == 1 ? ss[1] : a == 2 ? ss[2] : ss[3];
     lo = a == 0 ? l0 : a == 1 ? l1 : a == 2 ? l2 : l3;
 }
+// ---- short-pattern table -------------------------------------------------------------------------------------
+// The bi-interval (k, l, s) of a pattern is a function of the pattern alone, however the search reached it, so the
+// result of any extension whose RESULT is at most `kmer_depth` bases long can be read from a table indexed by the
+// pattern instead of being computed from two CP_OCC records.  Depth 8 = 87 380 entries x 16 B = 1.4 MB: it stays in
+// every XCD's L2, whereas the CP_OCC records of those shallow intervals (the widest ones: two records each) are
+// spread over the whole index and miss.  About a third of all extensions produce such short patterns.
+// Entry of pattern b0 b1 .. b(len-1): index (4^len - 4) / 3 + sum b_i << 2i; values with s == 0 are stored as zeros
+// (an empty interval only ever propagates s == 0, FMI_search.cpp:1040-1051).
+__device__ __forceinline__ uint32_t kmer_level_off(int len) { return (0x55555555u & ((1u << (2 * len)) - 1u)) - 1u; }
+__device__ __forceinline__ uint4 pack_iv(int64_t k, int64_t l, int64_t s, uint32_t n) {
+    uint4 w;
+    w.x = (uint32_t)k; w.y = (uint32_t)l; w.z = (uint32_t)s;
+    w.w = ((uint32_t)(k >> 32) & 0xffu) | ((uint32_t)(l >> 32) & 0xffu) << 8 | ((uint32_t)(s >> 32) & 0xffu) << 16 | n << 24;
+    return w;
+}
+__global__ __launch_bounds__(256) void fmi_build_kmer_level(FmiIdx ix, uint4 *tab, int len) {
+    const uint32_t c = blockIdx.x * 256u + threadIdx.x;
+    if (c >= (1u << (2 * len))) return;
+    int64_t k = 0, l = 0, s = 0;
+    if (len == 1) { const int a = (int)c; k = ix.count[a]; l = ix.count[3 - a]; s = ix.count[a + 1] - ix.count[a]; }
+    else {
+        const uint4 w = tab[kmer_level_off(len - 1) + (c >> 2)];          // the pattern without its first base
+        const int64_t pk = (int64_t)((uint64_t)(w.w & 0xffu) << 32 | w.x), pl = (int64_t)((uint64_t)((w.w >> 8) & 0xffu) << 32 | w.y);
+        const int64_t ps = (int64_t)((uint64_t)((w.w >> 16) & 0xffu) << 32 | w.z);
+        if (ps > 0) { unsigned long long c0 = 0, c1 = 0; backward_ext(ix, pk, pl, ps, (int)(c & 3u), k, l, s, c0, c1); }
+    }
+    if (s <= 0) k = l = s = 0;
+    tab[kmer_level_off(len) + c] = pack_iv(k, l, s, 0);
+}
+// One extension for the seeding kernel: either backwardExt on the index or, for `tlen` > 0, the table entry `tidx`.
+// Both kinds fetch through the same loads (a table entry is a quarter of a 64-byte line), so a wave with lanes of
+// both kinds still waits for memory once.
+__device__ __forceinline__ void extend(const FmiIdx &ix, int64_t k, int64_t l, int64_t s, int a, bool use_tab, uint32_t tidx,
+                                       bool tab_swap, int64_t &ko, int64_t &lo, int64_t &so, uint32_t &calls, uint32_t &recs,
+                                       uint32_t &tabs) {
+    const int64_t sp = k, ep = k + s;
+    int64_t c_sp[4], c_ep[4]; uint64_t b_sp[4], b_ep[4];
+    const CpOcc *r_sp = ix.cp_occ + (sp >> 6), *r_ep = ix.cp_occ + (ep >> 6);
+    if (use_tab) r_sp = r_ep = reinterpret_cast<const CpOcc *>(ix.kmer_tab) + (tidx >> 2);
+    load_rec(r_sp, c_sp, b_sp);
+    if (r_sp == r_ep) {
+#pragma unroll
+        for (int b = 0; b < 4; b++) { c_ep[b] = c_sp[b]; b_ep[b] = b_sp[b]; }
+    } else load_rec(r_ep, c_ep, b_ep);
+    if (use_tab) {
+        tabs++;
+        const uint32_t e = tidx & 3u;
+        const uint64_t lo64 = e == 0 ? (uint64_t)c_sp[0] : e == 1 ? (uint64_t)c_sp[2] : e == 2 ? b_sp[0] : b_sp[2];
+        const uint64_t hi64 = e == 0 ? (uint64_t)c_sp[1] : e == 1 ? (uint64_t)c_sp[3] : e == 2 ? b_sp[1] : b_sp[3];
+        const uint32_t wx = (uint32_t)lo64, wy = (uint32_t)(lo64 >> 32), wz = (uint32_t)hi64, ww = (uint32_t)(hi64 >> 32);
+        const int64_t tk = (int64_t)((uint64_t)(ww & 0xffu) << 32 | wx), tl = (int64_t)((uint64_t)((ww >> 8) & 0xffu) << 32 | wy);
+        so = (int64_t)((uint64_t)((ww >> 16) & 0xffu) << 32 | wz);
+        ko = tab_swap ? tl : tk; lo = tab_swap ? tk : tl;
+        return;
+    }
+    calls++;
+    recs += r_sp == r_ep ? 1u : 2u;
+    const int y_sp = (int)(sp & 63), y_ep = (int)(ep & 63);
+    const uint64_t m_sp = y_sp ? ~0ull << (64 - y_sp) : 0ull, m_ep = y_ep ? ~0ull << (64 - y_ep) : 0ull;
+    int64_t kk[4], ss[4];
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+        const int64_t o_sp = c_sp[b] + __popcll(b_sp[b] & m_sp);
+        const int64_t o_ep = c_ep[b] + __popcll(b_ep[b] & m_ep);
+        kk[b] = ix.count[b] + o_sp;
+        ss[b] = o_ep - o_sp;
+    }
+    const int64_t sent = (k <= ix.sentinel && k + s > ix.sentinel) ? 1 : 0;
+    const int64_t l3 = l + sent, l2 = l3 + ss[3], l1 = l2 + ss[2], l0 = l1 + ss[1];
+    ko = a == 0 ? kk[0] : a == 1 ? kk[1] : a == 2 ? kk[2] : kk[3];
+    so = a == 0 ? ss[0] : a == 1 ? ss[1] : a == 2 ? ss[2] : ss[3];
+    lo = a == 0 ? l0 : a == 1 ? l1 : a == 2 ? l2 : l3;
+}
 // ---- the seeding kernel: one lane = one read at a time, as a state machine ------------------------------------
 // A straight transcription (one lane runs the three passes as nested loops) leaves ~13 % of the lanes active
 // (PMC, profiles/r01_fmi_pmc.md): neighbouring reads sit in different loops, so every look-up site executes with a
@@ -107,7 +183,7 @@ __device__ __forceinline__ void backward_ext(const FmiIdx &ix, int64_t k, int64_
 // index look-up (the global-memory lists of the first version cost as many L2 misses as the look-ups).
 enum FmiState : int {
     ST_NEW_READ, ST_P1_NEXT, ST_START_POS, ST_FWD_STEP, ST_FWD_END, ST_BWD_COL, ST_BWD_ENT, ST_BWD_END, ST_POS_DONE,
-    ST_P2_NEXT, ST_P3_START, ST_P3_STEP, ST_READ_DONE, ST_DONE
+    ST_P2_NEXT, ST_P3_START, ST_P3_STEP, ST_P3_JUMP, ST_READ_DONE, ST_DONE
 };
 
 // LDSQ: the lane's current read sits in LDS as 4-bit codes ([word of 8 bases][lane], conflict-free), so stepping
@@ -130,7 +206,9 @@ __global__ __launch_bounds__(64) void fmi_seed_kernel(FmiIdx ix, const uint8_t *
     const int split_len = (int)(min_seed_len * 1.5 + .499);
     const int msl = min_seed_len + 1;
 
-    unsigned long long calls = 0, recs = 0, tot = 0;
+    unsigned long long tot = 0;
+    uint32_t calls = 0, recs = 0, tabs = 0;                  // per lane and launch: far below 2^32
+    const int D = LDSQ ? ix.kmer_depth : 0;
     int mx = 0;
     // ---- per-lane state
     int state = ST_NEW_READ;
@@ -146,6 +224,17 @@ __global__ __launch_bounds__(64) void fmi_seed_kernel(FmiIdx ix, const uint8_t *
     auto base_at = [&](int pos) -> int {
         if (LDSQ) return (int)((lq[(pos >> 3) * 64] >> ((pos & 7) * 4)) & 15u);
         return (int)q[pos];
+    };
+    // eight read codes from `start` on, as 4-bit nibbles (first base lowest); LDSQ only
+    auto nibbles_at = [&](int start) -> uint32_t {
+        const uint32_t w0 = lq[(start >> 3) * 64], w1 = lq[((start >> 3) + 1) * 64];   // w1 may be past the read: masked by callers
+        return (uint32_t)(((uint64_t)w1 << 32 | w0) >> ((start & 7) * 4));
+    };
+    // table index of the pattern of `plen` <= 8 bases starting at `start` (all of them A/C/G/T)
+    auto kmer_index = [&](int start, int plen) -> uint32_t {
+        uint32_t v = nibbles_at(start) & 0x33333333u;
+        v = (v | v >> 2) & 0x0f0f0f0fu; v = (v | v >> 4) & 0x00ff00ffu; v = (v | v >> 8) & 0xffffu;
+        return kmer_level_off(plen) + (v & ((1u << (2 * plen)) - 1u));
     };
     // The interval lists of one seeding position (FMI_search.cpp:531-650: prev[] / curr[]).  Backward columns address
     // the list by v = 0, 1, ... (0 = longest match = the NEWEST forward entry), which makes the reference's reversal
@@ -208,6 +297,7 @@ __global__ __launch_bounds__(64) void fmi_seed_kernel(FmiIdx ix, const uint8_t *
         steps++;
         bool need = false;
         int64_t K = 0, L = 0, S = 0; int A = 0;
+        int tstart = 0, tlen = 0;                            // pattern the extension produces, if short enough for the table
         if (state == ST_FWD_END) {
             if (sm_s >= min_intv) push_fwd();
             rev = true; nfwd = nprev;                        // first backward column reads the forward entries
@@ -330,6 +420,10 @@ __global__ __launch_bounds__(64) void fmi_seed_kernel(FmiIdx ix, const uint8_t *
                     sm_n = x; sm_k = ix.count[a]; sm_l = ix.count[3 - a]; sm_s = ix.count[a + 1] - ix.count[a];
                     j = x + 1;
                     state = ST_P3_STEP;
+                    // the first D - 1 steps of the walk cannot emit (D < minSeedLen + 1) and only stop at an N or the
+                    // read end: with D clean bases ahead their outcome is the table entry of q[x .. x+D-1]
+                    if (D > 1 && D < msl && x + D <= len && (nibbles_at(x) & 0x44444444u & (0xffffffffu >> (32 - 4 * D))) == 0u)
+                        state = ST_P3_JUMP;
                 } else x = next_x;
             }
         }
@@ -339,18 +433,27 @@ __global__ __launch_bounds__(64) void fmi_seed_kernel(FmiIdx ix, const uint8_t *
                 a = base_at(j);
                 next_x = j + 1;
                 if (a >= 4) state = ST_FWD_END;
-                else { K = sm_l; L = sm_k; S = sm_s; A = 3 - a; need = true; }
+                else {
+                    K = sm_l; L = sm_k; S = sm_s; A = 3 - a; need = true;
+                    if (j - x < D) { tstart = x; tlen = j - x + 1; }
+                }
             }
         } else if (state == ST_BWD_ENT) {
             s0 = p < C ? lds_get(list_slot(p)) : nxt_for == p ? nxt : list_get_g(p);
             K = s0.k; L = s0.l; S = s0.s; A = a; need = true;
+            if ((int)s0.n - j < D) { tstart = j; tlen = (int)s0.n - j + 1; }
+        } else if (state == ST_P3_JUMP) {
+            tstart = x; tlen = D; need = true;
         } else if (state == ST_P3_STEP) {
             if (j >= len) { x = next_x; state = ST_P3_START; }
             else {
                 next_x = j + 1;
                 a = base_at(j);
                 if (a >= 4) { x = next_x; state = ST_P3_START; }
-                else { K = sm_l; L = sm_k; S = sm_s; A = 3 - a; need = true; }
+                else {
+                    K = sm_l; L = sm_k; S = sm_s; A = 3 - a; need = true;
+                    if (j - x < D) { tstart = x; tlen = j - x + 1; }
+                }
             }
         }
         if (!need) continue;
@@ -359,7 +462,9 @@ __global__ __launch_bounds__(64) void fmi_seed_kernel(FmiIdx ix, const uint8_t *
         const bool fetch_next = state == ST_BWD_ENT && p + 1 < nprev && p + 1 >= C;
         PrevRec pre = nxt;
         if (fetch_next) { pre = list_get_g(p + 1); nxt_for = p + 1; }        // in flight together with the index records
-        backward_ext(ix, K, L, S, A, ko, lo, so, calls, recs);
+        const bool use_tab = tlen > 0;
+        const uint32_t tidx = use_tab ? kmer_index(tstart, tlen) : 0u;
+        extend(ix, K, L, S, A, use_tab, tidx, state != ST_BWD_ENT, ko, lo, so, calls, recs, tabs);
         nxt = pre;
         // ---- consume
         if (state == ST_FWD_STEP) {                          // forward: result is (l, k, s) of the reverse strand
@@ -386,6 +491,11 @@ __global__ __launch_bounds__(64) void fmi_seed_kernel(FmiIdx ix, const uint8_t *
                 if (ncur == 0) state = ST_BWD_END;
                 else { cur_m = (uint32_t)j; j--; state = ST_BWD_COL; }
             }
+        } else if (state == ST_P3_JUMP) {                    // D bases in one go
+            sm_k = lo; sm_l = ko; sm_s = so; sm_n = x + D - 1;
+            tabs += (uint32_t)(D - 2);                       // the look-up stands for D - 1 extensions of the reference
+            j = x + D; next_x = x + D;
+            state = ST_P3_STEP;
         } else {                                             // ST_P3_STEP
             sm_k = lo; sm_l = ko; sm_s = so; sm_n = j;
             if (sm_s < 20 && sm_n - x + 1 >= msl) {
@@ -395,8 +505,9 @@ __global__ __launch_bounds__(64) void fmi_seed_kernel(FmiIdx ix, const uint8_t *
         }
     }
     // statistics: one atomic per wave
+    unsigned long long c64 = calls, r64 = recs, t64 = tabs;
     for (int o = 32; o > 0; o >>= 1) {
-        calls += __shfl_xor(calls, o); tot += __shfl_xor(tot, o); recs += __shfl_xor(recs, o);
+        c64 += __shfl_xor(c64, o); tot += __shfl_xor(tot, o); r64 += __shfl_xor(r64, o); t64 += __shfl_xor(t64, o);
         const int v = __shfl_xor(mx, o); mx = v > mx ? v : mx;
         const unsigned long long sv = __shfl_xor(steps, o); steps = sv > steps ? sv : steps;
     }
@@ -404,8 +515,9 @@ __global__ __launch_bounds__(64) void fmi_seed_kernel(FmiIdx ix, const uint8_t *
     atomicAdd(&ct->list_sum, (unsigned long long)dbg_list);
     if (lane == 0) {
         atomicAdd(&ct->wave_steps, steps);
-        if (calls) atomicAdd(&ct->ext_calls, calls);
-        if (recs) atomicAdd(&ct->rec_reads, recs);
+        if (c64) atomicAdd(&ct->ext_calls, c64);
+        if (r64) atomicAdd(&ct->rec_reads, r64);
+        if (t64) atomicAdd(&ct->tab_reads, t64);
         if (tot) atomicAdd(&ct->total, tot);
         if (mx) atomicMax(&ct->max_per_read, mx);
     }
@@ -512,6 +624,7 @@ struct gab_fmi {
     int device = 0;
     FmiIdx ix;
     gab_devbuf index;       // CP_OCC array
+    gab_devbuf kmer;        // short-pattern table
     gab_devbuf ws;          // counters, counts, block sums
     gab_devbuf prev;        // prev[] scratch
     gab_devbuf slots;       // per-read output slots
@@ -560,6 +673,25 @@ extern "C" int gab_fmi_create(int device, int64_t ref_seq_len, const int64_t cou
     for (int i = 0; i < 5; i++) h->ix.count[i] = count_file[i] + 1;     // FMI_search.cpp:433-436
     h->ix.sentinel = sentinel_index;
     h->ix.ref_seq_len = ref_seq_len;
+    h->ix.kmer_tab = nullptr; h->ix.kmer_depth = 0;
+    {   // short-pattern table, level by level (each level extends the previous one by one base to the left)
+        const char *e = getenv("GAB_FMI_KMER_DEPTH");
+        const int depth = e ? std::max(0, std::min(8, atoi(e))) : 8;
+        if (depth > 0) {
+            const size_t entries = ((((size_t)1 << (2 * (depth + 1))) - 4) / 3 + 3) & ~(size_t)3;
+            rc = h->kmer.reserve(entries * sizeof(uint4));
+            if (rc) { gab_fmi_destroy(h); return rc; }
+            if (hipMemset(h->kmer.p, 0, entries * sizeof(uint4)) != hipSuccess) { gab_set_error("gab_fmi_create: memset failed"); gab_fmi_destroy(h); return GAB_EDEVICE; }
+            for (int len = 1; len <= depth; len++) {
+                const unsigned n = 1u << (2 * len);
+                hipLaunchKernelGGL(fmi_build_kmer_level, dim3((n + 255) / 256), dim3(256), 0, nullptr, h->ix, h->kmer.as<uint4>(), len);
+            }
+            if (hipDeviceSynchronize() != hipSuccess || hipGetLastError() != hipSuccess) {
+                gab_set_error("gab_fmi_create: building the short-pattern table failed"); gab_fmi_destroy(h); return GAB_EDEVICE;
+            }
+            h->ix.kmer_tab = h->kmer.as<uint4>(); h->ix.kmer_depth = depth;
+        }
+    }
     *out = h;
     return GAB_OK;
 }
@@ -596,7 +728,7 @@ extern "C" int gab_fmi_load(int device, const char *prefix, gab_fmi **out) {
 extern "C" void gab_fmi_destroy(gab_fmi *h) {
     if (!h) return;
     gab_device_guard g(h->device);
-    h->index.release(); h->ws.release(); h->prev.release(); h->slots.release(); h->out.release(); h->roff.release();
+    h->index.release(); h->kmer.release(); h->ws.release(); h->prev.release(); h->slots.release(); h->out.release(); h->roff.release();
     h->io.release();
     for (int k = 0; k < 2; k++) if (h->ev[k]) (void)hipEventDestroy(h->ev[k]);
     if (h->h_ct) (void)hipHostFree(h->h_ct);
@@ -684,7 +816,7 @@ extern "C" int gab_fmi_seed_device(gab_fmi *h, const uint8_t *d_enc, int32_t str
         for (;;) {                                        // at most two rounds: second with the exact slot size
             rc = h->slots.reserve(sizeof(OutRec) * (size_t)cap * (size_t)nb);
             if (rc) return rc;
-            h->h_ct->ext_calls = 0; h->h_ct->rec_reads = 0; h->h_ct->total = 0; h->h_ct->max_per_read = 0; h->h_ct->next_read = 0; h->h_ct->wave_steps = 0; h->h_ct->positions = h->h_ct->spills = h->h_ct->list_sum = 0;
+            h->h_ct->ext_calls = 0; h->h_ct->rec_reads = 0; h->h_ct->tab_reads = 0; h->h_ct->total = 0; h->h_ct->max_per_read = 0; h->h_ct->next_read = 0; h->h_ct->wave_steps = 0; h->h_ct->positions = h->h_ct->spills = h->h_ct->list_sum = 0;
             GAB_HIP(hipMemcpyAsync(d_ct, h->h_ct, sizeof(FmiCounters), hipMemcpyHostToDevice, s));
             GAB_HIP(hipEventRecord(h->ev[0], s));
             const int seed_blocks = (int)std::min<int64_t>(grid_waves, gab_ceil_div((int64_t)nb, 64));
@@ -708,11 +840,11 @@ extern "C" int gab_fmi_seed_device(gab_fmi *h, const uint8_t *d_enc, int32_t str
         float ms = 0;
         GAB_HIP(hipEventElapsedTime(&ms, h->ev[0], h->ev[1]));
         kms += ms;
-        ext_total += h->h_ct->ext_calls; rec_total += h->h_ct->rec_reads;
+        ext_total += h->h_ct->ext_calls + h->h_ct->tab_reads; rec_total += h->h_ct->rec_reads;
         if (getenv("GAB_FMI_DEBUG"))
-            fprintf(stderr, "[gab_fmi] batch of %d reads: %d waves (%d per CU), %.3f ms, %llu extensions, %llu wave steps -> %.1f extensions per step; %llu positions, %llu spilled, mean list %.2f\n",
-                    nb, seed_blocks_dbg, waves_per_cu, ms, h->h_ct->ext_calls, h->h_ct->wave_steps,
-                    (double)h->h_ct->ext_calls / (double)(h->h_ct->wave_steps ? h->h_ct->wave_steps : 1), h->h_ct->positions,
+            fprintf(stderr, "[gab_fmi] batch of %d reads: %d waves (%d per CU), %.3f ms, %llu index extensions + %llu table look-ups, %llu wave steps -> %.1f extensions per step; %llu positions, %llu spilled, mean list %.2f\n",
+                    nb, seed_blocks_dbg, waves_per_cu, ms, h->h_ct->ext_calls, h->h_ct->tab_reads, h->h_ct->wave_steps,
+                    (double)(h->h_ct->ext_calls + h->h_ct->tab_reads) / (double)(h->h_ct->wave_steps ? h->h_ct->wave_steps : 1), h->h_ct->positions,
                     h->h_ct->spills, (double)h->h_ct->list_sum / (double)(h->h_ct->positions ? h->h_ct->positions : 1));
         const int64_t add = (int64_t)h->h_ct->total;
         if ((size_t)(total + add) > out_cap) {
