@@ -530,7 +530,9 @@ class FmiWorkload:
         ach = alg / (k * 1e-3) / 1e9
         return {"bound": "hbm", "achieved": round(ach, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(ach / HBM_PEAK_GBS, 6), "traffic": None,
-                "note": "random 64-B CP_OCC records (1 or 2 per backwardExt, counted by the kernel); index >> 256 MiB Infinity Cache"}
+                "note": "random 64-B CP_OCC records (counted by the kernel; extensions answered by the L2-resident short-pattern "
+                        "table fetch none); measured chip ceiling for random 64-B reads is 55 G rec/s = 3.5 TB/s "
+                        "(profiles/r01_random_read_ceiling.md)"}
 
     def cpu_baseline(self, cores):
         import ctypes as C

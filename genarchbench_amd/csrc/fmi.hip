@@ -193,7 +193,7 @@ template <bool LDSQ>
 __global__ __launch_bounds__(64) void fmi_seed_kernel(FmiIdx ix, const uint8_t *__restrict__ enc, int32_t stride,
                                                       const int32_t *__restrict__ len_arr, int64_t first, int32_t nbatch,
                                                       int min_seed_len, PrevRec *prev, int prev_cap, OutRec *out_all, int cap,
-                                                      int32_t *counts, FmiCounters *ct, int lds_entries, int64_t enc_bytes) {
+                                                      int32_t *counts, FmiCounters *ct, int lds_entries, int64_t enc_bytes, int passes) {
     // dynamic LDS (LDSQ only): [ (stride + 7) / 8 words of read codes ][ lds_entries x 16-byte list entries ]  x 64 lanes
     extern __shared__ uint4 lds_all[];
     const int lane = threadIdx.x;
@@ -214,7 +214,7 @@ __global__ __launch_bounds__(64) void fmi_seed_kernel(FmiIdx ix, const uint8_t *
     int state = ST_NEW_READ;
     const uint8_t *q = enc; OutRec *out = out_all;
     int t = 0, len = 0, pass = 1, x = 0, next_x = 0, j = 0, a = 0;
-    int nprev = 0, ncur = 0, p = 0, curr_s = -1, n1 = 0, jrec = 0, nout = 0;
+    int nprev = 0, ncur = 0, p = 0, curr_s = -1, n1 = 0, jrec = 0, nout = 0, nout0 = 0;
     bool first_phase = true;
     uint32_t cur_m = 0;
     int64_t min_intv = 1, sm_k = 0, sm_l = 0, sm_s = 0;
@@ -324,7 +324,7 @@ __global__ __launch_bounds__(64) void fmi_seed_kernel(FmiIdx ix, const uint8_t *
         }
         if (state == ST_READ_DONE) {
             counts[t] = nout;
-            tot += (unsigned long long)nout; mx = nout > mx ? nout : mx;
+            tot += (unsigned long long)(nout - nout0); mx = nout > mx ? nout : mx;
             state = ST_NEW_READ;
         }
         if (__any(state == ST_NEW_READ)) {                   // wave-uniform: the whole wave helps the lanes that start a read
@@ -341,9 +341,11 @@ __global__ __launch_bounds__(64) void fmi_seed_kernel(FmiIdx ix, const uint8_t *
                 t = idx;
                 const int64_t r = first + t;
                 q = enc + r * (int64_t)stride; len = len_arr[r];
-                out = out_all + (int64_t)t * cap; nout = 0;
-                pass = 1; x = 0; min_intv = 1; p2q0 = 0; p2q1 = 0; p2n = 0;
-                state = ST_P1_NEXT;
+                out = out_all + (int64_t)t * cap;
+                x = 0; min_intv = 1; p2q0 = 0; p2q1 = 0; p2n = 0;
+                if (passes & 1) { nout = 0; pass = 1; state = ST_P1_NEXT; }
+                else { nout = counts[t]; pass = 3; state = ST_P3_START; }        // appends to what passes 1 and 2 found
+                nout0 = nout;
             }
             if (LDSQ) {
                 // read codes -> LDS column of the owning lane: lane w of the wave fetches the three aligned dwords around
@@ -399,7 +401,8 @@ __global__ __launch_bounds__(64) void fmi_seed_kernel(FmiIdx ix, const uint8_t *
                 }
             }
             if (started) state = ST_START_POS;
-            else { pass = 3; x = 0; state = ST_P3_START; }
+            else if (passes & 2) { pass = 3; x = 0; state = ST_P3_START; }
+            else state = ST_READ_DONE;                       // pass 3 runs as its own launch (next step)
         }
         if (state == ST_START_POS) {                         // getSMEMsOnePosOneThread :496-530
             next_x = x + 1;
@@ -763,7 +766,8 @@ extern "C" int gab_fmi_seed_device(gab_fmi *h, const uint8_t *d_enc, int32_t str
     const bool ldsq = stride <= kLdsQMax;
     const int lds_entries = ldsq ? (lds_entries_env > 0 ? lds_entries_env : 12) : 0;
     const size_t lds_bytes = ldsq ? (((size_t)(stride + 7) / 8 * 64 + 3) / 4 + (size_t)lds_entries * 64) * 16 : 0;
-    int waves_per_cu = 0, n_cu = 0;
+    const size_t lds_bytes_p3 = ldsq ? (((size_t)(stride + 7) / 8 * 64 + 3) / 4 + 64) * 16 : 0;   // read + slack for nibbles_at
+    int waves_per_cu = 0, waves_per_cu_p3 = 0, n_cu = 0;
     {
         hipDeviceProp_t prop;
         GAB_HIP(hipGetDeviceProperties(&prop, h->device));
@@ -771,10 +775,11 @@ extern "C" int gab_fmi_seed_device(gab_fmi *h, const uint8_t *d_enc, int32_t str
         if (ldsq) {
             GAB_HIP(hipFuncSetAttribute((const void *)fmi_seed_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             GAB_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&waves_per_cu, fmi_seed_kernel<true>, 64, lds_bytes));
+            GAB_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&waves_per_cu_p3, fmi_seed_kernel<true>, 64, lds_bytes_p3));
         } else GAB_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&waves_per_cu, fmi_seed_kernel<false>, 64, 0));
         GAB_CHECK(waves_per_cu > 0, "gab_fmi_seed_device: the seeding kernel does not fit a CU (stride %d)", stride);
     }
-    const int64_t grid_waves = (int64_t)n_cu * waves_per_cu;
+    const int64_t grid_waves = (int64_t)n_cu * std::max(waves_per_cu, waves_per_cu_p3);
     int64_t B = (int64_t)std::min<size_t>((size_t)nreads, std::max<size_t>(1024, h->scratch_budget / (64 * sizeof(OutRec))));
     B = std::min<int64_t>(B, 1 << 22);
     B = gab_ceil_div(nreads, gab_ceil_div(nreads, B));       // equal batches: no short last one
@@ -819,16 +824,23 @@ extern "C" int gab_fmi_seed_device(gab_fmi *h, const uint8_t *d_enc, int32_t str
             h->h_ct->ext_calls = 0; h->h_ct->rec_reads = 0; h->h_ct->tab_reads = 0; h->h_ct->total = 0; h->h_ct->max_per_read = 0; h->h_ct->next_read = 0; h->h_ct->wave_steps = 0; h->h_ct->positions = h->h_ct->spills = h->h_ct->list_sum = 0;
             GAB_HIP(hipMemcpyAsync(d_ct, h->h_ct, sizeof(FmiCounters), hipMemcpyHostToDevice, s));
             GAB_HIP(hipEventRecord(h->ev[0], s));
-            const int seed_blocks = (int)std::min<int64_t>(grid_waves, gab_ceil_div((int64_t)nb, 64));
+            const int seed_blocks = (int)std::min<int64_t>((int64_t)n_cu * waves_per_cu, gab_ceil_div((int64_t)nb, 64));
             seed_blocks_dbg = seed_blocks;
-            if (ldsq)
+            if (ldsq) {
+                // passes 1 + 2 need the interval lists in LDS, which caps the occupancy; pass 3 needs only the read, so it
+                // runs as a second launch of the same kernel with no list area and twice the waves
                 hipLaunchKernelGGL(fmi_seed_kernel<true>, dim3(seed_blocks), dim3(64), lds_bytes, s, h->ix, d_enc, stride, d_len, first,
                                    nb, min_seed_len, h->prev.as<PrevRec>(), (int)stride, h->slots.as<OutRec>(), cap, d_counts, d_ct,
-                                   lds_entries, (int64_t)nreads * stride);
-            else
+                                   lds_entries, (int64_t)nreads * stride, 1);
+                GAB_HIP(hipMemsetAsync(&d_ct->next_read, 0, sizeof(int32_t), s));
+                const int p3_blocks = (int)std::min<int64_t>((int64_t)n_cu * waves_per_cu_p3, gab_ceil_div((int64_t)nb, 64));
+                hipLaunchKernelGGL(fmi_seed_kernel<true>, dim3(p3_blocks), dim3(64), lds_bytes_p3, s, h->ix, d_enc, stride, d_len, first,
+                                   nb, min_seed_len, h->prev.as<PrevRec>(), (int)stride, h->slots.as<OutRec>(), cap, d_counts, d_ct,
+                                   0, (int64_t)nreads * stride, 2);
+            } else
                 hipLaunchKernelGGL(fmi_seed_kernel<false>, dim3(seed_blocks), dim3(64), 0, s, h->ix, d_enc, stride, d_len, first, nb,
                                    min_seed_len, h->prev.as<PrevRec>(), (int)stride, h->slots.as<OutRec>(), cap, d_counts, d_ct, 0,
-                                   (int64_t)nreads * stride);
+                                   (int64_t)nreads * stride, 3);
             hipLaunchKernelGGL(fmi_sort_slots, dim3(blocks), dim3(256), 0, s, h->slots.as<OutRec>(), cap, d_counts, nb);
             GAB_HIP(hipGetLastError());
             GAB_HIP(hipEventRecord(h->ev[1], s));
