@@ -255,7 +255,7 @@ class FastChainWorkload(ChainWorkload):
     mode = 1
     metric = "fast-chain ROI M seeds/sec"
     dtype = "i32+f32"
-    kernel = "chain_kernel<true>"
+    kernel = "fastchain_kernel"
 
 
 # ------------------------------------------------------------------------------------- bpm
