@@ -12,18 +12,15 @@
 // 64-byte CP_OCC records, one per 64 BWT rows.
 //
 // Mapping.  The reference interleaves reads in lock-step rounds inside a thread to overlap cache
-// misses; every read is nevertheless independent in all three passes.  Here one lane owns one read
-// and runs the three passes back to back; hundreds of thousands of lanes in flight hide the latency
-// of the two dependent 64-byte index reads per extension, which is what bounds the kernel: random
-// 64-B HBM transactions (a 0.5+ GB index does not fit the 256 MiB Infinity Cache).  Both records of
-// an extension are fetched with four 16-byte loads each before either is used; when both interval
-// ends fall into the same record it is fetched once.  The per-read list of forward intervals
-// (prev[]) lives in a global scratch laid out [entry][lane] (coalesced); the SMEMs of a read are
-// collected in a per-read slot, insertion-sorted by the owning lane, and compacted to the final
-// array with a three-kernel exclusive scan, so the output is already in the reference's order.
+// misses; every read is nevertheless independent in all three passes.  Here one lane owns one read at a
+// time and walks the three passes as an explicit state machine (see fmi_seed_kernel), so that the whole
+// wave meets at ONE look-up site per step; reads, interval lists and the re-seeding queue stay in LDS /
+// registers, and extensions that produce a pattern of at most eight bases are answered by an L2-resident
+// table of bi-intervals instead of the index.  What bounds the kernel is the rate of random index
+// look-ups (~55 G line fills/s on MI355X whatever the record size, profiles/r01_random_read_ceiling.md).
 //
-// Roofline: readlen + 40 B per SMEM of streaming traffic + 128 B per extension of random index
-// traffic (the extension count is returned by gab_fmi_last_stats).
+// Roofline: readlen + 40 B per SMEM of streaming traffic + 64 B per CP_OCC record actually fetched
+// (counted by the kernel, gab_fmi_last_records).
 #include "gab_internal.h"
 #include <algorithm>
 #include <new>
