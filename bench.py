@@ -159,7 +159,7 @@ class ChainWorkload:
     default_items = 10_000          # calls per GPU (chain-large: c_elegans 10k calls)
     seed = 5
     ref_exe = "chain_ref"
-    kernel = "chain_kernel<false>"
+    kernel = "chain_hw_kernel"
 
     def __init__(self, items, rank, dev):
         import torch

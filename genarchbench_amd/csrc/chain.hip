@@ -8,25 +8,19 @@
 //                    coordinates, no max_skip, fp32 floor gap cost when the window holds more
 //                    than six predecessors, double otherwise.
 //
-// Mapping.  The scores along i are a true recurrence (score[i] needs score[i-1]), so a call is
-// walked sequentially by ONE workgroup of four waves; the parallelism is (a) the 256 predecessors of
-// a window super-chunk, one per lane, and (b) thousands of independent calls, longest call first.
-// The latency of that sequential walk is the bound, so everything on the i-1 -> i dependence stays
-// on the CU: the last 1024 anchors (x, y, score, parent) live in an LDS ring.  Per anchor i:
-//   * the window start `st` is advanced with one 64-wide compare + ballot against a cached block of
-//     x values instead of the reference's scalar while-loop;
-//   * the window [st, i-1] is swept in descending 256-anchor super-chunks read from the LDS ring
-//     (anchors older than the ring come from global memory with agent-scope loads);
-//   * FASTCHAIN: per-wave DPP max-reduction, the four maxima combined through LDS (one barrier),
-//     ties -> larger j;
-//   * CHAIN: the sequential max_skip logic is reproduced exactly in three parallel steps
-//     (SURVEY.md App. B8): every unfiltered lane first scatters its mark targets[parent[j]] = i
-//     into a 16-bit LDS ring and publishes its chunk maximum (barrier), then reads its own mark and
-//     derives the "sc > max_f" improvement flag from an exclusive prefix-max (DPP scan + the earlier
-//     chunks' maxima) and publishes the ballot masks (barrier); finally every wave walks the masks
-//     of the four chunks in order for the saturating n_skip counter and its > 25 break.  Marks
-//     scattered by lanes past the break point are harmless because a mark value i is only ever
-//     compared with the current i.
+// Mapping.  The scores along i are a true recurrence (score[i] needs score[i-1]) and a batch takes as long as the walk
+// of its slowest call, so everything is arranged around the latency of one anchor step:
+//   * CHAIN (chain_hw_kernel): one main wave per call carries the dependence; the last 512 anchors (x, y, score,
+//     parent, segment id) live in an LDS ring; each lane owns an aligned group of four predecessors, a super-chunk is
+//     256 predecessors.  Two helper waves compute everything that does not depend on earlier results -- window start,
+//     filters, min(dq, dr, q_span) and the gap cost of the 256 newest predecessors -- eight anchors ahead into LDS.
+//     The sequential max_skip logic is reproduced exactly in three parallel steps: unfiltered
+//     items scatter their marks targets[parent[j]] = i into a tagged 16-bit LDS ring (a global array for windows
+//     deeper than the ring), the improvement flags come from an exclusive prefix-max (DPP scan), and the saturating
+//     n_skip counter has a closed form over the prefix sums of (+1 hit, -1 improvement).  Marks scattered by items
+//     past the break point are harmless because a mark value i is only ever compared with the current i.
+//   * FASTCHAIN (fastchain_kernel): block formulation, see below.
+//   * thousands of independent calls run concurrently, longest call first.
 //
 // Roofline: 24 B of HBM traffic per anchor (16 B in, 8 B out) against ~130-200 predecessor
 // evaluations per anchor: latency/VALU bound by construction; the window re-reads are served by
@@ -35,6 +29,7 @@
 #include <algorithm>
 #include <new>
 #include <vector>
+#include <stdlib.h>
 #include <string.h>
 
 namespace {
@@ -90,253 +85,303 @@ __device__ __forceinline__ uint64_t wave_shr1_u64(uint64_t v) {
 
 __device__ __forceinline__ int ilog2_u32(uint32_t v) { return 31 - __clz((int)v); }
 
-#ifndef GAB_CHAIN_WAVES
-#define GAB_CHAIN_WAVES 4
-#endif
-constexpr int kWaves = GAB_CHAIN_WAVES;   // waves per call (one workgroup)
-constexpr int kThreads = kWaves * 64;
 constexpr int kRing = 512;                // anchors kept in the LDS window ring
 constexpr int kRingSafe = kRing - 8;      // entries younger than this are read from the ring
 
-// One workgroup (4 waves) walks one call.  Per anchor i the predecessor window [st, i-1] is swept in
-// "super-chunks" of 256 predecessors, wave w taking chunk 4*s + w.  The last kRing anchors (x, y, seg id,
-// score, parent) live in an LDS ring, so the RAW dependence score[i-1] -> score[i] never leaves the CU;
-// predecessors older than the ring (windows > ~1000 anchors) are read back from global memory.
-// Workgroup barrier that waits for LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it would wait for
-// the global store of score[i] / parent[i] (a ~2 us write acknowledgement) on every anchor of the sequential walk.
-// Nothing crossing these barriers goes through global memory: the window ring, the marks and the publish slots are
-// all LDS.  (Global loads are waited for by the compiler at their first use, as always.)
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// ---- chain: the sequential walk (main wave) -----------------------------------------------------------------------
+// A call is walked by ONE wave (an earlier four-wave version spent most of its time on workgroup barriers and on
+// instructions all four waves executed for a window one wave can hold).  Each lane owns an ALIGNED group of four ring
+// entries (one ds_read_b128 per field), so a super-chunk is 256 predecessors and needs no barrier at all -- LDS
+// operations of one wave complete in program order.  Visiting order (descending j)
+// is lane order, and inside a lane item k = 0..3 <-> j = 4g+3-k.  The max_skip logic is the same three steps as
+// before with a 4-item sequential part inside the lane and wave scans across the lanes:
+//   marks     targets[parent[j]] = i for every unfiltered item (tagged 16-bit LDS ring / global array for deep windows)
+//   improve   sc > max(prefix max over earlier items, best so far)
+//   n_skip    counter reflected at 0: c = P - min(-c_in, running min of P), P = prefix sums of (+1 hit, -1 improvement)
+// ---- chain: main wave + helper waves ------------------------------------------------------------------------------
+// The walk of one call is a chain of dependent anchors, and the time of the whole batch is the walk of its longest
+// call (~1.9 us per anchor with either kernel above).  Most of an anchor's instructions do not depend on earlier
+// results at all: the filters, min(dq, dr, q_span) and the gap cost are pure geometry of (anchor, predecessor).
+// Here helper waves compute that geometry one block of kChBlock anchors AHEAD (window start, 256 newest predecessors
+// per anchor, coalesced reads of x / y) and leave it in LDS; the main wave, which alone carries the dependence, only
+// adds score[j], and runs the marks / prefix-max / n_skip steps described above.  Windows deeper than 256
+// predecessors continue in the main wave, which then evaluates the geometry itself.
+constexpr int kChHelpers = 2;
+constexpr int kChBlock = 8;
+constexpr int kGeoNone = (int)0x80000000;      // predecessor filtered out (or outside the window)
 
-template <bool FAST>
-__global__ __launch_bounds__(kThreads) void chain_kernel(const ChainWork *__restrict__ work,
-                                                         const uint64_t *__restrict__ xs,
-                                                         const uint64_t *__restrict__ ys,
-                                                         int32_t *score_out, int32_t *parent_out,
-                                                         int32_t *gmarks_all, unsigned long long *evals_out) {
-    __shared__ uint64_t ring_x[kRing];
-    __shared__ uint32_t ring_y[kRing];
-    __shared__ int32_t ring_sc[kRing];
-    __shared__ int32_t ring_par[kRing];
-    __shared__ uint8_t ring_sid[FAST ? 1 : kRing];
-    __shared__ uint16_t marks[FAST ? 1 : kMarkRing];
-    __shared__ uint64_t stage_x[kThreads], stage_y[kThreads];
-    __shared__ int32_t pub_max[2][kWaves], pub_j[2][kWaves];          // FAST: per-wave maxima (double-buffered)
-    // CHAIN: per-chunk maxima, scores and ballot masks; double-buffered by super-chunk parity so that a wave
-    // already in the next super-chunk's phase A never overwrites what a slower wave still reads in phase C
-    __shared__ int32_t pub_cmax[2][kWaves];
-    __shared__ int32_t pub_sc[2][kWaves][64];
-    __shared__ unsigned long long pub_imp[2][kWaves], pub_hit[2][kWaves], pub_valid[2][kWaves];
+__device__ __forceinline__ int32_t chain_geometry(uint64_t xi, int32_t qi, int32_t q_span, int32_t sidi, uint64_t xj, uint32_t yj,
+                                                  int32_t sidj, int32_t mdx, int32_t mdy, int32_t bw, bool multi_seg, double avg_d,
+                                                  bool &ok) {
+    const int64_t dr = (int64_t)(xi - xj);
+    const int32_t dq = qi - (int32_t)yj;
+    const bool same = sidi == sidj;
+    const int32_t dd = (int32_t)(dr > dq ? dr - dq : dq - dr);
+    const bool skip = (same && dr == 0) || dq <= 0 || (same && dq > mdy) || dq > mdx || (same && dd > bw) ||
+                      (multi_seg && same && dr > mdy);
+    ok = !skip;
+    const int32_t min_d = (int32_t)(dq < dr ? (int64_t)dq : dr);
+    int32_t v = min_d > q_span ? q_span : min_d;
+    const int32_t lg = dd ? ilog2_u32((uint32_t)dd) : 0;
+    const int32_t c_lin = (int32_t)__dmul_rn(__dmul_rn((double)dd, .01), avg_d);
+    int32_t gap;
+    if (!same) {
+        if (dr == 0) { ++v; gap = 0; }
+        else gap = c_lin < lg ? c_lin : lg;
+    } else gap = c_lin + (lg >> 1);
+    v -= (int32_t)(__dadd_rn((double)gap, .499));     // (int)((double)gap_cost * 1.0f + .499)
+    return v;
+}
+
+__global__ __launch_bounds__(64 * (1 + kChHelpers)) void chain_hw_kernel(const ChainWork *__restrict__ work,
+                                                                         const uint64_t *__restrict__ xs,
+                                                                         const uint64_t *__restrict__ ys, int32_t *score_out,
+                                                                         int32_t *parent_out, int32_t *gmarks_all,
+                                                                         unsigned long long *evals_out) {
+    __shared__ __attribute__((aligned(16))) uint64_t ring_x[kRing];
+    __shared__ __attribute__((aligned(16))) uint32_t ring_y[kRing];
+    __shared__ __attribute__((aligned(16))) int32_t ring_sc[kRing];
+    __shared__ __attribute__((aligned(16))) int32_t ring_par[kRing];
+    __shared__ __attribute__((aligned(16))) uint8_t ring_sid[kRing];
+    __shared__ __attribute__((aligned(16))) uint16_t marks[kMarkRing];
+    __shared__ __attribute__((aligned(16))) int32_t geo[2][kChBlock][256];
+    __shared__ int64_t meta_st[2][kChBlock];
+    __shared__ uint64_t meta_x[2][kChBlock], meta_y[2][kChBlock];
 
     const ChainWork w = work[blockIdx.x];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint64_t *X = xs + w.off, *Y = ys + w.off;
     int32_t *S = score_out + w.off, *P = parent_out + w.off;
-    int32_t *GM = FAST ? nullptr : gmarks_all + w.off;     // targets[] of the reference, used only beyond the LDS mark ring
+    int32_t *GM = gmarks_all + w.off;
     const int64_t n = w.n;
     const int32_t mdx = w.max_dist_x, mdy = w.max_dist_y, bw = w.bw;
     const uint64_t mdx64 = (uint64_t)(int64_t)mdx;
     const double avg_d = (double)w.avg_qspan;
-    const float k32 = (float)(0.01 * (double)w.avg_qspan);
     const bool multi_seg = w.n_segs > 1;
+    const int NEG = (int)0x80000000;
+    const int64_t nblocks = (n + kChBlock - 1) / kChBlock;
 
-    // cached block of x for the window-start search (every wave keeps its own copy: no barrier needed)
-    int64_t st = 0, sb = 0;
-    uint64_t XS = (lane < n) ? X[lane] : 0;
-    unsigned long long evals = 0;
-    int pub_phase = 0;
-
-    for (int64_t i = 0; i < n; i++) {
-        if ((i & (kThreads - 1)) == 0) {
-            // stage the next 256 anchors (coalesced) -- the previous block is no longer needed by anyone
-            lds_barrier();
-            // results leave the CU in coalesced blocks of 256 taken from the ring -- a store per anchor would put a
-            // ~2 us write acknowledgement (s_waitcnt vmcnt) on the sequential path of every anchor
-            if (i > 0) {
-                const int64_t jo = i - kThreads + tid;
-                S[jo] = ring_sc[jo & (kRing - 1)]; P[jo] = ring_par[jo & (kRing - 1)];
-            }
-            if (i + tid < n) { stage_x[tid] = X[i + tid]; stage_y[tid] = Y[i + tid]; }
-            if (!FAST && (i & 0x7fff) == 0)
-                for (int k = tid; k < kMarkRing; k += kThreads) marks[k] = 0;   // new tag epoch (see tag below)
-            __syncthreads();     // full barrier (once per 256 anchors): the flushed results are acknowledged by L2
-                                 // before any wave may read them back through the deep-window path
-        }
-        const uint64_t xi = stage_x[i & (kThreads - 1)], yi = stage_y[i & (kThreads - 1)];     // workgroup-uniform
-        const int32_t qi = (int32_t)yi, q_span = (int32_t)(yi >> 32 & 0xff), sidi = (int32_t)(yi >> 48 & 0xff);
-        // ---- window start (host_kernel.cpp:56-57 / fast :200-207)
-        for (;;) {
-            const int64_t cand = sb + lane;
-            const bool far = FAST ? ((xi - XS) > mdx64) : (xi > XS + mdx64);
-            const bool pass = cand < st || (cand < i && far);
-            const unsigned long long m = __ballot(pass);
-            if (m == ~0ull) {
-                sb += 64; st = sb;
-                XS = (sb + lane < n) ? X[sb + lane] : 0;
-                continue;
-            }
-            st = sb + __builtin_ctzll(~m);
-            break;
-        }
-        if (i - st > kMaxIter) st = i - kMaxIter;
-        if (st - sb >= 64) { sb = st & ~63ll; XS = (sb + lane < n) ? X[sb + lane] : 0; }
-
-        int32_t best = q_span, best_j = -1;
-        const int64_t count = i - st;
-        const bool wide = !((i - 1) - st <= 5);          // FAST only (:211/:440)
-        int n_skip = 0;
-        bool broke = false;
-        const uint16_t tag = (uint16_t)(0x8000 | (i & 0x7fff));
-
-        for (int64_t c0 = 0; c0 < count && !broke; c0 += kThreads) {
-            const int64_t j = i - 1 - c0 - tid;           // wave w owns lanes [64w, 64w+64) of the super-chunk
-            const bool valid = j >= st;
-            uint64_t xj = 0; uint32_t yj = 0; int sidj = 0, scj = 0, parj = -1;
-            if (valid) {
-                if (i - j <= kRingSafe) {
-                    const int r = (int)(j & (kRing - 1));
-                    xj = ring_x[r]; yj = ring_y[r]; scj = ring_sc[r];
-                    if (!FAST) { sidj = ring_sid[r]; parj = ring_par[r]; }
-                } else {
-                    // older than the LDS ring: L2-coherent loads (the values were stored by another wave of this CU)
-                    xj = X[j];
-                    const uint64_t yy = Y[j];
-                    yj = (uint32_t)yy; sidj = (int)(yy >> 48 & 0xff);
-                    scj = __hip_atomic_load(&S[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (!FAST) parj = __hip_atomic_load(&P[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-            }
-            bool ok = valid;
-            int32_t sc = 0;
-            if (FAST) {
-                const int32_t ddr = (int32_t)((uint32_t)xi - (uint32_t)xj);
-                const int32_t ddq = (int32_t)((uint32_t)qi - yj);
-                const uint32_t diff = (uint32_t)ddr - (uint32_t)ddq;
-                const int32_t dd = (int32_t)((int32_t)diff < 0 ? 0u - diff : diff);
-                ok = ok && !(dd > bw || ddr == 0 || ddq <= 0 || ddq > mdy || ddq > mdx);
-                const int32_t oc = min(min(ddr, ddq), q_span);
-                const int32_t lg = dd ? ilog2_u32((uint32_t)dd) : 0;
-                int32_t gc;
-                if (wide) gc = (int32_t)floorf(__fmul_rn((float)dd, k32)) + (lg >> 1);
-                else gc = (int32_t)__dmul_rn(__dmul_rn((double)dd, .01), avg_d) + (lg >> 1);
-                sc = (int32_t)((uint32_t)scj + (uint32_t)oc - (uint32_t)gc);
-                evals += valid ? 1 : 0;
-                // per-wave max (ties -> larger j = lower lane), then combine the four waves through LDS
-                const int v = ok ? sc : (int)0x80000000;
-                const int mx = __builtin_amdgcn_readlane(wave_incl_max(v), 63);
-                const unsigned long long who = __ballot(ok && sc == mx);
-                if (lane == 0) {
-                    pub_max[pub_phase][wave] = mx;
-                    pub_j[pub_phase][wave] = who ? (int32_t)(i - 1 - c0 - 64 * wave - __builtin_ctzll(who)) : -1;
-                }
-                lds_barrier();
-#pragma unroll
-                for (int ww = 0; ww < kWaves; ww++) {       // wave order = descending j: strict > keeps the larger j
-                    const int m2 = pub_max[pub_phase][ww];
-                    if (m2 > best) { best = m2; best_j = pub_j[pub_phase][ww]; }
-                }
-                pub_phase ^= 1;
-            } else {
-                const int64_t dr = (int64_t)(xi - xj);
-                const int32_t dq = qi - (int32_t)yj;
-                const bool same = sidi == sidj;
-                const int32_t dd = (int32_t)(dr > dq ? dr - dq : dq - dr);
-                const bool skip = (same && dr == 0) || dq <= 0 || (same && dq > mdy) || dq > mdx || (same && dd > bw) ||
-                                  (multi_seg && same && dr > mdy);
-                ok = ok && !skip;
-                const int32_t min_d = (int32_t)(dq < dr ? (int64_t)dq : dr);
-                sc = min_d > q_span ? q_span : min_d;
-                const int32_t lg = dd ? ilog2_u32((uint32_t)dd) : 0;
-                const int32_t c_lin = (int32_t)__dmul_rn(__dmul_rn((double)dd, .01), avg_d);
-                int32_t gap;
-                if (!same) {
-                    if (dr == 0) { ++sc; gap = 0; }
-                    else gap = c_lin < lg ? c_lin : lg;
-                } else gap = c_lin + (lg >> 1);
-                sc -= (int32_t)(__dadd_rn((double)gap, .499));     // (int)((double)gap_cost * 1.0f + .499)
-                sc += scj;
-                // phase A: scatter marks, publish the chunk maximum and the scores.  Marks of parents inside the LDS
-                // ring window go to LDS; a super-chunk that reaches further back (window > ~500 anchors) also uses the
-                // global targets[] array, and then needs full barriers (global stores must be acknowledged).
-                const bool deep = c0 + kThreads > kRingSafe;           // workgroup-uniform
-                if (ok && parj >= 0 && parj >= st) {
-                    if (i - parj <= kRingSafe) marks[parj & (kMarkRing - 1)] = tag;
-                    else __hip_atomic_store(&GM[parj], (int32_t)(i + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-                const int v = ok ? sc : (int)0x80000000;
-                const int incl = wave_incl_max(v);
-                if (lane == 63) pub_cmax[pub_phase][wave] = incl;
-                pub_sc[pub_phase][wave][lane] = sc;
-                if (deep) __syncthreads(); else lds_barrier();
-                // phase B: marks of ALL chunks of this super-chunk are visible
-                bool hit_raw = false;
-                if (ok) {
-                    if (i - j <= kRingSafe) hit_raw = marks[j & (kMarkRing - 1)] == tag;
-                    else hit_raw = __hip_atomic_load(&GM[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int32_t)(i + 1);
-                }
-                int before = wave_shr1(incl, (int)0x80000000);
-                before = max(before, best);
-#pragma unroll
-                for (int ww = 0; ww < kWaves; ww++) if (ww < wave) before = max(before, pub_cmax[pub_phase][ww]);
-                const bool imp = ok && sc > before;
-                const unsigned long long imp_m = __ballot(imp), hit_m = __ballot(hit_raw && !imp), valid_m = __ballot(valid);
-                if (lane == 0) { pub_imp[pub_phase][wave] = imp_m; pub_hit[pub_phase][wave] = hit_m; pub_valid[pub_phase][wave] = valid_m; }
-                lds_barrier();
-                // phase C: every wave walks the four chunks in order (identical scalar work, no further barrier)
-                unsigned long long visited = 0;
-                for (int ww = 0; ww < kWaves && !broke; ww++) {
-                    const unsigned long long im = pub_imp[pub_phase][ww], hm = pub_hit[pub_phase][ww], vm = pub_valid[pub_phase][ww];
-                    int brk = 64;
-                    if (hm == 0) {
-                        n_skip -= __popcll(im);
-                        n_skip = n_skip < 0 ? 0 : n_skip;
-                    } else {
-                        // n_skip is a counter reflected at 0: c_l = max(c_{l-1} + d_l, 0) with d = +1 on a hit, -1 on an
-                        // improvement.  Closed form over the chunk: c_l = P_l - min(-c_in, min_{t<=l} P_t), P = prefix sums
-                        // of d -- two DPP scans instead of a scalar walk over up to 64 events.
-                        const int d = (int)((hm >> lane) & 1) - (int)((im >> lane) & 1);
-                        const int pre = wave_incl_sum(d);
-                        const int mn = wave_incl_min(pre);
-                        const int cnt = pre - min(-n_skip, mn);
-                        const unsigned long long over = __ballot(((hm >> lane) & 1) && cnt > kMaxSkip);
-                        if (over) brk = __builtin_ctzll(over);
-                        else n_skip = __builtin_amdgcn_readlane(cnt, 63);
+    if (wave > 0) {
+        // ================= helper: geometry of block t, one block ahead of the main wave
+        int64_t st = 0, sb = 0;
+        uint64_t XS = (lane < n) ? X[lane] : 0;
+        for (int64_t t = 0; t < nblocks; t++) {
+            const int buf = (int)(t & 1);
+            for (int b = 0; b < kChBlock; b++) {
+                const int64_t i = t * kChBlock + b;
+                if (i >= n) break;
+                const uint64_t xi = X[i], yi = Y[i];       // wave-uniform
+                // window start with the reference's sequential-pointer semantics (host_kernel.cpp:56-57); every helper
+                // tracks it for every anchor (a ballot per anchor), so the helpers need no exchange among themselves
+                for (;;) {
+                    const int64_t cand = sb + lane;
+                    const bool far = xi > XS + mdx64;
+                    const bool pass = cand < st || (cand < i && far);
+                    const unsigned long long m = __ballot(pass);
+                    if (m == ~0ull) {
+                        sb += 64; st = sb;
+                        XS = (sb + lane < n) ? X[sb + lane] : 0;
+                        continue;
                     }
-                    const unsigned long long rec = im & (brk >= 64 ? ~0ull : ((1ull << brk) - 1));
-                    if (rec) {
-                        const int l = 63 - __builtin_clzll(rec);
-                        best = pub_sc[pub_phase][ww][l];
-                        best_j = (int32_t)(i - 1 - c0 - 64 * ww - l);
-                    }
-                    visited += (unsigned long long)__popcll(vm & (brk >= 64 ? ~0ull : ((2ull << brk) - 1)));
-                    broke = brk < 64;
+                    st = sb + __builtin_ctzll(~m);
+                    break;
                 }
-                if (tid == 0) evals += visited;
-                pub_phase ^= 1;
+                if (i - st > kMaxIter) st = i - kMaxIter;
+                if (st - sb >= 64) { sb = st & ~63ll; XS = (sb + lane < n) ? X[sb + lane] : 0; }
+                if ((b % kChHelpers) != wave - 1) continue;             // anchors are dealt round-robin to the helpers
+                if (lane == 0) { meta_st[buf][b] = st; meta_x[buf][b] = xi; meta_y[buf][b] = yi; }
+                const int32_t qi = (int32_t)yi, q_span = (int32_t)(yi >> 32 & 0xff), sidi = (int32_t)(yi >> 48 & 0xff);
+#pragma unroll
+                for (int p = 0; p < 4; p++) {
+                    const int64_t j = i - 1 - p * 64 - lane;
+                    if (j < st) continue;                               // (also covers j < 0)
+                    const uint64_t xj = X[j], yy = Y[j];
+                    bool ok;
+                    const int32_t v = chain_geometry(xi, qi, q_span, sidi, xj, (uint32_t)yy, (int32_t)(yy >> 48 & 0xff), mdx, mdy, bw,
+                                                     multi_seg, avg_d, ok);
+                    geo[buf][b][j & 255] = ok ? v : kGeoNone;
+                }
             }
+            __syncthreads();                                            // block t is ready / block t-1 is consumed
         }
-                // Every wave keeps the ring up to date by itself (lane 0 of each wave stores the same values), so a wave
-        // only ever reads ring entries it has written: no barrier is needed to publish anchor i.  The barriers of the
-        // super-chunks keep the four waves within one anchor of each other, which is what protects a slot from being
-        // recycled (1024 anchors later) while a slower wave could still read it (it reads at most kRingSafe back);
-        // an anchor with an empty window has no super-chunk, so it takes an explicit barrier.
-        if (lane == 0) {
-            const int r = (int)(i & (kRing - 1));
-            ring_x[r] = xi; ring_y[r] = (uint32_t)yi; ring_sc[r] = best; ring_par[r] = best_j;
-            if (!FAST) ring_sid[r] = (uint8_t)sidi;
-        }
-        if (count <= 0) lds_barrier();
+        __syncthreads();                                                // pairs with the main wave's last barrier
+        return;
     }
-    lds_barrier();
-    {   // flush the tail: anchors [n - rem, n) with rem = n mod 256 (or 256)
-        const int64_t done = n > 0 ? ((n - 1) & ~(int64_t)(kThreads - 1)) : 0;
-        const int64_t jo = done + tid;
+
+    // ================= main wave
+    unsigned long long evals = 0;
+    int64_t i = 0;
+    __syncthreads();                                                    // block 0 is ready
+    for (int64_t t = 0; t < nblocks; t++) {
+        const int buf = (int)(t & 1);
+        for (int b = 0; b < kChBlock && i < n; b++, i++) {
+            if ((i & 63) == 0) {
+                if (i > 0) {                                   // results leave the CU in coalesced blocks of 64
+                    const int64_t jo = i - 64 + lane;
+                    S[jo] = ring_sc[jo & (kRing - 1)]; P[jo] = ring_par[jo & (kRing - 1)];
+                }
+                if ((i & 0x7fff) == 0)
+                    for (int k = lane; k < kMarkRing; k += 64) marks[k] = 0;       // new tag epoch
+            }
+            const int64_t st = meta_st[buf][b];
+            const uint64_t xi = meta_x[buf][b], yi = meta_y[buf][b];
+            const int32_t qi = (int32_t)yi, q_span = (int32_t)(yi >> 32 & 0xff), sidi = (int32_t)(yi >> 48 & 0xff);
+
+            int32_t best = q_span, best_j = -1;
+            int n_skip = 0;
+            bool broke = false;
+            const uint16_t tag = (uint16_t)(0x8000 | (i & 0x7fff));
+
+            for (int64_t top = i - 1; top >= st && !broke;) {
+                const int64_t g = (top >> 2) - lane;           // this lane's group: entries 4g .. 4g+3
+                const int64_t j0 = 4 * g;
+                const bool first = top == i - 1;               // the 256 newest predecessors: geometry comes from the helpers
+                const bool in_ring = i - j0 <= kRingSafe;
+                const bool any_valid = j0 + 3 >= st && j0 <= top;
+                bool valid[4], ok[4];
+                int32_t sc[4], parj[4] = {-1, -1, -1, -1};
+#pragma unroll
+                for (int k = 0; k < 4; k++) { const int64_t j = j0 + 3 - k; valid[k] = j >= st && j <= top; ok[k] = false; sc[k] = 0; }
+                if (first) {
+                    if (any_valid) {
+                        const int r = (int)(j0 & (kRing - 1));
+                        const int4 gv = *reinterpret_cast<const int4 *>(&geo[buf][b][j0 & 255]);
+                        const int4 sv = *reinterpret_cast<const int4 *>(&ring_sc[r]);
+                        const int4 pv = *reinterpret_cast<const int4 *>(&ring_par[r]);
+                        const int gk[4] = {gv.w, gv.z, gv.y, gv.x}, sk[4] = {sv.w, sv.z, sv.y, sv.x};
+                        parj[0] = pv.w; parj[1] = pv.z; parj[2] = pv.y; parj[3] = pv.x;
+#pragma unroll
+                        for (int k = 0; k < 4; k++) { ok[k] = valid[k] && gk[k] != kGeoNone; sc[k] = gk[k] + sk[k]; }
+                    }
+                } else if (any_valid) {
+                    uint64_t xj[4] = {0, 0, 0, 0}; uint32_t yj[4] = {0, 0, 0, 0};
+                    int32_t scj[4] = {0, 0, 0, 0}, sidj[4] = {0, 0, 0, 0};
+                    if (in_ring) {
+                        const int r = (int)(j0 & (kRing - 1));
+                        const ulonglong2 xa = *reinterpret_cast<const ulonglong2 *>(&ring_x[r]);
+                        const ulonglong2 xb = *reinterpret_cast<const ulonglong2 *>(&ring_x[r + 2]);
+                        const uint4 yv = *reinterpret_cast<const uint4 *>(&ring_y[r]);
+                        const int4 sv = *reinterpret_cast<const int4 *>(&ring_sc[r]);
+                        const int4 pv = *reinterpret_cast<const int4 *>(&ring_par[r]);
+                        const uint32_t dv = *reinterpret_cast<const uint32_t *>(&ring_sid[r]);
+                        xj[0] = xb.y; xj[1] = xb.x; xj[2] = xa.y; xj[3] = xa.x;                 // item k <-> entry 3 - k
+                        yj[0] = yv.w; yj[1] = yv.z; yj[2] = yv.y; yj[3] = yv.x;
+                        scj[0] = sv.w; scj[1] = sv.z; scj[2] = sv.y; scj[3] = sv.x;
+                        parj[0] = pv.w; parj[1] = pv.z; parj[2] = pv.y; parj[3] = pv.x;
+                        sidj[0] = (int)(dv >> 24); sidj[1] = (int)(dv >> 16 & 0xff); sidj[2] = (int)(dv >> 8 & 0xff); sidj[3] = (int)(dv & 0xff);
+                    } else {
+                        // older than the LDS ring: the values were stored by this wave earlier; read them back from L2
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            const int64_t j = j0 + 3 - k;
+                            if (valid[k]) {
+                                xj[k] = X[j];
+                                const uint64_t yy = Y[j];
+                                yj[k] = (uint32_t)yy; sidj[k] = (int)(yy >> 48 & 0xff);
+                                scj[k] = __hip_atomic_load(&S[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                parj[k] = __hip_atomic_load(&P[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        bool okk;
+                        const int32_t v = chain_geometry(xi, qi, q_span, sidi, xj[k], yj[k], sidj[k], mdx, mdy, bw, multi_seg, avg_d, okk);
+                        ok[k] = valid[k] && okk;
+                        sc[k] = v + scj[k];
+                    }
+                }
+                // ---- marks: scatter, then read this group's own four tags (LDS is in order within the wave)
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    if (ok[k] && parj[k] >= 0 && parj[k] >= st) {
+                        if (i - parj[k] <= kRingSafe) marks[parj[k] & (kMarkRing - 1)] = tag;
+                        else __hip_atomic_store(&GM[parj[k]], (int32_t)(i + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+                const bool deep = i - (4 * ((top >> 2) - 63)) > kRingSafe;        // wave-uniform: this super-chunk leaves the ring
+                if (deep) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                bool hit[4];
+                {   // a mark lives in the LDS ring or in the global array according to the age of the marked anchor itself
+                    const uint2 mv = *reinterpret_cast<const uint2 *>(&marks[j0 & (kMarkRing - 1)]);
+                    hit[0] = (mv.y >> 16) == tag; hit[1] = (mv.y & 0xffffu) == tag; hit[2] = (mv.x >> 16) == tag; hit[3] = (mv.x & 0xffffu) == tag;
+                    if (!in_ring) {
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            const int64_t j = j0 + 3 - k;
+                            if (i - j > kRingSafe)
+                                hit[k] = ok[k] && __hip_atomic_load(&GM[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int32_t)(i + 1);
+                        }
+                    }
+                }
+                // ---- improvement flags
+                int lmax = NEG;
+#pragma unroll
+                for (int k = 0; k < 4; k++) lmax = ok[k] ? max(lmax, sc[k]) : lmax;
+                const int incl = wave_incl_max(lmax);
+                int run = max(wave_shr1(incl, NEG), best);
+                bool imp[4];
+                int d[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    imp[k] = ok[k] && sc[k] > run;
+                    run = ok[k] ? max(run, sc[k]) : run;
+                    d[k] = imp[k] ? -1 : (ok[k] && hit[k]) ? 1 : 0;
+                }
+                // ---- n_skip: reflected counter in closed form
+                const int p0 = d[0], p1 = p0 + d[1], p2 = p1 + d[2], p3 = p2 + d[3];
+                const int E = wave_incl_sum(p3) - p3;                              // exclusive sum over earlier lanes
+                const int mloc = min(min(p0, p1), min(p2, p3));
+                const int inclmin = wave_incl_min(E + mloc);
+                int rmin = min(-n_skip, wave_shr1(inclmin, 0x7fffffff));
+                int cnt[4];
+                const int pk[4] = {p0, p1, p2, p3};
+                int kfirst = 4;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    rmin = min(rmin, E + pk[k]);
+                    cnt[k] = E + pk[k] - rmin;
+                    if (d[k] == 1 && cnt[k] > kMaxSkip && kfirst == 4) kfirst = k;
+                }
+                const unsigned long long om = __ballot(kfirst < 4);
+                int fl = 64, fk = 4;
+                if (om) { fl = __builtin_ctzll(om); fk = __builtin_amdgcn_readlane(kfirst, fl); broke = true; }
+                else n_skip = __builtin_amdgcn_readlane(cnt[3], 63);
+                // ---- best = the last improvement before the break
+                const int klim = lane < fl ? 4 : lane == fl ? fk : 0;              // items k < klim of this lane count
+                int lastk = -1, lsc = 0; int64_t lj = 0;
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    if (imp[k] && k < klim) { lastk = k; lsc = sc[k]; lj = j0 + 3 - k; }
+                const unsigned long long lm = __ballot(lastk >= 0);
+                if (lm) {
+                    const int ll = 63 - __builtin_clzll(lm);
+                    best = __builtin_amdgcn_readlane(lsc, ll);
+                    best_j = __builtin_amdgcn_readlane((int)lj, ll);
+                }
+                // visited predecessors (statistics): valid items up to and including the break item
+                const int vlim = lane < fl ? 4 : lane == fl ? fk + 1 : 0;
+#pragma unroll
+                for (int k = 0; k < 4; k++) evals += (valid[k] && k < vlim) ? 1 : 0;
+                top = 4 * ((top >> 2) - 63) - 1;
+            }
+            if (lane == 0) {
+                const int r = (int)(i & (kRing - 1));
+                ring_x[r] = xi; ring_y[r] = (uint32_t)yi; ring_sc[r] = best; ring_par[r] = best_j;
+                ring_sid[r] = (uint8_t)sidi;
+            }
+        }
+        __syncthreads();                                                // block t consumed, block t+1 ready
+    }
+    {   // flush the tail: anchors [done, n) with done = the last multiple of 64 below n
+        const int64_t done = n > 0 ? ((n - 1) & ~63ll) : 0;
+        const int64_t jo = done + lane;
         if (jo < n) { S[jo] = ring_sc[jo & (kRing - 1)]; P[jo] = ring_par[jo & (kRing - 1)]; }
     }
-    if (FAST) { for (int o = 32; o > 0; o >>= 1) evals += __shfl_xor(evals, o); }
+    for (int o = 32; o > 0; o >>= 1) evals += __shfl_xor(evals, o);
     if (lane == 0 && evals) atomicAdd(evals_out, evals);
 }
-
 
 // ---- fast-chain: block formulation, one main wave + three helper waves per call ------------------------------------
 // Without max_skip the DP of an anchor is an order-independent maximum over its window (ties -> larger j), so the
@@ -600,7 +645,7 @@ extern "C" int gab_chain_run_device(gab_chain *h, int mode, const uint64_t *d_x,
     if (mode == GAB_FASTCHAIN)
         hipLaunchKernelGGL(fastchain_kernel, dim3((unsigned)nw), dim3(64 * (1 + kFcHelpers)), 0, s, d_work, d_x, d_y, d_score, d_parent, d_ev);
     else
-        hipLaunchKernelGGL(chain_kernel<false>, dim3((unsigned)nw), dim3(kThreads), 0, s, d_work, d_x, d_y, d_score, d_parent, d_gm, d_ev);
+        hipLaunchKernelGGL(chain_hw_kernel, dim3((unsigned)nw), dim3(64 * (1 + kChHelpers)), 0, s, d_work, d_x, d_y, d_score, d_parent, d_gm, d_ev);
     GAB_HIP(hipGetLastError());
     GAB_HIP(hipEventRecord(h->ev[1], s));
     GAB_HIP(hipMemcpyAsync(h->h_evals, d_ev, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
