@@ -85,7 +85,7 @@ __device__ __forceinline__ uint64_t wave_shr1_u64(uint64_t v) {
 
 __device__ __forceinline__ int ilog2_u32(uint32_t v) { return 31 - __clz((int)v); }
 
-constexpr int kRing = 512;                // anchors kept in the LDS window ring
+constexpr int kRing = 1024;               // anchors whose score / parent are kept in the LDS ring
 constexpr int kRingSafe = kRing - 8;      // entries younger than this are read from the ring
 
 // ---- chain: the sequential walk (main wave) -----------------------------------------------------------------------
@@ -107,7 +107,8 @@ constexpr int kRingSafe = kRing - 8;      // entries younger than this are read 
 // adds score[j], and runs the marks / prefix-max / n_skip steps described above.  Windows deeper than 256
 // predecessors continue in the main wave, which then evaluates the geometry itself.
 constexpr int kChHelpers = 2;
-constexpr int kChBlock = 8;
+constexpr int kChBlock = 2;
+constexpr int kGeoDepth = 1024;              // predecessors per anchor the helpers prepare (four super-chunks)
 constexpr int kGeoNone = (int)0x80000000;      // predecessor filtered out (or outside the window)
 
 __device__ __forceinline__ int32_t chain_geometry(uint64_t xi, int32_t qi, int32_t q_span, int32_t sidi, uint64_t xj, uint32_t yj,
@@ -138,14 +139,11 @@ __global__ __launch_bounds__(64 * (1 + kChHelpers)) void chain_hw_kernel(const C
                                                                          const uint64_t *__restrict__ ys, int32_t *score_out,
                                                                          int32_t *parent_out, int32_t *gmarks_all,
                                                                          unsigned long long *evals_out) {
-    __shared__ __attribute__((aligned(16))) uint64_t ring_x[kRing];
-    __shared__ __attribute__((aligned(16))) uint32_t ring_y[kRing];
     __shared__ __attribute__((aligned(16))) int32_t ring_sc[kRing];
     __shared__ __attribute__((aligned(16))) int32_t ring_par[kRing];
-    __shared__ __attribute__((aligned(16))) uint8_t ring_sid[kRing];
     __shared__ __attribute__((aligned(16))) uint16_t marks[kMarkRing];
-    __shared__ __attribute__((aligned(16))) int32_t geo[2][kChBlock][256];
-    __shared__ int64_t meta_st[2][kChBlock];
+    __shared__ __attribute__((aligned(16))) int32_t geo[2][kChBlock][kGeoDepth];
+    __shared__ int32_t meta_st[2][kChBlock];
     __shared__ uint64_t meta_x[2][kChBlock], meta_y[2][kChBlock];
 
     const ChainWork w = work[blockIdx.x];
@@ -153,28 +151,28 @@ __global__ __launch_bounds__(64 * (1 + kChHelpers)) void chain_hw_kernel(const C
     const uint64_t *X = xs + w.off, *Y = ys + w.off;
     int32_t *S = score_out + w.off, *P = parent_out + w.off;
     int32_t *GM = gmarks_all + w.off;
-    const int64_t n = w.n;
+    const int n = (int)w.n;                                  // < 2^31 (checked by the host): 32-bit indices inside a call
     const int32_t mdx = w.max_dist_x, mdy = w.max_dist_y, bw = w.bw;
     const uint64_t mdx64 = (uint64_t)(int64_t)mdx;
     const double avg_d = (double)w.avg_qspan;
     const bool multi_seg = w.n_segs > 1;
     const int NEG = (int)0x80000000;
-    const int64_t nblocks = (n + kChBlock - 1) / kChBlock;
+    const int nblocks = (n + kChBlock - 1) / kChBlock;
 
     if (wave > 0) {
         // ================= helper: geometry of block t, one block ahead of the main wave
-        int64_t st = 0, sb = 0;
+        int st = 0, sb = 0;
         uint64_t XS = (lane < n) ? X[lane] : 0;
-        for (int64_t t = 0; t < nblocks; t++) {
+        for (int t = 0; t < nblocks; t++) {
             const int buf = (int)(t & 1);
             for (int b = 0; b < kChBlock; b++) {
-                const int64_t i = t * kChBlock + b;
+                const int i = t * kChBlock + b;
                 if (i >= n) break;
                 const uint64_t xi = X[i], yi = Y[i];       // wave-uniform
                 // window start with the reference's sequential-pointer semantics (host_kernel.cpp:56-57); every helper
                 // tracks it for every anchor (a ballot per anchor), so the helpers need no exchange among themselves
                 for (;;) {
-                    const int64_t cand = sb + lane;
+                    const int cand = sb + lane;
                     const bool far = xi > XS + mdx64;
                     const bool pass = cand < st || (cand < i && far);
                     const unsigned long long m = __ballot(pass);
@@ -187,19 +185,18 @@ __global__ __launch_bounds__(64 * (1 + kChHelpers)) void chain_hw_kernel(const C
                     break;
                 }
                 if (i - st > kMaxIter) st = i - kMaxIter;
-                if (st - sb >= 64) { sb = st & ~63ll; XS = (sb + lane < n) ? X[sb + lane] : 0; }
+                if (st - sb >= 64) { sb = st & ~63; XS = (sb + lane < n) ? X[sb + lane] : 0; }
                 if ((b % kChHelpers) != wave - 1) continue;             // anchors are dealt round-robin to the helpers
                 if (lane == 0) { meta_st[buf][b] = st; meta_x[buf][b] = xi; meta_y[buf][b] = yi; }
                 const int32_t qi = (int32_t)yi, q_span = (int32_t)(yi >> 32 & 0xff), sidi = (int32_t)(yi >> 48 & 0xff);
-#pragma unroll
-                for (int p = 0; p < 4; p++) {
-                    const int64_t j = i - 1 - p * 64 - lane;
+                for (int p = 0; p < kGeoDepth / 64 && i - 1 - p * 64 >= st; p++) {
+                    const int j = i - 1 - p * 64 - lane;
                     if (j < st) continue;                               // (also covers j < 0)
                     const uint64_t xj = X[j], yy = Y[j];
                     bool ok;
                     const int32_t v = chain_geometry(xi, qi, q_span, sidi, xj, (uint32_t)yy, (int32_t)(yy >> 48 & 0xff), mdx, mdy, bw,
                                                      multi_seg, avg_d, ok);
-                    geo[buf][b][j & 255] = ok ? v : kGeoNone;
+                    geo[buf][b][j & (kGeoDepth - 1)] = ok ? v : kGeoNone;
                 }
             }
             __syncthreads();                                            // block t is ready / block t-1 is consumed
@@ -210,20 +207,20 @@ __global__ __launch_bounds__(64 * (1 + kChHelpers)) void chain_hw_kernel(const C
 
     // ================= main wave
     unsigned long long evals = 0;
-    int64_t i = 0;
+    int i = 0;
     __syncthreads();                                                    // block 0 is ready
-    for (int64_t t = 0; t < nblocks; t++) {
-        const int buf = (int)(t & 1);
+    for (int t = 0; t < nblocks; t++) {
+        const int buf = t & 1;
         for (int b = 0; b < kChBlock && i < n; b++, i++) {
             if ((i & 63) == 0) {
                 if (i > 0) {                                   // results leave the CU in coalesced blocks of 64
-                    const int64_t jo = i - 64 + lane;
+                    const int jo = i - 64 + lane;
                     S[jo] = ring_sc[jo & (kRing - 1)]; P[jo] = ring_par[jo & (kRing - 1)];
                 }
                 if ((i & 0x7fff) == 0)
                     for (int k = lane; k < kMarkRing; k += 64) marks[k] = 0;       // new tag epoch
             }
-            const int64_t st = meta_st[buf][b];
+            const int st = meta_st[buf][b];
             const uint64_t xi = meta_x[buf][b], yi = meta_y[buf][b];
             const int32_t qi = (int32_t)yi, q_span = (int32_t)(yi >> 32 & 0xff), sidi = (int32_t)(yi >> 48 & 0xff);
 
@@ -232,20 +229,21 @@ __global__ __launch_bounds__(64 * (1 + kChHelpers)) void chain_hw_kernel(const C
             bool broke = false;
             const uint16_t tag = (uint16_t)(0x8000 | (i & 0x7fff));
 
-            for (int64_t top = i - 1; top >= st && !broke;) {
-                const int64_t g = (top >> 2) - lane;           // this lane's group: entries 4g .. 4g+3
-                const int64_t j0 = 4 * g;
-                const bool first = top == i - 1;               // the 256 newest predecessors: geometry comes from the helpers
+            int chunk = 0;
+            for (int top = i - 1; top >= st && !broke; chunk++) {
+                const int g = (top >> 2) - lane;               // this lane's group: entries 4g .. 4g+3 (may be negative)
+                const int j0 = 4 * g;
+                const bool first = chunk < kGeoDepth / 256;    // the newest predecessors: geometry comes from the helpers
                 const bool in_ring = i - j0 <= kRingSafe;
                 const bool any_valid = j0 + 3 >= st && j0 <= top;
                 bool valid[4], ok[4];
                 int32_t sc[4], parj[4] = {-1, -1, -1, -1};
 #pragma unroll
-                for (int k = 0; k < 4; k++) { const int64_t j = j0 + 3 - k; valid[k] = j >= st && j <= top; ok[k] = false; sc[k] = 0; }
+                for (int k = 0; k < 4; k++) { const int j = j0 + 3 - k; valid[k] = j >= st && j <= top; ok[k] = false; sc[k] = 0; }
                 if (first) {
                     if (any_valid) {
                         const int r = (int)(j0 & (kRing - 1));
-                        const int4 gv = *reinterpret_cast<const int4 *>(&geo[buf][b][j0 & 255]);
+                        const int4 gv = *reinterpret_cast<const int4 *>(&geo[buf][b][j0 & (kGeoDepth - 1)]);
                         const int4 sv = *reinterpret_cast<const int4 *>(&ring_sc[r]);
                         const int4 pv = *reinterpret_cast<const int4 *>(&ring_par[r]);
                         const int gk[4] = {gv.w, gv.z, gv.y, gv.x}, sk[4] = {sv.w, sv.z, sv.y, sv.x};
@@ -256,29 +254,25 @@ __global__ __launch_bounds__(64 * (1 + kChHelpers)) void chain_hw_kernel(const C
                 } else if (any_valid) {
                     uint64_t xj[4] = {0, 0, 0, 0}; uint32_t yj[4] = {0, 0, 0, 0};
                     int32_t scj[4] = {0, 0, 0, 0}, sidj[4] = {0, 0, 0, 0};
+                    // beyond what the helpers prepared: x / y are input (plain loads), score / parent come from the LDS
+                    // ring while young enough, else back from L2 (stored by this wave earlier)
+                    if (!in_ring) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    int4 sv = {0, 0, 0, 0}, pv = {-1, -1, -1, -1};
                     if (in_ring) {
                         const int r = (int)(j0 & (kRing - 1));
-                        const ulonglong2 xa = *reinterpret_cast<const ulonglong2 *>(&ring_x[r]);
-                        const ulonglong2 xb = *reinterpret_cast<const ulonglong2 *>(&ring_x[r + 2]);
-                        const uint4 yv = *reinterpret_cast<const uint4 *>(&ring_y[r]);
-                        const int4 sv = *reinterpret_cast<const int4 *>(&ring_sc[r]);
-                        const int4 pv = *reinterpret_cast<const int4 *>(&ring_par[r]);
-                        const uint32_t dv = *reinterpret_cast<const uint32_t *>(&ring_sid[r]);
-                        xj[0] = xb.y; xj[1] = xb.x; xj[2] = xa.y; xj[3] = xa.x;                 // item k <-> entry 3 - k
-                        yj[0] = yv.w; yj[1] = yv.z; yj[2] = yv.y; yj[3] = yv.x;
-                        scj[0] = sv.w; scj[1] = sv.z; scj[2] = sv.y; scj[3] = sv.x;
-                        parj[0] = pv.w; parj[1] = pv.z; parj[2] = pv.y; parj[3] = pv.x;
-                        sidj[0] = (int)(dv >> 24); sidj[1] = (int)(dv >> 16 & 0xff); sidj[2] = (int)(dv >> 8 & 0xff); sidj[3] = (int)(dv & 0xff);
-                    } else {
-                        // older than the LDS ring: the values were stored by this wave earlier; read them back from L2
-                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        sv = *reinterpret_cast<const int4 *>(&ring_sc[r]);
+                        pv = *reinterpret_cast<const int4 *>(&ring_par[r]);
+                    }
+                    const int sk[4] = {sv.w, sv.z, sv.y, sv.x}, pk4[4] = {pv.w, pv.z, pv.y, pv.x};
 #pragma unroll
-                        for (int k = 0; k < 4; k++) {
-                            const int64_t j = j0 + 3 - k;
-                            if (valid[k]) {
-                                xj[k] = X[j];
-                                const uint64_t yy = Y[j];
-                                yj[k] = (uint32_t)yy; sidj[k] = (int)(yy >> 48 & 0xff);
+                    for (int k = 0; k < 4; k++) {
+                        const int j = j0 + 3 - k;
+                        if (valid[k]) {
+                            xj[k] = X[j];
+                            const uint64_t yy = Y[j];
+                            yj[k] = (uint32_t)yy; sidj[k] = (int)(yy >> 48 & 0xff);
+                            if (in_ring) { scj[k] = sk[k]; parj[k] = pk4[k]; }
+                            else {
                                 scj[k] = __hip_atomic_load(&S[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                                 parj[k] = __hip_atomic_load(&P[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             }
@@ -309,7 +303,7 @@ __global__ __launch_bounds__(64 * (1 + kChHelpers)) void chain_hw_kernel(const C
                     if (!in_ring) {
 #pragma unroll
                         for (int k = 0; k < 4; k++) {
-                            const int64_t j = j0 + 3 - k;
+                            const int j = j0 + 3 - k;
                             if (i - j > kRingSafe)
                                 hit[k] = ok[k] && __hip_atomic_load(&GM[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int32_t)(i + 1);
                         }
@@ -350,7 +344,7 @@ __global__ __launch_bounds__(64 * (1 + kChHelpers)) void chain_hw_kernel(const C
                 else n_skip = __builtin_amdgcn_readlane(cnt[3], 63);
                 // ---- best = the last improvement before the break
                 const int klim = lane < fl ? 4 : lane == fl ? fk : 0;              // items k < klim of this lane count
-                int lastk = -1, lsc = 0; int64_t lj = 0;
+                int lastk = -1, lsc = 0, lj = 0;
 #pragma unroll
                 for (int k = 0; k < 4; k++)
                     if (imp[k] && k < klim) { lastk = k; lsc = sc[k]; lj = j0 + 3 - k; }
@@ -358,7 +352,7 @@ __global__ __launch_bounds__(64 * (1 + kChHelpers)) void chain_hw_kernel(const C
                 if (lm) {
                     const int ll = 63 - __builtin_clzll(lm);
                     best = __builtin_amdgcn_readlane(lsc, ll);
-                    best_j = __builtin_amdgcn_readlane((int)lj, ll);
+                    best_j = __builtin_amdgcn_readlane(lj, ll);
                 }
                 // visited predecessors (statistics): valid items up to and including the break item
                 const int vlim = lane < fl ? 4 : lane == fl ? fk + 1 : 0;
@@ -367,16 +361,15 @@ __global__ __launch_bounds__(64 * (1 + kChHelpers)) void chain_hw_kernel(const C
                 top = 4 * ((top >> 2) - 63) - 1;
             }
             if (lane == 0) {
-                const int r = (int)(i & (kRing - 1));
-                ring_x[r] = xi; ring_y[r] = (uint32_t)yi; ring_sc[r] = best; ring_par[r] = best_j;
-                ring_sid[r] = (uint8_t)sidi;
+                const int r = i & (kRing - 1);
+                ring_sc[r] = best; ring_par[r] = best_j;
             }
         }
         __syncthreads();                                                // block t consumed, block t+1 ready
     }
     {   // flush the tail: anchors [done, n) with done = the last multiple of 64 below n
-        const int64_t done = n > 0 ? ((n - 1) & ~63ll) : 0;
-        const int64_t jo = done + lane;
+        const int done = n > 0 ? ((n - 1) & ~63) : 0;
+        const int jo = done + lane;
         if (jo < n) { S[jo] = ring_sc[jo & (kRing - 1)]; P[jo] = ring_par[jo & (kRing - 1)]; }
     }
     for (int o = 32; o > 0; o >>= 1) evals += __shfl_xor(evals, o);
