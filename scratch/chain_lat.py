@@ -8,10 +8,11 @@ order = np.argsort(-cb.hdr["n"], kind="stable")
 n = cb.hdr["n"][order]
 print("longest calls:", n[:5], "total anchors", cb.nanchors, flush=True)
 ce = ChainEngine(device=0)
+MODE = int(os.environ.get('MODE', '0'))
 def run(idx, label):
     sub = gabgen.ChainBatch(cb.hdr[idx].copy(), cb.call_off[idx].copy(), cb.x, cb.y)
-    ce.host_chain_kernel(sub, 0)
-    ce.host_chain_kernel(sub, 0)
+    ce.host_chain_kernel(sub, MODE)
+    ce.host_chain_kernel(sub, MODE)
     st = ce.last_stats()
     na = int(sub.hdr["n"].sum())
     print(f"{label}: calls={len(idx)} anchors={na} kernel_ms={st['kernel_ms']:.2f} evals/anchor={st['evals']/na:.1f} Mseeds/s={na/st['kernel_ms']/1e3:.1f}", flush=True)
