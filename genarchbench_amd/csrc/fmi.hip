@@ -617,6 +617,106 @@ __global__ __launch_bounds__(256) void fmi_validate(const int32_t *len, int64_t 
     }
 }
 
+// ---- suffix-array look-up -------------------------------------------------------------------
+// get_sa_entries(SMEM*, ..., max_occ, tid) FMI_search.cpp:1177-1196 on get_sa_entry_compressed :1103-1175.
+struct SaIdx { const int8_t *ms; const uint32_t *ls; };
+struct SaCounters { unsigned long long lf_steps; int32_t next_chunk; int32_t pad; };
+constexpr int kSaChunk = 4096;            // SMEMs a wave takes at a time
+
+__device__ __forceinline__ int sa_count_of(int64_t s, int32_t max_occ) {
+    if (s <= 0) return 0;
+    const int64_t step = s > max_occ ? s / max_occ : 1;
+    const int64_t c = (s + step - 1) / step;                  // rows k, k+step, ... below k+s
+    return (int)(c < max_occ ? c : max_occ);
+}
+__global__ __launch_bounds__(256) void fmi_sa_count(const gab_smem *__restrict__ sm, int64_t n, int32_t max_occ,
+                                                    int32_t *counts) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) counts[i] = sa_count_of(sm[i].s, max_occ);
+}
+// exclusive offsets from the counts and the scanned block sums (same scan kernels as the SMEM compaction)
+__global__ __launch_bounds__(256) void fmi_sa_offsets(const int32_t *counts, int64_t n, const int64_t *block_off, int64_t *coord_off) {
+    __shared__ int32_t sh[256];
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int c = i < n ? counts[i] : 0;
+    sh[threadIdx.x] = c;
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {
+        const int v = (int)threadIdx.x >= o ? sh[threadIdx.x - o] : 0;
+        __syncthreads();
+        sh[threadIdx.x] += v;
+        __syncthreads();
+    }
+    if (i < n) coord_off[i] = block_off[blockIdx.x] + sh[threadIdx.x] - c;
+}
+// One lane resolves one BWT row at a time and immediately takes the next row (of the same SMEM, else the next SMEM of
+// the wave's chunk) when it is done: LF walks have a geometric length (mean 7 steps, no bound), so lanes that waited
+// for the longest walk of a fixed assignment would idle most of the time.  Every wave step is one LF step = one random
+// CP_OCC record for every lane that has a row.
+__global__ __launch_bounds__(64) void fmi_sa_kernel(FmiIdx ix, SaIdx sa, const gab_smem *__restrict__ sm, int64_t n, int32_t max_occ,
+                                                    const int64_t *__restrict__ coord_off, int64_t *coords, SaCounters *ct) {
+    __shared__ int chunk_next;
+    const int lane = threadIdx.x;
+    unsigned long long steps = 0;
+    for (;;) {
+        // ---- the wave takes its next chunk of SMEMs
+        int64_t c0;
+        {
+            int v = 0;
+            if (lane == 0) v = atomicAdd(&ct->next_chunk, 1);
+            v = __shfl(v, 0);
+            c0 = (int64_t)v * kSaChunk;
+        }
+        if (c0 >= n) break;
+        const int64_t c1 = c0 + kSaChunk < n ? c0 + kSaChunk : n;
+        if (lane == 0) chunk_next = 0;
+        __syncthreads();
+        // ---- lane state: the SMEM it works on and the row of it being resolved
+        bool have = false;                 // a row is in flight
+        int cnt = 0, t = 0;                // rows of the current SMEM, next row index
+        int64_t k = 0, stp = 1, out = 0;   // first row, row stride, output position of row 0
+        int64_t sp = 0, offset = 0;
+        bool exhausted = false;
+        for (;;) {
+            if (!have) {
+                // next row of the current SMEM, else next SMEM(s) of the chunk
+                while (t >= cnt && !exhausted) {
+                    const int64_t i = c0 + atomicAdd(&chunk_next, 1);
+                    if (i >= c1) { exhausted = true; break; }
+                    const gab_smem s = sm[i];
+                    cnt = sa_count_of(s.s, max_occ); t = 0;
+                    k = s.k; stp = s.s > max_occ ? s.s / max_occ : 1; out = coord_off[i];
+                }
+                if (t < cnt) { sp = k + (int64_t)t * stp; offset = 0; have = true; }
+            }
+            if (__all(!have)) break;       // chunk done (every lane is out of rows)
+            if (have) {
+                if ((sp & 7) == 0) {
+                    coords[out + t] = ((int64_t)sa.ms[sp >> 3] << 32) + (int64_t)sa.ls[sp >> 3] + offset;
+                    t++; have = false;
+                } else {
+                    int64_t cnt4[4]; uint64_t bits[4];
+                    load_rec(ix.cp_occ + (sp >> 6), cnt4, bits);
+                    const int y = 63 - (int)(sp & 63);
+                    const int b = (bits[0] >> y) & 1 ? 0 : (bits[1] >> y) & 1 ? 1 : (bits[2] >> y) & 1 ? 2 : (bits[3] >> y) & 1 ? 3 : 4;
+                    if (b == 4) { coords[out + t] = offset; t++; have = false; }       // the sentinel row
+                    else {
+                        const int ysp = (int)(sp & 63);
+                        const uint64_t m = ysp ? ~0ull << (64 - ysp) : 0ull;
+                        const uint64_t bb = b == 0 ? bits[0] : b == 1 ? bits[1] : b == 2 ? bits[2] : bits[3];
+                        const int64_t cc = b == 0 ? cnt4[0] : b == 1 ? cnt4[1] : b == 2 ? cnt4[2] : cnt4[3];
+                        sp = ix.count[b] + cc + __popcll(bb & m);
+                        offset++; steps++;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    for (int o = 32; o > 0; o >>= 1) steps += __shfl_xor(steps, o);
+    if (lane == 0 && steps) atomicAdd(&ct->lf_steps, steps);
+}
+
 }  // namespace
 
 // =============================================================================== host side
@@ -631,6 +731,10 @@ struct gab_fmi {
     gab_devbuf out;         // compacted SMEMs
     gab_devbuf roff;        // read_off (nreads + 1)
     gab_devbuf io;          // staging for the host entry point
+    gab_devbuf sa;          // sampled suffix array: int8 ms bytes, then uint32 low words
+    gab_devbuf sa_ws, sa_off, sa_coords, sa_io;
+    SaIdx sa_ix = {nullptr, nullptr};
+    int64_t sa_lf_steps = 0; float sa_ms = 0; bool have_sa_stats = false;
     size_t scratch_budget = (size_t)6 << 30;
     hipEvent_t ev[2] = {nullptr, nullptr};
     FmiCounters *h_ct = nullptr;
@@ -705,7 +809,7 @@ extern "C" int gab_fmi_load(int device, const char *prefix, gab_fmi **out) {
     if (!f) { gab_set_error("gab_fmi_load: cannot open %s", name); return GAB_EINVAL; }
     int64_t ref_seq_len = 0, count[5], sentinel = -1;
     int rc = GAB_OK;
-    void *host = nullptr;
+    void *host = nullptr, *sa_host = nullptr;
     do {
         if (fread(&ref_seq_len, 8, 1, f) != 1 || fread(count, 8, 5, f) != 5 || ref_seq_len <= 0 ||
             ref_seq_len > 0x7fffffffffll) { gab_set_error("gab_fmi_load: %s: bad header", name); rc = GAB_EINVAL; break; }
@@ -713,14 +817,21 @@ extern "C" int gab_fmi_load(int device, const char *prefix, gab_fmi **out) {
         host = malloc(bytes);
         if (!host) { gab_set_error("gab_fmi_load: out of host memory (%zu bytes)", bytes); rc = GAB_ENOMEM; break; }
         if (fread(host, sizeof(CpOcc), n_occ, f) != n_occ) { gab_set_error("gab_fmi_load: %s: truncated", name); rc = GAB_EINVAL; break; }
-        // skip the sampled suffix array (SA_COMPX = 3: one int8 + one uint32 per 8 rows), FMI_search.cpp:439-447
+        // the sampled suffix array (SA_COMPX = 3: one int8 + one uint32 per 8 rows), FMI_search.cpp:439-447; seeding
+        // does not need it, gab_fmi_sa_lookup does
         const int64_t n_sa = (ref_seq_len >> 3) + 1;
-        if (fseek(f, (long)(n_sa * 5), SEEK_CUR) != 0 || fread(&sentinel, 8, 1, f) != 1) {
-            gab_set_error("gab_fmi_load: %s: truncated (sentinel index)", name); rc = GAB_EINVAL; break;
+        sa_host = malloc((size_t)n_sa * 5);
+        if (!sa_host) { gab_set_error("gab_fmi_load: out of host memory"); rc = GAB_ENOMEM; break; }
+        if (fread(sa_host, 1, (size_t)n_sa * 5, f) != (size_t)n_sa * 5 || fread(&sentinel, 8, 1, f) != 1) {
+            gab_set_error("gab_fmi_load: %s: truncated (suffix array / sentinel index)", name); rc = GAB_EINVAL; break;
         }
         rc = gab_fmi_create(device, ref_seq_len, count, host, sentinel, out);
+        if (rc == GAB_OK) {
+            rc = gab_fmi_set_sa(*out, (const int8_t *)sa_host, (const uint32_t *)((const char *)sa_host + n_sa));
+            if (rc) { gab_fmi_destroy(*out); *out = nullptr; }
+        }
     } while (0);
-    free(host);
+    free(host); free(sa_host);
     fclose(f);
     return rc;
 }
@@ -728,7 +839,7 @@ extern "C" int gab_fmi_load(int device, const char *prefix, gab_fmi **out) {
 extern "C" void gab_fmi_destroy(gab_fmi *h) {
     if (!h) return;
     gab_device_guard g(h->device);
-    h->index.release(); h->kmer.release(); h->ws.release(); h->prev.release(); h->slots.release(); h->out.release(); h->roff.release();
+    h->index.release(); h->kmer.release(); h->sa.release(); h->sa_ws.release(); h->sa_off.release(); h->sa_coords.release(); h->sa_io.release(); h->ws.release(); h->prev.release(); h->slots.release(); h->out.release(); h->roff.release();
     h->io.release();
     for (int k = 0; k < 2; k++) if (h->ev[k]) (void)hipEventDestroy(h->ev[k]);
     if (h->h_ct) (void)hipHostFree(h->h_ct);
@@ -932,5 +1043,117 @@ extern "C" int gab_fmi_last_records(gab_fmi *h, int64_t *cp_occ_records) {
     GAB_CHECK(h, "gab_fmi_last_records: NULL handle");
     GAB_CHECK(h->have_stats, "gab_fmi_last_records: no completed run on this handle");
     if (cp_occ_records) *cp_occ_records = h->rec_reads;
+    return GAB_OK;
+}
+
+// ---- suffix-array look-up: host side -----------------------------------------------------------------------------
+extern "C" int gab_fmi_set_sa(gab_fmi *h, const int8_t *sa_ms_byte, const uint32_t *sa_ls_word) {
+    GAB_CHECK(h, "gab_fmi_set_sa: NULL handle");
+    GAB_CHECK(sa_ms_byte && sa_ls_word, "gab_fmi_set_sa: NULL argument");
+    gab_device_guard g(h->device);
+    const size_t n_sa = (size_t)((h->ix.ref_seq_len >> 3) + 1), o_ls = (n_sa + 255) & ~(size_t)255;
+    int rc = h->sa.reserve(o_ls + 4 * n_sa);
+    if (rc) return rc;
+    GAB_HIP(hipMemcpy(h->sa.p, sa_ms_byte, n_sa, hipMemcpyHostToDevice));
+    GAB_HIP(hipMemcpy(h->sa.as<char>() + o_ls, sa_ls_word, 4 * n_sa, hipMemcpyHostToDevice));
+    h->sa_ix.ms = h->sa.as<int8_t>();
+    h->sa_ix.ls = (const uint32_t *)(h->sa.as<char>() + o_ls);
+    return GAB_OK;
+}
+
+extern "C" int gab_fmi_sa_lookup_device(gab_fmi *h, const gab_smem *d_smems, int64_t n, int32_t max_occ,
+                                        const int64_t **d_coords, const int64_t **d_coord_off, int64_t *total, void *stream_) {
+    GAB_CHECK(h, "gab_fmi_sa_lookup_device: NULL handle");
+    GAB_CHECK(h->sa_ix.ms, "gab_fmi_sa_lookup_device: the handle has no suffix array (gab_fmi_load or gab_fmi_set_sa)");
+    GAB_CHECK(n >= 0 && n < (1ll << 31), "gab_fmi_sa_lookup_device: n out of range");
+    GAB_CHECK(max_occ >= 1, "gab_fmi_sa_lookup_device: max_occ must be >= 1");
+    GAB_CHECK(total, "gab_fmi_sa_lookup_device: NULL total");
+    h->have_sa_stats = false;
+    *total = 0;
+    gab_device_guard g(h->device);
+    hipStream_t s = (hipStream_t)stream_;
+    int rc = h->sa_off.reserve(8 * (size_t)(n + 1));
+    if (rc) return rc;
+    if (d_coord_off) *d_coord_off = h->sa_off.as<int64_t>();
+    if (d_coords) *d_coords = nullptr;
+    if (n == 0) { GAB_HIP(hipMemsetAsync(h->sa_off.p, 0, 8, s)); return GAB_OK; }
+    GAB_CHECK(d_smems, "gab_fmi_sa_lookup_device: NULL buffer");
+    const int64_t blocks = gab_ceil_div(n, 256);
+    const size_t o_counts = 256, o_bs = (o_counts + 4 * (size_t)n + 63) & ~(size_t)63;
+    rc = h->sa_ws.reserve(o_bs + 8 * (size_t)(blocks + 1) + 64);
+    if (rc) return rc;
+    char *wb = h->sa_ws.as<char>();
+    SaCounters *d_ct = (SaCounters *)wb;
+    int32_t *d_counts = (int32_t *)(wb + o_counts);
+    int64_t *d_bs = (int64_t *)(wb + o_bs);
+    int64_t *d_off = h->sa_off.as<int64_t>();
+    GAB_HIP(hipMemsetAsync(d_ct, 0, sizeof(SaCounters), s));
+    GAB_HIP(hipEventRecord(h->ev[0], s));
+    hipLaunchKernelGGL(fmi_sa_count, dim3((unsigned)blocks), dim3(256), 0, s, d_smems, n, max_occ, d_counts);
+    // block sums -> exclusive scan; the scan kernel leaves the grand total in block_sums[nblocks]
+    hipLaunchKernelGGL(fmi_block_sums, dim3((unsigned)blocks), dim3(256), 0, s, d_counts, (int32_t)n, d_bs);
+    hipLaunchKernelGGL(fmi_scan_blocks, dim3(1), dim3(1024), 0, s, d_bs, (int32_t)blocks, (int64_t)0);
+    hipLaunchKernelGGL(fmi_sa_offsets, dim3((unsigned)blocks), dim3(256), 0, s, d_counts, n, d_bs, d_off);
+    GAB_HIP(hipGetLastError());
+    // total = off[n-1] + counts[n-1]
+    int64_t last_off = 0; int32_t last_cnt = 0;
+    GAB_HIP(hipMemcpyAsync(&last_off, d_off + (n - 1), 8, hipMemcpyDeviceToHost, s));
+    GAB_HIP(hipMemcpyAsync(&last_cnt, d_counts + (n - 1), 4, hipMemcpyDeviceToHost, s));
+    GAB_HIP(hipStreamSynchronize(s));
+    const int64_t tot = last_off + last_cnt;
+    GAB_HIP(hipMemcpyAsync(d_off + n, &tot, 8, hipMemcpyHostToDevice, s));
+    rc = h->sa_coords.reserve(8 * (size_t)std::max<int64_t>(tot, 1));
+    if (rc) return rc;
+    int n_cu = 256;
+    { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, h->device) == hipSuccess) n_cu = prop.multiProcessorCount; }
+    const int64_t chunks = gab_ceil_div(n, kSaChunk);
+    const unsigned waves = (unsigned)std::min<int64_t>(chunks, (int64_t)n_cu * 32);
+    hipLaunchKernelGGL(fmi_sa_kernel, dim3(waves), dim3(64), 0, s, h->ix, h->sa_ix, d_smems, n, max_occ, d_off, h->sa_coords.as<int64_t>(), d_ct);
+    GAB_HIP(hipGetLastError());
+    GAB_HIP(hipEventRecord(h->ev[1], s));
+    SaCounters hc;
+    GAB_HIP(hipMemcpyAsync(&hc, d_ct, sizeof hc, hipMemcpyDeviceToHost, s));
+    GAB_HIP(hipStreamSynchronize(s));
+    GAB_HIP(hipEventElapsedTime(&h->sa_ms, h->ev[0], h->ev[1]));
+    h->sa_lf_steps = (int64_t)hc.lf_steps;
+    h->have_sa_stats = true;
+    *total = tot;
+    if (d_coords) *d_coords = h->sa_coords.as<int64_t>();
+    return GAB_OK;
+}
+
+extern "C" int gab_fmi_sa_lookup(gab_fmi *h, const gab_smem *smems, int64_t n, int32_t max_occ, int64_t **coords,
+                                 int64_t **coord_off, int64_t *total) {
+    GAB_CHECK(h, "gab_fmi_sa_lookup: NULL handle");
+    GAB_CHECK(coords && coord_off && total, "gab_fmi_sa_lookup: NULL output argument");
+    *coords = nullptr; *coord_off = nullptr; *total = 0;
+    GAB_CHECK(n >= 0, "gab_fmi_sa_lookup: n < 0");
+    GAB_CHECK(n == 0 || smems, "gab_fmi_sa_lookup: NULL buffer");
+    gab_device_guard g(h->device);
+    hipStream_t s = nullptr;
+    int rc = h->sa_io.reserve(sizeof(gab_smem) * (size_t)std::max<int64_t>(n, 1));
+    if (rc) return rc;
+    if (n) GAB_HIP(hipMemcpyAsync(h->sa_io.p, smems, sizeof(gab_smem) * (size_t)n, hipMemcpyHostToDevice, s));
+    const int64_t *d_c = nullptr, *d_o = nullptr;
+    int64_t tot = 0;
+    rc = gab_fmi_sa_lookup_device(h, h->sa_io.as<gab_smem>(), n, max_occ, &d_c, &d_o, &tot, s);
+    if (rc) return rc;
+    int64_t *hc = (int64_t *)malloc(8 * (size_t)std::max<int64_t>(tot, 1)), *ho = (int64_t *)malloc(8 * (size_t)(n + 1));
+    if (!hc || !ho) { free(hc); free(ho); gab_set_error("gab_fmi_sa_lookup: out of host memory"); return GAB_ENOMEM; }
+    if (hipMemcpy(ho, d_o, 8 * (size_t)(n + 1), hipMemcpyDeviceToHost) != hipSuccess ||
+        (tot && hipMemcpy(hc, d_c, 8 * (size_t)tot, hipMemcpyDeviceToHost) != hipSuccess)) {
+        free(hc); free(ho); gab_set_error("gab_fmi_sa_lookup: D2H copy failed"); return GAB_EDEVICE;
+    }
+    *coords = hc; *coord_off = ho; *total = tot;
+    return GAB_OK;
+}
+
+extern "C" void gab_fmi_free_coords(int64_t *p) { free(p); }
+
+extern "C" int gab_fmi_last_sa_stats(gab_fmi *h, int64_t *lf_steps, float *kernel_ms) {
+    GAB_CHECK(h, "gab_fmi_last_sa_stats: NULL handle");
+    GAB_CHECK(h->have_sa_stats, "gab_fmi_last_sa_stats: no completed look-up on this handle");
+    if (lf_steps) *lf_steps = h->sa_lf_steps;
+    if (kernel_ms) *kernel_ms = h->sa_ms;
     return GAB_OK;
 }

@@ -59,3 +59,31 @@ class FMI_search:
         r = C.c_int64(0)
         check(lib().gab_fmi_last_records(self._h, C.byref(r)))
         return {"ext_calls": e.value, "smems": n.value, "kernel_ms": k.value, "cp_occ_records": r.value}
+
+    # ---- suffix-array look-up (FMI_search::get_sa_entries, FMI_search.cpp:1177-1196)
+    def set_sa(self, sa_ms_byte, sa_ls_word):
+        ms = np.ascontiguousarray(sa_ms_byte, np.int8); ls = np.ascontiguousarray(sa_ls_word, np.uint32)
+        check(lib().gab_fmi_set_sa(self._h, _p(ms), _p(ls)))
+
+    def get_sa_entries(self, smems, max_occ):
+        """smems: structured array (SMEM_DTYPE) -> (coords int64[total], coord_off int64[n+1])"""
+        sm = np.ascontiguousarray(smems)
+        co = C.c_void_p(); off = C.c_void_p(); tot = C.c_int64(0)
+        check(lib().gab_fmi_sa_lookup(self._h, _p(sm), C.c_int64(len(sm)), C.c_int32(max_occ), C.byref(co), C.byref(off), C.byref(tot)))
+        n = tot.value
+        coords = np.ctypeslib.as_array(C.cast(co, C.POINTER(C.c_int64)), shape=(max(n, 1),))[:n].copy()
+        coff = np.ctypeslib.as_array(C.cast(off, C.POINTER(C.c_int64)), shape=(len(sm) + 1,)).copy()
+        lib().gab_fmi_free_coords(co); lib().gab_fmi_free_coords(off)
+        return coords, coff
+
+    def get_sa_entries_device(self, d_smems, n, max_occ, stream=0):
+        """device pointer of gab_smem[n] (e.g. from seed_device) -> (device ptr coords, device ptr coord_off, total)"""
+        co = C.c_void_p(); off = C.c_void_p(); tot = C.c_int64(0)
+        check(lib().gab_fmi_sa_lookup_device(self._h, C.c_void_p(d_smems), C.c_int64(n), C.c_int32(max_occ), C.byref(co),
+                                             C.byref(off), C.byref(tot), C.c_void_p(stream)))
+        return co.value, off.value, tot.value
+
+    def last_sa_stats(self):
+        st = C.c_int64(0); ms = C.c_float(0)
+        check(lib().gab_fmi_last_sa_stats(self._h, C.byref(st), C.byref(ms)))
+        return {"lf_steps": st.value, "kernel_ms": ms.value}

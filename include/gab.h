@@ -220,6 +220,27 @@ int gab_fmi_last_stats(gab_fmi *h, int64_t *ext_calls, int64_t *nsmem, float *ke
  * ends share a record, else two) -- the random index traffic of the run is 64 B x this number */
 int gab_fmi_last_records(gab_fmi *h, int64_t *cp_occ_records);
 
+/* ---- fmi: suffix-array look-up -- the step BWA-MEM2 takes right after seeding:
+ *     FMI_search::get_sa_entries(SMEM *smemArray, int64_t *coordArray, int32_t *coordCountArray, uint32_t count,
+ *                                int32_t max_occ, int tid)          FMI_search.cpp:1177-1196
+ *     -> get_sa_entry_compressed (SA_COMPX = 3)                     FMI_search.cpp:1103-1175
+ * For SMEM i the BWT rows k, k+step, ... (< k+s, at most max_occ of them; step = s > max_occ ? s / max_occ : 1) are
+ * resolved to reference coordinates: a row that is a multiple of 8 is stored, any other row walks the LF mapping (one
+ * CP_OCC record per step) to a stored row or the sentinel.  Coordinates come back to back in SMEM order;
+ * coord_off[n + 1] delimits them (the reference only returns the running total).
+ * gab_fmi_load reads the sampled suffix array from <prefix>.bwt.2bit.64; a handle made by gab_fmi_create gets it
+ * with gab_fmi_set_sa (arrays of (reference_seq_len >> 3) + 1 entries, FMI_search.cpp:439-447). */
+int gab_fmi_set_sa(gab_fmi *h, const int8_t *sa_ms_byte, const uint32_t *sa_ls_word);
+/* host buffers; *coords and *coord_off are malloc'ed by the library, release them with gab_fmi_free_coords */
+int gab_fmi_sa_lookup(gab_fmi *h, const gab_smem *smems, int64_t n, int32_t max_occ, int64_t **coords,
+                      int64_t **coord_off, int64_t *total);
+void gab_fmi_free_coords(int64_t *p);
+/* device buffers; the outputs point into memory owned by the handle, valid until the next call on it */
+int gab_fmi_sa_lookup_device(gab_fmi *h, const gab_smem *d_smems, int64_t n, int32_t max_occ,
+                             const int64_t **d_coords, const int64_t **d_coord_off, int64_t *total, void *stream);
+/* last look-up: LF-mapping steps taken (one random 64-byte CP_OCC record each) and kernel ms */
+int gab_fmi_last_sa_stats(gab_fmi *h, int64_t *lf_steps, float *kernel_ms);
+
 #ifdef __cplusplus
 }
 #endif

@@ -30,8 +30,12 @@ int oracle_fmi_load(const char *prefix, oracle_fmindex *idx) {
     idx->cp_occ_size = (idx->ref_seq_len >> 6) + 1;
     idx->cp_occ = (oracle_cp_occ *)malloc(sizeof(oracle_cp_occ) * (size_t)idx->cp_occ_size);
     if (fread(idx->cp_occ, sizeof(oracle_cp_occ), (size_t)idx->cp_occ_size, f) != (size_t)idx->cp_occ_size) { fclose(f); return -2; }
+    /* sampled suffix array, FMI_search.cpp:439-447: int8 most-significant bytes, then uint32 low words */
     const int64_t n_sa = (idx->ref_seq_len >> 3) + 1;
-    if (fseek(f, n_sa * 5, SEEK_CUR) != 0 || fread(&idx->sentinel_index, 8, 1, f) != 1) { fclose(f); return -2; }
+    idx->sa_ms_byte = (int8_t *)malloc((size_t)n_sa);
+    idx->sa_ls_word = (uint32_t *)malloc(4 * (size_t)n_sa);
+    if (fread(idx->sa_ms_byte, 1, (size_t)n_sa, f) != (size_t)n_sa || fread(idx->sa_ls_word, 4, (size_t)n_sa, f) != (size_t)n_sa ||
+        fread(&idx->sentinel_index, 8, 1, f) != 1) { fclose(f); return -2; }
     fclose(f);
     return 0;
 }
@@ -44,9 +48,19 @@ void oracle_fmi_from_arrays(oracle_fmindex *idx, int64_t ref_seq_len, const int6
     idx->cp_occ = (oracle_cp_occ *)malloc(sizeof(oracle_cp_occ) * (size_t)idx->cp_occ_size);
     memcpy(idx->cp_occ, cp_occ, sizeof(oracle_cp_occ) * (size_t)idx->cp_occ_size);
     idx->sentinel_index = sentinel_index;
+    idx->sa_ms_byte = NULL; idx->sa_ls_word = NULL;
 }
 
-void oracle_fmi_free(oracle_fmindex *idx) { free(idx->cp_occ); idx->cp_occ = NULL; }
+void oracle_fmi_set_sa(oracle_fmindex *idx, const int8_t *sa_ms_byte, const uint32_t *sa_ls_word) {
+    const size_t n_sa = (size_t)((idx->ref_seq_len >> 3) + 1);
+    idx->sa_ms_byte = (int8_t *)malloc(n_sa); idx->sa_ls_word = (uint32_t *)malloc(4 * n_sa);
+    memcpy(idx->sa_ms_byte, sa_ms_byte, n_sa); memcpy(idx->sa_ls_word, sa_ls_word, 4 * n_sa);
+}
+
+void oracle_fmi_free(oracle_fmindex *idx) {
+    free(idx->cp_occ); free(idx->sa_ms_byte); free(idx->sa_ls_word);
+    idx->cp_occ = NULL; idx->sa_ms_byte = NULL; idx->sa_ls_word = NULL;
+}
 
 typedef struct { int64_t *calls; const oracle_fmindex *x; } fctx;
 
@@ -217,3 +231,51 @@ int64_t oracle_fmi_batch(const oracle_fmindex *idx, const uint8_t *enc, int32_t 
 }
 
 void oracle_fmi_release(oracle_smem *p) { free(p); }
+
+/* ---- suffix-array look-up ------------------------------------------------------------------ */
+/* get_sa_entry_compressed, FMI_search.cpp:1103-1175: rows that are a multiple of 8 are stored; any other row walks the
+ * LF mapping (one CP_OCC record per step) until it reaches a stored row or the sentinel, counting the steps. */
+static int64_t sa_entry_compressed(const oracle_fmindex *x, int64_t pos, int64_t *steps) {
+    int64_t offset = 0, sp = pos;
+    while ((sp & 7) != 0) {
+        const oracle_cp_occ *e = &x->cp_occ[sp >> 6];
+        const int y = 64 - (int)(sp & 63) - 1;
+        int b = 4;
+        for (int c = 0; c < 4; c++) if ((e->one_hot_bwt_str[c] >> y) & 1) { b = c; break; }
+        if (b == 4) return offset;                                      /* the sentinel row: SA = 0 */
+        sp = x->count[b] + occ(x, sp, b);
+        offset++;
+        if (steps) ++*steps;
+    }
+    return ((int64_t)x->sa_ms_byte[sp >> 3] << 32) + (int64_t)x->sa_ls_word[sp >> 3] + offset;
+}
+
+int64_t oracle_fmi_sa_count(const oracle_smem *smems, int64_t n, int32_t max_occ, int64_t *coord_off) {
+    int64_t total = 0;
+    for (int64_t i = 0; i < n; i++) {                                   /* loop shape of FMI_search.cpp:1177-1196 */
+        coord_off[i] = total;
+        const int64_t hi = smems[i].k + smems[i].s, step = smems[i].s > max_occ ? smems[i].s / max_occ : 1;
+        int32_t c = 0;
+        for (int64_t j = smems[i].k; j < hi && c < max_occ; j += step) c++;
+        total += c;
+    }
+    coord_off[n] = total;
+    return total;
+}
+
+int64_t oracle_fmi_sa_lookup(const oracle_fmindex *idx, const oracle_smem *smems, int64_t n, int32_t max_occ,
+                             const int64_t *coord_off, int64_t *coords, int64_t *lf_steps) {
+    if (!idx->sa_ms_byte || !idx->sa_ls_word) return -1;
+    int64_t steps = 0;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 1024) reduction(+ : steps)
+#endif
+    for (int64_t i = 0; i < n; i++) {
+        const int64_t hi = smems[i].k + smems[i].s, step = smems[i].s > max_occ ? smems[i].s / max_occ : 1;
+        int32_t c = 0;
+        for (int64_t j = smems[i].k; j < hi && c < max_occ; j += step, c++)
+            coords[coord_off[i] + c] = sa_entry_compressed(idx, j, &steps);
+    }
+    if (lf_steps) *lf_steps = steps;
+    return coord_off[n];
+}

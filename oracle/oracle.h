@@ -75,6 +75,8 @@ typedef struct { int64_t cp_count[4]; uint64_t one_hot_bwt_str[4]; } oracle_cp_o
 typedef struct {
     int64_t ref_seq_len, count[5] /* already +1 */, cp_occ_size, sentinel_index;
     oracle_cp_occ *cp_occ;
+    int8_t *sa_ms_byte;      /* sampled suffix array (SA_COMPX = 3: one entry per 8 BWT rows), NULL if not loaded */
+    uint32_t *sa_ls_word;
 } oracle_fmindex;
 typedef struct { uint32_t rid, m, n, pad; int64_t k, l, s; } oracle_smem;              /* SMEM, 40 bytes */
 int oracle_fmi_load(const char *prefix, oracle_fmindex *idx);                          /* <prefix>.bwt.2bit.64 */
@@ -88,6 +90,14 @@ int64_t oracle_fmi_batch(const oracle_fmindex *idx, const uint8_t *enc, int32_t 
                          int64_t nreads, int min_seed_len, int threads, oracle_smem **out_p, int64_t *read_off,
                          int64_t *ext_calls);
 void oracle_fmi_release(oracle_smem *p);
+/* suffix-array look-up of SMEM intervals (FMI_search.cpp:1103-1196): for SMEM i the rows k, k+step, ... (< k+s, at
+ * most max_occ of them, step = s > max_occ ? s / max_occ : 1) are resolved with get_sa_entry_compressed; coords are
+ * written back to back, coord_off[n+1] delimits them.  Returns the total, or -1 if the index has no SA arrays.
+ * lf_steps (optional) receives the number of LF-mapping steps taken. */
+void oracle_fmi_set_sa(oracle_fmindex *idx, const int8_t *sa_ms_byte, const uint32_t *sa_ls_word);
+int64_t oracle_fmi_sa_count(const oracle_smem *smems, int64_t n, int32_t max_occ, int64_t *coord_off);
+int64_t oracle_fmi_sa_lookup(const oracle_fmindex *idx, const oracle_smem *smems, int64_t n, int32_t max_occ,
+                             const int64_t *coord_off, int64_t *coords, int64_t *lf_steps);
 
 #ifdef __cplusplus
 }

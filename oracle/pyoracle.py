@@ -131,7 +131,7 @@ def wfa_cigars(res, idx=None):
 # ------------------------------------------------------------------ fmi
 class FmIndex(C.Structure):
     _fields_ = [("ref_seq_len", C.c_int64), ("count", C.c_int64 * 5), ("cp_occ_size", C.c_int64),
-                ("sentinel_index", C.c_int64), ("cp_occ", C.c_void_p)]
+                ("sentinel_index", C.c_int64), ("cp_occ", C.c_void_p), ("sa_ms_byte", C.c_void_p), ("sa_ls_word", C.c_void_p)]
 
 
 SMEM_DTYPE = np.dtype([("rid", np.uint32), ("m", np.uint32), ("n", np.uint32), ("pad", np.uint32),
@@ -157,6 +157,20 @@ def fmi(idx, reads, min_seed_len=19, threads=0, want_calls=False):
     arr = np.ctypeslib.as_array(C.cast(out, C.POINTER(C.c_uint8)), shape=(max(n, 1) * 40,))[:n * 40].copy().view(SMEM_DTYPE)
     L.oracle_fmi_release(out)
     return (arr, off, calls.value) if want_calls else (arr, off)
+
+
+def fmi_sa_lookup(idx, smems, max_occ):
+    """suffix-array coordinates of SMEM intervals -> (coords int64[total], coord_off int64[n+1], lf_steps)"""
+    L = lib()
+    L.oracle_fmi_sa_count.restype = C.c_int64; L.oracle_fmi_sa_lookup.restype = C.c_int64
+    sm = np.ascontiguousarray(smems)
+    off = np.zeros(len(sm) + 1, np.int64)
+    total = L.oracle_fmi_sa_count(_p(sm), C.c_int64(len(sm)), C.c_int32(max_occ), _p(off))
+    coords = np.zeros(max(total, 1), np.int64); steps = C.c_int64(0)
+    rc = L.oracle_fmi_sa_lookup(C.byref(idx), _p(sm), C.c_int64(len(sm)), C.c_int32(max_occ), _p(off), _p(coords), C.byref(steps))
+    if rc < 0:
+        raise ValueError("the index has no suffix-array samples")
+    return coords[:total], off, steps.value
 
 
 def fmi_text(smems, read_off):

@@ -137,6 +137,21 @@ def make_fmi(m):
                "rl_min": 60, "rl_max": 151, "index_sha256": hashlib.sha256(idx).hexdigest(), "index_bytes": len(idx),
                "reference": "fmi/fmi.cpp + bwa-mem2 library, and bwa-mem2 index, built by oracle/Makefile (clang++)",
                "command": "bwa_mem2_index_ref index <fa>; fmi_ref <fa> <fq> 64 19 1 ; drop 6 header lines"}
+    # suffix-array look-up: the driver never calls it, so the reference's own
+    # FMI_search::get_sa_entries is driven by oracle/ref_harness/fmi_sa_ref.cpp on the SMEMs of this fixture
+    import numpy as np
+    oidx = pyoracle.fmi_load(fa)
+    sm, off = pyoracle.fmi(oidx, reads, 19)
+    assert pyoracle.fmi_text(sm, off) == outs[0], "oracle SMEMs differ from the reference's"
+    smf = os.path.join(HERE, "_smems.bin"); cof = os.path.join(HERE, "_coords.bin")
+    sm.tofile(smf)
+    with open(os.path.join(HERE, name + ".sa_expected.txt"), "w") as f:
+        for max_occ in (500, 2):
+            subprocess.run([pyoracle.ref_path("fmi_sa_ref"), fa, smf, str(max_occ), cof], capture_output=True, check=True)
+            co = np.fromfile(cof, np.int64)
+            f.write(f"max_occ {max_occ} {len(co)}\n" + "\n".join(str(int(v)) for v in co) + "\n")
+    os.remove(smf); os.remove(cof)
+    m[name]["sa_command"] = "fmi_sa_ref <fa> <oracle SMEMs of the fixture, 40-byte records> <max_occ> <out> for max_occ 500 and 2"
     for ext in (".0123", ".amb", ".ann", ".pac", ".bwt.2bit.64"):
         os.remove(fa + ext)
 

@@ -1,4 +1,5 @@
 """GPU parity: fmi HIP kernel (through the C ABI) vs the oracle and the golden output."""
+import ctypes as C
 import numpy as np
 import pytest
 
@@ -101,4 +102,53 @@ def test_device_resident(tmp_path):
     off = np.zeros(reads.n + 1, np.int64)
     assert hip.hipMemcpy(off.ctypes.data_as(C.c_void_p), C.c_void_p(d_off), C.c_size_t(8 * (reads.n + 1)), C.c_int(2)) == 0
     same((host.view(SMEM_DTYPE), off), (w, woff))
+    f.close()
+
+
+# ---- suffix-array look-up -------------------------------------------------------------------
+@pytest.mark.parametrize("rseed,L,n,max_occ", [(91, 400_000, 20000, 500), (92, 400_000, 20000, 3), (93, 30_000, 4000, 1),
+                                                (94, 3_000, 2000, 50)])
+def test_sa_lookup_vs_oracle(tmp_path, rseed, L, n, max_occ):
+    from genarchbench_amd.fmi import FMI_search
+    ref = gabgen.fmi_ref(rseed, L, 10)
+    idx, prefix = build(ref, tmp_path)
+    reads = gabgen.fmi_reads(rseed + 100, ref, n, 40, 151)
+    f = FMI_search(prefix=prefix)                       # gab_fmi_load reads the sampled suffix array from the file
+    sm, _ = f.seed(reads, 19)
+    got, goff = f.get_sa_entries(sm, max_occ)
+    oidx = pyoracle.fmi_load(prefix)
+    want, woff, steps = pyoracle.fmi_sa_lookup(oidx, sm, max_occ)
+    np.testing.assert_array_equal(goff, woff)
+    np.testing.assert_array_equal(got, want)
+    assert f.last_sa_stats()["lf_steps"] == steps
+    f.close()
+
+
+def test_sa_lookup_in_memory_index_and_errors():
+    from genarchbench_amd._lib import GabError
+    from genarchbench_amd.fmi import FMI_search, SMEM_DTYPE
+    ref = gabgen.fmi_ref(95, 50_000, 5)
+    idx = mkindex.FmIndex(ref)
+    f = FMI_search(arrays=(idx.ref_seq_len, idx.count, idx.cp_occ, idx.sentinel_index))
+    reads = gabgen.fmi_reads(96, ref, 500, 80, 151)
+    sm, _ = f.seed(reads, 19)
+    with pytest.raises(GabError):
+        f.get_sa_entries(sm, 10)                        # no suffix array attached yet
+    f.set_sa(idx.sa_ms_byte, idx.sa_ls_word)
+    got, goff = f.get_sa_entries(sm, 10)
+    oidx = pyoracle.FmIndex()
+    cnt = (C.c_int64 * 5)(*[int(x) for x in idx.count])
+    pyoracle.lib().oracle_fmi_from_arrays(C.byref(oidx), C.c_int64(idx.ref_seq_len), cnt, idx.cp_occ.ctypes.data_as(C.c_void_p),
+                                          C.c_int64(idx.sentinel_index))
+    pyoracle.lib().oracle_fmi_set_sa(C.byref(oidx), idx.sa_ms_byte.ctypes.data_as(C.c_void_p), idx.sa_ls_word.ctypes.data_as(C.c_void_p))
+    want, woff, _ = pyoracle.fmi_sa_lookup(oidx, sm, 10)
+    np.testing.assert_array_equal(goff, woff)
+    np.testing.assert_array_equal(got, want)
+    # empty input and the sentinel row (k = sentinel index, s = 1 -> coordinate 0 + walk length)
+    e, eoff = f.get_sa_entries(np.zeros(0, SMEM_DTYPE), 10)
+    assert len(e) == 0 and list(eoff) == [0]
+    one = np.zeros(3, SMEM_DTYPE); one["k"] = [idx.sentinel_index, 0, 8]; one["s"] = [1, 1, 3]
+    g2, o2 = f.get_sa_entries(one, 10)
+    w2, wo2, _ = pyoracle.fmi_sa_lookup(oidx, one, 10)
+    np.testing.assert_array_equal(g2, w2); np.testing.assert_array_equal(o2, wo2)
     f.close()

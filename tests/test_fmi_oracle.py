@@ -82,3 +82,43 @@ def test_oracle_matches_live_reference(tmp_path):
     idx = pyoracle.fmi_load(str(tmp_path / "mine"))
     sm, off = pyoracle.fmi(idx, reads, 19)
     assert pyoracle.fmi_text(sm, off) == want
+
+
+# ---- suffix-array look-up -------------------------------------------------------------------
+def _sa_golden():
+    out, cur = {}, None
+    for line in open(f"{GOLDEN}/fmi_small.sa_expected.txt"):
+        if line.startswith("max_occ"):
+            _, mo, n = line.split(); cur = out.setdefault(int(mo), [])
+        else:
+            cur.append(int(line))
+    return {k: np.array(v, np.int64) for k, v in out.items()}
+
+
+def test_sa_lookup_matches_reference(index_prefix):
+    """oracle_fmi_sa_lookup == the reference's FMI_search::get_sa_entries (driven by oracle/ref_harness) on the
+    SMEMs of the fixture, for max_occ 500 (every row) and 2 (strided rows)"""
+    idx = pyoracle.fmi_load(index_prefix)
+    reads = read_fastq_reads(f"{GOLDEN}/fmi_small.reads.fq")
+    sm, _ = pyoracle.fmi(idx, reads, 19)
+    for max_occ, want in _sa_golden().items():
+        coords, off, _steps = pyoracle.fmi_sa_lookup(idx, sm, max_occ)
+        np.testing.assert_array_equal(coords, want)
+        assert off[-1] == len(want)
+
+
+def test_sa_coordinates_are_occurrences(index_prefix):
+    """size-independent property: every coordinate is a position where the seed occurs in the indexed text
+    (forward strand followed by its reverse complement)"""
+    idx = pyoracle.fmi_load(index_prefix)
+    ref = read_fasta_codes(f"{GOLDEN}/fmi_small.ref.fa")
+    both = np.concatenate([ref, 3 - ref[::-1]]).astype(np.uint8)
+    reads = read_fastq_reads(f"{GOLDEN}/fmi_small.reads.fq")
+    sm, _ = pyoracle.fmi(idx, reads, 19)
+    coords, off, _ = pyoracle.fmi_sa_lookup(idx, sm, 500)
+    for j in range(0, len(sm), 53):
+        r = sm[j]
+        sub = reads.enc[r["rid"], r["m"]:r["n"] + 1]
+        for c in coords[off[j]:off[j + 1]]:
+            np.testing.assert_array_equal(both[c:c + len(sub)], sub)
+        assert off[j + 1] - off[j] == min(int(r["s"]), 500)

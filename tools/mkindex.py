@@ -44,6 +44,9 @@ class FmIndex:
         self.count = np.array(list(r.count), np.int64)
         self.sentinel_index = r.sentinel_index
         self.cp_occ = np.ctypeslib.as_array(C.cast(r.cp_occ, C.POINTER(C.c_uint8)), shape=(r.cp_occ_size * 64,))
+        # sampled suffix array (one entry per 8 rows): most-significant bytes and low words, FMI_search.cpp:439-447
+        self.sa_ms_byte = np.ctypeslib.as_array(C.cast(r.sa_ms_byte, C.POINTER(C.c_int8)), shape=(r.n_sa,))
+        self.sa_ls_word = np.ctypeslib.as_array(C.cast(r.sa_ls_word, C.POINTER(C.c_uint32)), shape=(r.n_sa,))
 
     def write(self, prefix, with_bns=False, name="synthetic"):
         """<prefix>.bwt.2bit.64; with_bns also writes the .ann/.amb/.pac files the reference's loader needs"""
@@ -57,6 +60,6 @@ class FmIndex:
     def close(self):
         if self._raw.cp_occ:
             lib().gab_mkindex_free(C.byref(self._raw))
-            self.cp_occ = None
+            self.cp_occ = None; self.sa_ms_byte = None; self.sa_ls_word = None
 
     __del__ = close
