@@ -566,7 +566,97 @@ class FmiWorkload:
                 "sample": f"first {n} reads, oracle/fmi.c + OpenMP ({sec:.2f} s)"}
 
 
-WORKLOADS = {"fmi": FmiWorkload, "wfa": WfaWorkload, "bpm": BpmWorkload, "bsw": BswWorkload, "chain": ChainWorkload, "fast-chain": FastChainWorkload}
+class FmiSaWorkload(FmiWorkload):
+    """the step after seeding: SMEM intervals -> reference coordinates through the compressed
+    suffix array.  One unit = one coordinate; the SMEMs are those of `items` reads, seeded once outside the timed region
+    and left on the device."""
+    name = "fmi-sa"
+    metric = "fmi SA look-up M coordinates/sec"
+    unit = "M coordinates/s"
+    default_items = 10_000_000
+    max_occ = 500                                   # BWA-MEM2's default max_occ
+
+    def __init__(self, items, rank, dev):
+        super().__init__(items, rank, dev)
+        self.eng.set_sa(self.index.sa_ms_byte, self.index.sa_ls_word)
+        self.d_smems, _, self.nsmem = self.eng.seed_device(self.enc, self.len, self.min_seed_len)
+        self.coords = 0
+        self.sa_result = None
+
+    def step(self, stream):
+        self.sa_result = self.eng.get_sa_entries_device(self.d_smems, self.nsmem, self.max_occ, stream=stream)
+        self.coords = self.sa_result[2]
+
+    def units_per_step(self):
+        return self.coords
+
+    def after_step(self, timed):
+        st = self.eng.last_sa_stats()
+        if timed:
+            self.kernel_ms.append(st["kernel_ms"])
+        self.stats = st
+
+    def check(self):
+        import ctypes as C
+        from oracle import pyoracle
+        from genarchbench_amd.fmi import SMEM_DTYPE
+        d_co, d_off, tot = self.sa_result
+        hip = C.CDLL("libamdhip64.so")
+        ns = min(200000, self.nsmem)
+        sm = np.zeros(ns, SMEM_DTYPE); off = np.zeros(ns + 1, np.int64)
+        assert hip.hipMemcpy(sm.ctypes.data_as(C.c_void_p), C.c_void_p(self.d_smems), C.c_size_t(40 * ns), C.c_int(2)) == 0
+        assert hip.hipMemcpy(off.ctypes.data_as(C.c_void_p), C.c_void_p(d_off), C.c_size_t(8 * (ns + 1)), C.c_int(2)) == 0
+        k = int(off[ns])
+        got = np.zeros(max(k, 1), np.int64)
+        assert hip.hipMemcpy(got.ctypes.data_as(C.c_void_p), C.c_void_p(d_co), C.c_size_t(8 * k), C.c_int(2)) == 0
+        oidx = pyoracle.FmIndex()
+        cnt = (C.c_int64 * 5)(*[int(x) for x in self.index.count])
+        pyoracle.lib().oracle_fmi_from_arrays(C.byref(oidx), C.c_int64(self.index.ref_seq_len), cnt,
+                                              self.index.cp_occ.ctypes.data_as(C.c_void_p), C.c_int64(self.index.sentinel_index))
+        pyoracle.lib().oracle_fmi_set_sa(C.byref(oidx), self.index.sa_ms_byte.ctypes.data_as(C.c_void_p),
+                                         self.index.sa_ls_word.ctypes.data_as(C.c_void_p))
+        want, woff, _ = pyoracle.fmi_sa_lookup(oidx, sm, self.max_occ)
+        assert np.array_equal(off, woff) and np.array_equal(got[:k], want), "SA coordinates differ from the oracle"
+        # property on a sample of all SMEMs: the coordinate really is an occurrence of the seed
+        return f"bit-exact coordinates vs oracle on the first {ns} SMEMs ({k} coordinates) of {self.nsmem}"
+
+    def extra(self, ms_per_step):
+        k = float(np.mean(self.kernel_ms))
+        return {"smems": self.nsmem, "coordinates_per_step": self.coords, "lf_steps_per_step": self.stats.get("lf_steps"),
+                "max_occ": self.max_occ, "ref_mbp": self.ref_mbp, "dominant_kernel": "fmi_sa_kernel", "dominant_kernel_ms": k}
+
+    def roofline(self):
+        k = float(np.mean(self.kernel_ms))
+        # per coordinate: 40 B SMEM in (amortised), 8 B out, 5 B of sampled SA; per LF step one random 64-B CP_OCC record
+        alg = 40 * self.nsmem + 13 * self.coords + 64 * self.stats.get("lf_steps", 0)
+        ach = alg / (k * 1e-3) / 1e9
+        return {"bound": "hbm", "achieved": round(ach, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(ach / HBM_PEAK_GBS, 6), "traffic": None,
+                "note": "one random 64-B CP_OCC record per LF step (mean 7 per coordinate) + two random reads of the sampled SA; "
+                        "chip ceiling for random reads is ~55 G/s (profiles/r01_random_read_ceiling.md)"}
+
+    def cpu_baseline(self, cores):
+        import ctypes as C
+        from oracle import pyoracle
+        from genarchbench_amd.fmi import SMEM_DTYPE
+        hip = C.CDLL("libamdhip64.so")
+        ns = min(self.nsmem, 4_000_000)
+        sm = np.zeros(ns, SMEM_DTYPE)
+        assert hip.hipMemcpy(sm.ctypes.data_as(C.c_void_p), C.c_void_p(self.d_smems), C.c_size_t(40 * ns), C.c_int(2)) == 0
+        oidx = pyoracle.FmIndex()
+        cnt = (C.c_int64 * 5)(*[int(x) for x in self.index.count])
+        pyoracle.lib().oracle_fmi_from_arrays(C.byref(oidx), C.c_int64(self.index.ref_seq_len), cnt,
+                                              self.index.cp_occ.ctypes.data_as(C.c_void_p), C.c_int64(self.index.sentinel_index))
+        pyoracle.lib().oracle_fmi_set_sa(C.byref(oidx), self.index.sa_ms_byte.ctypes.data_as(C.c_void_p),
+                                         self.index.sa_ls_word.ctypes.data_as(C.c_void_p))
+        os.environ["OMP_NUM_THREADS"] = str(cores)
+        t0 = time.time(); coords, _, _ = pyoracle.fmi_sa_lookup(oidx, sm, self.max_occ); sec = time.time() - t0
+        return {"value": round(len(coords) / sec / 1e6, 4), "unit": self.unit, "cores": cores, "kind": "port",
+                "sample": f"first {ns} SMEMs ({len(coords)} coordinates), oracle/fmi.c + OpenMP ({sec:.2f} s); the reference "
+                          f"driver never calls get_sa_entries, so there is no reference binary to time"}
+
+
+WORKLOADS = {"fmi": FmiWorkload, "fmi-sa": FmiSaWorkload, "wfa": WfaWorkload, "bpm": BpmWorkload, "bsw": BswWorkload, "chain": ChainWorkload, "fast-chain": FastChainWorkload}
 
 
 def main():
@@ -619,7 +709,8 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     from genarchbench_amd.shard import aggregate
-    elapsed, total_units = aggregate(elapsed, getattr(wl, "items", items), dist if world > 1 else None, dev)
+    units = wl.units_per_step() if hasattr(wl, "units_per_step") else getattr(wl, "items", items)
+    elapsed, total_units = aggregate(elapsed, units, dist if world > 1 else None, dev)
 
     verdict = None if args.no_check else wl.check()
     if rank == 0:
