@@ -55,9 +55,12 @@ struct BswIO {
     int64_t ref_bytes, qry_bytes, n;
 };
 
-__device__ __forceinline__ int bsw_key(int qlen, int tlen) {
-    int tb = tlen >> 3; if (tb > kTBuckets - 1) tb = kTBuckets - 1;
-    return (qlen - 1) * kTBuckets + tb;
+// (query length, reference length / 8, h0 / 32): lanes of a wave then run the same number of rows AND start with bands of
+// similar width (row -1 is non-zero up to column ~h0, and the band stays ~2 x score wide until it reaches w)
+__device__ __forceinline__ int bsw_key(int qlen, int tlen, int h0) {
+    int tb = tlen >> 3; if (tb > kTBuckets / 4 - 1) tb = kTBuckets / 4 - 1;
+    int hc = h0 >> 5; if (hc > 3) hc = 3;
+    return (qlen - 1) * kTBuckets + tb * 4 + hc;
 }
 
 // ---- pass 1: validate + histogram ------------------------------------------------------
@@ -77,7 +80,7 @@ __global__ __launch_bounds__(256) void bsw_hist(BswIO io, uint32_t *hist, BswSta
             continue;
         }
         mh = h > mh ? h : mh;
-        atomicAdd(&hist[bsw_key(ql, tl)], 1u);
+        atomicAdd(&hist[bsw_key(ql, tl, h)], 1u);
     }
     // wave max of h0, one atomic per wave
     for (int o = 32; o > 0; o >>= 1) { int v = __shfl_xor(mh, o); mh = v > mh ? v : mh; }
@@ -117,7 +120,7 @@ __global__ __launch_bounds__(256) void bsw_scatter(BswIO io, uint32_t *cursor, u
     for (; i < io.n; i += stride) {
         int ql = io.len2[i], tl = io.len1[i];
         if (ql < 1 || ql > GAB_BSW_MAX_QLEN || tl < 1 || tl > GAB_BSW_MAX_TLEN) continue;
-        uint32_t pos = atomicAdd(&cursor[bsw_key(ql, tl)], 1u);
+        uint32_t pos = atomicAdd(&cursor[bsw_key(ql, tl, io.h0[i])], 1u);
         perm[pos] = (uint32_t)i;
     }
 }
