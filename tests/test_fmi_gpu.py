@@ -70,6 +70,40 @@ def test_repetitive_reads_overflow_slots(tmp_path):
     f.close()
 
 
+@pytest.mark.parametrize("lds_entries", [None, "4"])
+def test_repetitive_short_reads_spill_lists(tmp_path, monkeypatch, lds_entries):
+    """reads that fit the LDS path (<= 256 bases) on a repetitive reference: interval lists longer than the LDS ring
+    (forced with a 4-entry ring in the second variant) spill to the global scratch and are fetched one step ahead;
+    some reads also overflow their first-pass output slot"""
+    from genarchbench_amd.fmi import FMI_search
+    rng = np.random.default_rng(6)
+    unit = rng.integers(0, 4, 29).astype(np.uint8)
+    ref = np.concatenate([np.tile(unit, 400), rng.integers(0, 4, 30000).astype(np.uint8), np.tile(3 - unit[::-1], 150)])
+    idx, prefix = build(ref, tmp_path)
+    reads = gabgen.fmi_reads(10, ref, 6000, 120, 250)
+    w, woff, calls = pyoracle.fmi(pyoracle.fmi_load(prefix), reads, 10, want_calls=True)
+    if lds_entries is not None:
+        # the ring size is read once per process: exercise it through the C driver-style environment in a child
+        import subprocess, sys, json, os
+        code = ("import sys, numpy as np; sys.path.insert(0, %r); from tools import gabgen; from genarchbench_amd.fmi import FMI_search;"
+                "reads = gabgen.ReadBatch(np.load(%r), np.load(%r)); f = FMI_search(%r); sm, off = f.seed(reads, 10);"
+                "np.save(%r, sm); np.save(%r, off); print(f.last_stats()['ext_calls'])")
+        e, l = str(tmp_path / "enc.npy"), str(tmp_path / "len.npy")
+        np.save(e, reads.enc); np.save(l, reads.len)
+        so, oo = str(tmp_path / "sm.npy"), str(tmp_path / "off.npy")
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        r = subprocess.run([sys.executable, "-c", code % (root, e, l, prefix, so, oo)], capture_output=True, text=True,
+                           env=dict(os.environ, GAB_FMI_LDS_ENTRIES=lds_entries))
+        assert r.returncode == 0, r.stderr[-2000:]
+        got = (np.load(so), np.load(oo)); ext = int(r.stdout.split()[-1])
+    else:
+        f = FMI_search(prefix)
+        got = f.seed(reads, 10); ext = f.last_stats()["ext_calls"]
+        f.close()
+    same(got, (w, woff))
+    assert ext == calls
+
+
 def test_all_n_and_short_reads(tmp_path):
     from genarchbench_amd.fmi import FMI_search
     ref = gabgen.fmi_ref(5, 20000, 5)
