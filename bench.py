@@ -725,6 +725,9 @@ def main():
                        "items_per_gpu": items, "sharding": f"{world} x independent id ranges, no collective"},
             "roofline": wl.roofline(), "extra": wl.extra(ms), "parity": verdict,
         }
+        # BASELINE.md 3.5 also asks for the fraction of the MEASURED copy bandwidth (6.29 TB/s, MI355X_MICROARCH.md)
+        if out["roofline"].get("unit") == "GB/s" and out["roofline"].get("achieved") is not None:
+            out["roofline"]["frac_of_measured_copy_6290"] = round(out["roofline"]["achieved"] / 6290.0, 6)
         if not args.no_cpu_baseline:
             cores = host_cores()
             out["cpu_baseline"] = wl.cpu_baseline(cores)
