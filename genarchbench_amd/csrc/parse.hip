@@ -1,0 +1,413 @@
+// parse -- text inputs -> packed device buffers, on gfx950.
+//
+// Replaces, outside the region of interest, the line-by-line host parsers of the reference drivers:
+//   bsw      loadPairs                      /root/reference/benchmarks/bsw/src/main_banded.cpp:164-206 (+ :237-253)
+//   bpm      getline loop + swap            /root/reference/benchmarks/bpm/tools/align_benchmark.c:150-200, 247-252
+//   wfa      parse_input_sequences          /root/reference/benchmarks/wfa/tools/align_benchmark.c:110-194
+// The whole file is one buffer.  Three streaming passes build a newline index (count per 16 KB block, scan, fill),
+// then one thread per pair derives lengths / h0, two scans give the slab offsets and one wave per pair copies the
+// code bytes (64 consecutive bytes per instruction).  Everything is HBM streaming: the bound is bandwidth, and the
+// text is read three times (once per pass) -- the roofline of bench.py's parse-bsw workload counts it once.
+#include "gab_internal.h"
+#include <algorithm>
+#include <new>
+#include <string.h>
+
+namespace {
+
+constexpr int kBlockBytes = 16384;            // text bytes per workgroup in the newline passes (256 threads x 64 B)
+
+struct ParseFlags { int32_t bad; int32_t first_bad; };
+
+// ---- newline index ---------------------------------------------------------------------------------------------
+// 0x80 in every byte of w that is '\n', exactly (the add cannot carry across bytes)
+__device__ __forceinline__ uint32_t nl_flags(uint32_t w) {
+    const uint32_t x = w ^ 0x0a0a0a0au;
+    const uint32_t t = (x & 0x7f7f7f7fu) + 0x7f7f7f7fu;
+    return ~(t | x | 0x7f7f7f7fu);
+}
+__global__ __launch_bounds__(256) void nl_count(const char *__restrict__ text, int64_t n, int64_t *block_cnt) {
+    __shared__ int sh[4];
+    const int64_t base = (int64_t)blockIdx.x * kBlockBytes + (int64_t)threadIdx.x * 64;
+    int c = 0;
+    if (base + 64 <= n) {
+        const uint4 *p = reinterpret_cast<const uint4 *>(text + base);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint4 v = p[k];
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int j = 0; j < 4; j++) c += __popc(nl_flags(w[j]));
+        }
+    } else {
+        for (int k = 0; k < 64; k++) if (base + k < n && text[base + k] == '\n') c++;
+    }
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) block_cnt[blockIdx.x] = (int64_t)(sh[0] + sh[1] + sh[2] + sh[3]);
+}
+// exclusive scan of int64 values, single workgroup (the arrays here have at most a few hundred thousand entries);
+// out[n] receives the total
+__global__ __launch_bounds__(1024) void scan_i64(const int64_t *in, int64_t n, int64_t *out) {
+    __shared__ int64_t sh[1024];
+    int64_t carry = 0;
+    for (int64_t c0 = 0; c0 < n; c0 += 1024) {
+        const int64_t i = c0 + threadIdx.x;
+        const int64_t v = i < n ? in[i] : 0;
+        sh[threadIdx.x] = v;
+        __syncthreads();
+        for (int o = 1; o < 1024; o <<= 1) {
+            const int64_t add = (int)threadIdx.x >= o ? sh[threadIdx.x - o] : 0;
+            __syncthreads();
+            sh[threadIdx.x] += add;
+            __syncthreads();
+        }
+        if (i < n) out[i] = carry + sh[threadIdx.x] - v;
+        const int64_t total = sh[1023];
+        __syncthreads();
+        carry += total;
+    }
+    if (threadIdx.x == 0) out[n] = carry;
+}
+// line_start[l + 1] = position after the l-th newline; line_start[0] = 0
+__global__ __launch_bounds__(256) void nl_fill(const char *__restrict__ text, int64_t n, const int64_t *block_off, int64_t *line_start) {
+    __shared__ int wsum[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t base = (int64_t)blockIdx.x * kBlockBytes + (int64_t)threadIdx.x * 64;
+    // 64 bytes per thread as a bit mask of newlines
+    unsigned long long m = 0;
+    if (base + 64 <= n) {
+        const uint4 *p = reinterpret_cast<const uint4 *>(text + base);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint4 v = p[k];
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint32_t t = nl_flags(w[j]);
+                const uint32_t bits = ((t >> 7) & 1u) | ((t >> 14) & 2u) | ((t >> 21) & 4u) | ((t >> 28) & 8u);
+                m |= (unsigned long long)bits << (16 * k + 4 * j);
+            }
+        }
+    } else {
+        for (int k = 0; k < 64; k++) if (base + k < n && text[base + k] == '\n') m |= 1ull << k;
+    }
+    const int c = __popcll(m);
+    // exclusive prefix of c over the workgroup
+    int incl = c;
+    for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o); if (lane >= o) incl += v; }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int before = 0;
+    for (int w = 0; w < wave; w++) before += wsum[w];
+    int64_t idx = block_off[blockIdx.x] + before + incl - c;
+    while (m) {
+        const int b = __builtin_ctzll(m);
+        m &= m - 1;
+        line_start[++idx] = base + b + 1;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) line_start[0] = 0;
+}
+
+// ---- bsw ---------------------------------------------------------------------------------------------------------
+// per pair: h0 (sscanf "%d" on at most 9 characters, main_banded.cpp:179-180), len1 / len2 = line length without '\n'
+__global__ __launch_bounds__(256) void bsw_meta(const char *__restrict__ text, const int64_t *__restrict__ ls, int64_t npairs,
+                                                int32_t *len1, int32_t *len2, int32_t *h0, ParseFlags *fl) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= npairs) return;
+    const int64_t s0 = ls[3 * i], s1 = ls[3 * i + 1], s2 = ls[3 * i + 2], s3 = ls[3 * i + 3];
+    const int64_t hl = s1 - s0 - 1, l1 = s2 - s1 - 1, l2 = s3 - s2 - 1;
+    bool ok = hl >= 0 && hl <= 8 && l1 >= 1 && l1 <= 2045 && l2 >= 1 && l2 <= 253;
+    int v = 0;
+    if (ok) {
+        int64_t p = s0; const int64_t e = s1 - 1;
+        while (p < e && (text[p] == ' ' || text[p] == '\t')) p++;
+        bool neg = false;
+        if (p < e && (text[p] == '-' || text[p] == '+')) { neg = text[p] == '-'; p++; }
+        long long acc = 0;
+        while (p < e && text[p] >= '0' && text[p] <= '9') { acc = acc * 10 + (text[p] - '0'); p++; }
+        v = (int)(neg ? -acc : acc);
+    }
+    if (!ok) {
+        atomicAdd(&fl->bad, 1);
+        atomicMin((unsigned int *)&fl->first_bad, (unsigned int)(i > 0x7ffffffe ? 0x7ffffffe : i));
+        len1[i] = 0; len2[i] = 0; h0[i] = 0;
+        return;
+    }
+    len1[i] = (int32_t)l1; len2[i] = (int32_t)l2; h0[i] = v;
+}
+// exclusive scan of int32 lengths to int64 offsets: block sums, scan (scan_i64), apply
+__global__ __launch_bounds__(256) void len_block_sums(const int32_t *len, int64_t n, int64_t *block_sums) {
+    __shared__ int64_t sh[256];
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    sh[threadIdx.x] = i < n ? len[i] : 0;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o]; __syncthreads(); }
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = sh[0];
+}
+__global__ __launch_bounds__(256) void len_offsets(const int32_t *len, int64_t n, const int64_t *block_off, int64_t *off) {
+    __shared__ int64_t sh[256];
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t c = i < n ? len[i] : 0;
+    sh[threadIdx.x] = c;
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {
+        const int64_t v = (int)threadIdx.x >= o ? sh[threadIdx.x - o] : 0;
+        __syncthreads();
+        sh[threadIdx.x] += v;
+        __syncthreads();
+    }
+    if (i < n) off[i] = block_off[blockIdx.x] + sh[threadIdx.x] - c;
+}
+// one wave per pair: code = character - '0' (main_banded.cpp:192-193), 64 consecutive bytes per instruction
+__global__ __launch_bounds__(256) void bsw_codes(const char *__restrict__ text, const int64_t *__restrict__ ls, int64_t npairs,
+                                                 const int64_t *__restrict__ ref_off, const int64_t *__restrict__ qry_off,
+                                                 const int32_t *__restrict__ len1, const int32_t *__restrict__ len2,
+                                                 uint8_t *ref, uint8_t *qry) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6, nwaves = ((int64_t)gridDim.x * 256) >> 6;
+    for (int64_t i = wave; i < npairs; i += nwaves) {
+        const int64_t s1 = ls[3 * i + 1], s2 = ls[3 * i + 2];
+        const int l1 = len1[i], l2 = len2[i];
+        uint8_t *r = ref + ref_off[i], *q = qry + qry_off[i];
+        for (int k = lane; k < l1; k += 64) r[k] = (uint8_t)(text[s1 + k] - 48);
+        for (int k = lane; k < l2; k += 64) q[k] = (uint8_t)(text[s2 + k] - 48);
+    }
+}
+
+// ---- bpm / wfa -----------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pairs_meta(const char *__restrict__ text, const int64_t *__restrict__ ls, int64_t npairs, int swap,
+                                                  int64_t *pat_off, int32_t *pat_len, int64_t *txt_off, int32_t *txt_len, ParseFlags *fl) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= npairs) return;
+    const int64_t s0 = ls[2 * i], s1 = ls[2 * i + 1], s2 = ls[2 * i + 2];
+    // a line is <prefix char> <sequence> '\n'; the drivers drop the first character and the newline unconditionally
+    int64_t ao = s0 + 1, al = s1 - s0 - 2, bo = s1 + 1, bl = s2 - s1 - 2;
+    const bool ok = al >= 0 && bl >= 0 && al <= 0x7ffffff0 && bl <= 0x7ffffff0;
+    if (!ok) {
+        atomicAdd(&fl->bad, 1);
+        atomicMin((unsigned int *)&fl->first_bad, (unsigned int)(i > 0x7ffffffe ? 0x7ffffffe : i));
+        al = bl = 0;
+    }
+    if (swap && bl > al) {                       // the longer LINE becomes the pattern (bpm align_benchmark.c:177-181)
+        const int64_t to = ao, tl = al; ao = bo; al = bl; bo = to; bl = tl;
+    }
+    pat_off[i] = ao; pat_len[i] = (int32_t)al; txt_off[i] = bo; txt_len[i] = (int32_t)bl;
+}
+
+}  // namespace
+
+// =============================================================================== host side
+struct gab_parser {
+    int device = 0;
+    gab_devbuf text;        // device copy of the file (host-pointer entry points)
+    gab_devbuf idx;         // block counts / offsets, line starts
+    gab_devbuf meta;        // per-pair arrays
+    gab_devbuf slabs;       // bsw code slabs
+    gab_devbuf ws;          // flags + newline block counts / offsets
+    gab_devbuf scan;        // block sums of the length scans
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    float kernel_ms = 0; bool have_stats = false;
+};
+
+extern "C" int gab_parser_create(int device, gab_parser **out) {
+    if (!out) { gab_set_error("gab_parser_create: NULL argument"); return GAB_EINVAL; }
+    *out = nullptr;
+    int rc = gab_check_device(device);
+    if (rc) return rc;
+    gab_device_guard g(device);
+    gab_parser *p = new (std::nothrow) gab_parser();
+    if (!p) { gab_set_error("out of host memory"); return GAB_ENOMEM; }
+    p->device = device;
+    if (hipEventCreate(&p->ev[0]) != hipSuccess || hipEventCreate(&p->ev[1]) != hipSuccess) {
+        gab_set_error("gab_parser_create: event creation failed"); delete p; return GAB_EDEVICE;
+    }
+    *out = p;
+    return GAB_OK;
+}
+
+extern "C" void gab_parser_destroy(gab_parser *p) {
+    if (!p) return;
+    gab_device_guard g(p->device);
+    p->text.release(); p->idx.release(); p->meta.release(); p->slabs.release(); p->ws.release(); p->scan.release();
+    for (int k = 0; k < 2; k++) if (p->ev[k]) (void)hipEventDestroy(p->ev[k]);
+    delete p;
+}
+
+// newline index of d_text: returns the number of lines (= newlines) and the device array line_start[lines + 1]
+static int build_line_index(gab_parser *p, const char *d_text, int64_t nbytes, hipStream_t s, int64_t *nlines, const int64_t **d_ls) {
+    const int64_t nblocks = gab_ceil_div(nbytes, kBlockBytes);
+    // ws: [flags 64 B][block counts nblocks][block offsets nblocks + 1]
+    int rc = p->ws.reserve(64 + 8 * (size_t)(2 * nblocks + 2));
+    if (rc) return rc;
+    int64_t *d_cnt = (int64_t *)(p->ws.as<char>() + 64), *d_off = d_cnt + nblocks;
+    hipLaunchKernelGGL(nl_count, dim3((unsigned)nblocks), dim3(256), 0, s, d_text, nbytes, d_cnt);
+    hipLaunchKernelGGL(scan_i64, dim3(1), dim3(1024), 0, s, d_cnt, nblocks, d_off);
+    GAB_HIP(hipGetLastError());
+    int64_t total = 0;
+    GAB_HIP(hipMemcpyAsync(&total, d_off + nblocks, 8, hipMemcpyDeviceToHost, s));
+    GAB_HIP(hipStreamSynchronize(s));
+    rc = p->idx.reserve(8 * (size_t)(total + 2));
+    if (rc) return rc;
+    hipLaunchKernelGGL(nl_fill, dim3((unsigned)nblocks), dim3(256), 0, s, d_text, nbytes, d_off, p->idx.as<int64_t>());
+    GAB_HIP(hipGetLastError());
+    *nlines = total; *d_ls = p->idx.as<int64_t>();
+    return GAB_OK;
+}
+
+static int scan_lengths(gab_parser *p, const int32_t *d_len, int64_t n, int64_t *d_off, int64_t *total, hipStream_t s) {
+    const int64_t blocks = gab_ceil_div(n, 256);
+    int rc = p->scan.reserve(16 * (size_t)(blocks + 4));
+    if (rc) return rc;
+    int64_t *d_bs = p->scan.as<int64_t>(), *d_bo = d_bs + blocks + 1;
+    hipLaunchKernelGGL(len_block_sums, dim3((unsigned)blocks), dim3(256), 0, s, d_len, n, d_bs);
+    hipLaunchKernelGGL(scan_i64, dim3(1), dim3(1024), 0, s, d_bs, blocks, d_bo);
+    hipLaunchKernelGGL(len_offsets, dim3((unsigned)blocks), dim3(256), 0, s, d_len, n, d_bo, d_off);
+    GAB_HIP(hipGetLastError());
+    GAB_HIP(hipMemcpyAsync(total, d_bo + blocks, 8, hipMemcpyDeviceToHost, s));
+    return GAB_OK;
+}
+
+extern "C" int gab_bsw_parse_pairs_device(gab_parser *p, const char *d_text, int64_t nbytes, gab_bsw_packed *out, void *stream_) {
+    GAB_CHECK(p && out, "gab_bsw_parse_pairs_device: NULL argument");
+    memset(out, 0, sizeof *out);
+    GAB_CHECK(nbytes >= 0, "gab_bsw_parse_pairs_device: nbytes < 0");
+    p->have_stats = false;
+    if (nbytes == 0) return GAB_OK;
+    GAB_CHECK(d_text, "gab_bsw_parse_pairs_device: NULL text");
+    GAB_CHECK(((uintptr_t)d_text & 15) == 0, "gab_bsw_parse_pairs_device: the text buffer must be 16-byte aligned");
+    gab_device_guard g(p->device);
+    hipStream_t s = (hipStream_t)stream_;
+    GAB_HIP(hipEventRecord(p->ev[0], s));
+    int64_t nlines = 0; const int64_t *d_ls = nullptr;
+    int rc = build_line_index(p, d_text, nbytes, s, &nlines, &d_ls);
+    if (rc) return rc;
+    const int64_t n = nlines / 3;                        // numPairs = newline count / 3 (main_banded.cpp:237-253)
+    if (n == 0) { GAB_HIP(hipEventRecord(p->ev[1], s)); return GAB_OK; }
+    GAB_CHECK(n < (1ll << 31), "gab_bsw_parse_pairs_device: too many pairs");
+    // meta: len1 | len2 | h0 (int32 x n each) | ref_off | qry_off (int64 x (n + 1) each)
+    const size_t o_l2 = (4 * (size_t)n + 63) & ~(size_t)63, o_h0 = 2 * o_l2, o_ro = 3 * o_l2, o_qo = o_ro + ((8 * (size_t)(n + 1) + 63) & ~(size_t)63);
+    rc = p->meta.reserve(o_qo + 8 * (size_t)(n + 1) + 64);
+    if (rc) return rc;
+    char *mb = p->meta.as<char>();
+    int32_t *d_l1 = (int32_t *)mb, *d_l2 = (int32_t *)(mb + o_l2), *d_h0 = (int32_t *)(mb + o_h0);
+    int64_t *d_ro = (int64_t *)(mb + o_ro), *d_qo = (int64_t *)(mb + o_qo);
+    ParseFlags *d_fl = (ParseFlags *)p->ws.as<char>();
+    ParseFlags hf = {0, 0x7fffffff};
+    GAB_HIP(hipMemcpyAsync(d_fl, &hf, sizeof hf, hipMemcpyHostToDevice, s));
+    const int64_t blocks = gab_ceil_div(n, 256);
+    hipLaunchKernelGGL(bsw_meta, dim3((unsigned)blocks), dim3(256), 0, s, d_text, d_ls, n, d_l1, d_l2, d_h0, d_fl);
+    int64_t tot1 = 0, tot2 = 0;
+    rc = scan_lengths(p, d_l1, n, d_ro, &tot1, s);
+    if (rc) return rc;
+    GAB_HIP(hipStreamSynchronize(s));                    // (the two scans share the scratch and the host totals)
+    rc = scan_lengths(p, d_l2, n, d_qo, &tot2, s);
+    if (rc) return rc;
+    GAB_HIP(hipMemcpyAsync(&hf, d_fl, sizeof hf, hipMemcpyDeviceToHost, s));
+    GAB_HIP(hipStreamSynchronize(s));
+    if (hf.bad) {
+        gab_set_error("gab_bsw_parse_pairs: %d pair(s) are not in the plain format (first: pair %d): empty or over-long line",
+                      hf.bad, hf.first_bad);
+        return GAB_EINVAL;
+    }
+    const size_t rpad = ((size_t)tot1 + 3 + 255) & ~(size_t)255, qpad = ((size_t)tot2 + 3 + 255) & ~(size_t)255;
+    rc = p->slabs.reserve(rpad + qpad);
+    if (rc) return rc;
+    uint8_t *d_ref = p->slabs.as<uint8_t>(), *d_qry = d_ref + rpad;
+    int n_cu = 256;
+    { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, p->device) == hipSuccess) n_cu = prop.multiProcessorCount; }
+    hipLaunchKernelGGL(bsw_codes, dim3((unsigned)std::min<int64_t>(gab_ceil_div(n, 4), (int64_t)n_cu * 64)), dim3(256), 0, s, d_text, d_ls, n,
+                       d_ro, d_qo, d_l1, d_l2, d_ref, d_qry);
+    GAB_HIP(hipGetLastError());
+    GAB_HIP(hipEventRecord(p->ev[1], s));
+    GAB_HIP(hipStreamSynchronize(s));
+    GAB_HIP(hipEventElapsedTime(&p->kernel_ms, p->ev[0], p->ev[1]));
+    p->have_stats = true;
+    out->n = n; out->d_ref = d_ref; out->d_ref_off = d_ro; out->d_qry = d_qry; out->d_qry_off = d_qo;
+    out->d_len1 = d_l1; out->d_len2 = d_l2; out->d_h0 = d_h0; out->ref_bytes = (int64_t)rpad; out->qry_bytes = (int64_t)qpad;
+    return GAB_OK;
+}
+
+static int stage_text(gab_parser *p, const char *text, int64_t nbytes, hipStream_t s, const char **d_text) {
+    int rc = p->text.reserve((size_t)nbytes + 64);
+    if (rc) return rc;
+    GAB_HIP(hipMemcpyAsync(p->text.p, text, (size_t)nbytes, hipMemcpyHostToDevice, s));
+    *d_text = p->text.as<char>();
+    return GAB_OK;
+}
+
+extern "C" int gab_bsw_parse_pairs(gab_parser *p, const char *text, int64_t nbytes, gab_bsw_packed *out, void *stream_) {
+    GAB_CHECK(p && out, "gab_bsw_parse_pairs: NULL argument");
+    GAB_CHECK(nbytes >= 0 && (nbytes == 0 || text), "gab_bsw_parse_pairs: bad buffer");
+    if (nbytes == 0) { memset(out, 0, sizeof *out); return GAB_OK; }
+    gab_device_guard g(p->device);
+    const char *d_text = nullptr;
+    int rc = stage_text(p, text, nbytes, (hipStream_t)stream_, &d_text);
+    if (rc) return rc;
+    return gab_bsw_parse_pairs_device(p, d_text, nbytes, out, stream_);
+}
+
+extern "C" int gab_pairs_parse_device(gab_parser *p, const char *d_text, int64_t nbytes, int swap_longer_first, gab_pairs_packed *out,
+                                      void *stream_) {
+    GAB_CHECK(p && out, "gab_pairs_parse_device: NULL argument");
+    memset(out, 0, sizeof *out);
+    GAB_CHECK(nbytes >= 0, "gab_pairs_parse_device: nbytes < 0");
+    p->have_stats = false;
+    if (nbytes == 0) return GAB_OK;
+    GAB_CHECK(d_text, "gab_pairs_parse_device: NULL text");
+    GAB_CHECK(((uintptr_t)d_text & 15) == 0, "gab_pairs_parse_device: the text buffer must be 16-byte aligned");
+    gab_device_guard g(p->device);
+    hipStream_t s = (hipStream_t)stream_;
+    GAB_HIP(hipEventRecord(p->ev[0], s));
+    int64_t nlines = 0; const int64_t *d_ls = nullptr;
+    int rc = build_line_index(p, d_text, nbytes, s, &nlines, &d_ls);
+    if (rc) return rc;
+    const int64_t n = nlines / 2;
+    out->d_text = d_text; out->text_bytes = nbytes;
+    if (n == 0) { GAB_HIP(hipEventRecord(p->ev[1], s)); return GAB_OK; }
+    GAB_CHECK(n < (1ll << 31), "gab_pairs_parse_device: too many pairs");
+    const size_t o8 = (8 * (size_t)n + 63) & ~(size_t)63, o4 = (4 * (size_t)n + 63) & ~(size_t)63;
+    rc = p->meta.reserve(2 * o8 + 2 * o4 + 64);
+    if (rc) return rc;
+    char *mb = p->meta.as<char>();
+    int64_t *d_po = (int64_t *)mb, *d_to = (int64_t *)(mb + o8);
+    int32_t *d_pl = (int32_t *)(mb + 2 * o8), *d_tl = (int32_t *)(mb + 2 * o8 + o4);
+    ParseFlags *d_fl = (ParseFlags *)p->ws.as<char>();
+    ParseFlags hf = {0, 0x7fffffff};
+    GAB_HIP(hipMemcpyAsync(d_fl, &hf, sizeof hf, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(pairs_meta, dim3((unsigned)gab_ceil_div(n, 256)), dim3(256), 0, s, d_text, d_ls, n, swap_longer_first, d_po, d_pl,
+                       d_to, d_tl, d_fl);
+    GAB_HIP(hipGetLastError());
+    GAB_HIP(hipEventRecord(p->ev[1], s));
+    GAB_HIP(hipMemcpyAsync(&hf, d_fl, sizeof hf, hipMemcpyDeviceToHost, s));
+    GAB_HIP(hipStreamSynchronize(s));
+    if (hf.bad) {
+        gab_set_error("gab_pairs_parse: %d pair(s) have an empty line (first: pair %d)", hf.bad, hf.first_bad);
+        return GAB_EINVAL;
+    }
+    GAB_HIP(hipEventElapsedTime(&p->kernel_ms, p->ev[0], p->ev[1]));
+    p->have_stats = true;
+    out->n = n; out->d_pat_off = d_po; out->d_txt_off = d_to; out->d_pat_len = d_pl; out->d_txt_len = d_tl;
+    return GAB_OK;
+}
+
+extern "C" int gab_pairs_parse(gab_parser *p, const char *text, int64_t nbytes, int swap_longer_first, gab_pairs_packed *out, void *stream_) {
+    GAB_CHECK(p && out, "gab_pairs_parse: NULL argument");
+    GAB_CHECK(nbytes >= 0 && (nbytes == 0 || text), "gab_pairs_parse: bad buffer");
+    if (nbytes == 0) { memset(out, 0, sizeof *out); return GAB_OK; }
+    gab_device_guard g(p->device);
+    const char *d_text = nullptr;
+    int rc = stage_text(p, text, nbytes, (hipStream_t)stream_, &d_text);
+    if (rc) return rc;
+    rc = gab_pairs_parse_device(p, d_text, nbytes, swap_longer_first, out, stream_);
+    if (rc == GAB_OK) out->text_bytes = nbytes + 64;
+    return rc;
+}
+
+extern "C" int gab_parser_last_stats(gab_parser *p, float *kernel_ms) {
+    GAB_CHECK(p, "gab_parser_last_stats: NULL handle");
+    GAB_CHECK(p->have_stats, "gab_parser_last_stats: no completed parse on this handle");
+    if (kernel_ms) *kernel_ms = p->kernel_ms;
+    return GAB_OK;
+}

@@ -241,6 +241,44 @@ int gab_fmi_sa_lookup_device(gab_fmi *h, const gab_smem *d_smems, int64_t n, int
 /* last look-up: LF-mapping steps taken (one random 64-byte CP_OCC record each) and kernel ms */
 int gab_fmi_last_sa_stats(gab_fmi *h, int64_t *lf_steps, float *kernel_ms);
 
+/* ---- input parsers ---------------------------------------------------------
+ * The reference drivers parse their text inputs on the host, line by line, outside the region of interest
+ * (bsw: loadPairs, bsw/src/main_banded.cpp:164-206 -- fgets + sscanf per pair; bpm / wfa: getline per line,
+ * bpm/tools/align_benchmark.c:150-200, wfa/tools/align_benchmark.c:110-194).  At 10 M items that is the bulk of the
+ * end-to-end time.  These entry points take the WHOLE file as one buffer and build the packed, device-resident
+ * inputs of gab_bsw_run_device / gab_bpm_run_device / gab_wfa_run_device on the GPU: a newline index (count, scan,
+ * fill), then per pair the lengths, offsets, h0 and the code bytes.
+ * They accept exactly the well-formed files the reference accepts without hitting one of its buffer limits
+ * (every line ends with '\n'; bsw: h0 line of at most 8 characters, reference line < 2047, query line < 255
+ * characters, both non-empty) and return GAB_EINVAL otherwise -- a caller then falls back to its line-by-line parser.
+ * All outputs live in memory owned by the handle and stay valid until the next call on it. */
+typedef struct gab_parser gab_parser;
+typedef struct {
+    int64_t n;                                   /* pairs = newline count / 3 (main_banded.cpp:237-253) */
+    const uint8_t *d_ref; const int64_t *d_ref_off;      /* codes 0..4 back to back, byte offsets per pair */
+    const uint8_t *d_qry; const int64_t *d_qry_off;
+    const int32_t *d_len1, *d_len2, *d_h0;
+    int64_t ref_bytes, qry_bytes;
+} gab_bsw_packed;
+typedef struct {
+    int64_t n;                                   /* pairs = newline count / 2 */
+    const char *d_text;                          /* the file itself; sequences are used in place */
+    int64_t text_bytes;                          /* readable bytes of d_text (>= nbytes; the staged copy has 64 bytes of slack) */
+    const int64_t *d_pat_off, *d_txt_off;        /* first base of each sequence (the '>' / '<' prefix is skipped) */
+    const int32_t *d_pat_len, *d_txt_len;
+} gab_pairs_packed;
+int gab_parser_create(int device, gab_parser **out);
+void gab_parser_destroy(gab_parser *p);
+/* text: host pointer (copied to the device) or, for the _device variants, device pointer */
+int gab_bsw_parse_pairs(gab_parser *p, const char *text, int64_t nbytes, gab_bsw_packed *out, void *stream);
+int gab_bsw_parse_pairs_device(gab_parser *p, const char *d_text, int64_t nbytes, gab_bsw_packed *out, void *stream);
+/* swap_longer_first != 0: the longer line becomes the pattern (bpm, align_benchmark.c:177-181); 0: '>' is the pattern (wfa) */
+int gab_pairs_parse(gab_parser *p, const char *text, int64_t nbytes, int swap_longer_first, gab_pairs_packed *out, void *stream);
+int gab_pairs_parse_device(gab_parser *p, const char *d_text, int64_t nbytes, int swap_longer_first, gab_pairs_packed *out,
+                           void *stream);
+/* last parse: kernel milliseconds (HIP events on the launch stream, excluding the host-to-device copy of the text) */
+int gab_parser_last_stats(gab_parser *p, float *kernel_ms);
+
 #ifdef __cplusplus
 }
 #endif
