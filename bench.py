@@ -656,7 +656,102 @@ class FmiSaWorkload(FmiWorkload):
                           f"driver never calls get_sa_entries, so there is no reference binary to time"}
 
 
-WORKLOADS = {"fmi": FmiWorkload, "fmi-sa": FmiSaWorkload, "wfa": WfaWorkload, "bpm": BpmWorkload, "bsw": BswWorkload, "chain": ChainWorkload, "fast-chain": FastChainWorkload}
+class ParseBswWorkload:
+    """the bsw input text -> packed device buffers (what loadPairs does on the host, outside the
+    ROI, main_banded.cpp:164-206).  One unit = one byte of input text; the text is resident in HBM."""
+    name = "parse-bsw"
+    metric = "bsw input parse GB/sec of text"
+    unit = "GB/s"
+    dtype = "u8"
+    default_items = 10_000_000        # pairs
+    seed = 2
+
+    def __init__(self, items, rank, dev):
+        import torch
+        from tools import gabgen
+        from genarchbench_amd.parse import InputParser
+        self.items = items
+        t0 = time.time()
+        with tempfile.TemporaryDirectory() as td:
+            p = os.path.join(td, "pairs.txt")
+            gabgen.write_text("bsw", p, self.seed, items, 0)
+            self.text = np.fromfile(p, np.uint8)
+        log(f"[rank {rank}] wrote and read back the bsw input text of {items} pairs ({len(self.text) / 1e9:.2f} GB) in {time.time() - t0:.1f}s")
+        self.d_text = torch.from_numpy(self.text).to(dev)
+        self.ps = InputParser(device=dev.index or 0)
+        self.kernel_ms = []
+        self.pk = None
+
+    def step(self, stream):
+        self.pk = self.ps.bsw_pairs_device(self.d_text.data_ptr(), self.d_text.numel(), stream=stream)
+
+    def units_per_step(self):
+        return len(self.text) / 1e3          # the harness divides by 1e6: GB/s = bytes / 1e9 / s
+
+    def after_step(self, timed):
+        if timed:
+            self.kernel_ms.append(self.ps.last_stats()["kernel_ms"])
+
+    def check(self):
+        from tools import gabgen
+        got = self.ps.bsw_to_host(self.pk)
+        n = min(self.items, 200_000)
+        want = gabgen.bsw(self.seed, n, 0)
+        assert self.pk.n == self.items
+        assert np.array_equal(got["len1"][:n], want.len1) and np.array_equal(got["len2"][:n], want.len2) and \
+            np.array_equal(got["h0"][:n], want.h0), "parsed lengths / h0 differ from the generator's arrays"
+        for i in range(0, n, 37):
+            assert np.array_equal(got["ref"][got["ref_off"][i]:got["ref_off"][i] + got["len1"][i]],
+                                  want.ref[want.ref_off[i]:want.ref_off[i] + want.len1[i]]), "parsed reference codes differ"
+            assert np.array_equal(got["qry"][got["qry_off"][i]:got["qry_off"][i] + got["len2"][i]],
+                                  want.qry[want.qry_off[i]:want.qry_off[i] + want.len2[i]]), "parsed query codes differ"
+        assert (np.diff(got["ref_off"]) == ((got["len1"][:-1] + 3) & ~3)).all() and \
+            (np.diff(got["qry_off"]) == ((got["len2"][:-1] + 3) & ~3)).all(), "offsets are not the padded prefix sums"
+        return f"bit-exact lengths, h0 and codes vs the generator's arrays on the first {n} pairs (every 37th compared byte for byte); offsets consistent on all {self.items}"
+
+    def out_bytes(self):
+        return int(self.pk.ref_bytes + self.pk.qry_bytes + 28 * self.pk.n)
+
+    def extra(self, ms_per_step):
+        k = float(np.mean(self.kernel_ms))
+        return {"pairs": self.items, "text_bytes": int(len(self.text)), "packed_bytes": self.out_bytes(),
+                "m_pairs_per_s": round(self.items / (k * 1e3), 2), "dominant_kernel": "nl_fill / bsw_codes (5 streaming kernels)",
+                "dominant_kernel_ms": k}
+
+    def roofline(self):
+        k = float(np.mean(self.kernel_ms))
+        alg = len(self.text) + self.out_bytes()          # read the text once, write the packed buffers once
+        ach = alg / (k * 1e-3) / 1e9
+        return {"bound": "hbm", "achieved": round(ach, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(ach / HBM_PEAK_GBS, 6), "traffic": None,
+                "note": "streaming: the text is actually read three times (newline count, newline fill, code copy) and the "
+                        "8-byte line index (1 entry per ~70 B of text) written and read once; counted here: text once + outputs once"}
+
+    def cpu_baseline(self, cores):
+        """the C driver's line-by-line parser (same fgets / sscanf sequence as loadPairs) has no stand-alone entry point;
+        time the equivalent single-threaded numpy-free Python-free path: the driver binary's own 'Read time' on a sample"""
+        from oracle import pyoracle
+        from tools import gabgen
+        flags = open("/proc/cpuinfo").read()
+        ref = pyoracle.ref_path("bsw_ref_" + ("avx512" if " avx512bw" in flags else "avx2"))
+        exe, kind = (ref, "reference") if ref else (os.path.join(ROOT, "benchmarks", "bsw", "main_bsw"), "port")
+        n = min(self.items, 1_000_000)
+        with tempfile.TemporaryDirectory() as td:
+            p = os.path.join(td, "pairs.txt")
+            gabgen.write_text("bsw", p, self.seed, n, 0)
+            nbytes = os.path.getsize(p)
+            r = subprocess.run([exe, "-pairs", p, "-t", str(cores), "-b", "512"], capture_output=True, text=True)
+            m = re.search(r"Read time = ([\d.]+) s", r.stdout)
+            if r.returncode == 0 and m and float(m.group(1)) > 0:
+                sec = float(m.group(1))
+                return {"value": round(nbytes / sec / 1e9, 4), "unit": self.unit, "cores": 1, "kind": kind,
+                        "sample": f"{n} pairs ({nbytes / 1e6:.0f} MB): the 'Read time' line of "
+                                  f"{'the compiled reference (loadPairs, main_banded.cpp:164-206)' if ref else 'this repo C driver'}"
+                                  f" ({sec:.2f} s, single-threaded by construction)"}
+        return {"value": None, "unit": self.unit, "cores": 1, "kind": "port", "sample": "driver binary not available"}
+
+
+WORKLOADS = {"parse-bsw": ParseBswWorkload, "fmi": FmiWorkload, "fmi-sa": FmiSaWorkload, "wfa": WfaWorkload, "bpm": BpmWorkload, "bsw": BswWorkload, "chain": ChainWorkload, "fast-chain": FastChainWorkload}
 
 
 def main():

@@ -138,10 +138,11 @@ __global__ __launch_bounds__(256) void bsw_meta(const char *__restrict__ text, c
     len1[i] = (int32_t)l1; len2[i] = (int32_t)l2; h0[i] = v;
 }
 // exclusive scan of int32 lengths to int64 offsets: block sums, scan (scan_i64), apply
+// (lengths are rounded up to a multiple of 4: every sequence starts dword-aligned in its slab)
 __global__ __launch_bounds__(256) void len_block_sums(const int32_t *len, int64_t n, int64_t *block_sums) {
     __shared__ int64_t sh[256];
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    sh[threadIdx.x] = i < n ? len[i] : 0;
+    sh[threadIdx.x] = i < n ? ((len[i] + 3) & ~3) : 0;
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o]; __syncthreads(); }
     if (threadIdx.x == 0) block_sums[blockIdx.x] = sh[0];
@@ -149,7 +150,7 @@ __global__ __launch_bounds__(256) void len_block_sums(const int32_t *len, int64_
 __global__ __launch_bounds__(256) void len_offsets(const int32_t *len, int64_t n, const int64_t *block_off, int64_t *off) {
     __shared__ int64_t sh[256];
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int64_t c = i < n ? len[i] : 0;
+    const int64_t c = i < n ? ((len[i] + 3) & ~3) : 0;
     sh[threadIdx.x] = c;
     __syncthreads();
     for (int o = 1; o < 256; o <<= 1) {
@@ -160,19 +161,54 @@ __global__ __launch_bounds__(256) void len_offsets(const int32_t *len, int64_t n
     }
     if (i < n) off[i] = block_off[blockIdx.x] + sh[threadIdx.x] - c;
 }
-// one wave per pair: code = character - '0' (main_banded.cpp:192-193), 64 consecutive bytes per instruction
-__global__ __launch_bounds__(256) void bsw_codes(const char *__restrict__ text, const int64_t *__restrict__ ls, int64_t npairs,
-                                                 const int64_t *__restrict__ ref_off, const int64_t *__restrict__ qry_off,
-                                                 const int32_t *__restrict__ len1, const int32_t *__restrict__ len2,
-                                                 uint8_t *ref, uint8_t *qry) {
+// code = character - '0' (main_banded.cpp:192-193).  A wave takes 64 pairs: every lane loads the metadata of one pair
+// (coalesced), then each pair is copied with FOUR bytes per lane (one unaligned dword load from the text, one aligned
+// dword store into the slab: sequences start dword-aligned there) -- byte-wide accesses run at a quarter of the
+// address-unit rate.  The up-to-3 bytes past a sequence's end are padding nobody reads.
+__device__ __forceinline__ uint32_t text_ld4(const char *text, int64_t pos, int64_t nbytes) {
+    uint32_t w = 0;
+    if (pos + 4 <= nbytes) __builtin_memcpy(&w, text + pos, 4);
+    else for (int b = 0; b < 4; b++) if (pos + b < nbytes) w |= (uint32_t)(uint8_t)text[pos + b] << (8 * b);
+    return w;
+}
+// four independent byte subtractions x - '0' (no borrow between bytes: a character below '0' wraps like the reference's
+// uint8 arithmetic and must not disturb its neighbour)
+__device__ __forceinline__ uint32_t sub48x4(uint32_t x) {
+    const uint32_t H = 0x80808080u, y = 0x30303030u;
+    return ((x | H) - (y & ~H)) ^ ((x ^ ~y) & H);
+}
+__global__ __launch_bounds__(256) void bsw_codes(const char *__restrict__ text, int64_t nbytes, const int64_t *__restrict__ ls,
+                                                 int64_t npairs, const int64_t *__restrict__ ref_off,
+                                                 const int64_t *__restrict__ qry_off, const int32_t *__restrict__ len1,
+                                                 const int32_t *__restrict__ len2, uint8_t *ref, uint8_t *qry) {
     const int lane = threadIdx.x & 63;
     const int64_t wave = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6, nwaves = ((int64_t)gridDim.x * 256) >> 6;
-    for (int64_t i = wave; i < npairs; i += nwaves) {
-        const int64_t s1 = ls[3 * i + 1], s2 = ls[3 * i + 2];
-        const int l1 = len1[i], l2 = len2[i];
-        uint8_t *r = ref + ref_off[i], *q = qry + qry_off[i];
-        for (int k = lane; k < l1; k += 64) r[k] = (uint8_t)(text[s1 + k] - 48);
-        for (int k = lane; k < l2; k += 64) q[k] = (uint8_t)(text[s2 + k] - 48);
+    for (int64_t b0 = wave * 64; b0 < npairs; b0 += nwaves * 64) {
+        const int64_t mine = b0 + lane;
+        const bool have = mine < npairs;
+        const int64_t m_s1 = have ? ls[3 * mine + 1] : 0, m_s2 = have ? ls[3 * mine + 2] : 0;
+        const int64_t m_ro = have ? ref_off[mine] : 0, m_qo = have ? qry_off[mine] : 0;
+        const int m_l1 = have ? len1[mine] : 0, m_l2 = have ? len2[mine] : 0;
+        const int cnt = (int)(npairs - b0 < 64 ? npairs - b0 : 64);
+        for (int j0 = 0; j0 < cnt; j0 += 4) {
+            uint32_t rv[4], qv[4];
+            int64_t s1[4], ro[4], qo[4]; int l1[4], l2[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int j = j0 + u < cnt ? j0 + u : cnt - 1;          // (a duplicate of the last pair rewrites the same bytes)
+                s1[u] = __shfl(m_s1, j); const int64_t s2 = __shfl(m_s2, j); ro[u] = __shfl(m_ro, j); qo[u] = __shfl(m_qo, j);
+                l1[u] = __shfl(m_l1, j); l2[u] = __shfl(m_l2, j);
+                rv[u] = 4 * lane < l1[u] ? text_ld4(text, s1[u] + 4 * lane, nbytes) : 0u;
+                qv[u] = 4 * lane < l2[u] ? text_ld4(text, s2 + 4 * lane, nbytes) : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                if (4 * lane < l1[u]) *reinterpret_cast<uint32_t *>(ref + ro[u] + 4 * lane) = sub48x4(rv[u]);
+                if (4 * lane < l2[u]) *reinterpret_cast<uint32_t *>(qry + qo[u] + 4 * lane) = sub48x4(qv[u]);
+                for (int k = 256 + 4 * lane; k < l1[u]; k += 256)       // reference lines longer than 256 characters
+                    *reinterpret_cast<uint32_t *>(ref + ro[u] + k) = sub48x4(text_ld4(text, s1[u] + k, nbytes));
+            }
+        }
     }
 }
 
@@ -317,7 +353,7 @@ extern "C" int gab_bsw_parse_pairs_device(gab_parser *p, const char *d_text, int
     uint8_t *d_ref = p->slabs.as<uint8_t>(), *d_qry = d_ref + rpad;
     int n_cu = 256;
     { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, p->device) == hipSuccess) n_cu = prop.multiProcessorCount; }
-    hipLaunchKernelGGL(bsw_codes, dim3((unsigned)std::min<int64_t>(gab_ceil_div(n, 4), (int64_t)n_cu * 64)), dim3(256), 0, s, d_text, d_ls, n,
+    hipLaunchKernelGGL(bsw_codes, dim3((unsigned)std::min<int64_t>(gab_ceil_div(n, 256), (int64_t)n_cu * 16)), dim3(256), 0, s, d_text, nbytes, d_ls, n,
                        d_ro, d_qo, d_l1, d_l2, d_ref, d_qry);
     GAB_HIP(hipGetLastError());
     GAB_HIP(hipEventRecord(p->ev[1], s));

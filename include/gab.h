@@ -255,7 +255,7 @@ int gab_fmi_last_sa_stats(gab_fmi *h, int64_t *lf_steps, float *kernel_ms);
 typedef struct gab_parser gab_parser;
 typedef struct {
     int64_t n;                                   /* pairs = newline count / 3 (main_banded.cpp:237-253) */
-    const uint8_t *d_ref; const int64_t *d_ref_off;      /* codes 0..4 back to back, byte offsets per pair */
+    const uint8_t *d_ref; const int64_t *d_ref_off;      /* codes (character - '0'); byte offset of each pair's sequence, 4-byte aligned */
     const uint8_t *d_qry; const int64_t *d_qry_off;
     const int32_t *d_len1, *d_len2, *d_h0;
     int64_t ref_bytes, qry_bytes;

@@ -61,10 +61,14 @@ def test_bsw_parse_large_and_block_boundaries(tmp_path):
     assert pk.n == n
     np.testing.assert_array_equal(got["len1"], want.len1); np.testing.assert_array_equal(got["len2"], want.len2)
     np.testing.assert_array_equal(got["h0"], want.h0)
-    np.testing.assert_array_equal(got["ref_off"], np.concatenate([[0], np.cumsum(want.len1[:-1], dtype=np.int64)]))
-    # the slabs are the sequences back to back: compare whole
-    ref_cat = np.concatenate([want.ref[want.ref_off[i]:want.ref_off[i] + want.len1[i]] for i in range(0, n, 1)][:2000])
-    np.testing.assert_array_equal(got["ref"][:len(ref_cat)], ref_cat)
+    # every sequence starts on a 4-byte boundary right after the previous one
+    np.testing.assert_array_equal(got["ref_off"], np.concatenate([[0], np.cumsum((want.len1[:-1] + 3) & ~3, dtype=np.int64)]))
+    np.testing.assert_array_equal(got["qry_off"], np.concatenate([[0], np.cumsum((want.len2[:-1] + 3) & ~3, dtype=np.int64)]))
+    for i in list(range(0, 3000)) + list(range(3000, n, 997)):
+        np.testing.assert_array_equal(got["ref"][got["ref_off"][i]:got["ref_off"][i] + got["len1"][i]],
+                                      want.ref[want.ref_off[i]:want.ref_off[i] + want.len1[i]])
+        np.testing.assert_array_equal(got["qry"][got["qry_off"][i]:got["qry_off"][i] + got["len2"][i]],
+                                      want.qry[want.qry_off[i]:want.qry_off[i] + want.len2[i]])
     tail = n - 1
     np.testing.assert_array_equal(got["qry"][got["qry_off"][tail]:got["qry_off"][tail] + got["len2"][tail]],
                                   want.qry[want.qry_off[tail]:want.qry_off[tail] + want.len2[tail]])
@@ -80,8 +84,9 @@ def test_bsw_parse_rejects_what_the_reference_cannot_read():
     assert ps.bsw_pairs(ok).n == 1
     assert ps.bsw_pairs(ok + b"7\n01\n").n == 1            # incomplete trailing pair: newline count / 3
     assert ps.bsw_pairs(b"").n == 0
-    got = ps.bsw_to_host(ps.bsw_pairs(b" +42\n3210\n01\n-7\n4\n4\n"))
-    assert list(got["h0"]) == [42, -7] and list(got["len1"]) == [4, 1] and list(got["ref"]) == [3, 2, 1, 0, 4]
+    got = ps.bsw_to_host(ps.bsw_pairs(b" +42\n3210\n01\n-7\n4\n/5\n"))
+    assert list(got["h0"]) == [42, -7] and list(got["len1"]) == [4, 1] and list(got["ref"][:5]) == [3, 2, 1, 0, 4]
+    assert list(got["qry"][got["qry_off"][1]:got["qry_off"][1] + 2]) == [255, 5]      # '/' - '0' wraps like the reference's uint8
     for bad in (b"19\n\n012\n", b"19\n0123\n\n", b"123456789\n01\n01\n", b"1\n" + b"0" * 2046 + b"\n01\n", b"1\n01\n" + b"1" * 254 + b"\n"):
         with pytest.raises(GabError):
             ps.bsw_pairs(bad)
