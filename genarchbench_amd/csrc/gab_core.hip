@@ -41,3 +41,26 @@ int gab_check_device(int device) {
     }
     return GAB_OK;
 }
+
+// ---- plain device-memory helpers for C callers that keep data on the GPU between two entry points ----------------
+extern "C" int gab_device_alloc(int device, size_t bytes, void **out) {
+    if (!out) { gab_set_error("gab_device_alloc: NULL argument"); return GAB_EINVAL; }
+    *out = nullptr;
+    int rc = gab_check_device(device);
+    if (rc) return rc;
+    gab_device_guard g(device);
+    GAB_HIP(hipMalloc(out, bytes ? bytes : 1));
+    return GAB_OK;
+}
+extern "C" void gab_device_free(int device, void *p) {
+    if (!p) return;
+    gab_device_guard g(device);
+    (void)hipFree(p);
+}
+extern "C" int gab_device_copy_to_host(int device, void *dst, const void *d_src, size_t bytes) {
+    if (bytes == 0) return GAB_OK;
+    if (!dst || !d_src) { gab_set_error("gab_device_copy_to_host: NULL argument"); return GAB_EINVAL; }
+    gab_device_guard g(device);
+    GAB_HIP(hipMemcpy(dst, d_src, bytes, hipMemcpyDeviceToHost));
+    return GAB_OK;
+}

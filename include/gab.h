@@ -20,6 +20,7 @@
  */
 #ifndef GAB_H
 #define GAB_H
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -36,6 +37,10 @@ extern "C" {
 const char *gab_version(void);
 const char *gab_last_error(void);
 int gab_device_count(void);
+/* device memory for C callers that chain two *_device entry points (e.g. parser -> kernel) without a HIP toolchain */
+int gab_device_alloc(int device, size_t bytes, void **out);
+void gab_device_free(int device, void *p);
+int gab_device_copy_to_host(int device, void *dst, const void *d_src, size_t bytes);
 
 /* ---- bsw: banded Smith-Waterman seed extension ------------------------------------
  * Replaces  bsw[tid]->getScores16(SeqPair*, ref, qer, nPairsBatch, 1, w)

@@ -45,3 +45,22 @@ def test_driver_errors_like_the_reference(tmp_path):
     assert r.returncode != 0 and "pairFileName not specified" in r.stderr
     r = subprocess.run([os.path.join(ROOT, "benchmarks", "fmi", "fmi"), "a", "b"], capture_output=True, text=True)
     assert r.returncode == 1 and "Need five arguments" in r.stdout
+
+
+def test_bsw_driver_gpu_parse_mode(inputs, tmp_path):
+    """GAB_GPU_PARSE=1: the file is parsed on the GPU; stderr (the scores) must be byte-identical
+    to the line-by-line mode, and a file the GPU parser declines falls back to it"""
+    exe = os.path.join(ROOT, "benchmarks", "bsw", "main_bsw")
+    inp = f"{inputs}/bsw/small/bandedSWA_SRR7733443_100k_input.txt"
+    a = subprocess.run([exe, "-pairs", inp, "-t", "1", "-b", "512"], capture_output=True, text=True, timeout=300)
+    b = subprocess.run([exe, "-pairs", inp, "-t", "1", "-b", "512"], capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, GAB_GPU_PARSE="1", GAB_GPUS="1"))
+    assert a.returncode == 0 and b.returncode == 0, b.stderr[-500:]
+    assert "input parsed on the GPU" in b.stdout and "input parsed on the GPU" not in a.stdout
+    assert a.stderr == b.stderr
+    assert [l for l in b.stdout.splitlines() if l.startswith("Overall SW cycles")]
+    odd = tmp_path / "odd.txt"
+    odd.write_text("123456789\n0123\n012\n" * 32)             # nine-digit h0 line: fgets(temp, 10) splits it
+    c = subprocess.run([exe, "-pairs", str(odd), "-t", "1", "-b", "512"], capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, GAB_GPU_PARSE="1", GAB_GPUS="1"))
+    assert "GPU parser declined" in c.stderr
