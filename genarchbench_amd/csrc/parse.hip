@@ -11,6 +11,7 @@
 #include "gab_internal.h"
 #include <algorithm>
 #include <new>
+#include <stdlib.h>
 #include <string.h>
 
 namespace {
@@ -232,6 +233,110 @@ __global__ __launch_bounds__(256) void pairs_meta(const char *__restrict__ text,
     pat_off[i] = ao; pat_len[i] = (int32_t)al; txt_off[i] = bo; txt_len[i] = (int32_t)bl;
 }
 
+// ---- chain / fast-chain ------------------------------------------------------------------------------------------------
+// read_call (chain/src/host_data_io.cpp:13-51) is token based: 6 header fields, n x "x y", everything up to "EOR".  The
+// files the suite ships (and print_return-style writers produce) are line based: one header line, n anchor lines, one
+// "EOR" line.  The GPU path handles exactly that layout and verifies it (header n == number of anchor lines, two
+// unsigned decimal tokens per anchor line); anything else is declined.  The header lines themselves are parsed on the
+// host with the reference's own fscanf format, so the float avg_qspan is converted by the C library as in the reference.
+constexpr int kHdrSlot = 128;             // bytes reserved per header line handed to the host
+
+__global__ __launch_bounds__(256) void chain_mark_eor(const char *__restrict__ text, const int64_t *__restrict__ ls, int64_t nlines,
+                                                      int32_t *is_eor) {
+    const int64_t l = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (l >= nlines) return;
+    const int64_t s = ls[l], e = ls[l + 1] - 1;                // [s, e) without the newline
+    is_eor[l] = (e - s == 3 && text[s] == 'E' && text[s + 1] == 'O' && text[s + 2] == 'R') ? 1 : 0;
+}
+// eor_before[l] = number of EOR lines before line l (len_offsets on is_eor, unpadded) is computed by the caller with
+// the plain scan below
+__global__ __launch_bounds__(256) void flag_block_sums(const int32_t *v, int64_t n, int64_t *block_sums) {
+    __shared__ int64_t sh[256];
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    sh[threadIdx.x] = i < n ? v[i] : 0;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o]; __syncthreads(); }
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = sh[0];
+}
+__global__ __launch_bounds__(256) void flag_offsets(const int32_t *v, int64_t n, const int64_t *block_off, int64_t *off) {
+    __shared__ int64_t sh[256];
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t c = i < n ? v[i] : 0;
+    sh[threadIdx.x] = c;
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {
+        const int64_t a = (int)threadIdx.x >= o ? sh[threadIdx.x - o] : 0;
+        __syncthreads();
+        sh[threadIdx.x] += a;
+        __syncthreads();
+    }
+    if (i < n) off[i] = block_off[blockIdx.x] + sh[threadIdx.x] - c;
+}
+// per EOR line: the call it closes -> header line index, anchor count, and a copy of the header line for the host
+__global__ __launch_bounds__(256) void chain_calls(const char *__restrict__ text, const int64_t *__restrict__ ls, int64_t nlines,
+                                                   const int32_t *__restrict__ is_eor, const int64_t *__restrict__ eor_before,
+                                                   int64_t *eor_line, ParseFlags *fl) {
+    const int64_t l = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (l >= nlines || !is_eor[l]) return;
+    eor_line[eor_before[l]] = l;
+    (void)text; (void)ls; (void)fl;
+}
+__global__ __launch_bounds__(256) void chain_headers(const char *__restrict__ text, const int64_t *__restrict__ ls,
+                                                     const int64_t *__restrict__ eor_line, int64_t ncalls, int32_t *n_anchor,
+                                                     char *hdr_text, ParseFlags *fl) {
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c >= ncalls) return;
+    const int64_t h = c == 0 ? 0 : eor_line[c - 1] + 1, e = eor_line[c];      // header line, EOR line
+    const int64_t na = e - h - 1;
+    const int64_t s = ls[h < e ? h : e], len = ls[(h < e ? h : e) + 1] - 1 - s;
+    const bool ok = na >= 0 && na < (1ll << 31) && len >= 1 && len < kHdrSlot;
+    if (!ok) {
+        atomicAdd(&fl->bad, 1);
+        atomicMin((unsigned int *)&fl->first_bad, (unsigned int)(c > 0x7ffffffe ? 0x7ffffffe : c));
+        n_anchor[c] = 0;
+        hdr_text[c * kHdrSlot] = 0;
+        return;
+    }
+    n_anchor[c] = (int32_t)na;
+    for (int64_t k = 0; k < len; k++) hdr_text[c * kHdrSlot + k] = text[s + k];
+    hdr_text[c * kHdrSlot + len] = 0;
+}
+// one thread per line: an anchor line is "<x> <y>" with unsigned decimal tokens (fscanf "%llu%llu")
+__global__ __launch_bounds__(256) void chain_anchors(const char *__restrict__ text, const int64_t *__restrict__ ls, int64_t nlines,
+                                                     const int32_t *__restrict__ is_eor, const int64_t *__restrict__ eor_before,
+                                                     const int64_t *__restrict__ eor_line, const int64_t *__restrict__ call_off,
+                                                     int64_t ncalls, uint64_t *x, uint64_t *y, ParseFlags *fl) {
+    const int64_t l = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (l >= nlines || is_eor[l]) return;
+    const int64_t c = eor_before[l];
+    if (c >= ncalls) return;                                   // trailing lines after the last EOR: read_call stops there
+    const int64_t h = c == 0 ? 0 : eor_line[c - 1] + 1;
+    if (l == h) return;                                        // the header line
+    int64_t p = ls[l]; const int64_t e = ls[l + 1] - 1;
+    uint64_t v[2] = {0, 0};
+    bool ok = true;
+    for (int t = 0; t < 2 && ok; t++) {
+        while (p < e && (text[p] == ' ' || text[p] == '\t')) p++;
+        int digits = 0; uint64_t acc = 0;
+        while (p < e && text[p] >= '0' && text[p] <= '9') {
+            const uint64_t d = (uint64_t)(text[p] - '0');
+            if (acc > (0xffffffffffffffffull - d) / 10) ok = false;       // would overflow: strtoull saturates, decline
+            acc = acc * 10 + d; digits++; p++;
+        }
+        ok = ok && digits > 0;
+        v[t] = acc;
+    }
+    while (p < e && (text[p] == ' ' || text[p] == '\t' || text[p] == '\r')) p++;
+    ok = ok && p == e;
+    if (!ok) {
+        atomicAdd(&fl->bad, 1);
+        atomicMin((unsigned int *)&fl->first_bad, (unsigned int)(c > 0x7ffffffe ? 0x7ffffffe : c));
+        return;
+    }
+    const int64_t o = call_off[c] + (l - h - 1);
+    x[o] = v[0]; y[o] = v[1];
+}
+
 }  // namespace
 
 // =============================================================================== host side
@@ -243,6 +348,9 @@ struct gab_parser {
     gab_devbuf slabs;       // bsw code slabs
     gab_devbuf ws;          // flags + newline block counts / offsets
     gab_devbuf scan;        // block sums of the length scans
+    gab_devbuf chain;       // chain: per-line flags / prefix, EOR lines, anchor counts, header copies, call offsets
+    gab_devbuf anchors;     // chain: x | y
+    void *h_calls = nullptr; size_t h_calls_cap = 0;       // host: call_off + hdr handed to the caller
     hipEvent_t ev[2] = {nullptr, nullptr};
     float kernel_ms = 0; bool have_stats = false;
 };
@@ -266,7 +374,7 @@ extern "C" int gab_parser_create(int device, gab_parser **out) {
 extern "C" void gab_parser_destroy(gab_parser *p) {
     if (!p) return;
     gab_device_guard g(p->device);
-    p->text.release(); p->idx.release(); p->meta.release(); p->slabs.release(); p->ws.release(); p->scan.release();
+    p->text.release(); p->idx.release(); p->meta.release(); p->slabs.release(); p->ws.release(); p->scan.release(); p->chain.release(); p->anchors.release(); free(p->h_calls);
     for (int k = 0; k < 2; k++) if (p->ev[k]) (void)hipEventDestroy(p->ev[k]);
     delete p;
 }
@@ -446,4 +554,119 @@ extern "C" int gab_parser_last_stats(gab_parser *p, float *kernel_ms) {
     GAB_CHECK(p->have_stats, "gab_parser_last_stats: no completed parse on this handle");
     if (kernel_ms) *kernel_ms = p->kernel_ms;
     return GAB_OK;
+}
+
+// ---- chain: host side ---------------------------------------------------------------------------------------------
+static int scan_flags(gab_parser *p, const int32_t *d_v, int64_t n, int64_t *d_off, int64_t *total, hipStream_t s) {
+    const int64_t blocks = gab_ceil_div(n, 256);
+    int rc = p->scan.reserve(16 * (size_t)(blocks + 4));
+    if (rc) return rc;
+    int64_t *d_bs = p->scan.as<int64_t>(), *d_bo = d_bs + blocks + 1;
+    hipLaunchKernelGGL(flag_block_sums, dim3((unsigned)blocks), dim3(256), 0, s, d_v, n, d_bs);
+    hipLaunchKernelGGL(scan_i64, dim3(1), dim3(1024), 0, s, d_bs, blocks, d_bo);
+    hipLaunchKernelGGL(flag_offsets, dim3((unsigned)blocks), dim3(256), 0, s, d_v, n, d_bo, d_off);
+    GAB_HIP(hipGetLastError());
+    GAB_HIP(hipMemcpyAsync(total, d_bo + blocks, 8, hipMemcpyDeviceToHost, s));
+    GAB_HIP(hipStreamSynchronize(s));
+    return GAB_OK;
+}
+
+extern "C" int gab_chain_parse_device(gab_parser *p, const char *d_text, int64_t nbytes, gab_chain_packed *out, void *stream_) {
+    GAB_CHECK(p && out, "gab_chain_parse_device: NULL argument");
+    memset(out, 0, sizeof *out);
+    GAB_CHECK(nbytes >= 0, "gab_chain_parse_device: nbytes < 0");
+    p->have_stats = false;
+    if (nbytes == 0) return GAB_OK;
+    GAB_CHECK(d_text, "gab_chain_parse_device: NULL text");
+    GAB_CHECK(((uintptr_t)d_text & 15) == 0, "gab_chain_parse_device: the text buffer must be 16-byte aligned");
+    gab_device_guard g(p->device);
+    hipStream_t s = (hipStream_t)stream_;
+    GAB_HIP(hipEventRecord(p->ev[0], s));
+    int64_t nlines = 0; const int64_t *d_ls = nullptr;
+    int rc = build_line_index(p, d_text, nbytes, s, &nlines, &d_ls);
+    if (rc) return rc;
+    if (nlines == 0) return GAB_OK;
+    // chain buffer: is_eor int32[nlines] | eor_before int64[nlines + 1] | then per-call arrays (sized after the scan)
+    const size_t o_before = (4 * (size_t)nlines + 63) & ~(size_t)63, o_calls = o_before + ((8 * (size_t)(nlines + 1) + 63) & ~(size_t)63);
+    rc = p->chain.reserve(o_calls);
+    if (rc) return rc;
+    int32_t *d_eor = p->chain.as<int32_t>();
+    int64_t *d_before = (int64_t *)(p->chain.as<char>() + o_before);
+    ParseFlags *d_fl = (ParseFlags *)p->ws.as<char>();
+    ParseFlags hf = {0, 0x7fffffff};
+    GAB_HIP(hipMemcpyAsync(d_fl, &hf, sizeof hf, hipMemcpyHostToDevice, s));
+    const int64_t lblocks = gab_ceil_div(nlines, 256);
+    hipLaunchKernelGGL(chain_mark_eor, dim3((unsigned)lblocks), dim3(256), 0, s, d_text, d_ls, nlines, d_eor);
+    int64_t ncalls = 0;
+    rc = scan_flags(p, d_eor, nlines, d_before, &ncalls, s);
+    if (rc) return rc;
+    if (ncalls == 0) { gab_set_error("gab_chain_parse: no \"EOR\" line found"); return GAB_EINVAL; }
+    GAB_CHECK(ncalls < (1ll << 31), "gab_chain_parse_device: too many calls");
+    // per-call arrays live in a second buffer so that the per-line arrays above stay valid
+    const size_t c_eorl = 0, c_na = (8 * (size_t)ncalls + 63) & ~(size_t)63, c_off = c_na + ((4 * (size_t)ncalls + 63) & ~(size_t)63);
+    const size_t c_hdr = c_off + ((8 * (size_t)(ncalls + 1) + 63) & ~(size_t)63), c_end = c_hdr + (size_t)ncalls * kHdrSlot;
+    rc = p->meta.reserve(c_end);
+    if (rc) return rc;
+    char *cb = p->meta.as<char>();
+    int64_t *d_eorl = (int64_t *)(cb + c_eorl); int32_t *d_na = (int32_t *)(cb + c_na);
+    int64_t *d_coff = (int64_t *)(cb + c_off); char *d_hdr = cb + c_hdr;
+    hipLaunchKernelGGL(chain_calls, dim3((unsigned)lblocks), dim3(256), 0, s, d_text, d_ls, nlines, d_eor, d_before, d_eorl, d_fl);
+    const int64_t cblocks = gab_ceil_div(ncalls, 256);
+    hipLaunchKernelGGL(chain_headers, dim3((unsigned)cblocks), dim3(256), 0, s, d_text, d_ls, d_eorl, ncalls, d_na, d_hdr, d_fl);
+    int64_t total = 0;
+    rc = scan_flags(p, d_na, ncalls, d_coff, &total, s);
+    if (rc) return rc;
+    GAB_HIP(hipMemcpyAsync(d_coff + ncalls, &total, 8, hipMemcpyHostToDevice, s));
+    rc = p->anchors.reserve(16 * (size_t)std::max<int64_t>(total, 1));
+    if (rc) return rc;
+    uint64_t *d_x = p->anchors.as<uint64_t>(), *d_y = d_x + std::max<int64_t>(total, 1);
+    hipLaunchKernelGGL(chain_anchors, dim3((unsigned)lblocks), dim3(256), 0, s, d_text, d_ls, nlines, d_eor, d_before, d_eorl, d_coff,
+                       ncalls, d_x, d_y, d_fl);
+    GAB_HIP(hipGetLastError());
+    GAB_HIP(hipEventRecord(p->ev[1], s));
+    // host side of the call table: offsets + headers (parsed with the reference's fscanf format)
+    const size_t h_off = 0, h_hdr = (8 * (size_t)(ncalls + 1) + 63) & ~(size_t)63, h_txt = h_hdr + sizeof(gab_chain_hdr) * (size_t)ncalls;
+    const size_t h_end = h_txt + (size_t)ncalls * kHdrSlot;
+    if (h_end > p->h_calls_cap) {
+        free(p->h_calls);
+        p->h_calls = malloc(h_end); p->h_calls_cap = p->h_calls ? h_end : 0;
+        if (!p->h_calls) { gab_set_error("gab_chain_parse: out of host memory"); return GAB_ENOMEM; }
+    }
+    char *hb = (char *)p->h_calls;
+    int64_t *h_coff = (int64_t *)(hb + h_off); gab_chain_hdr *h_hdrs = (gab_chain_hdr *)(hb + h_hdr); char *h_text = hb + h_txt;
+    GAB_HIP(hipMemcpyAsync(h_coff, d_coff, 8 * (size_t)(ncalls + 1), hipMemcpyDeviceToHost, s));
+    GAB_HIP(hipMemcpyAsync(h_text, d_hdr, (size_t)ncalls * kHdrSlot, hipMemcpyDeviceToHost, s));
+    GAB_HIP(hipMemcpyAsync(&hf, d_fl, sizeof hf, hipMemcpyDeviceToHost, s));
+    GAB_HIP(hipStreamSynchronize(s));
+    if (hf.bad) {
+        gab_set_error("gab_chain_parse: %d line(s) are not in the one-record-per-line layout (first: call %d)", hf.bad, hf.first_bad);
+        return GAB_EINVAL;
+    }
+    for (int64_t c2 = 0; c2 < ncalls; c2++) {
+        long long n = 0; float avg = 0; int mdx = 0, mdy = 0, bw = 0, nsegs = 0; int used = 0;
+        const char *line = h_text + (size_t)c2 * kHdrSlot;
+        if (sscanf(line, "%lld%f%d%d%d%d %n", &n, &avg, &mdx, &mdy, &bw, &nsegs, &used) != 6 || line[used] != 0 ||
+            n != h_coff[c2 + 1] - h_coff[c2]) {
+            gab_set_error("gab_chain_parse: call %lld: header \"%s\" does not describe the %lld anchor lines that follow", (long long)c2,
+                          line, (long long)(h_coff[c2 + 1] - h_coff[c2]));
+            return GAB_EINVAL;
+        }
+        h_hdrs[c2].n = n; h_hdrs[c2].avg_qspan = avg; h_hdrs[c2].max_dist_x = mdx; h_hdrs[c2].max_dist_y = mdy;
+        h_hdrs[c2].bw = bw; h_hdrs[c2].n_segs = nsegs;
+    }
+    GAB_HIP(hipEventElapsedTime(&p->kernel_ms, p->ev[0], p->ev[1]));
+    p->have_stats = true;
+    out->ncalls = ncalls; out->total = total; out->d_x = d_x; out->d_y = d_y; out->call_off = h_coff; out->hdr = h_hdrs;
+    return GAB_OK;
+}
+
+extern "C" int gab_chain_parse(gab_parser *p, const char *text, int64_t nbytes, gab_chain_packed *out, void *stream_) {
+    GAB_CHECK(p && out, "gab_chain_parse: NULL argument");
+    GAB_CHECK(nbytes >= 0 && (nbytes == 0 || text), "gab_chain_parse: bad buffer");
+    if (nbytes == 0) { memset(out, 0, sizeof *out); return GAB_OK; }
+    gab_device_guard g(p->device);
+    const char *d_text = nullptr;
+    int rc = stage_text(p, text, nbytes, (hipStream_t)stream_, &d_text);
+    if (rc) return rc;
+    return gab_chain_parse_device(p, d_text, nbytes, out, stream_);
 }

@@ -18,6 +18,16 @@ class PairsPacked(C.Structure):
                 ("d_pat_len", C.c_void_p), ("d_txt_len", C.c_void_p)]
 
 
+class ChainHdr(C.Structure):
+    _fields_ = [("n", C.c_int64), ("avg_qspan", C.c_float), ("max_dist_x", C.c_int32), ("max_dist_y", C.c_int32),
+                ("bw", C.c_int32), ("n_segs", C.c_int32)]
+
+
+class ChainPacked(C.Structure):
+    _fields_ = [("ncalls", C.c_int64), ("total", C.c_int64), ("d_x", C.c_void_p), ("d_y", C.c_void_p),
+                ("call_off", C.POINTER(C.c_int64)), ("hdr", C.c_void_p)]
+
+
 def _d2h(ptr, nbytes, dtype):
     out = np.zeros(max(nbytes // np.dtype(dtype).itemsize, 1), dtype)
     if nbytes:
@@ -57,6 +67,21 @@ class InputParser:
         check(lib().gab_pairs_parse(self._h, buf.ctypes.data_as(C.c_void_p), C.c_int64(len(buf)), C.c_int(1 if swap_longer_first else 0),
                                     C.byref(out), C.c_void_p(stream)))
         return out
+
+    def chain(self, text: bytes, stream=0):
+        """chain / fast-chain input text -> ChainPacked (anchors on the device, call table on the host)"""
+        out = ChainPacked()
+        buf = np.frombuffer(text, np.uint8)
+        check(lib().gab_chain_parse(self._h, buf.ctypes.data_as(C.c_void_p), C.c_int64(len(buf)), C.byref(out), C.c_void_p(stream)))
+        return out
+
+    @staticmethod
+    def chain_to_host(pk):
+        from tools.gabgen import CHAIN_HDR
+        n = pk.ncalls
+        off = np.ctypeslib.as_array(pk.call_off, shape=(n + 1,)).copy()
+        hdr = np.ctypeslib.as_array(C.cast(pk.hdr, C.POINTER(C.c_uint8)), shape=(n * CHAIN_HDR.itemsize,)).copy().view(CHAIN_HDR)
+        return {"call_off": off, "hdr": hdr, "x": _d2h(pk.d_x, 8 * pk.total, np.uint64), "y": _d2h(pk.d_y, 8 * pk.total, np.uint64)}
 
     def last_stats(self):
         ms = C.c_float(0)

@@ -281,6 +281,18 @@ int gab_bsw_parse_pairs_device(gab_parser *p, const char *d_text, int64_t nbytes
 int gab_pairs_parse(gab_parser *p, const char *text, int64_t nbytes, int swap_longer_first, gab_pairs_packed *out, void *stream);
 int gab_pairs_parse_device(gab_parser *p, const char *d_text, int64_t nbytes, int swap_longer_first, gab_pairs_packed *out,
                            void *stream);
+/* chain / fast-chain (chain/src/host_data_io.cpp:13-51): files in the one-record-per-line layout -- a header line
+ * "n avg_qspan max_dist_x max_dist_y bw n_segs", n lines "x y", one line "EOR" -- become the inputs of
+ * gab_chain_run_device: anchors on the device, the call table (offsets and headers) on the host, as that entry point
+ * takes it.  The header lines are converted on the host with the reference's own fscanf format. */
+typedef struct {
+    int64_t ncalls, total;                       /* calls, anchors of all calls */
+    const uint64_t *d_x, *d_y;                   /* device: anchors of all calls back to back */
+    const int64_t *call_off;                     /* host: ncalls + 1 offsets into d_x / d_y */
+    const gab_chain_hdr *hdr;                    /* host: ncalls headers */
+} gab_chain_packed;
+int gab_chain_parse(gab_parser *p, const char *text, int64_t nbytes, gab_chain_packed *out, void *stream);
+int gab_chain_parse_device(gab_parser *p, const char *d_text, int64_t nbytes, gab_chain_packed *out, void *stream);
 /* last parse: kernel milliseconds (HIP events on the launch stream, excluding the host-to-device copy of the text) */
 int gab_parser_last_stats(gab_parser *p, float *kernel_ms);
 

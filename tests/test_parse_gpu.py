@@ -132,3 +132,53 @@ def test_pairs_parse_feeds_bpm_and_wfa():
     torch.cuda.synchronize()
     np.testing.assert_array_equal(score.cpu().numpy(), read_scores(f"{GOLDEN}/bpm_bench.expected.txt"))
     be.close(); ps.close()
+
+
+@pytest.mark.parametrize("name", ["chain_bench", "chain_dense"])
+def test_chain_parse_golden_end_to_end(name):
+    """GPU parse == the token reader; GPU parse -> GPU chain / fast-chain == the reference's expected output"""
+    import torch
+    from genarchbench_amd._lib import check, lib
+    from genarchbench_amd.parse import InputParser
+    from genarchbench_amd.chain import ChainEngine
+    from tests.util import read_chain_output
+    path = f"{GOLDEN}/{name}.in.txt"
+    text = open(path, "rb").read()
+    want = gabgen.read_chain_text(path)
+    ps = InputParser()
+    pk = ps.chain(text)
+    got = ps.chain_to_host(pk)
+    assert pk.ncalls == want.ncalls and pk.total == want.nanchors
+    np.testing.assert_array_equal(got["call_off"][:-1], want.call_off)
+    for f in ("n", "avg_qspan", "max_dist_x", "max_dist_y", "bw", "n_segs"):
+        np.testing.assert_array_equal(got["hdr"][f], want.hdr[f], err_msg=f)
+    np.testing.assert_array_equal(got["x"], want.x); np.testing.assert_array_equal(got["y"], want.y)
+    ce = ChainEngine(device=0)
+    for mode, tag in ((0, "chain"), (1, "fastchain")):
+        score = torch.empty(pk.total, dtype=torch.int32, device="cuda:0"); parent = torch.empty_like(score)
+        check(lib().gab_chain_run_device(ce._h, C.c_int(mode), C.c_void_p(pk.d_x), C.c_void_p(pk.d_y), pk.call_off, C.c_void_p(pk.hdr),
+                                         C.c_int64(pk.ncalls), C.c_void_p(score.data_ptr()), C.c_void_p(parent.data_ptr()), C.c_void_p(0)))
+        torch.cuda.synchronize()
+        ws, wp = read_chain_output(f"{GOLDEN}/{name}.{tag}.expected.txt")
+        np.testing.assert_array_equal(score.cpu().numpy(), ws); np.testing.assert_array_equal(parent.cpu().numpy(), wp)
+    ce.close(); ps.close()
+
+
+def test_chain_parse_declines_other_layouts():
+    from genarchbench_amd._lib import GabError
+    from genarchbench_amd.parse import InputParser
+    ps = InputParser()
+    ok = b"2\t15.000000\t5000\t5000\t500\t1\n10\t20\n30\t40\nEOR\n"
+    pk = ps.chain(ok)
+    got = ps.chain_to_host(pk)
+    assert pk.ncalls == 1 and list(got["x"]) == [10, 30] and list(got["y"]) == [20, 40] and got["hdr"]["avg_qspan"][0] == np.float32(15.0)
+    two = ps.chain(ok + b"0\t1.5\t1\t2\t3\t4\nEOR\n")
+    assert two.ncalls == 2 and two.total == 2
+    for bad in (b"3\t15.0\t5000\t5000\t500\t1\n10\t20\n30\t40\nEOR\n",            # header n != anchor lines
+                b"2\t15.0\t5000\t5000\t500\t1\n10 20 30 40\nEOR\n",              # all anchors on one line (legal for fscanf)
+                b"1\t15.0\t5000\t5000\t500\t1\n-5\t20\nEOR\n",                    # sign
+                b"1\t15.0\t5000\t5000\t500\t1\n99999999999999999999\t20\nEOR\n",  # overflows 64 bits
+                b"1\t15.0\t5000\t5000\t500\t1\n10\t20\n"):                         # no EOR
+        with pytest.raises(GabError):
+            ps.chain(bad)
+    ps.close()
