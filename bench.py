@@ -27,6 +27,31 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
+# HBM traffic of the dominant kernel(s) of a workload's LARGE configuration, measured once per round with rocprofv3 PMC
+# counters in separate passes (tools/profiling/hbm_traffic.sh -> profiles/r01_hbm_traffic.json); `double_fetch`: the
+# kernel reads wide coalesced streams, for which gfx950's FETCH_SIZE reports half the bytes (MI355X_MICROARCH.md, HBM)
+TRAFFIC_KERNELS = {"bsw": (["bsw_dp8"], False), "chain": (["chain_hw_kernel"], False), "fast-chain": (["fastchain_kernel"], False),
+                   "bpm": (["bpm_score<3>"], False), "wfa": (["wfa_lds<16>"], False), "fmi": (["fmi_seed_kernel<true>"], False),
+                   "fmi-sa": (["fmi_sa_kernel"], False), "parse-bsw": (["nl_count", "nl_fill", "bsw_meta", "bsw_codes", "len_offsets",
+                                                                       "len_block_sums"], True)}
+
+
+def pmc_traffic(name, is_large, kernel_ms):
+    """-> (GB/s over the live kernel time, detail dict) or (None, None)"""
+    path = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
+    if not is_large or name not in TRAFFIC_KERNELS or not os.path.exists(path) or not kernel_ms:
+        return None, None
+    tab = json.load(open(path)).get(name, {})
+    kernels, double_fetch = TRAFFIC_KERNELS[name]
+    f = sum(tab.get(k, {}).get("fetch_gb_raw", 0.0) for k in kernels) * (2.0 if double_fetch else 1.0)
+    w = sum(tab.get(k, {}).get("write_gb", 0.0) for k in kernels)
+    if f + w == 0:
+        return None, None
+    return round((f + w) / (kernel_ms * 1e-3), 3), {"fetch_GB_per_step": round(f, 3), "write_GB_per_step": round(w, 3),
+                                                     "fetch_correction": "x2 (wide coalesced streams)" if double_fetch else "none (narrow or random accesses)",
+                                                     "source": "profiles/r01_hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, one step"}
+
+
 def host_cores():
     """CPU threads this process may really use: affinity mask capped by the cgroup quota"""
     n = len(os.sched_getaffinity(0))
@@ -820,6 +845,11 @@ def main():
                        "items_per_gpu": items, "sharding": f"{world} x independent id ranges, no collective"},
             "roofline": wl.roofline(), "extra": wl.extra(ms), "parity": verdict,
         }
+        km = out["extra"].get("dominant_kernel_ms")
+        t, detail = pmc_traffic(W.name, items == W.default_items, km)
+        if t is not None:
+            out["roofline"]["traffic"] = t                  # GB/s of real HBM traffic, comparable with `achieved`
+            out["roofline"]["traffic_detail"] = detail
         # BASELINE.md 3.5 also asks for the fraction of the MEASURED copy bandwidth (6.29 TB/s, MI355X_MICROARCH.md)
         if out["roofline"].get("unit") == "GB/s" and out["roofline"].get("achieved") is not None:
             out["roofline"]["frac_of_measured_copy_6290"] = round(out["roofline"]["achieved"] / 6290.0, 6)
