@@ -124,11 +124,11 @@ class BswWorkload:
         k = float(np.mean(self.kernel_ms)) if self.kernel_ms else None
         return {"gcups": round(self.cells / (ms_per_step * 1e6), 2) if ms_per_step else None,
                 "cells_per_step": self.cells, "dominant_kernel": "bsw_dp8", "dominant_kernel_ms": k,
-                # the bound that matters: integer VALU issue.  21.1 lane-instructions per DP cell is the PMC figure
+                # the bound that matters: integer VALU issue.  19.7 lane-instructions per DP cell is the PMC figure
                 # (SQ_INSTS_VALU x 64 / cells, profiles/r01_bsw_pmc.md); peak = 256 CUs x 64 lanes x 2.4 GHz.
-                "valu": {"lane_instr_per_cell": 21.1, "achieved_T_lane_instr_per_s":
-                         round(21.1 * self.cells / (k * 1e9), 2) if k else None, "peak_T_lane_instr_per_s": 39.3,
-                         "frac": round(21.1 * self.cells / (k * 1e9) / 39.3, 3) if k else None}}
+                "valu": {"lane_instr_per_cell": 19.7, "achieved_T_lane_instr_per_s":
+                         round(19.7 * self.cells / (k * 1e9), 2) if k else None, "peak_T_lane_instr_per_s": 39.3,
+                         "frac": round(19.7 * self.cells / (k * 1e9) / 39.3, 3) if k else None}}
 
     def roofline(self):
         k = float(np.mean(self.kernel_ms))
