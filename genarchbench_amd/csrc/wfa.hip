@@ -75,6 +75,12 @@ __device__ __forceinline__ uint32_t lds_ld4(const uint8_t *base, int byte_off) {
     const uint32_t *w = reinterpret_cast<const uint32_t *>(base + (byte_off & ~3));
     return __builtin_amdgcn_alignbyte(w[1], w[0], (uint32_t)(byte_off & 3));
 }
+// eight bytes at any byte offset: three aligned dwords, two v_alignbyte
+__device__ __forceinline__ uint64_t lds_ld8(const uint8_t *base, int byte_off) {
+    const uint32_t *w = reinterpret_cast<const uint32_t *>(base + (byte_off & ~3));
+    const uint32_t w0 = w[0], w1 = w[1], w2 = w[2], sh = (uint32_t)(byte_off & 3);
+    return (uint64_t)__builtin_amdgcn_alignbyte(w2, w1, sh) << 32 | __builtin_amdgcn_alignbyte(w1, w0, sh);
+}
 __device__ __forceinline__ uint32_t glb_ld4(const char *p) { uint32_t w; __builtin_memcpy(&w, p, 4); return w; }
 
 // One pair, one wave.  LDSSEQ: P/T are LDS copies padded with kSeqPad bytes of 'X'/'Y';
@@ -109,6 +115,14 @@ __device__ bool wfa_pair(WfStore<OffT> &st, const WfaPen pen, const uint8_t *P, 
                 int o = (int)st.pool[cur.m + (k - cur.lo)];
                 int v = o - k, h = o;
                 for (;;) {
+                    if (LDSSEQ && v >= 0 && v <= plen && h >= 0 && h <= tlen) {
+                        // eight bases per step (the 'X' / 'Y' padding behind the strings is 16 bytes long and never matches)
+                        const uint64_t d8 = lds_ld8(P, v) ^ lds_ld8(T, h);
+                        if (d8 == 0) { o += 8; v += 8; h += 8; work += 8; continue; }
+                        const int c8 = __builtin_ctzll(d8) >> 3;
+                        o += c8; work += c8;
+                        break;
+                    }
                     if (v >= 0 && v <= plen && h >= 0 && h <= tlen) {
                         uint32_t a, b;
                         if (LDSSEQ) { a = lds_ld4(P, v); b = lds_ld4(T, h); }
