@@ -30,7 +30,7 @@ namespace {
 
 constexpr int kNull = -10;                 // AFFINE_WAVEFRONT_OFFSET_NULL
 constexpr int kNone = 0x7fffffff;          // "no wavefront" marker in the directory
-constexpr int kSeqPad = 16;                // physical 'X'/'Y' padding behind each LDS sequence
+constexpr int kSeqPad = 32;                // physical 'X'/'Y' padding behind each LDS sequence (>= 16 + 3 for the 16-byte extension reads)
 constexpr int kLdsMaxLen = 2040;           // longest sequence the LDS kernels accept
 
 struct WfaPen { int32_t x, o, e; };
@@ -116,10 +116,10 @@ __device__ bool wfa_pair(WfStore<OffT> &st, const WfaPen pen, const uint8_t *P, 
                 int v = o - k, h = o;
                 for (;;) {
                     if (LDSSEQ && v >= 0 && v <= plen && h >= 0 && h <= tlen) {
-                        // eight bases per step (the 'X' / 'Y' padding behind the strings is 16 bytes long and never matches)
-                        const uint64_t d8 = lds_ld8(P, v) ^ lds_ld8(T, h);
-                        if (d8 == 0) { o += 8; v += 8; h += 8; work += 8; continue; }
-                        const int c8 = __builtin_ctzll(d8) >> 3;
+                        // sixteen bases per step (the 'X' / 'Y' padding behind the strings never matches)
+                        const uint64_t d8 = lds_ld8(P, v) ^ lds_ld8(T, h), e8 = lds_ld8(P, v + 8) ^ lds_ld8(T, h + 8);
+                        if ((d8 | e8) == 0) { o += 16; v += 16; h += 16; work += 16; continue; }
+                        const int c8 = d8 ? __builtin_ctzll(d8) >> 3 : 8 + (__builtin_ctzll(e8) >> 3);
                         o += c8; work += c8;
                         break;
                     }
