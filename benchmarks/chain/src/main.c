@@ -88,6 +88,50 @@ int main(int argc, char **argv) {
     FILE *in = fopen(in_name, "r"), *out = fopen(out_name, "w");
     if (!in || !out) { fprintf(stderr, "ERROR: cannot open %s\n", !in ? in_name : out_name); exit(EXIT_FAILURE); }
 
+    /* GAB_GPU_PARSE=1 (one GPU): the file is read in one piece and parsed ON the GPU (gab_chain_parse);
+     * anchors stay on the device, the ROI calls gab_chain_run_device.  Files that are not in the one-record-per-line layout
+     * are declined and take the fscanf path below. */
+    if (getenv("GAB_GPU_PARSE") && atoi(getenv("GAB_GPU_PARSE")) && gab_pick_gpus(gpus) == 1) {
+        fseek(in, 0L, SEEK_END);
+        const long fsz = ftell(in);
+        fseek(in, 0L, SEEK_SET);
+        char *whole = (char *)malloc((size_t)fsz + 1);
+        gab_parser *ps = NULL; gab_chain_packed pk;
+        if (whole && fread(whole, 1, (size_t)fsz, in) == (size_t)fsz && gab_parser_create(0, &ps) == 0 &&
+            gab_chain_parse(ps, whole, fsz, &pk, NULL) == 0) {
+            free(whole);
+            fprintf(stderr, "Running with threads: %d (input parsed on the GPU)\n", numThreads);
+            gab_chain *h = NULL;
+            GAB_DIE_IF(gab_chain_create(0, &h), "gab_chain_create");
+            int32_t *d_score = NULL, *d_parent = NULL;
+            GAB_DIE_IF(gab_device_alloc(0, 4 * (size_t)pk.total + 4, (void **)&d_score), "gab_device_alloc");
+            GAB_DIE_IF(gab_device_alloc(0, 4 * (size_t)pk.total + 4, (void **)&d_parent), "gab_device_alloc");
+            int32_t *sc = (int32_t *)malloc(4 * (size_t)pk.total + 4), *pa = (int32_t *)malloc(4 * (size_t)pk.total + 4);
+            const double t0g = gab_now();
+            gab_roi_begin();
+            GAB_DIE_IF(gab_chain_run_device(h, GAB_CHAIN_MODE, pk.d_x, pk.d_y, pk.call_off, pk.hdr, pk.ncalls, d_score, d_parent, NULL),
+                       "gab_chain_run_device");
+            GAB_DIE_IF(gab_device_copy_to_host(0, sc, d_score, 4 * (size_t)pk.total), "gab_device_copy_to_host");
+            GAB_DIE_IF(gab_device_copy_to_host(0, pa, d_parent, 4 * (size_t)pk.total), "gab_device_copy_to_host");
+            gab_roi_end();
+            const double rt = gab_now() - t0g;
+            for (int64_t c2 = 0; c2 < pk.ncalls; c2++) {
+                fprintf(out, "%lld\n", (long long)pk.hdr[c2].n);
+                const int64_t o = pk.call_off[c2];
+                for (int64_t i = 0; i < pk.hdr[c2].n; i++) fprintf(out, "%d\t%d\n", sc[o + i], pa[o + i]);
+                fprintf(out, "EOR\n");
+            }
+            fprintf(stderr, "Time in kernel: %.2f sec\n", rt);
+            fclose(in); fclose(out);
+            gab_device_free(0, d_score); gab_device_free(0, d_parent); gab_chain_destroy(h); gab_parser_destroy(ps); free(sc); free(pa);
+            return 0;
+        }
+        fprintf(stderr, "GPU parser declined the file (%s); using the fscanf parser\n", gab_last_error());
+        if (ps) gab_parser_destroy(ps);
+        free(whole);
+        fseek(in, 0L, SEEK_SET);
+    }
+
     /* read_call (host_data_io.cpp:13-51): 6 header fields, n x "x y", then everything up to "EOR" */
     size_t ccap = 1024, acap = 1 << 20, ncalls = 0, na = 0;
     gab_chain_hdr *hdr = (gab_chain_hdr *)malloc(ccap * sizeof(*hdr));

@@ -64,3 +64,17 @@ def test_bsw_driver_gpu_parse_mode(inputs, tmp_path):
     c = subprocess.run([exe, "-pairs", str(odd), "-t", "1", "-b", "512"], capture_output=True, text=True, timeout=300,
                        env=dict(os.environ, GAB_GPU_PARSE="1", GAB_GPUS="1"))
     assert "GPU parser declined" in c.stderr
+
+
+@pytest.mark.parametrize("bench", ["chain", "fast-chain"])
+def test_chain_driver_gpu_parse_mode(inputs, tmp_path, bench):
+    """GAB_GPU_PARSE=1 in the chain drivers: same output file as the fscanf path"""
+    exe = os.path.join(ROOT, "benchmarks", bench, "chain")
+    inp = f"{inputs}/chain/small/in-1k.txt"
+    a, b = str(tmp_path / "a.txt"), str(tmp_path / "b.txt")
+    ra = subprocess.run([exe, "-i", inp, "-o", a, "-t", "1"], capture_output=True, text=True, timeout=300)
+    rb = subprocess.run([exe, "-i", inp, "-o", b, "-t", "1"], capture_output=True, text=True, timeout=300,
+                        env=dict(os.environ, GAB_GPU_PARSE="1", GAB_GPUS="1"))
+    assert ra.returncode == 0 and rb.returncode == 0, rb.stderr[-500:]
+    assert "input parsed on the GPU" in rb.stderr and "Time in kernel" in rb.stderr
+    assert open(a).read() == open(b).read()
