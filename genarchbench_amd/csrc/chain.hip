@@ -31,6 +31,7 @@
 #include <vector>
 #include <stdlib.h>
 #include <string.h>
+#include <type_traits>
 
 namespace {
 
@@ -406,22 +407,29 @@ __global__ __launch_bounds__(64 * (1 + kFcHelpers)) void fastchain_kernel(const 
     const uint64_t mdx64 = (uint64_t)(int64_t)mdx;
     const double avg_d = (double)w.avg_qspan;
     const float k32 = (float)(0.01 * (double)w.avg_qspan);
+    const int32_t mq = mdy < mdx ? mdy : mdx;
+    const uint32_t mq_u = mq < 0 ? 0u : (uint32_t)mq;       // negative limits reject every predecessor
     const int64_t nblocks = (n + 63) / 64;
 
     // any_narrow: wave-uniform "some lane of this block has a window of <= 6 predecessors" (only near the start of a
     // call): only then is the double-precision gap cost evaluated at all (real branch, not a select)
-    auto score_pred = [&](int32_t xa, int32_t ya, int32_t qsa, bool wide_a, bool any_narrow, int32_t xj, int32_t yj, int32_t sj,
+    // NARROW is a compile-time tag: written as a run-time `if (any_narrow)` the compiler if-converts the branch and the four
+    // double-precision instructions are executed on every step of every loop
+    auto score_pred = [&](auto narrow_tag, int32_t xa, int32_t ya, int32_t qsa, bool wide_a, int32_t xj, int32_t yj, int32_t sj,
                           bool &ok) -> int32_t {
+        constexpr bool NARROW = decltype(narrow_tag)::value;
         const int32_t ddr = (int32_t)((uint32_t)xa - (uint32_t)xj);
         const int32_t ddq = (int32_t)((uint32_t)ya - (uint32_t)yj);
-        const uint32_t diff = (uint32_t)ddr - (uint32_t)ddq;
-        const int32_t dd = (int32_t)((int32_t)diff < 0 ? 0u - diff : diff);
-        ok = !(dd > bw || ddr == 0 || ddq <= 0 || ddq > mdy || ddq > mdx);
+        const int32_t diff = (int32_t)((uint32_t)ddr - (uint32_t)ddq);
+        const int32_t dd = max(diff, (int32_t)(0u - (uint32_t)diff));          // |diff| with the AVX wrap-around for INT_MIN
+        // ddq <= 0 || ddq > max_dist_y || ddq > max_dist_x  ==  (unsigned)(ddq - 1) >= min(max_dist_y, max_dist_x)
+        ok = !(dd > bw || ddr == 0 || (uint32_t)ddq - 1u >= mq_u);
         const int32_t oc = min(min(ddr, ddq), qsa);
-        const int32_t lg = dd ? ilog2_u32((uint32_t)dd) : 0;
-        int32_t gc = (int32_t)floorf(__fmul_rn((float)dd, k32)) + (lg >> 1);
-        if (any_narrow) {
-            const int32_t gd = (int32_t)__dmul_rn(__dmul_rn((double)dd, .01), avg_d) + (lg >> 1);
+        // ilog2(dd) >> 1 with ilog2(0) = 0:  (31 - clz(dd | 1)) >> 1 = 15 - (clz(dd | 1) >> 1)
+        const int32_t lgh = 15 - (__clz((int)((uint32_t)dd | 1u)) >> 1);
+        int32_t gc = (int32_t)floorf(__fmul_rn((float)dd, k32)) + lgh;
+        if constexpr (NARROW) {
+            const int32_t gd = (int32_t)__dmul_rn(__dmul_rn((double)dd, .01), avg_d) + lgh;
             gc = wide_a ? gc : gd;
         }
         return (int32_t)((uint32_t)sj + (uint32_t)oc - (uint32_t)gc);
@@ -480,13 +488,16 @@ __global__ __launch_bounds__(64 * (1 + kFcHelpers)) void fastchain_kernel(const 
                     }
                     const int cnt = (int)(jb - st_lo + 1 < 64 ? jb - st_lo + 1 : 64);
                     const int jrel0 = (int)(jb - i0);
-                    for (int l = 0; l < cnt; l++) {
-                        const int32_t xj = __builtin_amdgcn_readlane(vx, l), yj = __builtin_amdgcn_readlane(vy, l), sj = __builtin_amdgcn_readlane(vs, l);
-                        const int jrel = jrel0 - l;
-                        bool ok;
-                        const int32_t sc = score_pred(xa, ya, qsa, wide_a, any_narrow, xj, yj, sj, ok);
-                        if (mine && ok && jrel >= st_rel && sc > best) { best = sc; best_j = jrel; }      // descending j: strict >
-                    }
+                    auto far_chunk = [&](auto tag) {
+                        for (int l = 0; l < cnt; l++) {
+                            const int32_t xj = __builtin_amdgcn_readlane(vx, l), yj = __builtin_amdgcn_readlane(vy, l), sj = __builtin_amdgcn_readlane(vs, l);
+                            const int jrel = jrel0 - l;
+                            bool ok;
+                            const int32_t sc = score_pred(tag, xa, ya, qsa, wide_a, xj, yj, sj, ok);
+                            if (mine && ok && jrel >= st_rel && sc > best) { best = sc; best_j = jrel; }      // descending j: strict >
+                        }
+                    };
+                    if (any_narrow) far_chunk(std::true_type{}); else far_chunk(std::false_type{});
                 }
                 part_best[par][wave - 1][lane] = best; part_j[par][wave - 1][lane] = best_j;
                 if (wave == 1) part_st[par][lane] = st_rel;
@@ -513,21 +524,27 @@ __global__ __launch_bounds__(64 * (1 + kFcHelpers)) void fastchain_kernel(const 
             // near predecessors: the previous block, newest (lane 63) first; they are newer than every far one
             int32_t nbest = (int32_t)0x80000000, nbj = 0;
             bool nhave = false;
-            for (int l = pnb - 1; l >= 0; l--) {
-                const int32_t xj = __builtin_amdgcn_readlane(pxa, l), yj = __builtin_amdgcn_readlane(pya, l), sj = __builtin_amdgcn_readlane(pbest, l);
-                const int jrel = l - 64;
-                bool ok;
-                const int32_t sc = score_pred(xa, ya, qsa, wide_a, any_narrow, xj, yj, sj, ok);
-                if (mine && ok && jrel >= st_rel && (!nhave || sc > nbest)) { nbest = sc; nbj = jrel; nhave = true; }
-            }
+            auto near_fold = [&](auto tag) {
+                for (int l = pnb - 1; l >= 0; l--) {
+                    const int32_t xj = __builtin_amdgcn_readlane(pxa, l), yj = __builtin_amdgcn_readlane(pya, l), sj = __builtin_amdgcn_readlane(pbest, l);
+                    const int jrel = l - 64;
+                    bool ok;
+                    const int32_t sc = score_pred(tag, xa, ya, qsa, wide_a, xj, yj, sj, ok);
+                    if (mine && ok && jrel >= st_rel && (!nhave || sc > nbest)) { nbest = sc; nbj = jrel; nhave = true; }
+                }
+            };
+            if (any_narrow) near_fold(std::true_type{}); else near_fold(std::false_type{});
             if (nhave && (nbest > best || (have && nbest == best))) { best = nbest; best_j = nbj; have = true; }
             // predecessors inside the block
-            for (int b = 0; b + 1 < nb; b++) {
-                const int32_t xj = __builtin_amdgcn_readlane(xa, b), yj = __builtin_amdgcn_readlane(ya, b), sj = __builtin_amdgcn_readlane(best, b);
-                bool ok;
-                const int32_t sc = score_pred(xa, ya, qsa, wide_a, any_narrow, xj, yj, sj, ok);
-                if (mine && lane > b && ok && b >= st_rel && (sc > best || (have && sc == best))) { best = sc; best_j = b; have = true; }
-            }
+            auto block_fold = [&](auto tag) {
+                for (int b = 0; b + 1 < nb; b++) {
+                    const int32_t xj = __builtin_amdgcn_readlane(xa, b), yj = __builtin_amdgcn_readlane(ya, b), sj = __builtin_amdgcn_readlane(best, b);
+                    bool ok;
+                    const int32_t sc = score_pred(tag, xa, ya, qsa, wide_a, xj, yj, sj, ok);
+                    if (mine && lane > b && ok && b >= st_rel && (sc > best || (have && sc == best))) { best = sc; best_j = b; have = true; }
+                }
+            };
+            if (any_narrow) block_fold(std::true_type{}); else block_fold(std::false_type{});
             if (mine) { S[i0 + lane] = best; P[i0 + lane] = have ? (int32_t)(i0 + best_j) : -1; }
             pxa = xa; pya = ya; pbest = best; pnb = nb;
         }
