@@ -148,7 +148,7 @@ __global__ __launch_bounds__(64 * (1 + kChHelpers)) void chain_hw_kernel(const C
     __shared__ uint64_t meta_x[2][kChBlock], meta_y[2][kChBlock];
 
     const ChainWork w = work[blockIdx.x];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave index: uniform, say so
     const uint64_t *X = xs + w.off, *Y = ys + w.off;
     int32_t *S = score_out + w.off, *P = parent_out + w.off;
     int32_t *GM = gmarks_all + w.off;
@@ -399,7 +399,7 @@ __global__ __launch_bounds__(64 * (1 + kFcHelpers)) void fastchain_kernel(const 
                                                                           int32_t *parent_out, unsigned long long *evals_out) {
     __shared__ int32_t part_best[2][kFcHelpers][64], part_j[2][kFcHelpers][64], part_st[2][64];
     const ChainWork w = work[blockIdx.x];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave index: uniform, say so
     const uint64_t *X = xs + w.off, *Y = ys + w.off;
     int32_t *S = score_out + w.off, *P = parent_out + w.off;
     const int64_t n = w.n;
