@@ -488,14 +488,18 @@ __global__ __launch_bounds__(64 * (1 + kFcHelpers)) void fastchain_kernel(const 
                     }
                     const int cnt = (int)(jb - st_lo + 1 < 64 ? jb - st_lo + 1 : 64);
                     const int jrel0 = (int)(jb - i0);
+                    // (four steps per trip by hand: the evaluations are independent, only the running maximum is a chain)
                     auto far_chunk = [&](auto tag) {
-                        for (int l = 0; l < cnt; l++) {
+                        auto step = [&](int l) {
                             const int32_t xj = __builtin_amdgcn_readlane(vx, l), yj = __builtin_amdgcn_readlane(vy, l), sj = __builtin_amdgcn_readlane(vs, l);
                             const int jrel = jrel0 - l;
                             bool ok;
                             const int32_t sc = score_pred(tag, xa, ya, qsa, wide_a, xj, yj, sj, ok);
                             if (mine && ok && jrel >= st_rel && sc > best) { best = sc; best_j = jrel; }      // descending j: strict >
-                        }
+                        };
+                        int l = 0;
+                        for (; l + 3 < cnt; l += 4) { step(l); step(l + 1); step(l + 2); step(l + 3); }
+                        for (; l < cnt; l++) step(l);
                     };
                     if (any_narrow) far_chunk(std::true_type{}); else far_chunk(std::false_type{});
                 }
@@ -525,13 +529,16 @@ __global__ __launch_bounds__(64 * (1 + kFcHelpers)) void fastchain_kernel(const 
             int32_t nbest = (int32_t)0x80000000, nbj = 0;
             bool nhave = false;
             auto near_fold = [&](auto tag) {
-                for (int l = pnb - 1; l >= 0; l--) {
+                auto step = [&](int l) {
                     const int32_t xj = __builtin_amdgcn_readlane(pxa, l), yj = __builtin_amdgcn_readlane(pya, l), sj = __builtin_amdgcn_readlane(pbest, l);
                     const int jrel = l - 64;
                     bool ok;
                     const int32_t sc = score_pred(tag, xa, ya, qsa, wide_a, xj, yj, sj, ok);
                     if (mine && ok && jrel >= st_rel && (!nhave || sc > nbest)) { nbest = sc; nbj = jrel; nhave = true; }
-                }
+                };
+                int l = pnb - 1;
+                for (; l >= 3; l -= 4) { step(l); step(l - 1); step(l - 2); step(l - 3); }
+                for (; l >= 0; l--) step(l);
             };
             if (any_narrow) near_fold(std::true_type{}); else near_fold(std::false_type{});
             if (nhave && (nbest > best || (have && nbest == best))) { best = nbest; best_j = nbj; have = true; }
