@@ -543,13 +543,27 @@ __global__ __launch_bounds__(64 * (1 + kFcHelpers)) void fastchain_kernel(const 
             if (any_narrow) near_fold(std::true_type{}); else near_fold(std::false_type{});
             if (nhave && (nbest > best || (have && nbest == best))) { best = nbest; best_j = nbj; have = true; }
             // predecessors inside the block
+            // The only true chain: anchor b's score is final after the folds 0 .. b-1 and feeds b+1 ...  Everything about
+            // the pair (a, b) that does not involve a score -- filters, overlap, gap cost -- is computed four steps ahead,
+            // so the dependent part of a step is readlane(best, b) + add + compare + select.
             auto block_fold = [&](auto tag) {
-                for (int b = 0; b + 1 < nb; b++) {
-                    const int32_t xj = __builtin_amdgcn_readlane(xa, b), yj = __builtin_amdgcn_readlane(ya, b), sj = __builtin_amdgcn_readlane(best, b);
-                    bool ok;
-                    const int32_t sc = score_pred(tag, xa, ya, qsa, wide_a, xj, yj, sj, ok);
-                    if (mine && lane > b && ok && b >= st_rel && (sc > best || (have && sc == best))) { best = sc; best_j = b; have = true; }
+                auto geom = [&](int b, bool &ok) -> int32_t {
+                    const int32_t xj = __builtin_amdgcn_readlane(xa, b), yj = __builtin_amdgcn_readlane(ya, b);
+                    const int32_t g = score_pred(tag, xa, ya, qsa, wide_a, xj, yj, 0, ok);          // oc - gc (sj = 0)
+                    ok = ok && mine && lane > b && b >= st_rel;
+                    return g;
+                };
+                auto fold = [&](int b, int32_t g, bool ok) {
+                    const int32_t sc = (int32_t)((uint32_t)__builtin_amdgcn_readlane(best, b) + (uint32_t)g);
+                    if (ok && (sc > best || (have && sc == best))) { best = sc; best_j = b; have = true; }
+                };
+                int b = 0;
+                for (; b + 4 < nb; b += 4) {
+                    bool o0, o1, o2, o3;
+                    const int32_t g0 = geom(b, o0), g1 = geom(b + 1, o1), g2 = geom(b + 2, o2), g3 = geom(b + 3, o3);
+                    fold(b, g0, o0); fold(b + 1, g1, o1); fold(b + 2, g2, o2); fold(b + 3, g3, o3);
                 }
+                for (; b + 1 < nb; b++) { bool o; const int32_t g = geom(b, o); fold(b, g, o); }
             };
             if (any_narrow) block_fold(std::true_type{}); else block_fold(std::false_type{});
             if (mine) { S[i0 + lane] = best; P[i0 + lane] = have ? (int32_t)(i0 + best_j) : -1; }
