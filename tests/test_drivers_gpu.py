@@ -78,3 +78,16 @@ def test_chain_driver_gpu_parse_mode(inputs, tmp_path, bench):
     assert ra.returncode == 0 and rb.returncode == 0, rb.stderr[-500:]
     assert "input parsed on the GPU" in rb.stderr and "Time in kernel" in rb.stderr
     assert open(a).read() == open(b).read()
+
+
+def test_bpm_driver_gpu_parse_mode(inputs, tmp_path):
+    """GAB_GPU_PARSE=1 in the bpm driver: same output file as the getline path"""
+    exe = os.path.join(ROOT, "benchmarks", "bpm", "bin", "align_benchmark")
+    inp = f"{inputs}/bpm/small/BPM_SRR7733443_100k_input.txt"
+    a, b = str(tmp_path / "a.txt"), str(tmp_path / "b.txt")
+    ra = subprocess.run([exe, "-a", "bpm-edit", "-i", inp, "-o", a, "-t", "1"], capture_output=True, text=True, timeout=300)
+    rb = subprocess.run([exe, "-a", "bpm-edit", "-i", inp, "-o", b, "-t", "1"], capture_output=True, text=True, timeout=300,
+                        env=dict(os.environ, GAB_GPU_PARSE="1", GAB_GPUS="1"))
+    assert ra.returncode == 0 and rb.returncode == 0, rb.stderr[-500:]
+    assert "indexed on the GPU" in rb.stderr
+    assert open(a).read() == open(b).read() and len(open(a).read()) > 0
