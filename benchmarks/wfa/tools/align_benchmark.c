@@ -66,6 +66,57 @@ int main(int argc, char **argv) {
     FILE *in = fopen(input, "r");
     if (!in) { fprintf(stderr, "Input file '%s' couldn't be opened\n", input); exit(1); }
     FILE *out = output ? fopen(output, "w") : NULL;
+    /* GAB_GPU_PARSE=1 (one GPU): the file is read in one piece and indexed ON the GPU (gab_pairs_parse, no swap; SURVEY.md
+     * 8f row f1); sequences are used in place in the device copy of the text, the CIGARs come back in one copy. */
+    if (getenv("GAB_GPU_PARSE") && atoi(getenv("GAB_GPU_PARSE")) && gab_pick_gpus(gpus) == 1) {
+        fseek(in, 0L, SEEK_END);
+        const long fsz = ftell(in);
+        fseek(in, 0L, SEEK_SET);
+        char *whole = (char *)malloc((size_t)fsz + 1);
+        gab_parser *ps = NULL; gab_pairs_packed pk;
+        if (whole && fread(whole, 1, (size_t)fsz, in) == (size_t)fsz && gab_parser_create(0, &ps) == 0 &&
+            gab_pairs_parse(ps, whole, fsz, 0, &pk, NULL) == 0) {
+            free(whole); fclose(in);
+            gab_wfa_penalties pen; pen.mismatch = ctx.pen.mismatch; pen.gap_opening = ctx.pen.gap_opening; pen.gap_extension = ctx.pen.gap_extension;
+            gab_wfa *h = NULL;
+            GAB_DIE_IF(gab_wfa_create(&pen, 0, &h), "gab_wfa_create");
+            char *d_ops = NULL; int32_t *d_len = NULL, *d_score = NULL;
+            GAB_DIE_IF(gab_device_alloc(0, (size_t)pk.cap_bytes + 16, (void **)&d_ops), "gab_device_alloc");
+            GAB_DIE_IF(gab_device_alloc(0, 4 * (size_t)pk.n + 4, (void **)&d_len), "gab_device_alloc");
+            GAB_DIE_IF(gab_device_alloc(0, 4 * (size_t)pk.n + 4, (void **)&d_score), "gab_device_alloc");
+            char *ops = (char *)malloc((size_t)pk.cap_bytes + 16);
+            int64_t *ooff = (int64_t *)malloc(8 * (size_t)pk.n + 8); int32_t *olen = (int32_t *)malloc(4 * (size_t)pk.n + 4);
+            const double t0g = tv_now();
+            gab_roi_begin();
+            GAB_DIE_IF(gab_wfa_run_device(h, pk.d_text, pk.text_bytes, pk.d_pat_off, pk.d_pat_len, pk.d_text, pk.text_bytes, pk.d_txt_off,
+                                          pk.d_txt_len, pk.n, d_ops, pk.d_cap_off, d_len, d_score, NULL), "gab_wfa_run_device");
+            GAB_DIE_IF(gab_device_copy_to_host(0, ops, d_ops, (size_t)pk.cap_bytes), "gab_device_copy_to_host");
+            GAB_DIE_IF(gab_device_copy_to_host(0, ooff, pk.d_cap_off, 8 * (size_t)pk.n), "gab_device_copy_to_host");
+            GAB_DIE_IF(gab_device_copy_to_host(0, olen, d_len, 4 * (size_t)pk.n), "gab_device_copy_to_host");
+            gab_roi_end();
+            const double t1g = tv_now();
+            if (out) {
+                for (int64_t i = 0; i < pk.n; i++) {
+                    fprintf(out, "id=%ld ", (long)i);
+                    const char *o = ops + ooff[i];
+                    const int n = olen[i];
+                    for (int k = 0; k < n;) { int r = k; while (r < n && o[r] == o[k]) r++; fprintf(out, "%d%c", r - k, o[k]); k = r; }
+                    fprintf(out, "\n");
+                }
+                fclose(out);
+            }
+            printf("Total.reads: %ld\n", (long)pk.n);
+            printf("Time.Benchmark: %f s\n", tv_now() - bench0);
+            printf("Time.Alignment: %f s (input indexed on the GPU)\n", t1g - t0g);
+            gab_device_free(0, d_ops); gab_device_free(0, d_len); gab_device_free(0, d_score);
+            gab_wfa_destroy(h); gab_parser_destroy(ps); free(ops); free(ooff); free(olen);
+            return 0;
+        }
+        fprintf(stderr, "GPU parser declined the file (%s); using the getline parser\n", gab_last_error());
+        if (ps) gab_parser_destroy(ps);
+        free(whole);
+        fseek(in, 0L, SEEK_SET);
+    }
     gab_pairs p;
     gab_pairs_read(in, &p);
     fclose(in);

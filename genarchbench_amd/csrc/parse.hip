@@ -215,7 +215,8 @@ __global__ __launch_bounds__(256) void bsw_codes(const char *__restrict__ text, 
 
 // ---- bpm / wfa -----------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void pairs_meta(const char *__restrict__ text, const int64_t *__restrict__ ls, int64_t npairs, int swap,
-                                                  int64_t *pat_off, int32_t *pat_len, int64_t *txt_off, int32_t *txt_len, ParseFlags *fl) {
+                                                  int64_t *pat_off, int32_t *pat_len, int64_t *txt_off, int32_t *txt_len, int32_t *sum_len,
+                                                  ParseFlags *fl) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= npairs) return;
     const int64_t s0 = ls[2 * i], s1 = ls[2 * i + 1], s2 = ls[2 * i + 2];
@@ -231,6 +232,7 @@ __global__ __launch_bounds__(256) void pairs_meta(const char *__restrict__ text,
         const int64_t to = ao, tl = al; ao = bo; al = bl; bo = to; bl = tl;
     }
     pat_off[i] = ao; pat_len[i] = (int32_t)al; txt_off[i] = bo; txt_len[i] = (int32_t)bl;
+    sum_len[i] = (int32_t)(al + bl);             // capacity of a per-pair output of pattern_length + text_length bytes (wfa CIGAR)
 }
 
 // ---- chain / fast-chain ------------------------------------------------------------------------------------------------
@@ -511,18 +513,21 @@ extern "C" int gab_pairs_parse_device(gab_parser *p, const char *d_text, int64_t
     out->d_text = d_text; out->text_bytes = nbytes;
     if (n == 0) { GAB_HIP(hipEventRecord(p->ev[1], s)); return GAB_OK; }
     GAB_CHECK(n < (1ll << 31), "gab_pairs_parse_device: too many pairs");
-    const size_t o8 = (8 * (size_t)n + 63) & ~(size_t)63, o4 = (4 * (size_t)n + 63) & ~(size_t)63;
-    rc = p->meta.reserve(2 * o8 + 2 * o4 + 64);
+    const size_t o8 = (8 * (size_t)(n + 1) + 63) & ~(size_t)63, o4 = (4 * (size_t)n + 63) & ~(size_t)63;
+    rc = p->meta.reserve(3 * o8 + 3 * o4 + 64);
     if (rc) return rc;
     char *mb = p->meta.as<char>();
-    int64_t *d_po = (int64_t *)mb, *d_to = (int64_t *)(mb + o8);
-    int32_t *d_pl = (int32_t *)(mb + 2 * o8), *d_tl = (int32_t *)(mb + 2 * o8 + o4);
+    int64_t *d_po = (int64_t *)mb, *d_to = (int64_t *)(mb + o8), *d_co = (int64_t *)(mb + 2 * o8);
+    int32_t *d_pl = (int32_t *)(mb + 3 * o8), *d_tl = (int32_t *)(mb + 3 * o8 + o4), *d_sl = (int32_t *)(mb + 3 * o8 + 2 * o4);
     ParseFlags *d_fl = (ParseFlags *)p->ws.as<char>();
     ParseFlags hf = {0, 0x7fffffff};
     GAB_HIP(hipMemcpyAsync(d_fl, &hf, sizeof hf, hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(pairs_meta, dim3((unsigned)gab_ceil_div(n, 256)), dim3(256), 0, s, d_text, d_ls, n, swap_longer_first, d_po, d_pl,
-                       d_to, d_tl, d_fl);
+                       d_to, d_tl, d_sl, d_fl);
     GAB_HIP(hipGetLastError());
+    int64_t cap_total = 0;
+    rc = scan_lengths(p, d_sl, n, d_co, &cap_total, s);      // (each slot rounded up to a multiple of 4 bytes)
+    if (rc) return rc;
     GAB_HIP(hipEventRecord(p->ev[1], s));
     GAB_HIP(hipMemcpyAsync(&hf, d_fl, sizeof hf, hipMemcpyDeviceToHost, s));
     GAB_HIP(hipStreamSynchronize(s));
@@ -532,7 +537,10 @@ extern "C" int gab_pairs_parse_device(gab_parser *p, const char *d_text, int64_t
     }
     GAB_HIP(hipEventElapsedTime(&p->kernel_ms, p->ev[0], p->ev[1]));
     p->have_stats = true;
+    GAB_HIP(hipMemcpyAsync(d_co + n, &cap_total, 8, hipMemcpyHostToDevice, s));
+    GAB_HIP(hipStreamSynchronize(s));
     out->n = n; out->d_pat_off = d_po; out->d_txt_off = d_to; out->d_pat_len = d_pl; out->d_txt_len = d_tl;
+    out->d_cap_off = d_co; out->cap_bytes = cap_total;
     return GAB_OK;
 }
 

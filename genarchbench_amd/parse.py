@@ -15,7 +15,7 @@ class BswPacked(C.Structure):
 
 class PairsPacked(C.Structure):
     _fields_ = [("n", C.c_int64), ("d_text", C.c_void_p), ("text_bytes", C.c_int64), ("d_pat_off", C.c_void_p), ("d_txt_off", C.c_void_p),
-                ("d_pat_len", C.c_void_p), ("d_txt_len", C.c_void_p)]
+                ("d_pat_len", C.c_void_p), ("d_txt_len", C.c_void_p), ("d_cap_off", C.c_void_p), ("cap_bytes", C.c_int64)]
 
 
 class ChainHdr(C.Structure):
@@ -102,4 +102,5 @@ class InputParser:
     def pairs_to_host(pk):
         n = pk.n
         return {"pat_off": _d2h(pk.d_pat_off, 8 * n, np.int64), "txt_off": _d2h(pk.d_txt_off, 8 * n, np.int64),
-                "pat_len": _d2h(pk.d_pat_len, 4 * n, np.int32), "txt_len": _d2h(pk.d_txt_len, 4 * n, np.int32)}
+                "pat_len": _d2h(pk.d_pat_len, 4 * n, np.int32), "txt_len": _d2h(pk.d_txt_len, 4 * n, np.int32),
+                "cap_off": _d2h(pk.d_cap_off, 8 * (n + 1), np.int64)}

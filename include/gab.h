@@ -271,6 +271,8 @@ typedef struct {
     int64_t text_bytes;                          /* readable bytes of d_text (>= nbytes; the staged copy has 64 bytes of slack) */
     const int64_t *d_pat_off, *d_txt_off;        /* first base of each sequence (the '>' / '<' prefix is skipped) */
     const int32_t *d_pat_len, *d_txt_len;
+    const int64_t *d_cap_off;                    /* n + 1 offsets of per-pair output slots of pattern_length + text_length bytes */
+    int64_t cap_bytes;                           /* (rounded up to 4): the ops_off / buffer size gab_wfa_run_device needs */
 } gab_pairs_packed;
 int gab_parser_create(int device, gab_parser **out);
 void gab_parser_destroy(gab_parser *p);

@@ -91,3 +91,18 @@ def test_bpm_driver_gpu_parse_mode(inputs, tmp_path):
     assert ra.returncode == 0 and rb.returncode == 0, rb.stderr[-500:]
     assert "indexed on the GPU" in rb.stderr
     assert open(a).read() == open(b).read() and len(open(a).read()) > 0
+
+
+def test_wfa_driver_gpu_parse_mode(inputs, tmp_path):
+    """GAB_GPU_PARSE=1 in the wfa driver: same CIGAR file as the getline path"""
+    exe = os.path.join(ROOT, "benchmarks", "wfa", "bin", "align_benchmark")
+    inp = f"{inputs}/wfa/small/WFA_SRR7733443_100k_input.txt"
+    if not os.path.exists(inp):
+        inp = [os.path.join(f"{inputs}/wfa/small", f) for f in os.listdir(f"{inputs}/wfa/small") if "input" in f][0]
+    a, b = str(tmp_path / "a.txt"), str(tmp_path / "b.txt")
+    ra = subprocess.run([exe, "-i", inp, "-o", a, "-t", "1"], capture_output=True, text=True, timeout=300)
+    rb = subprocess.run([exe, "-i", inp, "-o", b, "-t", "1"], capture_output=True, text=True, timeout=300,
+                        env=dict(os.environ, GAB_GPU_PARSE="1", GAB_GPUS="1"))
+    assert ra.returncode == 0 and rb.returncode == 0, rb.stderr[-500:]
+    assert "indexed on the GPU" in rb.stdout
+    assert open(a).read() == open(b).read() and len(open(a).read()) > 0
