@@ -192,22 +192,27 @@ __global__ __launch_bounds__(256) void bsw_codes(const char *__restrict__ text, 
         const int m_l1 = have ? len1[mine] : 0, m_l2 = have ? len2[mine] : 0;
         const int cnt = (int)(npairs - b0 < 64 ? npairs - b0 : 64);
         for (int j0 = 0; j0 < cnt; j0 += 4) {
-            uint32_t rv[4], qv[4];
-            int64_t s1[4], ro[4], qo[4]; int l1[4], l2[4];
+            // the dwords of a pair are numbered ref first, then query: lane v < nR copies reference dword v, the other
+            // lanes query dword v - nR, so a typical 160 + 80 byte pair is ONE load and ONE store instruction
+            uint32_t wv[4];
+            int64_t s1[4], s2[4], ro[4], qo[4]; int nR[4], nT[4];
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 const int j = j0 + u < cnt ? j0 + u : cnt - 1;          // (a duplicate of the last pair rewrites the same bytes)
-                s1[u] = __shfl(m_s1, j); const int64_t s2 = __shfl(m_s2, j); ro[u] = __shfl(m_ro, j); qo[u] = __shfl(m_qo, j);
-                l1[u] = __shfl(m_l1, j); l2[u] = __shfl(m_l2, j);
-                rv[u] = 4 * lane < l1[u] ? text_ld4(text, s1[u] + 4 * lane, nbytes) : 0u;
-                qv[u] = 4 * lane < l2[u] ? text_ld4(text, s2 + 4 * lane, nbytes) : 0u;
+                s1[u] = __shfl(m_s1, j); s2[u] = __shfl(m_s2, j); ro[u] = __shfl(m_ro, j); qo[u] = __shfl(m_qo, j);
+                nR[u] = (__shfl(m_l1, j) + 3) >> 2; nT[u] = nR[u] + ((__shfl(m_l2, j) + 3) >> 2);
+                const bool isq = lane >= nR[u];
+                wv[u] = lane < nT[u] ? text_ld4(text, (isq ? s2[u] - 4 * (int64_t)nR[u] : s1[u]) + 4 * lane, nbytes) : 0u;
             }
 #pragma unroll
             for (int u = 0; u < 4; u++) {
-                if (4 * lane < l1[u]) *reinterpret_cast<uint32_t *>(ref + ro[u] + 4 * lane) = sub48x4(rv[u]);
-                if (4 * lane < l2[u]) *reinterpret_cast<uint32_t *>(qry + qo[u] + 4 * lane) = sub48x4(qv[u]);
-                for (int k = 256 + 4 * lane; k < l1[u]; k += 256)       // reference lines longer than 256 characters
-                    *reinterpret_cast<uint32_t *>(ref + ro[u] + k) = sub48x4(text_ld4(text, s1[u] + k, nbytes));
+                const bool isq = lane >= nR[u];
+                if (lane < nT[u]) *reinterpret_cast<uint32_t *>(isq ? qry + qo[u] + 4 * (lane - nR[u]) : ref + ro[u] + 4 * lane) = sub48x4(wv[u]);
+                for (int v = 64 + lane; v < nT[u]; v += 64) {           // pairs longer than 256 characters
+                    const bool q2 = v >= nR[u];
+                    const uint32_t w = text_ld4(text, (q2 ? s2[u] - 4 * (int64_t)nR[u] : s1[u]) + 4 * (int64_t)v, nbytes);
+                    *reinterpret_cast<uint32_t *>(q2 ? qry + qo[u] + 4 * (v - nR[u]) : ref + ro[u] + 4 * v) = sub48x4(w);
+                }
             }
         }
     }
