@@ -16,7 +16,9 @@
 
 namespace {
 
-constexpr int kBlockBytes = 16384;            // text bytes per workgroup in the newline passes (256 threads x 64 B)
+constexpr int kSubBytes = 16384;              // one sweep of a workgroup: 256 threads x 64 B
+constexpr int kSubs = 8;                      // sweeps per workgroup (fewer, larger blocks keep the single-workgroup scan short)
+constexpr int kBlockBytes = kSubBytes * kSubs; // text bytes per workgroup in the newline passes
 
 struct ParseFlags { int32_t bad; int32_t first_bad; };
 
@@ -29,19 +31,21 @@ __device__ __forceinline__ uint32_t nl_flags(uint32_t w) {
 }
 __global__ __launch_bounds__(256) void nl_count(const char *__restrict__ text, int64_t n, int64_t *block_cnt) {
     __shared__ int sh[4];
-    const int64_t base = (int64_t)blockIdx.x * kBlockBytes + (int64_t)threadIdx.x * 64;
     int c = 0;
-    if (base + 64 <= n) {
-        const uint4 *p = reinterpret_cast<const uint4 *>(text + base);
+    for (int sub = 0; sub < kSubs; sub++) {
+        const int64_t base = (int64_t)blockIdx.x * kBlockBytes + (int64_t)sub * kSubBytes + (int64_t)threadIdx.x * 64;
+        if (base + 64 <= n) {
+            const uint4 *p = reinterpret_cast<const uint4 *>(text + base);
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const uint4 v = p[k];
-            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+            for (int k = 0; k < 4; k++) {
+                const uint4 v = p[k];
+                const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-            for (int j = 0; j < 4; j++) c += __popc(nl_flags(w[j]));
+                for (int j = 0; j < 4; j++) c += __popc(nl_flags(w[j]));
+            }
+        } else {
+            for (int k = 0; k < 64; k++) if (base + k < n && text[base + k] == '\n') c++;
         }
-    } else {
-        for (int k = 0; k < 64; k++) if (base + k < n && text[base + k] == '\n') c++;
     }
     for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = c;
@@ -75,38 +79,43 @@ __global__ __launch_bounds__(1024) void scan_i64(const int64_t *in, int64_t n, i
 __global__ __launch_bounds__(256) void nl_fill(const char *__restrict__ text, int64_t n, const int64_t *block_off, int64_t *line_start) {
     __shared__ int wsum[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t base = (int64_t)blockIdx.x * kBlockBytes + (int64_t)threadIdx.x * 64;
-    // 64 bytes per thread as a bit mask of newlines
-    unsigned long long m = 0;
-    if (base + 64 <= n) {
-        const uint4 *p = reinterpret_cast<const uint4 *>(text + base);
+    int64_t carry = block_off[blockIdx.x];                    // newlines before this sweep
+    for (int sub = 0; sub < kSubs; sub++) {
+        const int64_t base = (int64_t)blockIdx.x * kBlockBytes + (int64_t)sub * kSubBytes + (int64_t)threadIdx.x * 64;
+        // 64 bytes per thread as a bit mask of newlines
+        unsigned long long m = 0;
+        if (base + 64 <= n) {
+            const uint4 *p = reinterpret_cast<const uint4 *>(text + base);
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const uint4 v = p[k];
-            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+            for (int k = 0; k < 4; k++) {
+                const uint4 v = p[k];
+                const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const uint32_t t = nl_flags(w[j]);
-                const uint32_t bits = ((t >> 7) & 1u) | ((t >> 14) & 2u) | ((t >> 21) & 4u) | ((t >> 28) & 8u);
-                m |= (unsigned long long)bits << (16 * k + 4 * j);
+                for (int j = 0; j < 4; j++) {
+                    const uint32_t t = nl_flags(w[j]);
+                    const uint32_t bits = ((t >> 7) & 1u) | ((t >> 14) & 2u) | ((t >> 21) & 4u) | ((t >> 28) & 8u);
+                    m |= (unsigned long long)bits << (16 * k + 4 * j);
+                }
             }
+        } else {
+            for (int k = 0; k < 64; k++) if (base + k < n && text[base + k] == '\n') m |= 1ull << k;
         }
-    } else {
-        for (int k = 0; k < 64; k++) if (base + k < n && text[base + k] == '\n') m |= 1ull << k;
-    }
-    const int c = __popcll(m);
-    // exclusive prefix of c over the workgroup
-    int incl = c;
-    for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o); if (lane >= o) incl += v; }
-    if (lane == 63) wsum[wave] = incl;
-    __syncthreads();
-    int before = 0;
-    for (int w = 0; w < wave; w++) before += wsum[w];
-    int64_t idx = block_off[blockIdx.x] + before + incl - c;
-    while (m) {
-        const int b = __builtin_ctzll(m);
-        m &= m - 1;
-        line_start[++idx] = base + b + 1;
+        const int c = __popcll(m);
+        // exclusive prefix of c over the workgroup
+        int incl = c;
+        for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o); if (lane >= o) incl += v; }
+        __syncthreads();                                      // (wsum of the previous sweep has been read by everyone)
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        int before = 0;
+        for (int w = 0; w < wave; w++) before += wsum[w];
+        int64_t idx = carry + before + incl - c;
+        while (m) {
+            const int b = __builtin_ctzll(m);
+            m &= m - 1;
+            line_start[++idx] = base + b + 1;
+        }
+        carry += wsum[0] + wsum[1] + wsum[2] + wsum[3];
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) line_start[0] = 0;
 }
@@ -166,6 +175,12 @@ __global__ __launch_bounds__(256) void len_offsets(const int32_t *len, int64_t n
 // (coalesced), then each pair is copied with FOUR bytes per lane (one unaligned dword load from the text, one aligned
 // dword store into the slab: sequences start dword-aligned there) -- byte-wide accesses run at a quarter of the
 // address-unit rate.  The up-to-3 bytes past a sequence's end are padding nobody reads.
+// broadcast of a lane's value when the lane index is wave-uniform: v_readlane instead of an LDS permute
+__device__ __forceinline__ int bcast32(int v, int lane_uniform) { return __builtin_amdgcn_readlane(v, lane_uniform); }
+__device__ __forceinline__ int64_t bcast64(int64_t v, int lane_uniform) {
+    return (int64_t)((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)v >> 32), lane_uniform) << 32 |
+                     (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, lane_uniform));
+}
 __device__ __forceinline__ uint32_t text_ld4(const char *text, int64_t pos, int64_t nbytes) {
     uint32_t w = 0;
     if (pos + 4 <= nbytes) __builtin_memcpy(&w, text + pos, 4);
@@ -183,14 +198,14 @@ __global__ __launch_bounds__(256) void bsw_codes(const char *__restrict__ text, 
                                                  const int64_t *__restrict__ qry_off, const int32_t *__restrict__ len1,
                                                  const int32_t *__restrict__ len2, uint8_t *ref, uint8_t *qry) {
     const int lane = threadIdx.x & 63;
-    const int64_t wave = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6, nwaves = ((int64_t)gridDim.x * 256) >> 6;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), nwaves = (int64_t)gridDim.x * 4;
     for (int64_t b0 = wave * 64; b0 < npairs; b0 += nwaves * 64) {
         const int64_t mine = b0 + lane;
         const bool have = mine < npairs;
         const int64_t m_s1 = have ? ls[3 * mine + 1] : 0, m_s2 = have ? ls[3 * mine + 2] : 0;
         const int64_t m_ro = have ? ref_off[mine] : 0, m_qo = have ? qry_off[mine] : 0;
         const int m_l1 = have ? len1[mine] : 0, m_l2 = have ? len2[mine] : 0;
-        const int cnt = (int)(npairs - b0 < 64 ? npairs - b0 : 64);
+        const int cnt = __builtin_amdgcn_readfirstlane((int)(npairs - b0 < 64 ? npairs - b0 : 64));
         for (int j0 = 0; j0 < cnt; j0 += 4) {
             // the dwords of a pair are numbered ref first, then query: lane v < nR copies reference dword v, the other
             // lanes query dword v - nR, so a typical 160 + 80 byte pair is ONE load and ONE store instruction
@@ -199,8 +214,8 @@ __global__ __launch_bounds__(256) void bsw_codes(const char *__restrict__ text, 
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 const int j = j0 + u < cnt ? j0 + u : cnt - 1;          // (a duplicate of the last pair rewrites the same bytes)
-                s1[u] = __shfl(m_s1, j); s2[u] = __shfl(m_s2, j); ro[u] = __shfl(m_ro, j); qo[u] = __shfl(m_qo, j);
-                nR[u] = (__shfl(m_l1, j) + 3) >> 2; nT[u] = nR[u] + ((__shfl(m_l2, j) + 3) >> 2);
+                s1[u] = bcast64(m_s1, j); s2[u] = bcast64(m_s2, j); ro[u] = bcast64(m_ro, j); qo[u] = bcast64(m_qo, j);
+                nR[u] = (bcast32(m_l1, j) + 3) >> 2; nT[u] = nR[u] + ((bcast32(m_l2, j) + 3) >> 2);
                 const bool isq = lane >= nR[u];
                 wv[u] = lane < nT[u] ? text_ld4(text, (isq ? s2[u] - 4 * (int64_t)nR[u] : s1[u]) + 4 * lane, nbytes) : 0u;
             }
