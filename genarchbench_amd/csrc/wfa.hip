@@ -54,17 +54,35 @@ struct WfaCounters {
 // Per-score directory entry.  lo/hi as in affine_wavefront_t; bases index the offset pool.
 struct WfDir { int lo, hi, m, i, d; };
 
+// The LDS kernels (int16 offsets, pools below 64 K entries) keep a directory entry in three dwords -- lo | hi, baseM |
+// baseI, baseD as 16-bit fields, 0xffff = no wavefront -- which is 384 bytes of LDS less per pair than five ints and
+// worth two more waves per CU; the global-memory kernel (int32 offsets, pools of millions) keeps five ints.
 template <typename OffT>
 struct WfStore {
+    static constexpr int kDirInts = sizeof(OffT) == 2 ? 3 : 5;
     OffT *pool;           // offsets
-    int *dir;             // 5 ints per score: lo, hi, baseM, baseI, baseD
+    int *dir;             // kDirInts ints per score
     int pool_cap, dir_cap, used;
     __device__ __forceinline__ WfDir get(int s) const {
         WfDir w;
         if (s < 0) { w.lo = 1; w.hi = -1; w.m = w.i = w.d = kNone; return w; }
-        const int *p = dir + 5 * s;
-        w.lo = p[0]; w.hi = p[1]; w.m = p[2]; w.i = p[3]; w.d = p[4];
+        const int *p = dir + kDirInts * s;
+        if (kDirInts == 3) {
+            const uint32_t w0 = (uint32_t)p[0], w1 = (uint32_t)p[1], w2 = (uint32_t)p[2];
+            w.lo = (int)(int16_t)(w0 & 0xffffu); w.hi = (int)w0 >> 16;
+            const uint32_t m = w1 & 0xffffu, i = w1 >> 16, d = w2 & 0xffffu;
+            w.m = m == 0xffffu ? kNone : (int)m; w.i = i == 0xffffu ? kNone : (int)i; w.d = d == 0xffffu ? kNone : (int)d;
+        } else { w.lo = p[0]; w.hi = p[1]; w.m = p[2]; w.i = p[3]; w.d = p[4]; }
         return w;
+    }
+    // (called by one lane)
+    __device__ __forceinline__ void put(int s, int lo, int hi, int m, int i, int d) {
+        int *p = dir + kDirInts * s;
+        if (kDirInts == 3) {
+            p[0] = (int)(((uint32_t)lo & 0xffffu) | (uint32_t)hi << 16);
+            p[1] = (int)((m == kNone ? 0xffffu : (uint32_t)m) | (i == kNone ? 0xffffu : (uint32_t)i) << 16);
+            p[2] = (int)(d == kNone ? 0xffffu : (uint32_t)d);
+        } else { p[0] = lo; p[1] = hi; p[2] = m; p[3] = i; p[4] = d; }
     }
     __device__ __forceinline__ int at(int base, int lo, int hi, int k) const {
         return (base != kNone && lo <= k && k <= hi) ? (int)pool[base + (k - lo)] : kNull;
@@ -103,7 +121,7 @@ __device__ bool wfa_pair(WfStore<OffT> &st, const WfaPen pen, const uint8_t *P, 
     // score 0: M = {k = 0 -> offset 0}
     st.used = 0;
     if (st.dir_cap < 1 || st.pool_cap < 1) return false;
-    if (lane == 0) { st.dir[0] = 0; st.dir[1] = 0; st.dir[2] = 0; st.dir[3] = kNone; st.dir[4] = kNone; st.pool[0] = (OffT)0; }
+    if (lane == 0) { st.put(0, 0, 0, 0, kNone, kNone); st.pool[0] = (OffT)0; }
     st.used = 1;
     __syncthreads();
     int score = 0;
@@ -155,9 +173,8 @@ __device__ bool wfa_pair(WfStore<OffT> &st, const WfaPen pen, const uint8_t *P, 
         const WfDir ms = st.get(score - x), mg = st.get(score - oe), ie = st.get(score - e);
         const int de_base = ie.d, ie_base = ie.i;              // I and D of score-e share lo/hi
         const bool n_ms = ms.m == kNone, n_mg = mg.m == kNone, n_ie = ie_base == kNone, n_de = de_base == kNone;
-        int *dd = st.dir + 5 * score;
         if (n_ms && n_mg && n_ie && n_de) {
-            if (lane == 0) { dd[0] = 1; dd[1] = -1; dd[2] = kNone; dd[3] = kNone; dd[4] = kNone; }
+            if (lane == 0) st.put(score, 1, -1, kNone, kNone, kNone);
             __syncthreads();
             continue;
         }
@@ -170,7 +187,7 @@ __device__ bool wfa_pair(WfStore<OffT> &st, const WfaPen pen, const uint8_t *P, 
         if (st.used + need > st.pool_cap) return false;
         const int bM = st.used, bI = has_i ? bM + width : kNone, bD = has_d ? bM + width * (has_i ? 2 : 1) : kNone;
         st.used += need;
-        if (lane == 0) { dd[0] = lo; dd[1] = hi; dd[2] = bM; dd[3] = bI; dd[4] = bD; }
+        if (lane == 0) st.put(score, lo, hi, bM, bI, bD);
         for (int k = lo + lane; k <= hi; k += G) {
             int best = (!n_ms && ms.lo <= k && k <= ms.hi) ? (int)st.pool[ms.m + (k - ms.lo)] + 1 : kNull;
             if (has_i) {
@@ -281,7 +298,7 @@ __global__ __launch_bounds__(256) void wfa_classify(WfaIO io, WfaCounters *ct, u
 }
 
 // ---- LDS kernel: one G-lane group per pair, 64 / G pairs per wave (= per workgroup) ----------------
-// dynamic LDS per group: [dir: 5*dir_cap ints][P: seqp bytes][T: seqt bytes][pool: pool_cap int16]; the CIGAR is built over P/T
+// dynamic LDS per group: [dir: 3*dir_cap ints][P: seqp bytes][T: seqt bytes][pool: pool_cap int16]; the CIGAR is built over P/T
 template <int G>
 __global__ __launch_bounds__(64) void wfa_lds(WfaIO io, WfaPen pen, const uint32_t *__restrict__ list, uint32_t count,
                                               int dir_cap, int seqp, int seqt, int pool_cap, uint32_t group_bytes,
@@ -297,7 +314,7 @@ __global__ __launch_bounds__(64) void wfa_lds(WfaIO io, WfaPen pen, const uint32
         id = list[b];
         uint8_t *smem = smem_all + (size_t)grp * group_bytes;
         int *dir = reinterpret_cast<int *>(smem);
-        uint8_t *P = smem + (size_t)dir_cap * 20;
+        uint8_t *P = smem + (size_t)dir_cap * 12;
         uint8_t *T = P + seqp;
         // the backtrace never looks at the strings (affine_wavefronts_backtrace_matches__check only counts), so their
         // LDS region doubles as the CIGAR buffer: plen + tlen <= seqp + seqt bytes
@@ -439,7 +456,7 @@ extern "C" int gab_wfa_run_device(gab_wfa *h, const char *pat, int64_t pat_bytes
     const int groups[3] = {16, 64, 64};
     for (int pass = 0; pass < 3 && cnt; pass++) {
         const int dir_cap = dir_caps[pass], G = groups[pass];
-        const size_t per_group = (((size_t)dir_cap * 20 + (size_t)(seqp + seqt) + pool_bytes[pass]) + 15) & ~(size_t)15;
+        const size_t per_group = (((size_t)dir_cap * 12 + (size_t)(seqp + seqt) + pool_bytes[pass]) + 15) & ~(size_t)15;
         const size_t lds = per_group * (64 / G);
         if (lds > 160 * 1024 - 512) continue;            // sequences too long for this pool: let the next stage take them
         h->h_ct->n_over = 0;
