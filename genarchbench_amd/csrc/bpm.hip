@@ -36,7 +36,7 @@ namespace {
 constexpr int kMaxRegW = 4;                 // W classes kept in registers
 constexpr int kClasses = kMaxRegW + 1;      // class c = W for W <= 4, class 0 = W > 4
 constexpr int kBlock = 256;
-constexpr int kBandRows = 16;               // rows kept per column by the LDS band kernel
+constexpr int kBandRows = 8;                // rows kept per column by the LDS band kernel ({Pv, Mv} bits: one u16 per column)
 
 struct BpmIO {
     const char *pat; const int64_t *pat_off; const int32_t *pat_len;
@@ -49,7 +49,7 @@ struct BpmCounters {        // device-side, zeroed per run
     uint32_t cls_cursor[8];
     uint32_t wl_count[8];   // queued (unclean) pairs per class
     uint32_t wl2_count[8];  // pairs whose backtrace left the 64-row window (re-run with the full history)
-    uint32_t wl1_count[8];  // pairs whose backtrace left the 16-row LDS band (re-run with the 64-row window)
+    uint32_t wl1_count[8];  // pairs whose backtrace left the 8-row LDS band (re-run with the 64-row window)
     int32_t max_tlen[8];    // longest text per class (sizes the LDS band)
     int32_t bad, first_bad;
     unsigned long long steps;   // block steps executed by bpm_score (m * W summed)
@@ -261,12 +261,13 @@ __global__ __launch_bounds__(kBlock) void bpm_score(BpmIO io, const uint32_t *__
     if ((threadIdx.x & 63) == 0 && steps) atomicAdd(&ct->steps, steps);
 }
 
-// ---- LDS band path: 16 rows around the diagonal per column, history never leaves the CU -----------------------
+// ---- LDS band path: 8 rows around the diagonal per column, history never leaves the CU ------------------------
 // First stop of a queued pair.  One pair per lane, one wave per workgroup; the column history is one dword per
-// column ({Pv, Mv} bits of the 16 rows around the diagonal) in LDS as [column][lane], so the ~300 dependent reads of
+// column ({Pv, Mv} bits of the 8 rows around the diagonal: one u16; 16 rows halved the occupancy and were 16 % slower
+// end to end) in LDS as [column][lane], so the ~300 dependent reads of
 // the backtrace cost LDS latency instead of HBM latency (the global-history kernels below spend ~20 ms of pure
-// latency on 1.4 M pairs).  A backtrace that drifts more than 7 rows off the diagonal is queued for bpm_win.
-// dynamic LDS: [ (4W+1) x 64 masks (u64) ][ (cols) x 64 dwords ]
+// latency on 1.4 M pairs).  A backtrace that drifts more than 3 rows off the diagonal is queued for bpm_win.
+// dynamic LDS: [ (4W+1) x 64 masks (u64) ][ (cols) x 64 u16 ]
 template <int W>
 __global__ __launch_bounds__(64) void bpm_band(BpmIO io, const uint32_t *__restrict__ list, uint32_t nslots, int cols,
                                                int32_t *__restrict__ score_out, uint32_t *__restrict__ miss_list,
@@ -281,7 +282,7 @@ __global__ __launch_bounds__(64) void bpm_band(BpmIO io, const uint32_t *__restr
         const int n = io.pat_len[id], m = io.txt_len[id];
         const char *p = io.pat + io.pat_off[id], *t = io.txt + io.txt_off[id];
         uint64_t *peq = band_smem + lane;
-        uint32_t *B = reinterpret_cast<uint32_t *>(band_smem + (4 * W + 1) * 64) + lane;      // column c at B[c * 64]
+        uint16_t *B = reinterpret_cast<uint16_t *>(band_smem + (4 * W + 1) * 64) + lane;      // column c at B[c * 64]
         bpm_build_peq<W, 64>(peq, p, n);
         const int cshift = (n - m) / 2;
         auto start = [&](int col) { int r = col + cshift - kBandRows / 2; r = r < 0 ? 0 : r; return r > 64 * W - kBandRows ? 64 * W - kBandRows : r; };
@@ -289,7 +290,7 @@ __global__ __launch_bounds__(64) void bpm_band(BpmIO io, const uint32_t *__restr
         uint64_t P[W], M[W];
 #pragma unroll
         for (int b = 0; b < W; b++) { P[b] = ~0ull; M[b] = 0; }
-        B[0] = 0x0000ffffu;                                       // column 0: Pv = 1..1, Mv = 0
+        B[0] = (uint16_t)((1u << kBandRows) - 1u);                // column 0: Pv = 1..1, Mv = 0
         bool dummy = true;
         for (int h0 = 0; h0 < m; h0 += 4) {
             uint32_t w4 = ld_u32(t + h0);
@@ -306,9 +307,10 @@ __global__ __launch_bounds__(64) void bpm_band(BpmIO io, const uint32_t *__restr
 #pragma unroll
                 for (int b = 1; b < W; b++)
                     if (b0 == b) { plo = P[b]; mlo = M[b]; phi = b + 1 < W ? P[b + 1 < W ? b + 1 : b] : 0; mhi = b + 1 < W ? M[b + 1 < W ? b + 1 : b] : 0; }
-                const uint32_t pw = (uint32_t)((sh ? (plo >> sh) | (phi << (64 - sh)) : plo) & 0xffffu);
-                const uint32_t mw = (uint32_t)((sh ? (mlo >> sh) | (mhi << (64 - sh)) : mlo) & 0xffffu);
-                B[(h + 1) * 64] = pw | mw << 16;
+                const uint32_t bm = (1u << kBandRows) - 1u;
+                const uint32_t pw = (uint32_t)((sh ? (plo >> sh) | (phi << (64 - sh)) : plo)) & bm;
+                const uint32_t mw = (uint32_t)((sh ? (mlo >> sh) | (mhi << (64 - sh)) : mlo)) & bm;
+                B[(h + 1) * 64] = (uint16_t)(pw | mw << kBandRows);
             }
         }
         steps = (unsigned long long)m * W;
@@ -319,7 +321,7 @@ __global__ __launch_bounds__(64) void bpm_band(BpmIO io, const uint32_t *__restr
             const int r1 = start(h + 1), rh = start(h);
             if (v < r1 || v >= r1 + kBandRows || v < rh || v >= rh + kBandRows) { miss = true; break; }
             if ((B[(h + 1) * 64] >> (v - r1)) & 1) { ops++; v--; }
-            else if ((B[h * 64] >> (16 + v - rh)) & 1) { ops++; h--; }
+            else if ((B[h * 64] >> (kBandRows + v - rh)) & 1) { ops++; h--; }
             else { ops += t[h] != p[v]; h--; v--; }
         }
         if (miss) miss_id = (int64_t)id;
@@ -630,13 +632,13 @@ extern "C" int gab_bpm_run_device(gab_bpm *h, const char *pat, int64_t pat_bytes
     // more and get complete columns
     int64_t nfull = 0;
     {
-        // stage 0: 16-row band in LDS
+        // stage 0: 8-row band in LDS
         for (int W = 1; W <= kMaxRegW; W++) {
             const uint32_t cnt = h->h_ct->wl_count[W];
             if (!cnt) continue;
             nfull += cnt;
             const int cols = h->h_ct->max_tlen[W] + 1;
-            const size_t lds = sizeof(uint64_t) * 64 * (4 * W + 1) + sizeof(uint32_t) * 64 * (size_t)cols;
+            const size_t lds = sizeof(uint64_t) * 64 * (4 * W + 1) + sizeof(uint16_t) * 64 * (size_t)cols;
             const dim3 g((cnt + 63) / 64), blk(64);
             const uint32_t *list = d_wl + cstart[W];
             switch (W) {
