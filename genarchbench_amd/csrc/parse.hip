@@ -193,6 +193,7 @@ __device__ __forceinline__ uint32_t sub48x4(uint32_t x) {
     const uint32_t H = 0x80808080u, y = 0x30303030u;
     return ((x | H) - (y & ~H)) ^ ((x ^ ~y) & H);
 }
+constexpr int kCopyUnroll = 4;                // pairs whose loads are in flight together
 __global__ __launch_bounds__(256) void bsw_codes(const char *__restrict__ text, int64_t nbytes, const int64_t *__restrict__ ls,
                                                  int64_t npairs, const int64_t *__restrict__ ref_off,
                                                  const int64_t *__restrict__ qry_off, const int32_t *__restrict__ len1,
@@ -206,13 +207,13 @@ __global__ __launch_bounds__(256) void bsw_codes(const char *__restrict__ text, 
         const int64_t m_ro = have ? ref_off[mine] : 0, m_qo = have ? qry_off[mine] : 0;
         const int m_l1 = have ? len1[mine] : 0, m_l2 = have ? len2[mine] : 0;
         const int cnt = __builtin_amdgcn_readfirstlane((int)(npairs - b0 < 64 ? npairs - b0 : 64));
-        for (int j0 = 0; j0 < cnt; j0 += 4) {
+        for (int j0 = 0; j0 < cnt; j0 += kCopyUnroll) {
             // the dwords of a pair are numbered ref first, then query: lane v < nR copies reference dword v, the other
             // lanes query dword v - nR, so a typical 160 + 80 byte pair is ONE load and ONE store instruction
-            uint32_t wv[4];
-            int64_t s1[4], s2[4], ro[4], qo[4]; int nR[4], nT[4];
+            uint32_t wv[kCopyUnroll];
+            int64_t s1[kCopyUnroll], s2[kCopyUnroll], ro[kCopyUnroll], qo[kCopyUnroll]; int nR[kCopyUnroll], nT[kCopyUnroll];
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
+            for (int u = 0; u < kCopyUnroll; u++) {
                 const int j = j0 + u < cnt ? j0 + u : cnt - 1;          // (a duplicate of the last pair rewrites the same bytes)
                 s1[u] = bcast64(m_s1, j); s2[u] = bcast64(m_s2, j); ro[u] = bcast64(m_ro, j); qo[u] = bcast64(m_qo, j);
                 nR[u] = (bcast32(m_l1, j) + 3) >> 2; nT[u] = nR[u] + ((bcast32(m_l2, j) + 3) >> 2);
@@ -220,7 +221,7 @@ __global__ __launch_bounds__(256) void bsw_codes(const char *__restrict__ text, 
                 wv[u] = lane < nT[u] ? text_ld4(text, (isq ? s2[u] - 4 * (int64_t)nR[u] : s1[u]) + 4 * lane, nbytes) : 0u;
             }
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
+            for (int u = 0; u < kCopyUnroll; u++) {
                 const bool isq = lane >= nR[u];
                 if (lane < nT[u]) *reinterpret_cast<uint32_t *>(isq ? qry + qo[u] + 4 * (lane - nR[u]) : ref + ro[u] + 4 * lane) = sub48x4(wv[u]);
                 for (int v = 64 + lane; v < nT[u]; v += 64) {           // pairs longer than 256 characters
