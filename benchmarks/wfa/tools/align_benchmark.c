@@ -1,11 +1,12 @@
 /* align_benchmark (wfa) -- drop-in driver of the wfa benchmark on MI355X.
  *
  * Command line, input format and output of /root/reference/benchmarks/wfa/tools/align_benchmark.c:
- *     align_benchmark -i <input> [-o <output>] [-p M,X,O,E] [-t <threads>] [-g <gpus>]
+ *     align_benchmark -i <input> [-o <output>] [-p M,X,O,E] [--minimum-wavefront-length L
+ *                     --maximum-difference-distance D] [-t <threads>] [-g <gpus>]
  * output "id=%d <run-length CIGAR>" per pair (edit_cigar_print, wfa/gap_affine/edit_cigar.c:184-200; the
  * harness sorts by id, wfa/scripts/regression_small.sh:94); stdout "Total.reads:", "Time.Benchmark:",
- * "Time.Alignment:" (align_benchmark.c:529-533).  Complete mode only: --minimum-wavefront-length /
- * --maximum-difference-distance (adaptive reduction) are rejected.
+ * "Time.Alignment:" (align_benchmark.c:529-533).  --minimum-wavefront-length >= 0 selects the adaptive
+ * reduction (align_benchmark.c:359-368), otherwise the complete mode.
  * The per-pair ROI call affine_wavefronts_align (align_benchmark.c:415-437) becomes gab_wfa_run on chunks.
  */
 #include "../../common/gab_pairs.h"
@@ -13,8 +14,12 @@
 #include <sys/time.h>
 
 #define CHUNK_PAIRS (1 << 18)
-typedef struct { const gab_pairs *p; gab_wfa_penalties pen; char *ops; int64_t *ops_off; int32_t *ops_len, *score; } wfa_ctx;
-static void *gpu_init(int gpu, void *c) { gab_wfa *h = NULL; GAB_DIE_IF(gab_wfa_create(&((wfa_ctx *)c)->pen, gpu, &h), "gab_wfa_create"); return h; }
+typedef struct { const gab_pairs *p; gab_wfa_penalties pen; int min_wavefront_length, max_distance_threshold; char *ops; int64_t *ops_off; int32_t *ops_len, *score; } wfa_ctx;
+static void *gpu_init(int gpu, void *vc) {
+    wfa_ctx *c = (wfa_ctx *)vc; gab_wfa *h = NULL;
+    GAB_DIE_IF(gab_wfa_create_reduced(&c->pen, c->min_wavefront_length, c->max_distance_threshold, gpu, &h), "gab_wfa_create_reduced");
+    return h;
+}
 static void gpu_fini(int gpu, void *c, void *st) { (void)gpu; (void)c; gab_wfa_destroy((gab_wfa *)st); }
 static void run_chunk(int gpu, int64_t chunk, void *vctx, void *st) {
     (void)gpu;
@@ -29,6 +34,7 @@ int main(int argc, char **argv) {
     int threads = 1, gpus = 0, c;
     wfa_ctx ctx;
     ctx.pen.mismatch = 4; ctx.pen.gap_opening = 6; ctx.pen.gap_extension = 2;      /* align_benchmark.c:85-90 */
+    ctx.min_wavefront_length = -1; ctx.max_distance_threshold = -1;                /* :91-92: complete mode */
     int match = 0;
     static struct option lo[] = {{"input", required_argument, 0, 'i'}, {"output", required_argument, 0, 'o'},
                                  {"affine-penalties", required_argument, 0, 'p'},
@@ -37,7 +43,7 @@ int main(int argc, char **argv) {
                                  {"nthreads", required_argument, 0, 't'}, {"gpus", required_argument, 0, 'g'},
                                  {"progress", required_argument, 0, 'P'}, {"verbose", no_argument, 0, 'v'},
                                  {"help", no_argument, 0, 'h'}, {0, 0, 0, 0}};
-    if (argc <= 1) { fprintf(stderr, "USE: ./align_benchmark -i <input> [-o <output>] [-p M,X,O,E] [-t <threads>] [-g <gpus>]\n"); exit(0); }
+    if (argc <= 1) { fprintf(stderr, "USE: ./align_benchmark -i <input> [-o <output>] [-p M,X,O,E] [--minimum-wavefront-length <INT> --maximum-difference-distance <INT>] [-t <threads>] [-g <gpus>]\n"); exit(0); }
     while ((c = getopt_long(argc, argv, "i:o:p:t:g:P:vh", lo, NULL)) != -1) {
         switch (c) {
             case 'i': input = optarg; break;
@@ -49,13 +55,12 @@ int main(int argc, char **argv) {
                 s = strtok(NULL, ","); if (s) ctx.pen.gap_extension = atoi(s);
                 break;
             }
-            case 1000: case 1001:
-                if (atoi(optarg) >= 0 || c == 1001) { fprintf(stderr, "Adaptive wavefront reduction is not available in the MI355X driver (complete mode only)\n"); exit(1); }
-                break;
+            case 1000: ctx.min_wavefront_length = atoi(optarg); break;       /* align_benchmark.c:267-272 */
+            case 1001: ctx.max_distance_threshold = atoi(optarg); break;
             case 't': threads = atoi(optarg); break;
             case 'g': gpus = atoi(optarg); break;
             case 'P': case 'v': break;
-            case 'h': fprintf(stderr, "USE: ./align_benchmark -i <input> [-o <output>] [-p M,X,O,E] [-t <threads>] [-g <gpus>]\n"); exit(1);
+            case 'h': fprintf(stderr, "USE: ./align_benchmark -i <input> [-o <output>] [-p M,X,O,E] [--minimum-wavefront-length <INT> --maximum-difference-distance <INT>] [-t <threads>] [-g <gpus>]\n"); exit(1);
             default: fprintf(stderr, "Option not recognized\n"); exit(1);
         }
     }
@@ -79,7 +84,7 @@ int main(int argc, char **argv) {
             free(whole); fclose(in);
             gab_wfa_penalties pen; pen.mismatch = ctx.pen.mismatch; pen.gap_opening = ctx.pen.gap_opening; pen.gap_extension = ctx.pen.gap_extension;
             gab_wfa *h = NULL;
-            GAB_DIE_IF(gab_wfa_create(&pen, 0, &h), "gab_wfa_create");
+            GAB_DIE_IF(gab_wfa_create_reduced(&pen, ctx.min_wavefront_length, ctx.max_distance_threshold, 0, &h), "gab_wfa_create_reduced");
             char *d_ops = NULL; int32_t *d_len = NULL, *d_score = NULL;
             GAB_DIE_IF(gab_device_alloc(0, (size_t)pk.cap_bytes + 16, (void **)&d_ops), "gab_device_alloc");
             GAB_DIE_IF(gab_device_alloc(0, 4 * (size_t)pk.n + 4, (void **)&d_len), "gab_device_alloc");

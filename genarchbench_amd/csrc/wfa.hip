@@ -1,4 +1,4 @@
-// wfa -- gap-affine wavefront alignment (WFA v1, complete mode) with CIGAR backtrace, on gfx950.
+// wfa -- gap-affine wavefront alignment (WFA v1, complete mode and adaptive reduction) with CIGAR backtrace, on gfx950.
 //
 // Semantics: affine_wavefronts_align,
 //   /root/reference/benchmarks/wfa/gap_affine/affine_wavefront_align.c:325-361 = loop over scores of
@@ -8,6 +8,12 @@
 //   (affine_wavefront.h:48); the strings behave as if padded with 'X' / 'Y'
 //   (wfa/utils/string_padded.c:88-117).  Output = the un-run-length-encoded CIGAR operations the
 //   driver prints (wfa/tools/align_benchmark.c:417-437, 499-504).
+//   Adaptive mode (affine_wavefronts_new_reduced, affine_wavefront.c:162-181; --minimum-wavefront-length /
+//   --maximum-difference-distance): after each extension the M wavefront drops the outer diagonals that lag more than
+//   the threshold behind the best one (affine_wavefronts_reduce_wavefronts, affine_wavefront_extend.c:85-154); later
+//   wavefronts are computed from the reduced [lo, hi], the backtrace still reads the allocated [lo_base, hi_base]
+//   (affine_wavefront_backtrace.c:75-226).  It is a template variant (ADAPT) of the same code: the complete-mode
+//   kernels carry none of it.
 //
 // Mapping: one wavefront (64 lanes) per pair, lanes = diagonals k.  The whole O(s^2) wavefront
 // history of the pair -- needed by the backtrace -- lives in LDS as int16 offsets behind a small
@@ -33,7 +39,7 @@ constexpr int kNone = 0x7fffffff;          // "no wavefront" marker in the direc
 constexpr int kSeqPad = 32;                // physical 'X'/'Y' padding behind each LDS sequence (>= 16 + 3 for the 16-byte extension reads)
 constexpr int kLdsMaxLen = 2040;           // longest sequence the LDS kernels accept
 
-struct WfaPen { int32_t x, o, e; };
+struct WfaPen { int32_t x, o, e, min_len, max_dist; };   // the last two: adaptive reduction parameters
 
 struct WfaIO {
     const char *pat; const int64_t *pat_off; const int32_t *pat_len;
@@ -51,41 +57,61 @@ struct WfaCounters {
     unsigned long long work;          // wavefront cells computed + bases extended
 };
 
-// Per-score directory entry.  lo/hi as in affine_wavefront_t; bases index the offset pool.
-struct WfDir { int lo, hi, m, i, d; };
+// Per-score directory entry.  lo/hi (after reduction) and lob/hib (= lo_base/hi_base, as allocated) as in
+// affine_wavefront_t; the bases index the offset pool such that diagonal k lives at base + (k - lo) -- a reduction that
+// raises lo moves the bases along, so the computation never needs lob.
+struct WfDir { int lo, hi, m, i, d, lob, hib; };
 
 // The LDS kernels (int16 offsets, pools below 64 K entries) keep a directory entry in three dwords -- lo | hi, baseM |
 // baseI, baseD as 16-bit fields, 0xffff = no wavefront -- which is 384 bytes of LDS less per pair than five ints and
 // worth two more waves per CU; the global-memory kernel (int32 offsets, pools of millions) keeps five ints.
-template <typename OffT>
+// ADAPT adds one dword (lob | hib) resp. two ints.
+template <typename OffT, bool ADAPT>
 struct WfStore {
-    static constexpr int kDirInts = sizeof(OffT) == 2 ? 3 : 5;
+    static constexpr int kDirInts = (sizeof(OffT) == 2 ? 3 : 5) + (ADAPT ? (sizeof(OffT) == 2 ? 1 : 2) : 0);
+    static constexpr bool kPacked = sizeof(OffT) == 2;
     OffT *pool;           // offsets
     int *dir;             // kDirInts ints per score
     int pool_cap, dir_cap, used;
     __device__ __forceinline__ WfDir get(int s) const {
         WfDir w;
-        if (s < 0) { w.lo = 1; w.hi = -1; w.m = w.i = w.d = kNone; return w; }
+        if (s < 0) { w.lo = w.lob = 1; w.hi = w.hib = -1; w.m = w.i = w.d = kNone; return w; }
         const int *p = dir + kDirInts * s;
-        if (kDirInts == 3) {
+        if (kPacked) {
             const uint32_t w0 = (uint32_t)p[0], w1 = (uint32_t)p[1], w2 = (uint32_t)p[2];
             w.lo = (int)(int16_t)(w0 & 0xffffu); w.hi = (int)w0 >> 16;
             const uint32_t m = w1 & 0xffffu, i = w1 >> 16, d = w2 & 0xffffu;
             w.m = m == 0xffffu ? kNone : (int)m; w.i = i == 0xffffu ? kNone : (int)i; w.d = d == 0xffffu ? kNone : (int)d;
-        } else { w.lo = p[0]; w.hi = p[1]; w.m = p[2]; w.i = p[3]; w.d = p[4]; }
+            if (ADAPT) { w.lob = (int)(int16_t)((uint32_t)p[3] & 0xffffu); w.hib = p[3] >> 16; }
+        } else {
+            w.lo = p[0]; w.hi = p[1]; w.m = p[2]; w.i = p[3]; w.d = p[4];
+            if (ADAPT) { w.lob = p[5]; w.hib = p[6]; }
+        }
+        if (!ADAPT) { w.lob = w.lo; w.hib = w.hi; }
         return w;
     }
     // (called by one lane)
     __device__ __forceinline__ void put(int s, int lo, int hi, int m, int i, int d) {
         int *p = dir + kDirInts * s;
-        if (kDirInts == 3) {
+        if (kPacked) {
             p[0] = (int)(((uint32_t)lo & 0xffffu) | (uint32_t)hi << 16);
             p[1] = (int)((m == kNone ? 0xffffu : (uint32_t)m) | (i == kNone ? 0xffffu : (uint32_t)i) << 16);
             p[2] = (int)(d == kNone ? 0xffffu : (uint32_t)d);
         } else { p[0] = lo; p[1] = hi; p[2] = m; p[3] = i; p[4] = d; }
     }
+    // the allocated range of a new wavefront (called by one lane, ADAPT only)
+    __device__ __forceinline__ void put_base(int s, int lob, int hib) {
+        int *p = dir + kDirInts * s;
+        if (kPacked) p[3] = (int)(((uint32_t)lob & 0xffffu) | (uint32_t)hib << 16);
+        else { p[5] = lob; p[6] = hib; }
+    }
     __device__ __forceinline__ int at(int base, int lo, int hi, int k) const {
         return (base != kNone && lo <= k && k <= hi) ? (int)pool[base + (k - lo)] : kNull;
+    }
+    // the backtrace's view: the allocated range
+    __device__ __forceinline__ bool has_base(int base, const WfDir &w, int k) const { return base != kNone && w.lob <= k && k <= w.hib; }
+    __device__ __forceinline__ int at_base(int base, const WfDir &w, int k) const {
+        return has_base(base, w, k) ? (int)pool[base + (k - w.lo)] : kNull;
     }
 };
 
@@ -106,8 +132,8 @@ __device__ __forceinline__ uint32_t glb_ld4(const char *p) { uint32_t w; __built
 // Returns false if the history did not fit (nothing has been written to the outputs then).
 // G = lanes cooperating on the pair (64 = a whole wave, 16 = four pairs per wave); all G lanes run this function
 // with identical control flow, other groups of the same wave may take different branches (SIMT divergence).
-template <typename OffT, bool LDSSEQ, int G>
-__device__ bool wfa_pair(WfStore<OffT> &st, const WfaPen pen, const uint8_t *P, int plen, const uint8_t *T, int tlen,
+template <typename OffT, bool LDSSEQ, int G, bool ADAPT>
+__device__ bool wfa_pair(WfStore<OffT, ADAPT> &st, const WfaPen pen, const uint8_t *P, int plen, const uint8_t *T, int tlen,
                          char *ops_global, char *ops_lds, int32_t *ops_len_out, int32_t *score_out, unsigned long long &work) {
     // the backtrace writes right-aligned into `ops`: an LDS buffer when the caller has one (then the CIGAR leaves the CU
     // once, left-aligned and coalesced), else the pair's own output region (shifted in place afterwards)
@@ -121,7 +147,10 @@ __device__ bool wfa_pair(WfStore<OffT> &st, const WfaPen pen, const uint8_t *P, 
     // score 0: M = {k = 0 -> offset 0}
     st.used = 0;
     if (st.dir_cap < 1 || st.pool_cap < 1) return false;
-    if (lane == 0) { st.put(0, 0, 0, 0, kNone, kNone); st.pool[0] = (OffT)0; }
+    if (lane == 0) {
+        st.put(0, 0, 0, 0, kNone, kNone); st.pool[0] = (OffT)0;
+        if (ADAPT) st.put_base(0, 0, 0);
+    }
     st.used = 1;
     __syncthreads();
     int score = 0;
@@ -166,6 +195,33 @@ __device__ bool wfa_pair(WfStore<OffT> &st, const WfaPen pen, const uint8_t *P, 
             __syncthreads();
             // ---- end reached?
             if (cur.lo <= ak && ak <= cur.hi && (int)st.pool[cur.m + (ak - cur.lo)] >= tlen) break;
+            // ---- adaptive reduction (the reference reduces before the end test; the reduction never drops diagonal ak
+            // and the backtrace reads the allocated range, so the order does not matter)
+            if (ADAPT && cur.hi - cur.lo + 1 >= pen.min_len) {
+                auto dist = [&](int k) {                    // affine_wavefronts_compute_distance, affine_wavefront_utils.c:64-74
+                    const int o = (int)st.pool[cur.m + (k - cur.lo)];
+                    return max(plen - (o - k), tlen - o);
+                };
+                int min_d = max(plen, tlen);
+                for (int k = cur.lo + lane; k <= cur.hi; k += G) min_d = min(min_d, dist(k));
+                for (int o = G / 2; o > 0; o >>= 1) min_d = min(min_d, __shfl_xor(min_d, o));
+                // from the bottom: lo stops at the first diagonal within the threshold, at the latest at min(ak - 1, hi)
+                const int top = min(ak - 1, cur.hi);
+                int nlo = max(top, cur.lo);
+                for (int k = cur.lo + lane; k < top; k += G)
+                    if (dist(k) - min_d <= pen.max_dist) { nlo = min(nlo, k); break; }
+                for (int o = G / 2; o > 0; o >>= 1) nlo = min(nlo, __shfl_xor(nlo, o));
+                // from the top: hi stops at the first diagonal within the threshold, at the latest at max(ak + 1, lo)
+                const int bottom = max(ak + 1, nlo);
+                int nhi = min(bottom, cur.hi);
+                for (int k = cur.hi - lane; k > bottom; k -= G)
+                    if (dist(k) - min_d <= pen.max_dist) { nhi = max(nhi, k); break; }
+                for (int o = G / 2; o > 0; o >>= 1) nhi = max(nhi, __shfl_xor(nhi, o));
+                const int sh = nlo - cur.lo;
+                if (lane == 0 && (sh | (cur.hi - nhi)))
+                    st.put(score, nlo, nhi, cur.m + sh, cur.i == kNone ? kNone : cur.i + sh, cur.d == kNone ? kNone : cur.d + sh);
+                __syncthreads();
+            }
         }
         // ---- next wavefront
         score++;
@@ -174,7 +230,10 @@ __device__ bool wfa_pair(WfStore<OffT> &st, const WfaPen pen, const uint8_t *P, 
         const int de_base = ie.d, ie_base = ie.i;              // I and D of score-e share lo/hi
         const bool n_ms = ms.m == kNone, n_mg = mg.m == kNone, n_ie = ie_base == kNone, n_de = de_base == kNone;
         if (n_ms && n_mg && n_ie && n_de) {
-            if (lane == 0) st.put(score, 1, -1, kNone, kNone, kNone);
+            if (lane == 0) {
+                st.put(score, 1, -1, kNone, kNone, kNone);
+                if (ADAPT) st.put_base(score, 1, -1);
+            }
             __syncthreads();
             continue;
         }
@@ -187,7 +246,10 @@ __device__ bool wfa_pair(WfStore<OffT> &st, const WfaPen pen, const uint8_t *P, 
         if (st.used + need > st.pool_cap) return false;
         const int bM = st.used, bI = has_i ? bM + width : kNone, bD = has_d ? bM + width * (has_i ? 2 : 1) : kNone;
         st.used += need;
-        if (lane == 0) st.put(score, lo, hi, bM, bI, bD);
+        if (lane == 0) {
+            st.put(score, lo, hi, bM, bI, bD);
+            if (ADAPT) st.put_base(score, lo, hi);
+        }
         for (int k = lo + lane; k <= hi; k += G) {
             int best = (!n_ms && ms.lo <= k && k <= ms.hi) ? (int)st.pool[ms.m + (k - ms.lo)] + 1 : kNull;
             if (has_i) {
@@ -232,15 +294,15 @@ __device__ bool wfa_pair(WfStore<OffT> &st, const WfaPen pen, const uint8_t *P, 
             }
             const int s_go = s - oe, s_ge = s - e, s_mm = s - x;
             const WfDir wgo = st.get(s_go), wge = st.get(s_ge), wmm = st.get(s_mm);
-            const int del_ext = type == 1 ? kNull : st.at(wge.d, wge.lo, wge.hi, k + 1);
-            const int del_open = type == 1 ? kNull : st.at(wgo.m, wgo.lo, wgo.hi, k + 1);
-            const int ie_raw = st.at(wge.i, wge.lo, wge.hi, k - 1), io_raw = st.at(wgo.m, wgo.lo, wgo.hi, k - 1);
-            const bool ie_ok = wge.i != kNone && wge.lo <= k - 1 && k - 1 <= wge.hi;
-            const bool io_ok = wgo.m != kNone && wgo.lo <= k - 1 && k - 1 <= wgo.hi;
-            const bool mm_ok = wmm.m != kNone && wmm.lo <= k && k <= wmm.hi;
+            const int del_ext = type == 1 ? kNull : st.at_base(wge.d, wge, k + 1);
+            const int del_open = type == 1 ? kNull : st.at_base(wgo.m, wgo, k + 1);
+            const int ie_raw = st.at_base(wge.i, wge, k - 1), io_raw = st.at_base(wgo.m, wgo, k - 1);
+            const bool ie_ok = st.has_base(wge.i, wge, k - 1);
+            const bool io_ok = st.has_base(wgo.m, wgo, k - 1);
+            const bool mm_ok = st.has_base(wmm.m, wmm, k);
             const int ins_ext = (type == 2 || !ie_ok) ? kNull : ie_raw + 1;
             const int ins_open = (type == 2 || !io_ok) ? kNull : io_raw + 1;
-            const int misms = (type != 0 || !mm_ok) ? kNull : st.at(wmm.m, wmm.lo, wmm.hi, k) + 1;
+            const int misms = (type != 0 || !mm_ok) ? kNull : st.at_base(wmm.m, wmm, k) + 1;
             const int max_all = max(misms, max(max(ins_ext, ins_open), max(del_ext, del_open)));
             if (type == 0) { put_run('M', offset - max_all); offset = max_all; }
             if (max_all == del_ext) { if (valid) put('D'); s = s_ge; k++; type = 2; }
@@ -298,8 +360,8 @@ __global__ __launch_bounds__(256) void wfa_classify(WfaIO io, WfaCounters *ct, u
 }
 
 // ---- LDS kernel: one G-lane group per pair, 64 / G pairs per wave (= per workgroup) ----------------
-// dynamic LDS per group: [dir: 3*dir_cap ints][P: seqp bytes][T: seqt bytes][pool: pool_cap int16]; the CIGAR is built over P/T
-template <int G>
+// dynamic LDS per group: [dir: 3 (4 if ADAPT) * dir_cap ints][P: seqp bytes][T: seqt bytes][pool: pool_cap int16]; the CIGAR is built over P/T
+template <int G, bool ADAPT>
 __global__ __launch_bounds__(64) void wfa_lds(WfaIO io, WfaPen pen, const uint32_t *__restrict__ list, uint32_t count,
                                               int dir_cap, int seqp, int seqt, int pool_cap, uint32_t group_bytes,
                                               uint32_t *over_list, WfaCounters *ct) {
@@ -314,7 +376,7 @@ __global__ __launch_bounds__(64) void wfa_lds(WfaIO io, WfaPen pen, const uint32
         id = list[b];
         uint8_t *smem = smem_all + (size_t)grp * group_bytes;
         int *dir = reinterpret_cast<int *>(smem);
-        uint8_t *P = smem + (size_t)dir_cap * 12;
+        uint8_t *P = smem + (size_t)dir_cap * 4 * WfStore<int16_t, ADAPT>::kDirInts;
         uint8_t *T = P + seqp;
         // the backtrace never looks at the strings (affine_wavefronts_backtrace_matches__check only counts), so their
         // LDS region doubles as the CIGAR buffer: plen + tlen <= seqp + seqt bytes
@@ -325,9 +387,9 @@ __global__ __launch_bounds__(64) void wfa_lds(WfaIO io, WfaPen pen, const uint32
         for (int i = lane; i < plen + kSeqPad; i += G) P[i] = i < plen ? (uint8_t)gp[i] : (uint8_t)'X';
         for (int i = lane; i < tlen + kSeqPad; i += G) T[i] = i < tlen ? (uint8_t)gt[i] : (uint8_t)'Y';
         __syncthreads();
-        WfStore<int16_t> st;
+        WfStore<int16_t, ADAPT> st;
         st.pool = pool; st.dir = dir; st.pool_cap = pool_cap; st.dir_cap = dir_cap; st.used = 0;
-        ok = wfa_pair<int16_t, true, G>(st, pen, P, plen, T, tlen, io.ops + io.ops_off[id], opsbuf, io.ops_len + id, io.score + id, work);
+        ok = wfa_pair<int16_t, true, G, ADAPT>(st, pen, P, plen, T, tlen, io.ops + io.ops_off[id], opsbuf, io.ops_len + id, io.score + id, work);
         if (!ok && lane == 0) over_list[atomicAdd(&ct->n_over, 1u)] = id;
     }
     if (!have || !ok) work = 0;
@@ -336,6 +398,7 @@ __global__ __launch_bounds__(64) void wfa_lds(WfaIO io, WfaPen pen, const uint32
 }
 
 // ---- global kernel: int32 history in a scratch slab, any length ------------------------------
+template <bool ADAPT>
 __global__ __launch_bounds__(64) void wfa_global(WfaIO io, WfaPen pen, const uint32_t *__restrict__ list, uint32_t count,
                                                  int32_t *scratch, int64_t per_block, int dir_cap, int pool_cap,
                                                  uint32_t *over_list, WfaCounters *ct) {
@@ -344,10 +407,10 @@ __global__ __launch_bounds__(64) void wfa_global(WfaIO io, WfaPen pen, const uin
     for (uint32_t b = blockIdx.x; b < count; b += gridDim.x) {
         const uint32_t id = list[b];
         const int plen = io.pat_len[id], tlen = io.txt_len[id];
-        WfStore<int32_t> st;
-        st.dir = mine; st.pool = mine + (int64_t)dir_cap * 5; st.pool_cap = pool_cap; st.dir_cap = dir_cap; st.used = 0;
+        WfStore<int32_t, ADAPT> st;
+        st.dir = mine; st.pool = mine + (int64_t)dir_cap * WfStore<int32_t, ADAPT>::kDirInts; st.pool_cap = pool_cap; st.dir_cap = dir_cap; st.used = 0;
         unsigned long long work = 0;
-        const bool ok = wfa_pair<int32_t, false, 64>(st, pen, (const uint8_t *)(io.pat + io.pat_off[id]), plen,
+        const bool ok = wfa_pair<int32_t, false, 64, ADAPT>(st, pen, (const uint8_t *)(io.pat + io.pat_off[id]), plen,
                                                  (const uint8_t *)(io.txt + io.txt_off[id]), tlen,
                                                  io.ops + io.ops_off[id], nullptr, io.ops_len + id, io.score + id, work);
         if (!ok && lane == 0) over_list[atomicAdd(&ct->n_over, 1u)] = id;
@@ -363,6 +426,7 @@ __global__ __launch_bounds__(64) void wfa_global(WfaIO io, WfaPen pen, const uin
 struct gab_wfa {
     int device = 0;
     WfaPen pen;
+    bool adaptive = false;  // affine_wavefronts_new_reduced instead of _new_complete
     gab_devbuf ws;          // counters | 3 id lists
     gab_devbuf scratch;     // global-kernel history
     gab_devbuf io;          // staging for the host-pointer entry point
@@ -374,6 +438,11 @@ struct gab_wfa {
 };
 
 extern "C" int gab_wfa_create(const gab_wfa_penalties *p, int device, gab_wfa **out) {
+    return gab_wfa_create_reduced(p, -1, -1, device, out);
+}
+
+extern "C" int gab_wfa_create_reduced(const gab_wfa_penalties *p, int min_wavefront_length, int max_distance_threshold,
+                                      int device, gab_wfa **out) {
     if (!p || !out) { gab_set_error("gab_wfa_create: NULL argument"); return GAB_EINVAL; }
     *out = nullptr;
     GAB_CHECK(p->mismatch > 0 && p->gap_opening > 0 && p->gap_extension > 0 && p->mismatch < 4096 &&
@@ -387,11 +456,15 @@ extern "C" int gab_wfa_create(const gab_wfa_penalties *p, int device, gab_wfa **
     if (!h) { gab_set_error("out of host memory"); return GAB_ENOMEM; }
     h->device = device;
     h->pen.x = p->mismatch; h->pen.o = p->gap_opening; h->pen.e = p->gap_extension;
+    h->adaptive = min_wavefront_length >= 0;          // align_benchmark.c:359-368
+    h->pen.min_len = min_wavefront_length; h->pen.max_dist = max_distance_threshold;
     for (int k = 0; k < 4; k++)
         if (hipEventCreate(&h->ev[k]) != hipSuccess) { gab_set_error("hipEventCreate failed"); delete h; return GAB_EDEVICE; }
     if (hipHostMalloc((void **)&h->h_ct, sizeof(WfaCounters)) != hipSuccess ||
-        hipFuncSetAttribute((const void *)wfa_lds<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
-        hipFuncSetAttribute((const void *)wfa_lds<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+        hipFuncSetAttribute((const void *)wfa_lds<64, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+        hipFuncSetAttribute((const void *)wfa_lds<16, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+        hipFuncSetAttribute((const void *)wfa_lds<64, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+        hipFuncSetAttribute((const void *)wfa_lds<16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
         gab_set_error("gab_wfa_create: pinned allocation / LDS attribute failed"); delete h; return GAB_EDEVICE;
     }
     *out = h;
@@ -456,18 +529,15 @@ extern "C" int gab_wfa_run_device(gab_wfa *h, const char *pat, int64_t pat_bytes
     const int groups[3] = {16, 64, 64};
     for (int pass = 0; pass < 3 && cnt; pass++) {
         const int dir_cap = dir_caps[pass], G = groups[pass];
-        const size_t per_group = (((size_t)dir_cap * 12 + (size_t)(seqp + seqt) + pool_bytes[pass]) + 15) & ~(size_t)15;
+        const size_t per_group = (((size_t)dir_cap * (h->adaptive ? 16 : 12) + (size_t)(seqp + seqt) + pool_bytes[pass]) + 15) & ~(size_t)15;
         const size_t lds = per_group * (64 / G);
         if (lds > 160 * 1024 - 512) continue;            // sequences too long for this pool: let the next stage take them
         h->h_ct->n_over = 0;
         GAB_HIP(hipMemsetAsync(&d_ct->n_over, 0, 4, s));
         const unsigned blocks = (cnt + (64 / G) - 1) / (64 / G);
-        if (G == 16)
-            hipLaunchKernelGGL(wfa_lds<16>, dim3(blocks), dim3(64), lds, s, io, h->pen, cur, cnt, dir_cap, seqp, seqt,
-                               pool_bytes[pass] / 2, (uint32_t)per_group, nxt, d_ct);
-        else
-            hipLaunchKernelGGL(wfa_lds<64>, dim3(blocks), dim3(64), lds, s, io, h->pen, cur, cnt, dir_cap, seqp, seqt,
-                               pool_bytes[pass] / 2, (uint32_t)per_group, nxt, d_ct);
+        auto kern = G == 16 ? (h->adaptive ? wfa_lds<16, true> : wfa_lds<16, false>) : (h->adaptive ? wfa_lds<64, true> : wfa_lds<64, false>);
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(64), lds, s, io, h->pen, cur, cnt, dir_cap, seqp, seqt,
+                           pool_bytes[pass] / 2, (uint32_t)per_group, nxt, d_ct);
         GAB_HIP(hipGetLastError());
         if (!ev2) { GAB_HIP(hipEventRecord(h->ev[2], s)); ev2 = true; }
         GAB_HIP(hipMemcpyAsync(h->h_ct, d_ct, sizeof(WfaCounters), hipMemcpyDeviceToHost, s));
@@ -485,7 +555,7 @@ extern "C" int gab_wfa_run_device(gab_wfa *h, const char *pat, int64_t pat_bytes
         int64_t pool_cap = 1 << 20;                       // int32 elements per block
         int64_t dir_cap = 4096;
         while (c) {
-            int64_t per_block = dir_cap * 5 + pool_cap;
+            int64_t per_block = dir_cap * (h->adaptive ? 7 : 5) + pool_cap;
             int blocks = (int)std::min<int64_t>(c, std::max<int64_t>(1, (int64_t)(h->scratch_budget / 4) / per_block));
             blocks = std::min(blocks, 2048);
             if ((size_t)per_block * 4 > h->scratch_budget) {
@@ -495,7 +565,7 @@ extern "C" int gab_wfa_run_device(gab_wfa *h, const char *pat, int64_t pat_bytes
             rc = h->scratch.reserve((size_t)per_block * 4 * blocks);
             if (rc) return rc;
             GAB_HIP(hipMemsetAsync(&d_ct->n_over, 0, 4, s));
-            hipLaunchKernelGGL(wfa_global, dim3(blocks), dim3(64), 0, s, io, h->pen, list, c, h->scratch.as<int32_t>(),
+            hipLaunchKernelGGL(h->adaptive ? wfa_global<true> : wfa_global<false>, dim3(blocks), dim3(64), 0, s, io, h->pen, list, c, h->scratch.as<int32_t>(),
                                per_block, (int)dir_cap, (int)pool_cap, spill, d_ct);
             GAB_HIP(hipGetLastError());
             GAB_HIP(hipMemcpyAsync(h->h_ct, d_ct, sizeof(WfaCounters), hipMemcpyDeviceToHost, s));

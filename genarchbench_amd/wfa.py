@@ -24,10 +24,14 @@ def ops_layout(batch):
 
 
 class AffineWavefronts:
-    def __init__(self, mismatch=4, gap_opening=6, gap_extension=2, device=0):
+    """affine_wavefronts_new_complete, or -- with min_wavefront_length >= 0 -- affine_wavefronts_new_reduced
+    (wfa/gap_affine/affine_wavefront.c:141-181): the adaptive wavefront reduction"""
+
+    def __init__(self, mismatch=4, gap_opening=6, gap_extension=2, device=0, min_wavefront_length=-1, max_distance_threshold=-1):
         p = GabWfaPenalties(mismatch, gap_opening, gap_extension)
         self._h = C.c_void_p()
-        check(lib().gab_wfa_create(C.byref(p), C.c_int(device), C.byref(self._h)))
+        check(lib().gab_wfa_create_reduced(C.byref(p), C.c_int(min_wavefront_length), C.c_int(max_distance_threshold),
+                                           C.c_int(device), C.byref(self._h)))
 
     def close(self):
         if getattr(self, "_h", None):

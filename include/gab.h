@@ -157,8 +157,12 @@ int gab_bpm_last_stats(gab_bpm *h, int64_t *block_steps, int64_t *full_pairs,
  *           + the copy of wf->edit_cigar            wfa/tools/align_benchmark.c:415-437
  *           (kernel: wfa/gap_affine/affine_wavefront_align.c:325-361 and the files it calls).
  * One call over all pairs.  No swap: the '>' line is the pattern, the '<' line the text
- * (align_benchmark.c:152-160).  Complete mode only (no wavefront reduction), i.e. the
- * driver's default min_wavefront_length = -1 (align_benchmark.c:91,359-363).
+ * (align_benchmark.c:152-160).  gab_wfa_create = complete mode (affine_wavefronts_new_complete, the
+ * driver's default min_wavefront_length = -1, align_benchmark.c:91,359-363); gab_wfa_create_reduced =
+ * the adaptive reduction (affine_wavefronts_new_reduced, wfa/gap_affine/affine_wavefront.c:162-181,
+ * driver flags --minimum-wavefront-length / --maximum-difference-distance, align_benchmark.c:267-272,
+ * 364-368; the heuristic of affine_wavefronts_reduce_wavefronts, affine_wavefront_extend.c:85-154).
+ * min_wavefront_length < 0 selects the complete mode, as in the driver.
  * ops_out receives, for pair i, ops_len_out[i] operations 'M','X','I','D' starting at
  * ops_out[ops_off[i]]; the caller provides pattern_length + text_length bytes of room per pair
  * (edit_cigar_allocate, wfa/gap_affine/edit_cigar.c:38-47) and run-length encodes them when
@@ -170,6 +174,8 @@ typedef struct {
     int32_t mismatch, gap_opening, gap_extension; /* defaults 4, 6, 2 (align_benchmark.c:85-90); match = 0 */
 } gab_wfa_penalties;
 int gab_wfa_create(const gab_wfa_penalties *penalties, int device, gab_wfa **out);
+int gab_wfa_create_reduced(const gab_wfa_penalties *penalties, int min_wavefront_length, int max_distance_threshold,
+                           int device, gab_wfa **out);
 void gab_wfa_destroy(gab_wfa *h);
 int gab_wfa_run(gab_wfa *h, const char *pat, const int64_t *pat_off, const int32_t *pat_len,
                 const char *txt, const int64_t *txt_off, const int32_t *txt_len, int64_t n,

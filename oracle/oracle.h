@@ -63,7 +63,10 @@ void oracle_bpm_batch(const char *pat, const int64_t *pat_off, const int32_t *pa
 
 /* ---- wfa: see wfa.c.  ops = un-run-length-encoded CIGAR ('M','X','I','D'), capacity
  * pattern_length + text_length per pair; returns the number of operations. */
-typedef struct { int32_t mismatch, gap_opening, gap_extension; } oracle_wfa_penalties;
+typedef struct {
+    int32_t mismatch, gap_opening, gap_extension;
+    int32_t min_wavefront_length, max_distance_threshold;   /* adaptive reduction; min_wavefront_length < 0 = complete mode */
+} oracle_wfa_penalties;
 int oracle_wfa_one(const oracle_wfa_penalties *pen, const char *pattern, int plen, const char *text, int tlen,
                    char *ops_out, int *score_out, int64_t *cells);
 void oracle_wfa_batch(const oracle_wfa_penalties *pen, const char *pat, const int64_t *pat_off, const int32_t *pat_len,

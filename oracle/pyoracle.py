@@ -92,7 +92,8 @@ def bpm(batch, threads=0, want_steps=False):
 
 # ------------------------------------------------------------------ wfa
 class WfaPenalties(C.Structure):
-    _fields_ = [("mismatch", C.c_int32), ("gap_opening", C.c_int32), ("gap_extension", C.c_int32)]
+    _fields_ = [("mismatch", C.c_int32), ("gap_opening", C.c_int32), ("gap_extension", C.c_int32),
+                ("min_wavefront_length", C.c_int32), ("max_distance_threshold", C.c_int32)]
 
 
 def rle(ops):
@@ -105,9 +106,10 @@ def rle(ops):
     return "".join("%d%c" % (e - s, a[s]) for s, e in zip(starts, ends))
 
 
-def wfa(batch, pen=(4, 6, 2), threads=0, want_cells=False):
-    """batch: PairBatch (no swap: '>' line is the pattern).  returns (ops slab, ops_off, ops_len, score)"""
-    p = WfaPenalties(*pen)
+def wfa(batch, pen=(4, 6, 2), threads=0, want_cells=False, reduction=None):
+    """batch: PairBatch (no swap: '>' line is the pattern).  returns (ops slab, ops_off, ops_len, score).
+    reduction = (min_wavefront_length, max_distance_threshold) selects the adaptive mode"""
+    p = WfaPenalties(*pen, *(reduction if reduction is not None else (-1, -1)))
     cap = batch.pat_len.astype(np.int64) + batch.txt_len.astype(np.int64)
     ops_off = np.zeros(batch.n, np.int64)
     if batch.n > 1:

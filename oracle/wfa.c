@@ -1,13 +1,18 @@
 /* CPU ORACLE -- TEST INFRASTRUCTURE ONLY (see oracle.h).
  *
- * Gap-affine wavefront alignment (WFA v1, "complete" mode), as `align_benchmark` of the wfa
- * benchmark runs it:  affine_wavefronts_align
+ * Gap-affine wavefront alignment (WFA v1, "complete" mode and the adaptive reduction), as `align_benchmark`
+ * of the wfa benchmark runs it:  affine_wavefronts_align
  *   (/root/reference/benchmarks/wfa/gap_affine/affine_wavefront_align.c:325-361):
  *   extend (affine_wavefront_extend.c:241-252, scalar form) -> end test
  *   (affine_wavefront_utils.c:83-102) -> next wavefront (affine_wavefront_align.c:41-321)
  *   ... -> backtrace (affine_wavefront_backtrace.c:276-387) -> CIGAR operations.
  * Offsets are int32, a missing source reads as -10 (affine_wavefront.h:48), the strings behave as
  * if padded with 'X' (pattern) and 'Y' (text) on both sides (wfa/utils/string_padded.c:88-117).
+ * Adaptive mode (pen->min_wavefront_length >= 0; align_benchmark.c:359-368, --minimum-wavefront-length /
+ * --maximum-difference-distance): after every extension the M wavefront drops the outer diagonals that lag more
+ * than the threshold behind the best one (affine_wavefront_extend.c:85-154); the next wavefronts are computed
+ * from the reduced [lo, hi] (affine_wavefront_align.c:95-133), the backtrace still reads the whole allocated
+ * [lo_base, hi_base] (affine_wavefront_backtrace.c:75-226).
  * Per-pair state is created fresh (the reference's stale-slot reuse is benign).
  */
 #include "oracle.h"
@@ -19,7 +24,8 @@
 
 #define WF_NULL (-10)
 
-typedef struct { int lo, hi; int32_t *off; } wf_t;   /* off is centred: off[k], lo <= k <= hi; NULL if absent */
+/* off is centred: off[k], lob <= k <= hib as allocated; [lo, hi] is the range after reduction; NULL if absent */
+typedef struct { int lo, hi, lob, hib; int32_t *off; } wf_t;
 
 static inline int wf_get(const wf_t *w, int k) { return (w->off && w->lo <= k && k <= w->hi) ? w->off[k] : WF_NULL; }
 static inline int wf_lo(const wf_t *w) { return w->off ? w->lo : 1; }     /* null wavefront: lo=1, hi=-1 */
@@ -28,21 +34,54 @@ static inline int imax(int a, int b) { return a > b ? a : b; }
 static inline int imin(int a, int b) { return a < b ? a : b; }
 
 static wf_t wf_alloc(int lo, int hi) {
-    wf_t w; w.lo = lo; w.hi = hi;
+    wf_t w; w.lo = w.lob = lo; w.hi = w.hib = hi;
     int32_t *mem = (int32_t *)malloc(sizeof(int32_t) * (size_t)(hi - lo + 2));
     w.off = mem - lo;
     return w;
 }
-static void wf_free(wf_t *w) { if (w->off) free(w->off + w->lo); w->off = NULL; }
+static void wf_free(wf_t *w) { if (w->off) free(w->off + w->lob); w->off = NULL; }
+/* backtrace view: the allocated range */
+static inline int wf_get_base(const wf_t *w, int k) { return (w->off && w->lob <= k && k <= w->hib) ? w->off[k] : WF_NULL; }
+static inline int wf_has_base(const wf_t *w, int k) { return w->off && w->lob <= k && k <= w->hib; }
+
+/* affine_wavefronts_compute_distance, affine_wavefront_utils.c:64-74 */
+static inline int wf_distance(int plen, int tlen, int offset, int k) { return imax(plen - (offset - k), tlen - offset); }
+
+/* affine_wavefronts_reduce_wavefronts, affine_wavefront_extend.c:114-154 (the reduced range can never become empty:
+ * the bottom scan stops at min(ak-1, hi), the top scan at max(ak+1, lo)) */
+static void wf_reduce(wf_t *m, wf_t *i, wf_t *d, int plen, int tlen, int min_len, int max_thr) {
+    if (!m->off || m->hi - m->lo + 1 < min_len) return;
+    const int ak = tlen - plen;
+    int min_d = imax(plen, tlen);
+    for (int k = m->lo; k <= m->hi; k++) min_d = imin(min_d, wf_distance(plen, tlen, m->off[k], k));
+    const int top = imin(ak - 1, m->hi);
+    for (int k = m->lo; k < top; k++) {
+        if (wf_distance(plen, tlen, m->off[k], k) - min_d <= max_thr) break;
+        m->lo++;
+    }
+    const int bottom = imax(ak + 1, m->lo);
+    for (int k = m->hi; k > bottom; k--) {
+        if (wf_distance(plen, tlen, m->off[k], k) - min_d <= max_thr) break;
+        m->hi--;
+    }
+    if (i->off) { i->lo = imax(i->lo, m->lo); i->hi = imin(i->hi, m->hi); }
+    if (d->off) { d->lo = imax(d->lo, m->lo); d->hi = imin(d->hi, m->hi); }
+}
 
 int oracle_wfa_one(const oracle_wfa_penalties *pen, const char *pattern, int plen, const char *text, int tlen,
                    char *ops_out, int *score_out, int64_t *cells) {
     const int x = pen->mismatch, oe = pen->gap_opening + pen->gap_extension, e = pen->gap_extension;
-    const int max_score = imin(plen, tlen) * x + pen->gap_opening + abs(plen - tlen) * e + 1;
-    wf_t *M = (wf_t *)calloc((size_t)max_score + 2, sizeof(wf_t));
-    wf_t *I = (wf_t *)calloc((size_t)max_score + 2, sizeof(wf_t));
-    wf_t *D = (wf_t *)calloc((size_t)max_score + 2, sizeof(wf_t));
-    const wf_t none = {1, -1, NULL};
+    const int adaptive = pen->min_wavefront_length >= 0;
+    /* complete mode: the all-mismatch + one-gap alignment bounds the optimum.  The adaptive heuristic may end above it;
+     * the reference sizes its tables for 100000-base strings (align_benchmark.c:62,359-368, affine_wavefront.c:87-89),
+     * here they grow on demand up to that size */
+    const int bound = imin(plen, tlen) * x + pen->gap_opening + abs(plen - tlen) * e + 1;
+    const int max_score = adaptive ? 100000 * x + pen->gap_opening - 1 : bound;
+    int cap_s = bound + 2;
+    wf_t *M = (wf_t *)calloc((size_t)cap_s, sizeof(wf_t));
+    wf_t *I = (wf_t *)calloc((size_t)cap_s, sizeof(wf_t));
+    wf_t *D = (wf_t *)calloc((size_t)cap_s, sizeof(wf_t));
+    const wf_t none = {1, -1, 1, -1, NULL};
 #define PCH(v) (((v) >= 0 && (v) < plen) ? pattern[v] : 'X')
 #define TCH(h) (((h) >= 0 && (h) < tlen) ? text[h] : 'Y')
 #define SRC(A, s) ((s) >= 0 ? &(A)[s] : &none)
@@ -59,10 +98,19 @@ int oracle_wfa_one(const oracle_wfa_penalties *pen, const char *pattern, int ple
                 M[score].off[k] = o;
             }
         }
+        if (adaptive) wf_reduce(&M[score], &I[score], &D[score], plen, tlen, pen->min_wavefront_length, pen->max_distance_threshold);
         /* end reached? */
         if (M[score].off && M[score].lo <= ak && ak <= M[score].hi && M[score].off[ak] >= tlen) break;
         if (score >= max_score) { score = -1; break; }   /* cannot happen for a correct WFA */
         score++;
+        if (score >= cap_s) {
+            const int ncap = cap_s * 2;
+            M = (wf_t *)realloc(M, (size_t)ncap * sizeof(wf_t)); I = (wf_t *)realloc(I, (size_t)ncap * sizeof(wf_t));
+            D = (wf_t *)realloc(D, (size_t)ncap * sizeof(wf_t));
+            memset(M + cap_s, 0, (size_t)(ncap - cap_s) * sizeof(wf_t)); memset(I + cap_s, 0, (size_t)(ncap - cap_s) * sizeof(wf_t));
+            memset(D + cap_s, 0, (size_t)(ncap - cap_s) * sizeof(wf_t));
+            cap_s = ncap;
+        }
         const wf_t *msub = SRC(M, score - x), *mgap = SRC(M, score - oe), *iext = SRC(I, score - e), *dext = SRC(D, score - e);
         if (!msub->off && !mgap->off && !iext->off && !dext->off) continue;
         const int lo = imin(imin(wf_lo(msub), wf_lo(mgap)), imin(wf_lo(iext), wf_lo(dext))) - 1;
@@ -109,11 +157,11 @@ int oracle_wfa_one(const oracle_wfa_penalties *pen, const char *pattern, int ple
                 }
             }
             const int s_go = s - oe, s_ge = s - e, s_mm = s - x;
-            const int del_ext = type == BT_I ? WF_NULL : (s_ge >= 0 ? wf_get(&D[s_ge], k + 1) : WF_NULL);
-            const int del_open = type == BT_I ? WF_NULL : (s_go >= 0 ? wf_get(&M[s_go], k + 1) : WF_NULL);
-            const int ins_ext = type == BT_D ? WF_NULL : (s_ge >= 0 && I[s_ge].off && I[s_ge].lo <= k - 1 && k - 1 <= I[s_ge].hi ? I[s_ge].off[k - 1] + 1 : WF_NULL);
-            const int ins_open = type == BT_D ? WF_NULL : (s_go >= 0 && M[s_go].off && M[s_go].lo <= k - 1 && k - 1 <= M[s_go].hi ? M[s_go].off[k - 1] + 1 : WF_NULL);
-            const int misms = type != BT_M ? WF_NULL : (s_mm >= 0 && M[s_mm].off && M[s_mm].lo <= k && k <= M[s_mm].hi ? M[s_mm].off[k] + 1 : WF_NULL);
+            const int del_ext = type == BT_I ? WF_NULL : (s_ge >= 0 ? wf_get_base(&D[s_ge], k + 1) : WF_NULL);
+            const int del_open = type == BT_I ? WF_NULL : (s_go >= 0 ? wf_get_base(&M[s_go], k + 1) : WF_NULL);
+            const int ins_ext = type == BT_D ? WF_NULL : (s_ge >= 0 && wf_has_base(&I[s_ge], k - 1) ? I[s_ge].off[k - 1] + 1 : WF_NULL);
+            const int ins_open = type == BT_D ? WF_NULL : (s_go >= 0 && wf_has_base(&M[s_go], k - 1) ? M[s_go].off[k - 1] + 1 : WF_NULL);
+            const int misms = type != BT_M ? WF_NULL : (s_mm >= 0 && wf_has_base(&M[s_mm], k) ? M[s_mm].off[k] + 1 : WF_NULL);
             const int max_all = imax(misms, imax(imax(ins_ext, ins_open), imax(del_ext, del_open)));
             if (type == BT_M) {
                 for (int i = 0; i < offset - max_all; i++) buf[pos--] = 'M';
@@ -134,7 +182,7 @@ int oracle_wfa_one(const oracle_wfa_penalties *pen, const char *pattern, int ple
         free(buf);
     }
     if (score_out) *score_out = score;
-    for (int s = 0; s <= max_score + 1; s++) { wf_free(&M[s]); wf_free(&I[s]); wf_free(&D[s]); }
+    for (int s = 0; s < cap_s; s++) { wf_free(&M[s]); wf_free(&I[s]); wf_free(&D[s]); }
     free(M); free(I); free(D);
     return nops;
 }

@@ -94,23 +94,38 @@ def make_bpm(m):
                    "command": "bpm_ref -a bpm-edit -i <in> -o <out> -t 1|3 ; sort by id (as regression_small.sh:94 does)"}
 
 
+# adaptive mode: the reduction parameters the adaptive fixtures are produced with
+WFA_ADAPTIVE = [(10, 10), (5, 3), (1, 0)]
+
+
 def make_wfa(m):
     import re
-    for name, seed, n, mode, plen in [("wfa_bench", 401, 1500, 0, 151), ("wfa_adv", 402, 2000, 1, 240)]:
-        inp = os.path.join(HERE, name + ".in.txt")
-        gabgen.write_text("wfa", inp, seed, n, mode, plen)
+
+    def run_ref(inp, extra):
         outs = []
         for t in ("1", "3"):
-            out = os.path.join(HERE, name + ".tmp")
-            subprocess.run([pyoracle.ref_path("wfa_ref"), "-i", inp, "-o", out, "-t", t], capture_output=True, check=True)
+            out = inp + ".tmp"
+            subprocess.run([pyoracle.ref_path("wfa_ref"), "-i", inp, "-o", out, "-t", t] + extra, capture_output=True, check=True)
             lines = sorted(open(out).read().splitlines(), key=lambda l: int(re.match(r"id=(\d+)", l).group(1)))
             os.remove(out)
             outs.append(lines)
         assert outs[0] == outs[1], "wfa reference output depends on the thread count"
-        open(os.path.join(HERE, name + ".expected.txt"), "w").write("\n".join(outs[0]) + "\n")
+        return outs[0]
+
+    for name, seed, n, mode, plen in [("wfa_bench", 401, 1500, 0, 151), ("wfa_adv", 402, 2000, 1, 240)]:
+        inp = os.path.join(HERE, name + ".in.txt")
+        gabgen.write_text("wfa", inp, seed, n, mode, plen)
+        open(os.path.join(HERE, name + ".expected.txt"), "w").write("\n".join(run_ref(inp, [])) + "\n")
         m[name] = {"generator": "tools/gen gabgen wfa", "seed": seed, "n": n, "mode": mode, "plen": plen,
                    "reference": "wfa/tools/align_benchmark.c + wfa/{gap_affine,utils}/*.c built by oracle/Makefile",
                    "command": "wfa_ref -i <in> -o <out> -t 1|3 ; sort by id (as regression_small.sh:94 does)"}
+    # the same adversarial input through the reference's adaptive reduction
+    inp = os.path.join(HERE, "wfa_adv.in.txt")
+    for mwl, mdd in WFA_ADAPTIVE:
+        lines = run_ref(inp, ["--minimum-wavefront-length", str(mwl), "--maximum-difference-distance", str(mdd)])
+        open(os.path.join(HERE, f"wfa_adv.adaptive_{mwl}_{mdd}.expected.txt"), "w").write("\n".join(lines) + "\n")
+    m["wfa_adv"]["adaptive_command"] = ("wfa_ref -i <in> -o <out> -t 1|3 --minimum-wavefront-length L --maximum-difference-distance D "
+                                        "for (L, D) in " + repr(WFA_ADAPTIVE))
 
 
 def make_fmi(m):

@@ -106,3 +106,19 @@ def test_wfa_driver_gpu_parse_mode(inputs, tmp_path):
     assert ra.returncode == 0 and rb.returncode == 0, rb.stderr[-500:]
     assert "indexed on the GPU" in rb.stdout
     assert open(a).read() == open(b).read() and len(open(a).read()) > 0
+
+
+def test_wfa_driver_adaptive_flags(tmp_path):
+    """--minimum-wavefront-length / --maximum-difference-distance: the golden CIGARs of the reference's adaptive mode,
+    through both the getline path and the GPU parser"""
+    from tests.util import GOLDEN
+    exe = os.path.join(ROOT, "benchmarks", "wfa", "bin", "align_benchmark")
+    want = open(f"{GOLDEN}/wfa_adv.adaptive_5_3.expected.txt").read()
+    for env in ({}, {"GAB_GPU_PARSE": "1", "GAB_GPUS": "1"}):
+        out = str(tmp_path / "o.txt")
+        r = subprocess.run([exe, "-i", f"{GOLDEN}/wfa_adv.in.txt", "-o", out, "--minimum-wavefront-length", "5",
+                            "--maximum-difference-distance", "3"], capture_output=True, text=True, timeout=300,
+                           env=dict(os.environ, **env))
+        assert r.returncode == 0, r.stderr[-500:]
+        got = sorted(open(out).read().splitlines(), key=lambda l: int(l.split()[0][3:]))
+        assert "\n".join(got) + "\n" == want

@@ -82,6 +82,52 @@ def test_other_penalties():
         e.close()
 
 
+# ---- adaptive reduction ----------------------------------------------------------------------
+@pytest.mark.parametrize("red", [(10, 10), (5, 3), (1, 0)])
+def test_adaptive_golden(red):
+    from genarchbench_amd.wfa import AffineWavefronts
+    batch = gabgen.read_pairs_text(f"{GOLDEN}/wfa_adv.in.txt")
+    want = read_cigars(f"{GOLDEN}/wfa_adv.adaptive_{red[0]}_{red[1]}.expected.txt")
+    e = AffineWavefronts(min_wavefront_length=red[0], max_distance_threshold=red[1])
+    assert pyoracle.wfa_cigars(e.align(batch)) == want
+    e.close()
+
+
+@pytest.mark.parametrize("red,seed,n,mode,plen,pen", [((10, 50), 71, 40000, 0, 151, (4, 6, 2)), ((5, 3), 72, 20000, 1, 300, (4, 6, 2)),
+                                                      ((3, 1), 73, 3000, 1, 900, (4, 6, 2)), ((0, -1), 74, 5000, 1, 120, (4, 6, 2)),
+                                                      ((2, 5), 75, 5000, 1, 200, (2, 3, 1)), ((20, 2), 76, 5000, 1, 250, (5, 8, 3)),
+                                                      ((1, 0), 77, 65, 1, 40, (3, 1, 4))])
+def test_adaptive_vs_oracle(red, seed, n, mode, plen, pen):
+    from genarchbench_amd.wfa import AffineWavefronts
+    batch = gabgen.pairs(seed, n, mode, plen)
+    want = pyoracle.wfa(batch, pen, want_cells=True, reduction=red)
+    e = AffineWavefronts(*pen, min_wavefront_length=red[0], max_distance_threshold=red[1])
+    same(e.align(batch), want)
+    assert e.last_stats()["work"] == want[4]
+    e.close()
+
+
+def test_adaptive_long_sequences_global_path():
+    """the int32 / global-history kernel in adaptive mode, and the edge inputs"""
+    from genarchbench_amd.wfa import AffineWavefronts
+    rng = np.random.default_rng(12)
+    pats, txts = [b"A", b"ACGT", b"", b"XXYY", b"A" * 200], [b"A", b"", b"ACGT", b"YYXX", b"A" * 120]
+    for n, err in ((2500, 0.02), (6000, 0.05), (1500, 0.25), (300, 0.6)):
+        p = rng.choice(np.frombuffer(b"ACGT", np.uint8), n).tobytes()
+        t = bytearray()
+        for c in p:
+            r = rng.random()
+            if r < err / 3: continue
+            if r < 2 * err / 3: t.append(b"ACGT"[int(rng.integers(0, 4))])
+            t.append(c if r > err else b"ACGT"[int(rng.integers(0, 4))])
+        pats.append(p); txts.append(bytes(t))
+    b = gabgen.pairs_from_lists(pats, txts)
+    for red in [(10, 50), (5, 3), (0, -1)]:
+        e = AffineWavefronts(min_wavefront_length=red[0], max_distance_threshold=red[1])
+        same(e.align(b), pyoracle.wfa(b, reduction=red))
+        e.close()
+
+
 def test_device_resident(eng):
     import torch
     from genarchbench_amd.wfa import ops_layout

@@ -14,6 +14,16 @@ def test_oracle_matches_golden(name):
     assert pyoracle.wfa_cigars(pyoracle.wfa(batch)) == want
 
 
+@pytest.mark.parametrize("red", [(10, 10), (5, 3), (1, 0)])
+def test_oracle_adaptive_matches_golden(red):
+    """adaptive reduction (--minimum-wavefront-length / --maximum-difference-distance)"""
+    batch = gabgen.read_pairs_text(f"{GOLDEN}/wfa_adv.in.txt")
+    want = read_cigars(f"{GOLDEN}/wfa_adv.adaptive_{red[0]}_{red[1]}.expected.txt")
+    got = pyoracle.wfa_cigars(pyoracle.wfa(batch, reduction=red))
+    assert got == want
+    assert got != read_cigars(f"{GOLDEN}/wfa_adv.expected.txt")       # the reduction really changes some alignments
+
+
 def test_cigar_consistency():
     """size-independent property: the CIGAR consumes both strings and re-scores to the reported penalty"""
     b = gabgen.pairs(77, 3000, 1, 200)
