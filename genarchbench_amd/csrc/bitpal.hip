@@ -1,0 +1,308 @@
+// bitpal -- global alignment scores of the bpm benchmark's BitPAl algorithms on gfx950.
+//
+// Semantics: benchmark_bitpal_m0_x1_g1 / benchmark_bitpal_m1_x4_g2,
+//   /root/reference/benchmarks/bpm/benchmark/benchmark_bitpal.c:30-55, selected by the driver's
+//   `-a bitpal-edit` / `-a bitpal-scored` (bpm/tools/align_benchmark.c:259-264, 330-338).  They call the generated
+//   bit-vector programs bpm/bitpal/bitpal.m0.x1.g1.c / bitpal.m1.x4.g2.c, whose result is the Needleman-Wunsch score
+//   of the two strings: global, linear gap cost, characters compared as raw bytes, with
+//   (match, mismatch, gap) = (0, -1, -1) resp. (+1, -4, -2).  No CIGAR is produced.
+//
+// Mapping: BitPAl packs 63 DP columns into a machine word because a CPU core has one pair to work on; here there are
+// millions of independent pairs, so the lane, not the bit, is the unit of parallelism: ONE PAIR PER LANE, plain integer
+// DP.  The longer string is walked in chunks of 32 columns held in registers (32 scores + 32 bytes), the shorter string
+// is the row loop; the only memory state is the chunk's boundary column -- one score per row -- kept per lane in LDS as
+// int16 in [row][lane] order (conflict-free), or in a global scratch as int32 when a pair is too long for that.
+// The DP runs on S'[i][j] = S[i][j] - (i + j) * gap: vertical and horizontal moves then cost nothing, a diagonal move adds
+// match - 2 gap or mismatch - 2 gap, and both borders are zero, so one cell is compare / select / add / v_max3_i32 on
+// registers; per row there is one LDS read, one LDS write and a quarter of a dword load of the row string.
+//
+// Roofline: plen + tlen + 4 bytes of HBM traffic per pair against ~5 VALU per DP cell: integer-VALU bound.
+#include "gab_internal.h"
+#include <algorithm>
+#include <new>
+#include <string.h>
+
+namespace {
+
+constexpr int kChunk = 32;                 // DP columns per register chunk
+constexpr int kLdsRows = 1024;             // longest row string (the shorter of the pair) on the LDS path
+constexpr int kLdsCols = 16320;            // any: 0 <= S' <= min(i, j) * (match - 2 gap) <= 5 * 1024 fits int16
+constexpr int kBigBlocks = 256;            // workgroups of the global-scratch path
+
+struct BpIO {
+    const char *pat; const int64_t *pat_off; const int32_t *pat_len;
+    const char *txt; const int64_t *txt_off; const int32_t *txt_len;
+    int64_t pat_bytes, txt_bytes, n;
+    int32_t *score;
+};
+
+struct BpCounters {
+    int32_t bad, first_bad;
+    int32_t max_rows_lds, max_rows_big;     // longest row string per path
+    uint32_t n_lds, n_big;
+    unsigned long long cells;
+};
+
+struct BpScore { int32_t match, mismatch, gap; };
+
+// four bytes of a sequence at position `pos`; bytes at or behind `len` read as `fill` (never loads past the last dword
+// that holds a sequence byte: the slabs are readable to a multiple of 4 bytes only)
+__device__ __forceinline__ uint32_t seq_ld4(const char *s, int pos, int len, uint32_t fill) {
+    uint32_t w;
+    if (pos + 4 <= len) { __builtin_memcpy(&w, s + pos, 4); return w; }
+    w = fill * 0x01010101u;
+    for (int b = 0; b < 4; b++)
+        if (pos + b < len) w = (w & ~(0xffu << (8 * b))) | (uint32_t)(uint8_t)s[pos + b] << (8 * b);
+    return w;
+}
+
+// ---- pass 0: validate, split by path ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bitpal_classify(BpIO io, BpCounters *ct, uint32_t *list_lds, uint32_t *list_big) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    int ml = 0, mb = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < io.n; i += stride) {
+        const int pl = io.pat_len[i], tl = io.txt_len[i];
+        const int64_t po = io.pat_off[i], to = io.txt_off[i];
+        const bool ok = pl >= 0 && tl >= 0 && pl <= GAB_BITPAL_MAX_LEN && tl <= GAB_BITPAL_MAX_LEN && po >= 0 && to >= 0 &&
+                        ((po + pl + 3) & ~3ll) <= io.pat_bytes && ((to + tl + 3) & ~3ll) <= io.txt_bytes;
+        if (!ok) {
+            atomicAdd(&ct->bad, 1);
+            atomicMin((unsigned int *)&ct->first_bad, (unsigned int)(i + 1 > 0x7fffffff ? 0x7fffffff : i + 1));
+            continue;
+        }
+        const int rows = min(pl, tl), cols = max(pl, tl);
+        if (rows <= kLdsRows && cols <= kLdsCols) { list_lds[atomicAdd(&ct->n_lds, 1u)] = (uint32_t)i; ml = max(ml, rows); }
+        else { list_big[atomicAdd(&ct->n_big, 1u)] = (uint32_t)i; mb = max(mb, rows); }
+    }
+    for (int o = 32; o > 0; o >>= 1) { ml = max(ml, __shfl_xor(ml, o)); mb = max(mb, __shfl_xor(mb, o)); }
+    if ((threadIdx.x & 63) == 0) { atomicMax(&ct->max_rows_lds, ml); atomicMax(&ct->max_rows_big, mb); }
+}
+
+// ---- the DP: one pair per lane ------------------------------------------------------------------------------------------
+// LDSCOL: boundary column = int16 [row][lane] in dynamic LDS, one workgroup (= one wave) per 64 pairs;
+// otherwise int32 [row][lane] in this workgroup's slice of `gcol`, workgroups stride over the groups of 64 pairs.
+template <bool LDSCOL>
+__global__ __launch_bounds__(64) void bitpal_dp(BpIO io, const uint32_t *__restrict__ list, uint32_t count, BpScore sc,
+                                                int32_t *gcol, int64_t gcol_per_block, BpCounters *ct) {
+    extern __shared__ __attribute__((aligned(16))) int16_t col_lds[];
+    const int lane = threadIdx.x;
+    int32_t *col_glb = LDSCOL ? nullptr : gcol + (int64_t)blockIdx.x * gcol_per_block;
+    auto col_get = [&](int row) -> int { return LDSCOL ? (int)col_lds[row * 64 + lane] : col_glb[(int64_t)row * 64 + lane]; };
+    auto col_put = [&](int row, int v) {
+        if (LDSCOL) col_lds[row * 64 + lane] = (int16_t)v;
+        else col_glb[(int64_t)row * 64 + lane] = v;
+    };
+    const int G = sc.gap, Md = sc.match - 2 * sc.gap, Xd = sc.mismatch - 2 * sc.gap;    // diagonal increments of S'
+    unsigned long long cells = 0;
+    for (uint32_t g0 = blockIdx.x * 64u; g0 < count; g0 += gridDim.x * 64u) {
+        const uint32_t b = g0 + (uint32_t)lane;
+        const bool have = b < count;
+        int nc = 0, nr = 0;                                  // column string (the longer one, in registers) / row string
+        const char *cs = nullptr, *rs = nullptr;
+        uint32_t id = 0;
+        if (have) {
+            id = list[b];
+            const int pl = io.pat_len[id], tl = io.txt_len[id];
+            const char *p = io.pat + io.pat_off[id], *t = io.txt + io.txt_off[id];
+            if (pl >= tl) { nc = pl; cs = p; nr = tl; rs = t; } else { nc = tl; cs = t; nr = pl; rs = p; }
+        }
+        // column 0 of S': zero
+        for (int i = 0; i <= nr; i++) col_put(i, 0);
+        int ans = 0;                                         // both strings empty
+        const int nchunks = (nc + kChunk - 1) / kChunk;
+        for (int ch = 0; ch < nchunks; ch++) {
+            const int base = ch * kChunk;
+            uint32_t cw[kChunk / 4];                         // the chunk's bytes of the column string; 0xff behind its end
+#pragma unroll
+            for (int w = 0; w < kChunk / 4; w++) cw[w] = base + 4 * w < nc ? seq_ld4(cs, base + 4 * w, nc, 0xffu) : 0xffffffffu;
+            int H[kChunk];
+#pragma unroll
+            for (int c = 0; c < kChunk; c++) H[c] = 0;                           // row 0 of S'
+            int diag = 0;                                                       // S'[0][base]
+            uint32_t rw = 0;
+            for (int i = 1; i <= nr; i++) {
+                if (((i - 1) & 3) == 0) rw = seq_ld4(rs, i - 1, nr, 0u);
+                const uint32_t rc = rw & 0xffu;
+                rw >>= 8;
+                int left = col_get(i);                                          // H[i][base]
+                const int next_diag = left;
+                const uint32_t rc4 = rc * 0x01010101u;
+#pragma unroll
+                for (int c = 0; c < kChunk; c++) {
+                    const uint32_t x = cw[c >> 2] ^ rc4;                         // zero byte = equal characters
+                    const bool eq = ((x >> (8 * (c & 3))) & 0xffu) == 0;
+                    const int up = H[c];
+                    const int h = max(diag + (eq ? Md : Xd), max(up, left));
+                    diag = up; left = h; H[c] = h;
+                }
+                col_put(i, H[kChunk - 1]);
+                diag = next_diag;
+            }
+            if (nc > base && nc <= base + kChunk) {
+#pragma unroll
+                for (int c = 0; c < kChunk; c++) ans = (c == nc - 1 - base) ? H[c] : ans;
+            }
+        }
+        if (have) { io.score[id] = ans + (nc + nr) * G; cells += (unsigned long long)nc * (unsigned long long)nr; }
+    }
+    for (int o = 32; o > 0; o >>= 1) cells += __shfl_xor(cells, o);
+    if (lane == 0 && cells) atomicAdd(&ct->cells, cells);
+}
+
+}  // namespace
+
+// =============================================================================== host side
+struct gab_bitpal {
+    int device = 0;
+    BpScore sc;
+    gab_devbuf ws;          // counters | 2 id lists
+    gab_devbuf scratch;     // boundary columns of the global path
+    gab_devbuf io;          // staging for the host-pointer entry point
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    BpCounters *h_ct = nullptr;
+    bool have_stats = false;
+};
+
+extern "C" int gab_bitpal_create(int algorithm, int device, gab_bitpal **out) {
+    if (!out) { gab_set_error("gab_bitpal_create: NULL argument"); return GAB_EINVAL; }
+    *out = nullptr;
+    GAB_CHECK(algorithm == GAB_BITPAL_EDIT || algorithm == GAB_BITPAL_SCORED,
+              "gab_bitpal_create: algorithm %d is neither GAB_BITPAL_EDIT nor GAB_BITPAL_SCORED", algorithm);
+    int rc = gab_check_device(device);
+    if (rc) return rc;
+    gab_device_guard g(device);
+    gab_bitpal *h = new (std::nothrow) gab_bitpal();
+    if (!h) { gab_set_error("out of host memory"); return GAB_ENOMEM; }
+    h->device = device;
+    if (algorithm == GAB_BITPAL_EDIT) h->sc = BpScore{0, -1, -1};      // bitpal.m0.x1.g1.c
+    else h->sc = BpScore{1, -4, -2};                                   // bitpal.m1.x4.g2.c
+    for (int k = 0; k < 3; k++)
+        if (hipEventCreate(&h->ev[k]) != hipSuccess) { gab_set_error("hipEventCreate failed"); delete h; return GAB_EDEVICE; }
+    if (hipHostMalloc((void **)&h->h_ct, sizeof(BpCounters)) != hipSuccess ||
+        hipFuncSetAttribute((const void *)bitpal_dp<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+        gab_set_error("gab_bitpal_create: pinned allocation / LDS attribute failed"); delete h; return GAB_EDEVICE;
+    }
+    *out = h;
+    return GAB_OK;
+}
+
+extern "C" void gab_bitpal_destroy(gab_bitpal *h) {
+    if (!h) return;
+    gab_device_guard g(h->device);
+    h->ws.release(); h->scratch.release(); h->io.release();
+    for (int k = 0; k < 3; k++) if (h->ev[k]) (void)hipEventDestroy(h->ev[k]);
+    if (h->h_ct) (void)hipHostFree(h->h_ct);
+    delete h;
+}
+
+extern "C" int gab_bitpal_run_device(gab_bitpal *h, const char *pat, int64_t pat_bytes, const int64_t *pat_off,
+                                     const int32_t *pat_len, const char *txt, int64_t txt_bytes, const int64_t *txt_off,
+                                     const int32_t *txt_len, int64_t n, int32_t *score_out, void *stream_) {
+    GAB_CHECK(h, "gab_bitpal_run_device: NULL handle");
+    GAB_CHECK(n >= 0 && n < (1ll << 31), "gab_bitpal_run_device: n=%lld out of range", (long long)n);
+    h->have_stats = false;
+    if (n == 0) return GAB_OK;
+    GAB_CHECK(pat && pat_off && pat_len && txt && txt_off && txt_len && score_out, "gab_bitpal_run_device: NULL buffer");
+    gab_device_guard g(h->device);
+    hipStream_t s = (hipStream_t)stream_;
+    const size_t o_l0 = 256, o_l1 = o_l0 + 4 * (size_t)n;
+    int rc = h->ws.reserve(o_l1 + 4 * (size_t)n);
+    if (rc) return rc;
+    char *base = h->ws.as<char>();
+    BpCounters *d_ct = (BpCounters *)base;
+    uint32_t *l_lds = (uint32_t *)(base + o_l0), *l_big = (uint32_t *)(base + o_l1);
+    BpIO io{pat, pat_off, pat_len, txt, txt_off, txt_len, pat_bytes, txt_bytes, n, score_out};
+
+    GAB_HIP(hipEventRecord(h->ev[0], s));
+    memset(h->h_ct, 0, sizeof(BpCounters));
+    h->h_ct->first_bad = 0x7fffffff;
+    GAB_HIP(hipMemcpyAsync(d_ct, h->h_ct, sizeof(BpCounters), hipMemcpyHostToDevice, s));
+    const int grid = (int)std::min<int64_t>(gab_ceil_div(n, 256), 4096);
+    hipLaunchKernelGGL(bitpal_classify, dim3(grid), dim3(256), 0, s, io, d_ct, l_lds, l_big);
+    GAB_HIP(hipMemcpyAsync(h->h_ct, d_ct, sizeof(BpCounters), hipMemcpyDeviceToHost, s));
+    GAB_HIP(hipStreamSynchronize(s));
+    if (h->h_ct->bad) {
+        gab_set_error("gab_bitpal_run_device: %d pair(s) violate the limits (first: pair %d): need 0 <= length <= %d and "
+                      "offsets inside the slabs (readable to a multiple of 4 bytes)", h->h_ct->bad,
+                      h->h_ct->first_bad - 1, GAB_BITPAL_MAX_LEN);
+        return GAB_EINVAL;
+    }
+    const uint32_t n_lds = h->h_ct->n_lds, n_big = h->h_ct->n_big;
+    GAB_HIP(hipEventRecord(h->ev[1], s));
+    if (n_lds) {
+        const size_t lds = (size_t)(h->h_ct->max_rows_lds + 1) * 64 * sizeof(int16_t);
+        hipLaunchKernelGGL(bitpal_dp<true>, dim3((n_lds + 63) / 64), dim3(64), lds, s, io, l_lds, n_lds, h->sc, nullptr, 0, d_ct);
+        GAB_HIP(hipGetLastError());
+    }
+    if (n_big) {
+        const int64_t per_block = (int64_t)(h->h_ct->max_rows_big + 1) * 64;
+        const int blocks = (int)std::min<int64_t>((n_big + 63) / 64, kBigBlocks);
+        rc = h->scratch.reserve((size_t)per_block * 4 * (size_t)blocks);
+        if (rc) return rc;
+        hipLaunchKernelGGL(bitpal_dp<false>, dim3(blocks), dim3(64), 0, s, io, l_big, n_big, h->sc, h->scratch.as<int32_t>(),
+                           per_block, d_ct);
+        GAB_HIP(hipGetLastError());
+    }
+    GAB_HIP(hipMemcpyAsync(h->h_ct, d_ct, sizeof(BpCounters), hipMemcpyDeviceToHost, s));
+    GAB_HIP(hipEventRecord(h->ev[2], s));
+    GAB_HIP(hipStreamSynchronize(s));
+    h->have_stats = true;
+    return GAB_OK;
+}
+
+extern "C" int gab_bitpal_run(gab_bitpal *h, const char *pat, const int64_t *pat_off, const int32_t *pat_len,
+                              const char *txt, const int64_t *txt_off, const int32_t *txt_len, int64_t n,
+                              int32_t *score_out) {
+    GAB_CHECK(h, "gab_bitpal_run: NULL handle");
+    GAB_CHECK(n >= 0 && n < (1ll << 31), "gab_bitpal_run: n=%lld out of range", (long long)n);
+    if (n == 0) return GAB_OK;
+    GAB_CHECK(pat && pat_off && pat_len && txt && txt_off && txt_len && score_out, "gab_bitpal_run: NULL buffer");
+    gab_device_guard g(h->device);
+    int64_t pb = 0, tb = 0, pa = INT64_MAX, ta = INT64_MAX;
+    for (int64_t i = 0; i < n; i++) {
+        GAB_CHECK(pat_off[i] >= 0 && txt_off[i] >= 0 && pat_len[i] >= 0 && txt_len[i] >= 0,
+                  "gab_bitpal_run: negative offset/length at pair %lld", (long long)i);
+        pb = std::max(pb, pat_off[i] + pat_len[i]); tb = std::max(tb, txt_off[i] + txt_len[i]);
+        pa = std::min(pa, pat_off[i]); ta = std::min(ta, txt_off[i]);
+    }
+    pa &= ~(int64_t)255; ta &= ~(int64_t)255;      // stage only the referenced window [min, max) of each slab
+    const size_t ppad = ((size_t)(pb - pa) + 3 + 255) & ~(size_t)255, tpad = ((size_t)(tb - ta) + 3 + 255) & ~(size_t)255;
+    const size_t nn = (size_t)n;
+    size_t o = 0;
+    const size_t o_p = o; o += ppad;
+    const size_t o_t = o; o += tpad;
+    const size_t o_po = o; o += 8 * nn;
+    const size_t o_to = o; o += 8 * nn;
+    const size_t o_pl = o; o += 4 * nn;
+    const size_t o_tl = o; o += 4 * nn;
+    const size_t o_sc = o; o += 4 * nn;
+    int rc = h->io.reserve(o);
+    if (rc) return rc;
+    char *b = h->io.as<char>();
+    hipStream_t s = nullptr;
+    GAB_HIP(hipMemcpyAsync(b + o_p, pat + pa, (size_t)(pb - pa), hipMemcpyHostToDevice, s));
+    GAB_HIP(hipMemcpyAsync(b + o_t, txt + ta, (size_t)(tb - ta), hipMemcpyHostToDevice, s));
+    GAB_HIP(hipMemcpyAsync(b + o_po, pat_off, 8 * nn, hipMemcpyHostToDevice, s));
+    GAB_HIP(hipMemcpyAsync(b + o_to, txt_off, 8 * nn, hipMemcpyHostToDevice, s));
+    GAB_HIP(hipMemcpyAsync(b + o_pl, pat_len, 4 * nn, hipMemcpyHostToDevice, s));
+    GAB_HIP(hipMemcpyAsync(b + o_tl, txt_len, 4 * nn, hipMemcpyHostToDevice, s));
+    rc = gab_bitpal_run_device(h, b + o_p - pa, pa + (int64_t)ppad, (const int64_t *)(b + o_po), (const int32_t *)(b + o_pl),
+                               b + o_t - ta, ta + (int64_t)tpad, (const int64_t *)(b + o_to), (const int32_t *)(b + o_tl), n,
+                               (int32_t *)(b + o_sc), s);
+    if (rc) return rc;
+    GAB_HIP(hipMemcpyAsync(score_out, b + o_sc, 4 * nn, hipMemcpyDeviceToHost, s));
+    GAB_HIP(hipStreamSynchronize(s));
+    return GAB_OK;
+}
+
+extern "C" int gab_bitpal_last_stats(gab_bitpal *h, int64_t *cells, int64_t *long_pairs, float *kernel_ms, float *total_ms) {
+    GAB_CHECK(h, "gab_bitpal_last_stats: NULL handle");
+    GAB_CHECK(h->have_stats, "gab_bitpal_last_stats: no completed run on this handle");
+    gab_device_guard g(h->device);
+    GAB_HIP(hipEventSynchronize(h->ev[2]));
+    if (cells) *cells = (int64_t)h->h_ct->cells;
+    if (long_pairs) *long_pairs = (int64_t)h->h_ct->n_big;
+    if (kernel_ms) GAB_HIP(hipEventElapsedTime(kernel_ms, h->ev[1], h->ev[2]));
+    if (total_ms) GAB_HIP(hipEventElapsedTime(total_ms, h->ev[0], h->ev[2]));
+    return GAB_OK;
+}

@@ -152,6 +152,35 @@ int gab_bpm_run_device(gab_bpm *h, const char *pat, int64_t pat_bytes, const int
 int gab_bpm_last_stats(gab_bpm *h, int64_t *block_steps, int64_t *full_pairs,
                        float *score_kernel_ms, float *total_ms);
 
+/* ---- bitpal: the bpm driver's BitPAl algorithms (global alignment score, no CIGAR) -----------
+ * Replaces  it->score = benchmark_bitpal_m0_x1_g1(&align_input)   (-a bitpal-edit)
+ *           it->score = benchmark_bitpal_m1_x4_g2(&align_input)   (-a bitpal-scored)
+ *                                                    bpm/tools/align_benchmark.c:259-264, 330-338
+ *           (bpm/benchmark/benchmark_bitpal.c:30-55; generated kernels bpm/bitpal/bitpal.m0.x1.g1.c,
+ *            bpm/bitpal/bitpal.m1.x4.g2.c).
+ * score_out[i] = the Needleman-Wunsch score of pair i: global, linear gaps, raw-byte comparison, with
+ * (match, mismatch, gap) = (0, -1, -1) for GAB_BITPAL_EDIT and (+1, -4, -2) for GAB_BITPAL_SCORED --
+ * the value the reference prints as "[i] score=%d".  Same buffers as gab_bpm_run; the score is
+ * symmetric in the two strings, so the driver's swap is immaterial and not required.
+ */
+#define GAB_BITPAL_EDIT 0
+#define GAB_BITPAL_SCORED 1
+#define GAB_BITPAL_MAX_LEN 16320 /* kept equal to GAB_BPM_MAX_PLEN: the two algorithms share the driver and its inputs */
+typedef struct gab_bitpal gab_bitpal;
+int gab_bitpal_create(int algorithm, int device, gab_bitpal **out);
+void gab_bitpal_destroy(gab_bitpal *h);
+int gab_bitpal_run(gab_bitpal *h, const char *pat, const int64_t *pat_off, const int32_t *pat_len,
+                   const char *txt, const int64_t *txt_off, const int32_t *txt_len, int64_t n,
+                   int32_t *score_out);
+/* device buffers; slabs readable to a multiple of 4 bytes past the last sequence; synchronises `stream` */
+int gab_bitpal_run_device(gab_bitpal *h, const char *pat, int64_t pat_bytes, const int64_t *pat_off,
+                          const int32_t *pat_len, const char *txt, int64_t txt_bytes,
+                          const int64_t *txt_off, const int32_t *txt_len, int64_t n,
+                          int32_t *score_out, void *stream);
+/* last run: DP cells (pattern_length x text_length summed), pairs that took the global-scratch path,
+ * device time of the DP kernels and of the whole call (HIP events, ms) */
+int gab_bitpal_last_stats(gab_bitpal *h, int64_t *cells, int64_t *long_pairs, float *kernel_ms, float *total_ms);
+
 /* ---- wfa: gap-affine wavefront alignment with CIGAR ---------------------------------------
  * Replaces  affine_wavefronts_clear(wf); affine_wavefronts_align(wf, pattern, plen, text, tlen);
  *           + the copy of wf->edit_cigar            wfa/tools/align_benchmark.c:415-437

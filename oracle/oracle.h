@@ -61,6 +61,11 @@ void oracle_bpm_batch(const char *pat, const int64_t *pat_off, const int32_t *pa
                       const char *txt, const int64_t *txt_off, const int32_t *txt_len,
                       int64_t n, int threads, int32_t *score, int64_t *block_steps);
 
+/* ---- bitpal: see bitpal.c.  algorithm 0 = bitpal-edit (0,-1,-1), 1 = bitpal-scored (+1,-4,-2) */
+int oracle_bitpal_one(int algorithm, const char *a, int n, const char *b, int m);
+void oracle_bitpal_batch(int algorithm, const char *pat, const int64_t *pat_off, const int32_t *pat_len, const char *txt,
+                         const int64_t *txt_off, const int32_t *txt_len, int64_t n, int threads, int32_t *score);
+
 /* ---- wfa: see wfa.c.  ops = un-run-length-encoded CIGAR ('M','X','I','D'), capacity
  * pattern_length + text_length per pair; returns the number of operations. */
 typedef struct {

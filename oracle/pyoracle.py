@@ -90,6 +90,15 @@ def bpm(batch, threads=0, want_steps=False):
     return (score, st.value) if want_steps else score
 
 
+# ------------------------------------------------------------------ bitpal
+def bitpal(batch, algorithm, threads=0):
+    """algorithm 0 = bitpal-edit, 1 = bitpal-scored -> printed scores (int32)"""
+    out = np.zeros(batch.n, np.int32)
+    lib().oracle_bitpal_batch(C.c_int(algorithm), _p(batch.pat), _p(batch.pat_off), _p(batch.pat_len), _p(batch.txt),
+                              _p(batch.txt_off), _p(batch.txt_len), C.c_int64(batch.n), C.c_int(threads), _p(out))
+    return out
+
+
 # ------------------------------------------------------------------ wfa
 class WfaPenalties(C.Structure):
     _fields_ = [("mismatch", C.c_int32), ("gap_opening", C.c_int32), ("gap_extension", C.c_int32),

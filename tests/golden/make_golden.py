@@ -76,22 +76,28 @@ def make_chain(m):
 
 def make_bpm(m):
     import re
-    for name, seed, n, mode, plen in [("bpm_bench", 301, 1500, 0, 151), ("bpm_adv", 302, 2500, 1, 220)]:
-        inp = os.path.join(HERE, name + ".in.txt")
-        gabgen.write_text("bpm", inp, seed, n, mode, plen)
+
+    def run_ref(inp, alg):
         outs = []
         for t in ("1", "3"):
-            out = os.path.join(HERE, name + ".tmp")
-            subprocess.run([pyoracle.ref_path("bpm_ref"), "-a", "bpm-edit", "-i", inp, "-o", out, "-t", t],
-                           capture_output=True, check=True)
+            out = inp + ".tmp"
+            subprocess.run([pyoracle.ref_path("bpm_ref"), "-a", alg, "-i", inp, "-o", out, "-t", t], capture_output=True, check=True)
             lines = sorted(open(out).read().splitlines(), key=lambda l: int(re.match(r"\[(\d+)\]", l).group(1)))
             os.remove(out)
             outs.append(lines)
         assert outs[0] == outs[1], "bpm reference output depends on the thread count"
-        open(os.path.join(HERE, name + ".expected.txt"), "w").write("\n".join(outs[0]) + "\n")
+        return outs[0]
+
+    for name, seed, n, mode, plen in [("bpm_bench", 301, 1500, 0, 151), ("bpm_adv", 302, 2500, 1, 220)]:
+        inp = os.path.join(HERE, name + ".in.txt")
+        gabgen.write_text("bpm", inp, seed, n, mode, plen)
+        open(os.path.join(HERE, name + ".expected.txt"), "w").write("\n".join(run_ref(inp, "bpm-edit")) + "\n")
+        # the driver's other two algorithms on the same inputs
+        for alg in ("bitpal-edit", "bitpal-scored"):
+            open(os.path.join(HERE, f"{name}.{alg.replace('-', '_')}.expected.txt"), "w").write("\n".join(run_ref(inp, alg)) + "\n")
         m[name] = {"generator": "tools/gen gabgen bpm", "seed": seed, "n": n, "mode": mode, "plen": plen,
                    "reference": "bpm/tools/align_benchmark.c + bpm/{benchmark,bitpal,edit,system,utils}/*.c built by oracle/Makefile",
-                   "command": "bpm_ref -a bpm-edit -i <in> -o <out> -t 1|3 ; sort by id (as regression_small.sh:94 does)"}
+                   "command": "bpm_ref -a bpm-edit|bitpal-edit|bitpal-scored -i <in> -o <out> -t 1|3 ; sort by id (as regression_small.sh:94 does)"}
 
 
 # adaptive mode: the reduction parameters the adaptive fixtures are produced with
