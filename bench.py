@@ -372,6 +372,91 @@ class BpmWorkload:
                 "sample": f"first {n} pairs, oracle/bpm.c + OpenMP ({sec:.2f} s)"}
 
 
+# ------------------------------------------------------------------------------------- bitpal (bpm -a bitpal-scored / bitpal-edit)
+class BitpalWorkload(BpmWorkload):
+    name = "bitpal"
+    algorithm, alg_name = 1, "bitpal-scored"
+    metric = "bpm (bitpal-scored) ROI M alignments/sec"
+    dtype = "i32"
+
+    def __init__(self, items, rank, dev):
+        import torch
+        from tools import gabgen
+        from genarchbench_amd.bitpal import BitpalEngine
+        self.items = items
+        t0 = time.time()
+        raw = gabgen.pairs(self.seed, items, 0, self.plen, first=rank * items)
+        self.batch = b = raw.swapped_combined()
+        log(f"[rank {rank}] generated {items} bpm pairs in {time.time() - t0:.1f}s")
+        t = lambda a: torch.from_numpy(a).to(dev)
+        slab = t(b.pat)
+        self.d = [slab, t(b.pat_off), t(b.pat_len), slab, t(b.txt_off), t(b.txt_len)]
+        self.score = torch.empty(items, dtype=torch.int32, device=dev)
+        self.eng = BitpalEngine(self.algorithm, device=dev.index or 0)
+        self.alg_bytes = int(b.pat_len.astype(np.int64).sum() + b.txt_len.astype(np.int64).sum() + 4 * items)
+        self.kernel_ms, self.total_ms = [], []
+        self.stats = {}
+
+    def check(self):
+        from oracle import pyoracle
+        from tools import gabgen
+        got = self.score.cpu().numpy()
+        b = self.batch
+        gap = -2 if self.algorithm else -1
+        assert (got >= gap * (b.pat_len + b.txt_len)).all() and (got <= self.algorithm * np.minimum(b.pat_len, b.txt_len)).all(), "score out of bounds"
+        n = min(50000, self.items)
+        sub = gabgen.PairBatch(b.pat, b.pat_off[:n], b.pat_len[:n], b.txt, b.txt_off[:n], b.txt_len[:n])
+        assert np.array_equal(got[:n], pyoracle.bitpal(sub, self.algorithm)), "bitpal HIP output differs from the oracle"
+        return f"bit-exact vs oracle on first {n} pairs; bounds hold on all {self.items}"
+
+    def extra(self, ms_per_step):
+        k = float(np.mean(self.kernel_ms))
+        return {"dp_cells_per_step": self.stats.get("cells"), "long_pairs": self.stats.get("long_pairs"),
+                "gcups_kernel": round(self.stats.get("cells", 0) / (k * 1e6), 1),
+                # 3.5 VALU per DP cell in the ISA of bitpal_dp (2 per cell + 6 per four columns) against 256 CUs x 4 SIMDs
+                # issuing one wave64 VALU instruction every 4 cycles at 2.4 GHz
+                "valu_issue_frac_est": round(self.stats.get("cells", 0) * 3.5 / 64 / (k * 1e-3) / (256 * 2.4e9), 3),
+                "dominant_kernel": "bitpal_dp", "dominant_kernel_ms": k, "device_total_ms": float(np.mean(self.total_ms))}
+
+    def roofline(self):
+        k = float(np.mean(self.kernel_ms))
+        ach = self.alg_bytes / (k * 1e-3) / 1e9
+        return {"bound": "hbm", "achieved": round(ach, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(ach / HBM_PEAK_GBS, 6), "traffic": None,
+                "note": "plen+tlen+4 B per pair vs 3.5 integer VALU per DP cell (22.8 k cells per 151-bp pair): VALU-issue bound, see extra.valu_issue_frac_est"}
+
+    def cpu_baseline(self, cores):
+        from oracle import pyoracle
+        from tools import gabgen
+        exe = pyoracle.ref_path("bpm_ref")
+        n = min(self.items, 500_000)
+        if exe:
+            with tempfile.TemporaryDirectory() as td:
+                p = os.path.join(td, "bpm.txt")
+                gabgen.write_text("bpm", p, self.seed, n, 0, self.plen)
+                env = dict(os.environ, OMP_PROC_BIND="true", OMP_PLACES="cores")
+                r = subprocess.run([exe, "-a", self.alg_name, "-i", p, "-t", str(cores)], capture_output=True, text=True, env=env)
+                m = re.search(r"Time.Benchmark\s+([\d.]+) (ms|s|us)", r.stderr)
+                if r.returncode == 0 and m:
+                    sec = float(m.group(1)) * {"s": 1.0, "ms": 1e-3, "us": 1e-6}[m.group(2)]
+                    return {"value": round(n / sec / 1e6, 4), "unit": self.unit, "cores": cores, "kind": "reference",
+                            "sample": f"first {n} pairs of the same seeded input, reference align_benchmark -a {self.alg_name} "
+                                      f"-t {cores}, its own Time.Benchmark ({sec:.2f} s)"}
+                log("reference binary failed, using the oracle port:", r.stderr[-200:])
+        b = self.batch
+        n = min(self.items, 200_000)
+        sub = gabgen.PairBatch(b.pat, b.pat_off[:n], b.pat_len[:n], b.txt, b.txt_off[:n], b.txt_len[:n])
+        t0 = time.time(); pyoracle.bitpal(sub, self.algorithm, threads=cores); sec = time.time() - t0
+        return {"value": round(n / sec / 1e6, 4), "unit": self.unit, "cores": cores, "kind": "port",
+                "sample": f"first {n} pairs, oracle/bitpal.c + OpenMP ({sec:.2f} s)"}
+
+
+class BitpalEditWorkload(BitpalWorkload):
+    name = "bitpal-edit"
+    algorithm, alg_name = 0, "bitpal-edit"
+    metric = "bpm (bitpal-edit) ROI M alignments/sec"
+
+
 # ------------------------------------------------------------------------------------- wfa
 class WfaWorkload:
     name = "wfa"
@@ -776,7 +861,7 @@ class ParseBswWorkload:
         return {"value": None, "unit": self.unit, "cores": 1, "kind": "port", "sample": "driver binary not available"}
 
 
-WORKLOADS = {"parse-bsw": ParseBswWorkload, "fmi": FmiWorkload, "fmi-sa": FmiSaWorkload, "wfa": WfaWorkload, "bpm": BpmWorkload, "bsw": BswWorkload, "chain": ChainWorkload, "fast-chain": FastChainWorkload}
+WORKLOADS = {"bitpal": BitpalWorkload, "bitpal-edit": BitpalEditWorkload, "parse-bsw": ParseBswWorkload, "fmi": FmiWorkload, "fmi-sa": FmiSaWorkload, "wfa": WfaWorkload, "bpm": BpmWorkload, "bsw": BswWorkload, "chain": ChainWorkload, "fast-chain": FastChainWorkload}
 
 
 def main():

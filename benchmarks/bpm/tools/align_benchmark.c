@@ -2,13 +2,13 @@
  *
  * Command line, input format, output lines and the timing line the harness greps are those of
  * /root/reference/benchmarks/bpm/tools/align_benchmark.c:
- *     align_benchmark -a bpm-edit -i <input> [-o <output>] [-t <threads>] [-g <gpus>]
+ *     align_benchmark -a bpm-edit|bitpal-edit|bitpal-scored -i <input> [-o <output>] [-t <threads>] [-g <gpus>]
  * output "[id] score=%d" per pair (the harness sorts by id, bpm/scripts/regression_small.sh:94), stderr
  * "[Benchmark]", "=> Total.reads", "=> Time.Benchmark" formatted like timer_print
- * (bpm/system/profiler_timer.c:110-175).  Only -a bpm-edit is implemented (the regression scripts use
- * nothing else); the BitPAl variants are reported as unsupported.
+ * (bpm/system/profiler_timer.c:110-175).
  * The per-pair ROI call benchmark_edit_bpm (align_benchmark.c:243-257) becomes gab_bpm_run on chunks of
- * pairs, one host thread per GPU.  The driver applies the reference's swap: the longer line is the pattern.
+ * pairs, one host thread per GPU; benchmark_bitpal_m0_x1_g1 / _m1_x4_g2 (-a bitpal-edit / bitpal-scored, :259-264)
+ * become gab_bitpal_run the same way.  The driver applies the reference's swap: the longer line is the pattern.
  */
 #include "../../common/gab_pairs.h"
 #include <getopt.h>
@@ -18,15 +18,27 @@ typedef struct {
     const gab_pairs *p;
     int64_t *poff, *toff; int32_t *plen, *tlen;
     int32_t *score;
+    int bitpal;                  /* -1: bpm-edit, else GAB_BITPAL_EDIT / GAB_BITPAL_SCORED */
 } bpm_ctx;
-static void *gpu_init(int gpu, void *c) { (void)c; gab_bpm *h = NULL; GAB_DIE_IF(gab_bpm_create(gpu, &h), "gab_bpm_create"); return h; }
-static void gpu_fini(int gpu, void *c, void *st) { (void)gpu; (void)c; gab_bpm_destroy((gab_bpm *)st); }
+static void *gpu_init(int gpu, void *vc) {
+    bpm_ctx *c = (bpm_ctx *)vc;
+    if (c->bitpal >= 0) { gab_bitpal *h = NULL; GAB_DIE_IF(gab_bitpal_create(c->bitpal, gpu, &h), "gab_bitpal_create"); return h; }
+    gab_bpm *h = NULL; GAB_DIE_IF(gab_bpm_create(gpu, &h), "gab_bpm_create"); return h;
+}
+static void gpu_fini(int gpu, void *vc, void *st) {
+    (void)gpu;
+    if (((bpm_ctx *)vc)->bitpal >= 0) gab_bitpal_destroy((gab_bitpal *)st); else gab_bpm_destroy((gab_bpm *)st);
+}
 static void run_chunk(int gpu, int64_t chunk, void *vctx, void *st) {
     (void)gpu;
     bpm_ctx *c = (bpm_ctx *)vctx;
     const int64_t b = chunk * CHUNK_PAIRS, e = b + CHUNK_PAIRS < c->p->n ? b + CHUNK_PAIRS : c->p->n;
-    GAB_DIE_IF(gab_bpm_run((gab_bpm *)st, c->p->slab, c->poff + b, c->plen + b, c->p->slab, c->toff + b, c->tlen + b, e - b,
-                           c->score + b), "gab_bpm_run");
+    if (c->bitpal >= 0)
+        GAB_DIE_IF(gab_bitpal_run((gab_bitpal *)st, c->p->slab, c->poff + b, c->plen + b, c->p->slab, c->toff + b, c->tlen + b, e - b,
+                                  c->score + b), "gab_bitpal_run");
+    else
+        GAB_DIE_IF(gab_bpm_run((gab_bpm *)st, c->p->slab, c->poff + b, c->plen + b, c->p->slab, c->toff + b, c->tlen + b, e - b,
+                               c->score + b), "gab_bpm_run");
 }
 static void timer_print_like(FILE *f, double sec) {
     const double ns = sec * 1e9;
@@ -56,13 +68,16 @@ int main(int argc, char **argv) {
             case 't': threads = atoi(optarg); break;
             case 'g': gpus = atoi(optarg); break;
             case 'P': case 'v': break;
-            case 'h': fprintf(stderr, "USE: ./align_benchmark -a bpm-edit -i <input> [-o <output>] [-t <threads>] [-g <gpus>]\n"); exit(1);
+            case 'h': fprintf(stderr, "USE: ./align_benchmark -a bpm-edit|bitpal-edit|bitpal-scored -i <input> [-o <output>] [-t <threads>] [-g <gpus>]\n"); exit(1);
             default: fprintf(stderr, "Option not recognized\n"); exit(1);
         }
     }
     (void)threads;
     if (!algo) { fprintf(stderr, "Option --algorithm is required \n"); exit(1); }
-    if (strcmp(algo, "bpm-edit") != 0) { fprintf(stderr, "Algorithm '%s' is not available in the MI355X driver (only bpm-edit)\n", algo); exit(1); }
+    int bitpal = -1;                             /* align_benchmark.c:330-338 */
+    if (strcmp(algo, "bitpal-edit") == 0) bitpal = GAB_BITPAL_EDIT;
+    else if (strcmp(algo, "bitpal-scored") == 0) bitpal = GAB_BITPAL_SCORED;
+    else if (strcmp(algo, "bpm-edit") != 0) { fprintf(stderr, "Algorithm '%s' not recognized\n", algo); exit(1); }
     if (!input) { fprintf(stderr, "Option --input is required \n"); exit(1); }
     FILE *in = fopen(input, "r");
     if (!in) { fprintf(stderr, "Input file '%s' couldn't be opened\n", input); exit(1); }
@@ -78,14 +93,19 @@ int main(int argc, char **argv) {
         if (whole && fread(whole, 1, (size_t)fsz, in) == (size_t)fsz && gab_parser_create(0, &ps) == 0 &&
             gab_pairs_parse(ps, whole, fsz, 1, &pk, NULL) == 0) {
             free(whole); fclose(in);
-            gab_bpm *h = NULL;
-            GAB_DIE_IF(gab_bpm_create(0, &h), "gab_bpm_create");
+            gab_bpm *h = NULL; gab_bitpal *hb = NULL;
+            if (bitpal >= 0) GAB_DIE_IF(gab_bitpal_create(bitpal, 0, &hb), "gab_bitpal_create");
+            else GAB_DIE_IF(gab_bpm_create(0, &h), "gab_bpm_create");
             int32_t *d_score = NULL, *sc = (int32_t *)malloc(4 * (size_t)pk.n + 4);
             GAB_DIE_IF(gab_device_alloc(0, 4 * (size_t)pk.n + 4, (void **)&d_score), "gab_device_alloc");
             const double t0g = gab_now();
             gab_roi_begin();
-            GAB_DIE_IF(gab_bpm_run_device(h, pk.d_text, pk.text_bytes, pk.d_pat_off, pk.d_pat_len, pk.d_text, pk.text_bytes, pk.d_txt_off,
-                                          pk.d_txt_len, pk.n, d_score, NULL), "gab_bpm_run_device");
+            if (bitpal >= 0)
+                GAB_DIE_IF(gab_bitpal_run_device(hb, pk.d_text, pk.text_bytes, pk.d_pat_off, pk.d_pat_len, pk.d_text, pk.text_bytes,
+                                                 pk.d_txt_off, pk.d_txt_len, pk.n, d_score, NULL), "gab_bitpal_run_device");
+            else
+                GAB_DIE_IF(gab_bpm_run_device(h, pk.d_text, pk.text_bytes, pk.d_pat_off, pk.d_pat_len, pk.d_text, pk.text_bytes, pk.d_txt_off,
+                                              pk.d_txt_len, pk.n, d_score, NULL), "gab_bpm_run_device");
             GAB_DIE_IF(gab_device_copy_to_host(0, sc, d_score, 4 * (size_t)pk.n), "gab_device_copy_to_host");
             gab_roi_end();
             const double secg = gab_now() - t0g;
@@ -94,7 +114,7 @@ int main(int argc, char **argv) {
             fprintf(stderr, "=> Total.reads            %ld\n", (long)pk.n);
             fprintf(stderr, "=> Time.Benchmark      ");
             timer_print_like(stderr, secg);
-            gab_device_free(0, d_score); gab_bpm_destroy(h); gab_parser_destroy(ps); free(sc);
+            gab_device_free(0, d_score); gab_bpm_destroy(h); gab_bitpal_destroy(hb); gab_parser_destroy(ps); free(sc);
             return 0;
         }
         fprintf(stderr, "GPU parser declined the file (%s); using the getline parser\n", gab_last_error());
@@ -106,7 +126,7 @@ int main(int argc, char **argv) {
     gab_pairs_read(in, &p);
     fclose(in);
     bpm_ctx ctx;
-    ctx.p = &p;
+    ctx.p = &p; ctx.bitpal = bitpal;
     ctx.poff = (int64_t *)malloc(8 * (size_t)p.n + 8); ctx.toff = (int64_t *)malloc(8 * (size_t)p.n + 8);
     ctx.plen = (int32_t *)malloc(4 * (size_t)p.n + 4); ctx.tlen = (int32_t *)malloc(4 * (size_t)p.n + 4);
     ctx.score = (int32_t *)malloc(4 * (size_t)p.n + 4);

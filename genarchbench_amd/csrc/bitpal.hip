@@ -10,8 +10,10 @@
 // Mapping: BitPAl packs 63 DP columns into a machine word because a CPU core has one pair to work on; here there are
 // millions of independent pairs, so the lane, not the bit, is the unit of parallelism: ONE PAIR PER LANE, plain integer
 // DP.  The longer string is walked in chunks of 32 columns held in registers (32 scores + 32 bytes), the shorter string
-// is the row loop; the only memory state is the chunk's boundary column -- one score per row -- kept per lane in LDS as
-// int16 in [row][lane] order (conflict-free), or in a global scratch as int32 when a pair is too long for that.
+// is the row loop; the only memory state is the chunk's boundary column -- one score per row -- kept per lane in LDS in
+// [row][lane] order as ONE BYTE per row, the difference to the row above (0 .. match - 2 gap in the normalised scores
+// below), or in a global scratch as int32 when a pair is too long for that.  The byte column is what sets the occupancy:
+// 9.7 KB per wave for 151-bp pairs = 16 waves per CU (int16 scores: 8 waves and 19 % slower, profiles/r01_kernel_bounds.md).
 // The DP runs on S'[i][j] = S[i][j] - (i + j) * gap: vertical and horizontal moves then cost nothing, a diagonal move adds
 // match - 2 gap or mismatch - 2 gap, and both borders are zero, so one cell is compare / select / add / v_max3_i32 on
 // registers; per row there is one LDS read, one LDS write and a quarter of a dword load of the row string.
@@ -25,8 +27,7 @@
 namespace {
 
 constexpr int kChunk = 32;                 // DP columns per register chunk
-constexpr int kLdsRows = 1024;             // longest row string (the shorter of the pair) on the LDS path
-constexpr int kLdsCols = 16320;            // any: 0 <= S' <= min(i, j) * (match - 2 gap) <= 5 * 1024 fits int16
+constexpr int kLdsRows = 2048;             // longest row string (the shorter of the pair) on the LDS path: 128 KB of bytes per wave
 constexpr int kBigBlocks = 256;            // workgroups of the global-scratch path
 
 struct BpIO {
@@ -70,8 +71,8 @@ __global__ __launch_bounds__(256) void bitpal_classify(BpIO io, BpCounters *ct, 
             atomicMin((unsigned int *)&ct->first_bad, (unsigned int)(i + 1 > 0x7fffffff ? 0x7fffffff : i + 1));
             continue;
         }
-        const int rows = min(pl, tl), cols = max(pl, tl);
-        if (rows <= kLdsRows && cols <= kLdsCols) { list_lds[atomicAdd(&ct->n_lds, 1u)] = (uint32_t)i; ml = max(ml, rows); }
+        const int rows = min(pl, tl);
+        if (rows <= kLdsRows) { list_lds[atomicAdd(&ct->n_lds, 1u)] = (uint32_t)i; ml = max(ml, rows); }
         else { list_big[atomicAdd(&ct->n_big, 1u)] = (uint32_t)i; mb = max(mb, rows); }
     }
     for (int o = 32; o > 0; o >>= 1) { ml = max(ml, __shfl_xor(ml, o)); mb = max(mb, __shfl_xor(mb, o)); }
@@ -79,20 +80,24 @@ __global__ __launch_bounds__(256) void bitpal_classify(BpIO io, BpCounters *ct, 
 }
 
 // ---- the DP: one pair per lane ------------------------------------------------------------------------------------------
-// LDSCOL: boundary column = int16 [row][lane] in dynamic LDS, one workgroup (= one wave) per 64 pairs;
-// otherwise int32 [row][lane] in this workgroup's slice of `gcol`, workgroups stride over the groups of 64 pairs.
-template <bool LDSCOL>
+// LDSCOL: boundary column = uint8 row-to-row differences [row][lane] in dynamic LDS, one workgroup (= one wave) per 64
+// pairs; otherwise int32 scores [row][lane] in this workgroup's slice of `gcol`, workgroups stride over the groups of 64.
+// SCORED selects the scoring at compile time: the per-column diagonal increments of four columns are built as one
+// dword of bytes (SWAR), which needs the two values as constants.
+template <bool LDSCOL, bool SCORED>
 __global__ __launch_bounds__(64) void bitpal_dp(BpIO io, const uint32_t *__restrict__ list, uint32_t count, BpScore sc,
                                                 int32_t *gcol, int64_t gcol_per_block, BpCounters *ct) {
-    extern __shared__ __attribute__((aligned(16))) int16_t col_lds[];
+    extern __shared__ __attribute__((aligned(16))) uint8_t col_lds[];
     const int lane = threadIdx.x;
     int32_t *col_glb = LDSCOL ? nullptr : gcol + (int64_t)blockIdx.x * gcol_per_block;
+    // LDS: the value is the difference S'[row][.] - S'[row - 1][.]; global: the score itself
     auto col_get = [&](int row) -> int { return LDSCOL ? (int)col_lds[row * 64 + lane] : col_glb[(int64_t)row * 64 + lane]; };
     auto col_put = [&](int row, int v) {
-        if (LDSCOL) col_lds[row * 64 + lane] = (int16_t)v;
+        if (LDSCOL) col_lds[row * 64 + lane] = (uint8_t)v;
         else col_glb[(int64_t)row * 64 + lane] = v;
     };
-    const int G = sc.gap, Md = sc.match - 2 * sc.gap, Xd = sc.mismatch - 2 * sc.gap;    // diagonal increments of S'
+    // diagonal increments of S': match - 2 gap / mismatch - 2 gap = 2 / 1 (edit) and 5 / 0 (scored)
+    const int G = sc.gap;
     unsigned long long cells = 0;
     for (uint32_t g0 = blockIdx.x * 64u; g0 < count; g0 += gridDim.x * 64u) {
         const uint32_t b = g0 + (uint32_t)lane;
@@ -115,32 +120,53 @@ __global__ __launch_bounds__(64) void bitpal_dp(BpIO io, const uint32_t *__restr
             uint32_t cw[kChunk / 4];                         // the chunk's bytes of the column string; 0xff behind its end
 #pragma unroll
             for (int w = 0; w < kChunk / 4; w++) cw[w] = base + 4 * w < nc ? seq_ld4(cs, base + 4 * w, nc, 0xffu) : 0xffffffffu;
-            int H[kChunk];
+            // rows alternate between two register sets, so that "this row" never has to be copied over "previous row"
+            int Ha[kChunk], Hb[kChunk];
 #pragma unroll
-            for (int c = 0; c < kChunk; c++) H[c] = 0;                           // row 0 of S'
-            int diag = 0;                                                       // S'[0][base]
+            for (int c = 0; c < kChunk; c++) Ha[c] = 0;                          // row 0 of S'
+            int diag = 0;                                                       // S'[i - 1][base], starting with row 0
             uint32_t rw = 0;
-            for (int i = 1; i <= nr; i++) {
-                if (((i - 1) & 3) == 0) rw = seq_ld4(rs, i - 1, nr, 0u);
-                const uint32_t rc = rw & 0xffu;
-                rw >>= 8;
-                int left = col_get(i);                                          // H[i][base]
+            auto row = [&](int i, const int (&Hin)[kChunk], int (&Hout)[kChunk]) {
+                // the row's character in all four bytes (v_perm_b32 with the wave-uniform selector 0x01010101 * ((i - 1) & 3))
+                const uint32_t rc4 = __builtin_amdgcn_perm(rw, rw, (uint32_t)((i - 1) & 3) * 0x01010101u);
+                int left = LDSCOL ? diag + col_get(i) : col_get(i);             // S'[i][base]
                 const int next_diag = left;
-                const uint32_t rc4 = rc * 0x01010101u;
 #pragma unroll
-                for (int c = 0; c < kChunk; c++) {
-                    const uint32_t x = cw[c >> 2] ^ rc4;                         // zero byte = equal characters
-                    const bool eq = ((x >> (8 * (c & 3))) & 0xffu) == 0;
-                    const int up = H[c];
-                    const int h = max(diag + (eq ? Md : Xd), max(up, left));
-                    diag = up; left = h; H[c] = h;
+                for (int c4 = 0; c4 < kChunk / 4; c4++) {
+                    // four columns at a time: byte b of `inc` = the diagonal increment of column 4 c4 + b
+                    const uint32_t x = cw[c4] ^ rc4;                             // zero byte = equal characters
+                    const uint32_t nz = (((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x) >> 7;    // bit 0 of each byte: characters differ
+                    const uint32_t eq = ~nz & 0x01010101u;
+                    uint32_t inc = SCORED ? (eq << 2) + eq : eq + 0x01010101u;           // 5 or 0 / 2 or 1
+                    // keep the dword opaque: the four adds below then take their byte through SDWA (v_add_u32_sdwa ...
+                    // src1_sel:BYTE_n) instead of the compiler re-deriving each byte from `eq` with a bfe and an add
+                    asm("" : "+v"(inc));
+#pragma unroll
+                    for (int b = 0; b < 4; b++) {
+                        const int c = 4 * c4 + b;
+                        const int up = Hin[c];
+                        const int h = max(diag + (int)((inc >> (8 * b)) & 0xffu), max(up, left));
+                        diag = up; left = h; Hout[c] = h;
+                    }
                 }
-                col_put(i, H[kChunk - 1]);
+                col_put(i, LDSCOL ? Hout[kChunk - 1] - Hin[kChunk - 1] : Hout[kChunk - 1]);
                 diag = next_diag;
+            };
+            int i = 1;
+            for (; i < nr; i += 2) {
+                if (((i - 1) & 3) == 0) rw = seq_ld4(rs, i - 1, nr, 0u);
+                row(i, Ha, Hb);
+                row(i + 1, Hb, Ha);
+            }
+            if (i == nr) {
+                if (((i - 1) & 3) == 0) rw = seq_ld4(rs, i - 1, nr, 0u);
+                row(i, Ha, Hb);
+#pragma unroll
+                for (int c = 0; c < kChunk; c++) Ha[c] = Hb[c];
             }
             if (nc > base && nc <= base + kChunk) {
 #pragma unroll
-                for (int c = 0; c < kChunk; c++) ans = (c == nc - 1 - base) ? H[c] : ans;
+                for (int c = 0; c < kChunk; c++) ans = (c == nc - 1 - base) ? Ha[c] : ans;
             }
         }
         if (have) { io.score[id] = ans + (nc + nr) * G; cells += (unsigned long long)nc * (unsigned long long)nr; }
@@ -179,7 +205,8 @@ extern "C" int gab_bitpal_create(int algorithm, int device, gab_bitpal **out) {
     for (int k = 0; k < 3; k++)
         if (hipEventCreate(&h->ev[k]) != hipSuccess) { gab_set_error("hipEventCreate failed"); delete h; return GAB_EDEVICE; }
     if (hipHostMalloc((void **)&h->h_ct, sizeof(BpCounters)) != hipSuccess ||
-        hipFuncSetAttribute((const void *)bitpal_dp<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+        hipFuncSetAttribute((const void *)bitpal_dp<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+        hipFuncSetAttribute((const void *)bitpal_dp<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
         gab_set_error("gab_bitpal_create: pinned allocation / LDS attribute failed"); delete h; return GAB_EDEVICE;
     }
     *out = h;
@@ -228,10 +255,12 @@ extern "C" int gab_bitpal_run_device(gab_bitpal *h, const char *pat, int64_t pat
         return GAB_EINVAL;
     }
     const uint32_t n_lds = h->h_ct->n_lds, n_big = h->h_ct->n_big;
+    const bool scored = h->sc.match != 0;
     GAB_HIP(hipEventRecord(h->ev[1], s));
     if (n_lds) {
-        const size_t lds = (size_t)(h->h_ct->max_rows_lds + 1) * 64 * sizeof(int16_t);
-        hipLaunchKernelGGL(bitpal_dp<true>, dim3((n_lds + 63) / 64), dim3(64), lds, s, io, l_lds, n_lds, h->sc, nullptr, 0, d_ct);
+        const size_t lds = (size_t)(h->h_ct->max_rows_lds + 1) * 64;
+        auto kern = scored ? bitpal_dp<true, true> : bitpal_dp<true, false>;
+        hipLaunchKernelGGL(kern, dim3((n_lds + 63) / 64), dim3(64), lds, s, io, l_lds, n_lds, h->sc, nullptr, 0, d_ct);
         GAB_HIP(hipGetLastError());
     }
     if (n_big) {
@@ -239,7 +268,8 @@ extern "C" int gab_bitpal_run_device(gab_bitpal *h, const char *pat, int64_t pat
         const int blocks = (int)std::min<int64_t>((n_big + 63) / 64, kBigBlocks);
         rc = h->scratch.reserve((size_t)per_block * 4 * (size_t)blocks);
         if (rc) return rc;
-        hipLaunchKernelGGL(bitpal_dp<false>, dim3(blocks), dim3(64), 0, s, io, l_big, n_big, h->sc, h->scratch.as<int32_t>(),
+        auto kern = scored ? bitpal_dp<false, true> : bitpal_dp<false, false>;
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(64), 0, s, io, l_big, n_big, h->sc, h->scratch.as<int32_t>(),
                            per_block, d_ct);
         GAB_HIP(hipGetLastError());
     }

@@ -122,3 +122,17 @@ def test_wfa_driver_adaptive_flags(tmp_path):
         assert r.returncode == 0, r.stderr[-500:]
         got = sorted(open(out).read().splitlines(), key=lambda l: int(l.split()[0][3:]))
         assert "\n".join(got) + "\n" == want
+
+
+@pytest.mark.parametrize("alg", ["bitpal-edit", "bitpal-scored"])
+def test_bpm_driver_bitpal_algorithms(tmp_path, alg):
+    """-a bitpal-edit / bitpal-scored: the golden scores of the reference, through the getline path and the GPU parser"""
+    from tests.util import GOLDEN
+    exe = os.path.join(ROOT, "benchmarks", "bpm", "bin", "align_benchmark")
+    want = open(f"{GOLDEN}/bpm_adv.{alg.replace('-', '_')}.expected.txt").read()
+    for env in ({}, {"GAB_GPU_PARSE": "1", "GAB_GPUS": "1"}):
+        out = str(tmp_path / "o.txt")
+        r = subprocess.run([exe, "-a", alg, "-i", f"{GOLDEN}/bpm_adv.in.txt", "-o", out], capture_output=True, text=True,
+                           timeout=300, env=dict(os.environ, **env))
+        assert r.returncode == 0, r.stderr[-500:]
+        assert open(out).read() == want
