@@ -41,6 +41,7 @@ struct BpCounters {
     int32_t bad, first_bad;
     int32_t max_rows_lds, max_rows_big;     // longest row string per path
     uint32_t n_lds, n_big;
+    uint32_t cursors[2];                    // bitpal_scatter
     unsigned long long cells;
 };
 
@@ -57,26 +58,49 @@ __device__ __forceinline__ uint32_t seq_ld4(const char *s, int pos, int len, uin
     return w;
 }
 
-// ---- pass 0: validate, split by path ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void bitpal_classify(BpIO io, BpCounters *ct, uint32_t *list_lds, uint32_t *list_big) {
+// ---- pass 0: validate, count per path -----------------------------------------------------------------------------------
+// Counts are accumulated per lane and reduced once per wave: even one atomic per wave-iteration on a single address
+// serialises for milliseconds at 10 M pairs.  When every pair takes the LDS path (the usual case) no id list is needed at
+// all: the DP kernel then maps slot -> pair by identity.
+__device__ __forceinline__ bool bitpal_pair_ok(const BpIO &io, int64_t i) {
+    const int pl = io.pat_len[i], tl = io.txt_len[i];
+    const int64_t po = io.pat_off[i], to = io.txt_off[i];
+    return pl >= 0 && tl >= 0 && pl <= GAB_BITPAL_MAX_LEN && tl <= GAB_BITPAL_MAX_LEN && po >= 0 && to >= 0 &&
+           ((po + pl + 3) & ~3ll) <= io.pat_bytes && ((to + tl + 3) & ~3ll) <= io.txt_bytes;
+}
+
+__global__ __launch_bounds__(256) void bitpal_classify(BpIO io, BpCounters *ct) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     int ml = 0, mb = 0;
+    uint32_t n_lds = 0, n_big = 0;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < io.n; i += stride) {
-        const int pl = io.pat_len[i], tl = io.txt_len[i];
-        const int64_t po = io.pat_off[i], to = io.txt_off[i];
-        const bool ok = pl >= 0 && tl >= 0 && pl <= GAB_BITPAL_MAX_LEN && tl <= GAB_BITPAL_MAX_LEN && po >= 0 && to >= 0 &&
-                        ((po + pl + 3) & ~3ll) <= io.pat_bytes && ((to + tl + 3) & ~3ll) <= io.txt_bytes;
-        if (!ok) {
+        if (!bitpal_pair_ok(io, i)) {
             atomicAdd(&ct->bad, 1);
             atomicMin((unsigned int *)&ct->first_bad, (unsigned int)(i + 1 > 0x7fffffff ? 0x7fffffff : i + 1));
             continue;
         }
-        const int rows = min(pl, tl);
-        if (rows <= kLdsRows) { list_lds[atomicAdd(&ct->n_lds, 1u)] = (uint32_t)i; ml = max(ml, rows); }
-        else { list_big[atomicAdd(&ct->n_big, 1u)] = (uint32_t)i; mb = max(mb, rows); }
+        const int rows = min(io.pat_len[i], io.txt_len[i]);
+        if (rows <= kLdsRows) { n_lds++; ml = max(ml, rows); } else { n_big++; mb = max(mb, rows); }
     }
-    for (int o = 32; o > 0; o >>= 1) { ml = max(ml, __shfl_xor(ml, o)); mb = max(mb, __shfl_xor(mb, o)); }
-    if ((threadIdx.x & 63) == 0) { atomicMax(&ct->max_rows_lds, ml); atomicMax(&ct->max_rows_big, mb); }
+    for (int o = 32; o > 0; o >>= 1) {
+        ml = max(ml, __shfl_xor(ml, o)); mb = max(mb, __shfl_xor(mb, o));
+        n_lds += __shfl_xor(n_lds, o); n_big += __shfl_xor(n_big, o);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicMax(&ct->max_rows_lds, ml); atomicMax(&ct->max_rows_big, mb);
+        if (n_lds) atomicAdd(&ct->n_lds, n_lds);
+        if (n_big) atomicAdd(&ct->n_big, n_big);
+    }
+}
+
+// only when some pair is too long for the LDS column: the two id lists (the cursors start at zero)
+__global__ __launch_bounds__(256) void bitpal_scatter(BpIO io, uint32_t *cursors, uint32_t *list_lds, uint32_t *list_big) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < io.n; i += stride) {
+        const bool to_lds = min(io.pat_len[i], io.txt_len[i]) <= kLdsRows;
+        const uint32_t s_lds = gab_wave_slot(&cursors[0], to_lds), s_big = gab_wave_slot(&cursors[1], !to_lds);
+        if (to_lds) list_lds[s_lds] = (uint32_t)i; else list_big[s_big] = (uint32_t)i;
+    }
 }
 
 // ---- the DP: one pair per lane ------------------------------------------------------------------------------------------
@@ -106,7 +130,7 @@ __global__ __launch_bounds__(64) void bitpal_dp(BpIO io, const uint32_t *__restr
         const char *cs = nullptr, *rs = nullptr;
         uint32_t id = 0;
         if (have) {
-            id = list[b];
+            id = list ? list[b] : b;                         // no list: every pair is on this path
             const int pl = io.pat_len[id], tl = io.txt_len[id];
             const char *p = io.pat + io.pat_off[id], *t = io.txt + io.txt_off[id];
             if (pl >= tl) { nc = pl; cs = p; nr = tl; rs = t; } else { nc = tl; cs = t; nr = pl; rs = p; }
@@ -245,7 +269,7 @@ extern "C" int gab_bitpal_run_device(gab_bitpal *h, const char *pat, int64_t pat
     h->h_ct->first_bad = 0x7fffffff;
     GAB_HIP(hipMemcpyAsync(d_ct, h->h_ct, sizeof(BpCounters), hipMemcpyHostToDevice, s));
     const int grid = (int)std::min<int64_t>(gab_ceil_div(n, 256), 4096);
-    hipLaunchKernelGGL(bitpal_classify, dim3(grid), dim3(256), 0, s, io, d_ct, l_lds, l_big);
+    hipLaunchKernelGGL(bitpal_classify, dim3(grid), dim3(256), 0, s, io, d_ct);
     GAB_HIP(hipMemcpyAsync(h->h_ct, d_ct, sizeof(BpCounters), hipMemcpyDeviceToHost, s));
     GAB_HIP(hipStreamSynchronize(s));
     if (h->h_ct->bad) {
@@ -255,6 +279,8 @@ extern "C" int gab_bitpal_run_device(gab_bitpal *h, const char *pat, int64_t pat
         return GAB_EINVAL;
     }
     const uint32_t n_lds = h->h_ct->n_lds, n_big = h->h_ct->n_big;
+    if (n_big) hipLaunchKernelGGL(bitpal_scatter, dim3(grid), dim3(256), 0, s, io, d_ct->cursors, l_lds, l_big);
+    else l_lds = nullptr;
     const bool scored = h->sc.match != 0;
     GAB_HIP(hipEventRecord(h->ev[1], s));
     if (n_lds) {

@@ -60,3 +60,17 @@ struct gab_device_guard {
 int gab_check_device(int device);
 
 static inline int64_t gab_ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// Wave-aggregated "slot = (*counter)++" for the lanes with `active` set: one atomic per wave instead of one per lane
+// (10 M lanes incrementing one address take milliseconds), and consecutive lanes get consecutive slots, so a list filled
+// this way keeps the input order within a wave.  Call it from all lanes that are still in the loop.
+__device__ __forceinline__ uint32_t gab_wave_slot(uint32_t *counter, bool active) {
+    const unsigned long long m = __ballot(active);
+    if (!m) return 0;
+    const int lane = (int)(threadIdx.x & 63u);
+    const int leader = __builtin_ctzll(m);
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(m));
+    base = __shfl(base, leader);
+    return base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+}

@@ -54,6 +54,7 @@ struct WfaCounters {
     uint32_t n_lds, n_big;            // eligible pairs / pairs too long for LDS
     uint32_t n_over;                  // pairs queued by the current pass
     uint32_t pad;
+    uint32_t cursors[2];              // wfa_scatter
     unsigned long long work;          // wavefront cells computed + bases extended
 };
 
@@ -335,11 +336,14 @@ __device__ bool wfa_pair(WfStore<OffT, ADAPT> &st, const WfaPen pen, const uint8
     return true;
 }
 
-// ---- pass 0: validate, classify ------------------------------------------------------------
-__global__ __launch_bounds__(256) void wfa_classify(WfaIO io, WfaCounters *ct, uint32_t *list_lds, uint32_t *list_big) {
+// ---- pass 0: validate, count per path ------------------------------------------------------------
+// Counts are accumulated per lane and reduced once per wave (atomics of every wave-iteration on one address serialise).
+// When no pair is too long for the LDS kernels (the usual case) the first pass needs no id list: slot -> pair by identity.
+__global__ __launch_bounds__(256) void wfa_classify(WfaIO io, WfaCounters *ct) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     int mp = 0, mt = 0;
+    uint32_t n_lds = 0, n_big = 0;
     for (; i < io.n; i += stride) {
         const int pl = io.pat_len[i], tl = io.txt_len[i];
         const int64_t po = io.pat_off[i], to = io.txt_off[i];
@@ -350,13 +354,27 @@ __global__ __launch_bounds__(256) void wfa_classify(WfaIO io, WfaCounters *ct, u
             atomicMin((unsigned int *)&ct->first_bad, (unsigned int)(i + 1 > 0x7fffffff ? 0x7fffffff : i + 1));
             continue;
         }
-        if (pl <= kLdsMaxLen && tl <= kLdsMaxLen) {
-            list_lds[atomicAdd(&ct->n_lds, 1u)] = (uint32_t)i;
-            mp = max(mp, pl); mt = max(mt, tl);
-        } else list_big[atomicAdd(&ct->n_big, 1u)] = (uint32_t)i;
+        if (pl <= kLdsMaxLen && tl <= kLdsMaxLen) { n_lds++; mp = max(mp, pl); mt = max(mt, tl); } else n_big++;
     }
-    for (int o = 32; o > 0; o >>= 1) { mp = max(mp, __shfl_xor(mp, o)); mt = max(mt, __shfl_xor(mt, o)); }
-    if ((threadIdx.x & 63) == 0) { atomicMax(&ct->max_plen, mp); atomicMax(&ct->max_tlen, mt); }
+    for (int o = 32; o > 0; o >>= 1) {
+        mp = max(mp, __shfl_xor(mp, o)); mt = max(mt, __shfl_xor(mt, o));
+        n_lds += __shfl_xor(n_lds, o); n_big += __shfl_xor(n_big, o);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicMax(&ct->max_plen, mp); atomicMax(&ct->max_tlen, mt);
+        if (n_lds) atomicAdd(&ct->n_lds, n_lds);
+        if (n_big) atomicAdd(&ct->n_big, n_big);
+    }
+}
+
+// only when some pair is too long for the LDS kernels: the two id lists (the cursors start at zero)
+__global__ __launch_bounds__(256) void wfa_scatter(WfaIO io, uint32_t *cursors, uint32_t *list_lds, uint32_t *list_big) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < io.n; i += stride) {
+        const bool to_lds = io.pat_len[i] <= kLdsMaxLen && io.txt_len[i] <= kLdsMaxLen;
+        const uint32_t s_lds = gab_wave_slot(&cursors[0], to_lds), s_big = gab_wave_slot(&cursors[1], !to_lds);
+        if (to_lds) list_lds[s_lds] = (uint32_t)i; else list_big[s_big] = (uint32_t)i;
+    }
 }
 
 // ---- LDS kernel: one G-lane group per pair, 64 / G pairs per wave (= per workgroup) ----------------
@@ -373,7 +391,7 @@ __global__ __launch_bounds__(64) void wfa_lds(WfaIO io, WfaPen pen, const uint32
     bool ok = true, have = b < count;
     uint32_t id = 0;
     if (have) {
-        id = list[b];
+        id = list ? list[b] : b;                             // no list: every pair of the batch is in this pass
         uint8_t *smem = smem_all + (size_t)grp * group_bytes;
         int *dir = reinterpret_cast<int *>(smem);
         uint8_t *P = smem + (size_t)dir_cap * 4 * WfStore<int16_t, ADAPT>::kDirInts;
@@ -405,7 +423,7 @@ __global__ __launch_bounds__(64) void wfa_global(WfaIO io, WfaPen pen, const uin
     const int lane = threadIdx.x;
     int32_t *mine = scratch + (int64_t)blockIdx.x * per_block;
     for (uint32_t b = blockIdx.x; b < count; b += gridDim.x) {
-        const uint32_t id = list[b];
+        const uint32_t id = list ? list[b] : b;
         const int plen = io.pat_len[id], tlen = io.txt_len[id];
         WfStore<int32_t, ADAPT> st;
         st.dir = mine; st.pool = mine + (int64_t)dir_cap * WfStore<int32_t, ADAPT>::kDirInts; st.pool_cap = pool_cap; st.dir_cap = dir_cap; st.used = 0;
@@ -505,7 +523,7 @@ extern "C" int gab_wfa_run_device(gab_wfa *h, const char *pat, int64_t pat_bytes
     h->h_ct->first_bad = 0x7fffffff;
     GAB_HIP(hipMemcpyAsync(d_ct, h->h_ct, sizeof(WfaCounters), hipMemcpyHostToDevice, s));
     const int grid = (int)std::min<int64_t>(gab_ceil_div(n, 256), 4096);
-    hipLaunchKernelGGL(wfa_classify, dim3(grid), dim3(256), 0, s, io, d_ct, l_a, l_big);
+    hipLaunchKernelGGL(wfa_classify, dim3(grid), dim3(256), 0, s, io, d_ct);
     GAB_HIP(hipMemcpyAsync(h->h_ct, d_ct, sizeof(WfaCounters), hipMemcpyDeviceToHost, s));
     GAB_HIP(hipStreamSynchronize(s));
     if (h->h_ct->bad) {
@@ -521,7 +539,8 @@ extern "C" int gab_wfa_run_device(gab_wfa *h, const char *pat, int64_t pat_bytes
     GAB_HIP(hipEventRecord(h->ev[1], s));
     // LDS passes: (1) four pairs per wave with a 2 KB history each (scores up to ~35: the bulk of short-read pairs),
     // (2) one pair per wave with 12 KB, (3) one pair per wave with 96 KB; whatever overflows goes to global memory
-    uint32_t *cur = l_a, *nxt = l_b;
+    if (n_big) hipLaunchKernelGGL(wfa_scatter, dim3(grid), dim3(256), 0, s, io, d_ct->cursors, l_a, l_big);
+    uint32_t *cur = n_big ? l_a : nullptr, *nxt = l_b;      // nullptr: identity
     uint32_t cnt = n_lds;
     bool ev2 = false;
     const int pool_bytes[3] = {2 * 1024, 12 * 1024, 96 * 1024};
@@ -544,7 +563,8 @@ extern "C" int gab_wfa_run_device(gab_wfa *h, const char *pat, int64_t pat_bytes
         GAB_HIP(hipStreamSynchronize(s));
         cnt = h->h_ct->n_over;
         requeued += cnt;
-        std::swap(cur, nxt);
+        if (cur) std::swap(cur, nxt);
+        else { cur = nxt; nxt = l_a; }                  // the identity pass: its overflow list becomes the input
     }
     if (!ev2) GAB_HIP(hipEventRecord(h->ev[2], s));
     // pass 3+: global history; first the LDS leftovers, then the long pairs; pool grows on overflow
