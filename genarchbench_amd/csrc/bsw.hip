@@ -141,7 +141,7 @@ __global__ __launch_bounds__(64) void bsw_dp(BswIO io, BswConst c, const uint32_
                                             gab_bsw_result *__restrict__ result_out, BswStats *st) {
     extern __shared__ uint32_t lds[];
     const int lane = threadIdx.x;
-    const int64_t k = kbeg + (int64_t)blockIdx.x * 64 + lane;
+    const int64_t k = kbeg + (int64_t)(gridDim.x - 1 - blockIdx.x) * 64 + lane;   // heaviest waves (largest key) first
     const bool valid = k < kend;
     const uint32_t id = valid ? perm[k] : 0u;
 
@@ -339,7 +339,7 @@ __global__ __launch_bounds__(64) void bsw_dp8(BswIO io, BswConst c, const uint32
                                               gab_bsw_result *__restrict__ result_out, BswStats *st) {
     extern __shared__ uint32_t lds[];
     const int lane = threadIdx.x;
-    const int64_t k = kbeg + (int64_t)blockIdx.x * 64 + lane;
+    const int64_t k = kbeg + (int64_t)(gridDim.x - 1 - blockIdx.x) * 64 + lane;   // heaviest waves (largest key) first
     const bool valid = k < kend;
     const uint32_t id = valid ? perm[k] : 0u;
     const int ncell_dw = (qcap + 2) / 2;
@@ -543,6 +543,11 @@ struct gab_bsw {
     gab_devbuf ws;          // hist | start | cursor | qstart | stats | perm
     gab_devbuf io;          // staging for the host-pointer entry point
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};   // total begin, dp begin, dp end, total end
+    // the per-class DP launches rotate over the caller's stream and these, so that the draining tail of one class
+    // overlaps the next classes (fork / join with the events)
+    static constexpr int kAux = 1;        // 3 measured equal to 1
+    hipStream_t aux[kAux] = {nullptr};
+    hipEvent_t fork = nullptr, join[kAux] = {nullptr};
     bool have_stats = false;
     uint32_t *h_qstart = nullptr;   // pinned, kQBuckets + 1
     BswStats *h_stats = nullptr;    // pinned
@@ -578,6 +583,11 @@ extern "C" int gab_bsw_create(const gab_bsw_params *p, int device, gab_bsw **out
     }
     for (int k = 0; k < 4; k++)
         if (hipEventCreate(&h->ev[k]) != hipSuccess) { gab_set_error("hipEventCreate failed"); delete h; return GAB_EDEVICE; }
+    bool aux_ok = hipEventCreateWithFlags(&h->fork, hipEventDisableTiming) == hipSuccess;
+    for (int k = 0; k < gab_bsw::kAux && aux_ok; k++)
+        aux_ok = hipStreamCreateWithFlags(&h->aux[k], hipStreamNonBlocking) == hipSuccess &&
+                 hipEventCreateWithFlags(&h->join[k], hipEventDisableTiming) == hipSuccess;
+    if (!aux_ok) { gab_set_error("gab_bsw_create: stream / event creation failed"); delete h; return GAB_EDEVICE; }
     // the 256-base class needs more than the default 64 KiB of dynamic LDS
     if (hipFuncSetAttribute((const void *)bsw_dp<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
         hipFuncSetAttribute((const void *)bsw_dp<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
@@ -597,6 +607,11 @@ extern "C" void gab_bsw_destroy(gab_bsw *h) {
     gab_device_guard g(h->device);
     h->ws.release(); h->io.release();
     for (int k = 0; k < 4; k++) if (h->ev[k]) (void)hipEventDestroy(h->ev[k]);
+    if (h->fork) (void)hipEventDestroy(h->fork);
+    for (int k = 0; k < gab_bsw::kAux; k++) {
+        if (h->join[k]) (void)hipEventDestroy(h->join[k]);
+        if (h->aux[k]) (void)hipStreamDestroy(h->aux[k]);
+    }
     if (h->h_qstart) (void)hipHostFree(h->h_qstart);
     if (h->h_stats) (void)hipHostFree(h->h_stats);
     delete h;
@@ -656,11 +671,17 @@ extern "C" int gab_bsw_run_device(gab_bsw *h, const uint8_t *ref, int64_t ref_by
     const bool wide = (int64_t)h->h_stats->max_h0 + (int64_t)GAB_BSW_MAX_QLEN * h->cst.max_sc > 32767;
 
     GAB_HIP(hipEventRecord(h->ev[1], s));
-    for (int cls = 0; cls < kNumClasses; cls++) {
+    GAB_HIP(hipEventRecord(h->fork, s));
+    for (int k = 0; k < gab_bsw::kAux; k++) GAB_HIP(hipStreamWaitEvent(h->aux[k], h->fork, 0));
+    int nlaunch = 0;
+    hipStream_t s_main = s;
+    for (int cls = kNumClasses - 1; cls >= 0; cls--) {      // longest queries first: the tail of the step is made of short work
         const int64_t kb = h->h_qstart[cls * kClassStep], ke = h->h_qstart[(cls + 1) * kClassStep];
         if (ke <= kb) continue;
         const int qcap = (cls + 1) * kClassStep;
         const int blocks = (int)gab_ceil_div(ke - kb, 64);
+        s = (nlaunch % (gab_bsw::kAux + 1)) ? h->aux[nlaunch % (gab_bsw::kAux + 1) - 1] : s_main;
+        nlaunch++;
         // 8-bit cells when every H/E value of this class fits a byte: H <= h0 + qlen * max_sc
         if ((int64_t)h->h_stats->max_h0 + (int64_t)qcap * h->cst.max_sc <= 255 && h->cst.max_sc >= 0) {
             const size_t lds8 = sizeof(uint32_t) * 64 * ((size_t)(qcap + 2) / 2 + ((size_t)(qcap + 1) / 2 + 3) / 4 + 1);
@@ -676,7 +697,12 @@ extern "C" int gab_bsw_run_device(gab_bsw *h, const uint8_t *ref, int64_t ref_by
             hipLaunchKernelGGL(bsw_dp<false>, dim3(blocks), dim3(64), lds, s, io, h->cst, d_perm, kb, ke, qcap,
                                score_out, result_out, d_stats);
     }
+    s = s_main;
     GAB_HIP(hipGetLastError());
+    for (int k = 0; k < gab_bsw::kAux; k++) {
+        GAB_HIP(hipEventRecord(h->join[k], h->aux[k]));
+        GAB_HIP(hipStreamWaitEvent(s, h->join[k], 0));
+    }
     GAB_HIP(hipEventRecord(h->ev[2], s));
     GAB_HIP(hipMemcpyAsync(h->h_stats, d_stats, sizeof(BswStats), hipMemcpyDeviceToHost, s));
     GAB_HIP(hipEventRecord(h->ev[3], s));
