@@ -64,7 +64,9 @@ __device__ __forceinline__ int bsw_key(int qlen, int tlen, int h0) {
 }
 
 // ---- pass 1: validate + histogram ------------------------------------------------------
-__global__ __launch_bounds__(256) void bsw_hist(BswIO io, uint32_t *hist, BswStats *st) {
+// The value the histogram atomic returns is the pair's rank inside its bucket: it is kept, so that the scatter pass
+// needs no second round of 10 M atomics (each pass was atomic-throughput bound at ~13 G/s).
+__global__ __launch_bounds__(256) void bsw_hist(BswIO io, uint32_t *hist, uint32_t *rank, BswStats *st) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     int64_t stride = (int64_t)gridDim.x * blockDim.x;
     int mh = 0;
@@ -80,7 +82,7 @@ __global__ __launch_bounds__(256) void bsw_hist(BswIO io, uint32_t *hist, BswSta
             continue;
         }
         mh = h > mh ? h : mh;
-        atomicAdd(&hist[bsw_key(ql, tl, h)], 1u);
+        rank[i] = atomicAdd(&hist[bsw_key(ql, tl, h)], 1u);
     }
     // wave max of h0, one atomic per wave
     for (int o = 32; o > 0; o >>= 1) { int v = __shfl_xor(mh, o); mh = v > mh ? v : mh; }
@@ -114,14 +116,14 @@ __global__ __launch_bounds__(1024) void bsw_scan(const uint32_t *hist, uint32_t 
 }
 
 // ---- pass 3: scatter pair ids into bucket order -------------------------------------------
-__global__ __launch_bounds__(256) void bsw_scatter(BswIO io, uint32_t *cursor, uint32_t *perm) {
+__global__ __launch_bounds__(256) void bsw_scatter(BswIO io, const uint32_t *__restrict__ start, const uint32_t *__restrict__ rank,
+                                                   uint32_t *perm) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (; i < io.n; i += stride) {
         int ql = io.len2[i], tl = io.len1[i];
         if (ql < 1 || ql > GAB_BSW_MAX_QLEN || tl < 1 || tl > GAB_BSW_MAX_TLEN) continue;
-        uint32_t pos = atomicAdd(&cursor[bsw_key(ql, tl, io.h0[i])], 1u);
-        perm[pos] = (uint32_t)i;
+        perm[start[bsw_key(ql, tl, io.h0[i])] + rank[i]] = (uint32_t)i;
     }
 }
 
@@ -540,7 +542,7 @@ struct gab_bsw {
     int device = 0;
     gab_bsw_params prm;
     BswConst cst;
-    gab_devbuf ws;          // hist | start | cursor | qstart | stats | perm
+    gab_devbuf ws;          // hist | start | cursor | qstart | stats | perm | rank
     gab_devbuf io;          // staging for the host-pointer entry point
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};   // total begin, dp begin, dp end, total end
     // the per-class DP launches rotate over the caller's stream and these, so that the draining tail of one class
@@ -637,13 +639,14 @@ extern "C" int gab_bsw_run_device(gab_bsw *h, const uint8_t *ref, int64_t ref_by
     const size_t o_qstart = o_cursor + sizeof(uint32_t) * (kNumKeys + 1);
     const size_t o_stats = (o_qstart + sizeof(uint32_t) * (kQBuckets + 1) + 15) & ~(size_t)15;
     const size_t o_perm = (o_stats + sizeof(BswStats) + 255) & ~(size_t)255;
-    int rc = h->ws.reserve(o_perm + sizeof(uint32_t) * (size_t)n);
+    const size_t o_rank = o_perm + ((sizeof(uint32_t) * (size_t)n + 255) & ~(size_t)255);
+    int rc = h->ws.reserve(o_rank + sizeof(uint32_t) * (size_t)n);
     if (rc) return rc;
     char *base = h->ws.as<char>();
     uint32_t *d_hist = (uint32_t *)(base + o_hist), *d_start = (uint32_t *)(base + o_start);
     uint32_t *d_cursor = (uint32_t *)(base + o_cursor), *d_qstart = (uint32_t *)(base + o_qstart);
     BswStats *d_stats = (BswStats *)(base + o_stats);
-    uint32_t *d_perm = (uint32_t *)(base + o_perm);
+    uint32_t *d_perm = (uint32_t *)(base + o_perm), *d_rank = (uint32_t *)(base + o_rank);
 
     BswIO io{ref, ref_off, qry, qry_off, len1, len2, h0, ref_bytes, qry_bytes, n};
     GAB_HIP(hipEventRecord(h->ev[0], s));
@@ -655,9 +658,9 @@ extern "C" int gab_bsw_run_device(gab_bsw *h, const uint8_t *ref, int64_t ref_by
         GAB_HIP(hipMemcpyAsync(d_stats, h->h_stats, sizeof(BswStats), hipMemcpyHostToDevice, s));
     }
     int grid = (int)(gab_ceil_div(n, 256) < 4096 ? gab_ceil_div(n, 256) : 4096);
-    hipLaunchKernelGGL(bsw_hist, dim3(grid), dim3(256), 0, s, io, d_hist, d_stats);
+    hipLaunchKernelGGL(bsw_hist, dim3(grid), dim3(256), 0, s, io, d_hist, d_rank, d_stats);
     hipLaunchKernelGGL(bsw_scan, dim3(1), dim3(1024), 0, s, d_hist, d_start, d_cursor, d_qstart);
-    hipLaunchKernelGGL(bsw_scatter, dim3(grid), dim3(256), 0, s, io, d_cursor, d_perm);
+    hipLaunchKernelGGL(bsw_scatter, dim3(grid), dim3(256), 0, s, io, d_start, d_rank, d_perm);
     GAB_HIP(hipMemcpyAsync(h->h_qstart, d_qstart, sizeof(uint32_t) * (kQBuckets + 1), hipMemcpyDeviceToHost, s));
     GAB_HIP(hipMemcpyAsync(h->h_stats, d_stats, sizeof(BswStats), hipMemcpyDeviceToHost, s));
     GAB_HIP(hipStreamSynchronize(s));   // launch geometry of the DP depends on the class sizes
