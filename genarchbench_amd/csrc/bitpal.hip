@@ -268,7 +268,7 @@ extern "C" int gab_bitpal_run_device(gab_bitpal *h, const char *pat, int64_t pat
     memset(h->h_ct, 0, sizeof(BpCounters));
     h->h_ct->first_bad = 0x7fffffff;
     GAB_HIP(hipMemcpyAsync(d_ct, h->h_ct, sizeof(BpCounters), hipMemcpyHostToDevice, s));
-    const int grid = (int)std::min<int64_t>(gab_ceil_div(n, 256), 4096);
+    const int grid = (int)std::min<int64_t>(gab_ceil_div(n, 256), 1024);
     hipLaunchKernelGGL(bitpal_classify, dim3(grid), dim3(256), 0, s, io, d_ct);
     GAB_HIP(hipMemcpyAsync(h->h_ct, d_ct, sizeof(BpCounters), hipMemcpyDeviceToHost, s));
     GAB_HIP(hipStreamSynchronize(s));
