@@ -340,7 +340,8 @@ class BpmWorkload:
     def extra(self, ms_per_step):
         return {"block_steps_per_step": self.stats.get("block_steps"), "full_path_pairs": self.stats.get("full_pairs"),
                 "g_block_steps_per_s": round(self.stats.get("block_steps", 0) / (ms_per_step * 1e6), 2),
-                "dominant_kernel": "bpm_score<3>", "dominant_kernel_ms": float(np.mean(self.kernel_ms)),
+                "dominant_kernel": "bpm_score<3> (+ bpm_band<3> of the previous slice on a second stream)",
+                "dominant_kernel_ms": float(np.mean(self.kernel_ms)),
                 "device_total_ms": float(np.mean(self.total_ms))}
 
     def roofline(self):

@@ -36,6 +36,7 @@ namespace {
 constexpr int kMaxRegW = 4;                 // W classes kept in registers
 constexpr int kClasses = kMaxRegW + 1;      // class c = W for W <= 4, class 0 = W > 4
 constexpr int kBlock = 256;
+constexpr int kSlices = 8;                  // a class is scored in slices; the band kernel of slice k overlaps the score kernel of slice k + 1
 constexpr int kBandRows = 8;                // rows kept per column by the LDS band kernel ({Pv, Mv} bits: one u16 per column)
 
 struct BpmIO {
@@ -47,7 +48,8 @@ struct BpmIO {
 struct BpmCounters {        // device-side, zeroed per run
     uint32_t cls_count[8];  // pairs per W class (index = class)
     uint32_t cls_cursor[8];
-    uint32_t wl_count[8];   // queued (unclean) pairs per class
+    uint32_t wl_count[8];   // queued (unclean) pairs per class (host-side sum of the slices, for the stats)
+    uint32_t wl_slice[8][kSlices];   // ... per class and slice: written by bpm_score, read by bpm_band on the device
     uint32_t wl2_count[8];  // pairs whose backtrace left the 64-row window (re-run with the full history)
     uint32_t wl1_count[8];  // pairs whose backtrace left the 8-row LDS band (re-run with the 64-row window)
     int32_t max_tlen[8];    // longest text per class (sizes the LDS band)
@@ -201,7 +203,7 @@ __device__ __forceinline__ bool bpm_build_peq(uint64_t *peq, const char *p, int 
 template <int W>
 __global__ __launch_bounds__(kBlock) void bpm_score(BpmIO io, const uint32_t *__restrict__ perm, uint32_t kbeg,
                                                     uint32_t kend, int32_t *__restrict__ score_out,
-                                                    uint32_t *__restrict__ worklist, BpmCounters *ct) {
+                                                    uint32_t *__restrict__ worklist, uint32_t *wl_counter, BpmCounters *ct) {
     __shared__ uint64_t peq_s[(4 * W + 1) * kBlock];
     const uint32_t k = kbeg + blockIdx.x * kBlock + threadIdx.x;
     unsigned long long steps = 0;
@@ -252,7 +254,7 @@ __global__ __launch_bounds__(kBlock) void bpm_score(BpmIO io, const uint32_t *__
         if (q) {
             const int leader = __builtin_ctzll(q);
             uint32_t base = 0;
-            if ((int)(threadIdx.x & 63) == leader) base = atomicAdd(&ct->wl_count[W], (uint32_t)__popcll(q));
+            if ((int)(threadIdx.x & 63) == leader) base = atomicAdd(wl_counter, (uint32_t)__popcll(q));
             base = __shfl(base, leader);
             if (queue_id >= 0) worklist[base + (uint32_t)__popcll(q & ((1ull << (threadIdx.x & 63)) - 1))] = (uint32_t)queue_id;
         }
@@ -269,11 +271,16 @@ __global__ __launch_bounds__(kBlock) void bpm_score(BpmIO io, const uint32_t *__
 // latency on 1.4 M pairs).  A backtrace that drifts more than 3 rows off the diagonal is queued for bpm_win.
 // dynamic LDS: [ (4W+1) x 64 masks (u64) ][ (cols) x 64 u16 ]
 template <int W>
-__global__ __launch_bounds__(64) void bpm_band(BpmIO io, const uint32_t *__restrict__ list, uint32_t nslots, int cols,
+// The grid covers the whole slice (launched right behind the slice's score kernel, without a host round trip); the number
+// of queued pairs is read on the device and the workgroups behind it leave at once (a capped grid striding over the slots
+// was measured 3 % slower).
+__global__ __launch_bounds__(64) void bpm_band(BpmIO io, const uint32_t *__restrict__ list, const uint32_t *__restrict__ nslots_ptr, int cols,
                                                int32_t *__restrict__ score_out, uint32_t *__restrict__ miss_list,
                                                BpmCounters *ct) {
     extern __shared__ uint64_t band_smem[];
     const int lane = threadIdx.x;
+    const uint32_t nslots = *nslots_ptr;
+    if (blockIdx.x * 64u >= nslots) return;
     const uint32_t s = blockIdx.x * 64 + lane;
     int64_t miss_id = -1;
     unsigned long long steps = 0;
@@ -516,6 +523,8 @@ struct gab_bpm {
     gab_devbuf io;          // staging for the host-pointer entry point
     size_t scratch_budget = (size_t)8 << 30;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipStream_t aux = nullptr;     // the band kernels run here, each behind its slice's score kernel
+    hipEvent_t fork = nullptr, join = nullptr, scored[kSlices] = {};
     BpmCounters *h_ct = nullptr;   // pinned
     bool have_stats = false;
     int64_t last_full = 0;
@@ -532,6 +541,16 @@ extern "C" int gab_bpm_create(int device, gab_bpm **out) {
     h->device = device;
     for (int k = 0; k < 4; k++)
         if (hipEventCreate(&h->ev[k]) != hipSuccess) { gab_set_error("hipEventCreate failed"); delete h; return GAB_EDEVICE; }
+    // (a high-priority stream for the band kernels was measured 5 % slower: it starves the score kernel)
+    if (hipStreamCreateWithFlags(&h->aux, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&h->fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->join, hipEventDisableTiming) != hipSuccess) {
+        gab_set_error("gab_bpm_create: stream / event creation failed"); delete h; return GAB_EDEVICE;
+    }
+    for (int k = 0; k < kSlices; k++)
+        if (hipEventCreateWithFlags(&h->scored[k], hipEventDisableTiming) != hipSuccess) {
+            gab_set_error("gab_bpm_create: event creation failed"); delete h; return GAB_EDEVICE;
+        }
     if (hipFuncSetAttribute((const void *)bpm_band<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
         hipFuncSetAttribute((const void *)bpm_band<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
         hipFuncSetAttribute((const void *)bpm_band<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
@@ -550,15 +569,32 @@ extern "C" void gab_bpm_destroy(gab_bpm *h) {
     gab_device_guard g(h->device);
     h->ws.release(); h->scratch.release(); h->io.release();
     for (int k = 0; k < 4; k++) if (h->ev[k]) (void)hipEventDestroy(h->ev[k]);
+    if (h->fork) (void)hipEventDestroy(h->fork);
+    if (h->join) (void)hipEventDestroy(h->join);
+    for (int k = 0; k < kSlices; k++) if (h->scored[k]) (void)hipEventDestroy(h->scored[k]);
+    if (h->aux) (void)hipStreamDestroy(h->aux);
     if (h->h_ct) (void)hipHostFree(h->h_ct);
     delete h;
 }
 
 template <int W>
 static void launch_score(hipStream_t s, const BpmIO &io, const uint32_t *perm, uint32_t kb, uint32_t ke, int32_t *score,
-                         uint32_t *wl, BpmCounters *ct) {
+                         uint32_t *wl, uint32_t *wl_counter, BpmCounters *ct) {
     if (ke <= kb) return;
-    hipLaunchKernelGGL(bpm_score<W>, dim3((ke - kb + kBlock - 1) / kBlock), dim3(kBlock), 0, s, io, perm, kb, ke, score, wl, ct);
+    hipLaunchKernelGGL(bpm_score<W>, dim3((ke - kb + kBlock - 1) / kBlock), dim3(kBlock), 0, s, io, perm, kb, ke, score, wl,
+                       wl_counter, ct);
+}
+// the score kernel of one slice on `s`, its band kernel on `sb` behind the event
+template <int W>
+static int launch_slice(hipStream_t s, hipStream_t sb, hipEvent_t scored, const BpmIO &io, const uint32_t *perm, uint32_t kb,
+                        uint32_t ke, int32_t *score, uint32_t *wl, uint32_t *wl_counter, int cols, uint32_t *wl1, BpmCounters *ct) {
+    if (ke <= kb) return GAB_OK;
+    launch_score<W>(s, io, perm, kb, ke, score, wl, wl_counter, ct);
+    GAB_HIP(hipEventRecord(scored, s));
+    GAB_HIP(hipStreamWaitEvent(sb, scored, 0));
+    const size_t lds = sizeof(uint64_t) * 64 * (4 * W + 1) + sizeof(uint16_t) * 64 * (size_t)cols;
+    hipLaunchKernelGGL(bpm_band<W>, dim3((ke - kb + 63) / 64), dim3(64), lds, sb, io, wl, wl_counter, cols, score, wl1, ct);
+    return GAB_OK;
 }
 template <int W>
 static void launch_full(hipStream_t s, const BpmIO &io, const uint32_t *list, uint32_t nslots, uint64_t *hist,
@@ -617,40 +653,45 @@ extern "C" int gab_bpm_run_device(gab_bpm *h, const char *pat, int64_t pat_bytes
     if (!identity) hipLaunchKernelGGL(bpm_scatter, dim3(grid), dim3(256), 0, s, io, d_ct, d_perm);
     const uint32_t *perm_arg = identity ? nullptr : d_perm;
 
-    // score path; worklist of class W occupies d_wl[cstart[W] ..)
+    // score path + stage 0 of the queued (unclean) pairs (8-row band in LDS).  The worklist of class W occupies
+    // d_wl[cstart[W] ..); a class is cut into kSlices slices whose score kernels run back to back on the caller's stream
+    // while each slice's band kernel runs on h->aux behind an event: the latency-bound band kernel (2.7 of 7.9 ms, 23 %
+    // VALU busy on its own) then runs underneath the VALU-bound score kernel of the next slice and only the last
+    // slice's band is exposed.  Pairs whose backtrace leaves the band are queued once more (64-row window), and from
+    // there to complete columns.
     GAB_HIP(hipEventRecord(h->ev[1], s));
-    launch_score<1>(s, io, perm_arg, cstart[1], cstart[1] + ccount[1], score_out, d_wl + cstart[1], d_ct);
-    launch_score<2>(s, io, perm_arg, cstart[2], cstart[2] + ccount[2], score_out, d_wl + cstart[2], d_ct);
-    launch_score<3>(s, io, perm_arg, cstart[3], cstart[3] + ccount[3], score_out, d_wl + cstart[3], d_ct);
-    launch_score<4>(s, io, perm_arg, cstart[4], cstart[4] + ccount[4], score_out, d_wl + cstart[4], d_ct);
+    GAB_HIP(hipEventRecord(h->fork, s));
+    GAB_HIP(hipStreamWaitEvent(h->aux, h->fork, 0));
+    for (int W = 1; W <= kMaxRegW; W++) {
+        if (!ccount[W]) continue;
+        const int nsl = ccount[W] >= (1u << 18) ? kSlices : 1;
+        const uint32_t per = ((ccount[W] + nsl - 1) / nsl + kBlock - 1) / kBlock * kBlock;
+        const int cols = h->h_ct->max_tlen[W] + 1;
+        for (int k = 0; k < nsl; k++) {
+            const uint32_t kb = cstart[W] + std::min<uint32_t>(ccount[W], (uint32_t)k * per);
+            const uint32_t ke = cstart[W] + std::min<uint32_t>(ccount[W], (uint32_t)(k + 1) * per);
+            uint32_t *wl = d_wl + kb, *cnt = &d_ct->wl_slice[W][k], *wl1 = d_wl1 + cstart[W];
+            switch (W) {
+                case 1: rc = launch_slice<1>(s, h->aux, h->scored[k], io, perm_arg, kb, ke, score_out, wl, cnt, cols, wl1, d_ct); break;
+                case 2: rc = launch_slice<2>(s, h->aux, h->scored[k], io, perm_arg, kb, ke, score_out, wl, cnt, cols, wl1, d_ct); break;
+                case 3: rc = launch_slice<3>(s, h->aux, h->scored[k], io, perm_arg, kb, ke, score_out, wl, cnt, cols, wl1, d_ct); break;
+                default: rc = launch_slice<4>(s, h->aux, h->scored[k], io, perm_arg, kb, ke, score_out, wl, cnt, cols, wl1, d_ct); break;
+            }
+            if (rc) return rc;
+        }
+    }
     GAB_HIP(hipGetLastError());
+    GAB_HIP(hipEventRecord(h->join, h->aux));
+    GAB_HIP(hipStreamWaitEvent(s, h->join, 0));
     GAB_HIP(hipEventRecord(h->ev[2], s));
-    GAB_HIP(hipMemcpyAsync(h->h_ct, d_ct, sizeof(BpmCounters), hipMemcpyDeviceToHost, s));
-    GAB_HIP(hipStreamSynchronize(s));
 
-    // queued (unclean) pairs: first the windowed history; pairs whose backtrace leaves the window are queued once
-    // more and get complete columns
     int64_t nfull = 0;
     {
-        // stage 0: 8-row band in LDS
-        for (int W = 1; W <= kMaxRegW; W++) {
-            const uint32_t cnt = h->h_ct->wl_count[W];
-            if (!cnt) continue;
-            nfull += cnt;
-            const int cols = h->h_ct->max_tlen[W] + 1;
-            const size_t lds = sizeof(uint64_t) * 64 * (4 * W + 1) + sizeof(uint16_t) * 64 * (size_t)cols;
-            const dim3 g((cnt + 63) / 64), blk(64);
-            const uint32_t *list = d_wl + cstart[W];
-            switch (W) {
-                case 1: hipLaunchKernelGGL(bpm_band<1>, g, blk, lds, s, io, list, cnt, cols, score_out, d_wl1 + cstart[W], d_ct); break;
-                case 2: hipLaunchKernelGGL(bpm_band<2>, g, blk, lds, s, io, list, cnt, cols, score_out, d_wl1 + cstart[W], d_ct); break;
-                case 3: hipLaunchKernelGGL(bpm_band<3>, g, blk, lds, s, io, list, cnt, cols, score_out, d_wl1 + cstart[W], d_ct); break;
-                default: hipLaunchKernelGGL(bpm_band<4>, g, blk, lds, s, io, list, cnt, cols, score_out, d_wl1 + cstart[W], d_ct); break;
-            }
-        }
         GAB_HIP(hipGetLastError());
         GAB_HIP(hipMemcpyAsync(h->h_ct, d_ct, sizeof(BpmCounters), hipMemcpyDeviceToHost, s));
         GAB_HIP(hipStreamSynchronize(s));
+        for (int W = 1; W <= kMaxRegW; W++)
+            for (int k = 0; k < kSlices; k++) nfull += h->h_ct->wl_slice[W][k];
         // stage 1: 64-row window in global memory for the pairs that left the band
         uint32_t wcnt[kMaxRegW + 1];
         for (int W = 1; W <= kMaxRegW; W++) wcnt[W] = h->h_ct->wl1_count[W];

@@ -90,8 +90,7 @@ __global__ __launch_bounds__(256) void bsw_hist(BswIO io, uint32_t *hist, uint32
 }
 
 // ---- pass 2: exclusive scan of the 65536 bins (single workgroup) ---------------------------
-__global__ __launch_bounds__(1024) void bsw_scan(const uint32_t *hist, uint32_t *start, uint32_t *cursor,
-                                                 uint32_t *qstart) {
+__global__ __launch_bounds__(1024) void bsw_scan(const uint32_t *hist, uint32_t *start, uint32_t *qstart) {
     __shared__ uint32_t part[1024];
     const int t = threadIdx.x;
     constexpr int per = kNumKeys / 1024;   // 64 consecutive bins per thread
@@ -108,7 +107,7 @@ __global__ __launch_bounds__(1024) void bsw_scan(const uint32_t *hist, uint32_t 
     uint32_t run = part[t] - s;
     for (int k = 0; k < per; k++) {
         int b = t * per + k;
-        start[b] = run; cursor[b] = run;
+        start[b] = run;
         if ((b % kTBuckets) == 0) qstart[b / kTBuckets] = run;
         run += hist[b];
     }
@@ -542,7 +541,7 @@ struct gab_bsw {
     int device = 0;
     gab_bsw_params prm;
     BswConst cst;
-    gab_devbuf ws;          // hist | start | cursor | qstart | stats | perm | rank
+    gab_devbuf ws;          // hist | start | qstart | stats | perm | rank
     gab_devbuf io;          // staging for the host-pointer entry point
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};   // total begin, dp begin, dp end, total end
     // the per-class DP launches rotate over the caller's stream and these, so that the draining tail of one class
@@ -635,8 +634,7 @@ extern "C" int gab_bsw_run_device(gab_bsw *h, const uint8_t *ref, int64_t ref_by
     // workspace carve-up
     const size_t o_hist = 0;
     const size_t o_start = o_hist + sizeof(uint32_t) * kNumKeys;
-    const size_t o_cursor = o_start + sizeof(uint32_t) * (kNumKeys + 1);
-    const size_t o_qstart = o_cursor + sizeof(uint32_t) * (kNumKeys + 1);
+    const size_t o_qstart = o_start + sizeof(uint32_t) * (kNumKeys + 1);
     const size_t o_stats = (o_qstart + sizeof(uint32_t) * (kQBuckets + 1) + 15) & ~(size_t)15;
     const size_t o_perm = (o_stats + sizeof(BswStats) + 255) & ~(size_t)255;
     const size_t o_rank = o_perm + ((sizeof(uint32_t) * (size_t)n + 255) & ~(size_t)255);
@@ -644,7 +642,7 @@ extern "C" int gab_bsw_run_device(gab_bsw *h, const uint8_t *ref, int64_t ref_by
     if (rc) return rc;
     char *base = h->ws.as<char>();
     uint32_t *d_hist = (uint32_t *)(base + o_hist), *d_start = (uint32_t *)(base + o_start);
-    uint32_t *d_cursor = (uint32_t *)(base + o_cursor), *d_qstart = (uint32_t *)(base + o_qstart);
+    uint32_t *d_qstart = (uint32_t *)(base + o_qstart);
     BswStats *d_stats = (BswStats *)(base + o_stats);
     uint32_t *d_perm = (uint32_t *)(base + o_perm), *d_rank = (uint32_t *)(base + o_rank);
 
@@ -659,7 +657,7 @@ extern "C" int gab_bsw_run_device(gab_bsw *h, const uint8_t *ref, int64_t ref_by
     }
     int grid = (int)(gab_ceil_div(n, 256) < 4096 ? gab_ceil_div(n, 256) : 4096);
     hipLaunchKernelGGL(bsw_hist, dim3(grid), dim3(256), 0, s, io, d_hist, d_rank, d_stats);
-    hipLaunchKernelGGL(bsw_scan, dim3(1), dim3(1024), 0, s, d_hist, d_start, d_cursor, d_qstart);
+    hipLaunchKernelGGL(bsw_scan, dim3(1), dim3(1024), 0, s, d_hist, d_start, d_qstart);
     hipLaunchKernelGGL(bsw_scatter, dim3(grid), dim3(256), 0, s, io, d_start, d_rank, d_perm);
     GAB_HIP(hipMemcpyAsync(h->h_qstart, d_qstart, sizeof(uint32_t) * (kQBuckets + 1), hipMemcpyDeviceToHost, s));
     GAB_HIP(hipMemcpyAsync(h->h_stats, d_stats, sizeof(BswStats), hipMemcpyDeviceToHost, s));

@@ -148,7 +148,8 @@ int gab_bpm_run_device(gab_bpm *h, const char *pat, int64_t pat_bytes, const int
                        const int64_t *txt_off, const int32_t *txt_len, int64_t n,
                        int32_t *score_out, void *stream);
 /* last run: 64-row block steps executed, pairs that needed the history + backtrace path,
- * device time of the score kernels and of the whole call (HIP events, ms) */
+ * device time of the score kernels together with the first backtrace stage that runs underneath them, and of the
+ * whole call (HIP events, ms) */
 int gab_bpm_last_stats(gab_bpm *h, int64_t *block_steps, int64_t *full_pairs,
                        float *score_kernel_ms, float *total_ms);
 
