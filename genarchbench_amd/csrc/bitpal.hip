@@ -58,6 +58,19 @@ __device__ __forceinline__ uint32_t seq_ld4(const char *s, int pos, int len, uin
     return w;
 }
 
+// sixteen bytes: one 16-byte load when they all lie inside the sequence.  Every lane streams its own strings, and 16 waves
+// of 64 lanes keep far more lines alive than the 16 KB L1 holds, so with 4-byte loads each line was fetched again and
+// again (HBM fetch 16 GB per 10 M pairs = 5 x the algorithmic bytes)
+__device__ __forceinline__ uint4 seq_ld16(const char *s, int pos, int len, uint32_t fill) {
+    uint4 w;
+    if (pos + 16 <= len) { __builtin_memcpy(&w, s + pos, 16); return w; }
+    w.x = pos < len ? seq_ld4(s, pos, len, fill) : fill * 0x01010101u;
+    w.y = pos + 4 < len ? seq_ld4(s, pos + 4, len, fill) : fill * 0x01010101u;
+    w.z = pos + 8 < len ? seq_ld4(s, pos + 8, len, fill) : fill * 0x01010101u;
+    w.w = pos + 12 < len ? seq_ld4(s, pos + 12, len, fill) : fill * 0x01010101u;
+    return w;
+}
+
 // ---- pass 0: validate, count per path -----------------------------------------------------------------------------------
 // Counts are accumulated per lane and reduced once per wave: even one atomic per wave-iteration on a single address
 // serialises for milliseconds at 10 M pairs.  When every pair takes the LDS path (the usual case) no id list is needed at
@@ -143,13 +156,23 @@ __global__ __launch_bounds__(64) void bitpal_dp(BpIO io, const uint32_t *__restr
             const int base = ch * kChunk;
             uint32_t cw[kChunk / 4];                         // the chunk's bytes of the column string; 0xff behind its end
 #pragma unroll
-            for (int w = 0; w < kChunk / 4; w++) cw[w] = base + 4 * w < nc ? seq_ld4(cs, base + 4 * w, nc, 0xffu) : 0xffffffffu;
+            for (int w = 0; w < kChunk / 16; w++) {
+                const uint4 q = base + 16 * w < nc ? seq_ld16(cs, base + 16 * w, nc, 0xffu) : make_uint4(~0u, ~0u, ~0u, ~0u);
+                cw[4 * w] = q.x; cw[4 * w + 1] = q.y; cw[4 * w + 2] = q.z; cw[4 * w + 3] = q.w;
+            }
             // rows alternate between two register sets, so that "this row" never has to be copied over "previous row"
             int Ha[kChunk], Hb[kChunk];
 #pragma unroll
             for (int c = 0; c < kChunk; c++) Ha[c] = 0;                          // row 0 of S'
             int diag = 0;                                                       // S'[i - 1][base], starting with row 0
             uint32_t rw = 0;
+            uint4 rq = make_uint4(0u, 0u, 0u, 0u);           // sixteen characters of the row string
+            // the dword holding row i's character (called when (i - 1) % 4 == 0; all indices are wave-uniform)
+            auto next_rw = [&](int i) {
+                if (((i - 1) & 15) == 0) rq = seq_ld16(rs, i - 1, nr, 0u);
+                const int q = ((i - 1) >> 2) & 3;
+                rw = q == 0 ? rq.x : q == 1 ? rq.y : q == 2 ? rq.z : rq.w;
+            };
             auto row = [&](int i, const int (&Hin)[kChunk], int (&Hout)[kChunk]) {
                 // the row's character in all four bytes (v_perm_b32 with the wave-uniform selector 0x01010101 * ((i - 1) & 3))
                 const uint32_t rc4 = __builtin_amdgcn_perm(rw, rw, (uint32_t)((i - 1) & 3) * 0x01010101u);
@@ -178,12 +201,12 @@ __global__ __launch_bounds__(64) void bitpal_dp(BpIO io, const uint32_t *__restr
             };
             int i = 1;
             for (; i < nr; i += 2) {
-                if (((i - 1) & 3) == 0) rw = seq_ld4(rs, i - 1, nr, 0u);
+                if (((i - 1) & 3) == 0) next_rw(i);
                 row(i, Ha, Hb);
                 row(i + 1, Hb, Ha);
             }
             if (i == nr) {
-                if (((i - 1) & 3) == 0) rw = seq_ld4(rs, i - 1, nr, 0u);
+                if (((i - 1) & 3) == 0) next_rw(i);
                 row(i, Ha, Hb);
 #pragma unroll
                 for (int c = 0; c < kChunk; c++) Ha[c] = Hb[c];
