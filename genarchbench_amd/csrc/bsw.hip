@@ -114,15 +114,22 @@ __global__ __launch_bounds__(1024) void bsw_scan(const uint32_t *hist, uint32_t 
     if (t == 1023) { start[kNumKeys] = run; qstart[kQBuckets] = run; }
 }
 
-// ---- pass 3: scatter pair ids into bucket order -------------------------------------------
+// ---- pass 3: scatter the pairs' descriptors into bucket order -------------------------------
+// One 32-byte record per pair, written here from coalesced reads of the five input arrays and read coalesced by the DP
+// kernels: the DP kernels used to gather the five fields through the permutation (five random 64-byte sectors per pair,
+// 3.2 GB of the 7.6 GB the DP fetched per 10 M pairs against 2.1 GB of algorithmic bytes).
+struct __attribute__((aligned(32))) BswRec { int64_t ref_off, qry_off; int32_t len1, len2, h0; uint32_t id; };
+
 __global__ __launch_bounds__(256) void bsw_scatter(BswIO io, const uint32_t *__restrict__ start, const uint32_t *__restrict__ rank,
-                                                   uint32_t *perm) {
+                                                   BswRec *recs) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (; i < io.n; i += stride) {
         int ql = io.len2[i], tl = io.len1[i];
         if (ql < 1 || ql > GAB_BSW_MAX_QLEN || tl < 1 || tl > GAB_BSW_MAX_TLEN) continue;
-        perm[start[bsw_key(ql, tl, io.h0[i])] + rank[i]] = (uint32_t)i;
+        BswRec r;
+        r.ref_off = io.ref_off[i]; r.qry_off = io.qry_off[i]; r.len1 = tl; r.len2 = ql; r.h0 = io.h0[i]; r.id = (uint32_t)i;
+        recs[start[bsw_key(ql, tl, r.h0)] + rank[i]] = r;
     }
 }
 
@@ -136,7 +143,7 @@ __device__ __forceinline__ uint32_t load_u32_unaligned(const uint8_t *p) {
 // WIDE = false: H and E packed as (E << 16) | H in one dword per column (both < 2^15).
 // WIDE = true : H at lds[j*64+lane], E at lds[(qcap+1+j)*64+lane].
 template <bool WIDE>
-__global__ __launch_bounds__(64) void bsw_dp(BswIO io, BswConst c, const uint32_t *__restrict__ perm,
+__global__ __launch_bounds__(64) void bsw_dp(BswIO io, BswConst c, const BswRec *__restrict__ recs,
                                             int64_t kbeg, int64_t kend, int qcap,
                                             int32_t *__restrict__ score_out,
                                             gab_bsw_result *__restrict__ result_out, BswStats *st) {
@@ -144,7 +151,9 @@ __global__ __launch_bounds__(64) void bsw_dp(BswIO io, BswConst c, const uint32_
     const int lane = threadIdx.x;
     const int64_t k = kbeg + (int64_t)(gridDim.x - 1 - blockIdx.x) * 64 + lane;   // heaviest waves (largest key) first
     const bool valid = k < kend;
-    const uint32_t id = valid ? perm[k] : 0u;
+    BswRec rec; rec.ref_off = rec.qry_off = 0; rec.len1 = rec.len2 = rec.h0 = 0; rec.id = 0u;
+    if (valid) rec = recs[k];
+    const uint32_t id = rec.id;
 
     uint32_t *const H = lds + lane;                                   // [j*64]
     uint32_t *const E = lds + (size_t)(qcap + 1) * 64 + lane;         // WIDE only
@@ -153,9 +162,9 @@ __global__ __launch_bounds__(64) void bsw_dp(BswIO io, BswConst c, const uint32_
 
     unsigned long long cells = 0;
     if (valid) {
-        const int qlen = io.len2[id], tlen = io.len1[id], h0 = io.h0[id];
-        const uint8_t *q = io.qry + io.qry_off[id];
-        const uint8_t *t = io.ref + io.ref_off[id];
+        const int qlen = rec.len2, tlen = rec.len1, h0 = rec.h0;
+        const uint8_t *q = io.qry + rec.qry_off;
+        const uint8_t *t = io.ref + rec.ref_off;
         const int oe_del = c.o_del + c.e_del, oe_ins = c.o_ins + c.e_ins;
         const int e_del = c.e_del, e_ins = c.e_ins;
 
@@ -335,14 +344,16 @@ __device__ __forceinline__ BswCellOut bsw_cell(int diag, int e, int f, uint32_t 
     return o;
 }
 
-__global__ __launch_bounds__(64) void bsw_dp8(BswIO io, BswConst c, const uint32_t *__restrict__ perm, int64_t kbeg,
+__global__ __launch_bounds__(64) void bsw_dp8(BswIO io, BswConst c, const BswRec *__restrict__ recs, int64_t kbeg,
                                               int64_t kend, int qcap, int32_t *__restrict__ score_out,
                                               gab_bsw_result *__restrict__ result_out, BswStats *st) {
     extern __shared__ uint32_t lds[];
     const int lane = threadIdx.x;
     const int64_t k = kbeg + (int64_t)(gridDim.x - 1 - blockIdx.x) * 64 + lane;   // heaviest waves (largest key) first
     const bool valid = k < kend;
-    const uint32_t id = valid ? perm[k] : 0u;
+    BswRec rec; rec.ref_off = rec.qry_off = 0; rec.len1 = rec.len2 = rec.h0 = 0; rec.id = 0u;
+    if (valid) rec = recs[k];
+    const uint32_t id = rec.id;
     const int ncell_dw = (qcap + 2) / 2;
     // cell j of this lane: 16 bits at byte address ((j >> 1) * 64 + lane) * 4 + (j & 1) * 2
     uint8_t *const CB = reinterpret_cast<uint8_t *>(lds + lane);
@@ -353,9 +364,9 @@ __global__ __launch_bounds__(64) void bsw_dp8(BswIO io, BswConst c, const uint32
 
     unsigned long long cells = 0;
     if (valid) {
-        const int qlen = io.len2[id], tlen = io.len1[id], h0 = io.h0[id];
-        const uint8_t *q = io.qry + io.qry_off[id];
-        const uint8_t *t = io.ref + io.ref_off[id];
+        const int qlen = rec.len2, tlen = rec.len1, h0 = rec.h0;
+        const uint8_t *q = io.qry + rec.qry_off;
+        const uint8_t *t = io.ref + rec.ref_off;
         const int oe_del = c.o_del + c.e_del, oe_ins = c.o_ins + c.e_ins;
         const int e_del = c.e_del, e_ins = c.e_ins;
 
@@ -541,7 +552,7 @@ struct gab_bsw {
     int device = 0;
     gab_bsw_params prm;
     BswConst cst;
-    gab_devbuf ws;          // hist | start | qstart | stats | perm | rank
+    gab_devbuf ws;          // hist | start | qstart | stats | records in bucket order | rank
     gab_devbuf io;          // staging for the host-pointer entry point
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};   // total begin, dp begin, dp end, total end
     // the per-class DP launches rotate over the caller's stream and these, so that the draining tail of one class
@@ -637,14 +648,15 @@ extern "C" int gab_bsw_run_device(gab_bsw *h, const uint8_t *ref, int64_t ref_by
     const size_t o_qstart = o_start + sizeof(uint32_t) * (kNumKeys + 1);
     const size_t o_stats = (o_qstart + sizeof(uint32_t) * (kQBuckets + 1) + 15) & ~(size_t)15;
     const size_t o_perm = (o_stats + sizeof(BswStats) + 255) & ~(size_t)255;
-    const size_t o_rank = o_perm + ((sizeof(uint32_t) * (size_t)n + 255) & ~(size_t)255);
+    const size_t o_rank = o_perm + ((sizeof(BswRec) * (size_t)n + 255) & ~(size_t)255);
     int rc = h->ws.reserve(o_rank + sizeof(uint32_t) * (size_t)n);
     if (rc) return rc;
     char *base = h->ws.as<char>();
     uint32_t *d_hist = (uint32_t *)(base + o_hist), *d_start = (uint32_t *)(base + o_start);
     uint32_t *d_qstart = (uint32_t *)(base + o_qstart);
     BswStats *d_stats = (BswStats *)(base + o_stats);
-    uint32_t *d_perm = (uint32_t *)(base + o_perm), *d_rank = (uint32_t *)(base + o_rank);
+    BswRec *d_perm = (BswRec *)(base + o_perm);             // the pairs' records in bucket order
+    uint32_t *d_rank = (uint32_t *)(base + o_rank);
 
     BswIO io{ref, ref_off, qry, qry_off, len1, len2, h0, ref_bytes, qry_bytes, n};
     GAB_HIP(hipEventRecord(h->ev[0], s));
