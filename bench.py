@@ -127,7 +127,7 @@ class BswWorkload:
                 "dominant_kernel_timing": "HIP events around the DP launches of a step: one bsw_dp8 launch per query-length class, "
                                           "two in flight at a time (two streams), so rocprofv3's per-launch durations overlap; the matching "
                                           "figure is the first-start-to-last-end span (tools/profiling/kernel_span.py on "
-                                          "profiles/r01_bsw_large_kernel_trace.csv: 47.3-47.8 ms)",
+                                          "profiles/r01_bsw_large_kernel_trace.csv: 46.6-47.3 ms)",
                 # the bound that matters: integer VALU issue.  19.7 lane-instructions per DP cell is the PMC figure
                 # (SQ_INSTS_VALU x 64 / cells, profiles/r01_bsw_pmc.md); peak = 256 CUs x 64 lanes x 2.4 GHz.
                 "valu": {"lane_instr_per_cell": 19.7, "achieved_T_lane_instr_per_s":
