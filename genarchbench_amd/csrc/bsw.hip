@@ -647,20 +647,20 @@ extern "C" int gab_bsw_run_device(gab_bsw *h, const uint8_t *ref, int64_t ref_by
     const size_t o_start = o_hist + sizeof(uint32_t) * kNumKeys;
     const size_t o_qstart = o_start + sizeof(uint32_t) * (kNumKeys + 1);
     const size_t o_stats = (o_qstart + sizeof(uint32_t) * (kQBuckets + 1) + 15) & ~(size_t)15;
-    const size_t o_perm = (o_stats + sizeof(BswStats) + 255) & ~(size_t)255;
-    const size_t o_rank = o_perm + ((sizeof(BswRec) * (size_t)n + 255) & ~(size_t)255);
+    const size_t o_recs = (o_stats + sizeof(BswStats) + 255) & ~(size_t)255;
+    const size_t o_rank = o_recs + ((sizeof(BswRec) * (size_t)n + 255) & ~(size_t)255);
     int rc = h->ws.reserve(o_rank + sizeof(uint32_t) * (size_t)n);
     if (rc) return rc;
     char *base = h->ws.as<char>();
     uint32_t *d_hist = (uint32_t *)(base + o_hist), *d_start = (uint32_t *)(base + o_start);
     uint32_t *d_qstart = (uint32_t *)(base + o_qstart);
     BswStats *d_stats = (BswStats *)(base + o_stats);
-    BswRec *d_perm = (BswRec *)(base + o_perm);             // the pairs' records in bucket order
+    BswRec *d_recs = (BswRec *)(base + o_recs);             // the pairs' records in bucket order
     uint32_t *d_rank = (uint32_t *)(base + o_rank);
 
     BswIO io{ref, ref_off, qry, qry_off, len1, len2, h0, ref_bytes, qry_bytes, n};
     GAB_HIP(hipEventRecord(h->ev[0], s));
-    GAB_HIP(hipMemsetAsync(base, 0, o_perm, s));
+    GAB_HIP(hipMemsetAsync(base, 0, o_recs, s));
     {
         BswStats init; memset(&init, 0, sizeof(init)); init.first_bad = 0x7fffffff;
         // first_bad uses atomicMin, so it starts at INT_MAX (set by a tiny H2D after the memset)
@@ -670,7 +670,7 @@ extern "C" int gab_bsw_run_device(gab_bsw *h, const uint8_t *ref, int64_t ref_by
     int grid = (int)(gab_ceil_div(n, 256) < 4096 ? gab_ceil_div(n, 256) : 4096);
     hipLaunchKernelGGL(bsw_hist, dim3(grid), dim3(256), 0, s, io, d_hist, d_rank, d_stats);
     hipLaunchKernelGGL(bsw_scan, dim3(1), dim3(1024), 0, s, d_hist, d_start, d_qstart);
-    hipLaunchKernelGGL(bsw_scatter, dim3(grid), dim3(256), 0, s, io, d_start, d_rank, d_perm);
+    hipLaunchKernelGGL(bsw_scatter, dim3(grid), dim3(256), 0, s, io, d_start, d_rank, d_recs);
     GAB_HIP(hipMemcpyAsync(h->h_qstart, d_qstart, sizeof(uint32_t) * (kQBuckets + 1), hipMemcpyDeviceToHost, s));
     GAB_HIP(hipMemcpyAsync(h->h_stats, d_stats, sizeof(BswStats), hipMemcpyDeviceToHost, s));
     GAB_HIP(hipStreamSynchronize(s));   // launch geometry of the DP depends on the class sizes
@@ -698,16 +698,16 @@ extern "C" int gab_bsw_run_device(gab_bsw *h, const uint8_t *ref, int64_t ref_by
         // 8-bit cells when every H/E value of this class fits a byte: H <= h0 + qlen * max_sc
         if ((int64_t)h->h_stats->max_h0 + (int64_t)qcap * h->cst.max_sc <= 255 && h->cst.max_sc >= 0) {
             const size_t lds8 = sizeof(uint32_t) * 64 * ((size_t)(qcap + 2) / 2 + ((size_t)(qcap + 1) / 2 + 3) / 4 + 1);
-            hipLaunchKernelGGL(bsw_dp8, dim3(blocks), dim3(64), lds8, s, io, h->cst, d_perm, kb, ke, qcap, score_out, result_out,
+            hipLaunchKernelGGL(bsw_dp8, dim3(blocks), dim3(64), lds8, s, io, h->cst, d_recs, kb, ke, qcap, score_out, result_out,
                                d_stats);
             continue;
         }
         const size_t lds = sizeof(uint32_t) * 64 * ((size_t)(wide ? 2 : 1) * (qcap + 1) + (size_t)(qcap + 3) / 4);
         if (wide)
-            hipLaunchKernelGGL(bsw_dp<true>, dim3(blocks), dim3(64), lds, s, io, h->cst, d_perm, kb, ke, qcap,
+            hipLaunchKernelGGL(bsw_dp<true>, dim3(blocks), dim3(64), lds, s, io, h->cst, d_recs, kb, ke, qcap,
                                score_out, result_out, d_stats);
         else
-            hipLaunchKernelGGL(bsw_dp<false>, dim3(blocks), dim3(64), lds, s, io, h->cst, d_perm, kb, ke, qcap,
+            hipLaunchKernelGGL(bsw_dp<false>, dim3(blocks), dim3(64), lds, s, io, h->cst, d_recs, kb, ke, qcap,
                                score_out, result_out, d_stats);
     }
     s = s_main;
