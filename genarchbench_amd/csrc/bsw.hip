@@ -63,6 +63,12 @@ __device__ __forceinline__ int bsw_key(int qlen, int tlen, int h0) {
     return (qlen - 1) * kTBuckets + tb * 4 + hc;
 }
 
+// A 151-bp read set puts almost all pairs into ~256 NEIGHBOURING keys (one query length), i.e. 1 KB of counters behind a
+// handful of memory channels, and the histogram pass is bound by the atomic rate of those channels.  The counters are
+// therefore stored at a multiplicatively scrambled index (a bijection on 16 bits): neighbouring keys lie 16 KB apart.
+__device__ __forceinline__ int bsw_hslot(int key) { return (int)(((uint32_t)key * 4099u) & (uint32_t)(kNumKeys - 1)); }
+static_assert((kNumKeys & (kNumKeys - 1)) == 0, "bsw_hslot needs a power-of-two key space");
+
 // ---- pass 1: validate + histogram ------------------------------------------------------
 // The value the histogram atomic returns is the pair's rank inside its bucket: it is kept, so that the scatter pass
 // needs no second round of 10 M atomics (each pass was atomic-throughput bound at ~13 G/s).
@@ -82,7 +88,7 @@ __global__ __launch_bounds__(256) void bsw_hist(BswIO io, uint32_t *hist, uint32
             continue;
         }
         mh = h > mh ? h : mh;
-        rank[i] = atomicAdd(&hist[bsw_key(ql, tl, h)], 1u);
+        rank[i] = atomicAdd(&hist[bsw_hslot(bsw_key(ql, tl, h))], 1u);
     }
     // wave max of h0, one atomic per wave
     for (int o = 32; o > 0; o >>= 1) { int v = __shfl_xor(mh, o); mh = v > mh ? v : mh; }
@@ -95,7 +101,7 @@ __global__ __launch_bounds__(1024) void bsw_scan(const uint32_t *hist, uint32_t 
     const int t = threadIdx.x;
     constexpr int per = kNumKeys / 1024;   // 64 consecutive bins per thread
     uint32_t s = 0;
-    for (int k = 0; k < per; k++) s += hist[t * per + k];
+    for (int k = 0; k < per; k++) s += hist[bsw_hslot(t * per + k)];
     part[t] = s;
     __syncthreads();
     for (int o = 1; o < 1024; o <<= 1) {
@@ -109,7 +115,7 @@ __global__ __launch_bounds__(1024) void bsw_scan(const uint32_t *hist, uint32_t 
         int b = t * per + k;
         start[b] = run;
         if ((b % kTBuckets) == 0) qstart[b / kTBuckets] = run;
-        run += hist[b];
+        run += hist[bsw_hslot(b)];
     }
     if (t == 1023) { start[kNumKeys] = run; qstart[kQBuckets] = run; }
 }
