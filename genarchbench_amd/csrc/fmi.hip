@@ -46,6 +46,8 @@ struct FmiIdx {
 struct PrevRec { int64_t n, k, l, s; };                    // 32 bytes, [entry][lane]
 struct OutRec { uint32_t m, n; int64_t k, l, s; };         // 32 bytes, per-read slot
 
+constexpr int kReadPool = 64;               // reads a wave reserves from the global queue at a time
+
 struct FmiCounters {
     unsigned long long ext_calls;
     unsigned long long rec_reads;  // distinct 64-byte CP_OCC records fetched (1 or 2 per extension)
@@ -209,6 +211,7 @@ __global__ __launch_bounds__(64) void fmi_seed_kernel(FmiIdx ix, const uint8_t *
     int mx = 0;
     // ---- per-lane state
     int state = ST_NEW_READ;
+    int pool_next = 0, pool_end = 0;                         // wave-uniform: this wave's reserved slice of the read queue
     const uint8_t *q = enc; OutRec *out = out_all;
     int t = 0, len = 0, pass = 1, x = 0, next_x = 0, j = 0, a = 0;
     int nprev = 0, ncur = 0, p = 0, curr_s = -1, n1 = 0, jrec = 0, nout = 0, nout0 = 0;
@@ -328,10 +331,18 @@ __global__ __launch_bounds__(64) void fmi_seed_kernel(FmiIdx ix, const uint8_t *
             const bool want = state == ST_NEW_READ;
             const uint64_t wm = __ballot(want);
             const int leader = __builtin_ctzll(wm);
-            int idx0 = 0;
-            if (lane == leader) idx0 = atomicAdd(&ct->next_read, __builtin_popcountll(wm));   // one queue for the whole grid
-            idx0 = __shfl(idx0, leader);
-            const int idx = idx0 + __builtin_popcountll(wm & ((1ull << lane) - 1ull));
+            // one queue for the whole grid, drawn from in chunks of kReadPool reads per wave: a returning atomic on a single
+            // address per wave step with a finished read (millions per batch) serialises at ~7 ns apiece and stalls the
+            // wave for a memory round trip; the wave-local pool needs one per 64 reads
+            const int k = __builtin_popcountll(wm), rem = pool_end - pool_next;
+            int nb = 0;
+            if (rem < k) {
+                if (lane == leader) nb = atomicAdd(&ct->next_read, kReadPool);
+                nb = __builtin_amdgcn_readfirstlane(__shfl(nb, leader));
+            }
+            const int r = __builtin_popcountll(wm & ((1ull << lane) - 1ull));
+            const int idx = r < rem ? pool_next + r : nb + (r - rem);
+            if (rem < k) { pool_next = nb + (k - rem); pool_end = nb + kReadPool; } else pool_next += k;
             const bool got = want && idx < nbatch;
             if (want && !got) state = ST_DONE;
             if (got) {
