@@ -516,15 +516,17 @@ __global__ __launch_bounds__(64) void fmi_seed_kernel(FmiIdx ix, const uint8_t *
         }
     }
     // statistics: one atomic per wave
-    unsigned long long c64 = calls, r64 = recs, t64 = tabs;
+    unsigned long long c64 = calls, r64 = recs, t64 = tabs, p64 = dbg_pos, s64 = dbg_spill, l64 = dbg_list;
     for (int o = 32; o > 0; o >>= 1) {
         c64 += __shfl_xor(c64, o); tot += __shfl_xor(tot, o); r64 += __shfl_xor(r64, o); t64 += __shfl_xor(t64, o);
+        p64 += __shfl_xor(p64, o); s64 += __shfl_xor(s64, o); l64 += __shfl_xor(l64, o);
         const int v = __shfl_xor(mx, o); mx = v > mx ? v : mx;
         const unsigned long long sv = __shfl_xor(steps, o); steps = sv > steps ? sv : steps;
     }
-    atomicAdd(&ct->positions, (unsigned long long)dbg_pos); atomicAdd(&ct->spills, (unsigned long long)dbg_spill);
-    atomicAdd(&ct->list_sum, (unsigned long long)dbg_list);
     if (lane == 0) {
+        if (p64) atomicAdd(&ct->positions, p64);
+        if (s64) atomicAdd(&ct->spills, s64);
+        if (l64) atomicAdd(&ct->list_sum, l64);
         atomicAdd(&ct->wave_steps, steps);
         if (c64) atomicAdd(&ct->ext_calls, c64);
         if (r64) atomicAdd(&ct->rec_reads, r64);
