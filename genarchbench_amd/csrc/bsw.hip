@@ -673,7 +673,7 @@ extern "C" int gab_bsw_run_device(gab_bsw *h, const uint8_t *ref, int64_t ref_by
         *h->h_stats = init;
         GAB_HIP(hipMemcpyAsync(d_stats, h->h_stats, sizeof(BswStats), hipMemcpyHostToDevice, s));
     }
-    int grid = (int)(gab_ceil_div(n, 256) < 4096 ? gab_ceil_div(n, 256) : 4096);
+    int grid = (int)(gab_ceil_div(n, 256) < 1024 ? gab_ceil_div(n, 256) : 1024);   // (one same-address atomicMax per wave)
     hipLaunchKernelGGL(bsw_hist, dim3(grid), dim3(256), 0, s, io, d_hist, d_rank, d_stats);
     hipLaunchKernelGGL(bsw_scan, dim3(1), dim3(1024), 0, s, d_hist, d_start, d_qstart);
     hipLaunchKernelGGL(bsw_scatter, dim3(grid), dim3(256), 0, s, io, d_start, d_rank, d_recs);
