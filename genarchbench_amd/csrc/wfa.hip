@@ -127,6 +127,14 @@ __device__ __forceinline__ uint64_t lds_ld8(const uint8_t *base, int byte_off) {
     return (uint64_t)__builtin_amdgcn_alignbyte(w2, w1, sh) << 32 | __builtin_amdgcn_alignbyte(w1, w0, sh);
 }
 __device__ __forceinline__ uint32_t glb_ld4(const char *p) { uint32_t w; __builtin_memcpy(&w, p, 4); return w; }
+// four bytes of a sequence at `pos`; bytes at or behind `len` read as `fill` (never loads past the dword of the last base)
+__device__ __forceinline__ uint32_t seq_ld4(const char *s, int pos, int len, uint32_t fill) {
+    if (pos + 4 <= len) return glb_ld4(s + pos);
+    uint32_t w = fill * 0x01010101u;
+    for (int b = 0; b < 4; b++)
+        if (pos + b < len) w = (w & ~(0xffu << (8 * b))) | (uint32_t)(uint8_t)s[pos + b] << (8 * b);
+    return w;
+}
 
 // One pair, one wave.  LDSSEQ: P/T are LDS copies padded with kSeqPad bytes of 'X'/'Y';
 // otherwise they are the global sequences (readable to a multiple of 4 bytes past the end).
@@ -402,8 +410,9 @@ __global__ __launch_bounds__(64) void wfa_lds(WfaIO io, WfaPen pen, const uint32
         int16_t *pool = reinterpret_cast<int16_t *>(T + seqt);
         const int plen = io.pat_len[id], tlen = io.txt_len[id];
         const char *gp = io.pat + io.pat_off[id], *gt = io.txt + io.txt_off[id];
-        for (int i = lane; i < plen + kSeqPad; i += G) P[i] = i < plen ? (uint8_t)gp[i] : (uint8_t)'X';
-        for (int i = lane; i < tlen + kSeqPad; i += G) T[i] = i < tlen ? (uint8_t)gt[i] : (uint8_t)'Y';
+        // four bytes per lane and step (the LDS copies are dword-aligned and have room to the next multiple of four)
+        for (int i = 4 * lane; i < plen + kSeqPad; i += 4 * G) *reinterpret_cast<uint32_t *>(P + i) = seq_ld4(gp, i, plen, (uint32_t)'X');
+        for (int i = 4 * lane; i < tlen + kSeqPad; i += 4 * G) *reinterpret_cast<uint32_t *>(T + i) = seq_ld4(gt, i, tlen, (uint32_t)'Y');
         __syncthreads();
         WfStore<int16_t, ADAPT> st;
         st.pool = pool; st.dir = dir; st.pool_cap = pool_cap; st.dir_cap = dir_cap; st.used = 0;
