@@ -14,7 +14,9 @@
  *   - the caller owns every buffer.  "_run" variants take HOST pointers and do
  *     H2D + kernels + D2H synchronously; "_run_device" variants take DEVICE pointers
  *     (hipMalloc'ed or a torch tensor's data_ptr) and enqueue asynchronously on `stream`
- *     (a hipStream_t passed as void*, NULL = the default stream).
+ *     (a hipStream_t passed as void*, NULL = the default stream).  Some of them (bsw, bpm) run part of their
+ *     kernels on an internal second stream; it is forked from and joined back into `stream` by events
+ *     inside the call, so the caller only ever has to order against `stream`.
  *   - a handle is bound to one GPU; calls on distinct handles are thread-safe, so the
  *     multi-GPU drivers run one host thread (or one process) per GPU with no collective.
  */
