@@ -107,6 +107,7 @@ constexpr int kRingSafe = kRing - 8;      // entries younger than this are read 
 // per anchor, coalesced reads of x / y) and leave it in LDS; the main wave, which alone carries the dependence, only
 // adds score[j], and runs the marks / prefix-max / n_skip steps described above.  Windows deeper than 256
 // predecessors continue in the main wave, which then evaluates the geometry itself.
+constexpr int kChPriorityCalls = 128;         // the longest calls (= first workgroups) run at raised wave priority
 constexpr int kChHelpers = 2;
 constexpr int kChBlock = 2;
 constexpr int kGeoDepth = 1024;              // predecessors per anchor the helpers prepare (four super-chunks)
@@ -160,6 +161,9 @@ __global__ __launch_bounds__(64 * (1 + kChHelpers)) void chain_hw_kernel(const C
     const int NEG = (int)0x80000000;
     const int nblocks = (n + kChBlock - 1) / kChBlock;
 
+    // Calls are launched longest first and the walk of the longest ones is the critical path of the batch: their waves
+    // (main and helpers alike) get the instruction arbiter's preference over the mass of short calls (+2 %).
+    if (blockIdx.x < kChPriorityCalls) __builtin_amdgcn_s_setprio(3);
     if (wave > 0) {
         // ================= helper: geometry of block t, one block ahead of the main wave
         int st = 0, sb = 0;
