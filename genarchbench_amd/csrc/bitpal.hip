@@ -13,12 +13,14 @@
 // is the row loop; the only memory state is the chunk's boundary column -- one score per row -- kept per lane in LDS in
 // [row][lane] order as ONE BYTE per row, the difference to the row above (0 .. match - 2 gap in the normalised scores
 // below), or in a global scratch as int32 when a pair is too long for that.  The byte column is what sets the occupancy:
-// 9.7 KB per wave for 151-bp pairs = 16 waves per CU (int16 scores: 8 waves and 19 % slower, profiles/r01_kernel_bounds.md).
+// 9.7 KB per wave for 151-bp pairs = 16 waves per CU (int16 scores: 8 waves and 25 % slower).
 // The DP runs on S'[i][j] = S[i][j] - (i + j) * gap: vertical and horizontal moves then cost nothing, a diagonal move adds
-// match - 2 gap or mismatch - 2 gap, and both borders are zero, so one cell is compare / select / add / v_max3_i32 on
-// registers; per row there is one LDS read, one LDS write and a quarter of a dword load of the row string.
+// match - 2 gap or mismatch - 2 gap, and both borders are zero.  The increments of four columns are built as the bytes of
+// one dword (SWAR zero-byte test on columns ^ row character), so one cell is v_add_u32_sdwa (byte operand) + v_max3_i32;
+// per row there is one LDS read, one LDS write and a sixteenth of a 16-byte load of the row string.
 //
-// Roofline: plen + tlen + 4 bytes of HBM traffic per pair against ~5 VALU per DP cell: integer-VALU bound.
+// Roofline: plen + tlen + 4 algorithmic bytes per pair (the row string is really streamed once per 32-column chunk:
+// 3.1 x, profiles/r01_hbm_traffic.md) against 3.5 VALU per DP cell: integer-VALU bound, ~93 % of the issue rate.
 #include "gab_internal.h"
 #include <algorithm>
 #include <new>
