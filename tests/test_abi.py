@@ -42,7 +42,7 @@ def test_fails_loudly_without_gpu():
 def test_product_never_imports_oracle():
     """the product path must not route through oracle/ (see oracle/oracle.h)"""
     bad = []
-    for base in ("genarchbench_amd", "benchmarks", "include"):
+    for base in ("genarchbench_amd", "benchmarks", "include", "tools"):
         for dp, _, fns in os.walk(os.path.join(ROOT, base)):
             for fn in fns:
                 if fn.endswith((".py", ".c", ".h", ".cpp", ".hip", ".sh")) or fn == "Makefile":
