@@ -35,6 +35,18 @@ def test_vs_oracle(eng, seed, n, mode, plen):
     assert st["block_steps"] >= steps          # queued pairs are stepped twice (score pass + full pass)
 
 
+def test_sliced_classes(eng):
+    """classes of >= 2^18 pairs are scored in slices whose band kernels run on a second stream (device-side queue
+    lengths): two populated classes, unclean pairs in every slice"""
+    a = gabgen.pairs(58, 600000, 0, 151)
+    b = gabgen.pairs(59, 700000, 1, 100)
+    pats = np.concatenate([a.pat, b.pat]); txts = np.concatenate([a.txt, b.txt])
+    batch = gabgen.PairBatch(pats, np.concatenate([a.pat_off, b.pat_off + len(a.pat)]), np.concatenate([a.pat_len, b.pat_len]),
+                             txts, np.concatenate([a.txt_off, b.txt_off + len(a.txt)]), np.concatenate([a.txt_len, b.txt_len])).swapped_longer_first()
+    np.testing.assert_array_equal(eng.benchmark_edit_bpm(batch), pyoracle.bpm(batch))
+    assert eng.last_stats()["full_pairs"] > 10000
+
+
 def test_edge_cases(eng):
     pats = [b"A", b"ACGT", b"NNNN", b"acgt", b"A" * 64, b"A" * 65, b"ACGTN" * 30, b"N" * 130, b"ACGT" * 64, b"T" * 257]
     txts = [b"", b"ACGT", b"NNNN", b"ACGT", b"A" * 64, b"A" * 64, b"ACGTN" * 29, b"A" * 129, b"ACGT" * 63 + b"ACG", b"T" * 200]
