@@ -192,8 +192,11 @@ template <bool LDSQ>
 __global__ __launch_bounds__(64) void fmi_seed_kernel(FmiIdx ix, const uint8_t *__restrict__ enc, int32_t stride,
                                                       const int32_t *__restrict__ len_arr, int64_t first, int32_t nbatch,
                                                       int min_seed_len, PrevRec *prev, int prev_cap, OutRec *out_all, int cap,
-                                                      int32_t *counts, FmiCounters *ct, int lds_entries, int64_t enc_bytes, int passes) {
-    // dynamic LDS (LDSQ only): [ (stride + 7) / 8 words of read codes ][ lds_entries x 16-byte list entries ]  x 64 lanes
+                                                      int32_t *counts, FmiCounters *ct, int lds_entries, int64_t enc_bytes, int passes,
+                                                      int narrow_lists) {
+    // dynamic LDS (LDSQ only): [ (stride + 7) / 8 words of read codes ][ lds_entries list entries ]  x 64 lanes; a list entry
+    // is 16 bytes (k, l, s < 2^40, n < 256 packed), or -- narrow_lists, for indexes below 2^32 rows -- three dword planes
+    // and a byte plane = 13 bytes, which is two more waves per CU at 12 entries
     extern __shared__ uint4 lds_all[];
     const int lane = threadIdx.x;
     uint32_t *const lq = reinterpret_cast<uint32_t *>(lds_all) + lane;
@@ -246,7 +249,16 @@ __global__ __launch_bounds__(64) void fmi_seed_kernel(FmiIdx ix, const uint8_t *
     bool rev = true;
     int fslot = 0, Rslot = 0, nfwd = 0, nxt_for = -1;
     PrevRec nxt; nxt.n = nxt.k = nxt.l = nxt.s = 0;
+    // narrow: field f of slot e of this lane at lw[(3 e + f) * 64], its byte at lb[e * 64] (planes behind the read codes)
+    uint4 *const list_base = lds_all + ((stride + 7) / 8 * 64 + 3) / 4;
+    uint32_t *const lw = reinterpret_cast<uint32_t *>(list_base) + lane;
+    uint8_t *const lb = reinterpret_cast<uint8_t *>(list_base) + (size_t)C * 3 * 64 * 4 + lane;
     auto lds_put = [&](int slot, const PrevRec &r) {
+        if (narrow_lists) {
+            lw[(3 * slot) * 64] = (uint32_t)r.k; lw[(3 * slot + 1) * 64] = (uint32_t)r.l; lw[(3 * slot + 2) * 64] = (uint32_t)r.s;
+            lb[slot * 64] = (uint8_t)r.n;
+            return;
+        }
         uint4 w;
         w.x = (uint32_t)r.k; w.y = (uint32_t)r.l; w.z = (uint32_t)r.s;
         w.w = ((uint32_t)(r.k >> 32) & 0xffu) | ((uint32_t)(r.l >> 32) & 0xffu) << 8 | ((uint32_t)(r.s >> 32) & 0xffu) << 16 |
@@ -254,8 +266,13 @@ __global__ __launch_bounds__(64) void fmi_seed_kernel(FmiIdx ix, const uint8_t *
         lp[slot * 64] = w;
     };
     auto lds_get = [&](int slot) -> PrevRec {
-        const uint4 w = lp[slot * 64];
         PrevRec r;
+        if (narrow_lists) {
+            r.k = (int64_t)lw[(3 * slot) * 64]; r.l = (int64_t)lw[(3 * slot + 1) * 64]; r.s = (int64_t)lw[(3 * slot + 2) * 64];
+            r.n = (int64_t)lb[slot * 64];
+            return r;
+        }
+        const uint4 w = lp[slot * 64];
         r.k = (int64_t)((uint64_t)(w.w & 0xffu) << 32 | w.x); r.l = (int64_t)((uint64_t)((w.w >> 8) & 0xffu) << 32 | w.y);
         r.s = (int64_t)((uint64_t)((w.w >> 16) & 0xffu) << 32 | w.z); r.n = (int64_t)(w.w >> 24);
         return r;
@@ -886,7 +903,11 @@ extern "C" int gab_fmi_seed_device(gab_fmi *h, const uint8_t *d_enc, int32_t str
     static const int lds_entries_env = [] { const char *e = getenv("GAB_FMI_LDS_ENTRIES"); return e ? atoi(e) : 0; }();
     const bool ldsq = stride <= kLdsQMax;
     const int lds_entries = ldsq ? (lds_entries_env > 0 ? lds_entries_env : 12) : 0;
-    const size_t lds_bytes = ldsq ? (((size_t)(stride + 7) / 8 * 64 + 3) / 4 + (size_t)lds_entries * 64) * 16 : 0;
+    // list entries: 13 bytes (three dword planes + a byte plane) when every interval bound fits 32 bits, else 16 packed
+    static const bool wide_env = [] { const char *e = getenv("GAB_FMI_WIDE_LISTS"); return e && atoi(e) != 0; }();   // tests
+    const int narrow_lists = (h->ix.ref_seq_len < 0xffffffffll && !wide_env) ? 1 : 0;
+    const size_t list_bytes = narrow_lists ? (((size_t)lds_entries * 64 * 13 + 15) & ~(size_t)15) : (size_t)lds_entries * 64 * 16;
+    const size_t lds_bytes = ldsq ? (((size_t)(stride + 7) / 8 * 64 + 3) / 4) * 16 + list_bytes : 0;
     const size_t lds_bytes_p3 = ldsq ? (((size_t)(stride + 7) / 8 * 64 + 3) / 4 + 64) * 16 : 0;   // read + slack for nibbles_at
     int waves_per_cu = 0, waves_per_cu_p3 = 0, n_cu = 0;
     {
@@ -952,16 +973,16 @@ extern "C" int gab_fmi_seed_device(gab_fmi *h, const uint8_t *d_enc, int32_t str
                 // runs as a second launch of the same kernel with no list area and twice the waves
                 hipLaunchKernelGGL(fmi_seed_kernel<true>, dim3(seed_blocks), dim3(64), lds_bytes, s, h->ix, d_enc, stride, d_len, first,
                                    nb, min_seed_len, h->prev.as<PrevRec>(), (int)stride, h->slots.as<OutRec>(), cap, d_counts, d_ct,
-                                   lds_entries, (int64_t)nreads * stride, 1);
+                                   lds_entries, (int64_t)nreads * stride, 1, narrow_lists);
                 GAB_HIP(hipMemsetAsync(&d_ct->next_read, 0, sizeof(int32_t), s));
                 const int p3_blocks = (int)std::min<int64_t>((int64_t)n_cu * waves_per_cu_p3, gab_ceil_div((int64_t)nb, 64));
                 hipLaunchKernelGGL(fmi_seed_kernel<true>, dim3(p3_blocks), dim3(64), lds_bytes_p3, s, h->ix, d_enc, stride, d_len, first,
                                    nb, min_seed_len, h->prev.as<PrevRec>(), (int)stride, h->slots.as<OutRec>(), cap, d_counts, d_ct,
-                                   0, (int64_t)nreads * stride, 2);
+                                   0, (int64_t)nreads * stride, 2, narrow_lists);
             } else
                 hipLaunchKernelGGL(fmi_seed_kernel<false>, dim3(seed_blocks), dim3(64), 0, s, h->ix, d_enc, stride, d_len, first, nb,
                                    min_seed_len, h->prev.as<PrevRec>(), (int)stride, h->slots.as<OutRec>(), cap, d_counts, d_ct, 0,
-                                   (int64_t)nreads * stride, 3);
+                                   (int64_t)nreads * stride, 3, 0);
             hipLaunchKernelGGL(fmi_sort_slots, dim3(blocks), dim3(256), 0, s, h->slots.as<OutRec>(), cap, d_counts, nb);
             GAB_HIP(hipGetLastError());
             GAB_HIP(hipEventRecord(h->ev[1], s));

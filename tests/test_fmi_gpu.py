@@ -70,11 +70,12 @@ def test_repetitive_reads_overflow_slots(tmp_path):
     f.close()
 
 
-@pytest.mark.parametrize("lds_entries", [None, "4"])
+@pytest.mark.parametrize("lds_entries", [None, "4", "wide"])
 def test_repetitive_short_reads_spill_lists(tmp_path, monkeypatch, lds_entries):
     """reads that fit the LDS path (<= 256 bases) on a repetitive reference: interval lists longer than the LDS ring
     (forced with a 4-entry ring in the second variant) spill to the global scratch and are fetched one step ahead;
-    some reads also overflow their first-pass output slot"""
+    some reads also overflow their first-pass output slot.  Small indexes use the 13-byte list entries; the third variant
+    forces the 16-byte format of indexes with 2^32 rows or more"""
     from genarchbench_amd.fmi import FMI_search
     rng = np.random.default_rng(6)
     unit = rng.integers(0, 4, 29).astype(np.uint8)
@@ -93,7 +94,8 @@ def test_repetitive_short_reads_spill_lists(tmp_path, monkeypatch, lds_entries):
         so, oo = str(tmp_path / "sm.npy"), str(tmp_path / "off.npy")
         root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
         r = subprocess.run([sys.executable, "-c", code % (root, e, l, prefix, so, oo)], capture_output=True, text=True,
-                           env=dict(os.environ, GAB_FMI_LDS_ENTRIES=lds_entries))
+                           env=dict(os.environ, GAB_FMI_WIDE_LISTS="1") if lds_entries == "wide" else
+                           dict(os.environ, GAB_FMI_LDS_ENTRIES=lds_entries))
         assert r.returncode == 0, r.stderr[-2000:]
         got = (np.load(so), np.load(oo)); ext = int(r.stdout.split()[-1])
     else:
