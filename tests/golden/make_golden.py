@@ -46,7 +46,19 @@ def make_bsw(m):
         assert outs["avx512"] == outs["avx2"] == outs["sse41"], "reference ISA variants disagree"
         with open(os.path.join(HERE, name + ".expected.txt"), "w") as f:
             f.write("\n".join(outs["avx2"]) + "\n")
+        # all six fields of the extension result: the driver prints only the score, so the
+        # reference's scalarBandedSWAWrapper AND its vector getScores16 are driven by oracle/ref_harness/bsw_full_ref.cpp
+        full = {}
+        for isa in ("avx512", "avx2"):
+            for how in ("scalar", "vector"):
+                r = subprocess.run([pyoracle.ref_path("bsw_full_ref_" + isa), inp, how], capture_output=True, text=True, check=True)
+                full[isa, how] = r.stdout
+        assert len(set(full.values())) == 1, "reference scalar / vector / ISA variants disagree on the full result"
+        assert [l.split()[1] for l in full["avx2", "scalar"].splitlines()] == [l.split("=")[1] for l in outs["avx2"]]
+        open(os.path.join(HERE, name + ".full.expected.txt"), "w").write(full["avx2", "scalar"])
         m[name] = {"generator": "tools/gen gabgen bsw", "seed": seed, "n": n, "mode": mode,
+                   "full_command": "bsw_full_ref_<avx2|avx512> <in> scalar|vector (oracle/ref_harness/bsw_full_ref.cpp on the "
+                                   "reference's scalarBandedSWAWrapper and getScores16: identical output) -> '[i] score qle tle gtle gscore max_off'",
                    "reference": "bsw/src/{main_banded,bandedSWA}.cpp built by oracle/Makefile "
                                 "(-mavx512bw, -mavx2, -msse4.1: identical output)",
                    "command": "bsw_ref_<isa> -pairs <in> -t 1 -b 512 ; grep score= stderr"}

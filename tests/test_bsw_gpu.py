@@ -4,7 +4,7 @@ import pytest
 
 from oracle import pyoracle
 from tools import gabgen
-from tests.util import GOLDEN, read_bsw_input, read_scores
+from tests.util import GOLDEN, read_bsw_full, read_bsw_input, read_scores
 
 pytestmark = pytest.mark.gpu
 
@@ -47,6 +47,22 @@ def test_full_result_and_cells(sw):
     np.testing.assert_array_equal(res.cpu().numpy(), want)
     np.testing.assert_array_equal(score.cpu().numpy(), want[:, 0])
     assert sw.last_stats()["cells"] == cells
+
+
+@pytest.mark.parametrize("name", ["bsw_bench", "bsw_adv"])
+def test_full_result_golden(sw, name):
+    """result_out (all six fields) against the reference's own scalarBandedSWAWrapper / getScores16 output"""
+    import torch
+    batch = read_bsw_input(f"{GOLDEN}/{name}.in.txt")
+    want = read_bsw_full(f"{GOLDEN}/{name}.full.expected.txt")
+    dev = torch.device("cuda:0")
+    t = lambda a: torch.from_numpy(a).to(dev)
+    score = torch.full((batch.n,), -7, dtype=torch.int32, device=dev)
+    res = torch.full((batch.n, 6), -7, dtype=torch.int32, device=dev)
+    sw.run_device(t(batch.ref), t(batch.ref_off), t(batch.qry), t(batch.qry_off), t(batch.len1), t(batch.len2), t(batch.h0),
+                  score, res, stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(res.cpu().numpy(), want)
 
 
 def test_wide_mode_large_h0(sw):

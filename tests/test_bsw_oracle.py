@@ -7,7 +7,7 @@ import pytest
 
 from oracle import pyoracle
 from tools import gabgen
-from tests.util import GOLDEN, read_bsw_input, read_scores
+from tests.util import GOLDEN, read_bsw_full, read_bsw_input, read_scores
 
 
 @pytest.mark.parametrize("name", ["bsw_bench", "bsw_adv"])
@@ -17,6 +17,29 @@ def test_oracle_matches_golden(name):
     got = pyoracle.bsw(batch)[:, 0]
     assert batch.n == len(want)
     np.testing.assert_array_equal(got, want)
+
+
+@pytest.mark.parametrize("name", ["bsw_bench", "bsw_adv"])
+def test_oracle_full_result_matches_golden(name):
+    """all six fields (score, qle, tle, gtle, gscore, max_off) against the reference's scalarBandedSWAWrapper ==
+    getScores16 output (bsw/src/bandedSWA.cpp:241-252,258-276)"""
+    batch = read_bsw_input(f"{GOLDEN}/{name}.in.txt")
+    want = read_bsw_full(f"{GOLDEN}/{name}.full.expected.txt")
+    assert want.shape == (batch.n, 6)
+    np.testing.assert_array_equal(pyoracle.bsw(batch), want)
+    np.testing.assert_array_equal(want[:, 0], read_scores(f"{GOLDEN}/{name}.expected.txt"))
+
+
+@pytest.mark.skipif(pyoracle.ref_path("bsw_full_ref_avx2") is None, reason="oracle/_ref not built (no /root/reference)")
+@pytest.mark.parametrize("how", ["scalar", "vector"])
+def test_oracle_full_result_matches_live_reference(tmp_path, how):
+    """fresh seed, adversarial mode: six fields straight against the reference's class"""
+    n, seed = 4096, 993
+    p = str(tmp_path / "in.txt")
+    gabgen.write_text("bsw", p, seed, n, 1)
+    r = subprocess.run([pyoracle.ref_path("bsw_full_ref_avx2"), p, how], capture_output=True, text=True, check=True)
+    want = np.array([[int(v) for v in l.split()[1:]] for l in r.stdout.splitlines()], np.int32)
+    np.testing.assert_array_equal(pyoracle.bsw(gabgen.bsw(seed, n, 1)), want)
 
 
 @pytest.mark.parametrize("name,seed,n,mode", [("bsw_bench", 101, 2048, 0), ("bsw_adv", 102, 1536, 1)])

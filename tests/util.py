@@ -32,6 +32,12 @@ def read_scores(path):
     return np.array([out[i] for i in range(len(out))], np.int32)
 
 
+def read_bsw_full(path):
+    """'[i] score qle tle gtle gscore max_off' lines (oracle/ref_harness/bsw_full_ref.cpp) -> int32 [n, 6]"""
+    rows = [[int(v) for v in line.split()[1:]] for line in open(path) if line.startswith("[")]
+    return np.array(rows, np.int32).reshape(-1, 6)
+
+
 def has_gpu():
     try:
         import torch
