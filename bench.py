@@ -24,6 +24,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+ROUND = "r02"           # prefix of this round's evidence under profiles/
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
@@ -38,7 +39,7 @@ TRAFFIC_KERNELS = {"bsw": (["bsw_dp8"], False), "chain": (["chain_hw_kernel"], F
 
 def pmc_traffic(name, is_large, kernel_ms):
     """-> (GB/s over the live kernel time, detail dict) or (None, None)"""
-    path = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
+    path = os.path.join(ROOT, "profiles", f"{ROUND}_hbm_traffic.json")      # this round's table or nothing: never a stale one
     if not is_large or name not in TRAFFIC_KERNELS or not os.path.exists(path) or not kernel_ms:
         return None, None
     tab = json.load(open(path)).get(name, {})
@@ -49,7 +50,7 @@ def pmc_traffic(name, is_large, kernel_ms):
         return None, None
     return round((f + w) / (kernel_ms * 1e-3), 3), {"fetch_GB_per_step": round(f, 3), "write_GB_per_step": round(w, 3),
                                                      "fetch_correction": "x2 (wide coalesced streams)" if double_fetch else "none (narrow or random accesses)",
-                                                     "source": "profiles/r01_hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, one step"}
+                                                     "source": f"profiles/{ROUND}_hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, one step"}
 
 
 def host_cores():
@@ -66,6 +67,69 @@ def host_cores():
 
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
+
+
+# ---- the host-pointer path: what a drop-in driver times ("ROI on GPU includes H2D of packed inputs, kernels,
+# and D2H of results").  Same scheme as benchmarks/common/gab_driver.h: the item range is cut into chunks, WORKERS host
+# threads (each with its own engine handle = its own stream) pull chunk indices from a shared cursor and call the
+# host-pointer entry point gab_*_run on page-locked slabs, so one chunk's copies run under another chunk's kernels.
+HOST_WORKERS = int(os.environ.get("GAB_WORKERS_PER_GPU", "2"))
+
+
+def pin(*arrays):
+    """page-lock numpy arrays in place (gab_host_register), as the drivers do with their slabs before the ROI"""
+    import ctypes as C
+    from genarchbench_amd._lib import lib
+    done = []
+    for a in arrays:
+        if a.nbytes and lib().gab_host_register(C.c_void_p(a.ctypes.data), C.c_size_t(a.nbytes)) == 0:
+            done.append(a)
+    return done
+
+
+def unpin(arrays):
+    import ctypes as C
+    from genarchbench_amd._lib import lib
+    for a in arrays:
+        lib().gab_host_unregister(C.c_void_p(a.ctypes.data))
+
+
+def host_queue(nchunks, make_state, run_chunk, close_state, passes=3):
+    """-> best wall time (s) of `passes` timed passes after one untimed pass (device buffers get allocated there)"""
+    import threading
+    states = [make_state() for _ in range(HOST_WORKERS)]
+    err = []
+
+    def one_pass():
+        cur = [0]
+        lock = threading.Lock()
+
+        def worker(st):
+            try:
+                while True:
+                    with lock:
+                        c = cur[0]; cur[0] += 1
+                    if c >= nchunks:
+                        return
+                    run_chunk(st, c)            # a ctypes call: the GIL is released while it runs
+            except Exception as e:              # noqa: BLE001
+                err.append(e)
+        th = [threading.Thread(target=worker, args=(st,)) for st in states]
+        t0 = time.perf_counter()
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        return time.perf_counter() - t0
+    try:
+        one_pass()
+        best = min(one_pass() for _ in range(passes))
+    finally:
+        for st in states:
+            close_state(st)
+    if err:
+        raise err[0]
+    return best
 
 
 # ------------------------------------------------------------------------------------- bsw
@@ -142,6 +206,29 @@ class BswWorkload:
                 "note": "bsw is integer-VALU/LDS bound by construction (~7.4k DP cells per ~210 input bytes); "
                         "see gcups in 'extra'"}
 
+    def host_roi(self, chunk=1 << 20):
+        import ctypes as C
+        from genarchbench_amd._lib import check, lib
+        from genarchbench_amd.bsw import BandedPairWiseSW
+        b, n = self.batch, self.items
+        score = np.full(n, -1, np.int32)
+        pinned = pin(b.ref, b.qry, b.ref_off, b.qry_off, b.len1, b.len2, b.h0, score)
+        at = lambda a, i: C.c_void_p(a.ctypes.data + a.itemsize * i)
+        dv = self.sw.device
+
+        def run(st, c):
+            lo, hi = c * chunk, min(n, (c + 1) * chunk)
+            check(lib().gab_bsw_run(st._h, at(b.ref, 0), at(b.ref_off, lo), at(b.qry, 0), at(b.qry_off, lo), at(b.len1, lo), at(b.len2, lo),
+                                    at(b.h0, lo), C.c_int64(hi - lo), at(score, lo)))
+        try:
+            sec = host_queue((n + chunk - 1) // chunk, lambda: BandedPairWiseSW(device=dv), run, lambda st: st.close())
+        finally:
+            unpin(pinned)
+        assert np.array_equal(score, self.score.cpu().numpy()), "host-pointer path and device path disagree"
+        return {"ms": round(sec * 1e3, 3), "value": round(n / sec / 1e6, 3), "unit": self.unit, "chunk": chunk, "workers_per_gpu": HOST_WORKERS,
+                "note": "gab_bsw_run on page-locked host slabs, chunks pulled by worker threads (the C driver's ROI): H2D + sort + DP + D2H; "
+                        "all scores equal to the device path's"}
+
     def cpu_baseline(self, cores):
         """the compiled reference (oracle/_ref) if it travelled, else the oracle port; bounded sample"""
         from oracle import pyoracle
@@ -155,18 +242,20 @@ class BswWorkload:
                 p = os.path.join(td, "bsw.txt")
                 gabgen.write_text("bsw", p, self.seed, n, 0)
                 env = dict(os.environ, OMP_PROC_BIND="true", OMP_PLACES="cores")
-                r = subprocess.run([exe, "-pairs", p, "-t", str(cores), "-b", "512"], capture_output=True,
-                                   text=True, env=env)
-                m = re.search(r"Overall SW cycles = \d+, ([\d.]+) s", r.stdout)
-                if r.returncode == 0 and m and float(m.group(1)) > 0:
-                    # two decimals only in the reference's print -> recompute from cycles / freq
-                    cyc = int(re.search(r"Overall SW cycles = (\d+)", r.stdout).group(1))
-                    mhz = float(re.search(r"Processor freq: ([\d.]+) MHz", r.stdout).group(1))
-                    sec = cyc / (mhz * 1e6)
+                secs = []
+                for _ in range(3):          # the ROI of the sample is ~0.5 s and varies by 10-20 % between runs: three runs, median
+                    r = subprocess.run([exe, "-pairs", p, "-t", str(cores), "-b", "512"], capture_output=True, text=True, env=env)
+                    m = re.search(r"Overall SW cycles = (\d+)", r.stdout)
+                    f = re.search(r"Processor freq: ([\d.]+) MHz", r.stdout)
+                    if r.returncode != 0 or not m or not f or int(m.group(1)) <= 0:
+                        break
+                    secs.append(int(m.group(1)) / (float(f.group(1)) * 1e6))      # two decimals only in its "%0.2lf s": recompute
+                if len(secs) == 3:
+                    sec = sorted(secs)[1]
                     return {"value": round(n / sec / 1e6, 4), "unit": self.unit, "cores": cores,
-                            "kind": "reference",
+                            "kind": "reference", "runs_M_per_s": [round(n / x / 1e6, 3) for x in secs],
                             "sample": f"first {n} pairs of the same seeded input, reference main_bsw ({isa} build) "
-                                      f"-t {cores} -b 512, its own ROI timer ({sec:.2f} s)"}
+                                      f"-t {cores} -b 512, its own ROI timer: median of three runs ({sec:.2f} s; all three in runs_M_per_s)"}
                 log("reference binary failed, falling back to the oracle port:", r.stderr[-300:])
         n = min(self.items, 400_000)
         b = self.batch
@@ -204,7 +293,8 @@ class ChainWorkload:
         self.y = torch.from_numpy(b.y.view(np.int64)).to(dev)
         self.score = torch.empty(b.nanchors, dtype=torch.int32, device=dev)
         self.parent = torch.empty(b.nanchors, dtype=torch.int32, device=dev)
-        self.eng = ChainEngine(device=dev.index or 0)
+        self.dev_index = dev.index or 0
+        self.eng = ChainEngine(device=self.dev_index)
         self.alg_bytes = 24 * b.nanchors + 24 * items      # 24 B per seed + header
         self.kernel_ms = []
         self.evals = 0
@@ -248,6 +338,44 @@ class ChainWorkload:
                 "frac": round(ach / HBM_PEAK_GBS, 6), "traffic": None,
                 "note": "24 B/seed of HBM traffic vs ~100-200 predecessor evaluations/seed served from "
                         "registers/L1/L2: latency+VALU bound by construction; see g_evals_per_s"}
+
+    def host_roi(self):
+        import ctypes as C
+        from genarchbench_amd._lib import check, lib
+        from genarchbench_amd.chain import ChainEngine
+        b = self.batch
+        score = np.full(b.nanchors, -7, np.int32); parent = np.full(b.nanchors, -7, np.int32)
+        pinned = pin(b.x, b.y, score, parent)
+        at = lambda a, i: C.c_void_p(a.ctypes.data + a.itemsize * i)
+        # chunks of calls as benchmarks/chain/src/main.c cuts them: ~equal anchor counts, offsets re-based to the window
+        nchunks = int(os.environ.get("GAB_CHAIN_HOST_CHUNKS", "1"))
+        per = b.nanchors // nchunks + 1
+        beg, acc = [0], 0
+        for c in range(self.calls):
+            acc += int(b.hdr["n"][c])
+            if acc >= per and len(beg) < nchunks:
+                beg.append(c + 1); acc = 0
+        beg.append(self.calls)
+        offs = [np.ascontiguousarray(b.call_off[beg[k]:beg[k + 1]] - b.call_off[beg[k]]) for k in range(len(beg) - 1)]
+        dv = self.dev_index
+
+        def run(st, k):
+            lo, hi = beg[k], beg[k + 1]
+            if hi <= lo:
+                return
+            a0 = int(b.call_off[lo])
+            check(lib().gab_chain_run(st._h, C.c_int(self.mode), at(b.x, a0), at(b.y, a0), at(offs[k], 0), at(b.hdr, lo), C.c_int64(hi - lo),
+                                      at(score, a0), at(parent, a0)))
+        try:
+            sec = host_queue(len(beg) - 1, lambda: ChainEngine(device=dv), run, lambda st: st.close())
+        finally:
+            unpin(pinned)
+        assert np.array_equal(score, self.score.cpu().numpy()) and np.array_equal(parent, self.parent.cpu().numpy()), \
+            "host-pointer path and device path disagree"
+        return {"ms": round(sec * 1e3, 3), "value": round(b.nanchors / sec / 1e6, 3), "unit": self.unit, "chunks": len(beg) - 1,
+                "workers_per_gpu": HOST_WORKERS,
+                "note": "gab_chain_run on page-locked host arrays (the C driver's ROI): H2D of x, y + kernel + D2H of scores, parents; "
+                        "all results equal to the device path's"}
 
     def cpu_baseline(self, cores):
         from oracle import pyoracle
@@ -868,36 +996,42 @@ class ParseBswWorkload:
 
 WORKLOADS = {"bitpal": BitpalWorkload, "bitpal-edit": BitpalEditWorkload, "parse-bsw": ParseBswWorkload, "fmi": FmiWorkload, "fmi-sa": FmiSaWorkload, "wfa": WfaWorkload, "bpm": BpmWorkload, "bsw": BswWorkload, "chain": ChainWorkload, "fast-chain": FastChainWorkload}
 
+# The default run reports the whole metric of BASELINE.json ("M alignments/sec (bsw, bpm, wfa) + M seeds/sec (chain)"):
+# the headline line is bsw-large (configs[1], the configuration the metric is quoted on) and `extra.suite` carries the other
+# LARGE configurations (configs[2], configs[3], the fmi part of configs[4]) and the suite's SMALL inputs, each measured by
+# the same code path with its own roofline, CPU baseline and parity verdict.  (name, workload, items or None = large, steps)
+SUITE = [("chain-large", "chain", None, 5), ("fast-chain-large", "fast-chain", None, 5), ("bpm-large", "bpm", None, 5),
+         ("wfa-large", "wfa", None, 5),
+         ("bsw-small", "bsw", 100_000, 10), ("bpm-small", "bpm", 100_000, 10), ("wfa-small", "wfa", 100_000, 10),
+         ("chain-small", "chain", 1000, 10), ("fast-chain-small", "fast-chain", 1000, 10),
+         ("fmi-large", "fmi", None, 3)]
+SUITE_BUDGET_S = float(os.environ.get("GAB_BENCH_BUDGET_S", "400"))    # entries that would start after this are skipped (and say so)
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="bsw", choices=sorted(WORKLOADS))
-    ap.add_argument("--items", type=int, default=0, help="items per GPU per step (default: the large config)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-check", action="store_true")
-    args = ap.parse_args()
 
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks as a CHILD process
+    (torch.distributed.run, one rank per GPU) before this process has made any GPU call, pass its output through and
+    leave with its exit code.  A process that has touched the GPU is never replaced."""
+    import torch                                   # importing torch / counting devices does not initialise the GPU
+    have = torch.cuda.device_count()
+    if have < args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but only {have} GPU(s) are visible")
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), MASTER_ADDR="127.0.0.1")
+    log("bench.py: starting", args.gpus, "ranks:", " ".join(cmd))
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+def run_workload(W, items, steps, warmup, ctx, args, with_cpu=True, with_host=True):
+    """one workload, the bench contract's way: W untimed warm-up steps, K timed steps between barrier + synchronize on both
+    sides, MAX over ranks.  Returns the result dict on rank 0 (None elsewhere)."""
     import torch
-    import torch.distributed as dist
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: libgab_hip has no CPU fallback")
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    dev = torch.device("cuda", local_rank if world > 1 else 0)
-    torch.cuda.set_device(dev)
-    assert args.gpus == world or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-
-    W = WORKLOADS[args.workload]
-    items = args.items or W.default_items
+    rank, world, dev, dist = ctx["rank"], ctx["world"], ctx["dev"], ctx["dist"]
     wl = W(items, rank, dev)
     stream = torch.cuda.current_stream().cuda_stream
 
@@ -907,13 +1041,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         wl.step(stream)
         torch.cuda.synchronize()
         wl.after_step(False)
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         wl.step(stream)
         wl.after_step(True)          # reads the step's HIP events (waits for the step, as the ROI does)
     barrier()
@@ -923,29 +1057,117 @@ def main():
     elapsed, total_units = aggregate(elapsed, units, dist if world > 1 else None, dev)
 
     verdict = None if args.no_check else wl.check()
+    out = None
     if rank == 0:
-        ms = elapsed / args.steps * 1e3
+        ms = elapsed / steps * 1e3
         value = total_units / (ms * 1e-3) / 1e6       # units of all ranks / max-over-ranks time
+        large = items == W.default_items
         out = {
             "metric": W.metric, "value": round(value, 4), "unit": W.unit, "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4),
+            "steps": steps, "warmup": warmup, "ms_per_step": round(ms, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": W.dtype,
             "data": "synthetic (seeded generator tools/gen, SURVEY.md 8d distributions)",
-            "config": {"workload": f"{W.name}-large" if items == W.default_items else f"{W.name}-{items}",
+            "config": {"workload": f"{W.name}-large" if large else f"{W.name}-{items}",
                        "items_per_gpu": items, "sharding": f"{world} x independent id ranges, no collective"},
             "roofline": wl.roofline(), "extra": wl.extra(ms), "parity": verdict,
         }
         km = out["extra"].get("dominant_kernel_ms")
-        t, detail = pmc_traffic(W.name, items == W.default_items, km)
+        t, detail = pmc_traffic(W.name, large, km)
         if t is not None:
             out["roofline"]["traffic"] = t                  # GB/s of real HBM traffic, comparable with `achieved`
             out["roofline"]["traffic_detail"] = detail
         # BASELINE.md 3.5 also asks for the fraction of the MEASURED copy bandwidth (6.29 TB/s, MI355X_MICROARCH.md)
         if out["roofline"].get("unit") == "GB/s" and out["roofline"].get("achieved") is not None:
             out["roofline"]["frac_of_measured_copy_6290"] = round(out["roofline"]["achieved"] / 6290.0, 6)
-        if not args.no_cpu_baseline:
-            cores = host_cores()
-            out["cpu_baseline"] = wl.cpu_baseline(cores)
+        if with_host and hasattr(wl, "host_roi") and not args.no_host_roi:
+            # what a drop-in driver times: host pointers in, host pointers out (PCIe both ways), never `value`
+            try:
+                out["extra"]["roi_incl_pcie"] = wl.host_roi()
+            except Exception as e:      # the figure is informative; a failure must not lose the measured line
+                out["extra"]["roi_incl_pcie"] = {"error": str(e)[:300]}
+        if with_cpu and not args.no_cpu_baseline:
+            out["cpu_baseline"] = wl.cpu_baseline(host_cores())
+            cb, v = out["cpu_baseline"], out["value"]
+            if cb.get("value"):
+                out["extra"]["x_cpu_baseline"] = round(v / world / cb["value"], 2)      # one GPU vs the host's cores
+    del wl
+    torch.cuda.empty_cache()
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS),
+                    help="one workload only (default: bsw-large as the headline + the suite in extra.suite)")
+    ap.add_argument("--items", type=int, default=0, help="items per GPU per step (default: the large config)")
+    ap.add_argument("--no-suite", action="store_true", help="headline only")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-roi", action="store_true")
+    ap.add_argument("--no-check", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "0") or 0)
+    if world == 0 and args.gpus > 1:
+        self_launch(args)                          # does not return
+    world = max(world, 1)
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: start it as `python bench.py --gpus N` "
+                         f"or under torch.distributed.run with --nproc-per-node equal to --gpus")
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: libgab_hip has no CPU fallback")
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    torch.cuda.set_device(dev)
+    ctx = {"rank": rank, "world": world, "dev": dev, "dist": dist}
+    t_start = time.time()
+
+    W = WORKLOADS[args.workload or "bsw"]
+    out = run_workload(W, args.items or W.default_items, args.steps, args.warmup, ctx, args)
+
+    if args.workload is None and not args.items and not args.no_suite:
+        suite = {}
+        for name, wname, items, steps in SUITE:
+            go = [time.time() - t_start < SUITE_BUDGET_S]
+            if world > 1:
+                dist.broadcast_object_list(go, src=0)           # every rank takes the same branch
+            if not go[0]:
+                suite[name] = {"skipped": f"time budget of {SUITE_BUDGET_S:.0f} s reached (GAB_BENCH_BUDGET_S); run --workload {wname}"}
+                continue
+            SW = WORKLOADS[wname]
+            t0 = time.time()
+            try:
+                r = run_workload(SW, items or SW.default_items, min(steps, max(args.steps, 1)), 1, ctx, args,
+                                 with_host=items is None)
+            except Exception as e:
+                if world > 1:
+                    raise
+                log(f"suite entry {name} failed: {e}")
+                suite[name] = {"error": str(e)[:300]}
+                continue
+            if r is not None:
+                keep = {k: r[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "dtype", "config", "roofline", "parity") if k in r}
+                keep["cpu_baseline"] = r.get("cpu_baseline")
+                keep["extra"] = r.get("extra")
+                keep["wall_s"] = round(time.time() - t0, 1)
+                suite[name] = keep
+                log(f"suite: {name}: {r['value']} {r['unit']} ({keep['wall_s']} s)")
+        if out is not None:
+            out["extra"]["suite"] = suite
+            out["extra"]["suite_note"] = ("one entry per configuration of BASELINE.json's metric besides the headline, same contract "
+                                          "(value = whole-job throughput with inputs resident in HBM, max over ranks)")
+    if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

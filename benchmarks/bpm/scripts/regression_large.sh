@@ -11,7 +11,8 @@ binaries_path="$(dirname "$scriptfolder")"
 clean=1
 job="BPM-REGRESSION-LARGE"
 before_command=""
-commands=( "$binaries_path/bin/align_benchmark" )
+# $GAB_BPM_COMMAND substitutes another binary with the same CLI (e.g. the compiled reference, to run this harness on a box without a GPU)
+commands=( "${GAB_BPM_COMMAND:-$binaries_path/bin/align_benchmark}" )
 parallelism=( 'nodes=1, mpi=1, omp=1, gpus=1' )
 [[ -n "$GAB_REGRESSION_GPUS" ]] && parallelism+=( "nodes=1, mpi=1, omp=1, gpus=$GAB_REGRESSION_GPUS" )
 command_opts="-a bpm-edit -i \"$inputs_path/BPM_SRR7733443_10m_input.txt\" -o checksum.file -t \$OMP_NUM_THREADS"
@@ -20,6 +21,8 @@ after_run() (
     job_name="$1"
     kernel_time="$(grep "Time.Benchmark" "$job_name.err" | tr -s " " | cut -d " " -f 3,4)"
     sort -n -t "[" -k 2,2 checksum.file | diff --brief - "$inputs_path/output-reference.file" >/dev/null 2>&1 || { echo "The output file is not identical to the reference file"; return 1; }
-    echo "Kernel execution time $kernel_time"; return 0
+    echo "Kernel execution time $kernel_time"
+    grep "Energy consumption:" "$job_name.err"
+    return 0
 )
 source "$scriptfolder/../../run_wrapper.sh"

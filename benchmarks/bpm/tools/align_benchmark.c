@@ -10,29 +10,32 @@
  * pairs, one host thread per GPU; benchmark_bitpal_m0_x1_g1 / _m1_x4_g2 (-a bitpal-edit / bitpal-scored, :259-264)
  * become gab_bitpal_run the same way.  The driver applies the reference's swap: the longer line is the pattern.
  */
+#define GAB_ENERGY_STREAM stderr      /* where the reference prints "Energy consumption:" in this driver */
 #include "../../common/gab_pairs.h"
 #include <getopt.h>
 
-#define CHUNK_PAIRS (1 << 20)
+#define CHUNK_PAIRS (1 << 20)   /* default chunk of the work queue; $GAB_CHUNK overrides it */
 typedef struct {
     const gab_pairs *p;
     int64_t *poff, *toff; int32_t *plen, *tlen;
     int32_t *score;
     int bitpal;                  /* -1: bpm-edit, else GAB_BITPAL_EDIT / GAB_BITPAL_SCORED */
+    int64_t chunk;
 } bpm_ctx;
-static void *gpu_init(int gpu, void *vc) {
+static void *gpu_init(int worker, int gpu, void *vc) {
+    (void)worker;
     bpm_ctx *c = (bpm_ctx *)vc;
     if (c->bitpal >= 0) { gab_bitpal *h = NULL; GAB_DIE_IF(gab_bitpal_create(c->bitpal, gpu, &h), "gab_bitpal_create"); return h; }
     gab_bpm *h = NULL; GAB_DIE_IF(gab_bpm_create(gpu, &h), "gab_bpm_create"); return h;
 }
-static void gpu_fini(int gpu, void *vc, void *st) {
-    (void)gpu;
+static void gpu_fini(int worker, int gpu, void *vc, void *st) {
+    (void)gpu; (void)worker;
     if (((bpm_ctx *)vc)->bitpal >= 0) gab_bitpal_destroy((gab_bitpal *)st); else gab_bpm_destroy((gab_bpm *)st);
 }
-static void run_chunk(int gpu, int64_t chunk, void *vctx, void *st) {
-    (void)gpu;
+static void run_chunk(int worker, int gpu, int64_t chunk, void *vctx, void *st) {
+    (void)gpu; (void)worker;
     bpm_ctx *c = (bpm_ctx *)vctx;
-    const int64_t b = chunk * CHUNK_PAIRS, e = b + CHUNK_PAIRS < c->p->n ? b + CHUNK_PAIRS : c->p->n;
+    const int64_t b = chunk * c->chunk, e = b + c->chunk < c->p->n ? b + c->chunk : c->p->n;
     if (c->bitpal >= 0)
         GAB_DIE_IF(gab_bitpal_run((gab_bitpal *)st, c->p->slab, c->poff + b, c->plen + b, c->p->slab, c->toff + b, c->tlen + b, e - b,
                                   c->score + b), "gab_bitpal_run");
@@ -84,10 +87,8 @@ int main(int argc, char **argv) {
     FILE *out = output ? fopen(output, "w") : NULL;
     /* GAB_GPU_PARSE=1 (one GPU): the file is read in one piece and indexed ON the GPU (gab_pairs_parse with the swap rule,
      * SURVEY.md 8f row f1); the sequences are used in place in the device copy of the text. */
-    if (getenv("GAB_GPU_PARSE") && atoi(getenv("GAB_GPU_PARSE")) && gab_pick_gpus(gpus) == 1) {
-        fseek(in, 0L, SEEK_END);
-        const long fsz = ftell(in);
-        fseek(in, 0L, SEEK_SET);
+    const int64_t fsz = gab_regular_file_size(in);      /* -1 for pipes: they take the getline path */
+    if (getenv("GAB_GPU_PARSE") && atoi(getenv("GAB_GPU_PARSE")) && fsz >= 0 && gab_pick_gpus(gpus) == 1) {
         char *whole = (char *)malloc((size_t)fsz + 1);
         gab_parser *ps = NULL; gab_pairs_packed pk;
         if (whole && fread(whole, 1, (size_t)fsz, in) == (size_t)fsz && gab_parser_create(0, &ps) == 0 &&
@@ -136,14 +137,18 @@ int main(int argc, char **argv) {
         ctx.toff[i] = sw ? p.off1[i] : p.off2[i]; ctx.tlen[i] = sw ? p.len1[i] : p.len2[i];
     }
     const int ngpus = gab_pick_gpus(gpus);
+    ctx.chunk = gab_env_i64("GAB_CHUNK", CHUNK_PAIRS);
+    gab_pin(p.slab, p.used); gab_pin(ctx.poff, 8 * (size_t)p.n); gab_pin(ctx.toff, 8 * (size_t)p.n);
+    gab_pin(ctx.plen, 4 * (size_t)p.n); gab_pin(ctx.tlen, 4 * (size_t)p.n); gab_pin(ctx.score, 4 * (size_t)p.n);
     gab_queue q;
     gab_queue_open(&q, ngpus, gpu_init, run_chunk, gpu_fini, &ctx);
     const double t0 = gab_now();                 /* ROI: align_benchmark.c:213-337 */
-    gab_roi_begin();
-    gab_queue_run(&q, (p.n + CHUNK_PAIRS - 1) / CHUNK_PAIRS);
+    gab_roi_begin_n(ngpus);
+    gab_queue_run(&q, (p.n + ctx.chunk - 1) / ctx.chunk);
     gab_roi_end();
     const double sec = gab_now() - t0;
     gab_queue_close(&q);
+    gab_unpin(p.slab); gab_unpin(ctx.poff); gab_unpin(ctx.toff); gab_unpin(ctx.plen); gab_unpin(ctx.tlen); gab_unpin(ctx.score);
     if (out) { for (int64_t i = 0; i < p.n; i++) fprintf(out, "[%ld] score=%d\n", (long)i, ctx.score[i]); fclose(out); }
     fprintf(stderr, "[Benchmark]\n");
     fprintf(stderr, "=> Total.reads            %ld\n", (long)p.n);

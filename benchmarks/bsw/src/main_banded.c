@@ -8,8 +8,10 @@
  *            [-g <gpus>]
  *
  * Instead of T OpenMP threads each calling getScores16 on batches of B pairs (main_banded.cpp:338-350),
- * the ROI makes gab_bsw_run calls on chunks of pairs pulled by one host thread per GPU.  -t and -b are
- * accepted and ignored (they tune the CPU path only); -g / $GAB_GPUS selects the number of GPUs.
+ * the ROI makes gab_bsw_run calls on chunks of pairs ($GAB_CHUNK, default 2^20) pulled from a shared cursor by
+ * $GAB_WORKERS_PER_GPU host threads per GPU (default 2, each with its own handle: the H2D copy of one chunk runs under
+ * the kernels of another).  -t and -b are accepted and ignored (they tune the CPU path only); -g / $GAB_GPUS selects the
+ * number of GPUs.
  *
  * GAB_GPU_PARSE=1 (one GPU): the input file is read in one piece and parsed ON the GPU (gab_bsw_parse_pairs, SURVEY.md
  * 8f row f1) instead of line by line with fgets / sscanf; the packed buffers stay on the device and the ROI calls
@@ -21,7 +23,7 @@
 
 #define MAX_SEQ_LEN_REF 2048   /* main_banded.cpp:76-79 */
 #define MAX_SEQ_LEN_QER 256
-#define CHUNK_PAIRS (1 << 20)
+#define CHUNK_PAIRS (1 << 20)   /* default chunk of the work queue; $GAB_CHUNK overrides it */
 
 typedef struct {
     gab_bsw_params prm;
@@ -29,25 +31,27 @@ typedef struct {
     const int64_t *ref_off, *qry_off;
     const int32_t *len1, *len2, *h0;
     int32_t *score;
-    int64_t n;
-    double *busy;   /* per-GPU seconds inside gab_bsw_run */
+    int64_t n, chunk;
+    double *busy;   /* per-worker seconds inside gab_bsw_run */
 } bsw_ctx;
 
-static void *gpu_init(int gpu, void *vctx) {
+static void *gpu_init(int worker, int gpu, void *vctx) {
+    (void)worker;
     bsw_ctx *c = (bsw_ctx *)vctx;
     gab_bsw *h = NULL;
     GAB_DIE_IF(gab_bsw_create(&c->prm, gpu, &h), "gab_bsw_create");
     return h;
 }
-static void gpu_fini(int gpu, void *vctx, void *st) { (void)gpu; (void)vctx; gab_bsw_destroy((gab_bsw *)st); }
-static void run_chunk(int gpu, int64_t chunk, void *vctx, void *st) {
+static void gpu_fini(int worker, int gpu, void *vctx, void *st) { (void)worker; (void)gpu; (void)vctx; gab_bsw_destroy((gab_bsw *)st); }
+static void run_chunk(int worker, int gpu, int64_t chunk, void *vctx, void *st) {
+    (void)gpu;
     bsw_ctx *c = (bsw_ctx *)vctx;
-    const int64_t b = chunk * CHUNK_PAIRS, e = b + CHUNK_PAIRS < c->n ? b + CHUNK_PAIRS : c->n;
+    const int64_t b = chunk * c->chunk, e = b + c->chunk < c->n ? b + c->chunk : c->n;
     const double t0 = gab_now();
     /* offsets are absolute into the slabs, so a chunk is just a window of the per-pair arrays */
     GAB_DIE_IF(gab_bsw_run((gab_bsw *)st, c->ref, c->ref_off + b, c->qry, c->qry_off + b, c->len1 + b, c->len2 + b,
                            c->h0 + b, e - b, c->score + b), "gab_bsw_run");
-    c->busy[gpu] += gab_now() - t0;
+    c->busy[worker] += gab_now() - t0;
 }
 
 /* 5x5 matrix exactly as bwa_fill_scmat, main_banded.cpp:94-102 */
@@ -83,11 +87,10 @@ int main(int argc, char *argv[]) {
     FILE *pairFile = fopen(pairFileName, "r");
     if (!pairFile) { fprintf(stderr, "Could not open file: %s\n", pairFileName); exit(EXIT_FAILURE); }
 
-    if (getenv("GAB_GPU_PARSE") && atoi(getenv("GAB_GPU_PARSE")) && gab_pick_gpus(gpus) == 1) {
+    /* a pipe / process substitution has no size: only regular files take the whole-file GPU parser */
+    const int64_t fsz = gab_regular_file_size(pairFile);
+    if (getenv("GAB_GPU_PARSE") && atoi(getenv("GAB_GPU_PARSE")) && fsz >= 0 && gab_pick_gpus(gpus) == 1) {
         const double tR0 = gab_now();
-        fseek(pairFile, 0L, SEEK_END);
-        const long fsz = ftell(pairFile);
-        fseek(pairFile, 0L, SEEK_SET);
         char *whole = (char *)malloc((size_t)fsz + 1);
         gab_parser *ps = NULL; gab_bsw_packed pk;
         if (whole && fread(whole, 1, (size_t)fsz, pairFile) == (size_t)fsz && gab_parser_create(0, &ps) == 0 &&
@@ -129,7 +132,8 @@ int main(int argc, char *argv[]) {
         fseek(pairFile, 0L, SEEK_SET);
     }
 
-    /* numPairs = newline count / 3 (main_banded.cpp:237-253) */
+    /* numPairs = newline count / 3 (main_banded.cpp:237-253); the reference counts with fread + fseek, so it needs a
+     * seekable file too */
     size_t numLines = 0, nread;
     {
         const size_t bufSize = 1 << 20;
@@ -137,7 +141,7 @@ int main(int argc, char *argv[]) {
         while ((nread = fread(buffer, 1, bufSize, pairFile)) > 0)
             for (size_t i = 0; i < nread; i++) numLines += buffer[i] == '\n';
         free(buffer);
-        fseek(pairFile, 0L, SEEK_SET);
+        if (fseek(pairFile, 0L, SEEK_SET) != 0) { fprintf(stderr, "ERROR: %s is not seekable\n", pairFileName); exit(EXIT_FAILURE); }
     }
     const int64_t numPairs = (int64_t)(numLines / 3);
     printf("Number of input pairs: %ld\n", (long)numPairs);
@@ -181,19 +185,26 @@ int main(int argc, char *argv[]) {
     fill_scmat(w_match, w_mismatch, w_ambig, ctx.prm.mat);
     ctx.ref = ref; ctx.qry = qry; ctx.ref_off = ref_off; ctx.qry_off = qry_off;
     ctx.len1 = len1; ctx.len2 = len2; ctx.h0 = h0; ctx.score = score; ctx.n = n;
+    ctx.chunk = gab_env_i64("GAB_CHUNK", CHUNK_PAIRS);
     const int ngpus = gab_pick_gpus(gpus);
-    ctx.busy = (double *)calloc((size_t)ngpus, sizeof(double));
+    /* the slabs the ROI reads and writes are page-locked where the reference _mm_malloc's its own (main_banded.cpp:260-264) */
+    gab_pin(ref, refUsed + 8); gab_pin(qry, qryUsed + 8);
+    gab_pin(ref_off, 8 * (size_t)n); gab_pin(qry_off, 8 * (size_t)n);
+    gab_pin(len1, 4 * (size_t)n); gab_pin(len2, 4 * (size_t)n); gab_pin(h0, 4 * (size_t)n); gab_pin(score, 4 * (size_t)n);
     gab_queue q;
     gab_queue_open(&q, ngpus, gpu_init, run_chunk, gpu_fini, &ctx);     /* like `new BandedPairWiseSW` per thread: before the ROI */
+    ctx.busy = (double *)calloc((size_t)q.nworkers, sizeof(double));
 
     /* ---- region of interest (main_banded.cpp:290-389) ---- */
     const double t0 = gab_now();
-    gab_roi_begin();
-    gab_queue_run(&q, (n + CHUNK_PAIRS - 1) / CHUNK_PAIRS);
+    gab_roi_begin_n(ngpus);
+    gab_queue_run(&q, (n + ctx.chunk - 1) / ctx.chunk);
     gab_roi_end();
     const double roi = gab_now() - t0;
-    for (int g = 0; g < ngpus; g++) printf("%d] workTicks = %ld\n", g, (long)(ctx.busy[g] * 1e9));
+    const int nworkers = q.nworkers;
+    for (int k = 0; k < nworkers; k++) printf("%d] workTicks = %ld\n", k, (long)(ctx.busy[k] * 1e9));
     gab_queue_close(&q);
+    gab_unpin(ref); gab_unpin(qry); gab_unpin(ref_off); gab_unpin(qry_off); gab_unpin(len1); gab_unpin(len2); gab_unpin(h0); gab_unpin(score);
 
     printf("Executed HIP gfx950 code on %d GPU(s)...\n", ngpus);
     for (int64_t i = 0; i < n; ++i) fprintf(stderr, "[%ld] score=%d\n", (long)i, score[i]);
@@ -203,8 +214,8 @@ int main(int argc, char *argv[]) {
     printf("Overall SW cycles = %ld, %0.2lf s\n", (long)(roi * 1e9), roi);
     printf("Total Pairs processed: %ld\n", (long)n);
     double sum = 0, mx = 0;
-    for (int g = 0; g < ngpus; g++) { sum += ctx.busy[g]; if (ctx.busy[g] > mx) mx = ctx.busy[g]; }
-    printf("avgTicks = %lf, maxTicks = %ld, load imbalance = %lf\n", sum * 1e9 / ngpus, (long)(mx * 1e9), sum > 0 ? mx / (sum / ngpus) : 1.0);
+    for (int k = 0; k < nworkers; k++) { sum += ctx.busy[k]; if (ctx.busy[k] > mx) mx = ctx.busy[k]; }
+    printf("avgTicks = %lf, maxTicks = %ld, load imbalance = %lf\n", sum * 1e9 / nworkers, (long)(mx * 1e9), sum > 0 ? mx / (sum / nworkers) : 1.0);
     free(ref); free(qry); free(ref_off); free(qry_off); free(len1); free(len2); free(h0); free(score);
     free(lineR); free(lineQ); free(ctx.busy);
     return 0;

@@ -5,9 +5,10 @@
  * text I/O as chain/src/host_data_io.cpp:13-60.  The harness compares out.txt and greps "Time in kernel"
  * (chain/scripts/regression_small.sh:89,94).
  * The ROI call host_chain_kernel(calls, rets, numThreads) (main.cpp:154) becomes gab_chain_run over chunks
- * of calls pulled by one host thread per GPU.  Built twice: -DGAB_CHAIN_MODE=0 (chain) and =1 (fast-chain).
+ * of calls pulled by $GAB_WORKERS_PER_GPU host threads per GPU (default 2; $GAB_CHUNK = anchors per chunk).  Built twice: -DGAB_CHAIN_MODE=0 (chain) and =1 (fast-chain).
  * Extra flag: -g <gpus> (or $GAB_GPUS).  -t is accepted and ignored.
  */
+#define GAB_ENERGY_STREAM stderr      /* where the reference prints "Energy consumption:" in this driver */
 #include "../../common/gab_driver.h"
 #include <getopt.h>
 
@@ -24,15 +25,15 @@ typedef struct {
     int64_t *chunk_beg;      /* chunk c = calls [chunk_beg[c], chunk_beg[c+1]) */
 } chain_ctx;
 
-static void *gpu_init(int gpu, void *vctx) {
-    (void)vctx;
+static void *gpu_init(int worker, int gpu, void *vctx) {
+    (void)vctx; (void)worker;
     gab_chain *h = NULL;
     GAB_DIE_IF(gab_chain_create(gpu, &h), "gab_chain_create");
     return h;
 }
-static void gpu_fini(int gpu, void *vctx, void *st) { (void)gpu; (void)vctx; gab_chain_destroy((gab_chain *)st); }
-static void run_chunk(int gpu, int64_t chunk, void *vctx, void *st) {
-    (void)gpu;
+static void gpu_fini(int worker, int gpu, void *vctx, void *st) { (void)worker; (void)gpu; (void)vctx; gab_chain_destroy((gab_chain *)st); }
+static void run_chunk(int worker, int gpu, int64_t chunk, void *vctx, void *st) {
+    (void)gpu; (void)worker;
     chain_ctx *c = (chain_ctx *)vctx;
     const int64_t b = c->chunk_beg[chunk], e = c->chunk_beg[chunk + 1];
     if (e <= b) return;
@@ -91,10 +92,8 @@ int main(int argc, char **argv) {
     /* GAB_GPU_PARSE=1 (one GPU): the file is read in one piece and parsed ON the GPU (gab_chain_parse);
      * anchors stay on the device, the ROI calls gab_chain_run_device.  Files that are not in the one-record-per-line layout
      * are declined and take the fscanf path below. */
-    if (getenv("GAB_GPU_PARSE") && atoi(getenv("GAB_GPU_PARSE")) && gab_pick_gpus(gpus) == 1) {
-        fseek(in, 0L, SEEK_END);
-        const long fsz = ftell(in);
-        fseek(in, 0L, SEEK_SET);
+    const int64_t fsz = gab_regular_file_size(in);      /* -1 for pipes: they take the fscanf path */
+    if (getenv("GAB_GPU_PARSE") && atoi(getenv("GAB_GPU_PARSE")) && fsz >= 0 && gab_pick_gpus(gpus) == 1) {
         char *whole = (char *)malloc((size_t)fsz + 1);
         gab_parser *ps = NULL; gab_chain_packed pk;
         if (whole && fread(whole, 1, (size_t)fsz, in) == (size_t)fsz && gab_parser_create(0, &ps) == 0 &&
@@ -160,8 +159,11 @@ int main(int argc, char **argv) {
     ctx.x = x; ctx.y = y; ctx.call_off = call_off; ctx.hdr = hdr; ctx.ncalls = (int64_t)ncalls;
     ctx.score = (int32_t *)malloc(4 * (na + 1)); ctx.parent = (int32_t *)malloc(4 * (na + 1));
     const int ngpus = gab_pick_gpus(gpus);
-    /* chunks of ~equal anchor count; with one GPU everything is one call (longest-call-first inside) */
-    const int64_t nchunks_want = ngpus == 1 ? 1 : 8 * ngpus;
+    /* chunks of ~equal anchor count ($GAB_CHUNK anchors each when set); with one GPU everything is one call by default
+     * (a chunk takes as long as the walk of its longest call, so fewer, larger chunks are better for this kernel) */
+    const int64_t chunk_anchors = gab_env_i64("GAB_CHUNK", 0);
+    int64_t nchunks_want = chunk_anchors > 0 ? (int64_t)(na / (size_t)chunk_anchors) + 1 : (ngpus == 1 ? 1 : 8 * ngpus);
+    if (nchunks_want > (int64_t)ncalls) nchunks_want = ncalls > 0 ? (int64_t)ncalls : 1;
     ctx.chunk_beg = (int64_t *)malloc(8 * (size_t)(nchunks_want + 2));
     int64_t nchunks = 0;
     {
@@ -174,16 +176,18 @@ int main(int argc, char **argv) {
         }
         ctx.chunk_beg[++nchunks] = (int64_t)ncalls;
     }
+    gab_pin(x, 8 * na); gab_pin(y, 8 * na); gab_pin(ctx.score, 4 * na); gab_pin(ctx.parent, 4 * na);
     gab_queue q;
     gab_queue_open(&q, ngpus, gpu_init, run_chunk, gpu_fini, &ctx);
 
     /* ---- region of interest (main.cpp:111-193) ---- */
     const double t0 = gab_now();
-    gab_roi_begin();
+    gab_roi_begin_n(ngpus);
     gab_queue_run(&q, nchunks);
     gab_roi_end();
     const double runtime = gab_now() - t0;
     gab_queue_close(&q);
+    gab_unpin(x); gab_unpin(y); gab_unpin(ctx.score); gab_unpin(ctx.parent);
 
     /* print_return (host_data_io.cpp:53-60) */
     for (size_t c = 0; c < ncalls; c++) {

@@ -4,16 +4,26 @@
  * ROI switches.  The reference brackets its ROI with compile-time hooks
  * (-DPERF_ANALYSIS / -DVTUNE_ANALYSIS / -DFAPP_ANALYSIS / -DDYNAMORIO_ANALYSIS / -DPWR / -DRAPL_STOPWATCH,
  * e.g. /root/reference/benchmarks/bsw/src/main_banded.cpp:290-389).  The same -D names are accepted here so
- * existing build lines keep working: PERF_ANALYSIS drives the same perf_ctl.fifo protocol (pure POSIX);
- * the vendor-specific ones (VTune, Fujitsu fapp / Power API, DynamoRIO, RAPL) have no meaning on an
- * MI355X host path and compile to nothing -- use `rocprofv3 --kernel-trace` around the same ROI instead.
+ * existing build lines keep working:
+ *   PERF_ANALYSIS            the same perf_ctl.fifo protocol ("enable" / "disable" written to the fifo, pure POSIX);
+ *   PWR / RAPL_STOPWATCH     the reference prints "Energy consumption: %0.4lf J" of the node over the ROI (the harness
+ *                            greps it, bsw/scripts/regression_small.sh:99); here the line is the energy of the GPUs the
+ *                            run used, from ROCm SMI's accumulating energy counter (rsmi_dev_energy_count_get), loaded
+ *                            with dlopen so the drivers do not link against it; silently absent if SMI is;
+ *   VTUNE / FAPP / DYNAMORIO vendor tracers with no meaning on an MI355X host path: compile to nothing.
+ * In every build the ROI is also a roctx range ("gab_roi") when a roctx library can be dlopen'ed, so
+ * `rocprofv3 --marker-trace --kernel-trace -- <driver> ...` shows the kernels inside the same bracket the reference's
+ * profilers saw.
  *
- * Multi-GPU.  Work items are independent, so N GPUs are driven by N host threads that pull chunk indices
- * from one atomic cursor (the reference's `omp for schedule(dynamic)` over batches, lifted one level up);
- * there is no collective and no exchange step.
+ * Multi-GPU.  Work items are independent, so N GPUs are driven by host threads that pull chunk indices from one
+ * atomic cursor (the reference's `omp for schedule(dynamic)` over batches, lifted one level up); there is no
+ * collective and no exchange step.  GAB_WORKERS_PER_GPU=k (default 2) starts k such threads per GPU, each with its own
+ * engine handle and streams, so the H2D copy, the kernels and the D2H copy of consecutive chunks overlap;
+ * GAB_CHUNK=items overrides the driver's chunk size (tests use it to push small fixtures through the multi-chunk path).
  */
 #ifndef GAB_DRIVER_H
 #define GAB_DRIVER_H
+#include <dlfcn.h>
 #include <pthread.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -22,10 +32,20 @@
 #include <time.h>
 #include <fcntl.h>
 #include <unistd.h>
+#include <sys/stat.h>
 #include "gab.h"
 
 #ifndef PERF_ANALYSIS
 #define PERF_ANALYSIS 0
+#endif
+#ifndef PWR
+#define PWR 0
+#endif
+#ifndef RAPL_STOPWATCH
+#define RAPL_STOPWATCH 0
+#endif
+#ifndef GAB_ENERGY_STREAM       /* bsw and wfa print the energy line on stdout, chain / fast-chain / bpm / fmi on stderr */
+#define GAB_ENERGY_STREAM stdout
 #endif
 
 static inline double gab_now(void) {
@@ -34,19 +54,91 @@ static inline double gab_now(void) {
     return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
 }
 
+/* value of an integer environment variable, or `dflt` when unset / not positive */
+static inline int64_t gab_env_i64(const char *name, int64_t dflt) {
+    const char *e = getenv(name);
+    if (!e || !*e) return dflt;
+    const long long v = atoll(e);
+    return v > 0 ? (int64_t)v : dflt;
+}
+
+/* size of a regular file opened for reading, or -1 (pipes, /dev/stdin, process substitutions: the whole-file GPU
+ * parsers need the size up front, the line-by-line readers do not) */
+static inline int64_t gab_regular_file_size(FILE *f) {
+    struct stat st;
+    if (fstat(fileno(f), &st) != 0 || !S_ISREG(st.st_mode) || st.st_size < 0) return -1;
+    return (int64_t)st.st_size;
+}
+
+/* ---- ROI hooks ------------------------------------------------------------------------------- */
 #if PERF_ANALYSIS
 static int gab_perf_fd = -1;
 #endif
-static inline void gab_roi_begin(void) {
+typedef int (*gab_roctx_push_fn)(const char *);
+typedef int (*gab_roctx_pop_fn)(void);
+static gab_roctx_push_fn gab_roctx_push = NULL;
+static gab_roctx_pop_fn gab_roctx_pop = NULL;
+static int gab_roctx_state = 0;          /* 0: not probed, 1: available, -1: absent */
+static inline void gab_roctx_probe(void) {
+    if (gab_roctx_state) return;
+    gab_roctx_state = -1;
+    const char *names[] = {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so", "libroctx64.so.4"};
+    for (unsigned i = 0; i < sizeof names / sizeof *names; i++) {
+        void *h = dlopen(names[i], RTLD_NOW | RTLD_GLOBAL);
+        if (!h) continue;
+        gab_roctx_push = (gab_roctx_push_fn)dlsym(h, "roctxRangePushA");
+        gab_roctx_pop = (gab_roctx_pop_fn)dlsym(h, "roctxRangePop");
+        if (gab_roctx_push && gab_roctx_pop) { gab_roctx_state = 1; return; }
+    }
+}
+#if PWR || RAPL_STOPWATCH
+typedef int (*gab_rsmi_init_fn)(uint64_t);
+typedef int (*gab_rsmi_energy_fn)(uint32_t, uint64_t *, float *, uint64_t *);
+static gab_rsmi_energy_fn gab_rsmi_energy = NULL;
+static double gab_energy_j0 = 0.0;
+static int gab_energy_gpus = 1;
+static inline double gab_energy_now(void) {       /* joules accumulated by the first gab_energy_gpus GPUs, or -1 */
+    if (!gab_rsmi_energy) {
+        void *h = dlopen("librocm_smi64.so", RTLD_NOW);
+        if (!h) h = dlopen("librocm_smi64.so.1", RTLD_NOW);
+        if (!h) return -1.0;
+        gab_rsmi_init_fn init = (gab_rsmi_init_fn)dlsym(h, "rsmi_init");
+        gab_rsmi_energy = (gab_rsmi_energy_fn)dlsym(h, "rsmi_dev_energy_count_get");
+        if (!init || !gab_rsmi_energy || init(0) != 0) { gab_rsmi_energy = NULL; return -1.0; }
+    }
+    double j = 0.0;
+    for (int g = 0; g < gab_energy_gpus; g++) {
+        uint64_t cnt = 0, ts = 0; float res = 0.f;            /* counter x resolution = micro-joules */
+        if (gab_rsmi_energy((uint32_t)g, &cnt, &res, &ts) != 0) return -1.0;
+        j += (double)cnt * (double)res * 1e-6;
+    }
+    return j;
+}
+#endif
+/* `ngpus` only matters for the energy line */
+static inline void gab_roi_begin_n(int ngpus) {
+    (void)ngpus;
+#if PWR || RAPL_STOPWATCH
+    gab_energy_gpus = ngpus > 0 ? ngpus : 1;
+    gab_energy_j0 = gab_energy_now();
+#endif
 #if PERF_ANALYSIS
     gab_perf_fd = open("perf_ctl.fifo", O_WRONLY);
     if (gab_perf_fd == -1) fprintf(stderr, "ERROR opening the Perf pipe\n");
     else if (write(gab_perf_fd, "enable", 6) != 6) fprintf(stderr, "ERROR writing to the Perf pipe\n");
 #endif
+    gab_roctx_probe();
+    if (gab_roctx_state == 1) gab_roctx_push("gab_roi");
 }
+static inline void gab_roi_begin(void) { gab_roi_begin_n(1); }
 static inline void gab_roi_end(void) {
+    if (gab_roctx_state == 1) gab_roctx_pop();
 #if PERF_ANALYSIS
-    if (gab_perf_fd != -1) { if (write(gab_perf_fd, "disable", 7) != 7) {} close(gab_perf_fd); }
+    if (gab_perf_fd != -1) { if (write(gab_perf_fd, "disable", 7) != 7) {} close(gab_perf_fd); gab_perf_fd = -1; }
+#endif
+#if PWR || RAPL_STOPWATCH
+    const double j1 = gab_energy_now();
+    if (gab_energy_j0 >= 0.0 && j1 >= 0.0) fprintf(GAB_ENERGY_STREAM, "Energy consumption: %0.4lf J\n", j1 - gab_energy_j0);
 #endif
 }
 
@@ -62,13 +154,22 @@ static inline int gab_pick_gpus(int flag) {
 
 #define GAB_DIE_IF(rc, what) do { if ((rc) != 0) { fprintf(stderr, "ERROR: %s failed (%d): %s\n", what, (int)(rc), gab_last_error()); exit(EXIT_FAILURE); } } while (0)
 
+/* page-lock a slab the ROI hands to gab_*_run, in place, once it has its final size (outside the ROI, where the
+ * reference allocates its slabs, e.g. bsw/src/main_banded.cpp:260-264); GAB_NO_PIN=1 skips it (pageable copies) */
+static inline void gab_pin(const void *p, size_t bytes) {
+    if (gab_env_i64("GAB_NO_PIN", 0)) return;
+    if (gab_host_register((void *)p, bytes) != 0) fprintf(stderr, "note: could not page-lock %zu bytes (%s); copies will be staged\n", bytes, gab_last_error());
+}
+static inline void gab_unpin(const void *p) { if (!gab_env_i64("GAB_NO_PIN", 0)) gab_host_unregister((void *)p); }
+
 /* ---- per-GPU work queue ---------------------------------------------------------------------- */
-typedef void (*gab_chunk_fn)(int gpu, int64_t chunk, void *ctx, void *gpu_state);
-typedef void *(*gab_gpu_init_fn)(int gpu, void *ctx);
-typedef void (*gab_gpu_fini_fn)(int gpu, void *ctx, void *gpu_state);
+typedef void (*gab_chunk_fn)(int worker, int gpu, int64_t chunk, void *ctx, void *worker_state);
+typedef void *(*gab_gpu_init_fn)(int worker, int gpu, void *ctx);
+typedef void (*gab_gpu_fini_fn)(int worker, int gpu, void *ctx, void *worker_state);
 typedef struct {
-    int gpu; int64_t nchunks; int64_t *cursor; pthread_mutex_t *mu;
+    int worker, gpu; int64_t nchunks; int64_t *cursor; pthread_mutex_t *mu;
     gab_gpu_init_fn init; gab_chunk_fn run; gab_gpu_fini_fn fini; void *ctx; void *state;
+    int64_t done;       /* chunks this worker ran */
 } gab_worker;
 static void *gab_worker_main(void *p) {
     gab_worker *w = (gab_worker *)p;
@@ -77,31 +178,39 @@ static void *gab_worker_main(void *p) {
         int64_t c = (*w->cursor)++;
         pthread_mutex_unlock(w->mu);
         if (c >= w->nchunks) break;
-        w->run(w->gpu, c, w->ctx, w->state);
+        w->run(w->worker, w->gpu, c, w->ctx, w->state);
+        w->done++;
     }
     return NULL;
 }
 /* init/fini run outside the caller's timed region if the caller times only gab_queue_run */
-typedef struct { int ngpus; gab_worker *w; pthread_mutex_t mu; int64_t cursor; } gab_queue;
+typedef struct { int ngpus, nworkers; gab_worker *w; pthread_mutex_t mu; int64_t cursor; } gab_queue;
+static inline int gab_workers_per_gpu(void) { return (int)gab_env_i64("GAB_WORKERS_PER_GPU", 2); }
 static inline void gab_queue_open(gab_queue *q, int ngpus, gab_gpu_init_fn init, gab_chunk_fn run, gab_gpu_fini_fn fini, void *ctx) {
-    q->ngpus = ngpus; q->cursor = 0;
+    q->ngpus = ngpus; q->nworkers = ngpus * gab_workers_per_gpu(); q->cursor = 0;
     pthread_mutex_init(&q->mu, NULL);
-    q->w = (gab_worker *)calloc((size_t)ngpus, sizeof(gab_worker));
-    for (int g = 0; g < ngpus; g++) {
-        q->w[g].gpu = g; q->w[g].cursor = &q->cursor; q->w[g].mu = &q->mu;
-        q->w[g].init = init; q->w[g].run = run; q->w[g].fini = fini; q->w[g].ctx = ctx;
-        q->w[g].state = init ? init(g, ctx) : NULL;
+    q->w = (gab_worker *)calloc((size_t)q->nworkers, sizeof(gab_worker));
+    for (int k = 0; k < q->nworkers; k++) {
+        gab_worker *w = &q->w[k];
+        w->worker = k; w->gpu = k % ngpus; w->cursor = &q->cursor; w->mu = &q->mu;      /* worker k and k + ngpus share a GPU */
+        w->init = init; w->run = run; w->fini = fini; w->ctx = ctx;
+        w->state = init ? init(k, w->gpu, ctx) : NULL;
     }
 }
 static inline void gab_queue_run(gab_queue *q, int64_t nchunks) {
     q->cursor = 0;
-    pthread_t *th = (pthread_t *)calloc((size_t)q->ngpus, sizeof(pthread_t));
-    for (int g = 0; g < q->ngpus; g++) { q->w[g].nchunks = nchunks; pthread_create(&th[g], NULL, gab_worker_main, &q->w[g]); }
-    for (int g = 0; g < q->ngpus; g++) pthread_join(th[g], NULL);
+    pthread_t *th = (pthread_t *)calloc((size_t)q->nworkers, sizeof(pthread_t));
+    for (int k = 0; k < q->nworkers; k++) { q->w[k].nchunks = nchunks; q->w[k].done = 0; pthread_create(&th[k], NULL, gab_worker_main, &q->w[k]); }
+    for (int k = 0; k < q->nworkers; k++) pthread_join(th[k], NULL);
     free(th);
+    if (getenv("GAB_QUEUE_REPORT")) {       /* one line for tests / tuning: how the chunks were spread */
+        fprintf(stderr, "gab_queue: %ld chunks over %d workers on %d GPU(s):", (long)nchunks, q->nworkers, q->ngpus);
+        for (int k = 0; k < q->nworkers; k++) fprintf(stderr, " %ld", (long)q->w[k].done);
+        fprintf(stderr, "\n");
+    }
 }
 static inline void gab_queue_close(gab_queue *q) {
-    for (int g = 0; g < q->ngpus; g++) if (q->w[g].fini) q->w[g].fini(g, q->w[g].ctx, q->w[g].state);
+    for (int k = 0; k < q->nworkers; k++) if (q->w[k].fini) q->w[k].fini(k, q->w[k].gpu, q->w[k].ctx, q->w[k].state);
     free(q->w);
     pthread_mutex_destroy(&q->mu);
 }

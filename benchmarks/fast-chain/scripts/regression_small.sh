@@ -11,7 +11,8 @@ binaries_path="$(dirname "$scriptfolder")"
 clean=1
 job="FAST-CHAIN-REGRESSION-SMALL"
 before_command=""
-commands=( "$binaries_path/chain" )
+# $GAB_FASTCHAIN_COMMAND substitutes another binary with the same CLI (e.g. the compiled reference, to run this harness on a box without a GPU)
+commands=( "${GAB_FASTCHAIN_COMMAND:-$binaries_path/chain}" )
 parallelism=( 'nodes=1, mpi=1, omp=1, gpus=1' )
 [[ -n "$GAB_REGRESSION_GPUS" ]] && parallelism+=( "nodes=1, mpi=1, omp=1, gpus=$GAB_REGRESSION_GPUS" )
 command_opts="-i \"$inputs_path/in-1k.txt\" -o out.txt -t \$OMP_NUM_THREADS"
@@ -20,6 +21,8 @@ after_run() (
     job_name="$1"
     kernel_time="$(grep "Time in kernel" "$job_name.err" | cut -d " " -f 4)"
     diff --brief out.txt "$inputs_path/out-reference-no-heuristics-32b.txt" >/dev/null 2>&1 || { echo "The output file is not identical to the reference file"; return 1; }
-    echo "Kernel execution time $kernel_time s"; return 0
+    echo "Kernel execution time $kernel_time s"
+    grep "Energy consumption:" "$job_name.err"
+    return 0
 )
 source "$scriptfolder/../../run_wrapper.sh"

@@ -7,23 +7,42 @@
  * fmi/scripts/regression_small.sh:91,97-98).  <ref_prefix>.bwt.2bit.64 is BWA-MEM2's own index file; it is
  * loaded and replicated on every GPU before the ROI, as load_index precedes begin_computing in the reference.
  * The per-batch ROI body (getSMEMsAllPos -> re-seed -> bwtSeedStrategy -> sortSMEMs, fmi.cpp:288-348) becomes
- * gab_fmi_seed on chunks of reads, one host thread per GPU; batch_size and n_threads only shaped the CPU
+ * gab_fmi_seed on chunks of reads ($GAB_CHUNK, default 2^20) pulled by $GAB_WORKERS_PER_GPU host threads per GPU
+ * (default 2; the workers of a GPU share one copy of the index); batch_size and n_threads only shaped the CPU
  * scheduling and are accepted and ignored.
  */
+#define GAB_ENERGY_STREAM stderr      /* where the reference prints "Energy consumption:" in this driver */
 #include "../common/gab_driver.h"
 #include <zlib.h>
 
-#define CHUNK_READS (1 << 20)
+#define CHUNK_READS (1 << 20)   /* default chunk of the work queue; $GAB_CHUNK overrides it */
+#define MAX_GPUS 64
 typedef struct {
-    const char *prefix; const uint8_t *enc; int32_t stride; const int32_t *len; int64_t n; int32_t msl;
+    const char *prefix; const uint8_t *enc; int32_t stride; const int32_t *len; int64_t n, chunk; int32_t msl;
     gab_smem **out; int64_t *nout;      /* per chunk */
+    gab_fmi *owner[MAX_GPUS];           /* the handle that owns the index of each GPU; further workers clone it */
 } fmi_ctx;
-static void *gpu_init(int gpu, void *c) { gab_fmi *h = NULL; GAB_DIE_IF(gab_fmi_load(gpu, ((fmi_ctx *)c)->prefix, &h), "gab_fmi_load"); return h; }
-static void gpu_fini(int gpu, void *c, void *st) { (void)gpu; (void)c; gab_fmi_destroy((gab_fmi *)st); }
-static void run_chunk(int gpu, int64_t chunk, void *vctx, void *st) {
-    (void)gpu;
+/* the index is loaded ONCE per GPU and shared by that GPU's workers, as the reference's threads share one FMI_search */
+static void *gpu_init(int worker, int gpu, void *vc) {
+    (void)worker;
+    fmi_ctx *c = (fmi_ctx *)vc;
+    gab_fmi *h = NULL;
+    if (gpu < MAX_GPUS && c->owner[gpu]) { GAB_DIE_IF(gab_fmi_clone(c->owner[gpu], &h), "gab_fmi_clone"); return h; }
+    GAB_DIE_IF(gab_fmi_load(gpu, c->prefix, &h), "gab_fmi_load");
+    if (gpu < MAX_GPUS) c->owner[gpu] = h;
+    return h;
+}
+/* clones go first (workers are closed in index order and the owners are the first ngpus workers): defer the owners */
+static void gpu_fini(int worker, int gpu, void *vc, void *st) {
+    (void)worker;
+    fmi_ctx *c = (fmi_ctx *)vc;
+    if (gpu < MAX_GPUS && c->owner[gpu] == (gab_fmi *)st) return;       /* destroyed after the queue is closed */
+    gab_fmi_destroy((gab_fmi *)st);
+}
+static void run_chunk(int worker, int gpu, int64_t chunk, void *vctx, void *st) {
+    (void)gpu; (void)worker;
     fmi_ctx *c = (fmi_ctx *)vctx;
-    const int64_t b = chunk * CHUNK_READS, e = b + CHUNK_READS < c->n ? b + CHUNK_READS : c->n;
+    const int64_t b = chunk * c->chunk, e = b + c->chunk < c->n ? b + c->chunk : c->n;
     GAB_DIE_IF(gab_fmi_seed((gab_fmi *)st, c->enc + b * c->stride, c->stride, c->len + b, e - b, c->msl, &c->out[chunk],
                             &c->nout[chunk]), "gab_fmi_seed");
     for (int64_t i = 0; i < c->nout[chunk]; i++) c->out[chunk][i].rid += (uint32_t)b;      /* rid += batch offset, fmi.cpp:340-343 */
@@ -78,8 +97,11 @@ int main(int argc, char **argv) {
         }
     const int ngpus = gab_pick_gpus(0);
     fmi_ctx ctx;
+    memset(&ctx, 0, sizeof ctx);
+    ctx.chunk = gab_env_i64("GAB_CHUNK", CHUNK_READS);
     ctx.prefix = argv[1]; ctx.enc = enc; ctx.stride = max_rl; ctx.len = len; ctx.n = n; ctx.msl = atoi(argv[4]);
-    const int64_t nchunks = (n + CHUNK_READS - 1) / CHUNK_READS;
+    const int64_t nchunks = (n + ctx.chunk - 1) / ctx.chunk;
+    gab_pin(enc, (size_t)n * (size_t)max_rl); gab_pin(len, 4 * (size_t)n);
     ctx.out = (gab_smem **)calloc((size_t)nchunks, sizeof(gab_smem *)); ctx.nout = (int64_t *)calloc((size_t)nchunks, 8);
     gab_queue q;
     gab_queue_open(&q, ngpus, gpu_init, run_chunk, gpu_fini, &ctx);       /* index load: before the ROI (fmi.cpp:102-105) */
@@ -87,11 +109,13 @@ int main(int argc, char **argv) {
     printf("numReads = %ld, max_readlength = %d, min_readlength = %d\n", (long)n, max_rl, min_rl);
     printf("Running %d threads\n", atoi(argv[5]));
     const double t0 = gab_now();                 /* ROI: fmi.cpp:236-362 */
-    gab_roi_begin();
+    gab_roi_begin_n(ngpus);
     gab_queue_run(&q, nchunks);
     gab_roi_end();
     const double t1 = gab_now();
     gab_queue_close(&q);
+    for (int g = 0; g < MAX_GPUS; g++) if (ctx.owner[g]) gab_fmi_destroy(ctx.owner[g]);
+    gab_unpin(enc); gab_unpin(len);
     int64_t total = 0;
     for (int64_t c = 0; c < nchunks; c++) total += ctx.nout[c];
     printf("totalSmems = %ld\n", (long)total);

@@ -11,7 +11,8 @@ binaries_path="$(dirname "$scriptfolder")"
 clean=1
 job="WFA-REGRESSION-LARGE"
 before_command=""
-commands=( "$binaries_path/bin/align_benchmark" )
+# $GAB_WFA_COMMAND substitutes another binary with the same CLI (e.g. the compiled reference, to run this harness on a box without a GPU)
+commands=( "${GAB_WFA_COMMAND:-$binaries_path/bin/align_benchmark}" )
 parallelism=( 'nodes=1, mpi=1, omp=1, gpus=1' )
 [[ -n "$GAB_REGRESSION_GPUS" ]] && parallelism+=( "nodes=1, mpi=1, omp=1, gpus=$GAB_REGRESSION_GPUS" )
 command_opts="-i \"$inputs_path/WFA_SRR7733443_1m_input.txt\" -o checksum.file -t \$OMP_NUM_THREADS"
@@ -20,6 +21,8 @@ after_run() (
     job_name="$1"
     kernel_time="$(grep "Time.Alignment:" "$job_name.out" | cut -d " " -f 2)"
     sort -n -t "=" -k 2,2 checksum.file | diff --brief - "$inputs_path/output-reference.file" >/dev/null 2>&1 || { echo "The output file is not identical to the reference file"; return 1; }
-    echo "Kernel execution time $kernel_time s"; return 0
+    echo "Kernel execution time $kernel_time s"
+    grep "Energy consumption:" "$job_name.out"
+    return 0
 )
 source "$scriptfolder/../../run_wrapper.sh"

@@ -13,18 +13,19 @@
 #include <getopt.h>
 #include <sys/time.h>
 
-#define CHUNK_PAIRS (1 << 18)
-typedef struct { const gab_pairs *p; gab_wfa_penalties pen; int min_wavefront_length, max_distance_threshold; char *ops; int64_t *ops_off; int32_t *ops_len, *score; } wfa_ctx;
-static void *gpu_init(int gpu, void *vc) {
+#define CHUNK_PAIRS (1 << 18)   /* default chunk of the work queue; $GAB_CHUNK overrides it */
+typedef struct { const gab_pairs *p; int64_t chunk; gab_wfa_penalties pen; int min_wavefront_length, max_distance_threshold; char *ops; int64_t *ops_off; int32_t *ops_len, *score; } wfa_ctx;
+static void *gpu_init(int worker, int gpu, void *vc) {
+    (void)worker;
     wfa_ctx *c = (wfa_ctx *)vc; gab_wfa *h = NULL;
     GAB_DIE_IF(gab_wfa_create_reduced(&c->pen, c->min_wavefront_length, c->max_distance_threshold, gpu, &h), "gab_wfa_create_reduced");
     return h;
 }
-static void gpu_fini(int gpu, void *c, void *st) { (void)gpu; (void)c; gab_wfa_destroy((gab_wfa *)st); }
-static void run_chunk(int gpu, int64_t chunk, void *vctx, void *st) {
-    (void)gpu;
+static void gpu_fini(int worker, int gpu, void *c, void *st) { (void)worker; (void)gpu; (void)c; gab_wfa_destroy((gab_wfa *)st); }
+static void run_chunk(int worker, int gpu, int64_t chunk, void *vctx, void *st) {
+    (void)gpu; (void)worker;
     wfa_ctx *c = (wfa_ctx *)vctx;
-    const int64_t b = chunk * CHUNK_PAIRS, e = b + CHUNK_PAIRS < c->p->n ? b + CHUNK_PAIRS : c->p->n;
+    const int64_t b = chunk * c->chunk, e = b + c->chunk < c->p->n ? b + c->chunk : c->p->n;
     GAB_DIE_IF(gab_wfa_run((gab_wfa *)st, c->p->slab, c->p->off1 + b, c->p->len1 + b, c->p->slab, c->p->off2 + b, c->p->len2 + b,
                            e - b, c->ops, c->ops_off + b, c->ops_len + b, c->score + b), "gab_wfa_run");
 }
@@ -73,10 +74,8 @@ int main(int argc, char **argv) {
     FILE *out = output ? fopen(output, "w") : NULL;
     /* GAB_GPU_PARSE=1 (one GPU): the file is read in one piece and indexed ON the GPU (gab_pairs_parse, no swap; SURVEY.md
      * 8f row f1); sequences are used in place in the device copy of the text, the CIGARs come back in one copy. */
-    if (getenv("GAB_GPU_PARSE") && atoi(getenv("GAB_GPU_PARSE")) && gab_pick_gpus(gpus) == 1) {
-        fseek(in, 0L, SEEK_END);
-        const long fsz = ftell(in);
-        fseek(in, 0L, SEEK_SET);
+    const int64_t fsz = gab_regular_file_size(in);      /* -1 for pipes: they take the getline path */
+    if (getenv("GAB_GPU_PARSE") && atoi(getenv("GAB_GPU_PARSE")) && fsz >= 0 && gab_pick_gpus(gpus) == 1) {
         char *whole = (char *)malloc((size_t)fsz + 1);
         gab_parser *ps = NULL; gab_pairs_packed pk;
         if (whole && fread(whole, 1, (size_t)fsz, in) == (size_t)fsz && gab_parser_create(0, &ps) == 0 &&
@@ -132,14 +131,20 @@ int main(int argc, char **argv) {
     for (int64_t i = 0; i < p.n; i++) { ctx.ops_off[i] = tot; tot += (int64_t)p.len1[i] + p.len2[i]; }
     ctx.ops = (char *)malloc((size_t)tot + 16);
     const int ngpus = gab_pick_gpus(gpus);
+    ctx.chunk = gab_env_i64("GAB_CHUNK", CHUNK_PAIRS);
+    gab_pin(p.slab, p.used); gab_pin(p.off1, 8 * (size_t)p.n); gab_pin(p.off2, 8 * (size_t)p.n); gab_pin(p.len1, 4 * (size_t)p.n);
+    gab_pin(p.len2, 4 * (size_t)p.n); gab_pin(ctx.ops, (size_t)tot + 16); gab_pin(ctx.ops_off, 8 * (size_t)p.n);
+    gab_pin(ctx.ops_len, 4 * (size_t)p.n); gab_pin(ctx.score, 4 * (size_t)p.n);
     gab_queue q;
     gab_queue_open(&q, ngpus, gpu_init, run_chunk, gpu_fini, &ctx);
     const double t0 = tv_now();                  /* ROI: align_benchmark.c:378-491 */
-    gab_roi_begin();
-    gab_queue_run(&q, (p.n + CHUNK_PAIRS - 1) / CHUNK_PAIRS);
+    gab_roi_begin_n(ngpus);
+    gab_queue_run(&q, (p.n + ctx.chunk - 1) / ctx.chunk);
     gab_roi_end();
     const double t1 = tv_now();
     gab_queue_close(&q);
+    gab_unpin(p.slab); gab_unpin(p.off1); gab_unpin(p.off2); gab_unpin(p.len1); gab_unpin(p.len2); gab_unpin(ctx.ops);
+    gab_unpin(ctx.ops_off); gab_unpin(ctx.ops_len); gab_unpin(ctx.score);
     if (out) {
         for (int64_t i = 0; i < p.n; i++) {
             fprintf(out, "id=%ld ", (long)i);

@@ -228,6 +228,7 @@ __global__ __launch_bounds__(64) void bitpal_dp(BpIO io, const uint32_t *__restr
 
 // =============================================================================== host side
 struct gab_bitpal {
+    gab_host_stream hs;     // private stream of the host-pointer entry point(s)
     int device = 0;
     BpScore sc;
     gab_devbuf ws;          // counters | 2 id lists
@@ -265,7 +266,7 @@ extern "C" int gab_bitpal_create(int algorithm, int device, gab_bitpal **out) {
 extern "C" void gab_bitpal_destroy(gab_bitpal *h) {
     if (!h) return;
     gab_device_guard g(h->device);
-    h->ws.release(); h->scratch.release(); h->io.release();
+    h->ws.release(); h->scratch.release(); h->io.release(); h->hs.release();
     for (int k = 0; k < 3; k++) if (h->ev[k]) (void)hipEventDestroy(h->ev[k]);
     if (h->h_ct) (void)hipHostFree(h->h_ct);
     delete h;
@@ -361,6 +362,7 @@ extern "C" int gab_bitpal_run(gab_bitpal *h, const char *pat, const int64_t *pat
     if (rc) return rc;
     char *b = h->io.as<char>();
     hipStream_t s = nullptr;
+    if ((rc = h->hs.get(&s)) != GAB_OK) return rc;
     GAB_HIP(hipMemcpyAsync(b + o_p, pat + pa, (size_t)(pb - pa), hipMemcpyHostToDevice, s));
     GAB_HIP(hipMemcpyAsync(b + o_t, txt + ta, (size_t)(tb - ta), hipMemcpyHostToDevice, s));
     GAB_HIP(hipMemcpyAsync(b + o_po, pat_off, 8 * nn, hipMemcpyHostToDevice, s));

@@ -517,6 +517,7 @@ __global__ __launch_bounds__(kBlock) void bpm_full(BpmIO io, const uint32_t *__r
 
 // =============================================================================== host side
 struct gab_bpm {
+    gab_host_stream hs;     // private stream of the host-pointer entry point(s)
     int device = 0;
     gab_devbuf ws;          // counters | perm | worklists
     gab_devbuf scratch;     // history of the full path
@@ -567,7 +568,7 @@ extern "C" int gab_bpm_create(int device, gab_bpm **out) {
 extern "C" void gab_bpm_destroy(gab_bpm *h) {
     if (!h) return;
     gab_device_guard g(h->device);
-    h->ws.release(); h->scratch.release(); h->io.release();
+    h->ws.release(); h->scratch.release(); h->io.release(); h->hs.release();
     for (int k = 0; k < 4; k++) if (h->ev[k]) (void)hipEventDestroy(h->ev[k]);
     if (h->fork) (void)hipEventDestroy(h->fork);
     if (h->join) (void)hipEventDestroy(h->join);
@@ -816,6 +817,7 @@ extern "C" int gab_bpm_run(gab_bpm *h, const char *pat, const int64_t *pat_off, 
     if (rc) return rc;
     char *b = h->io.as<char>();
     hipStream_t s = nullptr;
+    if ((rc = h->hs.get(&s)) != GAB_OK) return rc;
     GAB_HIP(hipMemcpyAsync(b + o_p, pat + pa, (size_t)(pb - pa), hipMemcpyHostToDevice, s));
     GAB_HIP(hipMemcpyAsync(b + o_t, txt + ta, (size_t)(tb - ta), hipMemcpyHostToDevice, s));
     GAB_HIP(hipMemcpyAsync(b + o_po, pat_off, 8 * nn, hipMemcpyHostToDevice, s));

@@ -555,6 +555,7 @@ __global__ __launch_bounds__(64) void bsw_dp8(BswIO io, BswConst c, const BswRec
 
 // =============================================================================== host side
 struct gab_bsw {
+    gab_host_stream hs;     // private stream of the host-pointer entry point(s)
     int device = 0;
     gab_bsw_params prm;
     BswConst cst;
@@ -623,7 +624,7 @@ extern "C" int gab_bsw_create(const gab_bsw_params *p, int device, gab_bsw **out
 extern "C" void gab_bsw_destroy(gab_bsw *h) {
     if (!h) return;
     gab_device_guard g(h->device);
-    h->ws.release(); h->io.release();
+    h->ws.release(); h->io.release(); h->hs.release();
     for (int k = 0; k < 4; k++) if (h->ev[k]) (void)hipEventDestroy(h->ev[k]);
     if (h->fork) (void)hipEventDestroy(h->fork);
     for (int k = 0; k < gab_bsw::kAux; k++) {
@@ -763,6 +764,7 @@ extern "C" int gab_bsw_run(gab_bsw *h, const uint8_t *ref, const int64_t *ref_of
     if (rc) return rc;
     char *b = h->io.as<char>();
     hipStream_t s = nullptr;
+    if ((rc = h->hs.get(&s)) != GAB_OK) return rc;
     GAB_HIP(hipMemcpyAsync(b + o_ref, ref + ra, (size_t)(rb - ra), hipMemcpyHostToDevice, s));
     GAB_HIP(hipMemcpyAsync(b + o_qry, qry + qa, (size_t)(qb - qa), hipMemcpyHostToDevice, s));
     GAB_HIP(hipMemcpyAsync(b + o_roff, ref_off, 8 * nn, hipMemcpyHostToDevice, s));

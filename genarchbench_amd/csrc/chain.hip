@@ -583,6 +583,7 @@ __global__ __launch_bounds__(64 * (1 + kFcHelpers)) void fastchain_kernel(const 
 
 // =============================================================================== host side
 struct gab_chain {
+    gab_host_stream hs;     // private stream of the host-pointer entry point(s)
     int device = 0;
     gab_devbuf work;       // ChainWork[ncalls] + evals counter
     gab_devbuf gmarks;     // chain mode: targets[] for windows deeper than the LDS mark ring (one int32 per anchor)
@@ -612,7 +613,7 @@ extern "C" int gab_chain_create(int device, gab_chain **out) {
 extern "C" void gab_chain_destroy(gab_chain *h) {
     if (!h) return;
     gab_device_guard g(h->device);
-    h->work.release(); h->io.release(); h->gmarks.release();
+    h->work.release(); h->io.release(); h->hs.release(); h->gmarks.release();
     for (int k = 0; k < 2; k++) if (h->ev[k]) (void)hipEventDestroy(h->ev[k]);
     if (h->h_evals) (void)hipHostFree(h->h_evals);
     delete h;
@@ -709,6 +710,7 @@ extern "C" int gab_chain_run(gab_chain *h, int mode, const uint64_t *x, const ui
     uint64_t *dx = (uint64_t *)b, *dy = (uint64_t *)(b + 8 * t);
     int32_t *ds = (int32_t *)(b + 16 * t), *dp = (int32_t *)(b + 20 * t);
     hipStream_t s = nullptr;
+    if ((rc = h->hs.get(&s)) != GAB_OK) return rc;
     GAB_HIP(hipMemcpyAsync(dx, x, 8 * t, hipMemcpyHostToDevice, s));
     GAB_HIP(hipMemcpyAsync(dy, y, 8 * t, hipMemcpyHostToDevice, s));
     rc = gab_chain_run_device(h, mode, dx, dy, call_off, hdr, ncalls, ds, dp, s);

@@ -751,6 +751,7 @@ __global__ __launch_bounds__(64) void fmi_sa_kernel(FmiIdx ix, SaIdx sa, const g
 
 // =============================================================================== host side
 struct gab_fmi {
+    gab_host_stream hs;     // private stream of the host-pointer entry point(s)
     int device = 0;
     FmiIdx ix;
     gab_devbuf index;       // CP_OCC array
@@ -866,11 +867,24 @@ extern "C" int gab_fmi_load(int device, const char *prefix, gab_fmi **out) {
     return rc;
 }
 
+// A second handle on the same GPU that shares the read-only index of `src` (CP_OCC, short-pattern table, sampled suffix
+// array: the clone's devbufs for them stay empty, its FmiIdx / SaIdx point into src's) and owns only its work buffers.
+extern "C" int gab_fmi_clone(gab_fmi *src, gab_fmi **out) {
+    if (!src || !out) { gab_set_error("gab_fmi_clone: NULL argument"); return GAB_EINVAL; }
+    *out = nullptr;
+    gab_fmi *h = nullptr;
+    int rc = fmi_new_handle(src->device, &h);
+    if (rc) return rc;
+    h->ix = src->ix; h->sa_ix = src->sa_ix; h->scratch_budget = src->scratch_budget;
+    *out = h;
+    return GAB_OK;
+}
+
 extern "C" void gab_fmi_destroy(gab_fmi *h) {
     if (!h) return;
     gab_device_guard g(h->device);
     h->index.release(); h->kmer.release(); h->sa.release(); h->sa_ws.release(); h->sa_off.release(); h->sa_coords.release(); h->sa_io.release(); h->ws.release(); h->prev.release(); h->slots.release(); h->out.release(); h->roff.release();
-    h->io.release();
+    h->io.release(); h->hs.release();
     for (int k = 0; k < 2; k++) if (h->ev[k]) (void)hipEventDestroy(h->ev[k]);
     if (h->h_ct) (void)hipHostFree(h->h_ct);
     delete h;
@@ -1043,6 +1057,7 @@ extern "C" int gab_fmi_seed(gab_fmi *h, const uint8_t *enc, int32_t stride, cons
     int rc = h->io.reserve(o_len + 4 * (size_t)nreads);
     if (rc) return rc;
     hipStream_t s = nullptr;
+    if ((rc = h->hs.get(&s)) != GAB_OK) return rc;
     char *b = h->io.as<char>();
     GAB_HIP(hipMemcpyAsync(b, enc, eb, hipMemcpyHostToDevice, s));
     GAB_HIP(hipMemcpyAsync(b + o_len, len, 4 * (size_t)nreads, hipMemcpyHostToDevice, s));
@@ -1164,9 +1179,10 @@ extern "C" int gab_fmi_sa_lookup(gab_fmi *h, const gab_smem *smems, int64_t n, i
     GAB_CHECK(n >= 0, "gab_fmi_sa_lookup: n < 0");
     GAB_CHECK(n == 0 || smems, "gab_fmi_sa_lookup: NULL buffer");
     gab_device_guard g(h->device);
-    hipStream_t s = nullptr;
     int rc = h->sa_io.reserve(sizeof(gab_smem) * (size_t)std::max<int64_t>(n, 1));
     if (rc) return rc;
+    hipStream_t s = nullptr;
+    if ((rc = h->hs.get(&s)) != GAB_OK) return rc;
     if (n) GAB_HIP(hipMemcpyAsync(h->sa_io.p, smems, sizeof(gab_smem) * (size_t)n, hipMemcpyHostToDevice, s));
     const int64_t *d_c = nullptr, *d_o = nullptr;
     int64_t tot = 0;

@@ -1,6 +1,7 @@
 // libgab_hip.so -- library-level entry points (version, error reporting, device probing).
 #include "gab_internal.h"
 #include <string.h>
+#include <stdlib.h>
 
 static thread_local char g_err[512] = "";
 
@@ -63,4 +64,40 @@ extern "C" int gab_device_copy_to_host(int device, void *dst, const void *d_src,
     gab_device_guard g(device);
     GAB_HIP(hipMemcpy(dst, d_src, bytes, hipMemcpyDeviceToHost));
     return GAB_OK;
+}
+
+// ---- pinned host memory ------------------------------------------------------------------------------------------
+// The host-pointer entry points (gab_*_run) move their inputs with asynchronous copies on several streams; from pageable
+// memory the runtime stages every copy through its own bounce buffer at a fraction of the link rate.  A caller that
+// allocates its slabs here (where the reference drivers call _mm_malloc / malloc before the region of interest) gets
+// direct DMA.  Any device may use the memory (hipHostMallocPortable).
+extern "C" int gab_host_alloc(size_t bytes, void **out) {
+    if (!out) { gab_set_error("gab_host_alloc: NULL argument"); return GAB_EINVAL; }
+    *out = nullptr;
+    if (gab_device_count() <= 0) { gab_set_error("no HIP device visible"); return GAB_ENODEV; }
+    hipError_t e = hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocPortable);
+    if (e != hipSuccess) { *out = nullptr; gab_set_error("hipHostMalloc(%zu) failed: %s", bytes, hipGetErrorString(e)); return GAB_ENOMEM; }
+    return GAB_OK;
+}
+extern "C" void gab_host_free(void *p) {
+    if (!p) return;
+    if (gab_is_pinned(p)) (void)hipHostFree(p);
+    else free(p);                  // gab_slab_alloc of the drivers falls back to malloc when pinning fails
+}
+// page-lock memory the caller already owns (malloc, realloc, std::vector storage ...), in place
+extern "C" int gab_host_register(void *p, size_t bytes) {
+    if (!p || !bytes) return GAB_OK;
+    if (gab_device_count() <= 0) { gab_set_error("no HIP device visible"); return GAB_ENODEV; }
+    hipError_t e = hipHostRegister(p, bytes, hipHostRegisterPortable);
+    if (e != hipSuccess) { (void)hipGetLastError(); gab_set_error("hipHostRegister(%zu) failed: %s", bytes, hipGetErrorString(e)); return GAB_ENOMEM; }
+    return GAB_OK;
+}
+extern "C" void gab_host_unregister(void *p) {
+    if (p && hipHostUnregister(p) != hipSuccess) (void)hipGetLastError();
+}
+bool gab_is_pinned(const void *p) {
+    if (!p) return false;
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return a.type == hipMemoryTypeHost;
 }

@@ -57,7 +57,24 @@ struct gab_device_guard {
     ~gab_device_guard() { if (changed) (void)hipSetDevice(prev); }
 };
 
+// The private stream of a handle's host-pointer entry point (gab_*_run).  Non-blocking, so that several handles on one
+// GPU -- the drivers run GAB_WORKERS_PER_GPU host threads per GPU, each with its own handle -- overlap their H2D copies,
+// kernels and D2H copies instead of serialising on the NULL stream.  Created on first use (device already selected).
+struct gab_host_stream {
+    hipStream_t s = nullptr;
+    int get(hipStream_t *out) {
+        if (!s && hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) {
+            s = nullptr; gab_set_error("hipStreamCreateWithFlags failed: %s", hipGetErrorString(hipGetLastError()));
+            return GAB_EDEVICE;
+        }
+        *out = s;
+        return GAB_OK;
+    }
+    void release() { if (s) (void)hipStreamDestroy(s); s = nullptr; }
+};
+
 int gab_check_device(int device);
+bool gab_is_pinned(const void *p);      // hipHostMalloc'ed / registered host memory (direct DMA) or pageable
 
 static inline int64_t gab_ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 

@@ -451,6 +451,7 @@ __global__ __launch_bounds__(64) void wfa_global(WfaIO io, WfaPen pen, const uin
 
 // =============================================================================== host side
 struct gab_wfa {
+    gab_host_stream hs;     // private stream of the host-pointer entry point(s)
     int device = 0;
     WfaPen pen;
     bool adaptive = false;  // affine_wavefronts_new_reduced instead of _new_complete
@@ -501,7 +502,7 @@ extern "C" int gab_wfa_create_reduced(const gab_wfa_penalties *p, int min_wavefr
 extern "C" void gab_wfa_destroy(gab_wfa *h) {
     if (!h) return;
     gab_device_guard g(h->device);
-    h->ws.release(); h->scratch.release(); h->io.release();
+    h->ws.release(); h->scratch.release(); h->io.release(); h->hs.release();
     for (int k = 0; k < 4; k++) if (h->ev[k]) (void)hipEventDestroy(h->ev[k]);
     if (h->h_ct) (void)hipHostFree(h->h_ct);
     delete h;
@@ -648,6 +649,7 @@ extern "C" int gab_wfa_run(gab_wfa *h, const char *pat, const int64_t *pat_off, 
     if (rc) return rc;
     char *b = h->io.as<char>();
     hipStream_t s = nullptr;
+    if ((rc = h->hs.get(&s)) != GAB_OK) return rc;
     GAB_HIP(hipMemcpyAsync(b + o_p, pat + pa, (size_t)(pb - pa), hipMemcpyHostToDevice, s));
     GAB_HIP(hipMemcpyAsync(b + o_t, txt + ta, (size_t)(tb - ta), hipMemcpyHostToDevice, s));
     GAB_HIP(hipMemcpyAsync(b + o_po, pat_off, 8 * nn, hipMemcpyHostToDevice, s));

@@ -43,6 +43,16 @@ int gab_device_count(void);
 int gab_device_alloc(int device, size_t bytes, void **out);
 void gab_device_free(int device, void *p);
 int gab_device_copy_to_host(int device, void *dst, const void *d_src, size_t bytes);
+/* pinned (page-locked) host memory for the slabs handed to the host-pointer entry points gab_*_run: where the reference
+ * drivers allocate theirs before the region of interest (_mm_malloc, bsw/src/main_banded.cpp:260-264; malloc / std::vector
+ * elsewhere).  gab_*_run accepts any host memory; from pinned memory its chunked copies are direct DMA that overlaps the
+ * kernels, from pageable memory the runtime stages them at a fraction of the link rate. */
+int gab_host_alloc(size_t bytes, void **out);
+void gab_host_free(void *p);
+/* same, in place, for memory the caller already owns (malloc / realloc / std::vector storage): page-locks
+ * [p, p + bytes) until gab_host_unregister(p); do it after the buffer has reached its final size, outside the ROI */
+int gab_host_register(void *p, size_t bytes);
+void gab_host_unregister(void *p);
 
 /* ---- bsw: banded Smith-Waterman seed extension ------------------------------------
  * Replaces  bsw[tid]->getScores16(SeqPair*, ref, qer, nPairsBatch, 1, w)
@@ -247,6 +257,10 @@ int gab_fmi_load(int device, const char *prefix, gab_fmi **out);
 /* same, from memory: the three parts of the file as the reference writes them (count[] NOT yet +1) */
 int gab_fmi_create(int device, int64_t reference_seq_len, const int64_t count[5], const void *cp_occ,
                    int64_t sentinel_index, gab_fmi **out);
+/* a second handle on the same GPU that SHARES the read-only index of `src` (which must outlive it; attach the suffix
+ * array to src first) and owns only its work buffers: the drivers run several host threads per GPU, each with its own
+ * handle, the way the reference's threads share one FMI_search (fmi/fmi.cpp:102-103,250-263) */
+int gab_fmi_clone(gab_fmi *src, gab_fmi **out);
 void gab_fmi_destroy(gab_fmi *h);
 /* host buffers; *out is malloc'ed by the library, release it with gab_fmi_free */
 int gab_fmi_seed(gab_fmi *h, const uint8_t *enc, int32_t stride, const int32_t *len, int64_t nreads,

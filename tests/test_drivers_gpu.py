@@ -136,3 +136,114 @@ def test_bpm_driver_bitpal_algorithms(tmp_path, alg):
                            timeout=300, env=dict(os.environ, **env))
         assert r.returncode == 0, r.stderr[-500:]
         assert open(out).read() == want
+
+
+# ---- BASELINE.json config 5's code path on one GPU: many chunks, several queue workers per GPU ---------------------
+# (benchmarks/common/gab_driver.h: chunks pulled from a shared cursor by GAB_WORKERS_PER_GPU threads per GPU, each with its
+# own handle; matches the reference's `omp for schedule(dynamic)` over batches, bsw/src/main_banded.cpp:338-350,
+# fmi/fmi.cpp:250-263 with the `rid += batch offset` fix-up of :340-343)
+QUEUE_ENV = {"GAB_WORKERS_PER_GPU": "3", "GAB_QUEUE_REPORT": "1"}
+
+
+def _queue_report(stderr):
+    line = [l for l in stderr.splitlines() if l.startswith("gab_queue:")][-1]
+    head, counts = line.split(":", 2)[1:]
+    nchunks, nworkers = int(head.split()[0]), int(head.split()[3])
+    return nchunks, nworkers, [int(c) for c in counts.split()]
+
+
+@pytest.mark.parametrize("bench,chunk", [("bsw", 100), ("chain", 3000), ("fast-chain", 3000), ("bpm", 117), ("wfa", 64), ("fmi", 50)])
+def test_regression_small_many_chunks_three_workers(inputs, bench, chunk, tmp_path):
+    """the golden files again, with the input cut into many chunks spread over three workers that share device 0"""
+    env = dict(os.environ, GENARCH_BENCH_INPUTS_ROOT=inputs, GAB_CHUNK=str(chunk), clean="0", **QUEUE_ENV)
+    r = subprocess.run(["bash", os.path.join(ROOT, "benchmarks", bench, "scripts", "regression_small.sh")], cwd=tmp_path,
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "OK" in r.stdout and "FAILED" not in r.stdout, r.stdout
+
+
+def test_queue_spreads_chunks_over_workers(inputs, tmp_path):
+    """every chunk runs exactly once, on some worker; more than one worker takes part"""
+    exe = os.path.join(ROOT, "benchmarks", "bsw", "main_bsw")
+    inp = f"{inputs}/bsw/small/bandedSWA_SRR7733443_100k_input.txt"
+    one = subprocess.run([exe, "-pairs", inp, "-t", "1", "-b", "512"], capture_output=True, text=True, timeout=300,
+                         env=dict(os.environ, GAB_WORKERS_PER_GPU="1"))
+    many = subprocess.run([exe, "-pairs", inp, "-t", "1", "-b", "512"], capture_output=True, text=True, timeout=300,
+                          env=dict(os.environ, GAB_CHUNK="64", **QUEUE_ENV))
+    assert one.returncode == 0 and many.returncode == 0, many.stderr[-500:]
+    nchunks, nworkers, counts = _queue_report(many.stderr)
+    assert nchunks == 2048 // 64 and nworkers == 3 and sum(counts) == nchunks
+    assert sum(c > 0 for c in counts) >= 2
+    scores = lambda e: [l for l in e.splitlines() if "score=" in l]
+    assert scores(one.stderr) == scores(many.stderr) and len(scores(one.stderr)) == 2048
+    assert many.stdout.count("] workTicks = ") == 3
+
+
+def test_fmi_chunks_fix_up_read_ids(inputs, tmp_path):
+    """fmi: chunk-local read ids are shifted by the chunk's first read (fmi/fmi.cpp:340-343) and the chunks are printed in
+    order: stdout after the six header lines is identical whatever the chunking"""
+    exe = os.path.join(ROOT, "benchmarks", "fmi", "fmi")
+    args = [exe, f"{inputs}/fmi/broad", f"{inputs}/fmi/small/SRR7733443_1m_1.fastq", "512", "19", "1"]
+    a = subprocess.run(args, capture_output=True, text=True, timeout=300, env=dict(os.environ, GAB_WORKERS_PER_GPU="1"))
+    b = subprocess.run(args, capture_output=True, text=True, timeout=300, env=dict(os.environ, GAB_CHUNK="37", **QUEUE_ENV))
+    assert a.returncode == 0 and b.returncode == 0, b.stderr[-500:]
+    body = lambda o: o.splitlines()[6:]
+    assert body(a.stdout) == body(b.stdout) and len(body(a.stdout)) > 1200
+    assert body(b.stdout) == open(f"{inputs}/fmi/small/out-reference.txt").read().splitlines()
+    nchunks, nworkers, counts = _queue_report(b.stderr)
+    assert nchunks == (1200 + 36) // 37 and sum(counts) == nchunks
+
+
+def test_unpinned_and_piped_inputs(inputs, tmp_path):
+    """GAB_NO_PIN=1 (pageable slabs) gives the same scores; a pipe instead of a file is refused by the seek the reference
+    needs too, and GAB_GPU_PARSE on a pipe never reads an unknown size"""
+    exe = os.path.join(ROOT, "benchmarks", "bsw", "main_bsw")
+    inp = f"{inputs}/bsw/small/bandedSWA_SRR7733443_100k_input.txt"
+    a = subprocess.run([exe, "-pairs", inp, "-t", "1", "-b", "512"], capture_output=True, text=True, timeout=300)
+    b = subprocess.run([exe, "-pairs", inp, "-t", "1", "-b", "512"], capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, GAB_NO_PIN="1"))
+    assert a.returncode == 0 and b.returncode == 0 and a.stderr == b.stderr
+    for bench, args in [("bpm/bin/align_benchmark", ["-a", "bpm-edit", "-o", str(tmp_path / "o.txt")]),
+                        ("wfa/bin/align_benchmark", ["-o", str(tmp_path / "o.txt")])]:
+        name = "BPM" if bench.startswith("bpm") else "WFA"
+        src = f"{inputs}/{bench.split('/')[0]}/small/{name}_SRR7733443_100k_input.txt"
+        want = str(tmp_path / "want.txt")
+        r0 = subprocess.run([os.path.join(ROOT, "benchmarks", bench)] + args[:-1] + [want, "-i", src], capture_output=True, text=True, timeout=300)
+        assert r0.returncode == 0, r0.stderr[-300:]
+        # process substitution: the driver reads a pipe; with GAB_GPU_PARSE=1 it must take the getline path
+        cmd = f"{os.path.join(ROOT, 'benchmarks', bench)} {' '.join(args)} -i <(cat {src})"
+        r = subprocess.run(["bash", "-c", cmd], capture_output=True, text=True, timeout=300, env=dict(os.environ, GAB_GPU_PARSE="1", GAB_GPUS="1"))
+        assert r.returncode == 0, r.stderr[-300:]
+        assert "indexed on the GPU" not in r.stderr + r.stdout
+        assert open(str(tmp_path / "o.txt")).read() == open(want).read()
+
+
+def test_perf_analysis_fifo_protocol(inputs, tmp_path):
+    """-DPERF_ANALYSIS=1: the driver opens perf_ctl.fifo in its working directory and writes "enable" before and "disable"
+    after the ROI (bsw/src/main_banded.cpp:313-321,356-359); the reader here plays `perf stat --control fifo:`"""
+    import threading
+    build = tmp_path / "bin"
+    build.mkdir()
+    src = os.path.join(ROOT, "benchmarks", "bsw", "src", "main_banded.c")
+    lib = os.path.join(ROOT, "genarchbench_amd")
+    subprocess.check_call(["gcc", "-O2", "-std=gnu11", "-I", os.path.join(ROOT, "include"), "-DPERF_ANALYSIS=1", "-DPWR=1", src, "-o",
+                           str(build / "main_bsw_perf"), "-L", lib, "-lgab_hip", f"-Wl,-rpath,{lib}", "-lpthread", "-lm", "-ldl"])
+    fifo = tmp_path / "perf_ctl.fifo"
+    os.mkfifo(fifo)
+    got = []
+
+    def reader():
+        with open(fifo, "rb") as f:
+            got.append(f.read())
+    t = threading.Thread(target=reader)
+    t.start()
+    r = subprocess.run([str(build / "main_bsw_perf"), "-pairs", f"{inputs}/bsw/small/bandedSWA_SRR7733443_100k_input.txt", "-t", "1",
+                        "-b", "512"], cwd=tmp_path, capture_output=True, text=True, timeout=300)
+    t.join(timeout=30)
+    assert r.returncode == 0, r.stderr[-500:]
+    assert got and got[0] == b"enabledisable"
+    assert "ERROR opening the Perf pipe" not in r.stderr
+    # -DPWR=1: the energy line of the reference's harness (grep "Energy consumption:"), when ROCm SMI is readable
+    e = [l for l in r.stdout.splitlines() if l.startswith("Energy consumption:")]
+    assert len(e) <= 1 and all(float(l.split()[2]) >= 0 for l in e)
+    assert open(f"{inputs}/bsw/small/output-reference.file").read().splitlines() == [l for l in r.stderr.splitlines() if "score=" in l]
