@@ -515,12 +515,19 @@ __global__ __launch_bounds__(kBlock) void bpm_full(BpmIO io, const uint32_t *__r
 
 }  // namespace
 
+// lengths of the listed pairs, back to back (the host sizes the per-pair history slots of the generic path from them)
+__global__ __launch_bounds__(256) void bpm_gather_lens(const uint32_t *__restrict__ ids, uint32_t n, const int32_t *__restrict__ pat_len,
+                                                       const int32_t *__restrict__ txt_len, int32_t *__restrict__ pl, int32_t *__restrict__ tl) {
+    for (uint32_t k = blockIdx.x * 256u + threadIdx.x; k < n; k += gridDim.x * 256u) { pl[k] = pat_len[ids[k]]; tl[k] = txt_len[ids[k]]; }
+}
+
 // =============================================================================== host side
 struct gab_bpm {
     gab_host_stream hs;     // private stream of the host-pointer entry point(s)
     int device = 0;
     gab_devbuf ws;          // counters | perm | worklists
     gab_devbuf scratch;     // history of the full path
+    gab_devbuf lens;        // pattern / text lengths of the pairs on the generic path
     gab_devbuf io;          // staging for the host-pointer entry point
     size_t scratch_budget = (size_t)8 << 30;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -568,7 +575,7 @@ extern "C" int gab_bpm_create(int device, gab_bpm **out) {
 extern "C" void gab_bpm_destroy(gab_bpm *h) {
     if (!h) return;
     gab_device_guard g(h->device);
-    h->ws.release(); h->scratch.release(); h->io.release(); h->hs.release();
+    h->ws.release(); h->scratch.release(); h->lens.release(); h->io.release(); h->hs.release();
     for (int k = 0; k < 4; k++) if (h->ev[k]) (void)hipEventDestroy(h->ev[k]);
     if (h->fork) (void)hipEventDestroy(h->fork);
     if (h->join) (void)hipEventDestroy(h->join);
@@ -745,15 +752,16 @@ extern "C" int gab_bpm_run_device(gab_bpm *h, const char *pat, int64_t pat_bytes
         const uint32_t cnt0 = ccount[0];
         if (cnt0) {
             nfull += cnt0;
-            std::vector<uint32_t> ids(cnt0);
             std::vector<int32_t> pl(cnt0), tl(cnt0);
-            GAB_HIP(hipMemcpyAsync(ids.data(), d_perm + cstart[0], 4 * (size_t)cnt0, hipMemcpyDeviceToHost, s));
-            GAB_HIP(hipStreamSynchronize(s));
-            // lengths of those pairs (few and far between: gather one by one through a strided copy)
-            for (uint32_t k = 0; k < cnt0; k++) {
-                GAB_HIP(hipMemcpyAsync(&pl[k], pat_len + ids[k], 4, hipMemcpyDeviceToHost, s));
-                GAB_HIP(hipMemcpyAsync(&tl[k], txt_len + ids[k], 4, hipMemcpyDeviceToHost, s));
-            }
+            // lengths of those pairs: gathered on the device into one buffer, one copy back (a long-read input puts EVERY
+            // pair here; two 4-byte copies per pair were minutes of host latency at 10 M pairs)
+            rc = h->lens.reserve(8 * (size_t)cnt0);
+            if (rc) return rc;
+            int32_t *d_pl = h->lens.as<int32_t>(), *d_tl = d_pl + cnt0;
+            hipLaunchKernelGGL(bpm_gather_lens, dim3((unsigned)std::min<int64_t>(gab_ceil_div((int64_t)cnt0, 256), 4096)), dim3(256), 0, s,
+                               d_perm + cstart[0], cnt0, pat_len, txt_len, d_pl, d_tl);
+            GAB_HIP(hipMemcpyAsync(pl.data(), d_pl, 4 * (size_t)cnt0, hipMemcpyDeviceToHost, s));
+            GAB_HIP(hipMemcpyAsync(tl.data(), d_tl, 4 * (size_t)cnt0, hipMemcpyDeviceToHost, s));
             GAB_HIP(hipStreamSynchronize(s));
             uint32_t k0 = 0;
             while (k0 < cnt0) {

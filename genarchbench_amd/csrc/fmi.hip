@@ -766,7 +766,9 @@ struct gab_fmi {
     gab_devbuf sa_ws, sa_off, sa_coords, sa_io;
     SaIdx sa_ix = {nullptr, nullptr};
     int64_t sa_lf_steps = 0; float sa_ms = 0; bool have_sa_stats = false;
-    size_t scratch_budget = (size_t)6 << 30;
+    size_t scratch_budget = (size_t)6 << 30;   // bound of the two big scratch areas (per-lane spill lists, per-read output slots)
+    int lds_entries_env = 0;                   // $GAB_FMI_LDS_ENTRIES / $GAB_FMI_WIDE_LISTS as they were when the handle was made
+    bool wide_env = false;                     // (tests and bench.py: force the list format of indexes with >= 2^32 rows)
     hipEvent_t ev[2] = {nullptr, nullptr};
     FmiCounters *h_ct = nullptr;
     bool have_stats = false;
@@ -780,6 +782,9 @@ static int fmi_new_handle(int device, gab_fmi **out) {
     gab_fmi *h = new (std::nothrow) gab_fmi();
     if (!h) { gab_set_error("out of host memory"); return GAB_ENOMEM; }
     h->device = device;
+    { const char *e = getenv("GAB_FMI_LDS_ENTRIES"); h->lds_entries_env = e ? atoi(e) : 0; }
+    { const char *e = getenv("GAB_FMI_WIDE_LISTS"); h->wide_env = e && atoi(e) != 0; }
+    { const char *e = getenv("GAB_FMI_SCRATCH_MB"); if (e && atoll(e) > 0) h->scratch_budget = (size_t)atoll(e) << 20; }
     if (hipEventCreate(&h->ev[0]) != hipSuccess || hipEventCreate(&h->ev[1]) != hipSuccess ||
         hipHostMalloc((void **)&h->h_ct, sizeof(FmiCounters)) != hipSuccess) {
         gab_set_error("gab_fmi: event / pinned allocation failed"); delete h; return GAB_EDEVICE;
@@ -914,11 +919,11 @@ extern "C" int gab_fmi_seed_device(gab_fmi *h, const uint8_t *d_enc, int32_t str
     // counter.  Scratch: a spill area for interval lists longer than the LDS part (stride entries x 32 B per LANE,
     // touched only by the rare long list) and the output slot per READ (cap x 32 B).
     int cap = 48;
-    static const int lds_entries_env = [] { const char *e = getenv("GAB_FMI_LDS_ENTRIES"); return e ? atoi(e) : 0; }();
+    const int lds_entries_env = h->lds_entries_env;
     const bool ldsq = stride <= kLdsQMax;
     const int lds_entries = ldsq ? (lds_entries_env > 0 ? lds_entries_env : 12) : 0;
     // list entries: 13 bytes (three dword planes + a byte plane) when every interval bound fits 32 bits, else 16 packed
-    static const bool wide_env = [] { const char *e = getenv("GAB_FMI_WIDE_LISTS"); return e && atoi(e) != 0; }();   // tests
+    const bool wide_env = h->wide_env;
     const int narrow_lists = (h->ix.ref_seq_len < 0xffffffffll && !wide_env) ? 1 : 0;
     const size_t list_bytes = narrow_lists ? (((size_t)lds_entries * 64 * 13 + 15) & ~(size_t)15) : (size_t)lds_entries * 64 * 16;
     const size_t lds_bytes = ldsq ? (((size_t)(stride + 7) / 8 * 64 + 3) / 4) * 16 + list_bytes : 0;
@@ -934,6 +939,11 @@ extern "C" int gab_fmi_seed_device(gab_fmi *h, const uint8_t *d_enc, int32_t str
             GAB_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&waves_per_cu_p3, fmi_seed_kernel<true>, 64, lds_bytes_p3));
         } else GAB_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&waves_per_cu, fmi_seed_kernel<false>, 64, 0));
         GAB_CHECK(waves_per_cu > 0, "gab_fmi_seed_device: the seeding kernel does not fit a CU (stride %d)", stride);
+        // the per-lane spill area is stride x 32 B x 64 lanes per resident wave: long reads (no LDS lists: every list entry
+        // lives there) run on fewer waves rather than on tens of GB of scratch
+        const int64_t fit = (int64_t)(h->scratch_budget / (sizeof(PrevRec) * (size_t)stride * 64)) / n_cu;
+        if (fit < waves_per_cu) waves_per_cu = (int)std::max<int64_t>(fit, 1);
+        if (fit < waves_per_cu_p3) waves_per_cu_p3 = (int)std::max<int64_t>(fit, 1);
     }
     const int64_t grid_waves = (int64_t)n_cu * std::max(waves_per_cu, waves_per_cu_p3);
     int64_t B = (int64_t)std::min<size_t>((size_t)nreads, std::max<size_t>(1024, h->scratch_budget / (64 * sizeof(OutRec))));
@@ -970,9 +980,9 @@ extern "C" int gab_fmi_seed_device(gab_fmi *h, const uint8_t *d_enc, int32_t str
     int64_t total = 0;
     unsigned long long ext_total = 0, rec_total = 0;
     float kms = 0;
-    for (int64_t first = 0; first < nreads; first += B) {
-        const int32_t nb = (int32_t)std::min<int64_t>(B, nreads - first);
-        const int blocks = (int)gab_ceil_div(nb, 256);
+    for (int64_t first = 0; first < nreads;) {
+        int32_t nb = (int32_t)std::min<int64_t>(B, nreads - first);
+        int blocks = (int)gab_ceil_div(nb, 256);
         int seed_blocks_dbg = 0;
         for (;;) {                                        // at most two rounds: second with the exact slot size
             rc = h->slots.reserve(sizeof(OutRec) * (size_t)cap * (size_t)nb);
@@ -1004,6 +1014,13 @@ extern "C" int gab_fmi_seed_device(gab_fmi *h, const uint8_t *d_enc, int32_t str
             GAB_HIP(hipStreamSynchronize(s));
             if (h->h_ct->max_per_read <= cap) break;
             cap = h->h_ct->max_per_read + 8;              // some read overflowed its slot: redo the batch
+            // ... in smaller batches from here on if one repetitive read would otherwise multiply the slot buffer of millions
+            const size_t fitb = h->scratch_budget / (sizeof(OutRec) * (size_t)cap);
+            if ((size_t)nb > fitb && nb > 1024) {
+                B = (int64_t)std::max<size_t>(fitb, 1024);
+                nb = (int32_t)std::min<int64_t>(B, nreads - first);
+                blocks = (int)gab_ceil_div(nb, 256);
+            }
         }
         float ms = 0;
         GAB_HIP(hipEventElapsedTime(&ms, h->ev[0], h->ev[1]));
@@ -1033,6 +1050,7 @@ extern "C" int gab_fmi_seed_device(gab_fmi *h, const uint8_t *d_enc, int32_t str
                            h->roff.as<int64_t>(), h->out.as<gab_smem>());
         GAB_HIP(hipGetLastError());
         total += add;
+        first += nb;
     }
     GAB_HIP(hipMemcpyAsync(h->roff.as<int64_t>() + nreads, &total, 8, hipMemcpyHostToDevice, s));
     GAB_HIP(hipStreamSynchronize(s));

@@ -4,6 +4,21 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _cpu_quota():
+    n = len(os.sched_getaffinity(0))
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = max(1, min(n, int(int(q) / int(p))))
+    except Exception:
+        pass
+    return n
+
+
+# the GPU box shows every hardware thread of the host but grants a CPU quota: keep OpenMP (generators, oracle) inside it
+os.environ.setdefault("OMP_NUM_THREADS", str(_cpu_quota()))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 

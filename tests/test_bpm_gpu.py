@@ -85,3 +85,21 @@ def test_device_resident(eng):
                    sc, stream=torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     np.testing.assert_array_equal(sc.cpu().numpy(), pyoracle.bpm(batch))
+
+
+def test_many_long_patterns_generic_path(eng):
+    """every pair above 256 bases takes the generic (W > 4) path: their lengths come back in ONE copy (a gather kernel),
+    not two 4-byte copies per pair"""
+    rng = np.random.default_rng(17)
+    pats, txts = [], []
+    for _ in range(3000):
+        n = int(rng.integers(257, 700))
+        p = rng.integers(0, 4, n)
+        t = p.copy()
+        t[rng.integers(0, n, 12)] = rng.integers(0, 4, 12)
+        t = np.delete(t, rng.integers(0, n, 3))
+        lut = np.frombuffer(b"ACGT", np.uint8)
+        pats.append(lut[p].tobytes()); txts.append(lut[t].tobytes())
+    b = gabgen.pairs_from_lists(pats, txts)
+    np.testing.assert_array_equal(eng.benchmark_edit_bpm(b), pyoracle.bpm(b))
+    assert eng.last_stats()["full_pairs"] >= 3000

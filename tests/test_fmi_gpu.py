@@ -188,3 +188,65 @@ def test_sa_lookup_in_memory_index_and_errors():
     w2, wo2, _ = pyoracle.fmi_sa_lookup(oidx, one, 10)
     np.testing.assert_array_equal(g2, w2); np.testing.assert_array_equal(o2, wo2)
     f.close()
+
+
+# ---- an index of more than 2^32 rows (a human genome has ~6.2 G): k, l, s need the 40-bit forms everywhere ------------
+def _oracle_index(idx, with_sa=False):
+    oidx = pyoracle.FmIndex()
+    cnt = (C.c_int64 * 5)(*[int(x) for x in idx.count])
+    pyoracle.lib().oracle_fmi_from_arrays(C.byref(oidx), C.c_int64(idx.ref_seq_len), cnt, idx.cp_occ.ctypes.data_as(C.c_void_p),
+                                          C.c_int64(idx.sentinel_index))
+    if with_sa:
+        pyoracle.lib().oracle_fmi_set_sa(C.byref(oidx), idx.sa_ms_byte.ctypes.data_as(C.c_void_p), idx.sa_ls_word.ctypes.data_as(C.c_void_p))
+    return oidx
+
+
+def test_index_with_more_than_2_32_rows():
+    """The reference (U . revcomp(U))^m is indexed without sorting the whole text (tools/mkindex, checked against the
+    general builder in tests/test_mkindex.py): 4.4 G rows here, so interval bounds above 2^32 really flow through the
+    seeding kernel -- the 16-byte LDS list entries, pack / unpack of k, l, s, the short-pattern table, the output records --
+    and through the suffix-array look-up (coordinates above 2^32: the sampled SA's high bytes)."""
+    from genarchbench_amd.fmi import FMI_search
+    U = gabgen.fmi_ref(77, 1_000_000, 5)
+    m = 1101                                                     # k = 2202 copies of the 2 Mbp word
+    idx = mkindex.FmIndex(U, power=m)
+    assert idx.ref_seq_len > 2 ** 32
+    W = np.concatenate([U, (3 - U[::-1]).astype(np.uint8)])
+    reads = gabgen.fmi_reads(78, np.concatenate([W, W]), 40000, 60, 151)      # substitutions, N's, both strands
+    f = FMI_search(arrays=(idx.ref_seq_len, idx.count, idx.cp_occ, idx.sentinel_index))
+    got = f.seed(reads, 19)
+    oidx = _oracle_index(idx, with_sa=True)
+    w, woff, calls = pyoracle.fmi(oidx, reads, 19, want_calls=True)
+    same(got, (w, woff))
+    assert f.last_stats()["ext_calls"] == calls
+    assert (w["k"] > 2 ** 32).sum() > 1000 and (w["l"] > 2 ** 32).sum() > 1000 and w["s"].min() >= 2 * m
+    # the step after seeding on the same index: a few SMEMs only (LF walks are long in a periodic text)
+    f.set_sa(idx.sa_ms_byte, idx.sa_ls_word)
+    sub = w[(w["k"] > 2 ** 32)][:60]
+    co, coff = f.get_sa_entries(sub, 3)
+    wco, wcoff, _ = pyoracle.fmi_sa_lookup(oidx, sub, 3)
+    np.testing.assert_array_equal(coff, wcoff)
+    np.testing.assert_array_equal(co, wco)
+    assert (wco > 2 ** 32).any()
+    f.close()
+
+
+def test_scratch_budget_is_honoured(tmp_path, monkeypatch):
+    """$GAB_FMI_SCRATCH_MB: long reads (no LDS lists, every list entry in the per-lane spill area) run on fewer resident
+    waves instead of a spill area of stride x 32 B x every lane of the chip, and a repetitive read that overflows its output
+    slot shrinks the batches instead of multiplying the slot buffer; results unchanged"""
+    from genarchbench_amd.fmi import FMI_search
+    rng = np.random.default_rng(8)
+    unit = rng.integers(0, 4, 31).astype(np.uint8)
+    ref = np.concatenate([np.tile(unit, 500), rng.integers(0, 4, 60000).astype(np.uint8)])
+    idx, prefix = build(ref, tmp_path)
+    long_reads = gabgen.fmi_reads(12, ref, 3000, 600, 1500)                  # stride 1500: the global-list path
+    short_reads = gabgen.fmi_reads(13, ref, 40000, 100, 151)
+    want_long = pyoracle.fmi(pyoracle.fmi_load(prefix), long_reads, 15)
+    want_short = pyoracle.fmi(pyoracle.fmi_load(prefix), short_reads, 10)
+    monkeypatch.setenv("GAB_FMI_SCRATCH_MB", "64")
+    f = FMI_search(prefix)
+    same(f.seed(long_reads, 15), want_long)
+    same(f.seed(short_reads, 10), want_short)
+    assert np.diff(want_short[1]).max() > 48                                 # some read did overflow the first-pass slot
+    f.close()

@@ -65,3 +65,18 @@ def test_shard_ranges_tile_the_id_space():
     for world in (1, 2, 4, 8):
         spans = [shard_range(r, world, 1000) for r in range(world)]
         assert [s[0] for s in spans] == [1000 * r for r in range(world)] and all(s[1] == 1000 for s in spans)
+
+
+def test_bench_gpus_flag_is_binding():
+    """`bench.py --gpus N` either runs N ranks or fails: it never reports a 1-GPU number as an N-GPU one.
+    No launcher around it: it starts the ranks itself (as a child, before touching a GPU) and needs N visible GPUs;
+    under a launcher WORLD_SIZE must equal --gpus."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], env=env, capture_output=True,
+                       text=True, timeout=300)
+    import torch
+    if torch.cuda.device_count() < 2:
+        assert r.returncode != 0 and "GPU(s) are visible" in r.stderr + r.stdout
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "1"],
+                       env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr + r.stdout

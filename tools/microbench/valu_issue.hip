@@ -49,12 +49,77 @@
 #define I_SADU8(k) "v_sad_u8 %" #k ", %" #k ", %8, %9\n"
 #define I_MIN3U(k) "v_min3_u32 %" #k ", %" #k ", %8, %9\n"
 
+#define I_SUB(k) "v_sub_u32 %" #k ", %" #k ", %8\n"
+#define I_OR(k) "v_or_b32 %" #k ", %" #k ", %8\n"
+#define I_XOR(k) "v_xor_b32 %" #k ", %" #k ", %8\n"
+#define I_MOV(k) "v_mov_b32 %" #k ", %8\n"
+#define I_MINU(k) "v_min_u32 %" #k ", %" #k ", %8\n"
+#define I_MAXU(k) "v_max_u32 %" #k ", %" #k ", %8\n"
+#define I_LSHR(k) "v_lshrrev_b32 %" #k ", 1, %" #k "\n"
+#define I_ADDF(k) "v_add_f32 %" #k ", %" #k ", %8\n"
+#define I_SUBF(k) "v_sub_f32 %" #k ", %" #k ", %8\n"
+#define I_MULF(k) "v_mul_f32 %" #k ", %" #k ", %8\n"
+#define I_MAXF(k) "v_max_f32 %" #k ", %" #k ", %8\n"
+#define I_MINF(k) "v_min_f32 %" #k ", %" #k ", %8\n"
+#define I_MAX3F(k) "v_max3_f32 %" #k ", %" #k ", %8, %9\n"
+#define I_MED3F(k) "v_med3_f32 %" #k ", %" #k ", %8, %9\n"
+#define I_ADDF16(k) "v_add_f16 %" #k ", %" #k ", %8\n"
+#define I_MAXF16(k) "v_max_f16 %" #k ", %" #k ", %8\n"
+#define I_PKMAXF16(k) "v_pk_max_f16 %" #k ", %" #k ", %8\n"
+#define I_PKADDF16(k) "v_pk_add_f16 %" #k ", %" #k ", %8\n"
+#define I_ADDU16(k) "v_add_u16 %" #k ", %" #k ", %8\n"
+#define I_MAXI16(k) "v_max_i16 %" #k ", %" #k ", %8\n"
+#define I_MUL24(k) "v_mul_u32_u24 %" #k ", %" #k ", %8\n"
+#define I_CVTUB0(k) "v_cvt_f32_ubyte0 %" #k ", %" #k "\n"
+#define I_CVTUB2(k) "v_cvt_f32_ubyte2 %" #k ", %" #k "\n"
+#define I_CVTI(k) "v_cvt_f32_i32 %" #k ", %" #k "\n"
+#define I_CVTU8PK(k) "v_cvt_pk_u8_f32 %" #k ", %8, 1, %" #k "\n"
+#define I_BFI(k) "v_bfi_b32 %" #k ", %8, %" #k ", %9\n"
+#define I_XNOR(k) "v_xnor_b32 %" #k ", %" #k ", %8\n"
+#define I_DOT4(k) "v_dot4_i32_i8 %" #k ", %8, %9, %" #k "\n"
+#define I_ADDCO(k) "v_add_co_u32 %" #k ", vcc, %" #k ", %8\n"
+#define I_CMPCND(k) "v_cmp_eq_u32 vcc, %" #k ", %8\nv_cndmask_b32 %" #k ", %9, %8, vcc\n"
+#define I_SUBREVSDWA(k) "v_sub_u32_sdwa %" #k ", %" #k ", %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n"
+#define I_ANDE64(k) "v_and_b32_e64 %" #k ", %" #k ", %8\n"
+#define I_ADDE64(k) "v_add_u32_e64 %" #k ", %" #k ", %8\n"
+#define I_ADDFE64NEG(k) "v_add_f32_e64 %" #k ", %" #k ", -%8\n"
+#define I_MAXFE64ABS(k) "v_max_f32_e64 %" #k ", %" #k ", |%8|\n"
+#define I_ANDSGPR(k) "v_and_b32 %" #k ", s4, %" #k "\n"
+#define I_ADDLIT(k) "v_add_u32 %" #k ", 0x12345, %" #k "\n"
+#define I_ADDINL(k) "v_add_u32 %" #k ", 7, %" #k "\n"
+#define I_LSHL8(k) "v_lshlrev_b32 %" #k ", 8, %" #k "\n"
+#define I_LSHLV(k) "v_lshlrev_b32 %" #k ", %9, %" #k "\n"
+#define I_LSHL16(k) "v_lshlrev_b16 %" #k ", 1, %" #k "\n"
+#define I_LSHR16(k) "v_lshrrev_b16 %" #k ", 1, %" #k "\n"
+#define I_ASHR(k) "v_ashrrev_i32 %" #k ", 1, %" #k "\n"
+#define I_LSHLOR(k) "v_lshl_or_b32 %" #k ", %" #k ", 8, %8\n"
+#define I_MINU16(k) "v_min_u16 %" #k ", %" #k ", %8\n"
+#define I_MAXU16(k) "v_max_u16 %" #k ", %" #k ", %8\n"
+#define I_MINI16(k) "v_min_i16 %" #k ", %" #k ", %8\n"
+#define I_SUBU16(k) "v_sub_u16 %" #k ", %" #k ", %8\n"
+#define I_SUBU16C(k) "v_sub_u16_e64 %" #k ", %" #k ", %8 clamp\n"
+#define I_ADDU16C(k) "v_add_u16_e64 %" #k ", %" #k ", %8 clamp\n"
+#define I_SUBU32C(k) "v_sub_u32_e64 %" #k ", %" #k ", %8 clamp\n"
+#define I_MULLO16(k) "v_mul_lo_u16 %" #k ", %" #k ", %8\n"
+#define I_MADU16(k) "v_mad_u16 %" #k ", %" #k ", %8, %9\n"
+#define I_MINF16(k) "v_min_f16 %" #k ", %" #k ", %8\n"
+#define I_SUBF16(k) "v_sub_f16 %" #k ", %" #k ", %8\n"
+#define I_MULF16(k) "v_mul_f16 %" #k ", %" #k ", %8\n"
+#define I_FMAF16(k) "v_fma_f16 %" #k ", %" #k ", %8, %9\n"
+#define I_MACF32(k) "v_fmac_f32 %" #k ", %8, %9\n"
+#define I_MAXI16S(k) "v_max_i16 %" #k ", s4, %" #k "\n"
+#define I_ADDSGPR(k) "v_add_u32 %" #k ", s4, %" #k "\n"
+#define I_MAXI16LIT(k) "v_max_i16 %" #k ", 0, %" #k "\n"
+#define I_CNDAFTERCMP(k) "v_cndmask_b32 %" #k ", %" #k ", %8, vcc\n"
+#define I_READLANE(k) "v_readfirstlane_b32 s5, %" #k "\n"
+#define I_MBCNT(k) "v_mbcnt_lo_u32_b32 %" #k ", %8, %" #k "\n"
+
 enum { OP_ADD, OP_PKADD, OP_PKMAX, OP_PKSUBC, OP_PKMUL, OP_PKMAXSEL, OP_PERM, OP_SDWA, OP_MAX3, OP_MAX, OP_AND, OP_ANDOR, OP_LSHL, OP_BFE,
-       OP_ALIGN, OP_ADD3, OP_LSHLADD, OP_MULLO, OP_MADU24, OP_DPP, OP_MOVDPP, OP_FMA, OP_PKFMA16, OP_CNDMASK, OP_CMP, OP_SADU8, OP_MIN3U, OP_COUNT };
+       OP_ALIGN, OP_ADD3, OP_LSHLADD, OP_MULLO, OP_MADU24, OP_DPP, OP_MOVDPP, OP_FMA, OP_PKFMA16, OP_CNDMASK, OP_CMP, OP_SADU8, OP_MIN3U, OP_SUB, OP_OR, OP_XOR, OP_MOV, OP_MINU, OP_MAXU, OP_LSHR, OP_ADDF, OP_SUBF, OP_MULF, OP_MAXF, OP_MINF, OP_MAX3F, OP_MED3F, OP_ADDF16, OP_MAXF16, OP_PKMAXF16, OP_PKADDF16, OP_ADDU16, OP_MAXI16, OP_MUL24, OP_CVTUB0, OP_CVTUB2, OP_CVTI, OP_CVTU8PK, OP_BFI, OP_XNOR, OP_DOT4, OP_ADDCO, OP_CMPCND, OP_SUBREVSDWA, OP_ANDE64, OP_ADDE64, OP_ADDFE64NEG, OP_MAXFE64ABS, OP_ANDSGPR, OP_ADDLIT, OP_ADDINL, OP_LSHL8, OP_LSHLV, OP_LSHL16, OP_LSHR16, OP_ASHR, OP_LSHLOR, OP_MINU16, OP_MAXU16, OP_MINI16, OP_SUBU16, OP_SUBU16C, OP_ADDU16C, OP_SUBU32C, OP_MULLO16, OP_MADU16, OP_MINF16, OP_SUBF16, OP_MULF16, OP_FMAF16, OP_MACF32, OP_MAXI16S, OP_ADDSGPR, OP_MAXI16LIT, OP_CNDAFTERCMP, OP_READLANE, OP_MBCNT, OP_COUNT };
 static const char *kNames[OP_COUNT] = {"v_add_u32", "v_pk_add_u16", "v_pk_max_i16", "v_pk_sub_u16 clamp", "v_pk_mul_lo_u16", "v_pk_max_i16 op_sel",
     "v_perm_b32", "v_add_u32_sdwa (BYTE_1)", "v_max3_i32", "v_max_i32", "v_and_b32", "v_and_or_b32", "v_lshlrev_b32", "v_bfe_u32",
     "v_alignbyte_b32", "v_add3_u32", "v_lshl_add_u32", "v_mul_lo_u32", "v_mad_u32_u24", "v_add_u32_dpp row_shr:1", "v_mov_b32_dpp row_shr:1",
-    "v_fma_f32", "v_pk_fma_f16", "v_cndmask_b32 (vcc)", "v_cmp_lt_u32 (vcc)", "v_sad_u8", "v_min3_u32"};
+    "v_fma_f32", "v_pk_fma_f16", "v_cndmask_b32 (vcc)", "v_cmp_lt_u32 (vcc)", "v_sad_u8", "v_min3_u32", "v_sub_u32", "v_or_b32", "v_xor_b32", "v_mov_b32", "v_min_u32", "v_max_u32", "v_lshrrev_b32", "v_add_f32", "v_sub_f32", "v_mul_f32", "v_max_f32", "v_min_f32", "v_max3_f32", "v_med3_f32", "v_add_f16", "v_max_f16", "v_pk_max_f16", "v_pk_add_f16", "v_add_u16", "v_max_i16", "v_mul_u32_u24", "v_cvt_f32_ubyte0", "v_cvt_f32_ubyte2", "v_cvt_f32_i32", "v_cvt_pk_u8_f32", "v_bfi_b32", "v_xnor_b32", "v_dot4_i32_i8", "v_add_co_u32 (vcc)", "v_cmp_eq_u32 + v_cndmask_b32 (pair = 2 instr)", "v_sub_u32_sdwa (WORD_1)", "v_and_b32_e64 (VOP3 encoding)", "v_add_u32_e64 (VOP3 encoding)", "v_add_f32_e64 with neg modifier", "v_max_f32_e64 with abs modifier", "v_and_b32 with SGPR operand", "v_add_u32 with literal", "v_add_u32 with inline constant", "v_lshlrev_b32 by 8", "v_lshlrev_b32 by VGPR", "v_lshlrev_b16 by 1", "v_lshrrev_b16 by 1", "v_ashrrev_i32 by 1", "v_lshl_or_b32", "v_min_u16", "v_max_u16", "v_min_i16", "v_sub_u16", "v_sub_u16 clamp", "v_add_u16 clamp", "v_sub_u32 clamp", "v_mul_lo_u16", "v_mad_u16", "v_min_f16", "v_sub_f16", "v_mul_f16", "v_fma_f16", "v_fmac_f32", "v_max_i16 with SGPR operand", "v_add_u32 with SGPR operand", "v_max_i16 with inline constant", "v_cndmask_b32 x8 after one v_cmp (8 instr)", "v_readfirstlane_b32 s5 (SALU dest)", "v_mbcnt_lo_u32_b32"};
 
 template <int OP>
 __global__ __launch_bounds__(256) void issue(uint32_t *out, unsigned long long *cyc, uint32_t seed) {
@@ -93,6 +158,70 @@ __global__ __launch_bounds__(256) void issue(uint32_t *out, unsigned long long *
             else if constexpr (OP == OP_CMP) { ROW(I_CMP) }
             else if constexpr (OP == OP_SADU8) { ROW(I_SADU8) }
             else if constexpr (OP == OP_MIN3U) { ROW(I_MIN3U) }
+            else if constexpr (OP == OP_SUB) { ROW(I_SUB) }
+            else if constexpr (OP == OP_OR) { ROW(I_OR) }
+            else if constexpr (OP == OP_XOR) { ROW(I_XOR) }
+            else if constexpr (OP == OP_MOV) { ROW(I_MOV) }
+            else if constexpr (OP == OP_MINU) { ROW(I_MINU) }
+            else if constexpr (OP == OP_MAXU) { ROW(I_MAXU) }
+            else if constexpr (OP == OP_LSHR) { ROW(I_LSHR) }
+            else if constexpr (OP == OP_ADDF) { ROW(I_ADDF) }
+            else if constexpr (OP == OP_SUBF) { ROW(I_SUBF) }
+            else if constexpr (OP == OP_MULF) { ROW(I_MULF) }
+            else if constexpr (OP == OP_MAXF) { ROW(I_MAXF) }
+            else if constexpr (OP == OP_MINF) { ROW(I_MINF) }
+            else if constexpr (OP == OP_MAX3F) { ROW(I_MAX3F) }
+            else if constexpr (OP == OP_MED3F) { ROW(I_MED3F) }
+            else if constexpr (OP == OP_ADDF16) { ROW(I_ADDF16) }
+            else if constexpr (OP == OP_MAXF16) { ROW(I_MAXF16) }
+            else if constexpr (OP == OP_PKMAXF16) { ROW(I_PKMAXF16) }
+            else if constexpr (OP == OP_PKADDF16) { ROW(I_PKADDF16) }
+            else if constexpr (OP == OP_ADDU16) { ROW(I_ADDU16) }
+            else if constexpr (OP == OP_MAXI16) { ROW(I_MAXI16) }
+            else if constexpr (OP == OP_MUL24) { ROW(I_MUL24) }
+            else if constexpr (OP == OP_CVTUB0) { ROW(I_CVTUB0) }
+            else if constexpr (OP == OP_CVTUB2) { ROW(I_CVTUB2) }
+            else if constexpr (OP == OP_CVTI) { ROW(I_CVTI) }
+            else if constexpr (OP == OP_CVTU8PK) { ROW(I_CVTU8PK) }
+            else if constexpr (OP == OP_BFI) { ROW(I_BFI) }
+            else if constexpr (OP == OP_XNOR) { ROW(I_XNOR) }
+            else if constexpr (OP == OP_DOT4) { ROW(I_DOT4) }
+            else if constexpr (OP == OP_ADDCO) { ROW(I_ADDCO) }
+            else if constexpr (OP == OP_CMPCND) { ROW(I_CMPCND) }
+            else if constexpr (OP == OP_SUBREVSDWA) { ROW(I_SUBREVSDWA) }
+            else if constexpr (OP == OP_ANDE64) { ROW(I_ANDE64) }
+            else if constexpr (OP == OP_ADDE64) { ROW(I_ADDE64) }
+            else if constexpr (OP == OP_ADDFE64NEG) { ROW(I_ADDFE64NEG) }
+            else if constexpr (OP == OP_MAXFE64ABS) { ROW(I_MAXFE64ABS) }
+            else if constexpr (OP == OP_ANDSGPR) { ROW(I_ANDSGPR) }
+            else if constexpr (OP == OP_ADDLIT) { ROW(I_ADDLIT) }
+            else if constexpr (OP == OP_ADDINL) { ROW(I_ADDINL) }
+            else if constexpr (OP == OP_LSHL8) { ROW(I_LSHL8) }
+            else if constexpr (OP == OP_LSHLV) { ROW(I_LSHLV) }
+            else if constexpr (OP == OP_LSHL16) { ROW(I_LSHL16) }
+            else if constexpr (OP == OP_LSHR16) { ROW(I_LSHR16) }
+            else if constexpr (OP == OP_ASHR) { ROW(I_ASHR) }
+            else if constexpr (OP == OP_LSHLOR) { ROW(I_LSHLOR) }
+            else if constexpr (OP == OP_MINU16) { ROW(I_MINU16) }
+            else if constexpr (OP == OP_MAXU16) { ROW(I_MAXU16) }
+            else if constexpr (OP == OP_MINI16) { ROW(I_MINI16) }
+            else if constexpr (OP == OP_SUBU16) { ROW(I_SUBU16) }
+            else if constexpr (OP == OP_SUBU16C) { ROW(I_SUBU16C) }
+            else if constexpr (OP == OP_ADDU16C) { ROW(I_ADDU16C) }
+            else if constexpr (OP == OP_SUBU32C) { ROW(I_SUBU32C) }
+            else if constexpr (OP == OP_MULLO16) { ROW(I_MULLO16) }
+            else if constexpr (OP == OP_MADU16) { ROW(I_MADU16) }
+            else if constexpr (OP == OP_MINF16) { ROW(I_MINF16) }
+            else if constexpr (OP == OP_SUBF16) { ROW(I_SUBF16) }
+            else if constexpr (OP == OP_MULF16) { ROW(I_MULF16) }
+            else if constexpr (OP == OP_FMAF16) { ROW(I_FMAF16) }
+            else if constexpr (OP == OP_MACF32) { ROW(I_MACF32) }
+            else if constexpr (OP == OP_MAXI16S) { ROW(I_MAXI16S) }
+            else if constexpr (OP == OP_ADDSGPR) { ROW(I_ADDSGPR) }
+            else if constexpr (OP == OP_MAXI16LIT) { ROW(I_MAXI16LIT) }
+            else if constexpr (OP == OP_CNDAFTERCMP) { ROW(I_CNDAFTERCMP) }
+            else if constexpr (OP == OP_READLANE) { ROW(I_READLANE) }
+            else if constexpr (OP == OP_MBCNT) { ROW(I_MBCNT) }
         }
     }
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();

@@ -32,13 +32,18 @@ def lib():
 class FmIndex:
     """in-memory index: ref_seq_len, count[5] (file convention, not yet +1), cp_occ bytes, sentinel_index"""
 
-    def __init__(self, fwd_codes):
+    def __init__(self, fwd_codes, power=0):
+        """power = m > 0: the index of the reference (U . revcomp(U))^m with U = fwd_codes, produced without sorting the
+        whole text (gab_mkindex_build_power): how the tests get an index of >= 2^32 rows in seconds"""
         fwd = np.ascontiguousarray(fwd_codes, np.uint8)
         self._fwd = fwd
         self._raw = GabFmIndex()
-        rc = lib().gab_mkindex_build(fwd.ctypes.data_as(C.c_void_p), C.c_int64(len(fwd)), C.byref(self._raw))
+        if power:
+            rc = lib().gab_mkindex_build_power(fwd.ctypes.data_as(C.c_void_p), C.c_int64(len(fwd)), C.c_int64(power), C.byref(self._raw))
+        else:
+            rc = lib().gab_mkindex_build(fwd.ctypes.data_as(C.c_void_p), C.c_int64(len(fwd)), C.byref(self._raw))
         if rc:
-            raise RuntimeError(f"gab_mkindex_build failed ({rc})")
+            raise RuntimeError(f"gab_mkindex_build{'_power' if power else ''} failed ({rc})")
         r = self._raw
         self.ref_seq_len = r.ref_seq_len
         self.count = np.array(list(r.count), np.int64)

@@ -149,6 +149,103 @@ int gab_mkindex_build(const uint8_t *fwd, int64_t L, gab_fmindex *out) {
     return 0;
 }
 
+/* ------------------------------------------------------------------ periodic text, any size -----
+ * Index of the reference W^m with W = U . revcomp(U) (its own reverse complement), built WITHOUT sorting the whole text:
+ * BWA-MEM2 indexes T = reference + its reverse complement = W^k, k = 2m, w = |W|.  A suffix of T$ is W[r..) W^e $ with e
+ * full copies behind it.  Two such strings are ordered within their first 2w characters unless they are the same rotation
+ * r, and then the one with fewer copies (the $ comes sooner) is smaller.  Hence the suffix array of X = W^3 $ (e = 0, 1, 2)
+ * already is the suffix array of T$: every e = 2 entry of it stands for the run e = 2, 3, ..., k-1 in this order (all of
+ * them share >= 2w + 1 characters, enough to decide every comparison with an e <= 1 suffix), and the e = 0, 1 entries stay
+ * single rows.  Needs W primitive (checked) and k >= 3.  Rows, counts, the sampled suffix array and the sentinel row are
+ * produced in one streaming pass, so a >= 2^32-row index (what a human genome has: the 40-bit interval arithmetic of the
+ * seeding kernel) costs seconds.  tests/test_mkindex.py checks the result against gab_mkindex_build on small cases. */
+static int is_primitive(const uint8_t *W, int64_t w) {
+    int64_t *fail = (int64_t *)malloc(sizeof(int64_t) * (size_t)(w + 1));
+    if (!fail) return -1;
+    fail[0] = -1;
+    int64_t kk = -1;
+    for (int64_t i = 0; i < w; i++) {
+        while (kk >= 0 && W[kk] != W[i]) kk = fail[kk];
+        fail[i + 1] = ++kk;
+    }
+    const int64_t period = w - fail[w];
+    free(fail);
+    return !(period < w && w % period == 0);
+}
+typedef struct { gab_fmindex *o; int64_t row, run[4]; } emitter;
+static void emit_rows(emitter *E, int c, int64_t len, int64_t sa0, int64_t sa_step) {
+    /* `len` consecutive rows with BWT symbol c (0..3; 4 = the sentinel row, no bit set); row j has suffix position
+     * sa0 + j * sa_step.  Word by word: a run of a few thousand equal symbols is the common case. */
+    gab_fmindex *o = E->o;
+    const int64_t r0 = E->row, r1 = r0 + len;
+    for (int64_t i = r0; i < r1;) {
+        const int64_t wend = ((i >> 6) + 1) << 6, e = wend < r1 ? wend : r1;       /* rows [i, e) lie in one 64-row record */
+        gab_cp_occ *rec = &o->cp_occ[i >> 6];
+        if ((i & 63) == 0) for (int q = 0; q < 4; q++) rec->cp_count[q] = E->run[q] + (q == c ? i - r0 : 0);
+        if (c < 4) {
+            const int nb = (int)(e - i), sh = (int)(i & 63);                         /* nb bits from position sh, MSB first */
+            const uint64_t m = (nb == 64 ? ~0ull : ((1ull << nb) - 1ull) << (64 - nb)) >> sh;
+            rec->one_hot_bwt_str[c] |= m;
+        }
+        i = e;
+    }
+    for (int64_t i = (r0 + 7) & ~7ll; i < r1; i += 8) {
+        const int64_t sa = sa0 + (i - r0) * sa_step;
+        o->sa_ls_word[i >> 3] = (uint32_t)(sa & 0xffffffffll); o->sa_ms_byte[i >> 3] = (int8_t)(sa >> 32);
+    }
+    if (c < 4) E->run[c] += len;
+    E->row += len;
+}
+int gab_mkindex_build_power(const uint8_t *U, int64_t ulen, int64_t m, gab_fmindex *out) {
+    memset(out, 0, sizeof(*out));
+    const int64_t w = 2 * ulen, k = 2 * m;
+    if (ulen <= 0 || k < 3 || 3 * w + 1 >= 0x7fffffffll || (double)k * (double)w > 5.0e11) return -1;
+    uint8_t *W = (uint8_t *)malloc((size_t)w), *X = (uint8_t *)malloc((size_t)(3 * w + 1));
+    int32_t *SA = (int32_t *)malloc(sizeof(int32_t) * (size_t)(3 * w + 1));
+    if (!W || !X || !SA) { free(W); free(X); free(SA); return -2; }
+    int64_t cntW[4] = {0, 0, 0, 0};
+    for (int64_t i = 0; i < ulen; i++) {
+        if (U[i] > 3) { free(W); free(X); free(SA); return -3; }
+        W[i] = U[i]; W[w - 1 - i] = (uint8_t)(3 - U[i]);
+    }
+    for (int64_t i = 0; i < w; i++) cntW[W[i]]++;
+    if (is_primitive(W, w) != 1) { free(W); free(X); free(SA); return -5; }
+    for (int64_t i = 0; i < 3 * w; i++) X[i] = (uint8_t)(W[i % w] + 1);
+    X[3 * w] = 0;
+    if (gab_sais_u8(X, SA, (int32_t)(3 * w + 1), 5)) { free(W); free(X); free(SA); return -4; }
+    free(X);
+    const int64_t N = k * w, n = N + 1;
+    out->ref_seq_len = n;
+    out->count[0] = 0; out->count[1] = k * cntW[0]; out->count[2] = k * (cntW[0] + cntW[1]);
+    out->count[3] = k * (cntW[0] + cntW[1] + cntW[2]); out->count[4] = N;
+    out->cp_occ_size = (n >> 6) + 1;
+    out->cp_occ = (gab_cp_occ *)calloc((size_t)out->cp_occ_size, sizeof(gab_cp_occ));
+    out->n_sa = (n >> 3) + 1;
+    out->sa_ms_byte = (int8_t *)calloc((size_t)out->n_sa, 1);
+    out->sa_ls_word = (uint32_t *)calloc((size_t)out->n_sa, sizeof(uint32_t));
+    if (!out->cp_occ || !out->sa_ms_byte || !out->sa_ls_word) { free(W); free(SA); gab_mkindex_free(out); return -2; }
+    emitter E; memset(&E, 0, sizeof E); E.o = out;
+    out->sentinel_index = -1;
+    for (int64_t i = 0; i <= 3 * w; i++) {
+        const int64_t p = SA[i];
+        if (p == 3 * w) { emit_rows(&E, W[w - 1], 1, N, 0); continue; }          /* the empty suffix: preceded by T's last base */
+        const int64_t e = 2 - p / w, r = p % w;
+        const int c = r > 0 ? W[r - 1] : W[w - 1];
+        if (e < 2) { emit_rows(&E, c, 1, (k - 1 - e) * w + r, 0); continue; }
+        /* e' = 2 .. k-1: positions (k-1-e') * w + r, descending by w; the last one (e' = k-1) is position r of T */
+        if (r > 0) emit_rows(&E, c, k - 2, (k - 3) * w + r, -w);
+        else {
+            emit_rows(&E, c, k - 3, (k - 3) * w, -w);
+            out->sentinel_index = E.row;
+            emit_rows(&E, 4, 1, 0, 0);                                             /* suffix 0 = T itself: preceded by nothing */
+        }
+    }
+    free(W); free(SA);
+    /* the record behind the last row keeps the final counts when n is a multiple of 64 (as the full builder leaves it) */
+    if (E.row != n || out->sentinel_index < 0) { gab_mkindex_free(out); return -6; }
+    return 0;
+}
+
 void gab_mkindex_free(gab_fmindex *idx) {
     free(idx->cp_occ); free(idx->sa_ms_byte); free(idx->sa_ls_word);
     idx->cp_occ = NULL; idx->sa_ms_byte = NULL; idx->sa_ls_word = NULL;

@@ -31,6 +31,8 @@ typedef struct {
 
 /* fwd: ref_len base codes 0..3.  Returns 0 on success. */
 int gab_mkindex_build(const uint8_t *fwd, int64_t ref_len, gab_fmindex *out);
+/* index of the reference (U . revcomp(U))^m without sorting the whole text (see gab_mkindex.c): any size, e.g. >= 2^32 rows */
+int gab_mkindex_build_power(const uint8_t *U, int64_t ulen, int64_t m, gab_fmindex *out);
 void gab_mkindex_free(gab_fmindex *idx);
 /* writes <prefix>.bwt.2bit.64 */
 int gab_mkindex_write(const gab_fmindex *idx, const char *prefix);

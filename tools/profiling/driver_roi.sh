@@ -1,0 +1,31 @@
+#!/bin/bash
+# The drop-in drivers' own region of interest on the LARGE inputs (what a user of the reference's harness sees: host
+# pointers in, host pointers out, PCIe both ways), next to the compiled reference on the box's host cores when oracle/_ref
+# travelled.  Run on the GPU box:  bash tools/profiling/driver_roi.sh [workers ...]  -> one line per run on stdout
+cd "$GRAFT_REPO_ROOT" || exit 1
+T=/tmp/gab_roi; mkdir -p $T
+python - <<'PY'
+import sys, os
+sys.path.insert(0, os.getcwd())
+from tools import gabgen
+T = "/tmp/gab_roi"
+if not os.path.exists(f"{T}/bsw.txt"):
+    gabgen.write_text("bsw", f"{T}/bsw.txt", 2, 10_000_000, 0)
+if not os.path.exists(f"{T}/chain.txt"):
+    gabgen.write_text("chain", f"{T}/chain.txt", 5, 10_000, 0, 50, 60000)
+PY
+cores=$(python3 -c "import os; print(len(os.sched_getaffinity(0)))")
+for w in ${@:-1 2 3}; do   # chain-large through the driver needs its fscanf parse of 85 M anchors (~20 s) per run
+  export GAB_WORKERS_PER_GPU=$w GAB_GPUS=1
+  ./benchmarks/bsw/main_bsw -pairs $T/bsw.txt -t 1 -b 512 2> $T/bsw_err_$w.txt | grep -E "Overall SW" | sed "s/^/bsw-large driver, $w worker(s) per GPU: /"
+  echo "   md5 of the scores: $(grep score= $T/bsw_err_$w.txt | md5sum | cut -c1-12)"
+  ./benchmarks/chain/chain -i $T/chain.txt -o $T/chain_out_$w.txt -t 1 2>&1 | grep "Time in kernel" | sed "s/^/chain-large driver, $w worker(s) per GPU: /"
+  echo "   md5 of the output: $(md5sum $T/chain_out_$w.txt | cut -c1-12)"
+  ./benchmarks/fast-chain/chain -i $T/chain.txt -o $T/fchain_out_$w.txt -t 1 2>&1 | grep "Time in kernel" | sed "s/^/fast-chain-large driver, $w worker(s) per GPU: /"
+done
+if [[ -x oracle/_ref/bsw_ref_avx512 ]]; then
+  OMP_PROC_BIND=true OMP_PLACES=cores oracle/_ref/bsw_ref_avx512 -pairs $T/bsw.txt -t $cores -b 512 2> $T/bsw_ref_err.txt | grep -E "Overall SW" | sed "s/^/bsw-large reference (avx512), $cores threads: /"
+  echo "   md5 of the scores: $(grep score= $T/bsw_ref_err.txt | head -10000000 | md5sum | cut -c1-12)"
+  OMP_PROC_BIND=true OMP_PLACES=cores oracle/_ref/chain_ref -i $T/chain.txt -o $T/chain_ref_out.txt -t $cores 2>&1 | grep "Time in kernel" | sed "s/^/chain-large reference, $cores threads: /"
+  echo "   md5 of the output: $(md5sum $T/chain_ref_out.txt | cut -c1-12)"
+fi
