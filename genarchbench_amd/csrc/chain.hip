@@ -108,9 +108,18 @@ constexpr int kRingSafe = kRing - 8;      // entries younger than this are read 
 // adds score[j], and runs the marks / prefix-max / n_skip steps described above.  Windows deeper than 256
 // predecessors continue in the main wave, which then evaluates the geometry itself.
 constexpr int kChPriorityCalls = 128;         // the longest calls (= first workgroups) run at raised wave priority
-constexpr int kChHelpers = 2;
-constexpr int kChBlock = 2;
-constexpr int kGeoDepth = 1024;              // predecessors per anchor the helpers prepare (four super-chunks)
+#ifndef GAB_CH_HELPERS                        // tuning builds only (-DGAB_CH_HELPERS=.. -DGAB_CH_BLOCK=.. -DGAB_CH_GEODEPTH=..)
+#define GAB_CH_HELPERS 3
+#endif
+#ifndef GAB_CH_BLOCK
+#define GAB_CH_BLOCK GAB_CH_HELPERS
+#endif
+#ifndef GAB_CH_GEODEPTH
+#define GAB_CH_GEODEPTH 1024
+#endif
+constexpr int kChHelpers = GAB_CH_HELPERS;
+constexpr int kChBlock = GAB_CH_BLOCK;
+constexpr int kGeoDepth = GAB_CH_GEODEPTH;   // predecessors per anchor the helpers prepare (kGeoDepth / 256 super-chunks)
 constexpr int kGeoNone = (int)0x80000000;      // predecessor filtered out (or outside the window)
 
 __device__ __forceinline__ int32_t chain_geometry(uint64_t xi, int32_t qi, int32_t q_span, int32_t sidi, uint64_t xj, uint32_t yj,
@@ -132,7 +141,9 @@ __device__ __forceinline__ int32_t chain_geometry(uint64_t xi, int32_t qi, int32
         if (dr == 0) { ++v; gap = 0; }
         else gap = c_lin < lg ? c_lin : lg;
     } else gap = c_lin + (lg >> 1);
-    v -= (int32_t)(__dadd_rn((double)gap, .499));     // (int)((double)gap_cost * 1.0f + .499)
+    // (int)((double)gap_cost * 1.0f + .499): gap_cost is an integer, so the truncation gives gap_cost itself when it is
+    // >= 0 and gap_cost + 1 when it is negative (a negative avg_qspan makes it so): two integer operations, no fp64
+    v -= gap - (gap >> 31);
     return v;
 }
 
@@ -211,7 +222,7 @@ __global__ __launch_bounds__(64 * (1 + kChHelpers)) void chain_hw_kernel(const C
     }
 
     // ================= main wave
-    unsigned long long evals = 0;
+    unsigned long long evals = 0, exact_evals = 0;
     int i = 0;
     __syncthreads();                                                    // block 0 is ready
     for (int t = 0; t < nblocks; t++) {
@@ -229,141 +240,219 @@ __global__ __launch_bounds__(64 * (1 + kChHelpers)) void chain_hw_kernel(const C
             const uint64_t xi = meta_x[buf][b], yi = meta_y[buf][b];
             const int32_t qi = (int32_t)yi, q_span = (int32_t)(yi >> 32 & 0xff), sidi = (int32_t)(yi >> 48 & 0xff);
 
+            // ---- fast path: the plain maximum over the whole window (ties -> larger j), no marks / n_skip bookkeeping.
+            // It IS the reference's result whenever at most kMaxSkip unfiltered predecessors are newer than its argmax J*:
+            // n_skip grows by at most one per unfiltered item, so the scan cannot have stopped before J*; at J* the score
+            // beats everything newer (J* is the newest item with the maximum), and nothing older can improve on it, so
+            // whatever max_skip does afterwards leaves (score, parent) alone.  With no improvement over q_span at all the
+            // result is (q_span, -1) in both.  On the suite's inputs this certifies every anchor (dense adversarial sets:
+            // 96-98 %); the rest take the exact path below.
             int32_t best = q_span, best_j = -1;
-            int n_skip = 0;
-            bool broke = false;
-            const uint16_t tag = (uint16_t)(0x8000 | (i & 0x7fff));
-
-            int chunk = 0;
-            for (int top = i - 1; top >= st && !broke; chunk++) {
-                const int g = (top >> 2) - lane;               // this lane's group: entries 4g .. 4g+3 (may be negative)
-                const int j0 = 4 * g;
-                const bool first = chunk < kGeoDepth / 256;    // the newest predecessors: geometry comes from the helpers
-                const bool in_ring = i - j0 <= kRingSafe;
-                const bool any_valid = j0 + 3 >= st && j0 <= top;
-                bool valid[4], ok[4];
-                int32_t sc[4], parj[4] = {-1, -1, -1, -1};
+            bool certified;
+            {
+                int chunk = 0;
+                for (int top = i - 1; top >= st; chunk++) {
+                    const int g = (top >> 2) - lane;
+                    const int j0 = 4 * g;
+                    const bool first = chunk < kGeoDepth / 256;
+                    const bool in_ring = i - j0 <= kRingSafe;
+                    const bool any_valid = j0 + 3 >= st && j0 <= top;
+                    int lm = NEG, lj = 0;
+                    if (first) {
+                        if (any_valid) {
+                            const int r = (int)(j0 & (kRing - 1));
+                            const int4 gv = *reinterpret_cast<const int4 *>(&geo[buf][b][j0 & (kGeoDepth - 1)]);
+                            const int4 sv = *reinterpret_cast<const int4 *>(&ring_sc[r]);
+                            const int gk[4] = {gv.w, gv.z, gv.y, gv.x}, sk[4] = {sv.w, sv.z, sv.y, sv.x};
 #pragma unroll
-                for (int k = 0; k < 4; k++) { const int j = j0 + 3 - k; valid[k] = j >= st && j <= top; ok[k] = false; sc[k] = 0; }
-                if (first) {
-                    if (any_valid) {
-                        const int r = (int)(j0 & (kRing - 1));
-                        const int4 gv = *reinterpret_cast<const int4 *>(&geo[buf][b][j0 & (kGeoDepth - 1)]);
-                        const int4 sv = *reinterpret_cast<const int4 *>(&ring_sc[r]);
-                        const int4 pv = *reinterpret_cast<const int4 *>(&ring_par[r]);
-                        const int gk[4] = {gv.w, gv.z, gv.y, gv.x}, sk[4] = {sv.w, sv.z, sv.y, sv.x};
-                        parj[0] = pv.w; parj[1] = pv.z; parj[2] = pv.y; parj[3] = pv.x;
-#pragma unroll
-                        for (int k = 0; k < 4; k++) { ok[k] = valid[k] && gk[k] != kGeoNone; sc[k] = gk[k] + sk[k]; }
-                    }
-                } else if (any_valid) {
-                    uint64_t xj[4] = {0, 0, 0, 0}; uint32_t yj[4] = {0, 0, 0, 0};
-                    int32_t scj[4] = {0, 0, 0, 0}, sidj[4] = {0, 0, 0, 0};
-                    // beyond what the helpers prepared: x / y are input (plain loads), score / parent come from the LDS
-                    // ring while young enough, else back from L2 (stored by this wave earlier)
-                    if (!in_ring) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    int4 sv = {0, 0, 0, 0}, pv = {-1, -1, -1, -1};
-                    if (in_ring) {
-                        const int r = (int)(j0 & (kRing - 1));
-                        sv = *reinterpret_cast<const int4 *>(&ring_sc[r]);
-                        pv = *reinterpret_cast<const int4 *>(&ring_par[r]);
-                    }
-                    const int sk[4] = {sv.w, sv.z, sv.y, sv.x}, pk4[4] = {pv.w, pv.z, pv.y, pv.x};
-#pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        const int j = j0 + 3 - k;
-                        if (valid[k]) {
-                            xj[k] = X[j];
-                            const uint64_t yy = Y[j];
-                            yj[k] = (uint32_t)yy; sidj[k] = (int)(yy >> 48 & 0xff);
-                            if (in_ring) { scj[k] = sk[k]; parj[k] = pk4[k]; }
-                            else {
-                                scj[k] = __hip_atomic_load(&S[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                parj[k] = __hip_atomic_load(&P[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            for (int k = 0; k < 4; k++) {
+                                const int j = j0 + 3 - k;
+                                const int v = gk[k] + sk[k];
+                                if (j >= st && j <= top && gk[k] != kGeoNone && v > lm) { lm = v; lj = j; }
                             }
                         }
-                    }
-#pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        bool okk;
-                        const int32_t v = chain_geometry(xi, qi, q_span, sidi, xj[k], yj[k], sidj[k], mdx, mdy, bw, multi_seg, avg_d, okk);
-                        ok[k] = valid[k] && okk;
-                        sc[k] = v + scj[k];
-                    }
-                }
-                // ---- marks: scatter, then read this group's own four tags (LDS is in order within the wave)
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    if (ok[k] && parj[k] >= 0 && parj[k] >= st) {
-                        if (i - parj[k] <= kRingSafe) marks[parj[k] & (kMarkRing - 1)] = tag;
-                        else __hip_atomic_store(&GM[parj[k]], (int32_t)(i + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-                }
-                const bool deep = i - (4 * ((top >> 2) - 63)) > kRingSafe;        // wave-uniform: this super-chunk leaves the ring
-                if (deep) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                bool hit[4];
-                {   // a mark lives in the LDS ring or in the global array according to the age of the marked anchor itself
-                    const uint2 mv = *reinterpret_cast<const uint2 *>(&marks[j0 & (kMarkRing - 1)]);
-                    hit[0] = (mv.y >> 16) == tag; hit[1] = (mv.y & 0xffffu) == tag; hit[2] = (mv.x >> 16) == tag; hit[3] = (mv.x & 0xffffu) == tag;
-                    if (!in_ring) {
+                    } else if (any_valid) {
+                        if (!in_ring) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        int4 sv = {0, 0, 0, 0};
+                        if (in_ring) sv = *reinterpret_cast<const int4 *>(&ring_sc[(int)(j0 & (kRing - 1))]);
+                        const int sk[4] = {sv.w, sv.z, sv.y, sv.x};
 #pragma unroll
                         for (int k = 0; k < 4; k++) {
                             const int j = j0 + 3 - k;
-                            if (i - j > kRingSafe)
-                                hit[k] = ok[k] && __hip_atomic_load(&GM[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int32_t)(i + 1);
+                            if (j >= st && j <= top) {
+                                const uint64_t xj = X[j], yy = Y[j];
+                                const int scj = in_ring ? sk[k] : __hip_atomic_load(&S[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                bool okk;
+                                const int32_t v = chain_geometry(xi, qi, q_span, sidi, xj, (uint32_t)yy, (int32_t)(yy >> 48 & 0xff), mdx, mdy, bw,
+                                                                 multi_seg, avg_d, okk) + scj;
+                                if (okk && v > lm) { lm = v; lj = j; }
+                            }
                         }
                     }
+                    const int m = __builtin_amdgcn_readlane(wave_incl_max(lm), 63);
+                    if (m > best) {                              // wave-uniform; lane order is descending j: the first lane wins ties
+                        const unsigned long long mm = __ballot(lm == m);
+                        best = m; best_j = __builtin_amdgcn_readlane(lj, __builtin_ctzll(mm));
+                    }
+                    evals += (unsigned)max(min(top, j0 + 3) - max(st, j0) + 1, 0);
+                    top = 4 * ((top >> 2) - 63) - 1;
                 }
-                // ---- improvement flags
-                int lmax = NEG;
+                // level 1: the argmax is among the kMaxSkip newest anchors (free); level 2: count the unfiltered ones newer
+                // than it (only ever needed inside the region the helpers prepared)
+                certified = best_j < 0 || i - 1 - best_j <= kMaxSkip;
+                if (!certified && i - 1 - best_j < kGeoDepth - 8) {
+                    int cnt = 0;
+                    for (int top = i - 1; top > best_j; top = 4 * ((top >> 2) - 63) - 1) {
+                        const int j0 = 4 * ((top >> 2) - lane);
+                        if (j0 + 3 > best_j && j0 <= top) {
+                            const int4 gv = *reinterpret_cast<const int4 *>(&geo[buf][b][j0 & (kGeoDepth - 1)]);
+                            const int gk[4] = {gv.w, gv.z, gv.y, gv.x};
 #pragma unroll
-                for (int k = 0; k < 4; k++) lmax = ok[k] ? max(lmax, sc[k]) : lmax;
-                const int incl = wave_incl_max(lmax);
-                int run = max(wave_shr1(incl, NEG), best);
-                bool imp[4];
-                int d[4];
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    imp[k] = ok[k] && sc[k] > run;
-                    run = ok[k] ? max(run, sc[k]) : run;
-                    d[k] = imp[k] ? -1 : (ok[k] && hit[k]) ? 1 : 0;
+                            for (int k = 0; k < 4; k++) { const int j = j0 + 3 - k; cnt += (j > best_j && j <= top && gk[k] != kGeoNone) ? 1 : 0; }
+                        }
+                    }
+                    cnt = __builtin_amdgcn_readlane(wave_incl_sum(cnt), 63);
+                    certified = cnt <= kMaxSkip;
                 }
-                // ---- n_skip: reflected counter in closed form
-                const int p0 = d[0], p1 = p0 + d[1], p2 = p1 + d[2], p3 = p2 + d[3];
-                const int E = wave_incl_sum(p3) - p3;                              // exclusive sum over earlier lanes
-                const int mloc = min(min(p0, p1), min(p2, p3));
-                const int inclmin = wave_incl_min(E + mloc);
-                int rmin = min(-n_skip, wave_shr1(inclmin, 0x7fffffff));
-                int cnt[4];
-                const int pk[4] = {p0, p1, p2, p3};
-                int kfirst = 4;
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    rmin = min(rmin, E + pk[k]);
-                    cnt[k] = E + pk[k] - rmin;
-                    if (d[k] == 1 && cnt[k] > kMaxSkip && kfirst == 4) kfirst = k;
+            }
+            if (!certified) {
+                // ---- exact path: the reference's scan with its max_skip early exit, in parallel form
+                best = q_span; best_j = -1;
+                int n_skip = 0;
+                bool broke = false;
+                const uint16_t tag = (uint16_t)(0x8000 | (i & 0x7fff));
+
+                int chunk = 0;
+                for (int top = i - 1; top >= st && !broke; chunk++) {
+                    const int g = (top >> 2) - lane;               // this lane's group: entries 4g .. 4g+3 (may be negative)
+                    const int j0 = 4 * g;
+                    const bool first = chunk < kGeoDepth / 256;    // the newest predecessors: geometry comes from the helpers
+                    const bool in_ring = i - j0 <= kRingSafe;
+                    const bool any_valid = j0 + 3 >= st && j0 <= top;
+                    bool valid[4], ok[4];
+                    int32_t sc[4], parj[4] = {-1, -1, -1, -1};
+    #pragma unroll
+                    for (int k = 0; k < 4; k++) { const int j = j0 + 3 - k; valid[k] = j >= st && j <= top; ok[k] = false; sc[k] = 0; }
+                    if (first) {
+                        if (any_valid) {
+                            const int r = (int)(j0 & (kRing - 1));
+                            const int4 gv = *reinterpret_cast<const int4 *>(&geo[buf][b][j0 & (kGeoDepth - 1)]);
+                            const int4 sv = *reinterpret_cast<const int4 *>(&ring_sc[r]);
+                            const int4 pv = *reinterpret_cast<const int4 *>(&ring_par[r]);
+                            const int gk[4] = {gv.w, gv.z, gv.y, gv.x}, sk[4] = {sv.w, sv.z, sv.y, sv.x};
+                            parj[0] = pv.w; parj[1] = pv.z; parj[2] = pv.y; parj[3] = pv.x;
+    #pragma unroll
+                            for (int k = 0; k < 4; k++) { ok[k] = valid[k] && gk[k] != kGeoNone; sc[k] = gk[k] + sk[k]; }
+                        }
+                    } else if (any_valid) {
+                        uint64_t xj[4] = {0, 0, 0, 0}; uint32_t yj[4] = {0, 0, 0, 0};
+                        int32_t scj[4] = {0, 0, 0, 0}, sidj[4] = {0, 0, 0, 0};
+                        // beyond what the helpers prepared: x / y are input (plain loads), score / parent come from the LDS
+                        // ring while young enough, else back from L2 (stored by this wave earlier)
+                        if (!in_ring) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        int4 sv = {0, 0, 0, 0}, pv = {-1, -1, -1, -1};
+                        if (in_ring) {
+                            const int r = (int)(j0 & (kRing - 1));
+                            sv = *reinterpret_cast<const int4 *>(&ring_sc[r]);
+                            pv = *reinterpret_cast<const int4 *>(&ring_par[r]);
+                        }
+                        const int sk[4] = {sv.w, sv.z, sv.y, sv.x}, pk4[4] = {pv.w, pv.z, pv.y, pv.x};
+    #pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            const int j = j0 + 3 - k;
+                            if (valid[k]) {
+                                xj[k] = X[j];
+                                const uint64_t yy = Y[j];
+                                yj[k] = (uint32_t)yy; sidj[k] = (int)(yy >> 48 & 0xff);
+                                if (in_ring) { scj[k] = sk[k]; parj[k] = pk4[k]; }
+                                else {
+                                    scj[k] = __hip_atomic_load(&S[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                    parj[k] = __hip_atomic_load(&P[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                }
+                            }
+                        }
+    #pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            bool okk;
+                            const int32_t v = chain_geometry(xi, qi, q_span, sidi, xj[k], yj[k], sidj[k], mdx, mdy, bw, multi_seg, avg_d, okk);
+                            ok[k] = valid[k] && okk;
+                            sc[k] = v + scj[k];
+                        }
+                    }
+                    // ---- marks: scatter, then read this group's own four tags (LDS is in order within the wave)
+    #pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        if (ok[k] && parj[k] >= 0 && parj[k] >= st) {
+                            if (i - parj[k] <= kRingSafe) marks[parj[k] & (kMarkRing - 1)] = tag;
+                            else __hip_atomic_store(&GM[parj[k]], (int32_t)(i + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                    }
+                    const bool deep = i - (4 * ((top >> 2) - 63)) > kRingSafe;        // wave-uniform: this super-chunk leaves the ring
+                    if (deep) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    bool hit[4];
+                    {   // a mark lives in the LDS ring or in the global array according to the age of the marked anchor itself
+                        const uint2 mv = *reinterpret_cast<const uint2 *>(&marks[j0 & (kMarkRing - 1)]);
+                        hit[0] = (mv.y >> 16) == tag; hit[1] = (mv.y & 0xffffu) == tag; hit[2] = (mv.x >> 16) == tag; hit[3] = (mv.x & 0xffffu) == tag;
+                        if (!in_ring) {
+    #pragma unroll
+                            for (int k = 0; k < 4; k++) {
+                                const int j = j0 + 3 - k;
+                                if (i - j > kRingSafe)
+                                    hit[k] = ok[k] && __hip_atomic_load(&GM[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int32_t)(i + 1);
+                            }
+                        }
+                    }
+                    // ---- improvement flags
+                    int lmax = NEG;
+    #pragma unroll
+                    for (int k = 0; k < 4; k++) lmax = ok[k] ? max(lmax, sc[k]) : lmax;
+                    const int incl = wave_incl_max(lmax);
+                    int run = max(wave_shr1(incl, NEG), best);
+                    bool imp[4];
+                    int d[4];
+    #pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        imp[k] = ok[k] && sc[k] > run;
+                        run = ok[k] ? max(run, sc[k]) : run;
+                        d[k] = imp[k] ? -1 : (ok[k] && hit[k]) ? 1 : 0;
+                    }
+                    // ---- n_skip: reflected counter in closed form
+                    const int p0 = d[0], p1 = p0 + d[1], p2 = p1 + d[2], p3 = p2 + d[3];
+                    const int E = wave_incl_sum(p3) - p3;                              // exclusive sum over earlier lanes
+                    const int mloc = min(min(p0, p1), min(p2, p3));
+                    const int inclmin = wave_incl_min(E + mloc);
+                    int rmin = min(-n_skip, wave_shr1(inclmin, 0x7fffffff));
+                    int cnt[4];
+                    const int pk[4] = {p0, p1, p2, p3};
+                    int kfirst = 4;
+    #pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        rmin = min(rmin, E + pk[k]);
+                        cnt[k] = E + pk[k] - rmin;
+                        if (d[k] == 1 && cnt[k] > kMaxSkip && kfirst == 4) kfirst = k;
+                    }
+                    const unsigned long long om = __ballot(kfirst < 4);
+                    int fl = 64, fk = 4;
+                    if (om) { fl = __builtin_ctzll(om); fk = __builtin_amdgcn_readlane(kfirst, fl); broke = true; }
+                    else n_skip = __builtin_amdgcn_readlane(cnt[3], 63);
+                    // ---- best = the last improvement before the break
+                    const int klim = lane < fl ? 4 : lane == fl ? fk : 0;              // items k < klim of this lane count
+                    int lastk = -1, lsc = 0, lj = 0;
+    #pragma unroll
+                    for (int k = 0; k < 4; k++)
+                        if (imp[k] && k < klim) { lastk = k; lsc = sc[k]; lj = j0 + 3 - k; }
+                    const unsigned long long lm = __ballot(lastk >= 0);
+                    if (lm) {
+                        const int ll = 63 - __builtin_clzll(lm);
+                        best = __builtin_amdgcn_readlane(lsc, ll);
+                        best_j = __builtin_amdgcn_readlane(lj, ll);
+                    }
+                    // visited predecessors (statistics): valid items up to and including the break item
+                    const int vlim = lane < fl ? 4 : lane == fl ? fk + 1 : 0;
+    #pragma unroll
+                    for (int k = 0; k < 4; k++) exact_evals += (valid[k] && k < vlim) ? 1 : 0;
+                    top = 4 * ((top >> 2) - 63) - 1;
                 }
-                const unsigned long long om = __ballot(kfirst < 4);
-                int fl = 64, fk = 4;
-                if (om) { fl = __builtin_ctzll(om); fk = __builtin_amdgcn_readlane(kfirst, fl); broke = true; }
-                else n_skip = __builtin_amdgcn_readlane(cnt[3], 63);
-                // ---- best = the last improvement before the break
-                const int klim = lane < fl ? 4 : lane == fl ? fk : 0;              // items k < klim of this lane count
-                int lastk = -1, lsc = 0, lj = 0;
-#pragma unroll
-                for (int k = 0; k < 4; k++)
-                    if (imp[k] && k < klim) { lastk = k; lsc = sc[k]; lj = j0 + 3 - k; }
-                const unsigned long long lm = __ballot(lastk >= 0);
-                if (lm) {
-                    const int ll = 63 - __builtin_clzll(lm);
-                    best = __builtin_amdgcn_readlane(lsc, ll);
-                    best_j = __builtin_amdgcn_readlane(lj, ll);
-                }
-                // visited predecessors (statistics): valid items up to and including the break item
-                const int vlim = lane < fl ? 4 : lane == fl ? fk + 1 : 0;
-#pragma unroll
-                for (int k = 0; k < 4; k++) evals += (valid[k] && k < vlim) ? 1 : 0;
-                top = 4 * ((top >> 2) - 63) - 1;
             }
             if (lane == 0) {
                 const int r = i & (kRing - 1);
@@ -377,6 +466,7 @@ __global__ __launch_bounds__(64 * (1 + kChHelpers)) void chain_hw_kernel(const C
         const int jo = done + lane;
         if (jo < n) { S[jo] = ring_sc[jo & (kRing - 1)]; P[jo] = ring_par[jo & (kRing - 1)]; }
     }
+    evals += exact_evals;                                               // both passes of an anchor that needed the exact scan
     for (int o = 32; o > 0; o >>= 1) evals += __shfl_xor(evals, o);
     if (lane == 0 && evals) atomicAdd(evals_out, evals);
 }

@@ -132,7 +132,9 @@ int gab_chain_run(gab_chain *h, int mode, const uint64_t *x, const uint64_t *y, 
 int gab_chain_run_device(gab_chain *h, int mode, const uint64_t *d_x, const uint64_t *d_y,
                          const int64_t *call_off, const gab_chain_hdr *hdr, int64_t ncalls,
                          int32_t *d_score, int32_t *d_parent, void *stream);
-/* predecessor evaluations (inner-loop iterations) and kernel time (HIP events) of the last run */
+/* predecessor evaluations performed (chain: the whole window of an anchor resolved by the plain-maximum path, plus the
+ * reference's own visits for the anchors that needed its max_skip scan; fast-chain: the windows) and kernel time (HIP
+ * events) of the last run */
 int gab_chain_last_stats(gab_chain *h, int64_t *evals, float *kernel_ms);
 
 /* ---- bpm: bit-parallel Myers edit distance (+ backtrace-derived score) -----------------

@@ -36,7 +36,10 @@ def test_vs_oracle(eng, mode, seed, ncalls, gmode, nmin, nmax):
     s, p = eng.host_chain_kernel(batch, mode)
     np.testing.assert_array_equal(s, ws)
     np.testing.assert_array_equal(p, wp)
-    assert eng.last_stats()["evals"] == ev
+    # predecessor evaluations performed: the reference's visits are a lower bound (chain resolves most anchors by the plain
+    # maximum over the whole window, which the max_skip scan would have left early), the window sizes an upper bound
+    ev_gpu = eng.last_stats()["evals"]
+    assert ev_gpu == ev if mode == 1 else ev <= ev_gpu <= 2 * sum(min(i, 5000) for n in batch.hdr["n"] for i in range(int(n)))
 
 
 @pytest.mark.parametrize("mode", [0, 1])
