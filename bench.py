@@ -193,9 +193,15 @@ class BswWorkload:
                                           "figure is the first-start-to-last-end span (tools/profiling/kernel_span.py on "
                                           "profiles/r01_bsw_large_kernel_trace.csv: 46.6-47.3 ms)",
                 # the bound that matters: integer VALU issue.  19.7 lane-instructions per DP cell is the PMC figure
-                # (SQ_INSTS_VALU x 64 / cells, profiles/r01_bsw_pmc.md); peak = 256 CUs x 64 lanes x 2.4 GHz.
+                # (SQ_INSTS_VALU x 64 / cells, profiles/r01_bsw_pmc.md).  Peak: MEASURED, profiles/r02_valu_issue.md
+                # (tools/microbench/valu_issue.hip): the packed 16-bit, SDWA, v_perm_b32, v_and_or_b32 and 32-bit max/min
+                # instructions this kernel is made of issue once per 4 cycles per SIMD whatever the occupancy (38.4-38.6 T
+                # lane-instr/s measured, 256 CUs x 4 SIMDs x 64 lanes x 2.4 GHz / 4 = 39.3 T); only v_add/sub/and/or/xor/
+                # lshr/mov, fp32 add/mul/fma and the NON-packed 16-bit integer / f16 ops reach one per 2 cycles, and only with
+                # >= 4 waves per SIMD (2.56 cycles at 2) -- the kernel runs at 1.85 waves per SIMD (LDS-capped).
                 "valu": {"lane_instr_per_cell": 19.7, "achieved_T_lane_instr_per_s":
                          round(19.7 * self.cells / (k * 1e9), 2) if k else None, "peak_T_lane_instr_per_s": 39.3,
+                         "peak_source": "profiles/r02_valu_issue.md (measured issue rate of this kernel's instruction classes)",
                          "frac": round(19.7 * self.cells / (k * 1e9) / 39.3, 3) if k else None}}
 
     def roofline(self):
