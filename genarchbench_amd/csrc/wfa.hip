@@ -31,6 +31,8 @@
 #include <new>
 #include <vector>
 #include <string.h>
+#include <stdlib.h>
+#include <stdio.h>
 
 namespace {
 
@@ -143,7 +145,8 @@ __device__ __forceinline__ uint32_t seq_ld4(const char *s, int pos, int len, uin
 // with identical control flow, other groups of the same wave may take different branches (SIMT divergence).
 template <typename OffT, bool LDSSEQ, int G, bool ADAPT>
 __device__ bool wfa_pair(WfStore<OffT, ADAPT> &st, const WfaPen pen, const uint8_t *P, int plen, const uint8_t *T, int tlen,
-                         char *ops_global, char *ops_lds, int32_t *ops_len_out, int32_t *score_out, unsigned long long &work) {
+                         char *ops_global, char *ops_lds, int32_t *ops_len_out, int32_t *score_out, unsigned long long &work,
+                         const uint8_t *step_tab = nullptr) {
     // the backtrace writes right-aligned into `ops`: an LDS buffer when the caller has one (then the CIGAR leaves the CU
     // once, left-aligned and coalesced), else the pair's own output region (shifted in place afterwards)
     char *ops = ops_lds ? ops_lds : ops_global;
@@ -156,6 +159,18 @@ __device__ bool wfa_pair(WfStore<OffT, ADAPT> &st, const WfaPen pen, const uint8
     // score 0: M = {k = 0 -> offset 0}
     st.used = 0;
     if (st.dir_cap < 1 || st.pool_cap < 1) return false;
+    if (step_tab) {
+        // Which scores have a wavefront at all depends on the penalties alone (a wavefront is null iff its four sources
+        // are, and a computed one is never empty), so the host lists them: step_tab[s] = distance to the next score with a
+        // wavefront.  The loop below then visits only those (with x = 4, o + e = 8, e = 2: 0, 4, 8, 10, 12, ... -- half
+        // of the iterations were null scores); every directory entry starts out null so that look-ups of the skipped
+        // scores (s - x, s - o - e, s - e, and the backtrace's) read what the reference's NULL wavefronts say.
+        for (int sc = lane; sc < st.dir_cap; sc += G) {
+            st.put(sc, 1, -1, kNone, kNone, kNone);
+            if (ADAPT) st.put_base(sc, 1, -1);
+        }
+        __syncthreads();
+    }
     if (lane == 0) {
         st.put(0, 0, 0, 0, kNone, kNone); st.pool[0] = (OffT)0;
         if (ADAPT) st.put_base(0, 0, 0);
@@ -233,7 +248,7 @@ __device__ bool wfa_pair(WfStore<OffT, ADAPT> &st, const WfaPen pen, const uint8
             }
         }
         // ---- next wavefront
-        score++;
+        score += step_tab ? (int)step_tab[score] : 1;
         if (score >= st.dir_cap) return false;
         const WfDir ms = st.get(score - x), mg = st.get(score - oe), ie = st.get(score - e);
         const int de_base = ie.d, ie_base = ie.i;              // I and D of score-e share lo/hi
@@ -390,7 +405,7 @@ __global__ __launch_bounds__(256) void wfa_scatter(WfaIO io, uint32_t *cursors, 
 template <int G, bool ADAPT>
 __global__ __launch_bounds__(64) void wfa_lds(WfaIO io, WfaPen pen, const uint32_t *__restrict__ list, uint32_t count,
                                               int dir_cap, int seqp, int seqt, int pool_cap, uint32_t group_bytes,
-                                              uint32_t *over_list, WfaCounters *ct) {
+                                              uint32_t *over_list, WfaCounters *ct, const uint8_t *__restrict__ steps) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem_all[];
     constexpr int kGroups = 64 / G;
     const int grp = threadIdx.x / G, lane = threadIdx.x & (G - 1);
@@ -398,9 +413,13 @@ __global__ __launch_bounds__(64) void wfa_lds(WfaIO io, WfaPen pen, const uint32
     unsigned long long work = 0;
     bool ok = true, have = b < count;
     uint32_t id = 0;
+    // the score-step table of this penalty set (see wfa_pair), shared by the groups of the wave
+    const int tab_bytes = (dir_cap + 15) & ~15;
+    for (int i = threadIdx.x; i < dir_cap; i += 64) smem_all[i] = steps[i];
+    __syncthreads();
     if (have) {
         id = list ? list[b] : b;                             // no list: every pair of the batch is in this pass
-        uint8_t *smem = smem_all + (size_t)grp * group_bytes;
+        uint8_t *smem = smem_all + tab_bytes + (size_t)grp * group_bytes;
         int *dir = reinterpret_cast<int *>(smem);
         uint8_t *P = smem + (size_t)dir_cap * 4 * WfStore<int16_t, ADAPT>::kDirInts;
         uint8_t *T = P + seqp;
@@ -416,7 +435,8 @@ __global__ __launch_bounds__(64) void wfa_lds(WfaIO io, WfaPen pen, const uint32
         __syncthreads();
         WfStore<int16_t, ADAPT> st;
         st.pool = pool; st.dir = dir; st.pool_cap = pool_cap; st.dir_cap = dir_cap; st.used = 0;
-        ok = wfa_pair<int16_t, true, G, ADAPT>(st, pen, P, plen, T, tlen, io.ops + io.ops_off[id], opsbuf, io.ops_len + id, io.score + id, work);
+        ok = wfa_pair<int16_t, true, G, ADAPT>(st, pen, P, plen, T, tlen, io.ops + io.ops_off[id], opsbuf, io.ops_len + id, io.score + id, work,
+                                               smem_all);
         if (!ok && lane == 0) over_list[atomicAdd(&ct->n_over, 1u)] = id;
     }
     if (!have || !ok) work = 0;
@@ -456,6 +476,7 @@ struct gab_wfa {
     WfaPen pen;
     bool adaptive = false;  // affine_wavefronts_new_reduced instead of _new_complete
     gab_devbuf ws;          // counters | 3 id lists
+    gab_devbuf steps;       // per score: distance to the next score that has a wavefront (a function of the penalties)
     gab_devbuf scratch;     // global-kernel history
     gab_devbuf io;          // staging for the host-pointer entry point
     size_t scratch_budget = (size_t)8 << 30;
@@ -492,8 +513,31 @@ extern "C" int gab_wfa_create_reduced(const gab_wfa_penalties *p, int min_wavefr
         hipFuncSetAttribute((const void *)wfa_lds<64, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
         hipFuncSetAttribute((const void *)wfa_lds<16, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
         hipFuncSetAttribute((const void *)wfa_lds<64, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
-        hipFuncSetAttribute((const void *)wfa_lds<16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+        hipFuncSetAttribute((const void *)wfa_lds<16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+        hipFuncSetAttribute((const void *)wfa_lds<8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+        hipFuncSetAttribute((const void *)wfa_lds<8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+        hipFuncSetAttribute((const void *)wfa_lds<32, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+        hipFuncSetAttribute((const void *)wfa_lds<32, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
         gab_set_error("gab_wfa_create: pinned allocation / LDS attribute failed"); delete h; return GAB_EDEVICE;
+    }
+    {   // scores that have a wavefront: M[s] exists iff M[s-x], M[s-o-e], I[s-e] or D[s-e] does; I[s] / D[s] iff M[s-o-e] or
+        // I[s-e] / D[s-e] does (affine_wavefront_align.c:283-321) -- no data involved
+        constexpr int kSteps = 1024;                      // >= the largest LDS directory
+        const int x = h->pen.x, oe = h->pen.o + h->pen.e, e = h->pen.e;
+        std::vector<uint8_t> m(kSteps + 1, 0), g(kSteps + 1, 0), step(kSteps, 1);
+        m[0] = 1;
+        for (int sc = 1; sc <= kSteps; sc++) {
+            g[sc] = (sc >= oe && m[sc - oe]) || (sc >= e && g[sc - e]);
+            m[sc] = (sc >= x && m[sc - x]) || g[sc];
+        }
+        int next = kSteps + 255;
+        for (int sc = kSteps - 1; sc >= 0; sc--) {
+            if (m[sc + 1]) next = sc + 1;
+            step[sc] = (uint8_t)std::min(next - sc, 255);
+        }
+        if (h->steps.reserve(kSteps) != GAB_OK || hipMemcpy(h->steps.p, step.data(), kSteps, hipMemcpyHostToDevice) != hipSuccess) {
+            gab_set_error("gab_wfa_create: score-step table upload failed"); gab_wfa_destroy(h); return GAB_EDEVICE;
+        }
     }
     *out = h;
     return GAB_OK;
@@ -502,7 +546,7 @@ extern "C" int gab_wfa_create_reduced(const gab_wfa_penalties *p, int min_wavefr
 extern "C" void gab_wfa_destroy(gab_wfa *h) {
     if (!h) return;
     gab_device_guard g(h->device);
-    h->ws.release(); h->scratch.release(); h->io.release(); h->hs.release();
+    h->ws.release(); h->steps.release(); h->scratch.release(); h->io.release(); h->hs.release();
     for (int k = 0; k < 4; k++) if (h->ev[k]) (void)hipEventDestroy(h->ev[k]);
     if (h->h_ct) (void)hipHostFree(h->h_ct);
     delete h;
@@ -548,25 +592,28 @@ extern "C" int gab_wfa_run_device(gab_wfa *h, const char *pat, int64_t pat_bytes
 
     GAB_HIP(hipEventRecord(h->ev[1], s));
     // LDS passes: (1) four pairs per wave with a 2 KB history each (scores up to ~35: the bulk of short-read pairs),
-    // (2) one pair per wave with 12 KB, (3) one pair per wave with 96 KB; whatever overflows goes to global memory
+    // (2) one pair per wave with 6 KB (12 KB measured 4 % slower: 5.43 vs 5.21 ms per 1 M pairs), (3) one pair per wave with
+    // 96 KB; whatever overflows goes to global memory
     if (n_big) hipLaunchKernelGGL(wfa_scatter, dim3(grid), dim3(256), 0, s, io, d_ct->cursors, l_a, l_big);
     uint32_t *cur = n_big ? l_a : nullptr, *nxt = l_b;      // nullptr: identity
     uint32_t cnt = n_lds;
     bool ev2 = false;
-    const int pool_bytes[3] = {2 * 1024, 12 * 1024, 96 * 1024};
-    const int dir_caps[3] = {48, 128, 640};
-    const int groups[3] = {16, 64, 64};
+    int pool_bytes[3] = {2 * 1024, 6 * 1024, 96 * 1024};
+    int dir_caps[3] = {48, 96, 640};
+    int groups[3] = {16, 64, 64};
+    if (const char *e = getenv("GAB_WFA_TUNE")) sscanf(e, "%d,%d,%d,%d,%d,%d", &pool_bytes[0], &dir_caps[0], &pool_bytes[1], &dir_caps[1], &groups[0], &groups[1]);   // tuning runs only
     for (int pass = 0; pass < 3 && cnt; pass++) {
         const int dir_cap = dir_caps[pass], G = groups[pass];
         const size_t per_group = (((size_t)dir_cap * (h->adaptive ? 16 : 12) + (size_t)(seqp + seqt) + pool_bytes[pass]) + 15) & ~(size_t)15;
-        const size_t lds = per_group * (64 / G);
+        const size_t lds = per_group * (64 / G) + (((size_t)dir_cap + 15) & ~(size_t)15);
         if (lds > 160 * 1024 - 512) continue;            // sequences too long for this pool: let the next stage take them
         h->h_ct->n_over = 0;
         GAB_HIP(hipMemsetAsync(&d_ct->n_over, 0, 4, s));
         const unsigned blocks = (cnt + (64 / G) - 1) / (64 / G);
-        auto kern = G == 16 ? (h->adaptive ? wfa_lds<16, true> : wfa_lds<16, false>) : (h->adaptive ? wfa_lds<64, true> : wfa_lds<64, false>);
+        auto kern = G == 16 ? (h->adaptive ? wfa_lds<16, true> : wfa_lds<16, false>) : G == 8 ? (h->adaptive ? wfa_lds<8, true> : wfa_lds<8, false>)
+                    : G == 32 ? (h->adaptive ? wfa_lds<32, true> : wfa_lds<32, false>) : (h->adaptive ? wfa_lds<64, true> : wfa_lds<64, false>);
         hipLaunchKernelGGL(kern, dim3(blocks), dim3(64), lds, s, io, h->pen, cur, cnt, dir_cap, seqp, seqt,
-                           pool_bytes[pass] / 2, (uint32_t)per_group, nxt, d_ct);
+                           pool_bytes[pass] / 2, (uint32_t)per_group, nxt, d_ct, h->steps.as<uint8_t>());
         GAB_HIP(hipGetLastError());
         if (!ev2) { GAB_HIP(hipEventRecord(h->ev[2], s)); ev2 = true; }
         GAB_HIP(hipMemcpyAsync(h->h_ct, d_ct, sizeof(WfaCounters), hipMemcpyDeviceToHost, s));
