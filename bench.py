@@ -32,7 +32,7 @@ HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec 
 # counters in separate passes (tools/profiling/hbm_traffic.sh -> profiles/r01_hbm_traffic.json); `double_fetch`: the
 # kernel reads wide coalesced streams, for which gfx950's FETCH_SIZE reports half the bytes (MI355X_MICROARCH.md, HBM)
 TRAFFIC_KERNELS = {"bsw": (["bsw_dp8"], False), "chain": (["chain_hw_kernel"], False), "fast-chain": (["fastchain_kernel"], False),
-                   "bpm": (["bpm_score<3>"], False), "bitpal": (["bitpal_dp<true, true>"], False), "wfa": (["wfa_lds<16>"], False), "fmi": (["fmi_seed_kernel<true>"], False),
+                   "bpm": (["bpm_score<3>"], False), "bitpal": (["bitpal_dp<true, true>"], False), "wfa": (["wfa_lds<16"], False), "fmi": (["fmi_seed_kernel<true>"], False),
                    "fmi-sa": (["fmi_sa_kernel"], False), "parse-bsw": (["nl_count", "nl_fill", "bsw_meta", "bsw_codes", "len_offsets",
                                                                        "len_block_sums"], True)}
 
@@ -44,8 +44,9 @@ def pmc_traffic(name, is_large, kernel_ms):
         return None, None
     tab = json.load(open(path)).get(name, {})
     kernels, double_fetch = TRAFFIC_KERNELS[name]
-    f = sum(tab.get(k, {}).get("fetch_gb_raw", 0.0) for k in kernels) * (2.0 if double_fetch else 1.0)
-    w = sum(tab.get(k, {}).get("write_gb", 0.0) for k in kernels)
+    rows = [v for name, v in tab.items() if any(name.startswith(k) for k in kernels)]      # names carry their template arguments
+    f = sum(v.get("fetch_gb_raw", 0.0) for v in rows) * (2.0 if double_fetch else 1.0)
+    w = sum(v.get("write_gb", 0.0) for v in rows)
     if f + w == 0:
         return None, None
     return round((f + w) / (kernel_ms * 1e-3), 3), {"fetch_GB_per_step": round(f, 3), "write_GB_per_step": round(w, 3),
