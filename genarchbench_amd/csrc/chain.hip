@@ -669,6 +669,351 @@ __global__ __launch_bounds__(64 * (1 + kFcHelpers)) void fastchain_kernel(const 
     if (lane == 0 && evals) atomicAdd(evals_out, evals);
 }
 
+
+// ---- chain: block formulation with a certificate (chain_block_kernel) ----------------------------------------------
+// chain's max_skip makes the reference's scan of an anchor's window order-dependent, but only rarely outcome-dependent:
+// the result is the plain maximum over the window (ties -> larger j) whenever at most kMaxSkip unfiltered predecessors are
+// newer than its argmax (proof at the fast path of chain_hw_kernel above).  So chain is computed like fast-chain -- blocks
+// of 64 anchors, lane a <-> anchor i0 + a, every lane scoring a BROADCAST predecessor against its own anchor, helper waves
+// folding the far predecessors one block ahead -- with chain's own arithmetic (64-bit coordinates, segment ids, the fp64
+// gap cost of chain_geometry), plus one counter per lane:
+//     risk = unfiltered predecessors folded after (= newer than) the current argmax      (0 on every improvement)
+// Predecessors are folded oldest first (far chunks, previous block, inside the block), so `risk` is exact for an argmax
+// in the previous or the current block; for a far argmax it starts from the number of ALL unfiltered far predecessors
+// (an upper bound: the helpers fold interleaved chunks).  An anchor whose risk exceeds kMaxSkip when it becomes final is
+// re-done by the whole wave with the reference's own scan (chain_exact_global: marks, hits, n_skip, break) before its
+// score is broadcast to the younger anchors of the block.  On the suite's inputs that is ~1 % of the anchors.
+constexpr int kCbHelpers = 3;
+
+// Per-call facts the block kernel specialises on (one workgroup per call, before the DP; ChainWork.pad bit 0):
+//   plain = every anchor of the call carries the same segment id (then "sidi == sidj" is always true and the cross-segment
+//           gap rule never applies) AND max(x) - min(x) < 2^31 (then every x[i] - x[j] of the call is exact in 32 bits).
+// Both hold for every call of the suite's inputs (one reference strand per call); calls that miss either use the generic
+// arithmetic.  Reads x and y once: 16 B per seed at HBM speed.
+__global__ __launch_bounds__(256) void chain_facts_kernel(ChainWork *work, const uint64_t *__restrict__ xs, const uint64_t *__restrict__ ys) {
+    __shared__ unsigned long long s_lo[4], s_hi[4];
+    __shared__ int s_mixed[4];
+    ChainWork &w = work[blockIdx.x];
+    const uint64_t *X = xs + w.off, *Y = ys + w.off;
+    const int64_t n = w.n;
+    unsigned long long lo = ~0ull, hi = 0;
+    const uint32_t sid0 = n > 0 ? (uint32_t)(Y[0] >> 48 & 0xff) : 0;
+    int mixed = 0;
+    for (int64_t i = threadIdx.x; i < n; i += 256) {
+        const unsigned long long x = X[i];
+        lo = x < lo ? x : lo; hi = x > hi ? x : hi;
+        mixed |= ((uint32_t)(Y[i] >> 48 & 0xff) != sid0) ? 1 : 0;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long l2 = __shfl_xor(lo, o), h2 = __shfl_xor(hi, o);
+        lo = l2 < lo ? l2 : lo; hi = h2 > hi ? h2 : hi; mixed |= __shfl_xor(mixed, o);
+    }
+    if ((threadIdx.x & 63) == 0) { s_lo[threadIdx.x >> 6] = lo; s_hi[threadIdx.x >> 6] = hi; s_mixed[threadIdx.x >> 6] = mixed; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < 4; k++) { lo = s_lo[k] < lo ? s_lo[k] : lo; hi = s_hi[k] > hi ? s_hi[k] : hi; mixed |= s_mixed[k]; }
+        w.pad = (n > 0 && !mixed && hi - lo < 0x7fffffffull) ? 1 : 0;
+    }
+}
+
+// chain_geometry for a call with the facts above: one segment id, 32-bit-exact x differences.  `xa_lo` / `xj_lo` are the low
+// words of x; dq_lim = min(max_dist_y, max_dist_x) clamped at 0.  Same value and same filter as chain_geometry (the `same`
+// branch with dr held in 32 bits: dd = |dr - dq| wraps exactly like the reference's int64 -> int32 conversion).
+__device__ __forceinline__ int32_t chain_geometry_plain(uint32_t xa_lo, int32_t qa, int32_t q_span, uint32_t xj_lo, uint32_t yj, int32_t mdy,
+                                                        uint32_t dq_lim, int32_t bw, bool multi_seg, double avg_d, bool &ok) {
+    const int32_t dr = (int32_t)(xa_lo - xj_lo);
+    const int32_t dq = qa - (int32_t)yj;
+    const int32_t diff = (int32_t)((uint32_t)dr - (uint32_t)dq);
+    const int32_t dd = dr > dq ? diff : (int32_t)(0u - (uint32_t)diff);
+    // dq <= 0 || dq > max_dist_y || dq > max_dist_x  ==  (unsigned)(dq - 1) >= min(max_dist_y, max_dist_x)
+    ok = !(dr == 0 || (uint32_t)dq - 1u >= dq_lim || dd > bw || (multi_seg && dr > mdy));
+    const int32_t v = min(min(dq, dr), q_span);
+    const int32_t lgh = (31 - __clz((int)((uint32_t)dd | 1u))) >> 1;          // ilog2(dd) >> 1, ilog2(0) = 0
+    const int32_t gap = (int32_t)__dmul_rn(__dmul_rn((double)dd, .01), avg_d) + lgh;
+    return v - (gap - (gap >> 31));
+}
+
+
+// the reference's scan of ONE anchor, by one whole wave, everything from global memory (x, y input; score, parent of
+// the predecessors as stored so far; marks in the per-anchor global array with tag i + 1).  Same three parallel steps as
+// the exact path of chain_hw_kernel.  Returns (best, best_j absolute) in all lanes; `evals` counts the visited items.
+__device__ __forceinline__ void chain_exact_global(const uint64_t *X, const uint64_t *Y, const int32_t *S, const int32_t *P, int32_t *GM,
+                                                   int i, int st, int32_t mdx, int32_t mdy, int32_t bw, bool multi_seg, double avg_d,
+                                                   int32_t &best_out, int32_t &bestj_out, unsigned long long &evals) {
+    const int lane = threadIdx.x & 63;
+    const int NEG = (int)0x80000000;
+    const uint64_t xi = X[i], yi = Y[i];
+    const int32_t qi = (int32_t)yi, q_span = (int32_t)(yi >> 32 & 0xff), sidi = (int32_t)(yi >> 48 & 0xff);
+    int32_t best = q_span, best_j = -1;
+    int n_skip = 0;
+    bool broke = false;
+    for (int top = i - 1; top >= st && !broke;) {
+        const int j0 = 4 * ((top >> 2) - lane);
+        bool valid[4], ok[4];
+        int32_t sc[4], parj[4] = {-1, -1, -1, -1};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int j = j0 + 3 - k;
+            valid[k] = j >= st && j <= top; ok[k] = false; sc[k] = 0;
+            if (valid[k]) {
+                const uint64_t xj = X[j], yy = Y[j];
+                const int32_t scj = __hip_atomic_load(&S[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                parj[k] = __hip_atomic_load(&P[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                bool okk;
+                const int32_t v = chain_geometry(xi, qi, q_span, sidi, xj, (uint32_t)yy, (int32_t)(yy >> 48 & 0xff), mdx, mdy, bw, multi_seg, avg_d, okk);
+                ok[k] = okk; sc[k] = v + scj;
+            }
+        }
+        // marks: targets[parent[j]] = i for every unfiltered item, then this group's own four
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (ok[k] && parj[k] >= 0 && parj[k] >= st) __hip_atomic_store(&GM[parj[k]], (int32_t)(i + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        bool hit[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int j = j0 + 3 - k;
+            hit[k] = ok[k] && __hip_atomic_load(&GM[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int32_t)(i + 1);
+        }
+        int lmax = NEG;
+#pragma unroll
+        for (int k = 0; k < 4; k++) lmax = ok[k] ? max(lmax, sc[k]) : lmax;
+        const int incl = wave_incl_max(lmax);
+        int run = max(wave_shr1(incl, NEG), best);
+        bool imp[4];
+        int d[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            imp[k] = ok[k] && sc[k] > run;
+            run = ok[k] ? max(run, sc[k]) : run;
+            d[k] = imp[k] ? -1 : (ok[k] && hit[k]) ? 1 : 0;
+        }
+        const int p0 = d[0], p1 = p0 + d[1], p2 = p1 + d[2], p3 = p2 + d[3];
+        const int E = wave_incl_sum(p3) - p3;
+        const int mloc = min(min(p0, p1), min(p2, p3));
+        const int inclmin = wave_incl_min(E + mloc);
+        int rmin = min(-n_skip, wave_shr1(inclmin, 0x7fffffff));
+        int cnt[4];
+        const int pk[4] = {p0, p1, p2, p3};
+        int kfirst = 4;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            rmin = min(rmin, E + pk[k]);
+            cnt[k] = E + pk[k] - rmin;
+            if (d[k] == 1 && cnt[k] > kMaxSkip && kfirst == 4) kfirst = k;
+        }
+        const unsigned long long om = __ballot(kfirst < 4);
+        int fl = 64, fk = 4;
+        if (om) { fl = __builtin_ctzll(om); fk = __builtin_amdgcn_readlane(kfirst, fl); broke = true; }
+        else n_skip = __builtin_amdgcn_readlane(cnt[3], 63);
+        const int klim = lane < fl ? 4 : lane == fl ? fk : 0;
+        int lastk = -1, lsc = 0, lj = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (imp[k] && k < klim) { lastk = k; lsc = sc[k]; lj = j0 + 3 - k; }
+        const unsigned long long lm = __ballot(lastk >= 0);
+        if (lm) {
+            const int ll = 63 - __builtin_clzll(lm);
+            best = __builtin_amdgcn_readlane(lsc, ll);
+            best_j = __builtin_amdgcn_readlane(lj, ll);
+        }
+        const int vlim = lane < fl ? 4 : lane == fl ? fk + 1 : 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) evals += (valid[k] && k < vlim) ? 1 : 0;
+        top = 4 * ((top >> 2) - 63) - 1;
+    }
+    best_out = best; bestj_out = best_j;
+}
+
+__global__ __launch_bounds__(64 * (1 + kCbHelpers)) void chain_block_kernel(const ChainWork *__restrict__ work,
+                                                                            const uint64_t *__restrict__ xs,
+                                                                            const uint64_t *__restrict__ ys, int32_t *score_out,
+                                                                            int32_t *parent_out, int32_t *gmarks_all,
+                                                                            unsigned long long *evals_out) {
+    __shared__ int32_t part_best[2][kCbHelpers][64], part_j[2][kCbHelpers][64], part_ok[2][kCbHelpers][64], part_st[2][64];
+    const ChainWork w = work[blockIdx.x];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint64_t *X = xs + w.off, *Y = ys + w.off;
+    int32_t *S = score_out + w.off, *P = parent_out + w.off, *GM = gmarks_all + w.off;
+    const int n = (int)w.n;                                  // < 2^31 (checked by the host)
+    const int32_t mdx = w.max_dist_x, mdy = w.max_dist_y, bw = w.bw;
+    const uint64_t mdx64 = (uint64_t)(int64_t)mdx;
+    const double avg_d = (double)w.avg_qspan;
+    const bool multi_seg = w.n_segs > 1;
+    const bool plain = (w.pad & 1) != 0;                     // chain_facts_kernel: one segment id, 32-bit-exact x differences
+    const int32_t mq = mdy < mdx ? mdy : mdx;
+    const uint32_t dq_lim = mq < 0 ? 0u : (uint32_t)mq;
+    const int nblocks = (n + 63) / 64;
+    const int NEG = (int)0x80000000;
+
+    // geometry of (own anchor, broadcast predecessor): PLAIN is a compile-time tag so that the generic arithmetic (64-bit
+    // differences, segment rules) costs the plain calls nothing; the predecessor's fields come from `src` lanes of
+    // registers (v_readlane), only the ones the variant needs
+    struct Pred { uint64_t x; uint32_t y; int32_t sid; };
+    auto geom = [&](auto tag, uint64_t xa, int32_t qa, int32_t qsa, int32_t sida, const Pred &pv, int src, bool &ok) -> int32_t {
+        constexpr bool PLAIN = decltype(tag)::value;
+        const uint32_t xj_lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)pv.x, src);
+        const uint32_t yj = (uint32_t)__builtin_amdgcn_readlane((int)pv.y, src);
+        if constexpr (PLAIN) return chain_geometry_plain((uint32_t)xa, qa, qsa, xj_lo, yj, mdy, dq_lim, bw, multi_seg, avg_d, ok);
+        else {
+            const uint64_t xj = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(pv.x >> 32), src) << 32) | xj_lo;
+            return chain_geometry(xa, qa, qsa, sida, xj, yj, __builtin_amdgcn_readlane(pv.sid, src), mdx, mdy, bw, multi_seg, avg_d, ok);
+        }
+    };
+
+    // helper state: the sequential window-start pointer (each helper keeps its own identical copy)
+    int st = 0, sb = 0;
+    uint64_t XS = (wave > 0 && lane < n) ? X[lane] : 0;
+    // main state: the previous block (the "near" predecessors)
+    Pred prev = {0, 0, 0};
+    int32_t pbest = 0;
+    int pnb = 0;
+    unsigned long long evals = 0;
+
+    for (int t = -1; t < nblocks; t++) {
+        const int par = (t + 1) & 1;                         // LDS slot of block t+1; block t lives in par ^ 1
+        if (wave > 0) {
+            // ------------------------------------------------ helpers: block t + 1
+            const int kb = t + 1;
+            if (kb < nblocks) {
+                const int i0 = kb * 64;
+                const int nb = n - i0 < 64 ? n - i0 : 64;
+                const bool mine = lane < nb;
+                const uint64_t xa = mine ? X[i0 + lane] : 0, ya = mine ? Y[i0 + lane] : 0;
+                const int32_t qa = (int32_t)ya, qsa = (int32_t)(ya >> 32 & 0xff), sida = (int32_t)(ya >> 48 & 0xff);
+                int st_a = 0;
+                for (int a = 0; a < nb; a++) {               // host_kernel.cpp:56-57
+                    const int i = i0 + a;
+                    const uint64_t xi = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(xa >> 32), a) << 32) |
+                                        (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)xa, a);
+                    for (;;) {
+                        const int cand = sb + lane;
+                        const bool pass = cand < st || (cand < i && xi > XS + mdx64);
+                        const unsigned long long m = __ballot(pass);
+                        if (m == ~0ull) { sb += 64; st = sb; XS = (sb + lane < n) ? X[sb + lane] : 0; continue; }
+                        st = sb + __builtin_ctzll(~m);
+                        break;
+                    }
+                    if (i - st > kMaxIter) st = i - kMaxIter;
+                    if (st - sb >= 64) { sb = st & ~63; XS = (sb + lane < n) ? X[sb + lane] : 0; }
+                    if (lane == a) st_a = st;
+                }
+                const int st_rel = st_a - i0;
+                int32_t best = NEG, best_j = -1, nok = 0;    // helpers start below any score; q_span is the main wave's floor
+                const int st_lo = __builtin_amdgcn_readfirstlane(st_a);
+                // far predecessors j <= i0 - 65 (final since block t - 1), chunks of 64 dealt round-robin to the helpers
+                for (int jb = i0 - 65 - 64 * (wave - 1); jb >= st_lo; jb -= 64 * kCbHelpers) {
+                    const int jl = jb - lane;
+                    Pred pv = {0, 0, 0};
+                    int32_t vs = 0;
+                    if (jl >= st_lo) {
+                        pv.x = X[jl];
+                        const uint64_t yy = Y[jl];
+                        pv.y = (uint32_t)yy; pv.sid = (int32_t)(yy >> 48 & 0xff);
+                        vs = __hip_atomic_load(&S[jl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    const int cnt = jb - st_lo + 1 < 64 ? jb - st_lo + 1 : 64;
+                    const int jrel0 = jb - i0;
+                    // (four steps per trip by hand: the evaluations are independent, only the running maximum is a chain)
+                    auto far_chunk = [&](auto tag) {
+                        auto step = [&](int l) {             // descending j: strict > keeps the newest of equal scores
+                            bool ok;
+                            const int32_t sc = geom(tag, xa, qa, qsa, sida, pv, l, ok) + __builtin_amdgcn_readlane(vs, l);
+                            const int jrel = jrel0 - l;
+                            ok = ok && mine && jrel >= st_rel;
+                            nok += ok ? 1 : 0;
+                            if (ok && sc > best) { best = sc; best_j = jrel; }
+                        };
+                        int l = 0;
+                        for (; l + 3 < cnt; l += 4) { step(l); step(l + 1); step(l + 2); step(l + 3); }
+                        for (; l < cnt; l++) step(l);
+                    };
+                    if (plain) far_chunk(std::true_type{}); else far_chunk(std::false_type{});
+                }
+                part_best[par][wave - 1][lane] = best; part_j[par][wave - 1][lane] = best_j; part_ok[par][wave - 1][lane] = nok;
+                if (wave == 1) part_st[par][lane] = st_rel;
+            }
+        } else if (t >= 0) {
+            // ------------------------------------------------ main wave: block t
+            const int i0 = t * 64;
+            const int nb = n - i0 < 64 ? n - i0 : 64;
+            const bool mine = lane < nb;
+            const uint64_t xa = mine ? X[i0 + lane] : 0, ya = mine ? Y[i0 + lane] : 0;
+            const int32_t qa = (int32_t)ya, qsa = (int32_t)(ya >> 32 & 0xff), sida = (int32_t)(ya >> 48 & 0xff);
+            const Pred cur = {xa, (uint32_t)ya, sida};
+            const int st_rel = part_st[par ^ 1][lane];
+            if (mine) evals += (unsigned long long)(lane - st_rel);
+            int32_t best = qsa, best_j = -1;                 // best_j relative to i0, -1 = none
+            bool have = false;
+            int32_t risk = 0;                                // unfiltered predecessors folded after the current argmax (upper bound)
+            // helpers' partial maxima: chunks interleave, so the larger j wins a tie; all far unfiltered ones count as risk
+#pragma unroll
+            for (int hh = 0; hh < kCbHelpers; hh++) {
+                const int32_t b2 = part_best[par ^ 1][hh][lane], j2 = part_j[par ^ 1][hh][lane];
+                risk += part_ok[par ^ 1][hh][lane];
+                if (b2 > best || (have && b2 == best && j2 > best_j)) { best = b2; best_j = j2; have = true; }
+            }
+            auto fold = [&](int32_t sc, bool ok, int jrel) {
+                const bool up = ok && (sc > best || (have && sc == best));
+                risk = up ? 0 : risk + (ok ? 1 : 0);
+                if (up) { best = sc; best_j = jrel; have = true; }
+            };
+            // near predecessors: the previous block, OLDEST first (a newer one wins a tie), so that `risk` counts what is newer
+            auto near_fold = [&](auto tag) {
+                auto step = [&](int l) {
+                    bool ok;
+                    const int32_t sc = geom(tag, xa, qa, qsa, sida, prev, l, ok) + __builtin_amdgcn_readlane(pbest, l);
+                    fold(sc, ok && mine && l - 64 >= st_rel, l - 64);
+                };
+                int l = 0;
+                for (; l + 3 < pnb; l += 4) { step(l); step(l + 1); step(l + 2); step(l + 3); }
+                for (; l < pnb; l++) step(l);
+            };
+            if (plain) near_fold(std::true_type{}); else near_fold(std::false_type{});
+            // predecessors inside the block: anchor b is final once 0 .. b-1 are folded; if its certificate fails it is
+            // re-done exactly before its score is broadcast.  The geometry of (a, b) involves no score and is computed four
+            // steps ahead, so the dependent part of a step is readlane(best, b) + add + compare + select.
+            auto finalize = [&](int b) {
+                const int rb = __builtin_amdgcn_readlane(risk, b);
+                const bool hb = __builtin_amdgcn_readlane((int)have, b) != 0;
+                if (hb && rb > kMaxSkip) {                   // wave-uniform: the reference's own scan of anchor i0 + b
+                    if (mine && lane < b) { S[i0 + lane] = best; P[i0 + lane] = have ? i0 + best_j : -1; }
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    int32_t eb, ej;
+                    chain_exact_global(X, Y, S, P, GM, i0 + b, i0 + __builtin_amdgcn_readlane(st_rel, b), mdx, mdy, bw, multi_seg, avg_d, eb, ej, evals);
+                    if (lane == b) { best = eb; best_j = ej - i0; have = ej >= 0; risk = 0; }
+                }
+            };
+            auto block_fold = [&](auto tag) {
+                auto g = [&](int b, bool &ok) -> int32_t {
+                    const int32_t v = geom(tag, xa, qa, qsa, sida, cur, b, ok);
+                    ok = ok && mine && lane > b && b >= st_rel;
+                    return v;
+                };
+                int b = 0;
+                for (; b + 4 < nb; b += 4) {
+                    bool o0, o1, o2, o3;
+                    const int32_t g0 = g(b, o0), g1 = g(b + 1, o1), g2 = g(b + 2, o2), g3 = g(b + 3, o3);
+                    finalize(b);     fold(g0 + __builtin_amdgcn_readlane(best, b), o0, b);
+                    finalize(b + 1); fold(g1 + __builtin_amdgcn_readlane(best, b + 1), o1, b + 1);
+                    finalize(b + 2); fold(g2 + __builtin_amdgcn_readlane(best, b + 2), o2, b + 2);
+                    finalize(b + 3); fold(g3 + __builtin_amdgcn_readlane(best, b + 3), o3, b + 3);
+                }
+                for (; b < nb; b++) {
+                    finalize(b);
+                    if (b + 1 < nb) { bool o; const int32_t gg = g(b, o); fold(gg + __builtin_amdgcn_readlane(best, b), o, b); }
+                }
+            };
+            if (plain) block_fold(std::true_type{}); else block_fold(std::false_type{});
+            if (mine) { S[i0 + lane] = best; P[i0 + lane] = have ? i0 + best_j : -1; }
+            prev = cur; pbest = best; pnb = nb;
+        }
+        __syncthreads();       // results of block t are acknowledged by L2; partial maxima of block t+1 are in LDS
+    }
+    for (int o = 32; o > 0; o >>= 1) evals += __shfl_xor(evals, o);
+    if (lane == 0 && evals) atomicAdd(evals_out, evals);
+}
+
 }  // namespace
 
 // =============================================================================== host side
@@ -770,8 +1115,12 @@ extern "C" int gab_chain_run_device(gab_chain *h, int mode, const uint64_t *d_x,
     GAB_HIP(hipEventRecord(h->ev[0], s));
     if (mode == GAB_FASTCHAIN)
         hipLaunchKernelGGL(fastchain_kernel, dim3((unsigned)nw), dim3(64 * (1 + kFcHelpers)), 0, s, d_work, d_x, d_y, d_score, d_parent, d_ev);
-    else
+    else if (getenv("GAB_CHAIN_KERNEL") && !strcmp(getenv("GAB_CHAIN_KERNEL"), "walk"))      // the per-anchor walk (A/B runs)
         hipLaunchKernelGGL(chain_hw_kernel, dim3((unsigned)nw), dim3(64 * (1 + kChHelpers)), 0, s, d_work, d_x, d_y, d_score, d_parent, d_gm, d_ev);
+    else {
+        hipLaunchKernelGGL(chain_facts_kernel, dim3((unsigned)nw), dim3(256), 0, s, d_work, d_x, d_y);
+        hipLaunchKernelGGL(chain_block_kernel, dim3((unsigned)nw), dim3(64 * (1 + kCbHelpers)), 0, s, d_work, d_x, d_y, d_score, d_parent, d_gm, d_ev);
+    }
     GAB_HIP(hipGetLastError());
     GAB_HIP(hipEventRecord(h->ev[1], s));
     GAB_HIP(hipMemcpyAsync(h->h_evals, d_ev, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
