@@ -918,11 +918,16 @@ __global__ __launch_bounds__(64 * (1 + kCbHelpers)) void chain_block_kernel(cons
                     auto far_chunk = [&](auto tag) {
                         auto step = [&](int l) {             // descending j: strict > keeps the newest of equal scores
                             bool ok;
-                            const int32_t sc = geom(tag, xa, qa, qsa, sida, pv, l, ok) + __builtin_amdgcn_readlane(vs, l);
+                            int32_t sc = geom(tag, xa, qa, qsa, sida, pv, l, ok) + __builtin_amdgcn_readlane(vs, l);
+                            // every lane evaluates every predecessor and the result is SELECTED: left to itself the compiler
+                            // branches around the arithmetic of filtered lanes (exec-mask juggling and four branches per
+                            // step cost more issue slots than they save)
+                            asm volatile("" : "+v"(sc));
                             const int jrel = jrel0 - l;
-                            ok = ok && mine && jrel >= st_rel;
-                            nok += ok ? 1 : 0;
-                            if (ok && sc > best) { best = sc; best_j = jrel; }
+                            const bool okk = ok & mine & (jrel >= st_rel);
+                            nok += okk ? 1 : 0;
+                            const bool up = okk & (sc > best);
+                            best = up ? sc : best; best_j = up ? jrel : best_j;
                         };
                         int l = 0;
                         for (; l + 3 < cnt; l += 4) { step(l); step(l + 1); step(l + 2); step(l + 3); }
@@ -943,27 +948,32 @@ __global__ __launch_bounds__(64 * (1 + kCbHelpers)) void chain_block_kernel(cons
             const Pred cur = {xa, (uint32_t)ya, sida};
             const int st_rel = part_st[par ^ 1][lane];
             if (mine) evals += (unsigned long long)(lane - st_rel);
-            int32_t best = qsa, best_j = -1;                 // best_j relative to i0, -1 = none
-            bool have = false;
+            // State per lane: thr = the score a predecessor has to REACH to become the argmax -- q_span + 1 while nothing has
+            // improved on q_span (the reference's strict >), the best score itself afterwards (a newer predecessor wins a tie) --
+            // and best_j (relative to i0; kNoJ = none yet).  The anchor's score is thr, or thr - 1 = q_span while best_j is kNoJ.
+            constexpr int kNoJ = (int)0x80000000;
+            int32_t thr = qsa + 1, best_j = kNoJ;
             int32_t risk = 0;                                // unfiltered predecessors folded after the current argmax (upper bound)
             // helpers' partial maxima: chunks interleave, so the larger j wins a tie; all far unfiltered ones count as risk
 #pragma unroll
             for (int hh = 0; hh < kCbHelpers; hh++) {
                 const int32_t b2 = part_best[par ^ 1][hh][lane], j2 = part_j[par ^ 1][hh][lane];
                 risk += part_ok[par ^ 1][hh][lane];
-                if (b2 > best || (have && b2 == best && j2 > best_j)) { best = b2; best_j = j2; have = true; }
+                if (b2 >= thr && !(best_j != kNoJ && b2 == thr && j2 < best_j)) { thr = b2; best_j = j2; }
             }
             auto fold = [&](int32_t sc, bool ok, int jrel) {
-                const bool up = ok && (sc > best || (have && sc == best));
+                asm volatile("" : "+v"(sc));                 // (selected, not branched around: see the helpers' step)
+                const bool up = ok & (sc >= thr);
                 risk = up ? 0 : risk + (ok ? 1 : 0);
-                if (up) { best = sc; best_j = jrel; have = true; }
+                thr = up ? sc : thr; best_j = up ? jrel : best_j;
             };
+            auto score_of = [&](int b) { return __builtin_amdgcn_readlane(thr, b) - (__builtin_amdgcn_readlane(best_j, b) == kNoJ ? 1 : 0); };
             // near predecessors: the previous block, OLDEST first (a newer one wins a tie), so that `risk` counts what is newer
             auto near_fold = [&](auto tag) {
                 auto step = [&](int l) {
                     bool ok;
                     const int32_t sc = geom(tag, xa, qa, qsa, sida, prev, l, ok) + __builtin_amdgcn_readlane(pbest, l);
-                    fold(sc, ok && mine && l - 64 >= st_rel, l - 64);
+                    fold(sc, ok & mine & (l - 64 >= st_rel), l - 64);
                 };
                 int l = 0;
                 for (; l + 3 < pnb; l += 4) { step(l); step(l + 1); step(l + 2); step(l + 3); }
@@ -972,40 +982,40 @@ __global__ __launch_bounds__(64 * (1 + kCbHelpers)) void chain_block_kernel(cons
             if (plain) near_fold(std::true_type{}); else near_fold(std::false_type{});
             // predecessors inside the block: anchor b is final once 0 .. b-1 are folded; if its certificate fails it is
             // re-done exactly before its score is broadcast.  The geometry of (a, b) involves no score and is computed four
-            // steps ahead, so the dependent part of a step is readlane(best, b) + add + compare + select.
+            // steps ahead, so the dependent part of a step is readlane(score, b) + add + compare + select.
             auto finalize = [&](int b) {
                 const int rb = __builtin_amdgcn_readlane(risk, b);
-                const bool hb = __builtin_amdgcn_readlane((int)have, b) != 0;
-                if (hb && rb > kMaxSkip) {                   // wave-uniform: the reference's own scan of anchor i0 + b
-                    if (mine && lane < b) { S[i0 + lane] = best; P[i0 + lane] = have ? i0 + best_j : -1; }
+                if (rb > kMaxSkip && __builtin_amdgcn_readlane(best_j, b) != kNoJ) {     // wave-uniform: the reference's own scan of anchor i0 + b
+                    if (mine && lane < b) { S[i0 + lane] = thr - (best_j == kNoJ ? 1 : 0); P[i0 + lane] = best_j == kNoJ ? -1 : i0 + best_j; }
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     int32_t eb, ej;
                     chain_exact_global(X, Y, S, P, GM, i0 + b, i0 + __builtin_amdgcn_readlane(st_rel, b), mdx, mdy, bw, multi_seg, avg_d, eb, ej, evals);
-                    if (lane == b) { best = eb; best_j = ej - i0; have = ej >= 0; risk = 0; }
+                    if (lane == b) { thr = ej >= 0 ? eb : eb + 1; best_j = ej >= 0 ? ej - i0 : kNoJ; risk = 0; }
                 }
             };
             auto block_fold = [&](auto tag) {
                 auto g = [&](int b, bool &ok) -> int32_t {
                     const int32_t v = geom(tag, xa, qa, qsa, sida, cur, b, ok);
-                    ok = ok && mine && lane > b && b >= st_rel;
+                    ok = ok & mine & (lane > b) & (b >= st_rel);
                     return v;
                 };
                 int b = 0;
                 for (; b + 4 < nb; b += 4) {
                     bool o0, o1, o2, o3;
                     const int32_t g0 = g(b, o0), g1 = g(b + 1, o1), g2 = g(b + 2, o2), g3 = g(b + 3, o3);
-                    finalize(b);     fold(g0 + __builtin_amdgcn_readlane(best, b), o0, b);
-                    finalize(b + 1); fold(g1 + __builtin_amdgcn_readlane(best, b + 1), o1, b + 1);
-                    finalize(b + 2); fold(g2 + __builtin_amdgcn_readlane(best, b + 2), o2, b + 2);
-                    finalize(b + 3); fold(g3 + __builtin_amdgcn_readlane(best, b + 3), o3, b + 3);
+                    finalize(b);     fold(g0 + score_of(b), o0, b);
+                    finalize(b + 1); fold(g1 + score_of(b + 1), o1, b + 1);
+                    finalize(b + 2); fold(g2 + score_of(b + 2), o2, b + 2);
+                    finalize(b + 3); fold(g3 + score_of(b + 3), o3, b + 3);
                 }
                 for (; b < nb; b++) {
                     finalize(b);
-                    if (b + 1 < nb) { bool o; const int32_t gg = g(b, o); fold(gg + __builtin_amdgcn_readlane(best, b), o, b); }
+                    if (b + 1 < nb) { bool o; const int32_t gg = g(b, o); fold(gg + score_of(b), o, b); }
                 }
             };
             if (plain) block_fold(std::true_type{}); else block_fold(std::false_type{});
-            if (mine) { S[i0 + lane] = best; P[i0 + lane] = have ? i0 + best_j : -1; }
+            const int32_t best = thr - (best_j == kNoJ ? 1 : 0);
+            if (mine) { S[i0 + lane] = best; P[i0 + lane] = best_j == kNoJ ? -1 : i0 + best_j; }
             prev = cur; pbest = best; pnb = nb;
         }
         __syncthreads();       // results of block t are acknowledged by L2; partial maxima of block t+1 are in LDS
