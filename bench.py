@@ -31,7 +31,7 @@ HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec 
 # HBM traffic of the dominant kernel(s) of a workload's LARGE configuration, measured once per round with rocprofv3 PMC
 # counters in separate passes (tools/profiling/hbm_traffic.sh -> profiles/r01_hbm_traffic.json); `double_fetch`: the
 # kernel reads wide coalesced streams, for which gfx950's FETCH_SIZE reports half the bytes (MI355X_MICROARCH.md, HBM)
-TRAFFIC_KERNELS = {"bsw": (["bsw_dp8"], False), "chain": (["chain_hw_kernel"], False), "fast-chain": (["fastchain_kernel"], False),
+TRAFFIC_KERNELS = {"bsw": (["bsw_dp8"], False), "chain": (["chain_block_kernel", "chain_facts_kernel"], False), "fast-chain": (["fastchain_kernel"], False),
                    "bpm": (["bpm_score<3>"], False), "bitpal": (["bitpal_dp<true, true>"], False), "wfa": (["wfa_lds<16"], False), "fmi": (["fmi_seed_kernel<true>"], False),
                    "fmi-sa": (["fmi_sa_kernel"], False), "parse-bsw": (["nl_count", "nl_fill", "bsw_meta", "bsw_codes", "len_offsets",
                                                                        "len_block_sums"], True)}
@@ -284,7 +284,7 @@ class ChainWorkload:
     default_items = 10_000          # calls per GPU (chain-large: c_elegans 10k calls)
     seed = 5
     ref_exe = "chain_ref"
-    kernel = "chain_hw_kernel"
+    kernel = "chain_block_kernel"
 
     def __init__(self, items, rank, dev):
         import torch

@@ -3,7 +3,8 @@
 
 bench.py checks a slice per run (its check is outside the timed region but still has to stay short); this is the one-off
 exhaustive version: all 10 M bsw / bpm / bitpal pairs, all 1 M wfa pairs (scores, lengths and every CIGAR byte), all
-10 000 chain / fast-chain calls.  Writes a summary to stdout; profiles/r01_full_size_parity.md keeps the last one.
+10 000 chain / fast-chain calls, all 10 M fmi reads (77 M SMEM records).  Writes a summary to stdout;
+profiles/rNN_full_size_parity.md keeps the last one of each round.
 """
 import os
 import sys
@@ -22,7 +23,7 @@ def line(name, n, what, ok, t_gpu, t_cpu):
 
 
 def main():
-    which = sys.argv[1:] or ["bsw", "bpm", "bitpal", "wfa", "chain", "fast-chain"]
+    which = sys.argv[1:] or ["bsw", "bpm", "bitpal", "wfa", "chain", "fast-chain", "fmi"]
     ok = True
     print("| workload | items | compared | result | GPU (host-pointer entry point, incl. PCIe) | oracle, all host threads |\n|---|---|---|---|---|---|")
     if "bsw" in which:
@@ -79,6 +80,24 @@ def main():
         ok &= line(f"{nm}-large", f"{len(cb.hdr)} calls, {cb.nanchors} anchors", "score and parent of every anchor",
                    np.array_equal(s, ws) and np.array_equal(p, wp), t1 - t0, t2 - t1)
         e.close(); del cb
+    if "fmi" in which:
+        # fmi-large: all 10 M reads against the 256 Mbp index (bench.py checks the first 20 000 per run)
+        import ctypes as C
+        from tools import mkindex
+        from genarchbench_amd.fmi import FMI_search
+        ref = gabgen.fmi_ref(6, 256_000_000, 5)
+        idx = mkindex.FmIndex(ref)
+        reads = gabgen.fmi_reads(7, ref, 10_000_000, 151, 151)
+        e = FMI_search(arrays=(idx.ref_seq_len, idx.count, idx.cp_occ, idx.sentinel_index))
+        t0 = time.time(); sm, off = e.seed(reads, 19); t1 = time.time()
+        oidx = pyoracle.FmIndex()
+        cnt = (C.c_int64 * 5)(*[int(x) for x in idx.count])
+        pyoracle.lib().oracle_fmi_from_arrays(C.byref(oidx), C.c_int64(idx.ref_seq_len), cnt, idx.cp_occ.ctypes.data_as(C.c_void_p),
+                                              C.c_int64(idx.sentinel_index))
+        w, woff = pyoracle.fmi(oidx, reads, 19); t2 = time.time()
+        same = np.array_equal(off, woff) and len(sm) == len(w) and all(np.array_equal(sm[f], w[f]) for f in ("rid", "m", "n", "k", "l", "s"))
+        ok &= line("fmi-large (256 Mbp index)", f"{reads.n} reads, {len(w)} SMEMs", "all six fields of every SMEM, per-read offsets", same, t1 - t0, t2 - t1)
+        e.close()
     print("ALL IDENTICAL" if ok else "MISMATCH FOUND")
     return 0 if ok else 1
 
