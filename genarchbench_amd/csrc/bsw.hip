@@ -695,8 +695,15 @@ extern "C" int gab_bsw_run_device(gab_bsw *h, const uint8_t *ref, int64_t ref_by
     for (int k = 0; k < gab_bsw::kAux; k++) GAB_HIP(hipStreamWaitEvent(h->aux[k], h->fork, 0));
     int nlaunch = 0;
     hipStream_t s_main = s;
+    // Small batches (fewer waves than fill the chip a few times over) go out as ONE launch sized for their longest query:
+    // eight class launches of a couple of hundred waves each leave most CUs idle and pay eight launch latencies
+    // (100 k pairs: 3.0 -> 1.x ms); the records are in key order, so the heaviest waves still start first.
+    const bool one_launch = n <= (int64_t)64 * 8192;
+    int top_cls = kNumClasses - 1;
+    while (top_cls > 0 && h->h_qstart[(top_cls + 1) * kClassStep] <= h->h_qstart[top_cls * kClassStep]) top_cls--;
     for (int cls = kNumClasses - 1; cls >= 0; cls--) {      // longest queries first: the tail of the step is made of short work
-        const int64_t kb = h->h_qstart[cls * kClassStep], ke = h->h_qstart[(cls + 1) * kClassStep];
+        int64_t kb = h->h_qstart[cls * kClassStep], ke = h->h_qstart[(cls + 1) * kClassStep];
+        if (one_launch) { if (cls != top_cls) continue; kb = 0; }
         if (ke <= kb) continue;
         const int qcap = (cls + 1) * kClassStep;
         const int blocks = (int)gab_ceil_div(ke - kb, 64);
