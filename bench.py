@@ -1085,7 +1085,7 @@ def run_workload(W, items, steps, warmup, ctx, args, with_cpu=True, with_host=Tr
     elapsed = time.perf_counter() - t0
     from genarchbench_amd.shard import aggregate
     units = wl.units_per_step() if hasattr(wl, "units_per_step") else getattr(wl, "items", items)
-    elapsed, total_units = aggregate(elapsed, units, dist if world > 1 else None, dev)
+    elapsed, total_units = aggregate(elapsed, units, dist if world > 1 else None, ctx.get("agg_dev", dev))
 
     mark(f"{steps} timed steps done")
     verdict = None if args.no_check else wl.check()
@@ -1101,7 +1101,8 @@ def run_workload(W, items, steps, warmup, ctx, args, with_cpu=True, with_host=Tr
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": W.dtype,
             "data": "synthetic (seeded generator tools/gen, SURVEY.md 8d distributions)",
             "config": {"workload": f"{W.name}-large" if large else f"{W.name}-{items}",
-                       "items_per_gpu": items, "sharding": f"{world} x independent id ranges, no collective"},
+                       "items_per_gpu": items, "sharding": f"{world} x independent id ranges, no collective" +
+                       (" -- TEST MODE: all ranks share GPU 0 (GAB_BENCH_SHARE_GPU=1), not an N-GPU measurement" if ctx.get("share") else "")},
             "roofline": wl.roofline(), "extra": wl.extra(ms), "parity": verdict,
         }
         km = out["extra"].get("dominant_kernel_ms")
@@ -1161,14 +1162,20 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: libgab_hip has no CPU fallback")
+    # GAB_BENCH_SHARE_GPU=1 (tests only): the N ranks all use GPU 0 and rendezvous over gloo -- the N > 1 code path (id-range
+    # sharding, barrier, MAX / SUM aggregation) with real engine handles on a one-GPU box.  The line says so.
+    share = world > 1 and os.environ.get("GAB_BENCH_SHARE_GPU") == "1"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    dev = torch.device("cuda", local_rank if world > 1 else 0)
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank if world > 1 and not share else 0)
     torch.cuda.set_device(dev)
-    ctx = {"rank": rank, "world": world, "dev": dev, "dist": dist}
+    ctx = {"rank": rank, "world": world, "dev": dev, "dist": dist, "agg_dev": None if share else dev, "share": share}
     t_start = time.time()
 
     W = WORKLOADS[args.workload or "bsw"]

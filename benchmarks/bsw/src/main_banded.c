@@ -40,6 +40,9 @@ static void *gpu_init(int worker, int gpu, void *vctx) {
     bsw_ctx *c = (bsw_ctx *)vctx;
     gab_bsw *h = NULL;
     GAB_DIE_IF(gab_bsw_create(&c->prm, gpu, &h), "gab_bsw_create");
+    /* device buffers for one chunk, like the working buffers the reference's constructor allocates (bandedSWA.cpp:80-96) */
+    const int64_t m = c->chunk < c->n ? c->chunk : c->n;
+    GAB_DIE_IF(gab_bsw_reserve(h, m, m * (MAX_SEQ_LEN_REF / 8) + 4096, m * (MAX_SEQ_LEN_QER / 2) + 4096), "gab_bsw_reserve");
     return h;
 }
 static void gpu_fini(int worker, int gpu, void *vctx, void *st) { (void)worker; (void)gpu; (void)vctx; gab_bsw_destroy((gab_bsw *)st); }

@@ -23,12 +23,15 @@ typedef struct {
     int32_t *score, *parent;
     int64_t ncalls;
     int64_t *chunk_beg;      /* chunk c = calls [chunk_beg[c], chunk_beg[c+1]) */
+    int64_t max_chunk_anchors, max_chunk_calls;
 } chain_ctx;
 
 static void *gpu_init(int worker, int gpu, void *vctx) {
-    (void)vctx; (void)worker;
+    (void)worker;
+    chain_ctx *c = (chain_ctx *)vctx;
     gab_chain *h = NULL;
     GAB_DIE_IF(gab_chain_create(gpu, &h), "gab_chain_create");
+    GAB_DIE_IF(gab_chain_reserve(h, c->max_chunk_anchors, c->max_chunk_calls), "gab_chain_reserve");   /* buffers before the ROI */
     return h;
 }
 static void gpu_fini(int worker, int gpu, void *vctx, void *st) { (void)worker; (void)gpu; (void)vctx; gab_chain_destroy((gab_chain *)st); }
@@ -175,6 +178,14 @@ int main(int argc, char **argv) {
             if (acc >= per && nchunks + 1 < nchunks_want) { ctx.chunk_beg[++nchunks] = (int64_t)c + 1; acc = 0; }
         }
         ctx.chunk_beg[++nchunks] = (int64_t)ncalls;
+    }
+    ctx.max_chunk_anchors = 0; ctx.max_chunk_calls = 0;
+    for (int64_t c = 0; c < nchunks; c++) {
+        const int64_t b = ctx.chunk_beg[c], e = ctx.chunk_beg[c + 1];
+        if (e <= b) continue;
+        const int64_t a = call_off[e - 1] + hdr[e - 1].n - call_off[b];
+        if (a > ctx.max_chunk_anchors) ctx.max_chunk_anchors = a;
+        if (e - b > ctx.max_chunk_calls) ctx.max_chunk_calls = e - b;
     }
     gab_pin(x, 8 * na); gab_pin(y, 8 * na); gab_pin(ctx.score, 4 * na); gab_pin(ctx.parent, 4 * na);
     gab_queue q;

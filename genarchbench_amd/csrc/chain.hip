@@ -1170,6 +1170,23 @@ extern "C" int gab_chain_run(gab_chain *h, int mode, const uint64_t *x, const ui
     return GAB_OK;
 }
 
+// Pre-size the handle's device buffers for calls of up to max_anchors anchors in max_calls calls (see gab_bsw_reserve).
+extern "C" int gab_chain_reserve(gab_chain *h, int64_t max_anchors, int64_t max_calls) {
+    GAB_CHECK(h, "gab_chain_reserve: NULL handle");
+    GAB_CHECK(max_anchors >= 0 && max_calls >= 0 && max_calls < (1ll << 31), "gab_chain_reserve: size out of range");
+    gab_device_guard g(h->device);
+    int rc = h->io.reserve(24 * (size_t)max_anchors + 64);
+    if (rc) return rc;
+    if ((rc = h->gmarks.reserve(sizeof(int32_t) * (size_t)max_anchors + 64)) != GAB_OK) return rc;
+    if ((rc = h->work.reserve(sizeof(ChainWork) * (size_t)max_calls + 64)) != GAB_OK) return rc;
+    hipStream_t s = nullptr;
+    if ((rc = h->hs.get(&s)) != GAB_OK) return rc;
+    GAB_HIP(hipMemsetAsync(h->io.p, 0, h->io.cap, s));
+    GAB_HIP(hipMemsetAsync(h->gmarks.p, 0, h->gmarks.cap, s));
+    GAB_HIP(hipStreamSynchronize(s));
+    return GAB_OK;
+}
+
 extern "C" int gab_chain_last_stats(gab_chain *h, int64_t *evals, float *kernel_ms) {
     GAB_CHECK(h, "gab_chain_last_stats: NULL handle");
     GAB_CHECK(h->have_stats, "gab_chain_last_stats: no completed run on this handle");

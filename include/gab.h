@@ -12,9 +12,11 @@
  *     GAB_E* code and never calls exit(); gab_last_error() gives the message for the
  *     calling thread.
  *   - the caller owns every buffer.  "_run" variants take HOST pointers and do
- *     H2D + kernels + D2H synchronously; "_run_device" variants take DEVICE pointers
- *     (hipMalloc'ed or a torch tensor's data_ptr) and enqueue asynchronously on `stream`
- *     (a hipStream_t passed as void*, NULL = the default stream).  Some of them (bsw, bpm) run part of their
+ *     H2D + kernels + D2H synchronously (on a private non-blocking stream of the handle, so
+ *     that calls on several handles of one GPU overlap); "_run_device" variants take DEVICE pointers
+ *     (hipMalloc'ed or a torch tensor's data_ptr) and enqueue on `stream` (a hipStream_t passed
+ *     as void*, NULL = the default stream); each entry says where it synchronises `stream`
+ *     internally.  Some of them (bsw, bpm) run part of their
  *     kernels on an internal second stream; it is forked from and joined back into `stream` by events
  *     inside the call, so the caller only ever has to order against `stream`.
  *   - a handle is bound to one GPU; calls on distinct handles are thread-safe, so the
@@ -82,6 +84,11 @@ typedef struct {
 int gab_bsw_create(const gab_bsw_params *params, int device, gab_bsw **out);
 void gab_bsw_destroy(gab_bsw *h);
 
+/* optional: size the handle's device buffers now for calls of up to max_pairs pairs whose referenced windows of the two
+ * slabs are at most max_ref_bytes / max_qry_bytes, so that the first gab_bsw_run of a timed region does not allocate
+ * (the reference allocates its working buffers in the BandedPairWiseSW constructor, bsw/src/bandedSWA.cpp:80-96) */
+int gab_bsw_reserve(gab_bsw *h, int64_t max_pairs, int64_t max_ref_bytes, int64_t max_qry_bytes);
+
 /* Host buffers.  Pair i: reference (target) = ref[ref_off[i] .. +len1[i]), query =
  * qry[qry_off[i] .. +len2[i]), base codes 0..4 one byte each (what loadPairs produces,
  * main_banded.cpp:164-206), seed score h0[i].  score_out[i] = SeqPair.score. */
@@ -89,7 +96,9 @@ int gab_bsw_run(gab_bsw *h, const uint8_t *ref, const int64_t *ref_off, const ui
                 const int64_t *qry_off, const int32_t *len1, const int32_t *len2,
                 const int32_t *h0, int64_t n, int32_t *score_out);
 
-/* Device buffers, asynchronous on `stream`.  ref_bytes / qry_bytes = sizes of the two
+/* Device buffers.  Enqueues on `stream`, but synchronises it once mid-way (the launch geometry of the DP kernels needs
+ * the sizes of the query-length classes on the host); the DP launches and the result stores that follow are asynchronous:
+ * order later work against `stream` (or synchronise it) before reading score_out.  ref_bytes / qry_bytes = sizes of the two
  * sequence slabs (used for bounds validation of 4-byte reads: both slabs must be
  * readable up to a multiple of 4 bytes past the last base).  result_out may be NULL;
  * when given it receives all six result fields per pair. */
@@ -124,6 +133,8 @@ typedef struct {           /* call_t header, chain/src/host_data.h:23-28 */
 
 int gab_chain_create(int device, gab_chain **out);
 void gab_chain_destroy(gab_chain *h);
+/* optional: size the handle's device buffers now for calls of up to max_anchors anchors in max_calls calls (see gab_bsw_reserve) */
+int gab_chain_reserve(gab_chain *h, int64_t max_anchors, int64_t max_calls);
 /* everything on the host */
 int gab_chain_run(gab_chain *h, int mode, const uint64_t *x, const uint64_t *y, const int64_t *call_off,
                   const gab_chain_hdr *hdr, int64_t ncalls, int32_t *score_out, int32_t *parent_out);

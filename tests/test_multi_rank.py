@@ -80,3 +80,31 @@ def test_bench_gpus_flag_is_binding():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "1"],
                        env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr + r.stdout
+
+
+import pytest
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("workload,items", [("bsw", 200_000), ("chain", 600)])
+def test_two_ranks_real_engines_one_gpu(workload, items):
+    """the N > 1 path of bench.py with REAL engine handles: two ranks (torch.distributed.run, as the driver launches it),
+    each with its own handle on its own id range and checking its own shard against the oracle; on a one-GPU box both use
+    GPU 0 and rendezvous over gloo (GAB_BENCH_SHARE_GPU=1 -- the line says it is not a 2-GPU measurement)"""
+    import json
+    env = dict(os.environ, GAB_BENCH_SHARE_GPU="1", MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29531", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", workload, "--items", str(items),
+                        "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-host-roi"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and "TEST MODE" in d["config"]["sharding"]
+    assert d["parity"].startswith("bit-exact")
+    # whole-job value = units of BOTH ranks / max-over-ranks time
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", workload, "--items", str(items), "--steps", "2",
+                          "--warmup", "1", "--no-cpu-baseline", "--no-host-roi"], capture_output=True, text=True, timeout=600)
+    assert one.returncode == 0, one.stderr[-2000:]
+    d1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
+    assert d1["n_gpus"] == 1
+    assert d["value"] * d["ms_per_step"] == pytest.approx(2 * d1["value"] * d1["ms_per_step"], rel=0.02 if workload == "bsw" else 0.5)

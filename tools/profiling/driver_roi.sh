@@ -14,7 +14,15 @@ if not os.path.exists(f"{T}/bsw.txt"):
 if not os.path.exists(f"{T}/chain.txt"):
     gabgen.write_text("chain", f"{T}/chain.txt", 5, 10_000, 0, 50, 60000)
 PY
-cores=$(python3 -c "import os; print(len(os.sched_getaffinity(0)))")
+cores=$(python3 -c "
+import os
+n = len(os.sched_getaffinity(0))
+try:
+    q, p = open(\"/sys/fs/cgroup/cpu.max\").read().split()
+    n = n if q == \"max\" else max(1, min(n, int(q) // int(p)))
+except Exception:
+    pass
+print(n)")   # the CPU quota of the box, not every visible hardware thread
 for w in ${@:-1 2 3}; do   # chain-large through the driver needs its fscanf parse of 85 M anchors (~20 s) per run
   export GAB_WORKERS_PER_GPU=$w GAB_GPUS=1
   ./benchmarks/bsw/main_bsw -pairs $T/bsw.txt -t 1 -b 512 2> $T/bsw_err_$w.txt | grep -E "Overall SW" | sed "s/^/bsw-large driver, $w worker(s) per GPU: /"
