@@ -74,7 +74,7 @@ def log(*a):
 # and D2H of results").  Same scheme as benchmarks/common/gab_driver.h: the item range is cut into chunks, WORKERS host
 # threads (each with its own engine handle = its own stream) pull chunk indices from a shared cursor and call the
 # host-pointer entry point gab_*_run on page-locked slabs, so one chunk's copies run under another chunk's kernels.
-HOST_WORKERS = int(os.environ.get("GAB_WORKERS_PER_GPU", "2"))
+HOST_WORKERS = int(os.environ.get("GAB_WORKERS_PER_GPU", "3"))
 
 
 def pin(*arrays):

@@ -9,7 +9,7 @@
  *
  * Instead of T OpenMP threads each calling getScores16 on batches of B pairs (main_banded.cpp:338-350),
  * the ROI makes gab_bsw_run calls on chunks of pairs ($GAB_CHUNK, default 2^20) pulled from a shared cursor by
- * $GAB_WORKERS_PER_GPU host threads per GPU (default 2, each with its own handle: the H2D copy of one chunk runs under
+ * $GAB_WORKERS_PER_GPU host threads per GPU (default 3, each with its own handle: the H2D copy of one chunk runs under
  * the kernels of another).  -t and -b are accepted and ignored (they tune the CPU path only); -g / $GAB_GPUS selects the
  * number of GPUs.
  *
@@ -199,6 +199,9 @@ int main(int argc, char *argv[]) {
     ctx.busy = (double *)calloc((size_t)q.nworkers, sizeof(double));
 
     /* ---- region of interest (main_banded.cpp:290-389) ---- */
+    for (int64_t rep = gab_env_i64("GAB_ROI_WARMUPS", 0); rep > 0; rep--)       /* diagnosis only: untimed passes before the ROI */
+        gab_queue_run(&q, (n + ctx.chunk - 1) / ctx.chunk);
+    memset(ctx.busy, 0, sizeof(double) * (size_t)q.nworkers);
     const double t0 = gab_now();
     gab_roi_begin_n(ngpus);
     gab_queue_run(&q, (n + ctx.chunk - 1) / ctx.chunk);

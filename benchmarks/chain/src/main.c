@@ -5,7 +5,7 @@
  * text I/O as chain/src/host_data_io.cpp:13-60.  The harness compares out.txt and greps "Time in kernel"
  * (chain/scripts/regression_small.sh:89,94).
  * The ROI call host_chain_kernel(calls, rets, numThreads) (main.cpp:154) becomes gab_chain_run over chunks
- * of calls pulled by $GAB_WORKERS_PER_GPU host threads per GPU (default 2; $GAB_CHUNK = anchors per chunk).  Built twice: -DGAB_CHAIN_MODE=0 (chain) and =1 (fast-chain).
+ * of calls pulled by $GAB_WORKERS_PER_GPU host threads per GPU (default 3; $GAB_CHUNK = anchors per chunk).  Built twice: -DGAB_CHAIN_MODE=0 (chain) and =1 (fast-chain).
  * Extra flag: -g <gpus> (or $GAB_GPUS).  -t is accepted and ignored.
  */
 #define GAB_ENERGY_STREAM stderr      /* where the reference prints "Energy consumption:" in this driver */

@@ -17,7 +17,7 @@
  *
  * Multi-GPU.  Work items are independent, so N GPUs are driven by host threads that pull chunk indices from one
  * atomic cursor (the reference's `omp for schedule(dynamic)` over batches, lifted one level up); there is no
- * collective and no exchange step.  GAB_WORKERS_PER_GPU=k (default 2) starts k such threads per GPU, each with its own
+ * collective and no exchange step.  GAB_WORKERS_PER_GPU=k (default 3) starts k such threads per GPU, each with its own
  * engine handle and streams, so the H2D copy, the kernels and the D2H copy of consecutive chunks overlap;
  * GAB_CHUNK=items overrides the driver's chunk size (tests use it to push small fixtures through the multi-chunk path).
  */
@@ -185,7 +185,7 @@ static void *gab_worker_main(void *p) {
 }
 /* init/fini run outside the caller's timed region if the caller times only gab_queue_run */
 typedef struct { int ngpus, nworkers; gab_worker *w; pthread_mutex_t mu; int64_t cursor; } gab_queue;
-static inline int gab_workers_per_gpu(void) { return (int)gab_env_i64("GAB_WORKERS_PER_GPU", 2); }
+static inline int gab_workers_per_gpu(void) { return (int)gab_env_i64("GAB_WORKERS_PER_GPU", 3); }
 static inline void gab_queue_open(gab_queue *q, int ngpus, gab_gpu_init_fn init, gab_chunk_fn run, gab_gpu_fini_fn fini, void *ctx) {
     q->ngpus = ngpus; q->nworkers = ngpus * gab_workers_per_gpu(); q->cursor = 0;
     pthread_mutex_init(&q->mu, NULL);

@@ -8,7 +8,7 @@
  * loaded and replicated on every GPU before the ROI, as load_index precedes begin_computing in the reference.
  * The per-batch ROI body (getSMEMsAllPos -> re-seed -> bwtSeedStrategy -> sortSMEMs, fmi.cpp:288-348) becomes
  * gab_fmi_seed on chunks of reads ($GAB_CHUNK, default 2^20) pulled by $GAB_WORKERS_PER_GPU host threads per GPU
- * (default 2; the workers of a GPU share one copy of the index); batch_size and n_threads only shaped the CPU
+ * (default 3; the workers of a GPU share one copy of the index); batch_size and n_threads only shaped the CPU
  * scheduling and are accepted and ignored.
  */
 #define GAB_ENERGY_STREAM stderr      /* where the reference prints "Energy consumption:" in this driver */

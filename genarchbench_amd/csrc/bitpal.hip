@@ -363,12 +363,16 @@ extern "C" int gab_bitpal_run(gab_bitpal *h, const char *pat, const int64_t *pat
     char *b = h->io.as<char>();
     hipStream_t s = nullptr;
     if ((rc = h->hs.get(&s)) != GAB_OK) return rc;
-    GAB_HIP(hipMemcpyAsync(b + o_p, pat + pa, (size_t)(pb - pa), hipMemcpyHostToDevice, s));
-    GAB_HIP(hipMemcpyAsync(b + o_t, txt + ta, (size_t)(tb - ta), hipMemcpyHostToDevice, s));
-    GAB_HIP(hipMemcpyAsync(b + o_po, pat_off, 8 * nn, hipMemcpyHostToDevice, s));
-    GAB_HIP(hipMemcpyAsync(b + o_to, txt_off, 8 * nn, hipMemcpyHostToDevice, s));
-    GAB_HIP(hipMemcpyAsync(b + o_pl, pat_len, 4 * nn, hipMemcpyHostToDevice, s));
-    GAB_HIP(hipMemcpyAsync(b + o_tl, txt_len, 4 * nn, hipMemcpyHostToDevice, s));
+    {   // the copies of one chunk at a time per GPU (gab_core.hip: the workers of a GPU must not copy in lockstep)
+        std::lock_guard<std::mutex> gate(gab_h2d_mutex(h->device));
+        GAB_HIP(hipMemcpyAsync(b + o_p, pat + pa, (size_t)(pb - pa), hipMemcpyHostToDevice, s));
+        GAB_HIP(hipMemcpyAsync(b + o_t, txt + ta, (size_t)(tb - ta), hipMemcpyHostToDevice, s));
+        GAB_HIP(hipMemcpyAsync(b + o_po, pat_off, 8 * nn, hipMemcpyHostToDevice, s));
+        GAB_HIP(hipMemcpyAsync(b + o_to, txt_off, 8 * nn, hipMemcpyHostToDevice, s));
+        GAB_HIP(hipMemcpyAsync(b + o_pl, pat_len, 4 * nn, hipMemcpyHostToDevice, s));
+        GAB_HIP(hipMemcpyAsync(b + o_tl, txt_len, 4 * nn, hipMemcpyHostToDevice, s));
+        GAB_HIP(hipStreamSynchronize(s));
+    }
     rc = gab_bitpal_run_device(h, b + o_p - pa, pa + (int64_t)ppad, (const int64_t *)(b + o_po), (const int32_t *)(b + o_pl),
                                b + o_t - ta, ta + (int64_t)tpad, (const int64_t *)(b + o_to), (const int32_t *)(b + o_tl), n,
                                (int32_t *)(b + o_sc), s);

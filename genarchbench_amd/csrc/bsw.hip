@@ -23,8 +23,11 @@
 // ~7.4 k cells per ~210 input bytes); HBM traffic is the algorithmic minimum
 // len1 + len2 + 12 B per pair plus the 4-byte permutation entry.
 #include "gab_internal.h"
+#include <algorithm>
 #include <new>
 #include <string.h>
+#include <time.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -745,6 +748,9 @@ extern "C" int gab_bsw_run(gab_bsw *h, const uint8_t *ref, const int64_t *ref_of
     if (n == 0) return GAB_OK;
     GAB_CHECK(ref && ref_off && qry && qry_off && len1 && len2 && h0 && score_out, "gab_bsw_run: NULL buffer");
     gab_device_guard g(h->device);
+    const bool trace = getenv("GAB_BSW_TRACE") != nullptr;      // diagnosis: per-phase wall times of this call on stderr
+    auto now = [] { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; };
+    const double t_0 = now();
     // extent of the two slabs actually referenced: only [min, max) is staged, so a driver can hand a window
     // of a big input (absolute offsets) to each GPU without re-basing its offset arrays
     int64_t rb = 0, qb = 0, ra = INT64_MAX, qa = INT64_MAX;
@@ -772,21 +778,33 @@ extern "C" int gab_bsw_run(gab_bsw *h, const uint8_t *ref, const int64_t *ref_of
     char *b = h->io.as<char>();
     hipStream_t s = nullptr;
     if ((rc = h->hs.get(&s)) != GAB_OK) return rc;
-    GAB_HIP(hipMemcpyAsync(b + o_ref, ref + ra, (size_t)(rb - ra), hipMemcpyHostToDevice, s));
-    GAB_HIP(hipMemcpyAsync(b + o_qry, qry + qa, (size_t)(qb - qa), hipMemcpyHostToDevice, s));
-    GAB_HIP(hipMemcpyAsync(b + o_roff, ref_off, 8 * nn, hipMemcpyHostToDevice, s));
-    GAB_HIP(hipMemcpyAsync(b + o_qoff, qry_off, 8 * nn, hipMemcpyHostToDevice, s));
-    GAB_HIP(hipMemcpyAsync(b + o_l1, len1, 4 * nn, hipMemcpyHostToDevice, s));
-    GAB_HIP(hipMemcpyAsync(b + o_l2, len2, 4 * nn, hipMemcpyHostToDevice, s));
-    GAB_HIP(hipMemcpyAsync(b + o_h0, h0, 4 * nn, hipMemcpyHostToDevice, s));
+    const double t_1 = now();
+    {   // the copies of one chunk at a time per GPU (gab_core.hip: the workers of a GPU must not copy in lockstep)
+        std::lock_guard<std::mutex> gate(gab_h2d_mutex(h->device));
+        GAB_HIP(hipMemcpyAsync(b + o_ref, ref + ra, (size_t)(rb - ra), hipMemcpyHostToDevice, s));
+        GAB_HIP(hipMemcpyAsync(b + o_qry, qry + qa, (size_t)(qb - qa), hipMemcpyHostToDevice, s));
+        GAB_HIP(hipMemcpyAsync(b + o_roff, ref_off, 8 * nn, hipMemcpyHostToDevice, s));
+        GAB_HIP(hipMemcpyAsync(b + o_qoff, qry_off, 8 * nn, hipMemcpyHostToDevice, s));
+        GAB_HIP(hipMemcpyAsync(b + o_l1, len1, 4 * nn, hipMemcpyHostToDevice, s));
+        GAB_HIP(hipMemcpyAsync(b + o_l2, len2, 4 * nn, hipMemcpyHostToDevice, s));
+        GAB_HIP(hipMemcpyAsync(b + o_h0, h0, 4 * nn, hipMemcpyHostToDevice, s));
+        GAB_HIP(hipStreamSynchronize(s));
+    }
+    double t_2 = 0;
+    if (trace) { GAB_HIP(hipStreamSynchronize(s)); t_2 = now(); }
     // virtual slab origins: device address of byte 0 of the caller's slabs
     rc = gab_bsw_run_device(h, (const uint8_t *)(b + o_ref) - ra, ra + (int64_t)rpad, (const int64_t *)(b + o_roff),
                             (const uint8_t *)(b + o_qry) - qa, qa + (int64_t)qpad, (const int64_t *)(b + o_qoff),
                             (const int32_t *)(b + o_l1), (const int32_t *)(b + o_l2), (const int32_t *)(b + o_h0),
                             n, (int32_t *)(b + o_sc), nullptr, s);
     if (rc) return rc;
+    double t_3 = 0;
+    if (trace) { GAB_HIP(hipStreamSynchronize(s)); t_3 = now(); }
     GAB_HIP(hipMemcpyAsync(score_out, b + o_sc, 4 * nn, hipMemcpyDeviceToHost, s));
     GAB_HIP(hipStreamSynchronize(s));
+    if (trace)
+        fprintf(stderr, "[gab_bsw_run %p] %lld pairs: host scan %.2f ms, H2D of %.1f MB %.2f ms, sort + DP %.2f ms, D2H %.2f ms\n", (void *)h,
+                (long long)n, t_1 - t_0, (double)((rb - ra) + (qb - qa) + 28 * n) / 1e6, t_2 - t_1, t_3 - t_2, now() - t_3);
     return GAB_OK;
 }
 
@@ -798,7 +816,8 @@ extern "C" int gab_bsw_reserve(gab_bsw *h, int64_t max_pairs, int64_t max_ref_by
     GAB_CHECK(max_pairs >= 0 && max_pairs < (1ll << 31) && max_ref_bytes >= 0 && max_qry_bytes >= 0, "gab_bsw_reserve: size out of range");
     gab_device_guard g(h->device);
     const size_t nn = (size_t)max_pairs;
-    int rc = h->io.reserve((((size_t)max_ref_bytes + 3 + 511) & ~(size_t)255) + (((size_t)max_qry_bytes + 3 + 511) & ~(size_t)255) + 32 * nn + 1024);
+    int rc = h->io.reserve(std::max<size_t>((((size_t)max_ref_bytes + 3 + 511) & ~(size_t)255) + (((size_t)max_qry_bytes + 3 + 511) & ~(size_t)255) + 32 * nn + 1024,
+                                            (size_t)4 << 20));      // (at least the 4 MB gab_warm_copy_engines moves)
     if (rc) return rc;
     rc = h->ws.reserve(sizeof(uint32_t) * (2 * kNumKeys + kQBuckets + 4) + sizeof(BswStats) + 1024 + (sizeof(BswRec) + sizeof(uint32_t)) * nn);
     if (rc) return rc;
@@ -808,7 +827,7 @@ extern "C" int gab_bsw_reserve(gab_bsw *h, int64_t max_pairs, int64_t max_ref_by
     GAB_HIP(hipMemsetAsync(h->io.p, 0, h->io.cap, s));
     GAB_HIP(hipMemsetAsync(h->ws.p, 0, h->ws.cap, s));
     GAB_HIP(hipStreamSynchronize(s));
-    return GAB_OK;
+    return gab_warm_copy_engines(s, h->io.p);
 }
 
 extern "C" int gab_bsw_last_stats(gab_bsw *h, int64_t *cells, float *kernel_ms, float *total_ms) {

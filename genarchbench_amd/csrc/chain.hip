@@ -1034,6 +1034,9 @@ struct gab_chain {
     gab_devbuf gmarks;     // chain mode: targets[] for windows deeper than the LDS mark ring (one int32 per anchor)
     gab_devbuf io;         // staging for the host-pointer entry point
     hipEvent_t ev[2] = {nullptr, nullptr};
+    // the host-pointer entry point of big batches: two more streams and the events that order its copies and kernels
+    hipStream_t xs[2] = {nullptr, nullptr};
+    hipEvent_t xe[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     unsigned long long *h_evals = nullptr;   // pinned
     bool have_stats = false;
 };
@@ -1060,6 +1063,8 @@ extern "C" void gab_chain_destroy(gab_chain *h) {
     gab_device_guard g(h->device);
     h->work.release(); h->io.release(); h->hs.release(); h->gmarks.release();
     for (int k = 0; k < 2; k++) if (h->ev[k]) (void)hipEventDestroy(h->ev[k]);
+    for (int k = 0; k < 2; k++) if (h->xs[k]) (void)hipStreamDestroy(h->xs[k]);
+    for (int k = 0; k < 5; k++) if (h->xe[k]) (void)hipEventDestroy(h->xe[k]);
     if (h->h_evals) (void)hipHostFree(h->h_evals);
     delete h;
 }
@@ -1074,6 +1079,27 @@ static int chain_check_hdrs(const gab_chain_hdr *hdr, const int64_t *call_off, i
     }
     *total = end;
     return GAB_OK;
+}
+
+// the kernels of one work list (already on the device) on `s`; nothing else (no memset, no synchronisation)
+static void chain_launch(int mode, hipStream_t s, ChainWork *d_work, unsigned nw, const uint64_t *d_x, const uint64_t *d_y, int32_t *d_score,
+                         int32_t *d_parent, int32_t *d_gm, unsigned long long *d_ev) {
+    if (nw == 0) return;
+    if (mode == GAB_FASTCHAIN)
+        hipLaunchKernelGGL(fastchain_kernel, dim3(nw), dim3(64 * (1 + kFcHelpers)), 0, s, d_work, d_x, d_y, d_score, d_parent, d_ev);
+    else if (getenv("GAB_CHAIN_KERNEL") && !strcmp(getenv("GAB_CHAIN_KERNEL"), "walk"))      // the per-anchor walk (A/B runs)
+        hipLaunchKernelGGL(chain_hw_kernel, dim3(nw), dim3(64 * (1 + kChHelpers)), 0, s, d_work, d_x, d_y, d_score, d_parent, d_gm, d_ev);
+    else {
+        hipLaunchKernelGGL(chain_facts_kernel, dim3(nw), dim3(256), 0, s, d_work, d_x, d_y);
+        hipLaunchKernelGGL(chain_block_kernel, dim3(nw), dim3(64 * (1 + kCbHelpers)), 0, s, d_work, d_x, d_y, d_score, d_parent, d_gm, d_ev);
+    }
+}
+
+static ChainWork chain_work_of(const gab_chain_hdr &hd, int64_t off) {
+    ChainWork w;
+    w.off = off; w.n = hd.n; w.avg_qspan = hd.avg_qspan;
+    w.max_dist_x = hd.max_dist_x; w.max_dist_y = hd.max_dist_y; w.bw = hd.bw; w.n_segs = hd.n_segs; w.pad = 0;
+    return w;
 }
 
 extern "C" int gab_chain_run_device(gab_chain *h, int mode, const uint64_t *d_x, const uint64_t *d_y,
@@ -1123,18 +1149,118 @@ extern "C" int gab_chain_run_device(gab_chain *h, int mode, const uint64_t *d_x,
         GAB_HIP(hipMemsetAsync(d_gm, 0, sizeof(int32_t) * (size_t)total, s));      // vector::resize zero-fills targets
     }
     GAB_HIP(hipEventRecord(h->ev[0], s));
-    if (mode == GAB_FASTCHAIN)
-        hipLaunchKernelGGL(fastchain_kernel, dim3((unsigned)nw), dim3(64 * (1 + kFcHelpers)), 0, s, d_work, d_x, d_y, d_score, d_parent, d_ev);
-    else if (getenv("GAB_CHAIN_KERNEL") && !strcmp(getenv("GAB_CHAIN_KERNEL"), "walk"))      // the per-anchor walk (A/B runs)
-        hipLaunchKernelGGL(chain_hw_kernel, dim3((unsigned)nw), dim3(64 * (1 + kChHelpers)), 0, s, d_work, d_x, d_y, d_score, d_parent, d_gm, d_ev);
-    else {
-        hipLaunchKernelGGL(chain_facts_kernel, dim3((unsigned)nw), dim3(256), 0, s, d_work, d_x, d_y);
-        hipLaunchKernelGGL(chain_block_kernel, dim3((unsigned)nw), dim3(64 * (1 + kCbHelpers)), 0, s, d_work, d_x, d_y, d_score, d_parent, d_gm, d_ev);
-    }
+    chain_launch(mode, s, d_work, (unsigned)nw, d_x, d_y, d_score, d_parent, d_gm, d_ev);
     GAB_HIP(hipGetLastError());
     GAB_HIP(hipEventRecord(h->ev[1], s));
     GAB_HIP(hipMemcpyAsync(h->h_evals, d_ev, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
     GAB_HIP(hipStreamSynchronize(s));    // wk (host vector) must outlive the H2D copy
+    h->have_stats = true;
+    return GAB_OK;
+}
+
+// gab_chain_run for a big batch.  A batch takes at least as long as the fold of its longest call (~27 ms for 60 000 anchors),
+// and the copy of 16 B per anchor in and 8 B out takes about as long as all the kernels together, so plain
+// copy-in / kernels / copy-out doubles the time.  Order of events instead (three streams, ordered by events):
+//   A   the anchors of the LONGEST calls (~6 % of all) are copied first and their kernel starts at once: the critical path
+//       begins ~3 ms into the call instead of after the whole copy-in;
+//   B1  the first half of x / y follows, then the kernel of the remaining calls that lie in it, then -- once A is done too --
+//       the first half of the results goes back;
+//   B2  the second half is copied right behind the first (under B1's kernel), its kernel, its half of the results.
+// (Cutting the batch into independent gab_chain_run calls instead would put a long call into every piece: measured
+// 113 ms for 2 pieces, 272 ms for 8, against 74 ms unsplit.)
+static int chain_run_overlapped(gab_chain *h, int mode, const uint64_t *x, const uint64_t *y, const int64_t *call_off,
+                                const gab_chain_hdr *hdr, int64_t ncalls, int64_t total, int32_t *score_out, int32_t *parent_out,
+                                hipStream_t sA) {
+    h->have_stats = false;
+    const size_t t = (size_t)total;
+    char *b = h->io.as<char>();
+    uint64_t *dx = (uint64_t *)b, *dy = (uint64_t *)(b + 8 * t);
+    int32_t *ds = (int32_t *)(b + 16 * t), *dp = (int32_t *)(b + 20 * t);
+    for (int k = 0; k < 2; k++)
+        if (!h->xs[k] && hipStreamCreateWithFlags(&h->xs[k], hipStreamNonBlocking) != hipSuccess) { gab_set_error("gab_chain_run: stream creation failed"); return GAB_EDEVICE; }
+    for (int k = 0; k < 5; k++)
+        if (!h->xe[k] && hipEventCreateWithFlags(&h->xe[k], hipEventDisableTiming) != hipSuccess) { gab_set_error("gab_chain_run: event creation failed"); return GAB_EDEVICE; }
+    hipStream_t sB1 = h->xs[0], sB2 = h->xs[1];
+    // group A: the longest calls, up to ~6 % of the anchors (at least 64, at most 512 calls)
+    std::vector<int64_t> order((size_t)ncalls);
+    for (int64_t c = 0; c < ncalls; c++) order[(size_t)c] = c;
+    const size_t topn = (size_t)std::min<int64_t>(512, ncalls);
+    std::partial_sort(order.begin(), order.begin() + topn, order.end(), [&](int64_t a, int64_t c) { return hdr[a].n > hdr[c].n; });
+    std::vector<char> inA((size_t)ncalls, 0);
+    std::vector<ChainWork> wk[3];
+    int64_t accA = 0;
+    for (size_t k = 0; k < topn; k++) {
+        const int64_t c = order[k];
+        if (hdr[c].n == 0 || (k >= 64 && accA * 16 >= total)) break;
+        inA[(size_t)c] = 1; accA += hdr[c].n;
+        wk[0].push_back(chain_work_of(hdr[c], call_off[c]));
+    }
+    // the anchor index that splits the arrays in two halves
+    const int64_t mid = total / 2;
+    for (int64_t c = 0; c < ncalls; c++) {
+        if (inA[(size_t)c] || hdr[c].n == 0) continue;
+        wk[call_off[c] + hdr[c].n <= mid ? 1 : 2].push_back(chain_work_of(hdr[c], call_off[c]));
+    }
+    for (int g = 1; g < 3; g++) std::stable_sort(wk[g].begin(), wk[g].end(), [](const ChainWork &a, const ChainWork &c) { return a.n > c.n; });
+    const size_t nwt = wk[0].size() + wk[1].size() + wk[2].size();
+    const size_t o_ev = (sizeof(ChainWork) * nwt + 15) & ~(size_t)15;
+    int rc = h->work.reserve(o_ev + 16);
+    if (rc) return rc;
+    ChainWork *d_work[3];
+    d_work[0] = h->work.as<ChainWork>(); d_work[1] = d_work[0] + wk[0].size(); d_work[2] = d_work[1] + wk[1].size();
+    unsigned long long *d_ev = (unsigned long long *)(h->work.as<char>() + o_ev);
+    int32_t *d_gm = nullptr;
+    if (mode == GAB_CHAIN) {
+        if ((rc = h->gmarks.reserve(sizeof(int32_t) * t)) != GAB_OK) return rc;
+        d_gm = h->gmarks.as<int32_t>();
+    }
+    // ---- stream A
+    GAB_HIP(hipEventRecord(h->ev[0], sA));
+    GAB_HIP(hipMemsetAsync(d_ev, 0, 16, sA));
+    if (d_gm) GAB_HIP(hipMemsetAsync(d_gm, 0, sizeof(int32_t) * t, sA));              // vector::resize zero-fills targets
+    for (int g = 0; g < 3; g++)
+        if (!wk[g].empty()) GAB_HIP(hipMemcpyAsync(d_work[g], wk[g].data(), sizeof(ChainWork) * wk[g].size(), hipMemcpyHostToDevice, sA));
+    GAB_HIP(hipEventRecord(h->xe[0], sA));                                             // counters, marks and work lists are ready
+    for (const ChainWork &w : wk[0]) {
+        GAB_HIP(hipMemcpyAsync(dx + w.off, x + w.off, 8 * (size_t)w.n, hipMemcpyHostToDevice, sA));
+        GAB_HIP(hipMemcpyAsync(dy + w.off, y + w.off, 8 * (size_t)w.n, hipMemcpyHostToDevice, sA));
+    }
+    chain_launch(mode, sA, d_work[0], (unsigned)wk[0].size(), dx, dy, ds, dp, d_gm, d_ev);
+    GAB_HIP(hipEventRecord(h->xe[1], sA));                                             // A's results are final
+    // ---- stream B1: first half
+    GAB_HIP(hipStreamWaitEvent(sB1, h->xe[0], 0));
+    GAB_HIP(hipMemcpyAsync(dx, x, 8 * (size_t)mid, hipMemcpyHostToDevice, sB1));
+    GAB_HIP(hipMemcpyAsync(dy, y, 8 * (size_t)mid, hipMemcpyHostToDevice, sB1));
+    GAB_HIP(hipEventRecord(h->xe[2], sB1));                                            // first half is in
+    chain_launch(mode, sB1, d_work[1], (unsigned)wk[1].size(), dx, dy, ds, dp, d_gm, d_ev);
+    GAB_HIP(hipEventRecord(h->xe[4], sB1));                                            // B1's results are final
+    // ---- stream B2: second half right behind the first
+    GAB_HIP(hipStreamWaitEvent(sB2, h->xe[2], 0));
+    GAB_HIP(hipMemcpyAsync(dx + mid, x + mid, 8 * (t - (size_t)mid), hipMemcpyHostToDevice, sB2));
+    GAB_HIP(hipMemcpyAsync(dy + mid, y + mid, 8 * (t - (size_t)mid), hipMemcpyHostToDevice, sB2));
+    chain_launch(mode, sB2, d_work[2], (unsigned)wk[2].size(), dx, dy, ds, dp, d_gm, d_ev);
+    GAB_HIP(hipGetLastError());
+    // ---- results: each half once its own kernel and A's are done (a call of B2 may begin in the first half: its anchors
+    // below `mid` are copied with the second batch of results, so the first copy stops at the start of the first such call)
+    int64_t cut = mid;
+    for (const ChainWork &w : wk[2]) cut = std::min<int64_t>(cut, w.off);
+    GAB_HIP(hipStreamWaitEvent(sB1, h->xe[1], 0));
+    if (cut > 0) {
+        GAB_HIP(hipMemcpyAsync(score_out, ds, 4 * (size_t)cut, hipMemcpyDeviceToHost, sB1));
+        GAB_HIP(hipMemcpyAsync(parent_out, dp, 4 * (size_t)cut, hipMemcpyDeviceToHost, sB1));
+    }
+    GAB_HIP(hipStreamWaitEvent(sB2, h->xe[1], 0));
+    GAB_HIP(hipStreamWaitEvent(sB2, h->xe[4], 0));                                     // (calls of B1 that lie between `cut` and `mid`)
+    GAB_HIP(hipMemcpyAsync(score_out + cut, ds + cut, 4 * (t - (size_t)cut), hipMemcpyDeviceToHost, sB2));
+    GAB_HIP(hipMemcpyAsync(parent_out + cut, dp + cut, 4 * (t - (size_t)cut), hipMemcpyDeviceToHost, sB2));
+    // ---- join on stream A
+    GAB_HIP(hipEventRecord(h->xe[2], sB1));
+    GAB_HIP(hipEventRecord(h->xe[3], sB2));
+    GAB_HIP(hipStreamWaitEvent(sA, h->xe[2], 0));
+    GAB_HIP(hipStreamWaitEvent(sA, h->xe[3], 0));
+    GAB_HIP(hipEventRecord(h->ev[1], sA));
+    GAB_HIP(hipMemcpyAsync(h->h_evals, d_ev, sizeof(unsigned long long), hipMemcpyDeviceToHost, sA));
+    GAB_HIP(hipStreamSynchronize(sA));            // (the host work lists must outlive their copies)
     h->have_stats = true;
     return GAB_OK;
 }
@@ -1160,6 +1286,8 @@ extern "C" int gab_chain_run(gab_chain *h, int mode, const uint64_t *x, const ui
     int32_t *ds = (int32_t *)(b + 16 * t), *dp = (int32_t *)(b + 20 * t);
     hipStream_t s = nullptr;
     if ((rc = h->hs.get(&s)) != GAB_OK) return rc;
+    if (total >= ((int64_t)8 << 20) && ncalls >= 1024 && ncalls < (1ll << 31) && !getenv("GAB_CHAIN_NO_OVERLAP"))
+        return chain_run_overlapped(h, mode, x, y, call_off, hdr, ncalls, total, score_out, parent_out, s);
     GAB_HIP(hipMemcpyAsync(dx, x, 8 * t, hipMemcpyHostToDevice, s));
     GAB_HIP(hipMemcpyAsync(dy, y, 8 * t, hipMemcpyHostToDevice, s));
     rc = gab_chain_run_device(h, mode, dx, dy, call_off, hdr, ncalls, ds, dp, s);
@@ -1175,7 +1303,7 @@ extern "C" int gab_chain_reserve(gab_chain *h, int64_t max_anchors, int64_t max_
     GAB_CHECK(h, "gab_chain_reserve: NULL handle");
     GAB_CHECK(max_anchors >= 0 && max_calls >= 0 && max_calls < (1ll << 31), "gab_chain_reserve: size out of range");
     gab_device_guard g(h->device);
-    int rc = h->io.reserve(24 * (size_t)max_anchors + 64);
+    int rc = h->io.reserve(std::max<size_t>(24 * (size_t)max_anchors + 64, (size_t)4 << 20));      // (at least the 4 MB gab_warm_copy_engines moves)
     if (rc) return rc;
     if ((rc = h->gmarks.reserve(sizeof(int32_t) * (size_t)max_anchors + 64)) != GAB_OK) return rc;
     if ((rc = h->work.reserve(sizeof(ChainWork) * (size_t)max_calls + 64)) != GAB_OK) return rc;
@@ -1184,7 +1312,7 @@ extern "C" int gab_chain_reserve(gab_chain *h, int64_t max_anchors, int64_t max_
     GAB_HIP(hipMemsetAsync(h->io.p, 0, h->io.cap, s));
     GAB_HIP(hipMemsetAsync(h->gmarks.p, 0, h->gmarks.cap, s));
     GAB_HIP(hipStreamSynchronize(s));
-    return GAB_OK;
+    return gab_warm_copy_engines(s, h->io.p);
 }
 
 extern "C" int gab_chain_last_stats(gab_chain *h, int64_t *evals, float *kernel_ms) {

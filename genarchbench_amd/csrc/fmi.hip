@@ -1077,8 +1077,12 @@ extern "C" int gab_fmi_seed(gab_fmi *h, const uint8_t *enc, int32_t stride, cons
     hipStream_t s = nullptr;
     if ((rc = h->hs.get(&s)) != GAB_OK) return rc;
     char *b = h->io.as<char>();
-    GAB_HIP(hipMemcpyAsync(b, enc, eb, hipMemcpyHostToDevice, s));
-    GAB_HIP(hipMemcpyAsync(b + o_len, len, 4 * (size_t)nreads, hipMemcpyHostToDevice, s));
+    {   // the copies of one chunk at a time per GPU (gab_core.hip: the workers of a GPU must not copy in lockstep)
+        std::lock_guard<std::mutex> gate(gab_h2d_mutex(h->device));
+        GAB_HIP(hipMemcpyAsync(b, enc, eb, hipMemcpyHostToDevice, s));
+        GAB_HIP(hipMemcpyAsync(b + o_len, len, 4 * (size_t)nreads, hipMemcpyHostToDevice, s));
+        GAB_HIP(hipStreamSynchronize(s));
+    }
     const gab_smem *d_out = nullptr;
     int64_t n = 0;
     rc = gab_fmi_seed_device(h, (const uint8_t *)b, stride, (const int32_t *)(b + o_len), nreads, min_seed_len, &d_out,

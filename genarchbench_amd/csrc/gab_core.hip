@@ -2,6 +2,7 @@
 #include "gab_internal.h"
 #include <string.h>
 #include <stdlib.h>
+#include <mutex>
 
 static thread_local char g_err[512] = "";
 
@@ -35,6 +36,13 @@ int gab_check_device(int device) {
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) {
         gab_set_error("hipGetDeviceProperties(%d) failed", device);
         return GAB_EDEVICE;
+    }
+    if (const char *e = getenv("GAB_HIP_SCHEDULE")) {          // experiment knob: spin | yield | blocking (before the context exists)
+        static bool done = false;
+        if (!done) {
+            done = true;
+            (void)hipSetDeviceFlags(!strcmp(e, "spin") ? hipDeviceScheduleSpin : !strcmp(e, "yield") ? hipDeviceScheduleYield : hipDeviceScheduleBlockingSync);
+        }
     }
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
         gab_set_error("device %d is %s; this library is built for gfx950 only", device, prop.gcnArchName);
@@ -100,4 +108,31 @@ bool gab_is_pinned(const void *p) {
     hipPointerAttribute_t a;
     if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
     return a.type == hipMemoryTypeHost;
+}
+
+// ---- one host-to-device copy batch at a time per GPU ---------------------------------------------------------------
+// Several handles of one GPU (the drivers' queue workers) run their host-pointer entry points concurrently so that the
+// copy-in of one chunk overlaps the kernels of another.  Started together they fall into LOCKSTEP instead -- all copy at
+// once (each at a fraction of the link rate), then all compute at once -- and nothing overlaps (bsw-large through the C
+// driver, two workers: 96 ms; the same calls staggered: 65 ms).  The entry points therefore take this per-device lock around
+// "enqueue the H2D copies of my chunk and wait for them": copies go one chunk at a time at the full link rate while the
+// other workers' kernels run.
+static std::mutex g_h2d_mutex[64];
+std::mutex &gab_h2d_mutex(int device) { return g_h2d_mutex[device >= 0 && device < 64 ? device : 0]; }
+
+// The first host-to-device and the first device-to-host copy on a stream cost ~9 and ~8 ms (the copy queues behind a
+// stream are created on first use; measured in the bsw driver: 13 ms instead of 4.3 for the first 240 MB in, 8 ms instead
+// of 0.1 for the first 4 MB out).  The *_reserve entry points pay that before the region of interest: 4 MB each way
+// between page-locked memory and the handle's staging buffer (at least 4 MB by then).
+int gab_warm_copy_engines(hipStream_t s, void *dev) {
+    const size_t bytes = (size_t)4 << 20;
+    void *pinned = nullptr;
+    if (hipHostMalloc(&pinned, bytes, hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); return GAB_OK; }   // best effort
+    memset(pinned, 0, bytes);
+    hipError_t e = hipMemcpyAsync(dev, pinned, bytes, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(pinned, dev, bytes, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipHostFree(pinned);
+    if (e != hipSuccess) { gab_set_error("gab_warm_copy_engines: %s", hipGetErrorString(e)); return GAB_EDEVICE; }
+    return GAB_OK;
 }

@@ -1,7 +1,7 @@
 #!/bin/bash
 # The drop-in drivers' own region of interest on the LARGE inputs (what a user of the reference's harness sees: host
 # pointers in, host pointers out, PCIe both ways), next to the compiled reference on the box's host cores when oracle/_ref
-# travelled.  Run on the GPU box:  bash tools/profiling/driver_roi.sh [workers ...]  -> one line per run on stdout
+# travelled.  Run on the GPU box:  bash tests/driver_roi.sh [workers ...]  -> one line per run on stdout
 cd "$GRAFT_REPO_ROOT" || exit 1
 T=/tmp/gab_roi; mkdir -p $T
 python - <<'PY'
