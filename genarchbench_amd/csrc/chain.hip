@@ -1181,6 +1181,10 @@ static int chain_run_overlapped(gab_chain *h, int mode, const uint64_t *x, const
     for (int k = 0; k < 5; k++)
         if (!h->xe[k] && hipEventCreateWithFlags(&h->xe[k], hipEventDisableTiming) != hipSuccess) { gab_set_error("gab_chain_run: event creation failed"); return GAB_EDEVICE; }
     hipStream_t sB1 = h->xs[0], sB2 = h->xs[1];
+    const bool trace = getenv("GAB_CHAIN_TRACE") != nullptr;                          // diagnosis: a time line of the three streams on stderr
+    hipEvent_t tv[10] = {};
+    if (trace) for (auto &e : tv) (void)hipEventCreate(&e);
+    auto mark = [&](int k, hipStream_t st) { if (trace) (void)hipEventRecord(tv[k], st); };
     // group A: the longest calls, up to ~6 % of the anchors (at least 64, at most 512 calls)
     std::vector<int64_t> order((size_t)ncalls);
     for (int64_t c = 0; c < ncalls; c++) order[(size_t)c] = c;
@@ -1189,7 +1193,8 @@ static int chain_run_overlapped(gab_chain *h, int mode, const uint64_t *x, const
     std::vector<char> inA((size_t)ncalls, 0);
     std::vector<ChainWork> wk[3];
     int64_t accA = 0;
-    for (size_t k = 0; k < topn; k++) {
+    const int diag = getenv("GAB_CHAIN_DIAG") ? atoi(getenv("GAB_CHAIN_DIAG")) : 0;
+    for (size_t k = 0; k < topn && !(diag & 1); k++) {
         const int64_t c = order[k];
         if (hdr[c].n == 0 || (k >= 64 && accA * 16 >= total)) break;
         inA[(size_t)c] = 1; accA += hdr[c].n;
@@ -1216,6 +1221,7 @@ static int chain_run_overlapped(gab_chain *h, int mode, const uint64_t *x, const
     }
     // ---- stream A
     GAB_HIP(hipEventRecord(h->ev[0], sA));
+    mark(0, sA);
     GAB_HIP(hipMemsetAsync(d_ev, 0, 16, sA));
     if (d_gm) GAB_HIP(hipMemsetAsync(d_gm, 0, sizeof(int32_t) * t, sA));              // vector::resize zero-fills targets
     for (int g = 0; g < 3; g++)
@@ -1225,20 +1231,36 @@ static int chain_run_overlapped(gab_chain *h, int mode, const uint64_t *x, const
         GAB_HIP(hipMemcpyAsync(dx + w.off, x + w.off, 8 * (size_t)w.n, hipMemcpyHostToDevice, sA));
         GAB_HIP(hipMemcpyAsync(dy + w.off, y + w.off, 8 * (size_t)w.n, hipMemcpyHostToDevice, sA));
     }
+    mark(1, sA);
     chain_launch(mode, sA, d_work[0], (unsigned)wk[0].size(), dx, dy, ds, dp, d_gm, d_ev);
+    mark(2, sA);
     GAB_HIP(hipEventRecord(h->xe[1], sA));                                             // A's results are final
     // ---- stream B1: first half
     GAB_HIP(hipStreamWaitEvent(sB1, h->xe[0], 0));
     GAB_HIP(hipMemcpyAsync(dx, x, 8 * (size_t)mid, hipMemcpyHostToDevice, sB1));
     GAB_HIP(hipMemcpyAsync(dy, y, 8 * (size_t)mid, hipMemcpyHostToDevice, sB1));
     GAB_HIP(hipEventRecord(h->xe[2], sB1));                                            // first half is in
+    mark(3, sB1);
+    if (diag & 2) {
+        GAB_HIP(hipStreamWaitEvent(sB2, h->xe[2], 0));
+        GAB_HIP(hipMemcpyAsync(dx + mid, x + mid, 8 * (t - (size_t)mid), hipMemcpyHostToDevice, sB2));
+        GAB_HIP(hipMemcpyAsync(dy + mid, y + mid, 8 * (t - (size_t)mid), hipMemcpyHostToDevice, sB2));
+        GAB_HIP(hipEventRecord(h->xe[3], sB2));
+        GAB_HIP(hipStreamWaitEvent(sB1, h->xe[3], 0));
+    }
     chain_launch(mode, sB1, d_work[1], (unsigned)wk[1].size(), dx, dy, ds, dp, d_gm, d_ev);
+    mark(4, sB1);
     GAB_HIP(hipEventRecord(h->xe[4], sB1));                                            // B1's results are final
     // ---- stream B2: second half right behind the first
+    if (!(diag & 2)) {
     GAB_HIP(hipStreamWaitEvent(sB2, h->xe[2], 0));
     GAB_HIP(hipMemcpyAsync(dx + mid, x + mid, 8 * (t - (size_t)mid), hipMemcpyHostToDevice, sB2));
     GAB_HIP(hipMemcpyAsync(dy + mid, y + mid, 8 * (t - (size_t)mid), hipMemcpyHostToDevice, sB2));
+    }
+    if (diag & 4) GAB_HIP(hipStreamWaitEvent(sB2, h->xe[4], 0));
+    mark(5, sB2);
     chain_launch(mode, sB2, d_work[2], (unsigned)wk[2].size(), dx, dy, ds, dp, d_gm, d_ev);
+    mark(6, sB2);
     GAB_HIP(hipGetLastError());
     // ---- results: each half once its own kernel and A's are done (a call of B2 may begin in the first half: its anchors
     // below `mid` are copied with the second batch of results, so the first copy stops at the start of the first such call)
@@ -1254,6 +1276,7 @@ static int chain_run_overlapped(gab_chain *h, int mode, const uint64_t *x, const
     GAB_HIP(hipMemcpyAsync(score_out + cut, ds + cut, 4 * (t - (size_t)cut), hipMemcpyDeviceToHost, sB2));
     GAB_HIP(hipMemcpyAsync(parent_out + cut, dp + cut, 4 * (t - (size_t)cut), hipMemcpyDeviceToHost, sB2));
     // ---- join on stream A
+    mark(7, sB1); mark(8, sB2);
     GAB_HIP(hipEventRecord(h->xe[2], sB1));
     GAB_HIP(hipEventRecord(h->xe[3], sB2));
     GAB_HIP(hipStreamWaitEvent(sA, h->xe[2], 0));
@@ -1261,6 +1284,14 @@ static int chain_run_overlapped(gab_chain *h, int mode, const uint64_t *x, const
     GAB_HIP(hipEventRecord(h->ev[1], sA));
     GAB_HIP(hipMemcpyAsync(h->h_evals, d_ev, sizeof(unsigned long long), hipMemcpyDeviceToHost, sA));
     GAB_HIP(hipStreamSynchronize(sA));            // (the host work lists must outlive their copies)
+    if (trace) {
+        const char *nm[9] = {"start", "A copied", "A kernel done", "first half copied", "B1 kernel done", "second half copied", "B2 kernel done",
+                             "first results back", "all results back"};
+        fprintf(stderr, "[gab_chain_run] %zu + %zu + %zu calls, A = %lld anchors:", wk[0].size(), wk[1].size(), wk[2].size(), (long long)accA);
+        for (int k = 1; k < 9; k++) { float ms = 0; (void)hipEventElapsedTime(&ms, tv[0], tv[k]); fprintf(stderr, "  %s %.1f", nm[k], ms); }
+        fprintf(stderr, " ms\n");
+        for (auto &e : tv) (void)hipEventDestroy(e);
+    }
     h->have_stats = true;
     return GAB_OK;
 }

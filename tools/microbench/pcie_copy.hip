@@ -8,6 +8,17 @@
 #include <stdlib.h>
 #include <string.h>
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s failed: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
+// a kernel that copies through the host's address space (page-locked memory is mapped into the device's): 16 B per lane and step
+__global__ void shader_copy(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n16) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+// the same, in scattered pieces: piece p of `piece16` uint4 goes from src + perm[p] * piece16 to dst + perm[p] * piece16 (a gather in sorted order)
+__global__ void shader_copy_pieces(const uint4 *__restrict__ src, uint4 *__restrict__ dst, const unsigned *__restrict__ perm, size_t piece16, unsigned npieces) {
+    for (unsigned p = blockIdx.x; p < npieces; p += gridDim.x) {
+        const size_t o = (size_t)perm[p] * piece16;
+        for (size_t i = threadIdx.x; i < piece16; i += blockDim.x) dst[o + i] = src[o + i];
+    }
+}
 static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 int main() {
     const size_t MB = 1 << 20, bytes = 1024 * MB;
@@ -50,6 +61,42 @@ int main() {
         CK(hipStreamSynchronize(s0));
         char name[96]; snprintf(name, sizeof name, "H2D registered in %zu KiB pieces (%zu MiB)", piece >> 10, total >> 20);
         row(name, now() - t, (double)total);
+    }
+    // copies done by a kernel instead of the copy engine (registered memory, device pointer of the host range)
+    {
+        void *hp = nullptr, *hp2 = nullptr;
+        CK(hipHostGetDevicePointer(&hp, pageable, 0)); CK(hipHostGetDevicePointer(&hp2, pageable2, 0));
+        for (int grid : {64, 256, 1024, 4096}) {
+            char name[96];
+            CK(hipDeviceSynchronize()); t = now();
+            hipLaunchKernelGGL(shader_copy, dim3(grid), dim3(256), 0, s0, (const uint4 *)hp, (uint4 *)dev, bytes / 16);
+            CK(hipStreamSynchronize(s0));
+            snprintf(name, sizeof name, "kernel reads host memory, %d x 256 threads", grid); row(name, now() - t, bytes);
+            t = now();
+            hipLaunchKernelGGL(shader_copy, dim3(grid), dim3(256), 0, s0, (const uint4 *)dev, (uint4 *)hp2, bytes / 16);
+            CK(hipStreamSynchronize(s0));
+            snprintf(name, sizeof name, "kernel writes host memory, %d x 256 threads", grid); row(name, now() - t, bytes);
+        }
+        // pieces of 256 KiB in a shuffled order, host -> device
+        const size_t piece = 256 * 1024; const unsigned np = (unsigned)(bytes / piece);
+        unsigned *perm = (unsigned *)malloc(4 * np), *dperm = nullptr;
+        for (unsigned i = 0; i < np; i++) perm[i] = i;
+        for (unsigned i = np - 1; i > 0; i--) { unsigned j = (unsigned)((i * 2654435761u) % (i + 1)); unsigned v = perm[i]; perm[i] = perm[j]; perm[j] = v; }
+        CK(hipMalloc((void **)&dperm, 4 * np)); CK(hipMemcpy(dperm, perm, 4 * np, hipMemcpyHostToDevice));
+        for (int grid : {64, 256, 1024}) {
+            char name[96];
+            t = now();
+            hipLaunchKernelGGL(shader_copy_pieces, dim3(grid), dim3(256), 0, s0, (const uint4 *)hp, (uint4 *)dev, dperm, piece / 16, np);
+            CK(hipStreamSynchronize(s0));
+            snprintf(name, sizeof name, "kernel reads host memory in shuffled 256 KiB pieces, %d x 256 threads", grid); row(name, now() - t, bytes);
+        }
+        // both directions at once: kernel reads on s0, kernel writes on s1
+        t = now();
+        hipLaunchKernelGGL(shader_copy, dim3(256), dim3(256), 0, s0, (const uint4 *)hp, (uint4 *)dev, bytes / 16);
+        hipLaunchKernelGGL(shader_copy, dim3(256), dim3(256), 0, s1, (const uint4 *)dev2, (uint4 *)hp2, bytes / 16);
+        CK(hipStreamSynchronize(s0)); CK(hipStreamSynchronize(s1));
+        row("kernel reads + kernel writes host memory at once (2 GiB)", now() - t, 2.0 * bytes);
+        CK(hipFree(dperm)); free(perm);
     }
     t = now(); CK(hipHostUnregister(pageable)); CK(hipHostUnregister(pageable2)); row("hipHostUnregister x 2", now() - t, 2.0 * bytes);
     char *pinned = nullptr;
