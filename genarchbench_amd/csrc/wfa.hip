@@ -60,6 +60,16 @@ struct WfaCounters {
     unsigned long long work;          // wavefront cells computed + bases extended
 };
 
+// One-byte offsets for the first LDS tier: value + 10 in a byte (null = -10 -> 0), good for offsets up to 245.  An offset
+// never exceeds tlen + (number of score steps taken): extension stops at the padding and every later step adds at most 1.
+struct OffB {
+    uint8_t v;
+    OffB() = default;
+    __device__ __forceinline__ explicit OffB(int x) : v((uint8_t)(x + 10)) {}
+    __device__ __forceinline__ explicit operator int() const { return (int)v - 10; }
+};
+constexpr int kOffBMax = 245;
+
 // Per-score directory entry.  lo/hi (after reduction) and lob/hib (= lo_base/hi_base, as allocated) as in
 // affine_wavefront_t; the bases index the offset pool such that diagonal k lives at base + (k - lo) -- a reduction that
 // raises lo moves the bases along, so the computation never needs lob.
@@ -71,8 +81,12 @@ struct WfDir { int lo, hi, m, i, d, lob, hib; };
 // ADAPT adds one dword (lob | hib) resp. two ints.
 template <typename OffT, bool ADAPT>
 struct WfStore {
-    static constexpr int kDirInts = (sizeof(OffT) == 2 ? 3 : 5) + (ADAPT ? (sizeof(OffT) == 2 ? 1 : 2) : 0);
-    static constexpr bool kPacked = sizeof(OffT) == 2;
+    // the byte tier in complete mode: ONE dword per score -- lo | hi as signed bytes, baseM in 11 bits (0x7ff = none), two
+    // flags for "has I" / "has D": the I and D wavefronts always follow M in the pool (baseI = baseM + width, baseD behind
+    // it), so their bases need no storage.  384 bytes less per pair than three dwords at 48 scores, spent on the pool.
+    static constexpr bool kCompact = sizeof(OffT) == 1 && !ADAPT;
+    static constexpr int kDirInts = kCompact ? 1 : (sizeof(OffT) <= 2 ? 3 : 5) + (ADAPT ? (sizeof(OffT) <= 2 ? 1 : 2) : 0);
+    static constexpr bool kPacked = sizeof(OffT) <= 2;
     OffT *pool;           // offsets
     int *dir;             // kDirInts ints per score
     int pool_cap, dir_cap, used;
@@ -80,7 +94,14 @@ struct WfStore {
         WfDir w;
         if (s < 0) { w.lo = w.lob = 1; w.hi = w.hib = -1; w.m = w.i = w.d = kNone; return w; }
         const int *p = dir + kDirInts * s;
-        if (kPacked) {
+        if (kCompact) {
+            const uint32_t w0 = (uint32_t)p[0], mm = (w0 >> 16) & 0x7ffu;
+            w.lo = (int)(int8_t)(w0 & 0xffu); w.hi = (int)(int8_t)((w0 >> 8) & 0xffu);
+            const int width = w.hi - w.lo + 1;
+            w.m = mm == 0x7ffu ? kNone : (int)mm;
+            w.i = (w0 >> 27) & 1u ? (int)mm + width : kNone;
+            w.d = (w0 >> 28) & 1u ? (int)mm + (((w0 >> 27) & 1u) ? 2 * width : width) : kNone;
+        } else if (kPacked) {
             const uint32_t w0 = (uint32_t)p[0], w1 = (uint32_t)p[1], w2 = (uint32_t)p[2];
             w.lo = (int)(int16_t)(w0 & 0xffffu); w.hi = (int)w0 >> 16;
             const uint32_t m = w1 & 0xffffu, i = w1 >> 16, d = w2 & 0xffffu;
@@ -96,7 +117,10 @@ struct WfStore {
     // (called by one lane)
     __device__ __forceinline__ void put(int s, int lo, int hi, int m, int i, int d) {
         int *p = dir + kDirInts * s;
-        if (kPacked) {
+        if (kCompact) {
+            p[0] = (int)(((uint32_t)lo & 0xffu) | ((uint32_t)hi & 0xffu) << 8 | (m == kNone ? 0x7ffu : (uint32_t)m) << 16 |
+                         (i != kNone ? 1u << 27 : 0u) | (d != kNone ? 1u << 28 : 0u));
+        } else if (kPacked) {
             p[0] = (int)(((uint32_t)lo & 0xffffu) | (uint32_t)hi << 16);
             p[1] = (int)((m == kNone ? 0xffffu : (uint32_t)m) | (i == kNone ? 0xffffu : (uint32_t)i) << 16);
             p[2] = (int)(d == kNone ? 0xffffu : (uint32_t)d);
@@ -402,7 +426,7 @@ __global__ __launch_bounds__(256) void wfa_scatter(WfaIO io, uint32_t *cursors, 
 
 // ---- LDS kernel: one G-lane group per pair, 64 / G pairs per wave (= per workgroup) ----------------
 // dynamic LDS per group: [dir: 3 (4 if ADAPT) * dir_cap ints][P: seqp bytes][T: seqt bytes][pool: pool_cap int16]; the CIGAR is built over P/T
-template <int G, bool ADAPT>
+template <int G, bool ADAPT, typename OffT>
 __global__ __launch_bounds__(64) void wfa_lds(WfaIO io, WfaPen pen, const uint32_t *__restrict__ list, uint32_t count,
                                               int dir_cap, int seqp, int seqt, int pool_cap, uint32_t group_bytes,
                                               uint32_t *over_list, WfaCounters *ct, const uint8_t *__restrict__ steps) {
@@ -421,21 +445,21 @@ __global__ __launch_bounds__(64) void wfa_lds(WfaIO io, WfaPen pen, const uint32
         id = list ? list[b] : b;                             // no list: every pair of the batch is in this pass
         uint8_t *smem = smem_all + tab_bytes + (size_t)grp * group_bytes;
         int *dir = reinterpret_cast<int *>(smem);
-        uint8_t *P = smem + (size_t)dir_cap * 4 * WfStore<int16_t, ADAPT>::kDirInts;
+        uint8_t *P = smem + (size_t)dir_cap * 4 * WfStore<OffT, ADAPT>::kDirInts;
         uint8_t *T = P + seqp;
         // the backtrace never looks at the strings (affine_wavefronts_backtrace_matches__check only counts), so their
         // LDS region doubles as the CIGAR buffer: plen + tlen <= seqp + seqt bytes
         char *opsbuf = reinterpret_cast<char *>(P);
-        int16_t *pool = reinterpret_cast<int16_t *>(T + seqt);
+        OffT *pool = reinterpret_cast<OffT *>(T + seqt);
         const int plen = io.pat_len[id], tlen = io.txt_len[id];
         const char *gp = io.pat + io.pat_off[id], *gt = io.txt + io.txt_off[id];
         // four bytes per lane and step (the LDS copies are dword-aligned and have room to the next multiple of four)
         for (int i = 4 * lane; i < plen + kSeqPad; i += 4 * G) *reinterpret_cast<uint32_t *>(P + i) = seq_ld4(gp, i, plen, (uint32_t)'X');
         for (int i = 4 * lane; i < tlen + kSeqPad; i += 4 * G) *reinterpret_cast<uint32_t *>(T + i) = seq_ld4(gt, i, tlen, (uint32_t)'Y');
         __syncthreads();
-        WfStore<int16_t, ADAPT> st;
+        WfStore<OffT, ADAPT> st;
         st.pool = pool; st.dir = dir; st.pool_cap = pool_cap; st.dir_cap = dir_cap; st.used = 0;
-        ok = wfa_pair<int16_t, true, G, ADAPT>(st, pen, P, plen, T, tlen, io.ops + io.ops_off[id], opsbuf, io.ops_len + id, io.score + id, work,
+        ok = wfa_pair<OffT, true, G, ADAPT>(st, pen, P, plen, T, tlen, io.ops + io.ops_off[id], opsbuf, io.ops_len + id, io.score + id, work,
                                                smem_all);
         if (!ok && lane == 0) over_list[atomicAdd(&ct->n_over, 1u)] = id;
     }
@@ -465,6 +489,21 @@ __global__ __launch_bounds__(64) void wfa_global(WfaIO io, WfaPen pen, const uin
         if (lane == 0 && ok) atomicAdd(&ct->work, work);
         __syncthreads();
     }
+}
+
+using WfaLdsKernel = void (*)(WfaIO, WfaPen, const uint32_t *, uint32_t, int, int, int, int, uint32_t, uint32_t *, WfaCounters *, const uint8_t *);
+// the LDS kernel for G lanes per pair; byte_offsets: the one-byte history of the first tier
+WfaLdsKernel wfa_lds_kernel(int G, bool adaptive, bool byte_offsets) {
+#define GAB_WFA_K(g) (byte_offsets ? (adaptive ? wfa_lds<g, true, OffB> : wfa_lds<g, false, OffB>) : (adaptive ? wfa_lds<g, true, int16_t> : wfa_lds<g, false, int16_t>))
+    return G == 8 ? GAB_WFA_K(8) : G == 16 ? GAB_WFA_K(16) : G == 32 ? GAB_WFA_K(32) : GAB_WFA_K(64);
+#undef GAB_WFA_K
+}
+bool wfa_lds_allow_big() {
+    for (int G : {8, 16, 32, 64})
+        for (int a = 0; a < 2; a++)
+            for (int b = 0; b < 2; b++)
+                if (hipFuncSetAttribute((const void *)wfa_lds_kernel(G, a != 0, b != 0), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return false;
+    return true;
 }
 
 }  // namespace
@@ -510,14 +549,7 @@ extern "C" int gab_wfa_create_reduced(const gab_wfa_penalties *p, int min_wavefr
     for (int k = 0; k < 4; k++)
         if (hipEventCreate(&h->ev[k]) != hipSuccess) { gab_set_error("hipEventCreate failed"); delete h; return GAB_EDEVICE; }
     if (hipHostMalloc((void **)&h->h_ct, sizeof(WfaCounters)) != hipSuccess ||
-        hipFuncSetAttribute((const void *)wfa_lds<64, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
-        hipFuncSetAttribute((const void *)wfa_lds<16, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
-        hipFuncSetAttribute((const void *)wfa_lds<64, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
-        hipFuncSetAttribute((const void *)wfa_lds<16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
-        hipFuncSetAttribute((const void *)wfa_lds<8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
-        hipFuncSetAttribute((const void *)wfa_lds<8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
-        hipFuncSetAttribute((const void *)wfa_lds<32, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
-        hipFuncSetAttribute((const void *)wfa_lds<32, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+        !wfa_lds_allow_big()) {
         gab_set_error("gab_wfa_create: pinned allocation / LDS attribute failed"); delete h; return GAB_EDEVICE;
     }
     {   // scores that have a wavefront: M[s] exists iff M[s-x], M[s-o-e], I[s-e] or D[s-e] does; I[s] / D[s] iff M[s-o-e] or
@@ -591,29 +623,46 @@ extern "C" int gab_wfa_run_device(gab_wfa *h, const char *pat, int64_t pat_bytes
     int64_t requeued = 0;
 
     GAB_HIP(hipEventRecord(h->ev[1], s));
-    // LDS passes: (1) four pairs per wave with a 2 KB history each (scores up to ~35: the bulk of short-read pairs),
-    // (2) one pair per wave with 6 KB (12 KB measured 4 % slower: 5.43 vs 5.21 ms per 1 M pairs), (3) one pair per wave with
-    // 96 KB; whatever overflows goes to global memory
+    // LDS passes: (1) four pairs per wave, each with a history of ~1.9 K one-byte offsets (scores below 56: 99.4 % of the
+    // 151-bp pairs at 2 % error; int16 offsets in a 2 KB pool when the strings are too long for bytes), (2) one pair per
+    // wave with 12 KB of int16 offsets, (3) one pair per wave with 96 KB; whatever overflows goes to global memory
     if (n_big) hipLaunchKernelGGL(wfa_scatter, dim3(grid), dim3(256), 0, s, io, d_ct->cursors, l_a, l_big);
     uint32_t *cur = n_big ? l_a : nullptr, *nxt = l_b;      // nullptr: identity
     uint32_t cnt = n_lds;
     bool ev2 = false;
-    int pool_bytes[3] = {2 * 1024, 6 * 1024, 96 * 1024};
-    int dir_caps[3] = {48, 96, 640};
+    int pool_bytes[3] = {2 * 1024, 12 * 1024, 96 * 1024};
+    int dir_caps[3] = {48, 128, 640};
     int groups[3] = {16, 64, 64};
-    if (const char *e = getenv("GAB_WFA_TUNE")) sscanf(e, "%d,%d,%d,%d,%d,%d", &pool_bytes[0], &dir_caps[0], &pool_bytes[1], &dir_caps[1], &groups[0], &groups[1]);   // tuning runs only
+    int byte_tier = 1;
+    const bool tuned = getenv("GAB_WFA_TUNE") != nullptr;
+    if (tuned) sscanf(getenv("GAB_WFA_TUNE"), "%d,%d,%d,%d,%d,%d,%d", &pool_bytes[0], &dir_caps[0], &pool_bytes[1], &dir_caps[1], &groups[0], &groups[1], &byte_tier);   // tuning runs only
+    // First tier with one-byte offsets (OffB) when no offset can leave the byte's range: text length + one per score step.
+    // Its LDS is budgeted per pair: 2496 B = 10 032 B per wave of four pairs = 16 waves per CU, the measured optimum (the
+    // next allocation step down, 14 waves, costs 9 %; 18-20 waves with a smaller history re-queue too many pairs).  In
+    // complete mode the history a pair needs is a function of its score alone (lo / hi do not depend on the data), so the
+    // directory is sized to the scores the pool can hold: 56 scores, ~1.9 K offsets.
+    bool byte_ok = byte_tier != 0;
+    if (byte_ok && !(tuned && byte_tier > 1)) {
+        dir_caps[0] = h->adaptive ? 48 : 56;
+        const int room = 2496 - dir_caps[0] * (h->adaptive ? 16 : 4) - (seqp + seqt);
+        if (room < 1024) byte_ok = false;
+        byte_tier = std::min(room & ~15, 2032);
+    }
+    if (byte_ok && h->h_ct->max_tlen + dir_caps[0] + 2 > kOffBMax) byte_ok = false;
+    if (!byte_ok && !tuned) dir_caps[0] = 48;
     for (int pass = 0; pass < 3 && cnt; pass++) {
         const int dir_cap = dir_caps[pass], G = groups[pass];
-        const size_t per_group = (((size_t)dir_cap * (h->adaptive ? 16 : 12) + (size_t)(seqp + seqt) + pool_bytes[pass]) + 15) & ~(size_t)15;
+        const bool bytes = pass == 0 && byte_ok;
+        if (bytes) pool_bytes[0] = std::min(byte_tier, 2046);
+        const size_t per_group = (((size_t)dir_cap * (h->adaptive ? 16 : bytes ? 4 : 12) + (size_t)(seqp + seqt) + pool_bytes[pass]) + 15) & ~(size_t)15;
         const size_t lds = per_group * (64 / G) + (((size_t)dir_cap + 15) & ~(size_t)15);
         if (lds > 160 * 1024 - 512) continue;            // sequences too long for this pool: let the next stage take them
         h->h_ct->n_over = 0;
         GAB_HIP(hipMemsetAsync(&d_ct->n_over, 0, 4, s));
         const unsigned blocks = (cnt + (64 / G) - 1) / (64 / G);
-        auto kern = G == 16 ? (h->adaptive ? wfa_lds<16, true> : wfa_lds<16, false>) : G == 8 ? (h->adaptive ? wfa_lds<8, true> : wfa_lds<8, false>)
-                    : G == 32 ? (h->adaptive ? wfa_lds<32, true> : wfa_lds<32, false>) : (h->adaptive ? wfa_lds<64, true> : wfa_lds<64, false>);
+        WfaLdsKernel kern = wfa_lds_kernel(G, h->adaptive, bytes);
         hipLaunchKernelGGL(kern, dim3(blocks), dim3(64), lds, s, io, h->pen, cur, cnt, dir_cap, seqp, seqt,
-                           pool_bytes[pass] / 2, (uint32_t)per_group, nxt, d_ct, h->steps.as<uint8_t>());
+                           pool_bytes[pass] / (bytes ? 1 : 2), (uint32_t)per_group, nxt, d_ct, h->steps.as<uint8_t>());
         GAB_HIP(hipGetLastError());
         if (!ev2) { GAB_HIP(hipEventRecord(h->ev[2], s)); ev2 = true; }
         GAB_HIP(hipMemcpyAsync(h->h_ct, d_ct, sizeof(WfaCounters), hipMemcpyDeviceToHost, s));
