@@ -70,6 +70,21 @@ struct OffB {
 };
 constexpr int kOffBMax = 245;
 
+// The work counter is statistics, but 250 000 waves of a 3 ms launch adding to ONE address serialise in L2 (~8 ns per
+// atomic = 2 ms): the waves add to one of 256 slots, 128 bytes apart, behind the counters; wfa_sum_work folds them.
+constexpr int kWorkSlots = 256, kWorkSlotStride = 16;           // in unsigned long long
+constexpr size_t kCountersBytes = 256, kSlotsBytes = (size_t)kWorkSlots * kWorkSlotStride * 8;
+__device__ __forceinline__ unsigned long long *wfa_work_slot(WfaCounters *ct) {
+    return reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(ct) + kCountersBytes) + (blockIdx.x & (kWorkSlots - 1)) * kWorkSlotStride;
+}
+__global__ __launch_bounds__(256) void wfa_sum_work(WfaCounters *ct) {
+    unsigned long long *slot = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(ct) + kCountersBytes) + threadIdx.x * kWorkSlotStride;
+    unsigned long long v = *slot;
+    *slot = 0;
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if ((threadIdx.x & 63) == 0 && v) atomicAdd(&ct->work, v);
+}
+
 // Per-score directory entry.  lo/hi (after reduction) and lob/hib (= lo_base/hi_base, as allocated) as in
 // affine_wavefront_t; the bases index the offset pool such that diagonal k lives at base + (k - lo) -- a reduction that
 // raises lo moves the bases along, so the computation never needs lob.
@@ -407,7 +422,15 @@ __global__ __launch_bounds__(256) void wfa_classify(WfaIO io, WfaCounters *ct) {
         mp = max(mp, __shfl_xor(mp, o)); mt = max(mt, __shfl_xor(mt, o));
         n_lds += __shfl_xor(n_lds, o); n_big += __shfl_xor(n_big, o);
     }
-    if ((threadIdx.x & 63) == 0) {
+    // one set of atomics per workgroup: they all hit the same four addresses and serialise in L2 (~8 ns each; 4096 waves
+    // x 4 were 0.13 of this kernel's 0.15 ms)
+    __shared__ int s_mp[4], s_mt[4];
+    __shared__ uint32_t s_nl[4], s_nb[4];
+    const int wv = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { s_mp[wv] = mp; s_mt[wv] = mt; s_nl[wv] = n_lds; s_nb[wv] = n_big; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < 4; k++) { mp = max(mp, s_mp[k]); mt = max(mt, s_mt[k]); n_lds += s_nl[k]; n_big += s_nb[k]; }
         atomicMax(&ct->max_plen, mp); atomicMax(&ct->max_tlen, mt);
         if (n_lds) atomicAdd(&ct->n_lds, n_lds);
         if (n_big) atomicAdd(&ct->n_big, n_big);
@@ -465,7 +488,160 @@ __global__ __launch_bounds__(64) void wfa_lds(WfaIO io, WfaPen pen, const uint32
     }
     if (!have || !ok) work = 0;
     for (int o = 32; o > 0; o >>= 1) work += __shfl_xor(work, o);
-    if (threadIdx.x == 0 && work) atomicAdd(&ct->work, work);
+    if (threadIdx.x == 0 && work) atomicAdd(wfa_work_slot(ct), work);
+}
+
+
+// ---- complete mode, first tier: the directory as a table of the penalties ------------------------------------------
+// Without the adaptive reduction nothing in a pair's directory depends on the data: whether M / I / D of a score exist,
+// their [lo, hi] (min / max of the sources' -1 / +1) and where they land in the pool (allocation in score order) follow
+// from the penalties alone.  gab_wfa_create lists one WfRow per score that has a wavefront, with the resolved facts of
+// its three source scores; the kernel then needs no directory in LDS (the room goes to the offset pool), no look-ups and
+// no decoding: all groups of a wave walk the rows in lockstep, so the row index is wave-uniform and the row arrives by
+// scalar loads.  A missing source is an empty range (lo = 1, hi = -1): every read of it is out of range = null.
+struct WfRow {
+    int score, lo, hi, bM, bI, bD, used_end, has_gap;     // bI / bD valid iff has_gap (I and D exist at the same scores)
+    int ms_m, ms_lo, ms_hi;                               // M[score - x]
+    int mg_m, mg_lo, mg_hi;                               // M[score - o - e]
+    int ie_i, ie_d, ie_lo, ie_hi;                         // I / D[score - e]
+    int r_ms, r_mg, r_ie;                                 // rows of the three source scores (0 when there is none)
+    int pad[3];
+};
+static_assert(sizeof(WfRow) == 96, "WfRow is read as dwords");
+
+template <int G>
+__device__ bool wfa_pair_static(OffB *pool, int pool_cap, const WfRow *__restrict__ rows, int nrows, const WfaPen pen,
+                                const uint8_t *P, int plen, const uint8_t *T, int tlen, char *ops_global, char *ops,
+                                int32_t *ops_len_out, int32_t *score_out, unsigned long long &work) {
+    const int lane = threadIdx.x & (G - 1);
+    const int ak = tlen - plen;
+    if (pool_cap < 1 || nrows < 1) return false;
+    if (lane == 0) pool[0] = OffB(0);
+    __syncthreads();
+    auto at = [&](int base, int lo, int hi, int k) { return (lo <= k && k <= hi) ? (int)pool[base + (k - lo)] : kNull; };
+    int r = 0;
+    for (;;) {
+        const WfRow &c = rows[__builtin_amdgcn_readfirstlane(r)];
+        // ---- extend every diagonal of M[score]
+        for (int k = c.lo + lane; k <= c.hi; k += G) {
+            int o = (int)pool[c.bM + (k - c.lo)];
+            int v = o - k, h = o;
+            for (;;) {
+                if (v >= 0 && v <= plen && h >= 0 && h <= tlen) {
+                    // sixteen bases per step (the 'X' / 'Y' padding behind the strings never matches)
+                    const uint64_t d8 = lds_ld8(P, v) ^ lds_ld8(T, h), e8 = lds_ld8(P, v + 8) ^ lds_ld8(T, h + 8);
+                    if ((d8 | e8) == 0) { o += 16; v += 16; h += 16; work += 16; continue; }
+                    const int c8 = d8 ? __builtin_ctzll(d8) >> 3 : 8 + (__builtin_ctzll(e8) >> 3);
+                    o += c8; work += c8;
+                }
+                break;                                          // outside the strings 'X' meets 'Y': no match
+            }
+            pool[c.bM + (k - c.lo)] = OffB(o);
+        }
+        __syncthreads();
+        if (c.lo <= ak && ak <= c.hi && (int)pool[c.bM + (ak - c.lo)] >= tlen) break;
+        // ---- next wavefront
+        r++;
+        if (r >= nrows) return false;
+        const WfRow &n = rows[__builtin_amdgcn_readfirstlane(r)];
+        if (n.used_end > pool_cap) return false;
+        for (int k = n.lo + lane; k <= n.hi; k += G) {
+            int best = (n.ms_lo <= k && k <= n.ms_hi) ? (int)pool[n.ms_m + (k - n.ms_lo)] + 1 : kNull;
+            if (n.has_gap) {
+                const int ins = max(at(n.mg_m, n.mg_lo, n.mg_hi, k - 1), at(n.ie_i, n.ie_lo, n.ie_hi, k - 1)) + 1;
+                const int del = max(at(n.mg_m, n.mg_lo, n.mg_hi, k + 1), at(n.ie_d, n.ie_lo, n.ie_hi, k + 1));
+                pool[n.bI + (k - n.lo)] = OffB(ins);
+                pool[n.bD + (k - n.lo)] = OffB(del);
+                best = max(best, max(ins, del));
+            }
+            pool[n.bM + (k - n.lo)] = OffB(best);
+        }
+        work += (lane == 0) ? (unsigned)(n.hi - n.lo + 1) : 0u;
+        __syncthreads();
+    }
+
+    // ---- backtrace: as in wfa_pair, the directory entries of s - o - e, s - e, s - x being the source fields of row(s)
+    const int cap = plen + tlen;
+    int pos = cap - 1;
+    int k = ak;
+    const int x = pen.x, oe = pen.o + pen.e, e = pen.e;
+    const int score = rows[r].score;
+    {
+        int s = score;
+        int offset = (int)pool[rows[r].bM + (k - rows[r].lo)];
+        int type = 0;                                           // 0 = M, 1 = I, 2 = D
+        auto valid_loc = [&](int kk, int oo) { return oo - kk > 0 && oo - kk <= plen && oo > 0 && oo <= tlen; };
+        bool valid = valid_loc(k, offset);
+        int v = offset - k, h = offset;
+        auto put = [&](char ch) { if (lane == 0) ops[pos] = ch; pos--; };
+        auto put_run = [&](char ch, int cnt) {
+            for (int i = lane; i < cnt; i += G) ops[pos - i] = ch;
+            pos -= cnt > 0 ? cnt : 0;
+        };
+        auto in = [&](int lo, int hi, int kk) { return lo <= kk && kk <= hi; };
+        while (v > 0 && h > 0 && s > 0) {
+            if (!valid) {
+                valid = valid_loc(k, offset);
+                if (valid) {
+                    if (k < ak) put_run('I', ak - k);
+                    else if (k > ak) put_run('D', k - ak);
+                }
+            }
+            const WfRow w = rows[r];
+            const int del_ext = type == 1 ? kNull : at(w.ie_d, w.ie_lo, w.ie_hi, k + 1);
+            const int del_open = type == 1 ? kNull : at(w.mg_m, w.mg_lo, w.mg_hi, k + 1);
+            const bool ie_ok = in(w.ie_lo, w.ie_hi, k - 1), io_ok = in(w.mg_lo, w.mg_hi, k - 1), mm_ok = in(w.ms_lo, w.ms_hi, k);
+            const int ins_ext = (type == 2 || !ie_ok) ? kNull : (int)pool[w.ie_i + (k - 1 - w.ie_lo)] + 1;
+            const int ins_open = (type == 2 || !io_ok) ? kNull : (int)pool[w.mg_m + (k - 1 - w.mg_lo)] + 1;
+            const int misms = (type != 0 || !mm_ok) ? kNull : (int)pool[w.ms_m + (k - w.ms_lo)] + 1;
+            const int max_all = max(misms, max(max(ins_ext, ins_open), max(del_ext, del_open)));
+            if (type == 0) { put_run('M', offset - max_all); offset = max_all; }
+            if (max_all == del_ext) { if (valid) put('D'); s -= e; r = w.r_ie; k++; type = 2; }
+            else if (max_all == del_open) { if (valid) put('D'); s -= oe; r = w.r_mg; k++; type = 0; }
+            else if (max_all == ins_ext) { if (valid) put('I'); s -= e; r = w.r_ie; k--; offset--; type = 1; }
+            else if (max_all == ins_open) { if (valid) put('I'); s -= oe; r = w.r_mg; k--; offset--; type = 0; }
+            else { if (valid) put('X'); s -= x; r = w.r_ms; offset--; }
+            v = offset - k; h = offset;
+        }
+        if (s == 0) put_run('M', offset);
+        else { put_run('D', v); put_run('I', h); }
+    }
+    pos++;
+    const int nops = cap - pos;
+    __syncthreads();
+    for (int i = lane; i < nops; i += G) ops_global[i] = ops[pos + i];
+    if (lane == 0) { *ops_len_out = nops; *score_out = score; }
+    return true;
+}
+
+// dynamic LDS per group: [P: seqp bytes][T: seqt bytes][pool: pool_cap bytes]; the CIGAR is built over P/T
+template <int G>
+__global__ __launch_bounds__(64) void wfa_lds_static(WfaIO io, WfaPen pen, const uint32_t *__restrict__ list, uint32_t count,
+                                                     int seqp, int seqt, int pool_cap, uint32_t group_bytes, uint32_t *over_list,
+                                                     WfaCounters *ct, const WfRow *__restrict__ rows, int nrows) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem_all[];
+    constexpr int kGroups = 64 / G;
+    const int grp = threadIdx.x / G, lane = threadIdx.x & (G - 1);
+    const uint32_t b = blockIdx.x * kGroups + grp;
+    unsigned long long work = 0;
+    bool ok = true, have = b < count;
+    uint32_t id = 0;
+    if (have) {
+        id = list ? list[b] : b;
+        uint8_t *P = smem_all + (size_t)grp * group_bytes, *T = P + seqp;
+        OffB *pool = reinterpret_cast<OffB *>(T + seqt);
+        const int plen = io.pat_len[id], tlen = io.txt_len[id];
+        const char *gp = io.pat + io.pat_off[id], *gt = io.txt + io.txt_off[id];
+        for (int i = 4 * lane; i < plen + kSeqPad; i += 4 * G) *reinterpret_cast<uint32_t *>(P + i) = seq_ld4(gp, i, plen, (uint32_t)'X');
+        for (int i = 4 * lane; i < tlen + kSeqPad; i += 4 * G) *reinterpret_cast<uint32_t *>(T + i) = seq_ld4(gt, i, tlen, (uint32_t)'Y');
+        __syncthreads();
+        ok = wfa_pair_static<G>(pool, pool_cap, rows, nrows, pen, P, plen, T, tlen, io.ops + io.ops_off[id], reinterpret_cast<char *>(P),
+                                io.ops_len + id, io.score + id, work);
+        if (!ok && lane == 0) over_list[atomicAdd(&ct->n_over, 1u)] = id;
+    }
+    if (!have || !ok) work = 0;
+    for (int o = 32; o > 0; o >>= 1) work += __shfl_xor(work, o);
+    if (threadIdx.x == 0 && work) atomicAdd(wfa_work_slot(ct), work);
 }
 
 // ---- global kernel: int32 history in a scratch slab, any length ------------------------------
@@ -486,7 +662,7 @@ __global__ __launch_bounds__(64) void wfa_global(WfaIO io, WfaPen pen, const uin
                                                  io.ops + io.ops_off[id], nullptr, io.ops_len + id, io.score + id, work);
         if (!ok && lane == 0) over_list[atomicAdd(&ct->n_over, 1u)] = id;
         for (int o = 32; o > 0; o >>= 1) work += __shfl_xor(work, o);
-        if (lane == 0 && ok) atomicAdd(&ct->work, work);
+        if (lane == 0 && ok) atomicAdd(wfa_work_slot(ct), work);
         __syncthreads();
     }
 }
@@ -515,6 +691,8 @@ struct gab_wfa {
     WfaPen pen;
     bool adaptive = false;  // affine_wavefronts_new_reduced instead of _new_complete
     gab_devbuf ws;          // counters | 3 id lists
+    gab_devbuf rows;        // complete mode: the directory of every pair as a function of the penalties (WfRow per score with a wavefront)
+    int nrows = 0;
     gab_devbuf steps;       // per score: distance to the next score that has a wavefront (a function of the penalties)
     gab_devbuf scratch;     // global-kernel history
     gab_devbuf io;          // staging for the host-pointer entry point
@@ -571,6 +749,46 @@ extern "C" int gab_wfa_create_reduced(const gab_wfa_penalties *p, int min_wavefr
             gab_set_error("gab_wfa_create: score-step table upload failed"); gab_wfa_destroy(h); return GAB_EDEVICE;
         }
     }
+    if (!h->adaptive) {
+        // the same DP with ranges and pool positions: what wfa_pair would write into its directory, pair after pair
+        // (affine_wavefront_align.c:85-106 compute_limits, :56-84 allocate_wavefronts, :283-321)
+        constexpr int kMaxRows = 240, kMaxScore = 1024;
+        struct Ent { bool m = false, g = false; int lo = 1, hi = -1, bm = 0, bi = 0, bd = 0, row = 0; };
+        std::vector<Ent> ent(kMaxScore + 1);
+        std::vector<WfRow> rows;
+        const int x = h->pen.x, oe = h->pen.o + h->pen.e, e = h->pen.e;
+        ent[0].m = true; ent[0].lo = ent[0].hi = 0; ent[0].bm = 0; ent[0].row = 0;
+        WfRow r0; memset(&r0, 0, sizeof r0);
+        r0.used_end = 1; r0.ms_lo = r0.mg_lo = r0.ie_lo = 1; r0.ms_hi = r0.mg_hi = r0.ie_hi = -1;
+        rows.push_back(r0);
+        int used = 1;
+        const Ent none;
+        for (int sc = 1; sc <= kMaxScore && (int)rows.size() < kMaxRows; sc++) {
+            const Ent &ms = sc >= x ? ent[sc - x] : none, &mg = sc >= oe ? ent[sc - oe] : none, &ie = sc >= e ? ent[sc - e] : none;
+            const bool n_ms = !ms.m, n_mg = !mg.m, n_ie = !ie.g;
+            if (n_ms && n_mg && n_ie) continue;
+            Ent &t = ent[sc];
+            t.lo = std::min(std::min(n_ms ? 1 : ms.lo, n_mg ? 1 : mg.lo), n_ie ? 1 : ie.lo) - 1;
+            t.hi = std::max(std::max(n_ms ? -1 : ms.hi, n_mg ? -1 : mg.hi), n_ie ? -1 : ie.hi) + 1;
+            const int width = t.hi - t.lo + 1;
+            t.m = true; t.g = !n_mg || !n_ie;
+            t.bm = used; t.bi = used + width; t.bd = used + 2 * width;
+            used += width * (t.g ? 3 : 1);
+            if (used > 60000 || t.lo < -120 || t.hi > 120) break;
+            t.row = (int)rows.size();
+            WfRow r; memset(&r, 0, sizeof r);
+            r.score = sc; r.lo = t.lo; r.hi = t.hi; r.bM = t.bm; r.bI = t.bi; r.bD = t.bd; r.used_end = used; r.has_gap = t.g;
+            r.ms_m = n_ms ? 0 : ms.bm; r.ms_lo = n_ms ? 1 : ms.lo; r.ms_hi = n_ms ? -1 : ms.hi; r.r_ms = n_ms ? 0 : ms.row;
+            r.mg_m = n_mg ? 0 : mg.bm; r.mg_lo = n_mg ? 1 : mg.lo; r.mg_hi = n_mg ? -1 : mg.hi; r.r_mg = n_mg ? 0 : mg.row;
+            r.ie_i = n_ie ? 0 : ie.bi; r.ie_d = n_ie ? 0 : ie.bd; r.ie_lo = n_ie ? 1 : ie.lo; r.ie_hi = n_ie ? -1 : ie.hi; r.r_ie = n_ie ? 0 : ie.row;
+            rows.push_back(r);
+        }
+        h->nrows = (int)rows.size();
+        if (h->rows.reserve(sizeof(WfRow) * rows.size()) != GAB_OK ||
+            hipMemcpy(h->rows.p, rows.data(), sizeof(WfRow) * rows.size(), hipMemcpyHostToDevice) != hipSuccess) {
+            gab_set_error("gab_wfa_create: directory table upload failed"); gab_wfa_destroy(h); return GAB_EDEVICE;
+        }
+    }
     *out = h;
     return GAB_OK;
 }
@@ -578,7 +796,7 @@ extern "C" int gab_wfa_create_reduced(const gab_wfa_penalties *p, int min_wavefr
 extern "C" void gab_wfa_destroy(gab_wfa *h) {
     if (!h) return;
     gab_device_guard g(h->device);
-    h->ws.release(); h->steps.release(); h->scratch.release(); h->io.release(); h->hs.release();
+    h->ws.release(); h->steps.release(); h->rows.release(); h->scratch.release(); h->io.release(); h->hs.release();
     for (int k = 0; k < 4; k++) if (h->ev[k]) (void)hipEventDestroy(h->ev[k]);
     if (h->h_ct) (void)hipHostFree(h->h_ct);
     delete h;
@@ -596,7 +814,7 @@ extern "C" int gab_wfa_run_device(gab_wfa *h, const char *pat, int64_t pat_bytes
               "gab_wfa_run_device: NULL buffer");
     gab_device_guard g(h->device);
     hipStream_t s = (hipStream_t)stream_;
-    const size_t o_l0 = 256, o_l1 = o_l0 + 4 * (size_t)n, o_l2 = o_l1 + 4 * (size_t)n;
+    const size_t o_l0 = kCountersBytes + kSlotsBytes, o_l1 = o_l0 + 4 * (size_t)n, o_l2 = o_l1 + 4 * (size_t)n;
     int rc = h->ws.reserve(o_l2 + 4 * (size_t)n);
     if (rc) return rc;
     char *base = h->ws.as<char>();
@@ -608,7 +826,8 @@ extern "C" int gab_wfa_run_device(gab_wfa *h, const char *pat, int64_t pat_bytes
     memset(h->h_ct, 0, sizeof(WfaCounters));
     h->h_ct->first_bad = 0x7fffffff;
     GAB_HIP(hipMemcpyAsync(d_ct, h->h_ct, sizeof(WfaCounters), hipMemcpyHostToDevice, s));
-    const int grid = (int)std::min<int64_t>(gab_ceil_div(n, 256), 1024);
+    GAB_HIP(hipMemsetAsync(base + kCountersBytes, 0, kSlotsBytes, s));
+    const int grid = (int)std::min<int64_t>(gab_ceil_div(n, 256), 512);
     hipLaunchKernelGGL(wfa_classify, dim3(grid), dim3(256), 0, s, io, d_ct);
     GAB_HIP(hipMemcpyAsync(h->h_ct, d_ct, sizeof(WfaCounters), hipMemcpyDeviceToHost, s));
     GAB_HIP(hipStreamSynchronize(s));
@@ -650,8 +869,29 @@ extern "C" int gab_wfa_run_device(gab_wfa *h, const char *pat, int64_t pat_bytes
     }
     if (byte_ok && h->h_ct->max_tlen + dir_caps[0] + 2 > kOffBMax) byte_ok = false;
     if (!byte_ok && !tuned) dir_caps[0] = 48;
+    // complete mode: the first tier takes its directory from the penalties' table (wfa_pair_static) -- no directory in LDS
+    const int static_rows = std::min(h->nrows, kOffBMax - 2 - h->h_ct->max_tlen);
+    const int static_pool = std::min(2496 - (seqp + seqt), 4080) & ~15;
+    const bool use_static = !h->adaptive && byte_tier != 0 && !getenv("GAB_WFA_NO_STATIC") && groups[0] == 16 && static_rows >= 16 && static_pool >= 1024;
     for (int pass = 0; pass < 3 && cnt; pass++) {
         const int dir_cap = dir_caps[pass], G = groups[pass];
+        if (pass == 0 && use_static) {
+            const size_t per_group = (size_t)(seqp + seqt) + static_pool;
+            h->h_ct->n_over = 0;
+            GAB_HIP(hipMemsetAsync(&d_ct->n_over, 0, 4, s));
+            hipLaunchKernelGGL(wfa_lds_static<16>, dim3((cnt + 3) / 4), dim3(64), per_group * 4, s, io, h->pen, cur, cnt, seqp, seqt, static_pool,
+                               (uint32_t)per_group, nxt, d_ct, h->rows.as<WfRow>(), static_rows);
+            GAB_HIP(hipGetLastError());
+            GAB_HIP(hipEventRecord(h->ev[2], s)); ev2 = true;
+            hipLaunchKernelGGL(wfa_sum_work, dim3(1), dim3(kWorkSlots), 0, s, d_ct);
+            GAB_HIP(hipMemcpyAsync(h->h_ct, d_ct, sizeof(WfaCounters), hipMemcpyDeviceToHost, s));
+            GAB_HIP(hipStreamSynchronize(s));
+            cnt = h->h_ct->n_over;
+            requeued += cnt;
+            if (cur) std::swap(cur, nxt);
+            else { cur = nxt; nxt = l_a; }
+            continue;
+        }
         const bool bytes = pass == 0 && byte_ok;
         if (bytes) pool_bytes[0] = std::min(byte_tier, 2046);
         const size_t per_group = (((size_t)dir_cap * (h->adaptive ? 16 : bytes ? 4 : 12) + (size_t)(seqp + seqt) + pool_bytes[pass]) + 15) & ~(size_t)15;
@@ -665,6 +905,7 @@ extern "C" int gab_wfa_run_device(gab_wfa *h, const char *pat, int64_t pat_bytes
                            pool_bytes[pass] / (bytes ? 1 : 2), (uint32_t)per_group, nxt, d_ct, h->steps.as<uint8_t>());
         GAB_HIP(hipGetLastError());
         if (!ev2) { GAB_HIP(hipEventRecord(h->ev[2], s)); ev2 = true; }
+        hipLaunchKernelGGL(wfa_sum_work, dim3(1), dim3(kWorkSlots), 0, s, d_ct);
         GAB_HIP(hipMemcpyAsync(h->h_ct, d_ct, sizeof(WfaCounters), hipMemcpyDeviceToHost, s));
         GAB_HIP(hipStreamSynchronize(s));
         cnt = h->h_ct->n_over;
@@ -694,6 +935,7 @@ extern "C" int gab_wfa_run_device(gab_wfa *h, const char *pat, int64_t pat_bytes
             hipLaunchKernelGGL(h->adaptive ? wfa_global<true> : wfa_global<false>, dim3(blocks), dim3(64), 0, s, io, h->pen, list, c, h->scratch.as<int32_t>(),
                                per_block, (int)dir_cap, (int)pool_cap, spill, d_ct);
             GAB_HIP(hipGetLastError());
+            hipLaunchKernelGGL(wfa_sum_work, dim3(1), dim3(kWorkSlots), 0, s, d_ct);
             GAB_HIP(hipMemcpyAsync(h->h_ct, d_ct, sizeof(WfaCounters), hipMemcpyDeviceToHost, s));
             GAB_HIP(hipStreamSynchronize(s));
             c = h->h_ct->n_over;

@@ -73,6 +73,43 @@ def test_long_sequences_global_path(eng):
     assert eng.last_stats()["requeued"] >= 1
 
 
+def _mutated(rng, n, err):
+    p = rng.choice(np.frombuffer(b"ACGT", np.uint8), n).tobytes()
+    t = bytearray()
+    for c in p:
+        r = rng.random()
+        if r < err / 3: continue
+        if r < 2 * err / 3: t.append(b"ACGT"[int(rng.integers(0, 4))])
+        t.append(c if r > err else b"ACGT"[int(rng.integers(0, 4))])
+    return p, bytes(t)
+
+
+@pytest.mark.parametrize("tmax,pen,red", [(187, (4, 6, 2), None), (188, (4, 6, 2), None), (187, (1, 1, 1), None), (187, (2, 3, 1), None),
+                                          (195, (4, 6, 2), (10, 50)), (196, (4, 6, 2), (10, 50))])
+def test_one_byte_history_limits(tmax, pen, red):
+    """the first tier keeps offsets as one byte (value + 10) when max text length + its score cap + 2 <= 245 (187 in
+    complete mode, 195 in adaptive mode) and as int16 above: batches on both sides of the switch, with texts at the
+    limit, scores on both sides of the tier's cap and offsets that run past the end of the text (+1 per score step on
+    the diagonals beyond the last one), under penalty sets that visit every score"""
+    from genarchbench_amd.wfa import AffineWavefronts
+    rng = np.random.default_rng(tmax)
+    pats, txts = [], []
+    while len(pats) < 3000:
+        n = int(rng.integers(tmax - 25, tmax + 1))
+        p, t = _mutated(rng, n, float(rng.choice([0.0, 0.01, 0.03, 0.06, 0.12])))
+        if len(t) > tmax: t = t[:tmax]
+        pats.append(p); txts.append(t)
+    pats += [b"ACGT" * 40, b"A" * (tmax - 30), b"ACGTTGCA" * 20]
+    txts += [(b"ACGT" * 47)[:tmax], b"A" * tmax, (b"ACGTTGCA" * 24)[:tmax]]          # text at the limit, pure insertions
+    b = gabgen.pairs_from_lists(pats, txts)
+    assert int(b.txt_len.max()) == tmax
+    kw = {} if red is None else dict(min_wavefront_length=red[0], max_distance_threshold=red[1])
+    e = AffineWavefronts(*pen, **kw)
+    same(e.align(b), pyoracle.wfa(b, pen) if red is None else pyoracle.wfa(b, pen, reduction=red))
+    assert e.last_stats()["requeued"] >= 1          # some pairs exceed the first tier
+    e.close()
+
+
 def test_other_penalties():
     from genarchbench_amd.wfa import AffineWavefronts
     b = gabgen.pairs(67, 5000, 1, 120)
