@@ -69,6 +69,7 @@ struct OffB {
     __device__ __forceinline__ explicit operator int() const { return (int)v - 10; }
 };
 constexpr int kOffBMax = 245;
+constexpr int kOffBSafe = 240;       // an M offset above this sends the pair to the next tier (I = M + 1 of the same step is already stored)
 
 // The work counter is statistics, but 250 000 waves of a 3 ms launch adding to ONE address serialise in L2 (~8 ns per
 // atomic = 2 ms): the waves add to one of 256 slots, 128 bytes apart, behind the counters; wfa_sum_work folds them.
@@ -217,6 +218,7 @@ __device__ bool wfa_pair(WfStore<OffT, ADAPT> &st, const WfaPen pen, const uint8
     st.used = 1;
     __syncthreads();
     int score = 0;
+    bool too_big = false;
     for (;;) {
         WfDir cur = st.get(score);
         if (cur.m != kNone) {
@@ -254,8 +256,14 @@ __device__ bool wfa_pair(WfStore<OffT, ADAPT> &st, const WfaPen pen, const uint8
                     break;
                 }
                 st.pool[cur.m + (k - cur.lo)] = (OffT)o;
+                if (sizeof(OffT) == 1) too_big = too_big || o > kOffBSafe;
             }
             __syncthreads();
+            if (sizeof(OffT) == 1) {
+                // one-byte offsets: an offset beyond the byte's range sends the pair to the next tier
+                const uint64_t gm = (G == 64 ? ~0ull : ((1ull << (G & 63)) - 1)) << (threadIdx.x & 63 & ~(G - 1));
+                if (__ballot(too_big) & gm) return false;
+            }
             // ---- end reached?
             if (cur.lo <= ak && ak <= cur.hi && (int)st.pool[cur.m + (ak - cur.lo)] >= tlen) break;
             // ---- adaptive reduction (the reference reduces before the end test; the reduction never drops diagonal ak
@@ -342,9 +350,9 @@ __device__ bool wfa_pair(WfStore<OffT, ADAPT> &st, const WfaPen pen, const uint8
         auto valid_loc = [&](int kk, int oo) { return oo - kk > 0 && oo - kk <= plen && oo > 0 && oo <= tlen; };
         bool valid = valid_loc(k, offset);
         int v = offset - k, h = offset;
-        auto put = [&](char c) { if (lane == 0) ops[pos] = c; pos--; };
+        auto put = [&](char c) { if (lane == 0 && pos >= 0) ops[pos] = c; pos--; };
         auto put_run = [&](char c, int cnt) {
-            for (int i = lane; i < cnt; i += G) ops[pos - i] = c;
+            for (int i = lane; i < cnt && pos - i >= 0; i += G) ops[pos - i] = c;
             pos -= cnt > 0 ? cnt : 0;
         };
         while (v > 0 && h > 0 && s > 0) {
@@ -378,7 +386,9 @@ __device__ bool wfa_pair(WfStore<OffT, ADAPT> &st, const WfaPen pen, const uint8
         if (s == 0) put_run('M', offset);
         else { put_run('D', v); put_run('I', h); }
     }
-    pos++;
+    // (writes in front of the buffer were dropped: a CIGAR longer than plen + tlen -- a sequence matching the other's padding
+    // byte beyond its end, where the reference overflows its buffer -- keeps its last plen + tlen operations)
+    pos = max(pos, -1) + 1;
     const int nops = cap - pos;
     __syncthreads();
     if (ops_lds) {
@@ -509,6 +519,14 @@ struct WfRow {
 };
 static_assert(sizeof(WfRow) == 96, "WfRow is read as dwords");
 
+// a workgroup of the LDS kernels is ONE wave: LDS instructions of a wave execute in order, so a store by one lane is seen by a
+// later load of another lane without draining the queue -- only the compiler must not reorder them
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 template <int G>
 __device__ bool wfa_pair_static(OffB *pool, int pool_cap, const WfRow *__restrict__ rows, int nrows, const WfaPen pen,
                                 const uint8_t *P, int plen, const uint8_t *T, int tlen, char *ops_global, char *ops,
@@ -516,31 +534,39 @@ __device__ bool wfa_pair_static(OffB *pool, int pool_cap, const WfRow *__restric
     const int lane = threadIdx.x & (G - 1);
     const int ak = tlen - plen;
     if (pool_cap < 1 || nrows < 1) return false;
-    if (lane == 0) pool[0] = OffB(0);
-    __syncthreads();
     auto at = [&](int base, int lo, int hi, int k) { return (lo <= k && k <= hi) ? (int)pool[base + (k - lo)] : kNull; };
-    int r = 0;
-    for (;;) {
-        const WfRow &c = rows[__builtin_amdgcn_readfirstlane(r)];
-        // ---- extend every diagonal of M[score]
-        for (int k = c.lo + lane; k <= c.hi; k += G) {
-            int o = (int)pool[c.bM + (k - c.lo)];
-            int v = o - k, h = o;
-            for (;;) {
-                if (v >= 0 && v <= plen && h >= 0 && h <= tlen) {
-                    // sixteen bases per step (the 'X' / 'Y' padding behind the strings never matches)
-                    const uint64_t d8 = lds_ld8(P, v) ^ lds_ld8(T, h), e8 = lds_ld8(P, v + 8) ^ lds_ld8(T, h + 8);
-                    if ((d8 | e8) == 0) { o += 16; v += 16; h += 16; work += 16; continue; }
-                    const int c8 = d8 ? __builtin_ctzll(d8) >> 3 : 8 + (__builtin_ctzll(e8) >> 3);
-                    o += c8; work += c8;
-                }
-                break;                                          // outside the strings 'X' meets 'Y': no match
+    // affine_wavefronts_extend_mwavefront_compute on one diagonal (the padded strings: affine_wavefront_extend.c:51-83)
+    auto extend = [&](int o, int k) {
+        int v = o - k, h = o;
+        for (;;) {
+            if (v >= 0 && v <= plen && h >= 0 && h <= tlen) {
+                // sixteen bases per step; the LDS copies carry kSeqPad bytes of 'X' / 'Y' behind the strings
+                const uint64_t d8 = lds_ld8(P, v) ^ lds_ld8(T, h), e8 = lds_ld8(P, v + 8) ^ lds_ld8(T, h + 8);
+                if ((d8 | e8) == 0) { o += 16; v += 16; h += 16; work += 16; continue; }
+                const int c8 = d8 ? __builtin_ctzll(d8) >> 3 : 8 + (__builtin_ctzll(e8) >> 3);
+                o += c8; work += c8;
             }
-            pool[c.bM + (k - c.lo)] = OffB(o);
+            break;      // outside the strings 'X' meets 'Y' (the kernel keeps pairs that contain the other's padding byte out of this tier)
         }
-        __syncthreads();
-        if (c.lo <= ak && ak <= c.hi && (int)pool[c.bM + (ak - c.lo)] >= tlen) break;
-        // ---- next wavefront
+        return o;
+    };
+    // Every wavefront is extended by the lane that computed it, before it is stored: a score step is one pass -- read the
+    // sources, max, extend, store -- with one synchronisation, and the end test is a vote on the register of diagonal ak.
+    const uint64_t group_mask = (G == 64 ? ~0ull : ((1ull << G) - 1)) << (threadIdx.x & 63 & ~(G - 1));
+    int r = 0;
+    bool at_end = false, too_big = false;
+    if (lane == 0) {
+        const int o = extend(0, 0);
+        pool[0] = OffB(o);
+        at_end = ak == 0 && o >= tlen;
+        too_big = o > kOffBSafe;
+    }
+    for (;;) {
+        // an offset beyond the byte's range (a pattern full of the text's padding byte can run past the end of the text):
+        // the pair goes to the int16 tier
+        if (__ballot(too_big) & group_mask) return false;
+        if (__ballot(at_end) & group_mask) break;
+        wave_sync();
         r++;
         if (r >= nrows) return false;
         const WfRow &n = rows[__builtin_amdgcn_readfirstlane(r)];
@@ -554,11 +580,14 @@ __device__ bool wfa_pair_static(OffB *pool, int pool_cap, const WfRow *__restric
                 pool[n.bD + (k - n.lo)] = OffB(del);
                 best = max(best, max(ins, del));
             }
+            best = extend(best, k);
             pool[n.bM + (k - n.lo)] = OffB(best);
+            at_end = at_end || (k == ak && best >= tlen);
+            too_big = too_big || best > kOffBSafe;
         }
         work += (lane == 0) ? (unsigned)(n.hi - n.lo + 1) : 0u;
-        __syncthreads();
     }
+    wave_sync();
 
     // ---- backtrace: as in wfa_pair, the directory entries of s - o - e, s - e, s - x being the source fields of row(s)
     const int cap = plen + tlen;
@@ -573,9 +602,9 @@ __device__ bool wfa_pair_static(OffB *pool, int pool_cap, const WfRow *__restric
         auto valid_loc = [&](int kk, int oo) { return oo - kk > 0 && oo - kk <= plen && oo > 0 && oo <= tlen; };
         bool valid = valid_loc(k, offset);
         int v = offset - k, h = offset;
-        auto put = [&](char ch) { if (lane == 0) ops[pos] = ch; pos--; };
+        auto put = [&](char ch) { if (lane == 0 && pos >= 0) ops[pos] = ch; pos--; };
         auto put_run = [&](char ch, int cnt) {
-            for (int i = lane; i < cnt; i += G) ops[pos - i] = ch;
+            for (int i = lane; i < cnt && pos - i >= 0; i += G) ops[pos - i] = ch;
             pos -= cnt > 0 ? cnt : 0;
         };
         auto in = [&](int lo, int hi, int kk) { return lo <= kk && kk <= hi; };
@@ -606,9 +635,11 @@ __device__ bool wfa_pair_static(OffB *pool, int pool_cap, const WfRow *__restric
         if (s == 0) put_run('M', offset);
         else { put_run('D', v); put_run('I', h); }
     }
-    pos++;
+    // (writes in front of the buffer were dropped: a CIGAR longer than plen + tlen -- a sequence matching the other's padding
+    // byte beyond its end, where the reference overflows its buffer -- keeps its last plen + tlen operations)
+    pos = max(pos, -1) + 1;
     const int nops = cap - pos;
-    __syncthreads();
+    wave_sync();
     for (int i = lane; i < nops; i += G) ops_global[i] = ops[pos + i];
     if (lane == 0) { *ops_len_out = nops; *score_out = score; }
     return true;
@@ -632,9 +663,24 @@ __global__ __launch_bounds__(64) void wfa_lds_static(WfaIO io, WfaPen pen, const
         OffB *pool = reinterpret_cast<OffB *>(T + seqt);
         const int plen = io.pat_len[id], tlen = io.txt_len[id];
         const char *gp = io.pat + io.pat_off[id], *gt = io.txt + io.txt_off[id];
-        for (int i = 4 * lane; i < plen + kSeqPad; i += 4 * G) *reinterpret_cast<uint32_t *>(P + i) = seq_ld4(gp, i, plen, (uint32_t)'X');
-        for (int i = 4 * lane; i < tlen + kSeqPad; i += 4 * G) *reinterpret_cast<uint32_t *>(T + i) = seq_ld4(gt, i, tlen, (uint32_t)'Y');
-        __syncthreads();
+        // A pattern byte 'Y' or a text byte 'X' could match the OTHER string's padding outside the strings; wfa_pair_static
+        // does not look there, so such a pair (never a DNA read) goes to the general kernel.
+        auto has_byte = [](uint32_t w, uint32_t c) { const uint32_t x = w ^ (c * 0x01010101u); return ((x - 0x01010101u) & ~x & 0x80808080u) != 0; };
+        bool pad_byte = false;
+        for (int i = 4 * lane; i < plen + kSeqPad; i += 4 * G) {
+            const uint32_t w = seq_ld4(gp, i, plen, (uint32_t)'X');
+            *reinterpret_cast<uint32_t *>(P + i) = w;
+            pad_byte = pad_byte || has_byte(w, 'Y');
+        }
+        for (int i = 4 * lane; i < tlen + kSeqPad; i += 4 * G) {
+            const uint32_t w = seq_ld4(gt, i, tlen, (uint32_t)'Y');
+            *reinterpret_cast<uint32_t *>(T + i) = w;
+            pad_byte = pad_byte || has_byte(w, 'X');
+        }
+        const uint64_t gm = (G == 64 ? ~0ull : ((1ull << (G & 63)) - 1)) << (threadIdx.x & 63 & ~(G - 1));
+        wave_sync();
+        if (__ballot(pad_byte) & gm) ok = false;
+        else
         ok = wfa_pair_static<G>(pool, pool_cap, rows, nrows, pen, P, plen, T, tlen, io.ops + io.ops_off[id], reinterpret_cast<char *>(P),
                                 io.ops_len + id, io.score + id, work);
         if (!ok && lane == 0) over_list[atomicAdd(&ct->n_over, 1u)] = id;
@@ -842,9 +888,10 @@ extern "C" int gab_wfa_run_device(gab_wfa *h, const char *pat, int64_t pat_bytes
     int64_t requeued = 0;
 
     GAB_HIP(hipEventRecord(h->ev[1], s));
-    // LDS passes: (1) four pairs per wave, each with a history of ~1.9 K one-byte offsets (scores below 56: 99.4 % of the
-    // 151-bp pairs at 2 % error; int16 offsets in a 2 KB pool when the strings are too long for bytes), (2) one pair per
-    // wave with 12 KB of int16 offsets, (3) one pair per wave with 96 KB; whatever overflows goes to global memory
+    // LDS passes: (1) four pairs per wave with one-byte offsets -- complete mode: wfa_lds_static with a ~1.5 K and then a 3 K
+    // history; adaptive mode: wfa_lds<16, OffB> with its directory in LDS; int16 offsets in a 2 KB pool when the strings are
+    // too long for bytes -- (2) one pair per wave with 12 KB of int16 offsets, (3) one pair per wave with 96 KB; whatever
+    // overflows goes to global memory
     if (n_big) hipLaunchKernelGGL(wfa_scatter, dim3(grid), dim3(256), 0, s, io, d_ct->cursors, l_a, l_big);
     uint32_t *cur = n_big ? l_a : nullptr, *nxt = l_b;      // nullptr: identity
     uint32_t cnt = n_lds;
@@ -871,25 +918,39 @@ extern "C" int gab_wfa_run_device(gab_wfa *h, const char *pat, int64_t pat_bytes
     if (!byte_ok && !tuned) dir_caps[0] = 48;
     // complete mode: the first tier takes its directory from the penalties' table (wfa_pair_static) -- no directory in LDS
     const int static_rows = std::min(h->nrows, kOffBMax - 2 - h->h_ct->max_tlen);
-    const int static_pool = std::min(2496 - (seqp + seqt), 4080) & ~15;
-    const bool use_static = !h->adaptive && byte_tier != 0 && !getenv("GAB_WFA_NO_STATIC") && groups[0] == 16 && static_rows >= 16 && static_pool >= 1024;
+    // LDS per pair of the first launch: 1904 B = 7616 B per wave of four = 20 waves per CU (what the kernel's 93 VGPRs allow;
+    // 1920 B per pair already falls to 18 waves: the allocation granule), i.e. ~1.5 K offsets behind two 151-bp strings
+    const int static_pool = tuned && byte_tier > 1 ? byte_tier : std::min(1904 - (seqp + seqt), 4080) & ~15;
+    const bool use_static = !h->adaptive && byte_tier != 0 && !getenv("GAB_WFA_NO_STATIC") && (groups[0] == 16 || groups[0] == 8) && static_rows >= 16 && static_pool >= 1024;
     for (int pass = 0; pass < 3 && cnt; pass++) {
         const int dir_cap = dir_caps[pass], G = groups[pass];
         if (pass == 0 && use_static) {
-            const size_t per_group = (size_t)(seqp + seqt) + static_pool;
-            h->h_ct->n_over = 0;
-            GAB_HIP(hipMemsetAsync(&d_ct->n_over, 0, 4, s));
-            hipLaunchKernelGGL(wfa_lds_static<16>, dim3((cnt + 3) / 4), dim3(64), per_group * 4, s, io, h->pen, cur, cnt, seqp, seqt, static_pool,
-                               (uint32_t)per_group, nxt, d_ct, h->rows.as<WfRow>(), static_rows);
-            GAB_HIP(hipGetLastError());
-            GAB_HIP(hipEventRecord(h->ev[2], s)); ev2 = true;
-            hipLaunchKernelGGL(wfa_sum_work, dim3(1), dim3(kWorkSlots), 0, s, d_ct);
-            GAB_HIP(hipMemcpyAsync(h->h_ct, d_ct, sizeof(WfaCounters), hipMemcpyDeviceToHost, s));
-            GAB_HIP(hipStreamSynchronize(s));
-            cnt = h->h_ct->n_over;
-            requeued += cnt;
-            if (cur) std::swap(cur, nxt);
-            else { cur = nxt; nxt = l_a; }
+            // two launches: the small pool takes ~98 % of the 151-bp pairs (scores below 48) at 20 waves per CU, a 3 KB pool
+            // the scores up to ~70 of the rest (measured: 2560-3072 B best, 4080 and 6144 B 2 % slower)
+            int static_pool2 = 3072;
+            if (const char *e2 = getenv("GAB_WFA_POOL2")) static_pool2 = atoi(e2);
+            const int pools[2] = {static_pool, static_pool2};
+            for (int tier = 0; tier < 2 && cnt; tier++) {
+                if (tier == 1 && pools[1] <= pools[0]) break;
+                const size_t per_group = (size_t)(seqp + seqt) + pools[tier];
+                h->h_ct->n_over = 0;
+                GAB_HIP(hipMemsetAsync(&d_ct->n_over, 0, 4, s));
+                if (groups[0] == 8)
+                    hipLaunchKernelGGL(wfa_lds_static<8>, dim3((cnt + 7) / 8), dim3(64), per_group * 8, s, io, h->pen, cur, cnt, seqp, seqt, pools[tier],
+                                       (uint32_t)per_group, nxt, d_ct, h->rows.as<WfRow>(), static_rows);
+                else
+                    hipLaunchKernelGGL(wfa_lds_static<16>, dim3((cnt + 3) / 4), dim3(64), per_group * 4, s, io, h->pen, cur, cnt, seqp, seqt, pools[tier],
+                                       (uint32_t)per_group, nxt, d_ct, h->rows.as<WfRow>(), static_rows);
+                GAB_HIP(hipGetLastError());
+                if (!ev2) { GAB_HIP(hipEventRecord(h->ev[2], s)); ev2 = true; }
+                hipLaunchKernelGGL(wfa_sum_work, dim3(1), dim3(kWorkSlots), 0, s, d_ct);
+                GAB_HIP(hipMemcpyAsync(h->h_ct, d_ct, sizeof(WfaCounters), hipMemcpyDeviceToHost, s));
+                GAB_HIP(hipStreamSynchronize(s));
+                cnt = h->h_ct->n_over;
+                requeued += cnt;
+                if (cur) std::swap(cur, nxt);
+                else { cur = nxt; nxt = l_a; }
+            }
             continue;
         }
         const bool bytes = pass == 0 && byte_ok;

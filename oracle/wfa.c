@@ -143,6 +143,10 @@ int oracle_wfa_one(const oracle_wfa_penalties *pen, const char *pattern, int ple
         const int cap = plen + tlen;
         char *buf = (char *)malloc((size_t)cap + 1);
         int pos = cap - 1;                       /* begin_offset */
+        /* A sequence that contains the OTHER sequence's padding byte can match that padding and run past the end; the
+         * reference then writes more than plen + tlen operations into a buffer of that size (undefined behaviour).  Here
+         * and in the GPU kernels the writes in front of the buffer are dropped: the last plen + tlen operations remain. */
+#define PUT(c_) do { if (pos >= 0) buf[pos] = (c_); pos--; } while (0)
         int s = score, k = ak, offset = M[score].off[k];
         enum { BT_M, BT_I, BT_D } type = BT_M;
 #define VALID(k_, o_) ((o_) - (k_) > 0 && (o_) - (k_) <= plen && (o_) > 0 && (o_) <= tlen)
@@ -152,8 +156,8 @@ int oracle_wfa_one(const oracle_wfa_penalties *pen, const char *pattern, int ple
             if (!valid) {
                 valid = VALID(k, offset);
                 if (valid) {                      /* trailing gap, backtrace.c:47-63 */
-                    if (k < ak) for (int i = k; i < ak; i++) buf[pos--] = 'I';
-                    else if (k > ak) for (int i = ak; i < k; i++) buf[pos--] = 'D';
+                    if (k < ak) for (int i = k; i < ak; i++) PUT('I');
+                    else if (k > ak) for (int i = ak; i < k; i++) PUT('D');
                 }
             }
             const int s_go = s - oe, s_ge = s - e, s_mm = s - x;
@@ -164,18 +168,19 @@ int oracle_wfa_one(const oracle_wfa_penalties *pen, const char *pattern, int ple
             const int misms = type != BT_M ? WF_NULL : (s_mm >= 0 && wf_has_base(&M[s_mm], k) ? M[s_mm].off[k] + 1 : WF_NULL);
             const int max_all = imax(misms, imax(imax(ins_ext, ins_open), imax(del_ext, del_open)));
             if (type == BT_M) {
-                for (int i = 0; i < offset - max_all; i++) buf[pos--] = 'M';
+                for (int i = 0; i < offset - max_all; i++) PUT('M');
                 offset = max_all;
             }
-            if (max_all == del_ext) { if (valid) buf[pos--] = 'D'; s = s_ge; k++; type = BT_D; }
-            else if (max_all == del_open) { if (valid) buf[pos--] = 'D'; s = s_go; k++; type = BT_M; }
-            else if (max_all == ins_ext) { if (valid) buf[pos--] = 'I'; s = s_ge; k--; offset--; type = BT_I; }
-            else if (max_all == ins_open) { if (valid) buf[pos--] = 'I'; s = s_go; k--; offset--; type = BT_M; }
-            else { if (valid) buf[pos--] = 'X'; s = s_mm; offset--; }      /* max_all == misms */
+            if (max_all == del_ext) { if (valid) PUT('D'); s = s_ge; k++; type = BT_D; }
+            else if (max_all == del_open) { if (valid) PUT('D'); s = s_go; k++; type = BT_M; }
+            else if (max_all == ins_ext) { if (valid) PUT('I'); s = s_ge; k--; offset--; type = BT_I; }
+            else if (max_all == ins_open) { if (valid) PUT('I'); s = s_go; k--; offset--; type = BT_M; }
+            else { if (valid) PUT('X'); s = s_mm; offset--; }      /* max_all == misms */
             v = offset - k; h = offset;
         }
-        if (s == 0) { for (int i = 0; i < offset; i++) buf[pos--] = 'M'; }
-        else { while (v > 0) { buf[pos--] = 'D'; v--; } while (h > 0) { buf[pos--] = 'I'; h--; } }
+        if (s == 0) { for (int i = 0; i < offset; i++) PUT('M'); }
+        else { while (v > 0) { PUT('D'); v--; } while (h > 0) { PUT('I'); h--; } }
+        if (pos < -1) pos = -1;
         pos++;
         nops = cap - pos;
         if (ops_out) memcpy(ops_out, buf + pos, (size_t)nops);

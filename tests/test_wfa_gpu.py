@@ -55,6 +55,31 @@ def test_edge_and_padding_chars(eng):
     same(eng.align(b), pyoracle.wfa(b))
 
 
+def test_padding_characters_inside_the_strings(eng):
+    """bases that ARE the reference's padding bytes: a pattern position beyond its end reads 'X', a text position beyond its
+    end reads 'Y', so an 'X' in the text (a 'Y' in the pattern) can match the other string's padding and carry an extension
+    past the end -- in every tier, at low and high scores"""
+    rng = np.random.default_rng(21)
+    alpha = np.frombuffer(b"ACGTXY", np.uint8)
+    pats, txts = [], []
+    for _ in range(4000):
+        n = int(rng.integers(5, 150))
+        err = float(rng.choice([0.0, 0.02, 0.05, 0.2]))
+        p = rng.choice(alpha, n, p=[.2, .2, .2, .2, .1, .1]).tobytes()
+        t = bytearray()
+        for c in p:
+            r = rng.random()
+            if r < err / 3: continue
+            if r < 2 * err / 3: t.append(int(rng.choice(alpha)))
+            t.append(c if r > err else int(rng.choice(alpha)))
+        # tails made of the other string's padding byte
+        if rng.random() < 0.3: t += b"X" * int(rng.integers(1, 12))
+        if rng.random() < 0.3: p += b"Y" * int(rng.integers(1, 12))
+        pats.append(p); txts.append(bytes(t))
+    b = gabgen.pairs_from_lists(pats, txts)
+    same(eng.align(b), pyoracle.wfa(b))
+
+
 def test_long_sequences_global_path(eng):
     """sequences beyond the LDS limit and scores beyond the LDS pools -> global-history kernel"""
     rng = np.random.default_rng(11)
