@@ -1193,8 +1193,7 @@ static int chain_run_overlapped(gab_chain *h, int mode, const uint64_t *x, const
     std::vector<char> inA((size_t)ncalls, 0);
     std::vector<ChainWork> wk[3];
     int64_t accA = 0;
-    const int diag = getenv("GAB_CHAIN_DIAG") ? atoi(getenv("GAB_CHAIN_DIAG")) : 0;
-    for (size_t k = 0; k < topn && !(diag & 1); k++) {
+    for (size_t k = 0; k < topn; k++) {
         const int64_t c = order[k];
         if (hdr[c].n == 0 || (k >= 64 && accA * 16 >= total)) break;
         inA[(size_t)c] = 1; accA += hdr[c].n;
@@ -1241,23 +1240,13 @@ static int chain_run_overlapped(gab_chain *h, int mode, const uint64_t *x, const
     GAB_HIP(hipMemcpyAsync(dy, y, 8 * (size_t)mid, hipMemcpyHostToDevice, sB1));
     GAB_HIP(hipEventRecord(h->xe[2], sB1));                                            // first half is in
     mark(3, sB1);
-    if (diag & 2) {
-        GAB_HIP(hipStreamWaitEvent(sB2, h->xe[2], 0));
-        GAB_HIP(hipMemcpyAsync(dx + mid, x + mid, 8 * (t - (size_t)mid), hipMemcpyHostToDevice, sB2));
-        GAB_HIP(hipMemcpyAsync(dy + mid, y + mid, 8 * (t - (size_t)mid), hipMemcpyHostToDevice, sB2));
-        GAB_HIP(hipEventRecord(h->xe[3], sB2));
-        GAB_HIP(hipStreamWaitEvent(sB1, h->xe[3], 0));
-    }
     chain_launch(mode, sB1, d_work[1], (unsigned)wk[1].size(), dx, dy, ds, dp, d_gm, d_ev);
     mark(4, sB1);
     GAB_HIP(hipEventRecord(h->xe[4], sB1));                                            // B1's results are final
     // ---- stream B2: second half right behind the first
-    if (!(diag & 2)) {
     GAB_HIP(hipStreamWaitEvent(sB2, h->xe[2], 0));
     GAB_HIP(hipMemcpyAsync(dx + mid, x + mid, 8 * (t - (size_t)mid), hipMemcpyHostToDevice, sB2));
     GAB_HIP(hipMemcpyAsync(dy + mid, y + mid, 8 * (t - (size_t)mid), hipMemcpyHostToDevice, sB2));
-    }
-    if (diag & 4) GAB_HIP(hipStreamWaitEvent(sB2, h->xe[4], 0));
     mark(5, sB2);
     chain_launch(mode, sB2, d_work[2], (unsigned)wk[2].size(), dx, dy, ds, dp, d_gm, d_ev);
     mark(6, sB2);
