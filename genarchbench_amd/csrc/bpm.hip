@@ -324,12 +324,31 @@ __global__ __launch_bounds__(64) void bpm_band(BpmIO io, const uint32_t *__restr
         (void)cols;
         int ops = 0, v = n - 1, h = m - 1;
         bool miss = false;
+        // The walk itself only needs the band bits (LDS); the two bases of a diagonal step only feed the count, but as byte
+        // loads at the step they put a global-memory round trip (~0.7 us) into every step.  Both strings are read backwards,
+        // at most one byte per step, so each is held as the 8-byte chunk under the cursor plus the chunk below it, which is
+        // requested when the cursor enters a chunk: a load has eight steps to arrive.
+        const int n4 = (n + 3) & ~3, m4 = (m + 3) & ~3;                    // readable bytes (the slabs are padded to dwords)
+        auto chunk = [](const char *q, int k, int len4, uint32_t &lo, uint32_t &hi) {
+            lo = hi = 0;
+            if (k >= 0) { lo = ld_u32(q + 8 * k); if (8 * k + 4 < len4) hi = ld_u32(q + 8 * k + 4); }
+        };
+        int tk = h >> 3, pk = v >> 3;
+        uint32_t tlo, thi, tnlo, tnhi, plo2, phi2, pnlo, pnhi;
+        chunk(t, tk, m4, tlo, thi); chunk(t, tk - 1, m4, tnlo, tnhi);
+        chunk(p, pk, n4, plo2, phi2); chunk(p, pk - 1, n4, pnlo, pnhi);
         while (v >= 0 && h >= 0) {
             const int r1 = start(h + 1), rh = start(h);
             if (v < r1 || v >= r1 + kBandRows || v < rh || v >= rh + kBandRows) { miss = true; break; }
-            if ((B[(h + 1) * 64] >> (v - r1)) & 1) { ops++; v--; }
-            else if ((B[h * 64] >> (kBandRows + v - rh)) & 1) { ops++; h--; }
-            else { ops += t[h] != p[v]; h--; v--; }
+            if ((h >> 3) != tk) { tk--; tlo = tnlo; thi = tnhi; chunk(t, tk - 1, m4, tnlo, tnhi); }
+            if ((v >> 3) != pk) { pk--; plo2 = pnlo; phi2 = pnhi; chunk(p, pk - 1, n4, pnlo, pnhi); }
+            const uint32_t bc = B[(h + 1) * 64], bp = B[h * 64];
+            if ((bc >> (v - r1)) & 1) { ops++; v--; }
+            else if ((bp >> (kBandRows + v - rh)) & 1) { ops++; h--; }
+            else {
+                const uint32_t tc = (((h & 4) ? thi : tlo) >> ((h & 3) * 8)) & 0xffu, pc = (((v & 4) ? phi2 : plo2) >> ((v & 3) * 8)) & 0xffu;
+                ops += tc != pc; h--; v--;
+            }
         }
         if (miss) miss_id = (int64_t)id;
         else score_out[id] = -(ops + (h + 1) + (v + 1));
