@@ -33,7 +33,12 @@
 #include <string.h>
 #include <type_traits>
 
+#ifndef GAB_CHAIN_PRIO
+#define GAB_CHAIN_PRIO 3
+#endif
 namespace {
+constexpr int kMainWavePrio = GAB_CHAIN_PRIO;
+constexpr int64_t kLongCall = 20000;
 
 constexpr int kMaxIter = 5000;
 constexpr int kMaxSkip = 25;
@@ -487,13 +492,17 @@ __global__ __launch_bounds__(64 * (1 + kChHelpers)) void chain_hw_kernel(const C
 // One __syncthreads per block hands the results of block t to the helpers (global scores, acknowledged by L2) and the
 // partial maxima of block t+1 to the main wave (LDS).
 constexpr int kFcHelpers = 3;
-__global__ __launch_bounds__(64 * (1 + kFcHelpers)) void fastchain_kernel(const ChainWork *__restrict__ work,
+template <int H>
+__global__ __launch_bounds__(64 * (1 + H)) void fastchain_kernel(const ChainWork *__restrict__ work,
                                                                           const uint64_t *__restrict__ xs,
                                                                           const uint64_t *__restrict__ ys, int32_t *score_out,
                                                                           int32_t *parent_out, unsigned long long *evals_out) {
-    __shared__ int32_t part_best[2][kFcHelpers][64], part_j[2][kFcHelpers][64], part_st[2][64];
+    __shared__ int32_t part_best[2][H][64], part_j[2][H][64], part_st[2][64];
     const ChainWork w = work[blockIdx.x];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave index: uniform, say so
+    // a long call is the batch's critical path (its blocks are strictly sequential) and shares its SIMDs with the waves of
+    // short calls, which are not: the waves of long calls are issued first (-DGAB_CHAIN_PRIO=0 switches this off for A/B runs)
+    if (kMainWavePrio && w.n >= kLongCall) __builtin_amdgcn_s_setprio(kMainWavePrio);
     const uint64_t *X = xs + w.off, *Y = ys + w.off;
     int32_t *S = score_out + w.off, *P = parent_out + w.off;
     const int64_t n = w.n;
@@ -573,7 +582,7 @@ __global__ __launch_bounds__(64 * (1 + kFcHelpers)) void fastchain_kernel(const 
                 const int64_t st_lo = __builtin_amdgcn_readfirstlane((int)(uint32_t)st_a) |
                                       ((int64_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(st_a >> 32)) << 32);
                 // far predecessors j <= i0 - 65, chunks of 64 dealt round-robin to the helpers
-                for (int64_t jb = i0 - 65 - 64 * (wave - 1); jb >= st_lo; jb -= 64 * kFcHelpers) {
+                for (int64_t jb = i0 - 65 - 64 * (wave - 1); jb >= st_lo; jb -= 64 * H) {
                     const int64_t jl = jb - lane;
                     int32_t vx = 0, vy = 0, vs = 0;
                     if (jl >= st_lo) {
@@ -615,7 +624,7 @@ __global__ __launch_bounds__(64 * (1 + kFcHelpers)) void fastchain_kernel(const 
             bool have = false;
             // helpers' partial maxima: chunks interleave, so the larger j wins a tie
 #pragma unroll
-            for (int hh = 0; hh < kFcHelpers; hh++) {
+            for (int hh = 0; hh < H; hh++) {
                 const int32_t b2 = part_best[par ^ 1][hh][lane], j2 = part_j[par ^ 1][hh][lane];
                 if (b2 > best || (have && b2 == best && j2 > best_j)) { best = b2; best_j = j2; have = true; }
             }
@@ -825,14 +834,18 @@ __device__ __forceinline__ void chain_exact_global(const uint64_t *X, const uint
     best_out = best; bestj_out = best_j;
 }
 
-__global__ __launch_bounds__(64 * (1 + kCbHelpers)) void chain_block_kernel(const ChainWork *__restrict__ work,
+template <int H>
+__global__ __launch_bounds__(64 * (1 + H)) void chain_block_kernel(const ChainWork *__restrict__ work,
                                                                             const uint64_t *__restrict__ xs,
                                                                             const uint64_t *__restrict__ ys, int32_t *score_out,
                                                                             int32_t *parent_out, int32_t *gmarks_all,
                                                                             unsigned long long *evals_out) {
-    __shared__ int32_t part_best[2][kCbHelpers][64], part_j[2][kCbHelpers][64], part_ok[2][kCbHelpers][64], part_st[2][64];
+    __shared__ int32_t part_best[2][H][64], part_j[2][H][64], part_ok[2][H][64], part_st[2][64];
     const ChainWork w = work[blockIdx.x];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    // a long call is the batch's critical path (its blocks are strictly sequential) and shares its SIMDs with the waves of
+    // short calls, which are not: the waves of long calls are issued first (-DGAB_CHAIN_PRIO=0 switches this off for A/B runs)
+    if (kMainWavePrio && w.n >= kLongCall) __builtin_amdgcn_s_setprio(kMainWavePrio);
     const uint64_t *X = xs + w.off, *Y = ys + w.off;
     int32_t *S = score_out + w.off, *P = parent_out + w.off, *GM = gmarks_all + w.off;
     const int n = (int)w.n;                                  // < 2^31 (checked by the host)
@@ -902,7 +915,7 @@ __global__ __launch_bounds__(64 * (1 + kCbHelpers)) void chain_block_kernel(cons
                 int32_t best = NEG, best_j = -1, nok = 0;    // helpers start below any score; q_span is the main wave's floor
                 const int st_lo = __builtin_amdgcn_readfirstlane(st_a);
                 // far predecessors j <= i0 - 65 (final since block t - 1), chunks of 64 dealt round-robin to the helpers
-                for (int jb = i0 - 65 - 64 * (wave - 1); jb >= st_lo; jb -= 64 * kCbHelpers) {
+                for (int jb = i0 - 65 - 64 * (wave - 1); jb >= st_lo; jb -= 64 * H) {
                     const int jl = jb - lane;
                     Pred pv = {0, 0, 0};
                     int32_t vs = 0;
@@ -956,7 +969,7 @@ __global__ __launch_bounds__(64 * (1 + kCbHelpers)) void chain_block_kernel(cons
             int32_t risk = 0;                                // unfiltered predecessors folded after the current argmax (upper bound)
             // helpers' partial maxima: chunks interleave, so the larger j wins a tie; all far unfiltered ones count as risk
 #pragma unroll
-            for (int hh = 0; hh < kCbHelpers; hh++) {
+            for (int hh = 0; hh < H; hh++) {
                 const int32_t b2 = part_best[par ^ 1][hh][lane], j2 = part_j[par ^ 1][hh][lane];
                 risk += part_ok[par ^ 1][hh][lane];
                 if (b2 >= thr && !(best_j != kNoJ && b2 == thr && j2 < best_j)) { thr = b2; best_j = j2; }
@@ -1081,17 +1094,31 @@ static int chain_check_hdrs(const gab_chain_hdr *hdr, const int64_t *call_off, i
     return GAB_OK;
 }
 
+// How many helper waves a batch gets.  Three is the throughput optimum (chain-large: 35.6 ms; five 51.8, seven 50.0: every
+// helper repeats the window-start search of the block).  But a batch whose longest call alone outlasts everything else is
+// bound by that call's blocks, and those finish sooner with more hands: 1 000 calls / 8 M anchors, longest 60 000 --
+// chain 25.8 -> 21.7 -> 20.2 ms with 3 / 5 / 7 helpers, fast-chain 24.7 -> 21.4 -> 20.1 ms.  Seven are used when the batch,
+// at the seven-helper throughput (1.6 G anchors/s), would be done in 0.6 of the longest call's time (0.34 us per anchor).
+static int chain_helpers_for(int64_t total_anchors, int64_t longest_call) {
+    if (const char *e = getenv("GAB_CHAIN_HELPERS")) { const int v = atoi(e); if (v == 3 || v == 5 || v == 7) return v; }   // A/B runs
+    return total_anchors <= 326 * longest_call ? 7 : 3;
+}
+
 // the kernels of one work list (already on the device) on `s`; nothing else (no memset, no synchronisation)
-static void chain_launch(int mode, hipStream_t s, ChainWork *d_work, unsigned nw, const uint64_t *d_x, const uint64_t *d_y, int32_t *d_score,
-                         int32_t *d_parent, int32_t *d_gm, unsigned long long *d_ev) {
+static void chain_launch(int mode, int helpers, hipStream_t s, ChainWork *d_work, unsigned nw, const uint64_t *d_x, const uint64_t *d_y,
+                         int32_t *d_score, int32_t *d_parent, int32_t *d_gm, unsigned long long *d_ev) {
     if (nw == 0) return;
-    if (mode == GAB_FASTCHAIN)
-        hipLaunchKernelGGL(fastchain_kernel, dim3(nw), dim3(64 * (1 + kFcHelpers)), 0, s, d_work, d_x, d_y, d_score, d_parent, d_ev);
-    else if (getenv("GAB_CHAIN_KERNEL") && !strcmp(getenv("GAB_CHAIN_KERNEL"), "walk"))      // the per-anchor walk (A/B runs)
+    if (mode == GAB_FASTCHAIN) {
+        if (helpers == 7) hipLaunchKernelGGL(fastchain_kernel<7>, dim3(nw), dim3(64 * 8), 0, s, d_work, d_x, d_y, d_score, d_parent, d_ev);
+        else if (helpers == 5) hipLaunchKernelGGL(fastchain_kernel<5>, dim3(nw), dim3(64 * 6), 0, s, d_work, d_x, d_y, d_score, d_parent, d_ev);
+        else hipLaunchKernelGGL(fastchain_kernel<kFcHelpers>, dim3(nw), dim3(64 * (1 + kFcHelpers)), 0, s, d_work, d_x, d_y, d_score, d_parent, d_ev);
+    } else if (getenv("GAB_CHAIN_KERNEL") && !strcmp(getenv("GAB_CHAIN_KERNEL"), "walk"))      // the per-anchor walk (A/B runs)
         hipLaunchKernelGGL(chain_hw_kernel, dim3(nw), dim3(64 * (1 + kChHelpers)), 0, s, d_work, d_x, d_y, d_score, d_parent, d_gm, d_ev);
     else {
         hipLaunchKernelGGL(chain_facts_kernel, dim3(nw), dim3(256), 0, s, d_work, d_x, d_y);
-        hipLaunchKernelGGL(chain_block_kernel, dim3(nw), dim3(64 * (1 + kCbHelpers)), 0, s, d_work, d_x, d_y, d_score, d_parent, d_gm, d_ev);
+        if (helpers == 7) hipLaunchKernelGGL(chain_block_kernel<7>, dim3(nw), dim3(64 * 8), 0, s, d_work, d_x, d_y, d_score, d_parent, d_gm, d_ev);
+        else if (helpers == 5) hipLaunchKernelGGL(chain_block_kernel<5>, dim3(nw), dim3(64 * 6), 0, s, d_work, d_x, d_y, d_score, d_parent, d_gm, d_ev);
+        else hipLaunchKernelGGL(chain_block_kernel<kCbHelpers>, dim3(nw), dim3(64 * (1 + kCbHelpers)), 0, s, d_work, d_x, d_y, d_score, d_parent, d_gm, d_ev);
     }
 }
 
@@ -1149,7 +1176,7 @@ extern "C" int gab_chain_run_device(gab_chain *h, int mode, const uint64_t *d_x,
         GAB_HIP(hipMemsetAsync(d_gm, 0, sizeof(int32_t) * (size_t)total, s));      // vector::resize zero-fills targets
     }
     GAB_HIP(hipEventRecord(h->ev[0], s));
-    chain_launch(mode, s, d_work, (unsigned)nw, d_x, d_y, d_score, d_parent, d_gm, d_ev);
+    chain_launch(mode, chain_helpers_for(total, wk.empty() ? 0 : wk[0].n), s, d_work, (unsigned)nw, d_x, d_y, d_score, d_parent, d_gm, d_ev);
     GAB_HIP(hipGetLastError());
     GAB_HIP(hipEventRecord(h->ev[1], s));
     GAB_HIP(hipMemcpyAsync(h->h_evals, d_ev, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
@@ -1231,7 +1258,7 @@ static int chain_run_overlapped(gab_chain *h, int mode, const uint64_t *x, const
         GAB_HIP(hipMemcpyAsync(dy + w.off, y + w.off, 8 * (size_t)w.n, hipMemcpyHostToDevice, sA));
     }
     mark(1, sA);
-    chain_launch(mode, sA, d_work[0], (unsigned)wk[0].size(), dx, dy, ds, dp, d_gm, d_ev);
+    chain_launch(mode, 3, sA, d_work[0], (unsigned)wk[0].size(), dx, dy, ds, dp, d_gm, d_ev);
     mark(2, sA);
     GAB_HIP(hipEventRecord(h->xe[1], sA));                                             // A's results are final
     // ---- stream B1: first half
@@ -1240,7 +1267,7 @@ static int chain_run_overlapped(gab_chain *h, int mode, const uint64_t *x, const
     GAB_HIP(hipMemcpyAsync(dy, y, 8 * (size_t)mid, hipMemcpyHostToDevice, sB1));
     GAB_HIP(hipEventRecord(h->xe[2], sB1));                                            // first half is in
     mark(3, sB1);
-    chain_launch(mode, sB1, d_work[1], (unsigned)wk[1].size(), dx, dy, ds, dp, d_gm, d_ev);
+    chain_launch(mode, 3, sB1, d_work[1], (unsigned)wk[1].size(), dx, dy, ds, dp, d_gm, d_ev);
     mark(4, sB1);
     GAB_HIP(hipEventRecord(h->xe[4], sB1));                                            // B1's results are final
     // ---- stream B2: second half right behind the first
@@ -1248,7 +1275,7 @@ static int chain_run_overlapped(gab_chain *h, int mode, const uint64_t *x, const
     GAB_HIP(hipMemcpyAsync(dx + mid, x + mid, 8 * (t - (size_t)mid), hipMemcpyHostToDevice, sB2));
     GAB_HIP(hipMemcpyAsync(dy + mid, y + mid, 8 * (t - (size_t)mid), hipMemcpyHostToDevice, sB2));
     mark(5, sB2);
-    chain_launch(mode, sB2, d_work[2], (unsigned)wk[2].size(), dx, dy, ds, dp, d_gm, d_ev);
+    chain_launch(mode, 3, sB2, d_work[2], (unsigned)wk[2].size(), dx, dy, ds, dp, d_gm, d_ev);
     mark(6, sB2);
     GAB_HIP(hipGetLastError());
     // ---- results: each half once its own kernel and A's are done (a call of B2 may begin in the first half: its anchors

@@ -42,6 +42,19 @@ def test_vs_oracle(eng, mode, seed, ncalls, gmode, nmin, nmax):
     assert ev_gpu == ev if mode == 1 else ev <= ev_gpu <= 2 * sum(min(i, 5000) for n in batch.hdr["n"] for i in range(int(n)))
 
 
+@pytest.mark.parametrize("helpers", [3, 5, 7])
+@pytest.mark.parametrize("mode", [0, 1])
+def test_every_helper_count(eng, mode, helpers, monkeypatch):
+    """the library picks three helper waves per call for throughput-bound batches and seven for batches bound by their
+    longest call; every instantiation has to give the reference's result (the environment variable pins the choice)"""
+    monkeypatch.setenv("GAB_CHAIN_HELPERS", str(helpers))
+    for batch in (gabgen.chain(35, 40, 0, 50, 30000), gabgen.chain(36, 25, 1, 500, 9000)):
+        ws, wp = pyoracle.chain(batch, mode)
+        s, p = eng.host_chain_kernel(batch, mode)
+        np.testing.assert_array_equal(s, ws)
+        np.testing.assert_array_equal(p, wp)
+
+
 @pytest.mark.parametrize("mode", [0, 1])
 def test_edge_calls(eng, mode):
     """empty call, single anchor, duplicates, unsorted x, window clamp (max_iter), huge max_dist"""
