@@ -33,12 +33,7 @@
 #include <string.h>
 #include <type_traits>
 
-#ifndef GAB_CHAIN_PRIO
-#define GAB_CHAIN_PRIO 3
-#endif
 namespace {
-constexpr int kMainWavePrio = GAB_CHAIN_PRIO;
-constexpr int64_t kLongCall = 20000;
 
 constexpr int kMaxIter = 5000;
 constexpr int kMaxSkip = 25;
@@ -500,9 +495,6 @@ __global__ __launch_bounds__(64 * (1 + H)) void fastchain_kernel(const ChainWork
     __shared__ int32_t part_best[2][H][64], part_j[2][H][64], part_st[2][64];
     const ChainWork w = work[blockIdx.x];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave index: uniform, say so
-    // a long call is the batch's critical path (its blocks are strictly sequential) and shares its SIMDs with the waves of
-    // short calls, which are not: the waves of long calls are issued first (-DGAB_CHAIN_PRIO=0 switches this off for A/B runs)
-    if (kMainWavePrio && w.n >= kLongCall) __builtin_amdgcn_s_setprio(kMainWavePrio);
     const uint64_t *X = xs + w.off, *Y = ys + w.off;
     int32_t *S = score_out + w.off, *P = parent_out + w.off;
     const int64_t n = w.n;
@@ -843,9 +835,6 @@ __global__ __launch_bounds__(64 * (1 + H)) void chain_block_kernel(const ChainWo
     __shared__ int32_t part_best[2][H][64], part_j[2][H][64], part_ok[2][H][64], part_st[2][64];
     const ChainWork w = work[blockIdx.x];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    // a long call is the batch's critical path (its blocks are strictly sequential) and shares its SIMDs with the waves of
-    // short calls, which are not: the waves of long calls are issued first (-DGAB_CHAIN_PRIO=0 switches this off for A/B runs)
-    if (kMainWavePrio && w.n >= kLongCall) __builtin_amdgcn_s_setprio(kMainWavePrio);
     const uint64_t *X = xs + w.off, *Y = ys + w.off;
     int32_t *S = score_out + w.off, *P = parent_out + w.off, *GM = gmarks_all + w.off;
     const int n = (int)w.n;                                  // < 2^31 (checked by the host)
