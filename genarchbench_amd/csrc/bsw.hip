@@ -98,29 +98,39 @@ __global__ __launch_bounds__(256) void bsw_hist(BswIO io, uint32_t *hist, uint32
     if ((threadIdx.x & 63) == 0 && mh > 0) atomicMax(&st->max_h0, mh);
 }
 
-// ---- pass 2: exclusive scan of the 65536 bins (single workgroup) ---------------------------
-__global__ __launch_bounds__(1024) void bsw_scan(const uint32_t *hist, uint32_t *start, uint32_t *qstart) {
-    __shared__ uint32_t part[1024];
-    const int t = threadIdx.x;
-    constexpr int per = kNumKeys / 1024;   // 64 consecutive bins per thread
-    uint32_t s = 0;
-    for (int k = 0; k < per; k++) s += hist[bsw_hslot(t * per + k)];
-    part[t] = s;
+// ---- pass 2: exclusive scan of the 65536 bins ----------------------------------------------
+// Two launches of 64 workgroups: (a) every thread takes ONE bin -- the counters sit at scrambled slots, so a thread that
+// walks 64 consecutive bins pays 128 scattered loads one after the other (a single workgroup doing that took 113 us,
+// 9 % of a 100 000-pair batch) -- and the workgroup scans its 1024 bins; (b) adds the totals of the workgroups in front.
+constexpr int kScanBlocks = kNumKeys / 1024;
+static_assert(kScanBlocks == 64, "bsw_scan_b reduces the block totals with one wave");
+__global__ __launch_bounds__(1024) void bsw_scan_a(const uint32_t *__restrict__ hist, uint32_t *__restrict__ start, uint32_t *__restrict__ sums) {
+    __shared__ uint32_t wsum[16];
+    const int t = threadIdx.x, key = blockIdx.x * 1024 + t, lane = t & 63, wv = t >> 6;
+    const uint32_t v = hist[bsw_hslot(key)];
+    uint32_t inc = v;
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t u = __shfl_up(inc, o); if (lane >= o) inc += u; }
+    if (lane == 63) wsum[wv] = inc;
     __syncthreads();
-    for (int o = 1; o < 1024; o <<= 1) {
-        uint32_t v = t >= o ? part[t - o] : 0;
-        __syncthreads();
-        part[t] += v;
-        __syncthreads();
+    uint32_t before = 0;
+    for (int k = 0; k < wv; k++) before += wsum[k];
+    start[key] = before + inc - v;
+    if (t == 1023) sums[blockIdx.x] = before + inc;
+}
+__global__ __launch_bounds__(1024) void bsw_scan_b(uint32_t *__restrict__ start, const uint32_t *__restrict__ sums, uint32_t *__restrict__ qstart) {
+    __shared__ uint32_t s_off, s_total;
+    const int t = threadIdx.x, key = blockIdx.x * 1024 + t;
+    if (t < 64) {
+        const uint32_t sv = sums[t];
+        uint32_t mine = t < (int)blockIdx.x ? sv : 0, all = sv;
+        for (int o = 32; o > 0; o >>= 1) { mine += __shfl_xor(mine, o); all += __shfl_xor(all, o); }
+        if (t == 0) { s_off = mine; s_total = all; }
     }
-    uint32_t run = part[t] - s;
-    for (int k = 0; k < per; k++) {
-        int b = t * per + k;
-        start[b] = run;
-        if ((b % kTBuckets) == 0) qstart[b / kTBuckets] = run;
-        run += hist[bsw_hslot(b)];
-    }
-    if (t == 1023) { start[kNumKeys] = run; qstart[kQBuckets] = run; }
+    __syncthreads();
+    const uint32_t run = start[key] + s_off;
+    start[key] = run;
+    if ((key % kTBuckets) == 0) qstart[key / kTBuckets] = run;
+    if (key == kNumKeys - 1) { start[kNumKeys] = s_total; qstart[kQBuckets] = s_total; }
 }
 
 // ---- pass 3: scatter the pairs' descriptors into bucket order -------------------------------
@@ -656,7 +666,8 @@ extern "C" int gab_bsw_run_device(gab_bsw *h, const uint8_t *ref, int64_t ref_by
     const size_t o_hist = 0;
     const size_t o_start = o_hist + sizeof(uint32_t) * kNumKeys;
     const size_t o_qstart = o_start + sizeof(uint32_t) * (kNumKeys + 1);
-    const size_t o_stats = (o_qstart + sizeof(uint32_t) * (kQBuckets + 1) + 15) & ~(size_t)15;
+    const size_t o_sums = o_qstart + sizeof(uint32_t) * (kQBuckets + 1);
+    const size_t o_stats = (o_sums + sizeof(uint32_t) * kScanBlocks + 15) & ~(size_t)15;
     const size_t o_recs = (o_stats + sizeof(BswStats) + 255) & ~(size_t)255;
     const size_t o_rank = o_recs + ((sizeof(BswRec) * (size_t)n + 255) & ~(size_t)255);
     int rc = h->ws.reserve(o_rank + sizeof(uint32_t) * (size_t)n);
@@ -679,7 +690,8 @@ extern "C" int gab_bsw_run_device(gab_bsw *h, const uint8_t *ref, int64_t ref_by
     }
     int grid = (int)(gab_ceil_div(n, 256) < 1024 ? gab_ceil_div(n, 256) : 1024);   // (one same-address atomicMax per wave)
     hipLaunchKernelGGL(bsw_hist, dim3(grid), dim3(256), 0, s, io, d_hist, d_rank, d_stats);
-    hipLaunchKernelGGL(bsw_scan, dim3(1), dim3(1024), 0, s, d_hist, d_start, d_qstart);
+    hipLaunchKernelGGL(bsw_scan_a, dim3(kScanBlocks), dim3(1024), 0, s, d_hist, d_start, (uint32_t *)(base + o_sums));
+    hipLaunchKernelGGL(bsw_scan_b, dim3(kScanBlocks), dim3(1024), 0, s, d_start, (const uint32_t *)(base + o_sums), d_qstart);
     hipLaunchKernelGGL(bsw_scatter, dim3(grid), dim3(256), 0, s, io, d_start, d_rank, d_recs);
     GAB_HIP(hipMemcpyAsync(h->h_qstart, d_qstart, sizeof(uint32_t) * (kQBuckets + 1), hipMemcpyDeviceToHost, s));
     GAB_HIP(hipMemcpyAsync(h->h_stats, d_stats, sizeof(BswStats), hipMemcpyDeviceToHost, s));
