@@ -487,6 +487,7 @@ __global__ __launch_bounds__(64 * (1 + kChHelpers)) void chain_hw_kernel(const C
 // One __syncthreads per block hands the results of block t to the helpers (global scores, acknowledged by L2) and the
 // partial maxima of block t+1 to the main wave (LDS).
 constexpr int kFcHelpers = 3;
+constexpr int kGapTab = 2048;             // entries of the per-call gap-cost table (LDS, int32): bw + 2 of them are used
 template <int H>
 __global__ __launch_bounds__(64 * (1 + H)) void fastchain_kernel(const ChainWork *__restrict__ work,
                                                                           const uint64_t *__restrict__ xs,
@@ -506,6 +507,7 @@ __global__ __launch_bounds__(64 * (1 + H)) void fastchain_kernel(const ChainWork
     const uint32_t mq_u = mq < 0 ? 0u : (uint32_t)mq;       // negative limits reject every predecessor
     const int64_t nblocks = (n + 63) / 64;
 
+    __shared__ int32_t gap_tab[kGapTab];
     // any_narrow: wave-uniform "some lane of this block has a window of <= 6 predecessors" (only near the start of a
     // call): only then is the double-precision gap cost evaluated at all (real branch, not a select)
     // NARROW is a compile-time tag: written as a run-time `if (any_narrow)` the compiler if-converts the branch and the four
@@ -521,14 +523,28 @@ __global__ __launch_bounds__(64 * (1 + H)) void fastchain_kernel(const ChainWork
         ok = !(dd > bw || ddr == 0 || (uint32_t)ddq - 1u >= mq_u);
         const int32_t oc = min(min(ddr, ddq), qsa);
         // ilog2(dd) >> 1 with ilog2(0) = 0:  (31 - clz(dd | 1)) >> 1 = 15 - (clz(dd | 1) >> 1)
-        const int32_t lgh = 15 - (__clz((int)((uint32_t)dd | 1u)) >> 1);
-        int32_t gc = (int32_t)floorf(__fmul_rn((float)dd, k32)) + lgh;
+        int32_t gc;
         if constexpr (NARROW) {
+            const int32_t lgh = 15 - (__clz((int)((uint32_t)dd | 1u)) >> 1);
+            gc = (int32_t)floorf(__fmul_rn((float)dd, k32)) + lgh;
             const int32_t gd = (int32_t)__dmul_rn(__dmul_rn((double)dd, .01), avg_d) + lgh;
             gc = wide_a ? gc : gd;
+        } else {
+            // the fp32 gap cost of every dd a pair can pass the filter with: 0 .. bw from the table of the call, and INT_MIN (the
+            // only negative |diff|, which `dd > bw` lets through like the AVX code does) from entry bw + 1, where every dd > bw lands
+            gc = gap_tab[min((uint32_t)dd, (uint32_t)bw + 1u)];
         }
         return (int32_t)((uint32_t)sj + (uint32_t)oc - (uint32_t)gc);
     };
+    // (blocks in which some lane has a narrow window, and calls whose bw does not fit the table, take the arithmetic variant)
+    const bool use_tab = bw >= 0 && bw <= kGapTab - 2;
+    if (use_tab) {
+        for (int d = threadIdx.x; d <= bw + 1; d += 64 * (1 + H)) {
+            const int32_t dv = d <= bw ? d : (int32_t)0x80000000;
+            gap_tab[d] = (int32_t)floorf(__fmul_rn((float)dv, k32)) + (15 - (__clz((int)((uint32_t)dv | 1u)) >> 1));
+        }
+        __syncthreads();
+    }
 
     // helper state: the sequential window-start pointer (each helper keeps its own identical copy)
     int64_t st = 0, sb = 0;
@@ -596,7 +612,7 @@ __global__ __launch_bounds__(64 * (1 + H)) void fastchain_kernel(const ChainWork
                         for (; l + 3 < cnt; l += 4) { step(l); step(l + 1); step(l + 2); step(l + 3); }
                         for (; l < cnt; l++) step(l);
                     };
-                    if (any_narrow) far_chunk(std::true_type{}); else far_chunk(std::false_type{});
+                    if (any_narrow || !use_tab) far_chunk(std::true_type{}); else far_chunk(std::false_type{});
                 }
                 part_best[par][wave - 1][lane] = best; part_j[par][wave - 1][lane] = best_j;
                 if (wave == 1) part_st[par][lane] = st_rel;
@@ -635,7 +651,7 @@ __global__ __launch_bounds__(64 * (1 + H)) void fastchain_kernel(const ChainWork
                 for (; l >= 3; l -= 4) { step(l); step(l - 1); step(l - 2); step(l - 3); }
                 for (; l >= 0; l--) step(l);
             };
-            if (any_narrow) near_fold(std::true_type{}); else near_fold(std::false_type{});
+            if (any_narrow || !use_tab) near_fold(std::true_type{}); else near_fold(std::false_type{});
             if (nhave && (nbest > best || (have && nbest == best))) { best = nbest; best_j = nbj; have = true; }
             // predecessors inside the block
             // The only true chain: anchor b's score is final after the folds 0 .. b-1 and feeds b+1 ...  Everything about
@@ -660,7 +676,7 @@ __global__ __launch_bounds__(64 * (1 + H)) void fastchain_kernel(const ChainWork
                 }
                 for (; b + 1 < nb; b++) { bool o; const int32_t g = geom(b, o); fold(b, g, o); }
             };
-            if (any_narrow) block_fold(std::true_type{}); else block_fold(std::false_type{});
+            if (any_narrow || !use_tab) block_fold(std::true_type{}); else block_fold(std::false_type{});
             if (mine) { S[i0 + lane] = best; P[i0 + lane] = have ? (int32_t)(i0 + best_j) : -1; }
             pxa = xa; pya = ya; pbest = best; pnb = nb;
         }
@@ -713,15 +729,27 @@ __global__ __launch_bounds__(256) void chain_facts_kernel(ChainWork *work, const
     __syncthreads();
     if (threadIdx.x == 0) {
         for (int k = 1; k < 4; k++) { lo = s_lo[k] < lo ? s_lo[k] : lo; hi = s_hi[k] > hi ? s_hi[k] : hi; mixed |= s_mixed[k]; }
-        w.pad = (n > 0 && !mixed && hi - lo < 0x7fffffffull) ? 1 : 0;
+        // ... and, for the gap-cost table of the block kernel: 0 <= bw <= kGapTab - 2, and dq - dr cannot wrap for a pair that
+        // passes the dq filter (dq in [1, min(max_dist_x, max_dist_y)]): then dd = |dr - dq| is an exact value in [0, 2^31)
+        const int32_t mq = w.max_dist_y < w.max_dist_x ? w.max_dist_y : w.max_dist_x;
+        const unsigned long long lim = mq < 0 ? 0ull : (unsigned long long)mq;
+        w.pad = (n > 0 && !mixed && hi - lo + lim < 0x7fffffffull && w.bw >= 0 && w.bw <= kGapTab - 2) ? 1 : 0;
     }
 }
 
 // chain_geometry for a call with the facts above: one segment id, 32-bit-exact x differences.  `xa_lo` / `xj_lo` are the low
 // words of x; dq_lim = min(max_dist_y, max_dist_x) clamped at 0.  Same value and same filter as chain_geometry (the `same`
 // branch with dr held in 32 bits: dd = |dr - dq| wraps exactly like the reference's int64 -> int32 conversion).
+// The gap cost -- (int)(dd * .01 * avg_qspan) in fp64 (two conversions and two multiplications at the fp64 rate) + ilog2(dd) / 2,
+// rounded -- depends on dd alone, and a pair with dd > bw is filtered: gap_tab[dd] for dd = 0 .. bw (built per call by
+// chain_gap_cost below, in LDS), one ds_read instead of ten instructions.  Pairs with dd > bw read entry bw + 1 (never used).
+__device__ __forceinline__ int32_t chain_gap_cost(int32_t dd, double avg_d) {
+    const int32_t lgh = (31 - __clz((int)((uint32_t)dd | 1u))) >> 1;          // ilog2(dd) >> 1, ilog2(0) = 0
+    const int32_t gap = (int32_t)__dmul_rn(__dmul_rn((double)dd, .01), avg_d) + lgh;
+    return gap - (gap >> 31);
+}
 __device__ __forceinline__ int32_t chain_geometry_plain(uint32_t xa_lo, int32_t qa, int32_t q_span, uint32_t xj_lo, uint32_t yj, int32_t mdy,
-                                                        uint32_t dq_lim, int32_t bw, bool multi_seg, double avg_d, bool &ok) {
+                                                        uint32_t dq_lim, int32_t bw, bool multi_seg, const int32_t *gap_tab, bool &ok) {
     const int32_t dr = (int32_t)(xa_lo - xj_lo);
     const int32_t dq = qa - (int32_t)yj;
     const int32_t diff = (int32_t)((uint32_t)dr - (uint32_t)dq);
@@ -729,9 +757,7 @@ __device__ __forceinline__ int32_t chain_geometry_plain(uint32_t xa_lo, int32_t 
     // dq <= 0 || dq > max_dist_y || dq > max_dist_x  ==  (unsigned)(dq - 1) >= min(max_dist_y, max_dist_x)
     ok = !(dr == 0 || (uint32_t)dq - 1u >= dq_lim || dd > bw || (multi_seg && dr > mdy));
     const int32_t v = min(min(dq, dr), q_span);
-    const int32_t lgh = (31 - __clz((int)((uint32_t)dd | 1u))) >> 1;          // ilog2(dd) >> 1, ilog2(0) = 0
-    const int32_t gap = (int32_t)__dmul_rn(__dmul_rn((double)dd, .01), avg_d) + lgh;
-    return v - (gap - (gap >> 31));
+    return v - gap_tab[min((uint32_t)dd, (uint32_t)bw + 1u)];
 }
 
 
@@ -842,11 +868,16 @@ __global__ __launch_bounds__(64 * (1 + H)) void chain_block_kernel(const ChainWo
     const uint64_t mdx64 = (uint64_t)(int64_t)mdx;
     const double avg_d = (double)w.avg_qspan;
     const bool multi_seg = w.n_segs > 1;
-    const bool plain = (w.pad & 1) != 0;                     // chain_facts_kernel: one segment id, 32-bit-exact x differences
+    const bool plain = (w.pad & 1) != 0;                     // chain_facts_kernel: one segment id, 32-bit-exact x differences, bw fits the table
     const int32_t mq = mdy < mdx ? mdy : mdx;
     const uint32_t dq_lim = mq < 0 ? 0u : (uint32_t)mq;
     const int nblocks = (n + 63) / 64;
     const int NEG = (int)0x80000000;
+    __shared__ int32_t gap_tab[kGapTab];
+    if (plain) {
+        for (int d = threadIdx.x; d <= bw + 1; d += 64 * (1 + H)) gap_tab[d] = chain_gap_cost(d, avg_d);
+        __syncthreads();
+    }
 
     // geometry of (own anchor, broadcast predecessor): PLAIN is a compile-time tag so that the generic arithmetic (64-bit
     // differences, segment rules) costs the plain calls nothing; the predecessor's fields come from `src` lanes of
@@ -856,7 +887,7 @@ __global__ __launch_bounds__(64 * (1 + H)) void chain_block_kernel(const ChainWo
         constexpr bool PLAIN = decltype(tag)::value;
         const uint32_t xj_lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)pv.x, src);
         const uint32_t yj = (uint32_t)__builtin_amdgcn_readlane((int)pv.y, src);
-        if constexpr (PLAIN) return chain_geometry_plain((uint32_t)xa, qa, qsa, xj_lo, yj, mdy, dq_lim, bw, multi_seg, avg_d, ok);
+        if constexpr (PLAIN) return chain_geometry_plain((uint32_t)xa, qa, qsa, xj_lo, yj, mdy, dq_lim, bw, multi_seg, gap_tab, ok);
         else {
             const uint64_t xj = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(pv.x >> 32), src) << 32) | xj_lo;
             return chain_geometry(xa, qa, qsa, sida, xj, yj, __builtin_amdgcn_readlane(pv.sid, src), mdx, mdy, bw, multi_seg, avg_d, ok);

@@ -56,6 +56,26 @@ def test_every_helper_count(eng, mode, helpers, monkeypatch):
 
 
 @pytest.mark.parametrize("mode", [0, 1])
+def test_gap_cost_table_limits(eng, mode):
+    """the block kernels read the gap cost of a pair from a per-call table of bw + 2 entries when 0 <= bw <= 2046 and
+    compute it otherwise: band widths on both sides of the limit, 0 and 1, with diagonal differences from 0 to beyond bw,
+    fractional and large avg_qspan"""
+    rng = np.random.default_rng(17)
+    Y = lambda q, span=15, seg=0: (np.uint64(seg) << np.uint64(48)) | (np.uint64(span) << np.uint64(32)) | np.uint64(q)
+    calls = []
+    for bw, aq in ((0, 15.0), (1, 15.0), (500, 14.37), (2046, 15.0), (2047, 15.0), (2046, 250.5), (3000, 7.25)):
+        x = np.sort(rng.integers(0, 60000, 2500)).astype(np.uint64)
+        q = (x.astype(np.int64) // 2 + rng.integers(0, max(2 * bw, 4) + 50, 2500)).clip(0)      # dd = |dr - dq| up to ~2 bw
+        calls.append((aq, 5000, 5000, bw, 1, x, np.array([Y(int(v), int(s)) for v, s in zip(q, rng.integers(1, 60, 2500))], np.uint64)))
+    batch = gabgen.chain_from_calls(calls)
+    ws, wp = pyoracle.chain(batch, mode)
+    s, p = eng.host_chain_kernel(batch, mode)
+    np.testing.assert_array_equal(s, ws)
+    np.testing.assert_array_equal(p, wp)
+    assert (wp >= 0).sum() > 1000          # the filter lets many pairs through: the gap cost matters
+
+
+@pytest.mark.parametrize("mode", [0, 1])
 def test_edge_calls(eng, mode):
     """empty call, single anchor, duplicates, unsorted x, window clamp (max_iter), huge max_dist"""
     rng = np.random.default_rng(5)
