@@ -753,7 +753,9 @@ __device__ __forceinline__ int32_t chain_geometry_plain(uint32_t xa_lo, int32_t 
     const int32_t dr = (int32_t)(xa_lo - xj_lo);
     const int32_t dq = qa - (int32_t)yj;
     const int32_t diff = (int32_t)((uint32_t)dr - (uint32_t)dq);
-    const int32_t dd = dr > dq ? diff : (int32_t)(0u - (uint32_t)diff);
+    // |dr - dq|: exact for every pair that passes the dq filter (chain_facts_kernel: dq - dr cannot wrap then); a pair that
+    // fails it is filtered whatever dd says, so the reference's `dr > dq ? dr - dq : dq - dr` on wrapped values is not needed
+    const int32_t dd = max(diff, (int32_t)(0u - (uint32_t)diff));
     // dq <= 0 || dq > max_dist_y || dq > max_dist_x  ==  (unsigned)(dq - 1) >= min(max_dist_y, max_dist_x)
     ok = !(dr == 0 || (uint32_t)dq - 1u >= dq_lim || dd > bw || (multi_seg && dr > mdy));
     const int32_t v = min(min(dq, dr), q_span);
