@@ -222,6 +222,10 @@ int gab_bitpal_last_stats(gab_bitpal *h, int64_t *cells, int64_t *long_pairs, fl
  * ops_out[ops_off[i]]; the caller provides pattern_length + text_length bytes of room per pair
  * (edit_cigar_allocate, wfa/gap_affine/edit_cigar.c:38-47) and run-length encodes them when
  * printing (edit_cigar_print, :184-200).  score_out[i] = the alignment penalty.
+ * Bytes equal to the reference's padding characters -- 'Y' in a pattern, 'X' in a text -- match the OTHER sequence's
+ * padding as they do in the reference (wfa/utils/string_padded.c:88-117), so an alignment can run past the end of a
+ * sequence.  Where that makes the CIGAR longer than pattern_length + text_length the reference overflows its buffer;
+ * this library keeps the last pattern_length + text_length operations (never written outside the pair's room).
  */
 #define GAB_WFA_MAX_LEN 100000 /* MAX_SEQUENCE_LENGTH, wfa/tools/align_benchmark.c:62 */
 typedef struct gab_wfa gab_wfa;
