@@ -367,6 +367,9 @@ __global__ __launch_bounds__(64) void bsw_dp8(BswIO io, BswConst c, const BswRec
                                               int64_t kend, int qcap, int32_t *__restrict__ score_out,
                                               gab_bsw_result *__restrict__ result_out, BswStats *st) {
     extern __shared__ uint32_t lds[];
+    __shared__ __attribute__((aligned(8))) uint32_t row_tab[10];     // BswConst.row_lo / row_hi per reference base, for per-lane look-ups
+    if (threadIdx.x < 5) { row_tab[2 * threadIdx.x] = c.row_lo[threadIdx.x]; row_tab[2 * threadIdx.x + 1] = c.row_hi[threadIdx.x]; }
+    __syncthreads();
     const int lane = threadIdx.x;
     const int64_t k = kbeg + (int64_t)(gridDim.x - 1 - blockIdx.x) * 64 + lane;   // heaviest waves (largest key) first
     const bool valid = k < kend;
@@ -423,11 +426,10 @@ __global__ __launch_bounds__(64) void bsw_dp8(BswIO io, BswConst c, const BswRec
         for (int i = 0; i < tlen; i++) {
             const int tc = (tw >> ((i & 3) * 8)) & 0xff;
             if ((i & 3) == 3 && i + 1 < tlen) tw = load_u32_unaligned(t + i + 1);
-            uint32_t rlo = c.row_lo[4], rhi = c.row_hi[4];
-            rlo = tc == 0 ? c.row_lo[0] : rlo; rhi = tc == 0 ? c.row_hi[0] : rhi;
-            rlo = tc == 1 ? c.row_lo[1] : rlo; rhi = tc == 1 ? c.row_hi[1] : rhi;
-            rlo = tc == 2 ? c.row_lo[2] : rlo; rhi = tc == 2 ? c.row_hi[2] : rhi;
-            rlo = tc == 3 ? c.row_lo[3] : rlo; rhi = tc == 3 ? c.row_hi[3] : rhi;
+            // the packed score vector of this row's reference base: one 8-byte LDS read (five v_cmp + ten v_cndmask + the SGPR
+            // moves they need were ~100 cycles per row)
+            const uint2 rr = *reinterpret_cast<const uint2 *>(&row_tab[2 * (tc < 4 ? tc : 4)]);
+            const uint32_t rlo = rr.x, rhi = rr.y;
             if (beg < i - w) beg = i - w;
             if (end > i + w + 1) end = i + w + 1;
             if (end > qlen) end = qlen;
@@ -623,7 +625,7 @@ extern "C" int gab_bsw_create(const gab_bsw_params *p, int device, gab_bsw **out
     // the 256-base class needs more than the default 64 KiB of dynamic LDS
     if (hipFuncSetAttribute((const void *)bsw_dp<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
         hipFuncSetAttribute((const void *)bsw_dp<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
-        hipFuncSetAttribute((const void *)bsw_dp8, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+        hipFuncSetAttribute((const void *)bsw_dp8, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64) != hipSuccess) {
         gab_set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed"); delete h; return GAB_EDEVICE;
     }
     if (hipHostMalloc((void **)&h->h_qstart, sizeof(uint32_t) * (kQBuckets + 1)) != hipSuccess ||
