@@ -24,11 +24,22 @@ class ChainEngine:
 
     __del__ = close
 
-    def host_chain_kernel(self, batch, mode=CHAIN):
-        """batch: tools.gabgen.ChainBatch-like (hdr records, call_off, x, y) -> (scores, parents)"""
+    def host_chain_kernel(self, batch, mode=CHAIN, pinned=False):
+        """batch: tools.gabgen.ChainBatch-like (hdr records, call_off, x, y) -> (scores, parents).
+        pinned: page-lock the four arrays for the call, as the drivers do with their slabs (gab_host_register)"""
         score = np.full(batch.nanchors, -777, np.int32); parent = np.full(batch.nanchors, -777, np.int32)
-        check(lib().gab_chain_run(self._h, C.c_int(mode), _p(batch.x), _p(batch.y), _p(batch.call_off),
-                                  _p(batch.hdr), C.c_int64(batch.ncalls), _p(score), _p(parent)))
+        locked = []
+        if pinned:
+            for a in (batch.x, batch.y, score, parent):
+                if a.nbytes:
+                    check(lib().gab_host_register(C.c_void_p(a.ctypes.data), C.c_size_t(a.nbytes)))
+                    locked.append(a)
+        try:
+            check(lib().gab_chain_run(self._h, C.c_int(mode), _p(batch.x), _p(batch.y), _p(batch.call_off),
+                                      _p(batch.hdr), C.c_int64(batch.ncalls), _p(score), _p(parent)))
+        finally:
+            for a in locked:
+                lib().gab_host_unregister(C.c_void_p(a.ctypes.data))
         return score, parent
 
     def run_device(self, mode, x, y, call_off, hdr, score, parent, stream=0):

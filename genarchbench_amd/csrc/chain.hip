@@ -29,6 +29,7 @@
 #include <algorithm>
 #include <new>
 #include <vector>
+#include <chrono>
 #include <stdlib.h>
 #include <string.h>
 #include <type_traits>
@@ -44,6 +45,91 @@ struct ChainWork {                        // one call, device-side descriptor
     float avg_qspan;
     int32_t max_dist_x, max_dist_y, bw, n_segs, pad;
 };
+
+// ---- the host-pointer path of big batches: the anchors come in by a KERNEL, longest call first -----------------------
+// (see chain_run_fed).  A call's workgroup waits until its anchors are there and writes its results through to the caller's
+// page-locked arrays block by block; all members null = the plain device path.
+struct ChainFeed {
+    uint32_t *facts;                          // per work item: 0 = anchors not here yet; 2 | (plain ? 1 : 0) once they are
+    int32_t *host_score, *host_parent;        // device addresses of the caller's result arrays
+    uint32_t *abort;                          // set by a wait that gave up; every other wait then gives up too
+};
+struct ChainChunk { int64_t off; int32_t n, item; };          // up to kFeedChunk anchors of work item `item`
+constexpr int kFeedChunk = 2048;
+constexpr long kFeedSpinLimit = 4000000;      // x ~1 us of s_sleep: a wait gives up after seconds, so the grid always drains
+
+// wait (thread 0, sleeping) until the anchors of this workgroup's call are in device memory; returns the facts word (0: gave up)
+__device__ __forceinline__ uint32_t chain_feed_wait(const ChainFeed &feed, uint32_t *s_word) {
+    if (threadIdx.x == 0) {
+        uint32_t f = 0;
+        for (long spins = 0;; spins++) {
+            f = __hip_atomic_load(&feed.facts[blockIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (f) break;
+            if (spins > kFeedSpinLimit || __hip_atomic_load(feed.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                __hip_atomic_store(feed.abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(32);
+        }
+        *s_word = f;
+    }
+    __syncthreads();
+    // the anchors were written by another kernel while this CU may hold older copies of their cache lines (a neighbouring
+    // call's tail shares a line with this call's head): acquire at agent scope drops them
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    return *s_word;
+}
+
+// Copies the anchors of the chunks, in table order (longest call first), from the caller's page-locked arrays (read over the
+// bus by the lanes: 51-57 GB/s, profiles/r02_pcie_copy.md) to the device arrays, collects what chain_facts_kernel would
+// (x range, one segment id?) and, with the last chunk of a call, publishes the call's facts word.
+__global__ __launch_bounds__(256) void chain_gather_kernel(const ChainChunk *__restrict__ chunks, uint32_t nchunks,
+                                                           const uint64_t *__restrict__ hx, const uint64_t *__restrict__ hy,
+                                                           uint64_t *__restrict__ dx, uint64_t *__restrict__ dy,
+                                                           const ChainWork *__restrict__ work, const uint32_t *__restrict__ need,
+                                                           uint32_t *done, unsigned long long *xlo, unsigned long long *xhi,
+                                                           uint32_t *mixed, uint32_t *facts, volatile uint8_t *started, int gap_tab_max) {
+    __shared__ unsigned long long s_lo[4], s_hi[4];
+    __shared__ uint32_t s_mx[4];
+    if (threadIdx.x == 0) started[blockIdx.x] = 1;            // (host memory: the host launches the DP once every workgroup is resident)
+    for (uint32_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
+        const ChainChunk ch = chunks[c];
+        const ChainWork w = work[ch.item];
+        const uint32_t sid0 = (uint32_t)(hy[w.off] >> 48 & 0xff);
+        unsigned long long lo = ~0ull, hi = 0;
+        uint32_t mx = 0;
+        for (int i = threadIdx.x; i < ch.n; i += 256) {
+            const uint64_t x = hx[ch.off + i], y = hy[ch.off + i];
+            dx[ch.off + i] = x; dy[ch.off + i] = y;
+            lo = x < lo ? x : lo; hi = x > hi ? x : hi;
+            mx |= ((uint32_t)(y >> 48 & 0xff) != sid0) ? 1u : 0u;
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            const unsigned long long l2 = __shfl_xor(lo, o), h2 = __shfl_xor(hi, o);
+            lo = l2 < lo ? l2 : lo; hi = h2 > hi ? h2 : hi; mx |= __shfl_xor(mx, o);
+        }
+        if ((threadIdx.x & 63) == 0) { s_lo[threadIdx.x >> 6] = lo; s_hi[threadIdx.x >> 6] = hi; s_mx[threadIdx.x >> 6] = mx; }
+        __threadfence();                                      // this thread's anchors are visible device-wide ...
+        __syncthreads();                                      // ... and so are everybody's, before thread 0 counts the chunk
+        if (threadIdx.x == 0) {
+            for (int k = 1; k < 4; k++) { lo = s_lo[k] < lo ? s_lo[k] : lo; hi = s_hi[k] > hi ? s_hi[k] : hi; mx |= s_mx[k]; }
+            atomicMin(&xlo[ch.item], lo); atomicMax(&xhi[ch.item], hi);
+            if (mx) atomicOr(&mixed[ch.item], 1u);
+            __threadfence();
+            if (atomicAdd(&done[ch.item], 1u) + 1u == need[ch.item]) {
+                __threadfence();
+                const unsigned long long L = __hip_atomic_load(&xlo[ch.item], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                                         H = __hip_atomic_load(&xhi[ch.item], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t M = __hip_atomic_load(&mixed[ch.item], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int32_t mq = w.max_dist_y < w.max_dist_x ? w.max_dist_y : w.max_dist_x;
+                const unsigned long long lim = mq < 0 ? 0ull : (unsigned long long)mq;
+                const bool plain = w.n > 0 && !M && H - L + lim < 0x7fffffffull && w.bw >= 0 && w.bw <= gap_tab_max;   // = chain_facts_kernel
+                __hip_atomic_store(&facts[ch.item], 2u | (plain ? 1u : 0u), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        __syncthreads();
+    }
+}
 
 #define GAB_DPP(old, src, ctrl, rmask) __builtin_amdgcn_update_dpp((old), (src), (ctrl), (rmask), 0xf, false)
 
@@ -489,11 +575,13 @@ __global__ __launch_bounds__(64 * (1 + kChHelpers)) void chain_hw_kernel(const C
 constexpr int kFcHelpers = 3;
 constexpr int kGapTab = 2048;             // entries of the per-call gap-cost table (LDS, int32): bw + 2 of them are used
 template <int H>
-__global__ __launch_bounds__(64 * (1 + H)) void fastchain_kernel(const ChainWork *__restrict__ work,
-                                                                          const uint64_t *__restrict__ xs,
-                                                                          const uint64_t *__restrict__ ys, int32_t *score_out,
-                                                                          int32_t *parent_out, unsigned long long *evals_out) {
+__global__ __launch_bounds__(64 * (1 + H)) void fastchain_kernel(const ChainWork *__restrict__ work, const uint64_t *xs, const uint64_t *ys,
+                                                                          int32_t *score_out, int32_t *parent_out,
+                                                                          unsigned long long *evals_out, ChainFeed feed) {
+    // (xs / ys are not __restrict__: in the fed variant another kernel writes them while this one waits)
     __shared__ int32_t part_best[2][H][64], part_j[2][H][64], part_st[2][64];
+    __shared__ uint32_t feed_word;
+    if (feed.facts && chain_feed_wait(feed, &feed_word) == 0) return;
     const ChainWork w = work[blockIdx.x];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave index: uniform, say so
     const uint64_t *X = xs + w.off, *Y = ys + w.off;
@@ -677,7 +765,11 @@ __global__ __launch_bounds__(64 * (1 + H)) void fastchain_kernel(const ChainWork
                 for (; b + 1 < nb; b++) { bool o; const int32_t g = geom(b, o); fold(b, g, o); }
             };
             if (any_narrow || !use_tab) block_fold(std::true_type{}); else block_fold(std::false_type{});
-            if (mine) { S[i0 + lane] = best; P[i0 + lane] = have ? (int32_t)(i0 + best_j) : -1; }
+            if (mine) {
+                const int32_t par_ = have ? (int32_t)(i0 + best_j) : -1;
+                S[i0 + lane] = best; P[i0 + lane] = par_;
+                if (feed.host_score) { feed.host_score[w.off + i0 + lane] = best; feed.host_parent[w.off + i0 + lane] = par_; }
+            }
             pxa = xa; pya = ya; pbest = best; pnb = nb;
         }
         __syncthreads();       // results of block t are acknowledged by L2; partial maxima of block t+1 are in LDS
@@ -855,12 +947,14 @@ __device__ __forceinline__ void chain_exact_global(const uint64_t *X, const uint
 }
 
 template <int H>
-__global__ __launch_bounds__(64 * (1 + H)) void chain_block_kernel(const ChainWork *__restrict__ work,
-                                                                            const uint64_t *__restrict__ xs,
-                                                                            const uint64_t *__restrict__ ys, int32_t *score_out,
-                                                                            int32_t *parent_out, int32_t *gmarks_all,
-                                                                            unsigned long long *evals_out) {
+__global__ __launch_bounds__(64 * (1 + H)) void chain_block_kernel(const ChainWork *__restrict__ work, const uint64_t *xs, const uint64_t *ys,
+                                                                            int32_t *score_out, int32_t *parent_out, int32_t *gmarks_all,
+                                                                            unsigned long long *evals_out, ChainFeed feed) {
+    // (xs / ys are not __restrict__: in the fed variant another kernel writes them while this one waits)
     __shared__ int32_t part_best[2][H][64], part_j[2][H][64], part_ok[2][H][64], part_st[2][64];
+    __shared__ uint32_t feed_word;
+    uint32_t fed_facts = 0;
+    if (feed.facts && (fed_facts = chain_feed_wait(feed, &feed_word)) == 0) return;
     const ChainWork w = work[blockIdx.x];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint64_t *X = xs + w.off, *Y = ys + w.off;
@@ -870,7 +964,7 @@ __global__ __launch_bounds__(64 * (1 + H)) void chain_block_kernel(const ChainWo
     const uint64_t mdx64 = (uint64_t)(int64_t)mdx;
     const double avg_d = (double)w.avg_qspan;
     const bool multi_seg = w.n_segs > 1;
-    const bool plain = (w.pad & 1) != 0;                     // chain_facts_kernel: one segment id, 32-bit-exact x differences, bw fits the table
+    const bool plain = ((feed.facts ? fed_facts : (uint32_t)w.pad) & 1u) != 0;   // chain_facts_kernel / chain_gather_kernel: one segment id, 32-bit-exact x differences, bw fits the table
     const int32_t mq = mdy < mdx ? mdy : mdx;
     const uint32_t dq_lim = mq < 0 ? 0u : (uint32_t)mq;
     const int nblocks = (n + 63) / 64;
@@ -1050,7 +1144,11 @@ __global__ __launch_bounds__(64 * (1 + H)) void chain_block_kernel(const ChainWo
             };
             if (plain) block_fold(std::true_type{}); else block_fold(std::false_type{});
             const int32_t best = thr - (best_j == kNoJ ? 1 : 0);
-            if (mine) { S[i0 + lane] = best; P[i0 + lane] = best_j == kNoJ ? -1 : i0 + best_j; }
+            if (mine) {
+                const int32_t par_ = best_j == kNoJ ? -1 : i0 + best_j;
+                S[i0 + lane] = best; P[i0 + lane] = par_;
+                if (feed.host_score) { feed.host_score[w.off + i0 + lane] = best; feed.host_parent[w.off + i0 + lane] = par_; }
+            }
             prev = cur; pbest = best; pnb = nb;
         }
         __syncthreads();       // results of block t are acknowledged by L2; partial maxima of block t+1 are in LDS
@@ -1072,7 +1170,9 @@ struct gab_chain {
     // the host-pointer entry point of big batches: two more streams and the events that order its copies and kernels
     hipStream_t xs[2] = {nullptr, nullptr};
     hipEvent_t xe[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-    unsigned long long *h_evals = nullptr;   // pinned
+    unsigned long long *h_evals = nullptr;   // pinned: evals, (spare), abort word of the fed path
+    uint8_t *h_started = nullptr;            // pinned: one byte per workgroup of chain_gather_kernel
+    hipEvent_t xe_fed = nullptr;
     bool have_stats = false;
 };
 
@@ -1086,7 +1186,8 @@ extern "C" int gab_chain_create(int device, gab_chain **out) {
     if (!h) { gab_set_error("out of host memory"); return GAB_ENOMEM; }
     h->device = device;
     if (hipEventCreate(&h->ev[0]) != hipSuccess || hipEventCreate(&h->ev[1]) != hipSuccess ||
-        hipHostMalloc((void **)&h->h_evals, sizeof(unsigned long long)) != hipSuccess) {
+        hipHostMalloc((void **)&h->h_evals, 64) != hipSuccess ||
+        hipEventCreateWithFlags(&h->xe_fed, hipEventDisableTiming) != hipSuccess) {
         gab_set_error("gab_chain_create: event / pinned allocation failed"); delete h; return GAB_EDEVICE;
     }
     *out = h;
@@ -1101,6 +1202,8 @@ extern "C" void gab_chain_destroy(gab_chain *h) {
     for (int k = 0; k < 2; k++) if (h->xs[k]) (void)hipStreamDestroy(h->xs[k]);
     for (int k = 0; k < 5; k++) if (h->xe[k]) (void)hipEventDestroy(h->xe[k]);
     if (h->h_evals) (void)hipHostFree(h->h_evals);
+    if (h->h_started) (void)hipHostFree(h->h_started);
+    if (h->xe_fed) (void)hipEventDestroy(h->xe_fed);
     delete h;
 }
 
@@ -1128,19 +1231,20 @@ static int chain_helpers_for(int64_t total_anchors, int64_t longest_call) {
 
 // the kernels of one work list (already on the device) on `s`; nothing else (no memset, no synchronisation)
 static void chain_launch(int mode, int helpers, hipStream_t s, ChainWork *d_work, unsigned nw, const uint64_t *d_x, const uint64_t *d_y,
-                         int32_t *d_score, int32_t *d_parent, int32_t *d_gm, unsigned long long *d_ev) {
+                         int32_t *d_score, int32_t *d_parent, int32_t *d_gm, unsigned long long *d_ev, const ChainFeed *feed_in = nullptr) {
+    const ChainFeed feed = feed_in ? *feed_in : ChainFeed{nullptr, nullptr, nullptr, nullptr};
     if (nw == 0) return;
     if (mode == GAB_FASTCHAIN) {
-        if (helpers == 7) hipLaunchKernelGGL(fastchain_kernel<7>, dim3(nw), dim3(64 * 8), 0, s, d_work, d_x, d_y, d_score, d_parent, d_ev);
-        else if (helpers == 5) hipLaunchKernelGGL(fastchain_kernel<5>, dim3(nw), dim3(64 * 6), 0, s, d_work, d_x, d_y, d_score, d_parent, d_ev);
-        else hipLaunchKernelGGL(fastchain_kernel<kFcHelpers>, dim3(nw), dim3(64 * (1 + kFcHelpers)), 0, s, d_work, d_x, d_y, d_score, d_parent, d_ev);
+        if (helpers == 7) hipLaunchKernelGGL(fastchain_kernel<7>, dim3(nw), dim3(64 * 8), 0, s, d_work, d_x, d_y, d_score, d_parent, d_ev, feed);
+        else if (helpers == 5) hipLaunchKernelGGL(fastchain_kernel<5>, dim3(nw), dim3(64 * 6), 0, s, d_work, d_x, d_y, d_score, d_parent, d_ev, feed);
+        else hipLaunchKernelGGL(fastchain_kernel<kFcHelpers>, dim3(nw), dim3(64 * (1 + kFcHelpers)), 0, s, d_work, d_x, d_y, d_score, d_parent, d_ev, feed);
     } else if (getenv("GAB_CHAIN_KERNEL") && !strcmp(getenv("GAB_CHAIN_KERNEL"), "walk"))      // the per-anchor walk (A/B runs)
         hipLaunchKernelGGL(chain_hw_kernel, dim3(nw), dim3(64 * (1 + kChHelpers)), 0, s, d_work, d_x, d_y, d_score, d_parent, d_gm, d_ev);
     else {
-        hipLaunchKernelGGL(chain_facts_kernel, dim3(nw), dim3(256), 0, s, d_work, d_x, d_y);
-        if (helpers == 7) hipLaunchKernelGGL(chain_block_kernel<7>, dim3(nw), dim3(64 * 8), 0, s, d_work, d_x, d_y, d_score, d_parent, d_gm, d_ev);
-        else if (helpers == 5) hipLaunchKernelGGL(chain_block_kernel<5>, dim3(nw), dim3(64 * 6), 0, s, d_work, d_x, d_y, d_score, d_parent, d_gm, d_ev);
-        else hipLaunchKernelGGL(chain_block_kernel<kCbHelpers>, dim3(nw), dim3(64 * (1 + kCbHelpers)), 0, s, d_work, d_x, d_y, d_score, d_parent, d_gm, d_ev);
+        if (!feed.facts) hipLaunchKernelGGL(chain_facts_kernel, dim3(nw), dim3(256), 0, s, d_work, d_x, d_y);
+        if (helpers == 7) hipLaunchKernelGGL(chain_block_kernel<7>, dim3(nw), dim3(64 * 8), 0, s, d_work, d_x, d_y, d_score, d_parent, d_gm, d_ev, feed);
+        else if (helpers == 5) hipLaunchKernelGGL(chain_block_kernel<5>, dim3(nw), dim3(64 * 6), 0, s, d_work, d_x, d_y, d_score, d_parent, d_gm, d_ev, feed);
+        else hipLaunchKernelGGL(chain_block_kernel<kCbHelpers>, dim3(nw), dim3(64 * (1 + kCbHelpers)), 0, s, d_work, d_x, d_y, d_score, d_parent, d_gm, d_ev, feed);
     }
 }
 
@@ -1334,6 +1438,119 @@ static int chain_run_overlapped(gab_chain *h, int mode, const uint64_t *x, const
     return GAB_OK;
 }
 
+// gab_chain_run for a big batch on page-locked arrays.  A call's workgroup can start as soon as ITS anchors are on the device,
+// and the batch takes at least as long as its longest call, so the anchors should arrive longest call first -- an order the
+// copy engines cannot follow (20 000 pieces of ~0.3 MB: a third of their rate) but a kernel can: chain_gather_kernel reads
+// the caller's arrays over the bus in that order and publishes a word per call; ONE launch of the DP kernel (its workgroups
+// are dispatched in the same order) waits per call; results are written through to the caller's arrays block by block.
+// The DP kernel is launched only after every workgroup of the gather kernel has reported in (they are resident then and
+// cannot be locked out by waiting workgroups), and a wait gives up after seconds, so the grid drains in every case.
+// Returns GAB_EAGAIN-like 1 when the arrays are not device-accessible (the caller takes the copy-engine path).
+static int chain_run_fed(gab_chain *h, int mode, const uint64_t *x, const uint64_t *y, const int64_t *call_off,
+                         const gab_chain_hdr *hdr, int64_t ncalls, int64_t total, int32_t *score_out, int32_t *parent_out,
+                         hipStream_t sA) {
+    void *hx = nullptr, *hy = nullptr, *hs = nullptr, *hp = nullptr;
+    if (hipHostGetDevicePointer(&hx, (void *)x, 0) != hipSuccess || hipHostGetDevicePointer(&hy, (void *)y, 0) != hipSuccess ||
+        hipHostGetDevicePointer(&hs, (void *)score_out, 0) != hipSuccess || hipHostGetDevicePointer(&hp, (void *)parent_out, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        return 1;
+    }
+    h->have_stats = false;
+    const size_t t = (size_t)total;
+    char *b = h->io.as<char>();
+    uint64_t *dx = (uint64_t *)b, *dy = (uint64_t *)(b + 8 * t);
+    int32_t *ds = (int32_t *)(b + 16 * t), *dp = (int32_t *)(b + 20 * t);
+    if (!h->xs[0] && hipStreamCreateWithFlags(&h->xs[0], hipStreamNonBlocking) != hipSuccess) { gab_set_error("gab_chain_run: stream creation failed"); return GAB_EDEVICE; }
+    hipStream_t sG = h->xs[0];
+    constexpr int kGatherBlocks = 256;
+    if (!h->h_started && hipHostMalloc((void **)&h->h_started, kGatherBlocks + 64) != hipSuccess) { gab_set_error("gab_chain_run: pinned allocation failed"); return GAB_EDEVICE; }
+    // work list, longest call first, and its chunk table
+    std::vector<ChainWork> wk;
+    wk.reserve((size_t)ncalls);
+    for (int64_t c = 0; c < ncalls; c++) if (hdr[c].n) wk.push_back(chain_work_of(hdr[c], call_off[c]));
+    std::stable_sort(wk.begin(), wk.end(), [](const ChainWork &a, const ChainWork &c) { return a.n > c.n; });
+    const size_t nw = wk.size();
+    std::vector<ChainChunk> chunks;
+    std::vector<uint32_t> need(nw);
+    chunks.reserve(t / kFeedChunk + nw);
+    for (size_t k = 0; k < nw; k++) {
+        need[k] = (uint32_t)((wk[k].n + kFeedChunk - 1) / kFeedChunk);
+        for (int64_t o = 0; o < wk[k].n; o += kFeedChunk)
+            chunks.push_back(ChainChunk{wk[k].off + o, (int32_t)std::min<int64_t>(kFeedChunk, wk[k].n - o), (int32_t)k});
+    }
+    GAB_CHECK(chunks.size() < (1ull << 32), "gab_chain_run: too many chunks");
+    // device scratch: work | evals, abort | facts | done | need | mixed | xlo | xhi | chunks
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t o_ev = up(sizeof(ChainWork) * nw), o_facts = o_ev + 256, o_done = o_facts + up(4 * nw), o_need = o_done + up(4 * nw),
+                 o_mixed = o_need + up(4 * nw), o_xlo = o_mixed + up(4 * nw), o_xhi = o_xlo + up(8 * nw), o_chunks = o_xhi + up(8 * nw);
+    int rc = h->work.reserve(o_chunks + sizeof(ChainChunk) * chunks.size());
+    if (rc) return rc;
+    char *wb = h->work.as<char>();
+    ChainWork *d_work = (ChainWork *)wb;
+    unsigned long long *d_ev = (unsigned long long *)(wb + o_ev);
+    uint32_t *d_abort = (uint32_t *)(wb + o_ev + 16);
+    int32_t *d_gm = nullptr;
+    if (mode == GAB_CHAIN) {
+        if ((rc = h->gmarks.reserve(sizeof(int32_t) * t)) != GAB_OK) return rc;
+        d_gm = h->gmarks.as<int32_t>();
+    }
+    const bool trace = getenv("GAB_CHAIN_TRACE") != nullptr;
+    hipEvent_t tv[4] = {};
+    if (trace) for (auto &e : tv) (void)hipEventCreate(&e);
+    // ---- gather stream
+    GAB_HIP(hipEventRecord(h->ev[0], sA));
+    if (trace) (void)hipEventRecord(tv[0], sG);
+    GAB_HIP(hipMemsetAsync(wb + o_ev, 0, o_xlo - o_ev, sG));                       // evals, abort, facts, done, (need), mixed
+    GAB_HIP(hipMemsetAsync(wb + o_xlo, 0xff, o_xhi - o_xlo, sG));
+    GAB_HIP(hipMemsetAsync(wb + o_xhi, 0, o_chunks - o_xhi, sG));
+    GAB_HIP(hipMemcpyAsync(d_work, wk.data(), sizeof(ChainWork) * nw, hipMemcpyHostToDevice, sG));
+    GAB_HIP(hipMemcpyAsync(wb + o_need, need.data(), 4 * nw, hipMemcpyHostToDevice, sG));
+    GAB_HIP(hipMemcpyAsync(wb + o_chunks, chunks.data(), sizeof(ChainChunk) * chunks.size(), hipMemcpyHostToDevice, sG));
+    if (d_gm) GAB_HIP(hipMemsetAsync(d_gm, 0, sizeof(int32_t) * t, sG));            // vector::resize zero-fills targets
+    memset(h->h_started, 0, kGatherBlocks);
+    void *d_started = nullptr;
+    GAB_HIP(hipHostGetDevicePointer(&d_started, h->h_started, 0));
+    GAB_HIP(hipEventRecord(h->xe_fed, sG));                                         // tables and zeroed arrays are in place
+    hipLaunchKernelGGL(chain_gather_kernel, dim3(kGatherBlocks), dim3(256), 0, sG, (const ChainChunk *)(wb + o_chunks), (uint32_t)chunks.size(),
+                       (const uint64_t *)hx, (const uint64_t *)hy, dx, dy, (const ChainWork *)d_work, (const uint32_t *)(wb + o_need),
+                       (uint32_t *)(wb + o_done), (unsigned long long *)(wb + o_xlo), (unsigned long long *)(wb + o_xhi),
+                       (uint32_t *)(wb + o_mixed), (uint32_t *)(wb + o_facts), (volatile uint8_t *)d_started, kGapTab - 2);
+    GAB_HIP(hipGetLastError());
+    if (trace) (void)hipEventRecord(tv[1], sG);
+    // ---- wait until every gather workgroup is resident (they all start at once on an idle GPU: tens of microseconds);
+    // if that does not happen in time, let the gather finish first -- the DP kernel then finds every word published
+    {
+        const auto t0 = std::chrono::steady_clock::now();
+        bool all = false;
+        while (!all) {
+            all = true;
+            for (int k = 0; k < kGatherBlocks; k++) if (!((volatile uint8_t *)h->h_started)[k]) { all = false; break; }
+            if (!all && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) break;
+        }
+        if (!all) GAB_HIP(hipStreamSynchronize(sG));
+    }
+    // ---- the DP: one launch, its workgroups wait for their call
+    GAB_HIP(hipStreamWaitEvent(sA, h->xe_fed, 0));
+    ChainFeed feed{(uint32_t *)(wb + o_facts), (int32_t *)hs, (int32_t *)hp, d_abort};
+    if (trace) (void)hipEventRecord(tv[2], sA);
+    chain_launch(mode, 3, sA, d_work, (unsigned)nw, dx, dy, ds, dp, d_gm, d_ev, &feed);
+    GAB_HIP(hipGetLastError());
+    if (trace) (void)hipEventRecord(tv[3], sA);
+    GAB_HIP(hipEventRecord(h->ev[1], sA));
+    GAB_HIP(hipMemcpyAsync(h->h_evals, d_ev, 2 * sizeof(unsigned long long) + 8, hipMemcpyDeviceToHost, sA));
+    GAB_HIP(hipStreamSynchronize(sG));
+    GAB_HIP(hipStreamSynchronize(sA));            // (the host vectors must outlive their copies)
+    if (trace) {
+        float a = 0, c = 0;
+        (void)hipEventElapsedTime(&a, tv[0], tv[1]); (void)hipEventElapsedTime(&c, tv[0], tv[3]);
+        fprintf(stderr, "[gab_chain_run] fed: %zu calls in %zu chunks; all anchors on the device after %.1f ms, DP done after %.1f ms\n", nw, chunks.size(), a, c);
+        for (auto &e : tv) (void)hipEventDestroy(e);
+    }
+    GAB_CHECK(((uint32_t *)h->h_evals)[4] == 0, "gab_chain_run: the DP kernel gave up waiting for its anchors");
+    h->have_stats = true;
+    return GAB_OK;
+}
+
 extern "C" int gab_chain_run(gab_chain *h, int mode, const uint64_t *x, const uint64_t *y,
                              const int64_t *call_off, const gab_chain_hdr *hdr, int64_t ncalls,
                              int32_t *score_out, int32_t *parent_out) {
@@ -1355,8 +1572,15 @@ extern "C" int gab_chain_run(gab_chain *h, int mode, const uint64_t *x, const ui
     int32_t *ds = (int32_t *)(b + 16 * t), *dp = (int32_t *)(b + 20 * t);
     hipStream_t s = nullptr;
     if ((rc = h->hs.get(&s)) != GAB_OK) return rc;
-    if (total >= ((int64_t)8 << 20) && ncalls >= 1024 && ncalls < (1ll << 31) && !getenv("GAB_CHAIN_NO_OVERLAP"))
+    // (GAB_CHAIN_FEED_MIN: tests push small batches through the big-batch paths)
+    const int64_t big = getenv("GAB_CHAIN_FEED_MIN") ? atoll(getenv("GAB_CHAIN_FEED_MIN")) : ((int64_t)8 << 20);
+    if (total >= big && (ncalls >= 1024 || getenv("GAB_CHAIN_FEED_MIN")) && ncalls < (1ll << 31) && !getenv("GAB_CHAIN_NO_OVERLAP")) {
+        if (!getenv("GAB_CHAIN_NO_FEED") && !(getenv("GAB_CHAIN_KERNEL") && !strcmp(getenv("GAB_CHAIN_KERNEL"), "walk"))) {
+            rc = chain_run_fed(h, mode, x, y, call_off, hdr, ncalls, total, score_out, parent_out, s);
+            if (rc != 1) return rc;               // 1: the arrays are not page-locked
+        }
         return chain_run_overlapped(h, mode, x, y, call_off, hdr, ncalls, total, score_out, parent_out, s);
+    }
     GAB_HIP(hipMemcpyAsync(dx, x, 8 * t, hipMemcpyHostToDevice, s));
     GAB_HIP(hipMemcpyAsync(dy, y, 8 * t, hipMemcpyHostToDevice, s));
     rc = gab_chain_run_device(h, mode, dx, dy, call_off, hdr, ncalls, ds, dp, s);

@@ -55,6 +55,27 @@ def test_every_helper_count(eng, mode, helpers, monkeypatch):
         np.testing.assert_array_equal(p, wp)
 
 
+@pytest.mark.parametrize("pinned", [True, False])
+@pytest.mark.parametrize("mode", [0, 1])
+def test_big_batch_host_paths(eng, mode, pinned, monkeypatch):
+    """gab_chain_run on big batches: page-locked arrays take the fed path (a kernel fetches the anchors longest call first,
+    the DP workgroups wait per call and write their results through to the host arrays), pageable ones the copy-engine
+    path with three streams; the threshold is lowered so that both run here, on calls that miss the block kernel's
+    per-call shortcuts as well (several segment ids, x spread over more than 2^31, wide bands)"""
+    monkeypatch.setenv("GAB_CHAIN_FEED_MIN", "1000")
+    rng = np.random.default_rng(23)
+    Y = lambda q, span=15, seg=0: (np.uint64(seg) << np.uint64(48)) | (np.uint64(span) << np.uint64(32)) | np.uint64(q)
+    x = np.sort(np.concatenate([rng.integers(0, 20000, 1500), (1 << 33) + rng.integers(0, 20000, 1500)])).astype(np.uint64)
+    q = (x.astype(np.int64) % 20000 + rng.integers(-30, 30, 3000)).clip(0)
+    odd = gabgen.chain_from_calls([(15.0, 5000, 5000, 500, 3, x, np.array([Y(int(v), 15, int(g)) for v, g in zip(q, rng.integers(0, 3, 3000))], np.uint64)),
+                                   (15.0, 5000, 5000, 3000, 1, x % np.uint64(50000), np.array([Y(int(v)) for v in q], np.uint64))])
+    for batch in (gabgen.chain(37, 300, 0, 1, 20000), gabgen.chain(38, 40, 1, 500, 9000), odd):
+        ws, wp = pyoracle.chain(batch, mode)
+        s, p = eng.host_chain_kernel(batch, mode, pinned=pinned)
+        np.testing.assert_array_equal(s, ws)
+        np.testing.assert_array_equal(p, wp)
+
+
 @pytest.mark.parametrize("mode", [0, 1])
 def test_gap_cost_table_limits(eng, mode):
     """the block kernels read the gap cost of a pair from a per-call table of bw + 2 entries when 0 <= bw <= 2046 and
