@@ -41,9 +41,10 @@ constexpr int kMaxSkip = 25;
 constexpr int kMarkRing = 1024;           // LDS ring of mark tags for the newest anchors; older marks go to global memory
 
 struct ChainWork {                        // one call, device-side descriptor
-    int64_t off, n;
+    int64_t off, n;                       // first anchor in the DEVICE arrays (x, y, score, parent, marks), number of anchors
     float avg_qspan;
     int32_t max_dist_x, max_dist_y, bw, n_segs, pad;
+    int64_t hoff;                         // first anchor in the caller's arrays (= off except in the fed path, which pads calls to lines)
 };
 
 // ---- the host-pointer path of big batches: the anchors come in by a KERNEL, longest call first -----------------------
@@ -53,8 +54,9 @@ struct ChainFeed {
     uint32_t *facts;                          // per work item: 0 = anchors not here yet; 2 | (plain ? 1 : 0) once they are
     int32_t *host_score, *host_parent;        // device addresses of the caller's result arrays
     uint32_t *abort;                          // set by a wait that gave up; every other wait then gives up too
+    unsigned long long *dbg;                  // diagnosis (GAB_CHAIN_TRACE): per work item wall-clock ticks at start / ready / done
 };
-struct ChainChunk { int64_t off; int32_t n, item; };          // up to kFeedChunk anchors of work item `item`
+struct ChainChunk { int64_t hoff, doff; int32_t n, item; };   // up to kFeedChunk anchors of work item `item`: where they are, where they go
 constexpr int kFeedChunk = 2048;
 constexpr long kFeedSpinLimit = 4000000;      // x ~1 us of s_sleep: a wait gives up after seconds, so the grid always drains
 
@@ -74,9 +76,11 @@ __device__ __forceinline__ uint32_t chain_feed_wait(const ChainFeed &feed, uint3
         *s_word = f;
     }
     __syncthreads();
-    // the anchors were written by another kernel while this CU may hold older copies of their cache lines (a neighbouring
-    // call's tail shares a line with this call's head): acquire at agent scope drops them
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    // No cache of this XCD can hold an older copy of the call's lines: the fed path starts every call on a 128-byte line of the
+    // device arrays, nothing but this workgroup reads them, and the gather kernel stores write-through.  (An agent-scope
+    // acquire here -- and __threadfence() in the gather kernel -- invalidates / writes back the whole L2 of the XCD: with
+    // 10 000 workgroups and 48 000 chunks doing that, the DP ran at 0.42 of its speed while the anchors came in.)
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     return *s_word;
 }
 
@@ -95,36 +99,49 @@ __global__ __launch_bounds__(256) void chain_gather_kernel(const ChainChunk *__r
     for (uint32_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
         const ChainChunk ch = chunks[c];
         const ChainWork w = work[ch.item];
-        const uint32_t sid0 = (uint32_t)(hy[w.off] >> 48 & 0xff);
+        const uint32_t sid0 = (uint32_t)(hy[w.hoff] >> 48 & 0xff);
         unsigned long long lo = ~0ull, hi = 0;
         uint32_t mx = 0;
-        for (int i = threadIdx.x; i < ch.n; i += 256) {
-            const uint64_t x = hx[ch.off + i], y = hy[ch.off + i];
-            dx[ch.off + i] = x; dy[ch.off + i] = y;
-            lo = x < lo ? x : lo; hi = x > hi ? x : hi;
-            mx |= ((uint32_t)(y >> 48 & 0xff) != sid0) ? 1u : 0u;
+        // all loads of the chunk first (16 per thread): the bus needs megabytes in flight, not one load per thread
+        constexpr int kPer = kFeedChunk / 256;
+        uint64_t xv[kPer], yv[kPer];
+#pragma unroll
+        for (int k = 0; k < kPer; k++) {
+            const int i = threadIdx.x + 256 * k, ii = i < ch.n ? i : 0;
+            xv[k] = hx[ch.hoff + ii]; yv[k] = hy[ch.hoff + ii];
+        }
+#pragma unroll
+        for (int k = 0; k < kPer; k++) {
+            const int i = threadIdx.x + 256 * k;
+            if (i < ch.n) {
+                const uint64_t x = xv[k], y = yv[k];
+                // write-through (device-scope) stores: the reader sits on any XCD, and the L2 of this one is not its L2
+                __hip_atomic_store(&dx[ch.doff + i], x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&dy[ch.doff + i], y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                lo = x < lo ? x : lo; hi = x > hi ? x : hi;
+                mx |= ((uint32_t)(y >> 48 & 0xff) != sid0) ? 1u : 0u;
+            }
         }
         for (int o = 32; o > 0; o >>= 1) {
             const unsigned long long l2 = __shfl_xor(lo, o), h2 = __shfl_xor(hi, o);
             lo = l2 < lo ? l2 : lo; hi = h2 > hi ? h2 : hi; mx |= __shfl_xor(mx, o);
         }
         if ((threadIdx.x & 63) == 0) { s_lo[threadIdx.x >> 6] = lo; s_hi[threadIdx.x >> 6] = hi; s_mx[threadIdx.x >> 6] = mx; }
-        __threadfence();                                      // this thread's anchors are visible device-wide ...
-        __syncthreads();                                      // ... and so are everybody's, before thread 0 counts the chunk
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // this wave's stores have completed (at the device's coherence point) ...
+        __syncthreads();                                         // ... and so have everybody's, before thread 0 counts the chunk
         if (threadIdx.x == 0) {
             for (int k = 1; k < 4; k++) { lo = s_lo[k] < lo ? s_lo[k] : lo; hi = s_hi[k] > hi ? s_hi[k] : hi; mx |= s_mx[k]; }
             atomicMin(&xlo[ch.item], lo); atomicMax(&xhi[ch.item], hi);
             if (mx) atomicOr(&mixed[ch.item], 1u);
-            __threadfence();
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");          // the three have been performed before the chunk is counted
             if (atomicAdd(&done[ch.item], 1u) + 1u == need[ch.item]) {
-                __threadfence();
                 const unsigned long long L = __hip_atomic_load(&xlo[ch.item], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
                                          H = __hip_atomic_load(&xhi[ch.item], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const uint32_t M = __hip_atomic_load(&mixed[ch.item], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const int32_t mq = w.max_dist_y < w.max_dist_x ? w.max_dist_y : w.max_dist_x;
                 const unsigned long long lim = mq < 0 ? 0ull : (unsigned long long)mq;
                 const bool plain = w.n > 0 && !M && H - L + lim < 0x7fffffffull && w.bw >= 0 && w.bw <= gap_tab_max;   // = chain_facts_kernel
-                __hip_atomic_store(&facts[ch.item], 2u | (plain ? 1u : 0u), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&facts[ch.item], 2u | (plain ? 1u : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
         __syncthreads();
@@ -768,7 +785,7 @@ __global__ __launch_bounds__(64 * (1 + H)) void fastchain_kernel(const ChainWork
             if (mine) {
                 const int32_t par_ = have ? (int32_t)(i0 + best_j) : -1;
                 S[i0 + lane] = best; P[i0 + lane] = par_;
-                if (feed.host_score) { feed.host_score[w.off + i0 + lane] = best; feed.host_parent[w.off + i0 + lane] = par_; }
+                if (feed.host_score) { feed.host_score[w.hoff + i0 + lane] = best; feed.host_parent[w.hoff + i0 + lane] = par_; }
             }
             pxa = xa; pya = ya; pbest = best; pnb = nb;
         }
@@ -954,7 +971,9 @@ __global__ __launch_bounds__(64 * (1 + H)) void chain_block_kernel(const ChainWo
     __shared__ int32_t part_best[2][H][64], part_j[2][H][64], part_ok[2][H][64], part_st[2][64];
     __shared__ uint32_t feed_word;
     uint32_t fed_facts = 0;
+    if (feed.dbg && threadIdx.x == 0) feed.dbg[3 * blockIdx.x] = wall_clock64();
     if (feed.facts && (fed_facts = chain_feed_wait(feed, &feed_word)) == 0) return;
+    if (feed.dbg && threadIdx.x == 0) feed.dbg[3 * blockIdx.x + 1] = wall_clock64();
     const ChainWork w = work[blockIdx.x];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint64_t *X = xs + w.off, *Y = ys + w.off;
@@ -1147,7 +1166,7 @@ __global__ __launch_bounds__(64 * (1 + H)) void chain_block_kernel(const ChainWo
             if (mine) {
                 const int32_t par_ = best_j == kNoJ ? -1 : i0 + best_j;
                 S[i0 + lane] = best; P[i0 + lane] = par_;
-                if (feed.host_score) { feed.host_score[w.off + i0 + lane] = best; feed.host_parent[w.off + i0 + lane] = par_; }
+                if (feed.host_score) { feed.host_score[w.hoff + i0 + lane] = best; feed.host_parent[w.hoff + i0 + lane] = par_; }
             }
             prev = cur; pbest = best; pnb = nb;
         }
@@ -1155,6 +1174,7 @@ __global__ __launch_bounds__(64 * (1 + H)) void chain_block_kernel(const ChainWo
     }
     for (int o = 32; o > 0; o >>= 1) evals += __shfl_xor(evals, o);
     if (lane == 0 && evals) atomicAdd(evals_out, evals);
+    if (feed.dbg && threadIdx.x == 0) feed.dbg[3 * blockIdx.x + 2] = wall_clock64();
 }
 
 }  // namespace
@@ -1232,7 +1252,7 @@ static int chain_helpers_for(int64_t total_anchors, int64_t longest_call) {
 // the kernels of one work list (already on the device) on `s`; nothing else (no memset, no synchronisation)
 static void chain_launch(int mode, int helpers, hipStream_t s, ChainWork *d_work, unsigned nw, const uint64_t *d_x, const uint64_t *d_y,
                          int32_t *d_score, int32_t *d_parent, int32_t *d_gm, unsigned long long *d_ev, const ChainFeed *feed_in = nullptr) {
-    const ChainFeed feed = feed_in ? *feed_in : ChainFeed{nullptr, nullptr, nullptr, nullptr};
+    const ChainFeed feed = feed_in ? *feed_in : ChainFeed{nullptr, nullptr, nullptr, nullptr, nullptr};
     if (nw == 0) return;
     if (mode == GAB_FASTCHAIN) {
         if (helpers == 7) hipLaunchKernelGGL(fastchain_kernel<7>, dim3(nw), dim3(64 * 8), 0, s, d_work, d_x, d_y, d_score, d_parent, d_ev, feed);
@@ -1250,7 +1270,7 @@ static void chain_launch(int mode, int helpers, hipStream_t s, ChainWork *d_work
 
 static ChainWork chain_work_of(const gab_chain_hdr &hd, int64_t off) {
     ChainWork w;
-    w.off = off; w.n = hd.n; w.avg_qspan = hd.avg_qspan;
+    w.off = w.hoff = off; w.n = hd.n; w.avg_qspan = hd.avg_qspan;
     w.max_dist_x = hd.max_dist_x; w.max_dist_y = hd.max_dist_y; w.bw = hd.bw; w.n_segs = hd.n_segs; w.pad = 0;
     return w;
 }
@@ -1277,7 +1297,7 @@ extern "C" int gab_chain_run_device(gab_chain *h, int mode, const uint64_t *d_x,
     for (int64_t c = 0; c < ncalls; c++) {
         if (hdr[c].n == 0) continue;
         ChainWork w;
-        w.off = call_off[c]; w.n = hdr[c].n; w.avg_qspan = hdr[c].avg_qspan;
+        w.off = w.hoff = call_off[c]; w.n = hdr[c].n; w.avg_qspan = hdr[c].avg_qspan;
         w.max_dist_x = hdr[c].max_dist_x; w.max_dist_y = hdr[c].max_dist_y; w.bw = hdr[c].bw;
         w.n_segs = hdr[c].n_segs; w.pad = 0;
         wk.push_back(w);
@@ -1456,15 +1476,12 @@ static int chain_run_fed(gab_chain *h, int mode, const uint64_t *x, const uint64
         return 1;
     }
     h->have_stats = false;
-    const size_t t = (size_t)total;
-    char *b = h->io.as<char>();
-    uint64_t *dx = (uint64_t *)b, *dy = (uint64_t *)(b + 8 * t);
-    int32_t *ds = (int32_t *)(b + 16 * t), *dp = (int32_t *)(b + 20 * t);
     if (!h->xs[0] && hipStreamCreateWithFlags(&h->xs[0], hipStreamNonBlocking) != hipSuccess) { gab_set_error("gab_chain_run: stream creation failed"); return GAB_EDEVICE; }
     hipStream_t sG = h->xs[0];
     constexpr int kGatherBlocks = 256;
     if (!h->h_started && hipHostMalloc((void **)&h->h_started, kGatherBlocks + 64) != hipSuccess) { gab_set_error("gab_chain_run: pinned allocation failed"); return GAB_EDEVICE; }
-    // work list, longest call first, and its chunk table
+    // work list, longest call first; on the device every call starts on a 128-byte line (16 anchors), so that no cache line is
+    // shared between calls (see chain_feed_wait); and the chunk table
     std::vector<ChainWork> wk;
     wk.reserve((size_t)ncalls);
     for (int64_t c = 0; c < ncalls; c++) if (hdr[c].n) wk.push_back(chain_work_of(hdr[c], call_off[c]));
@@ -1472,19 +1489,27 @@ static int chain_run_fed(gab_chain *h, int mode, const uint64_t *x, const uint64
     const size_t nw = wk.size();
     std::vector<ChainChunk> chunks;
     std::vector<uint32_t> need(nw);
-    chunks.reserve(t / kFeedChunk + nw);
+    chunks.reserve((size_t)total / kFeedChunk + nw);
+    int64_t dtotal = 0;
     for (size_t k = 0; k < nw; k++) {
+        wk[k].off = dtotal;
+        dtotal += (wk[k].n + 15) & ~(int64_t)15;
         need[k] = (uint32_t)((wk[k].n + kFeedChunk - 1) / kFeedChunk);
         for (int64_t o = 0; o < wk[k].n; o += kFeedChunk)
-            chunks.push_back(ChainChunk{wk[k].off + o, (int32_t)std::min<int64_t>(kFeedChunk, wk[k].n - o), (int32_t)k});
+            chunks.push_back(ChainChunk{wk[k].hoff + o, wk[k].off + o, (int32_t)std::min<int64_t>(kFeedChunk, wk[k].n - o), (int32_t)k});
     }
+    const size_t t = (size_t)dtotal;
+    int rc = h->io.reserve(24 * t + 64);
+    if (rc) return rc;
+    char *b = h->io.as<char>();
+    uint64_t *dx = (uint64_t *)b, *dy = (uint64_t *)(b + 8 * t);
+    int32_t *ds = (int32_t *)(b + 16 * t), *dp = (int32_t *)(b + 20 * t);
     GAB_CHECK(chunks.size() < (1ull << 32), "gab_chain_run: too many chunks");
     // device scratch: work | evals, abort | facts | done | need | mixed | xlo | xhi | chunks
     auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
     const size_t o_ev = up(sizeof(ChainWork) * nw), o_facts = o_ev + 256, o_done = o_facts + up(4 * nw), o_need = o_done + up(4 * nw),
                  o_mixed = o_need + up(4 * nw), o_xlo = o_mixed + up(4 * nw), o_xhi = o_xlo + up(8 * nw), o_chunks = o_xhi + up(8 * nw);
-    int rc = h->work.reserve(o_chunks + sizeof(ChainChunk) * chunks.size());
-    if (rc) return rc;
+    if ((rc = h->work.reserve(o_chunks + sizeof(ChainChunk) * chunks.size())) != GAB_OK) return rc;
     char *wb = h->work.as<char>();
     ChainWork *d_work = (ChainWork *)wb;
     unsigned long long *d_ev = (unsigned long long *)(wb + o_ev);
@@ -1531,7 +1556,10 @@ static int chain_run_fed(gab_chain *h, int mode, const uint64_t *x, const uint64
     }
     // ---- the DP: one launch, its workgroups wait for their call
     GAB_HIP(hipStreamWaitEvent(sA, h->xe_fed, 0));
-    ChainFeed feed{(uint32_t *)(wb + o_facts), (int32_t *)hs, (int32_t *)hp, d_abort};
+    const bool write_through = true;              // (measured: results by two copies at the end instead cost their 12 ms in full)
+    unsigned long long *d_dbg = nullptr;
+    if (trace && mode == GAB_CHAIN) { (void)hipMalloc((void **)&d_dbg, 24 * nw); (void)hipMemsetAsync(d_dbg, 0, 24 * nw, sA); }
+    ChainFeed feed{(uint32_t *)(wb + o_facts), write_through ? (int32_t *)hs : nullptr, write_through ? (int32_t *)hp : nullptr, d_abort, d_dbg};
     if (trace) (void)hipEventRecord(tv[2], sA);
     chain_launch(mode, 3, sA, d_work, (unsigned)nw, dx, dy, ds, dp, d_gm, d_ev, &feed);
     GAB_HIP(hipGetLastError());
@@ -1545,6 +1573,16 @@ static int chain_run_fed(gab_chain *h, int mode, const uint64_t *x, const uint64
         (void)hipEventElapsedTime(&a, tv[0], tv[1]); (void)hipEventElapsedTime(&c, tv[0], tv[3]);
         fprintf(stderr, "[gab_chain_run] fed: %zu calls in %zu chunks; all anchors on the device after %.1f ms, DP done after %.1f ms\n", nw, chunks.size(), a, c);
         for (auto &e : tv) (void)hipEventDestroy(e);
+        if (d_dbg) {
+            std::vector<unsigned long long> dbg(3 * nw);
+            (void)hipMemcpy(dbg.data(), d_dbg, 24 * nw, hipMemcpyDeviceToHost);
+            unsigned long long t0 = ~0ull;
+            for (size_t k = 0; k < nw; k++) t0 = std::min(t0, dbg[3 * k]);
+            for (size_t k : {(size_t)0, (size_t)50, (size_t)300, (size_t)900, (size_t)1100, (size_t)1300, (size_t)1600, (size_t)2500, (size_t)5000, nw - 1})
+                if (k < nw) fprintf(stderr, "   item %zu (n = %lld): dispatched %.2f ms, anchors there %.2f ms, done %.2f ms\n", k, (long long)wk[k].n,
+                                    (dbg[3 * k] - t0) * 1e-5, (dbg[3 * k + 1] - t0) * 1e-5, (dbg[3 * k + 2] - t0) * 1e-5);
+            (void)hipFree(d_dbg);
+        }
     }
     GAB_CHECK(((uint32_t *)h->h_evals)[4] == 0, "gab_chain_run: the DP kernel gave up waiting for its anchors");
     h->have_stats = true;
@@ -1596,10 +1634,13 @@ extern "C" int gab_chain_reserve(gab_chain *h, int64_t max_anchors, int64_t max_
     GAB_CHECK(h, "gab_chain_reserve: NULL handle");
     GAB_CHECK(max_anchors >= 0 && max_calls >= 0 && max_calls < (1ll << 31), "gab_chain_reserve: size out of range");
     gab_device_guard g(h->device);
-    int rc = h->io.reserve(std::max<size_t>(24 * (size_t)max_anchors + 64, (size_t)4 << 20));      // (at least the 4 MB gab_warm_copy_engines moves)
+    // (the fed path of gab_chain_run starts every call on a line of 16 anchors and keeps its per-call words and its chunk table
+    // behind the work list)
+    const size_t padded = (size_t)max_anchors + 16 * (size_t)max_calls;
+    int rc = h->io.reserve(std::max<size_t>(24 * padded + 64, (size_t)4 << 20));      // (at least the 4 MB gab_warm_copy_engines moves)
     if (rc) return rc;
-    if ((rc = h->gmarks.reserve(sizeof(int32_t) * (size_t)max_anchors + 64)) != GAB_OK) return rc;
-    if ((rc = h->work.reserve(sizeof(ChainWork) * (size_t)max_calls + 64)) != GAB_OK) return rc;
+    if ((rc = h->gmarks.reserve(sizeof(int32_t) * padded + 64)) != GAB_OK) return rc;
+    if ((rc = h->work.reserve((sizeof(ChainWork) + 32 + 7 * 256 / 8) * (size_t)max_calls + sizeof(ChainChunk) * ((size_t)max_anchors / kFeedChunk + (size_t)max_calls) + 4096)) != GAB_OK) return rc;
     hipStream_t s = nullptr;
     if ((rc = h->hs.get(&s)) != GAB_OK) return rc;
     GAB_HIP(hipMemsetAsync(h->io.p, 0, h->io.cap, s));
