@@ -381,7 +381,8 @@ class ChainWorkload:
             "host-pointer path and device path disagree"
         return {"ms": round(sec * 1e3, 3), "value": round(b.nanchors / sec / 1e6, 3), "unit": self.unit, "chunks": len(beg) - 1,
                 "workers_per_gpu": HOST_WORKERS,
-                "note": "gab_chain_run on page-locked host arrays (the C driver's ROI): H2D of x, y + kernel + D2H of scores, parents; "
+                "note": "gab_chain_run on page-locked host arrays (the C driver's ROI): a kernel fetches x, y longest call first, the DP "
+                        "workgroups wait per call and write scores, parents through; "
                         "all results equal to the device path's"}
 
     def cpu_baseline(self, cores):
