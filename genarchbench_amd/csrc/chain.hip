@@ -590,15 +590,18 @@ __global__ __launch_bounds__(64 * (1 + kChHelpers)) void chain_hw_kernel(const C
 // One __syncthreads per block hands the results of block t to the helpers (global scores, acknowledged by L2) and the
 // partial maxima of block t+1 to the main wave (LDS).
 constexpr int kFcHelpers = 3;
+// anchors as the DP kernels see them: __restrict__ (loads may move across the kernel's own stores) except in the fed variant,
+// where another kernel writes them while this one waits
+template <bool FED> struct AnchorPtr { using type = const uint64_t *__restrict__; };
+template <> struct AnchorPtr<true> { using type = const uint64_t *; };
 constexpr int kGapTab = 2048;             // entries of the per-call gap-cost table (LDS, int32): bw + 2 of them are used
-template <int H>
-__global__ __launch_bounds__(64 * (1 + H)) void fastchain_kernel(const ChainWork *__restrict__ work, const uint64_t *xs, const uint64_t *ys,
-                                                                          int32_t *score_out, int32_t *parent_out,
-                                                                          unsigned long long *evals_out, ChainFeed feed) {
-    // (xs / ys are not __restrict__: in the fed variant another kernel writes them while this one waits)
+template <int H, bool FED>
+__device__ __forceinline__ void fastchain_body(const ChainWork *__restrict__ work, typename AnchorPtr<FED>::type xs,
+                                               typename AnchorPtr<FED>::type ys, int32_t *score_out, int32_t *parent_out,
+                                               unsigned long long *evals_out, ChainFeed feed) {
     __shared__ int32_t part_best[2][H][64], part_j[2][H][64], part_st[2][64];
     __shared__ uint32_t feed_word;
-    if (feed.facts && chain_feed_wait(feed, &feed_word) == 0) return;
+    if (FED && chain_feed_wait(feed, &feed_word) == 0) return;
     const ChainWork w = work[blockIdx.x];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave index: uniform, say so
     const uint64_t *X = xs + w.off, *Y = ys + w.off;
@@ -785,7 +788,7 @@ __global__ __launch_bounds__(64 * (1 + H)) void fastchain_kernel(const ChainWork
             if (mine) {
                 const int32_t par_ = have ? (int32_t)(i0 + best_j) : -1;
                 S[i0 + lane] = best; P[i0 + lane] = par_;
-                if (feed.host_score) { feed.host_score[w.hoff + i0 + lane] = best; feed.host_parent[w.hoff + i0 + lane] = par_; }
+                if (FED) { feed.host_score[w.hoff + i0 + lane] = best; feed.host_parent[w.hoff + i0 + lane] = par_; }
             }
             pxa = xa; pya = ya; pbest = best; pnb = nb;
         }
@@ -793,6 +796,20 @@ __global__ __launch_bounds__(64 * (1 + H)) void fastchain_kernel(const ChainWork
     }
     for (int o = 32; o > 0; o >>= 1) evals += __shfl_xor(evals, o);
     if (lane == 0 && evals) atomicAdd(evals_out, evals);
+}
+
+// throughput form (three helpers): seven waves per SIMD, +3.7 %; latency form: no register cap (see chain_block_kernel)
+template <int H, bool FED>
+__global__ __launch_bounds__(64 * (1 + H)) __attribute__((amdgpu_waves_per_eu(7, 7)))
+void fastchain_kernel(const ChainWork *__restrict__ work, typename AnchorPtr<FED>::type xs, typename AnchorPtr<FED>::type ys, int32_t *score_out,
+                      int32_t *parent_out, unsigned long long *evals_out, ChainFeed feed) {
+    fastchain_body<H, FED>(work, xs, ys, score_out, parent_out, evals_out, feed);
+}
+template <int H, bool FED>
+__global__ __launch_bounds__(64 * (1 + H))
+void fastchain_kernel_lat(const ChainWork *__restrict__ work, typename AnchorPtr<FED>::type xs, typename AnchorPtr<FED>::type ys, int32_t *score_out,
+                          int32_t *parent_out, unsigned long long *evals_out, ChainFeed feed) {
+    fastchain_body<H, FED>(work, xs, ys, score_out, parent_out, evals_out, feed);
 }
 
 
@@ -963,17 +980,16 @@ __device__ __forceinline__ void chain_exact_global(const uint64_t *X, const uint
     best_out = best; bestj_out = best_j;
 }
 
-template <int H>
-__global__ __launch_bounds__(64 * (1 + H)) void chain_block_kernel(const ChainWork *__restrict__ work, const uint64_t *xs, const uint64_t *ys,
-                                                                            int32_t *score_out, int32_t *parent_out, int32_t *gmarks_all,
-                                                                            unsigned long long *evals_out, ChainFeed feed) {
-    // (xs / ys are not __restrict__: in the fed variant another kernel writes them while this one waits)
+template <int H, bool FED>
+__device__ __forceinline__ void chain_block_body(const ChainWork *__restrict__ work, typename AnchorPtr<FED>::type xs,
+                                                 typename AnchorPtr<FED>::type ys, int32_t *score_out, int32_t *parent_out,
+                                                 int32_t *gmarks_all, unsigned long long *evals_out, ChainFeed feed) {
     __shared__ int32_t part_best[2][H][64], part_j[2][H][64], part_ok[2][H][64], part_st[2][64];
     __shared__ uint32_t feed_word;
     uint32_t fed_facts = 0;
-    if (feed.dbg && threadIdx.x == 0) feed.dbg[3 * blockIdx.x] = wall_clock64();
-    if (feed.facts && (fed_facts = chain_feed_wait(feed, &feed_word)) == 0) return;
-    if (feed.dbg && threadIdx.x == 0) feed.dbg[3 * blockIdx.x + 1] = wall_clock64();
+    if (FED && feed.dbg && threadIdx.x == 0) feed.dbg[3 * blockIdx.x] = wall_clock64();
+    if (FED && (fed_facts = chain_feed_wait(feed, &feed_word)) == 0) return;
+    if (FED && feed.dbg && threadIdx.x == 0) feed.dbg[3 * blockIdx.x + 1] = wall_clock64();
     const ChainWork w = work[blockIdx.x];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint64_t *X = xs + w.off, *Y = ys + w.off;
@@ -983,7 +999,7 @@ __global__ __launch_bounds__(64 * (1 + H)) void chain_block_kernel(const ChainWo
     const uint64_t mdx64 = (uint64_t)(int64_t)mdx;
     const double avg_d = (double)w.avg_qspan;
     const bool multi_seg = w.n_segs > 1;
-    const bool plain = ((feed.facts ? fed_facts : (uint32_t)w.pad) & 1u) != 0;   // chain_facts_kernel / chain_gather_kernel: one segment id, 32-bit-exact x differences, bw fits the table
+    const bool plain = ((FED ? fed_facts : (uint32_t)w.pad) & 1u) != 0;   // chain_facts_kernel / chain_gather_kernel: one segment id, 32-bit-exact x differences, bw fits the table
     const int32_t mq = mdy < mdx ? mdy : mdx;
     const uint32_t dq_lim = mq < 0 ? 0u : (uint32_t)mq;
     const int nblocks = (n + 63) / 64;
@@ -1166,7 +1182,7 @@ __global__ __launch_bounds__(64 * (1 + H)) void chain_block_kernel(const ChainWo
             if (mine) {
                 const int32_t par_ = best_j == kNoJ ? -1 : i0 + best_j;
                 S[i0 + lane] = best; P[i0 + lane] = par_;
-                if (feed.host_score) { feed.host_score[w.hoff + i0 + lane] = best; feed.host_parent[w.hoff + i0 + lane] = par_; }
+                if (FED) { feed.host_score[w.hoff + i0 + lane] = best; feed.host_parent[w.hoff + i0 + lane] = par_; }
             }
             prev = cur; pbest = best; pnb = nb;
         }
@@ -1174,7 +1190,23 @@ __global__ __launch_bounds__(64 * (1 + H)) void chain_block_kernel(const ChainWo
     }
     for (int o = 32; o > 0; o >>= 1) evals += __shfl_xor(evals, o);
     if (lane == 0 && evals) atomicAdd(evals_out, evals);
-    if (feed.dbg && threadIdx.x == 0) feed.dbg[3 * blockIdx.x + 2] = wall_clock64();
+    if (FED && feed.dbg && threadIdx.x == 0) feed.dbg[3 * blockIdx.x + 2] = wall_clock64();
+}
+
+// Throughput form (three helpers, big batches): six waves per SIMD = six calls per CU -- 80 VGPRs and 84 B of scratch instead
+// of 99 and none; the kernel is bound by resident calls x per-call latency and a sixth call per CU is worth +5 %.
+// Latency form (batches bound by their longest call): no register cap, the spills would lengthen the critical path (3-5 %).
+template <int H, bool FED>
+__global__ __launch_bounds__(64 * (1 + H)) __attribute__((amdgpu_waves_per_eu(6, 6)))
+void chain_block_kernel(const ChainWork *__restrict__ work, typename AnchorPtr<FED>::type xs, typename AnchorPtr<FED>::type ys, int32_t *score_out,
+                        int32_t *parent_out, int32_t *gmarks_all, unsigned long long *evals_out, ChainFeed feed) {
+    chain_block_body<H, FED>(work, xs, ys, score_out, parent_out, gmarks_all, evals_out, feed);
+}
+template <int H, bool FED>
+__global__ __launch_bounds__(64 * (1 + H))
+void chain_block_kernel_lat(const ChainWork *__restrict__ work, typename AnchorPtr<FED>::type xs, typename AnchorPtr<FED>::type ys, int32_t *score_out,
+                            int32_t *parent_out, int32_t *gmarks_all, unsigned long long *evals_out, ChainFeed feed) {
+    chain_block_body<H, FED>(work, xs, ys, score_out, parent_out, gmarks_all, evals_out, feed);
 }
 
 }  // namespace
@@ -1255,16 +1287,21 @@ static void chain_launch(int mode, int helpers, hipStream_t s, ChainWork *d_work
     const ChainFeed feed = feed_in ? *feed_in : ChainFeed{nullptr, nullptr, nullptr, nullptr, nullptr};
     if (nw == 0) return;
     if (mode == GAB_FASTCHAIN) {
-        if (helpers == 7) hipLaunchKernelGGL(fastchain_kernel<7>, dim3(nw), dim3(64 * 8), 0, s, d_work, d_x, d_y, d_score, d_parent, d_ev, feed);
-        else if (helpers == 5) hipLaunchKernelGGL(fastchain_kernel<5>, dim3(nw), dim3(64 * 6), 0, s, d_work, d_x, d_y, d_score, d_parent, d_ev, feed);
-        else hipLaunchKernelGGL(fastchain_kernel<kFcHelpers>, dim3(nw), dim3(64 * (1 + kFcHelpers)), 0, s, d_work, d_x, d_y, d_score, d_parent, d_ev, feed);
+        if (feed.facts) hipLaunchKernelGGL((fastchain_kernel<kFcHelpers, true>), dim3(nw), dim3(64 * (1 + kFcHelpers)), 0, s, d_work, d_x, d_y, d_score, d_parent, d_ev, feed);
+        else if (helpers == 7) hipLaunchKernelGGL((fastchain_kernel_lat<7, false>), dim3(nw), dim3(64 * 8), 0, s, d_work, d_x, d_y, d_score, d_parent, d_ev, feed);
+        else if (helpers == 5) hipLaunchKernelGGL((fastchain_kernel_lat<5, false>), dim3(nw), dim3(64 * 6), 0, s, d_work, d_x, d_y, d_score, d_parent, d_ev, feed);
+        else hipLaunchKernelGGL((fastchain_kernel<kFcHelpers, false>), dim3(nw), dim3(64 * (1 + kFcHelpers)), 0, s, d_work, d_x, d_y, d_score, d_parent, d_ev, feed);
     } else if (getenv("GAB_CHAIN_KERNEL") && !strcmp(getenv("GAB_CHAIN_KERNEL"), "walk"))      // the per-anchor walk (A/B runs)
         hipLaunchKernelGGL(chain_hw_kernel, dim3(nw), dim3(64 * (1 + kChHelpers)), 0, s, d_work, d_x, d_y, d_score, d_parent, d_gm, d_ev);
     else {
-        if (!feed.facts) hipLaunchKernelGGL(chain_facts_kernel, dim3(nw), dim3(256), 0, s, d_work, d_x, d_y);
-        if (helpers == 7) hipLaunchKernelGGL(chain_block_kernel<7>, dim3(nw), dim3(64 * 8), 0, s, d_work, d_x, d_y, d_score, d_parent, d_gm, d_ev, feed);
-        else if (helpers == 5) hipLaunchKernelGGL(chain_block_kernel<5>, dim3(nw), dim3(64 * 6), 0, s, d_work, d_x, d_y, d_score, d_parent, d_gm, d_ev, feed);
-        else hipLaunchKernelGGL(chain_block_kernel<kCbHelpers>, dim3(nw), dim3(64 * (1 + kCbHelpers)), 0, s, d_work, d_x, d_y, d_score, d_parent, d_gm, d_ev, feed);
+        if (feed.facts) {
+            hipLaunchKernelGGL((chain_block_kernel<kCbHelpers, true>), dim3(nw), dim3(64 * (1 + kCbHelpers)), 0, s, d_work, d_x, d_y, d_score, d_parent, d_gm, d_ev, feed);
+            return;
+        }
+        hipLaunchKernelGGL(chain_facts_kernel, dim3(nw), dim3(256), 0, s, d_work, d_x, d_y);
+        if (helpers == 7) hipLaunchKernelGGL((chain_block_kernel_lat<7, false>), dim3(nw), dim3(64 * 8), 0, s, d_work, d_x, d_y, d_score, d_parent, d_gm, d_ev, feed);
+        else if (helpers == 5) hipLaunchKernelGGL((chain_block_kernel_lat<5, false>), dim3(nw), dim3(64 * 6), 0, s, d_work, d_x, d_y, d_score, d_parent, d_gm, d_ev, feed);
+        else hipLaunchKernelGGL((chain_block_kernel<kCbHelpers, false>), dim3(nw), dim3(64 * (1 + kCbHelpers)), 0, s, d_work, d_x, d_y, d_score, d_parent, d_gm, d_ev, feed);
     }
 }
 
