@@ -655,7 +655,7 @@ __device__ bool wfa_pair_static(OffB *pool, int pool_cap, const WfRow *__restric
 
 // dynamic LDS per group: [P: seqp bytes][T: seqt bytes][pool: pool_cap bytes]; the CIGAR is built over P/T
 template <int G, bool CHAINED>
-__global__ __launch_bounds__(64) void wfa_lds_static(WfaIO io, WfaPen pen, const uint32_t *__restrict__ list, uint32_t count,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void wfa_lds_static(WfaIO io, WfaPen pen, const uint32_t *__restrict__ list, uint32_t count,
                                                      const uint32_t *__restrict__ count_ptr, int seqp, int seqt, int pool_cap,
                                                      uint32_t group_bytes, uint32_t *over_list, uint32_t *over_count, WfaCounters *ct,
                                                      const WfRow *__restrict__ rows, int nrows) {
@@ -934,9 +934,11 @@ extern "C" int gab_wfa_run_device(gab_wfa *h, const char *pat, int64_t pat_bytes
     if (!byte_ok && !tuned) dir_caps[0] = 48;
     // complete mode: the first tier takes its directory from the penalties' table (wfa_pair_static) -- no directory in LDS
     const int static_rows = std::min(h->nrows, kOffBMax - 2 - h->h_ct->max_tlen);
-    // LDS per pair of the first launch: 1904 B = 7616 B per wave of four = 20 waves per CU (what the kernel's 93 VGPRs allow;
-    // 1920 B per pair already falls to 18 waves: the allocation granule), i.e. ~1.5 K offsets behind two 151-bp strings
-    const int static_pool = tuned && byte_tier > 1 ? byte_tier : std::min(1904 - (seqp + seqt), 4080) & ~15;
+    // LDS per pair of the first launch: 1568 B = 6272 B per wave of four = 24 waves per CU, six per SIMD (the kernel is
+    // compiled for that: 73 VGPRs, no scratch), i.e. ~1.2 K offsets behind two 151-bp strings = scores below 44 = 96 % of the
+    // pairs.  Measured: 1 520 offsets at 20 waves 382 M/s, 1 344 at 23 waves 391, 1 088-1 184 at 24 waves 405; the history a
+    // pair needs steps with its score, so 1 216-1 312 offsets buy nothing over 1 184 and cost a wave.
+    const int static_pool = tuned && byte_tier > 1 ? byte_tier : std::min(1568 - (seqp + seqt), 4080) & ~15;
     const bool use_static = !h->adaptive && byte_tier != 0 && !getenv("GAB_WFA_NO_STATIC") && (groups[0] == 16 || groups[0] == 8) && static_rows >= 16 && static_pool >= 1024;
     // The tiers are launched back to back: tier k + 1 reads the number of pairs tier k left ON THE DEVICE and is sized by an
     // estimate (its waves stride over whatever there is), so the host looks at the counters once, after the last LDS tier
@@ -952,11 +954,11 @@ extern "C" int gab_wfa_run_device(gab_wfa *h, const char *pat, int64_t pat_bytes
         else { cur = nxt; nxt = l_a; }                      // the identity pass: its overflow list becomes the input
         tier++;
     };
-    const double shares[4] = {1.0, 0.08, 0.02, 0.005};       // expected share of the batch that reaches tier k (151-bp reads at 2 %: 2 %, 0.05 %, ~0)
+    const double shares[4] = {1.0, 0.10, 0.02, 0.005};       // expected share of the batch that reaches tier k (151-bp reads at 2 %: 4 %, 0.07 %, ~0)
     if (cnt && use_static) {
-        // two launches: the small pool takes ~98 % of the 151-bp pairs (scores below 48) at 20 waves per CU, a 3 KB pool
-        // the scores up to ~70 of the rest (measured: 2560-3072 B best, 4080 and 6144 B 2 % slower)
-        int static_pool2 = 3072;
+        // two launches: the small pool takes 96 % of the 151-bp pairs at 24 waves per CU, a 2.5 KB pool the scores up to ~64 of
+        // the rest (measured: 2048-2560 B best, 4080 B 4 % slower)
+        int static_pool2 = 2560;
         if (const char *e2 = getenv("GAB_WFA_POOL2")) static_pool2 = atoi(e2);
         const int pools[2] = {static_pool, static_pool2};
         for (int k = 0; k < 2; k++) {
