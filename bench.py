@@ -32,7 +32,7 @@ HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec 
 # counters in separate passes (tools/profiling/hbm_traffic.sh -> profiles/r01_hbm_traffic.json); `double_fetch`: the
 # kernel reads wide coalesced streams, for which gfx950's FETCH_SIZE reports half the bytes (MI355X_MICROARCH.md, HBM)
 TRAFFIC_KERNELS = {"bsw": (["bsw_dp8"], False), "chain": (["chain_block_kernel", "chain_facts_kernel"], False), "fast-chain": (["fastchain_kernel"], False),
-                   "bpm": (["bpm_score<3>"], False), "bitpal": (["bitpal_dp<true, true>"], False), "wfa": (["wfa_lds_static<16>"], False), "fmi": (["fmi_seed_kernel<true>"], False),
+                   "bpm": (["bpm_score<3>"], False), "bitpal": (["bitpal_dp<true, true>"], False), "wfa": (["wfa_lds_static<16, false>"], False), "fmi": (["fmi_seed_kernel<true>"], False),
                    "fmi-sa": (["fmi_sa_kernel"], False), "parse-bsw": (["nl_count", "nl_fill", "bsw_meta", "bsw_codes", "len_offsets",
                                                                        "len_block_sums"], True)}
 
@@ -659,7 +659,7 @@ class WfaWorkload:
 
     def extra(self, ms_per_step):
         return {"work_units_per_step": self.stats.get("work"), "requeued_pairs": self.stats.get("requeued"),
-                "dominant_kernel": "wfa_lds_static<16> (first launch)", "dominant_kernel_ms": float(np.mean(self.kernel_ms)),
+                "dominant_kernel": "wfa_lds_static<16, false> (first launch)", "dominant_kernel_ms": float(np.mean(self.kernel_ms)),
                 "device_total_ms": float(np.mean(self.total_ms))}
 
     def roofline(self):
@@ -667,7 +667,7 @@ class WfaWorkload:
         ach = self.alg_bytes / (k * 1e-3) / 1e9
         return {"bound": "hbm", "achieved": round(ach, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(ach / HBM_PEAK_GBS, 6), "traffic": None,
-                "note": "plen+tlen+cigar+4 B per pair; the kernel is instruction-issue bound (72 % VALU busy at 31 % lane utilisation: four pairs per wave, lanes = diagonals)"}
+                "note": "plen+tlen+cigar+4 B per pair; the kernel is instruction-issue bound (84 % VALU busy at 31 % lane utilisation: four pairs per wave, lanes = diagonals)"}
 
     def cpu_baseline(self, cores):
         from oracle import pyoracle
