@@ -101,7 +101,14 @@ __global__ __launch_bounds__(256) void bitpal_classify(BpIO io, BpCounters *ct) 
         ml = max(ml, __shfl_xor(ml, o)); mb = max(mb, __shfl_xor(mb, o));
         n_lds += __shfl_xor(n_lds, o); n_big += __shfl_xor(n_big, o);
     }
-    if ((threadIdx.x & 63) == 0) {
+    // one set of atomics per workgroup: they all hit the same four addresses and serialise in L2 (see wfa_classify)
+    __shared__ int s_ml[4], s_mb[4];
+    __shared__ uint32_t s_nl[4], s_nb[4];
+    const int wv = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { s_ml[wv] = ml; s_mb[wv] = mb; s_nl[wv] = n_lds; s_nb[wv] = n_big; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < 4; k++) { ml = max(ml, s_ml[k]); mb = max(mb, s_mb[k]); n_lds += s_nl[k]; n_big += s_nb[k]; }
         atomicMax(&ct->max_rows_lds, ml); atomicMax(&ct->max_rows_big, mb);
         if (n_lds) atomicAdd(&ct->n_lds, n_lds);
         if (n_big) atomicAdd(&ct->n_big, n_big);
@@ -294,7 +301,7 @@ extern "C" int gab_bitpal_run_device(gab_bitpal *h, const char *pat, int64_t pat
     memset(h->h_ct, 0, sizeof(BpCounters));
     h->h_ct->first_bad = 0x7fffffff;
     GAB_HIP(hipMemcpyAsync(d_ct, h->h_ct, sizeof(BpCounters), hipMemcpyHostToDevice, s));
-    const int grid = (int)std::min<int64_t>(gab_ceil_div(n, 256), 1024);
+    const int grid = (int)std::min<int64_t>(gab_ceil_div(n, 256), 512);
     hipLaunchKernelGGL(bitpal_classify, dim3(grid), dim3(256), 0, s, io, d_ct);
     GAB_HIP(hipMemcpyAsync(h->h_ct, d_ct, sizeof(BpCounters), hipMemcpyDeviceToHost, s));
     GAB_HIP(hipStreamSynchronize(s));

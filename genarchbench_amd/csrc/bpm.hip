@@ -118,17 +118,25 @@ __global__ __launch_bounds__(256) void bpm_count(BpmIO io, BpmCounters *ct) {
 #pragma unroll
         for (int k = 0; k < kClasses; k++) { mine[k] += cls == k; mt[k] = (cls == k && m > mt[k]) ? m : mt[k]; }
     }
+    // wave reductions, then one set of atomics per workgroup (they serialise in L2 on a handful of addresses)
+    __shared__ int s_mt[4][kClasses];
+    __shared__ uint32_t s_cnt[4][kClasses];
+    const int wv = threadIdx.x >> 6;
 #pragma unroll
     for (int k = 0; k < kClasses; k++) {
         int v = mt[k];
         for (int o = 32; o > 0; o >>= 1) { const int u = __shfl_xor(v, o); v = u > v ? u : v; }
-        if ((threadIdx.x & 63) == 0 && v > 0) atomicMax(&ct->max_tlen[k], v);
+        uint32_t c = mine[k];
+        for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+        if ((threadIdx.x & 63) == 0) { s_mt[wv][k] = v; s_cnt[wv][k] = c; }
     }
-#pragma unroll
-    for (int k = 0; k < kClasses; k++) {
-        uint32_t v = mine[k];
-        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-        if ((threadIdx.x & 63) == 0 && v) atomicAdd(&ct->cls_count[k], v);
+    __syncthreads();
+    if (threadIdx.x < kClasses) {
+        const int k = threadIdx.x;
+        int v = 0; uint32_t c = 0;
+        for (int w2 = 0; w2 < 4; w2++) { v = s_mt[w2][k] > v ? s_mt[w2][k] : v; c += s_cnt[w2][k]; }
+        if (v > 0) atomicMax(&ct->max_tlen[k], v);
+        if (c) atomicAdd(&ct->cls_count[k], c);
     }
 }
 
