@@ -20,13 +20,21 @@ typedef struct {
     int64_t *poff, *toff; int32_t *plen, *tlen;
     int32_t *score;
     int bitpal;                  /* -1: bpm-edit, else GAB_BITPAL_EDIT / GAB_BITPAL_SCORED */
-    int64_t chunk;
+    int64_t chunk, max_seq_bytes;
 } bpm_ctx;
 static void *gpu_init(int worker, int gpu, void *vc) {
     (void)worker;
     bpm_ctx *c = (bpm_ctx *)vc;
-    if (c->bitpal >= 0) { gab_bitpal *h = NULL; GAB_DIE_IF(gab_bitpal_create(c->bitpal, gpu, &h), "gab_bitpal_create"); return h; }
-    gab_bpm *h = NULL; GAB_DIE_IF(gab_bpm_create(gpu, &h), "gab_bpm_create"); return h;
+    /* buffers for the largest chunk and warm copy queues, outside the ROI */
+    const int64_t np = c->chunk < c->p->n ? c->chunk : c->p->n;
+    if (c->bitpal >= 0) {
+        gab_bitpal *h = NULL; GAB_DIE_IF(gab_bitpal_create(c->bitpal, gpu, &h), "gab_bitpal_create");
+        GAB_DIE_IF(gab_bitpal_reserve(h, np, c->max_seq_bytes), "gab_bitpal_reserve");
+        return h;
+    }
+    gab_bpm *h = NULL; GAB_DIE_IF(gab_bpm_create(gpu, &h), "gab_bpm_create");
+    GAB_DIE_IF(gab_bpm_reserve(h, np, c->max_seq_bytes), "gab_bpm_reserve");
+    return h;
 }
 static void gpu_fini(int worker, int gpu, void *vc, void *st) {
     (void)gpu; (void)worker;
@@ -138,6 +146,13 @@ int main(int argc, char **argv) {
     }
     const int ngpus = gab_pick_gpus(gpus);
     ctx.chunk = gab_env_i64("GAB_CHUNK", CHUNK_PAIRS);
+    ctx.max_seq_bytes = 0;                       /* the widest chunk: what gpu_init reserves for */
+    for (int64_t b = 0; b < p.n; b += ctx.chunk) {
+        const int64_t e = b + ctx.chunk < p.n ? b + ctx.chunk : p.n;
+        const int64_t lo = p.off1[b] < p.off2[b] ? p.off1[b] : p.off2[b];
+        const int64_t h1 = p.off1[e - 1] + p.len1[e - 1], h2 = p.off2[e - 1] + p.len2[e - 1], hi = h1 > h2 ? h1 : h2;
+        if (hi - lo + 512 > ctx.max_seq_bytes) ctx.max_seq_bytes = hi - lo + 512;
+    }
     gab_pin(p.slab, p.used); gab_pin(ctx.poff, 8 * (size_t)p.n); gab_pin(ctx.toff, 8 * (size_t)p.n);
     gab_pin(ctx.plen, 4 * (size_t)p.n); gab_pin(ctx.tlen, 4 * (size_t)p.n); gab_pin(ctx.score, 4 * (size_t)p.n);
     gab_queue q;

@@ -14,11 +14,13 @@
 #include <sys/time.h>
 
 #define CHUNK_PAIRS (1 << 18)   /* default chunk of the work queue; $GAB_CHUNK overrides it */
-typedef struct { const gab_pairs *p; int64_t chunk; gab_wfa_penalties pen; int min_wavefront_length, max_distance_threshold; char *ops; int64_t *ops_off; int32_t *ops_len, *score; } wfa_ctx;
+typedef struct { const gab_pairs *p; int64_t chunk; gab_wfa_penalties pen; int min_wavefront_length, max_distance_threshold; char *ops; int64_t *ops_off; int32_t *ops_len, *score; int64_t max_seq_bytes, max_ops_bytes; } wfa_ctx;
 static void *gpu_init(int worker, int gpu, void *vc) {
     (void)worker;
     wfa_ctx *c = (wfa_ctx *)vc; gab_wfa *h = NULL;
     GAB_DIE_IF(gab_wfa_create_reduced(&c->pen, c->min_wavefront_length, c->max_distance_threshold, gpu, &h), "gab_wfa_create_reduced");
+    /* buffers for the largest chunk and warm copy queues, outside the ROI (the reference allocates its wavefronts before it too) */
+    GAB_DIE_IF(gab_wfa_reserve(h, c->chunk < c->p->n ? c->chunk : c->p->n, c->max_seq_bytes, c->max_ops_bytes), "gab_wfa_reserve");
     return h;
 }
 static void gpu_fini(int worker, int gpu, void *c, void *st) { (void)worker; (void)gpu; (void)c; gab_wfa_destroy((gab_wfa *)st); }
@@ -132,6 +134,15 @@ int main(int argc, char **argv) {
     ctx.ops = (char *)malloc((size_t)tot + 16);
     const int ngpus = gab_pick_gpus(gpus);
     ctx.chunk = gab_env_i64("GAB_CHUNK", CHUNK_PAIRS);
+    ctx.max_seq_bytes = ctx.max_ops_bytes = 0;       /* the widest chunk: what gpu_init reserves for */
+    for (int64_t b = 0; b < p.n; b += ctx.chunk) {
+        const int64_t e = b + ctx.chunk < p.n ? b + ctx.chunk : p.n;
+        const int64_t lo = p.off1[b] < p.off2[b] ? p.off1[b] : p.off2[b];
+        const int64_t h1 = p.off1[e - 1] + p.len1[e - 1], h2 = p.off2[e - 1] + p.len2[e - 1], hi = h1 > h2 ? h1 : h2;
+        const int64_t ops = ctx.ops_off[e - 1] + p.len1[e - 1] + p.len2[e - 1] - ctx.ops_off[b];
+        if (hi - lo + 512 > ctx.max_seq_bytes) ctx.max_seq_bytes = hi - lo + 512;
+        if (ops + 512 > ctx.max_ops_bytes) ctx.max_ops_bytes = ops + 512;
+    }
     gab_pin(p.slab, p.used); gab_pin(p.off1, 8 * (size_t)p.n); gab_pin(p.off2, 8 * (size_t)p.n); gab_pin(p.len1, 4 * (size_t)p.n);
     gab_pin(p.len2, 4 * (size_t)p.n); gab_pin(ctx.ops, (size_t)tot + 16); gab_pin(ctx.ops_off, 8 * (size_t)p.n);
     gab_pin(ctx.ops_len, 4 * (size_t)p.n); gab_pin(ctx.score, 4 * (size_t)p.n);

@@ -355,7 +355,10 @@ extern "C" int gab_bitpal_run(gab_bitpal *h, const char *pat, const int64_t *pat
         pa = std::min(pa, pat_off[i]); ta = std::min(ta, txt_off[i]);
     }
     pa &= ~(int64_t)255; ta &= ~(int64_t)255;      // stage only the referenced window [min, max) of each slab
-    const size_t ppad = ((size_t)(pb - pa) + 3 + 255) & ~(size_t)255, tpad = ((size_t)(tb - ta) + 3 + 255) & ~(size_t)255;
+    // one slab for both (the drivers' pair files: '>' and '<' lines interleaved): the window is staged once, not twice
+    const bool shared = pat == txt;
+    if (shared) { pa = ta = std::min(pa, ta); pb = tb = std::max(pb, tb); }
+    const size_t ppad = ((size_t)(pb - pa) + 3 + 255) & ~(size_t)255, tpad = shared ? 0 : ((size_t)(tb - ta) + 3 + 255) & ~(size_t)255;
     const size_t nn = (size_t)n;
     size_t o = 0;
     const size_t o_p = o; o += ppad;
@@ -373,7 +376,7 @@ extern "C" int gab_bitpal_run(gab_bitpal *h, const char *pat, const int64_t *pat
     {   // the copies of one chunk at a time per GPU (gab_core.hip: the workers of a GPU must not copy in lockstep)
         std::lock_guard<std::mutex> gate(gab_h2d_mutex(h->device));
         GAB_HIP(hipMemcpyAsync(b + o_p, pat + pa, (size_t)(pb - pa), hipMemcpyHostToDevice, s));
-        GAB_HIP(hipMemcpyAsync(b + o_t, txt + ta, (size_t)(tb - ta), hipMemcpyHostToDevice, s));
+        if (!shared) GAB_HIP(hipMemcpyAsync(b + o_t, txt + ta, (size_t)(tb - ta), hipMemcpyHostToDevice, s));
         GAB_HIP(hipMemcpyAsync(b + o_po, pat_off, 8 * nn, hipMemcpyHostToDevice, s));
         GAB_HIP(hipMemcpyAsync(b + o_to, txt_off, 8 * nn, hipMemcpyHostToDevice, s));
         GAB_HIP(hipMemcpyAsync(b + o_pl, pat_len, 4 * nn, hipMemcpyHostToDevice, s));
@@ -381,12 +384,29 @@ extern "C" int gab_bitpal_run(gab_bitpal *h, const char *pat, const int64_t *pat
         GAB_HIP(hipStreamSynchronize(s));
     }
     rc = gab_bitpal_run_device(h, b + o_p - pa, pa + (int64_t)ppad, (const int64_t *)(b + o_po), (const int32_t *)(b + o_pl),
-                               b + o_t - ta, ta + (int64_t)tpad, (const int64_t *)(b + o_to), (const int32_t *)(b + o_tl), n,
+                               (shared ? b + o_p : b + o_t) - ta, ta + (int64_t)(shared ? ppad : tpad), (const int64_t *)(b + o_to), (const int32_t *)(b + o_tl), n,
                                (int32_t *)(b + o_sc), s);
     if (rc) return rc;
     GAB_HIP(hipMemcpyAsync(score_out, b + o_sc, 4 * nn, hipMemcpyDeviceToHost, s));
     GAB_HIP(hipStreamSynchronize(s));
     return GAB_OK;
+}
+
+// see gab_bpm_reserve
+extern "C" int gab_bitpal_reserve(gab_bitpal *h, int64_t max_pairs, int64_t max_seq_bytes) {
+    GAB_CHECK(h, "gab_bitpal_reserve: NULL handle");
+    GAB_CHECK(max_pairs >= 0 && max_pairs < (1ll << 31) && max_seq_bytes >= 0, "gab_bitpal_reserve: size out of range");
+    gab_device_guard g(h->device);
+    const size_t nn = (size_t)max_pairs;
+    int rc = h->io.reserve(std::max<size_t>(2 * (((size_t)max_seq_bytes + 3 + 511) & ~(size_t)255) + 28 * nn + 1024, (size_t)4 << 20));
+    if (rc) return rc;
+    if ((rc = h->ws.reserve(sizeof(BpCounters) + 512 + 3 * 4 * nn)) != GAB_OK) return rc;
+    hipStream_t s = nullptr;
+    if ((rc = h->hs.get(&s)) != GAB_OK) return rc;
+    GAB_HIP(hipMemsetAsync(h->io.p, 0, h->io.cap, s));
+    GAB_HIP(hipMemsetAsync(h->ws.p, 0, h->ws.cap, s));
+    GAB_HIP(hipStreamSynchronize(s));
+    return gab_warm_copy_engines(s, h->io.p);
 }
 
 extern "C" int gab_bitpal_last_stats(gab_bitpal *h, int64_t *cells, int64_t *long_pairs, float *kernel_ms, float *total_ms) {

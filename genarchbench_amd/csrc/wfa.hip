@@ -1056,7 +1056,10 @@ extern "C" int gab_wfa_run(gab_wfa *h, const char *pat, const int64_t *pat_off, 
         pa = std::min(pa, pat_off[i]); ta = std::min(ta, txt_off[i]); oa = std::min(oa, ops_off[i]);
     }
     pa &= ~(int64_t)255; ta &= ~(int64_t)255;   // stage only the referenced windows (oa stays exact: it is written back)
-    const size_t ppad = ((size_t)(pb - pa) + 3 + 255) & ~(size_t)255, tpad = ((size_t)(tb - ta) + 3 + 255) & ~(size_t)255;
+    // one slab for both (the drivers' pair files: '>' and '<' lines interleaved): the window is staged once, not twice
+    const bool shared = pat == txt;
+    if (shared) { pa = ta = std::min(pa, ta); pb = tb = std::max(pb, tb); }
+    const size_t ppad = ((size_t)(pb - pa) + 3 + 255) & ~(size_t)255, tpad = shared ? 0 : ((size_t)(tb - ta) + 3 + 255) & ~(size_t)255;
     const size_t opad = ((size_t)(ob - oa) + 255) & ~(size_t)255, nn = (size_t)n;
     size_t o = 0;
     const size_t o_p = o; o += ppad;
@@ -1077,7 +1080,7 @@ extern "C" int gab_wfa_run(gab_wfa *h, const char *pat, const int64_t *pat_off, 
     {   // the copies of one chunk at a time per GPU (gab_core.hip: the workers of a GPU must not copy in lockstep)
         std::lock_guard<std::mutex> gate(gab_h2d_mutex(h->device));
         GAB_HIP(hipMemcpyAsync(b + o_p, pat + pa, (size_t)(pb - pa), hipMemcpyHostToDevice, s));
-        GAB_HIP(hipMemcpyAsync(b + o_t, txt + ta, (size_t)(tb - ta), hipMemcpyHostToDevice, s));
+        if (!shared) GAB_HIP(hipMemcpyAsync(b + o_t, txt + ta, (size_t)(tb - ta), hipMemcpyHostToDevice, s));
         GAB_HIP(hipMemcpyAsync(b + o_po, pat_off, 8 * nn, hipMemcpyHostToDevice, s));
         GAB_HIP(hipMemcpyAsync(b + o_to, txt_off, 8 * nn, hipMemcpyHostToDevice, s));
         GAB_HIP(hipMemcpyAsync(b + o_oo, ops_off, 8 * nn, hipMemcpyHostToDevice, s));
@@ -1086,7 +1089,7 @@ extern "C" int gab_wfa_run(gab_wfa *h, const char *pat, const int64_t *pat_off, 
         GAB_HIP(hipStreamSynchronize(s));
     }
     rc = gab_wfa_run_device(h, b + o_p - pa, pa + (int64_t)ppad, (const int64_t *)(b + o_po), (const int32_t *)(b + o_pl),
-                            b + o_t - ta, ta + (int64_t)tpad, (const int64_t *)(b + o_to), (const int32_t *)(b + o_tl), n, b + o_ops - oa,
+                            (shared ? b + o_p : b + o_t) - ta, ta + (int64_t)(shared ? ppad : tpad), (const int64_t *)(b + o_to), (const int32_t *)(b + o_tl), n, b + o_ops - oa,
                             (const int64_t *)(b + o_oo), (int32_t *)(b + o_ol), (int32_t *)(b + o_sc), s);
     if (rc) return rc;
     // only each pair's own operations are defined; copy the window back and let the caller read ops_len[i] bytes per pair
@@ -1095,6 +1098,24 @@ extern "C" int gab_wfa_run(gab_wfa *h, const char *pat, const int64_t *pat_off, 
     GAB_HIP(hipMemcpyAsync(score_out, b + o_sc, 4 * nn, hipMemcpyDeviceToHost, s));
     GAB_HIP(hipStreamSynchronize(s));
     return GAB_OK;
+}
+
+// see gab_bpm_reserve; max_ops_bytes = the room of the CIGAR operations (pattern + text length per pair)
+extern "C" int gab_wfa_reserve(gab_wfa *h, int64_t max_pairs, int64_t max_seq_bytes, int64_t max_ops_bytes) {
+    GAB_CHECK(h, "gab_wfa_reserve: NULL handle");
+    GAB_CHECK(max_pairs >= 0 && max_pairs < (1ll << 31) && max_seq_bytes >= 0 && max_ops_bytes >= 0, "gab_wfa_reserve: size out of range");
+    gab_device_guard g(h->device);
+    const size_t nn = (size_t)max_pairs;
+    int rc = h->io.reserve(std::max<size_t>(2 * (((size_t)max_seq_bytes + 3 + 511) & ~(size_t)255) + (((size_t)max_ops_bytes + 511) & ~(size_t)255) + 44 * nn + 1024,
+                                            (size_t)4 << 20));
+    if (rc) return rc;
+    if ((rc = h->ws.reserve(kCountersBytes + kSlotsBytes + 3 * 4 * nn + 1024)) != GAB_OK) return rc;
+    hipStream_t s = nullptr;
+    if ((rc = h->hs.get(&s)) != GAB_OK) return rc;
+    GAB_HIP(hipMemsetAsync(h->io.p, 0, h->io.cap, s));
+    GAB_HIP(hipMemsetAsync(h->ws.p, 0, h->ws.cap, s));
+    GAB_HIP(hipStreamSynchronize(s));
+    return gab_warm_copy_engines(s, h->io.p);
 }
 
 extern "C" int gab_wfa_last_stats(gab_wfa *h, int64_t *work, int64_t *requeued, float *first_pass_ms, float *total_ms) {

@@ -162,6 +162,10 @@ int gab_chain_last_stats(gab_chain *h, int64_t *evals, float *kernel_ms);
 typedef struct gab_bpm gab_bpm;
 int gab_bpm_create(int device, gab_bpm **out);
 void gab_bpm_destroy(gab_bpm *h);
+/* optional, outside the timed region: device buffers for calls of up to max_pairs pairs whose sequences span up to
+ * max_seq_bytes of the slab(s), and warm copy queues (see gab_bsw_reserve).  pat and txt may be the same slab (the drivers'
+ * pair files): its window is then staged once. */
+int gab_bpm_reserve(gab_bpm *h, int64_t max_pairs, int64_t max_seq_bytes);
 int gab_bpm_run(gab_bpm *h, const char *pat, const int64_t *pat_off, const int32_t *pat_len,
                 const char *txt, const int64_t *txt_off, const int32_t *txt_len, int64_t n,
                 int32_t *score_out);
@@ -195,6 +199,7 @@ int gab_bpm_last_stats(gab_bpm *h, int64_t *block_steps, int64_t *full_pairs,
 typedef struct gab_bitpal gab_bitpal;
 int gab_bitpal_create(int algorithm, int device, gab_bitpal **out);
 void gab_bitpal_destroy(gab_bitpal *h);
+int gab_bitpal_reserve(gab_bitpal *h, int64_t max_pairs, int64_t max_seq_bytes);      /* see gab_bpm_reserve */
 int gab_bitpal_run(gab_bitpal *h, const char *pat, const int64_t *pat_off, const int32_t *pat_len,
                    const char *txt, const int64_t *txt_off, const int32_t *txt_len, int64_t n,
                    int32_t *score_out);
@@ -236,6 +241,8 @@ int gab_wfa_create(const gab_wfa_penalties *penalties, int device, gab_wfa **out
 int gab_wfa_create_reduced(const gab_wfa_penalties *penalties, int min_wavefront_length, int max_distance_threshold,
                            int device, gab_wfa **out);
 void gab_wfa_destroy(gab_wfa *h);
+/* see gab_bpm_reserve; max_ops_bytes = the room of the CIGAR operations of a call (pattern + text length per pair) */
+int gab_wfa_reserve(gab_wfa *h, int64_t max_pairs, int64_t max_seq_bytes, int64_t max_ops_bytes);
 int gab_wfa_run(gab_wfa *h, const char *pat, const int64_t *pat_off, const int32_t *pat_len,
                 const char *txt, const int64_t *txt_off, const int32_t *txt_len, int64_t n,
                 char *ops_out, const int64_t *ops_off, int32_t *ops_len_out, int32_t *score_out);

@@ -13,6 +13,10 @@ if not os.path.exists(f"{T}/bsw.txt"):
     gabgen.write_text("bsw", f"{T}/bsw.txt", 2, 10_000_000, 0)
 if not os.path.exists(f"{T}/chain.txt"):
     gabgen.write_text("chain", f"{T}/chain.txt", 5, 10_000, 0, 50, 60000)
+if not os.path.exists(f"{T}/bpm.txt"):
+    gabgen.write_text("bpm", f"{T}/bpm.txt", 3, 10_000_000, 0, 151)
+if not os.path.exists(f"{T}/wfa.txt"):
+    gabgen.write_text("wfa", f"{T}/wfa.txt", 4, 1_000_000, 0, 151)
 PY
 cores=$(python3 -c "
 import os
@@ -30,10 +34,18 @@ for w in ${@:-1 2 3}; do   # chain-large through the driver needs its fscanf par
   ./benchmarks/chain/chain -i $T/chain.txt -o $T/chain_out_$w.txt -t 1 2>&1 | grep "Time in kernel" | sed "s/^/chain-large driver, $w worker(s) per GPU: /"
   echo "   md5 of the output: $(md5sum $T/chain_out_$w.txt | cut -c1-12)"
   ./benchmarks/fast-chain/chain -i $T/chain.txt -o $T/fchain_out_$w.txt -t 1 2>&1 | grep "Time in kernel" | sed "s/^/fast-chain-large driver, $w worker(s) per GPU: /"
+  ./benchmarks/bpm/bin/align_benchmark -a bpm-edit -i $T/bpm.txt -o $T/bpm_out_$w.txt -t 1 2>&1 | grep "Time.Benchmark" | tr -s " " | sed "s/^/bpm-large driver, $w worker(s) per GPU: /"
+  echo "   md5 of the sorted output: $(sort -n -t "[" -k 2,2 $T/bpm_out_$w.txt | md5sum | cut -c1-12)"
+  ./benchmarks/wfa/bin/align_benchmark -i $T/wfa.txt -o $T/wfa_out_$w.txt -t 1 2>&1 | grep "Time.Alignment" | sed "s/^/wfa-large driver, $w worker(s) per GPU: /"
+  echo "   md5 of the sorted output: $(sort -n -t "=" -k 2,2 $T/wfa_out_$w.txt | md5sum | cut -c1-12)"
 done
 if [[ -x oracle/_ref/bsw_ref_avx512 ]]; then
   OMP_PROC_BIND=true OMP_PLACES=cores oracle/_ref/bsw_ref_avx512 -pairs $T/bsw.txt -t $cores -b 512 2> $T/bsw_ref_err.txt | grep -E "Overall SW" | sed "s/^/bsw-large reference (avx512), $cores threads: /"
   echo "   md5 of the scores: $(grep score= $T/bsw_ref_err.txt | head -10000000 | md5sum | cut -c1-12)"
   OMP_PROC_BIND=true OMP_PLACES=cores oracle/_ref/chain_ref -i $T/chain.txt -o $T/chain_ref_out.txt -t $cores 2>&1 | grep "Time in kernel" | sed "s/^/chain-large reference, $cores threads: /"
   echo "   md5 of the output: $(md5sum $T/chain_ref_out.txt | cut -c1-12)"
+  OMP_PROC_BIND=true OMP_PLACES=cores oracle/_ref/bpm_ref -a bpm-edit -i $T/bpm.txt -o $T/bpm_ref_out.txt -t $cores 2>&1 | grep "Time.Benchmark" | tr -s " " | sed "s/^/bpm-large reference, $cores threads: /"
+  echo "   md5 of the sorted output: $(sort -n -t "[" -k 2,2 $T/bpm_ref_out.txt | md5sum | cut -c1-12)"
+  OMP_PROC_BIND=true OMP_PLACES=cores oracle/_ref/wfa_ref -i $T/wfa.txt -o $T/wfa_ref_out.txt -t $cores 2>&1 | grep "Time.Alignment" | sed "s/^/wfa-large reference, $cores threads: /"
+  echo "   md5 of the sorted output: $(sort -n -t "=" -k 2,2 $T/wfa_ref_out.txt | md5sum | cut -c1-12)"
 fi
