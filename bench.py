@@ -446,7 +446,8 @@ class BpmWorkload:
         slab = t(b.pat)
         self.d = [slab, t(b.pat_off), t(b.pat_len), slab, t(b.txt_off), t(b.txt_len)]
         self.score = torch.empty(items, dtype=torch.int32, device=dev)
-        self.eng = BpmEngine(device=dev.index or 0)
+        self.dev_index = dev.index or 0
+        self.eng = BpmEngine(device=self.dev_index)
         self.alg_bytes = int(b.pat_len.astype(np.int64).sum() + b.txt_len.astype(np.int64).sum() + 4 * items)
         self.kernel_ms, self.total_ms = [], []
         self.stats = {}
@@ -623,7 +624,8 @@ class WfaWorkload:
         self.d_off = t(self.off)
         self.ops_len = torch.zeros(items, dtype=torch.int32, device=dev)
         self.score = torch.zeros(items, dtype=torch.int32, device=dev)
-        self.eng = AffineWavefronts(device=dev.index or 0)
+        self.dev_index = dev.index or 0
+        self.eng = AffineWavefronts(device=self.dev_index)
         self.in_bytes = int(b.pat_len.astype(np.int64).sum() + b.txt_len.astype(np.int64).sum() + 4 * items)
         self.alg_bytes = self.in_bytes
         self.kernel_ms, self.total_ms = [], []
@@ -668,6 +670,34 @@ class WfaWorkload:
         return {"bound": "hbm", "achieved": round(ach, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(ach / HBM_PEAK_GBS, 6), "traffic": None,
                 "note": "plen+tlen+cigar+4 B per pair; the kernel is instruction-issue bound (84 % VALU busy at 31 % lane utilisation: four pairs per wave, lanes = diagonals)"}
+
+    def host_roi(self, chunk=1 << 18):
+        import ctypes as C
+        from genarchbench_amd._lib import check, lib
+        from genarchbench_amd.wfa import AffineWavefronts
+        b, n = self.batch, self.items
+        total = int(self.off[-1] + b.pat_len[-1] + b.txt_len[-1]) if n else 0
+        ops = np.zeros(total + 16, np.uint8); ln = np.zeros(n, np.int32); sc = np.full(n, -1, np.int32)
+        pinned = pin(b.pat, b.txt, b.pat_off, b.txt_off, b.pat_len, b.txt_len, ops, self.off, ln, sc)
+        at = lambda a, i: C.c_void_p(a.ctypes.data + a.itemsize * i)
+
+        def run(st, c):
+            lo, hi = c * chunk, min(n, (c + 1) * chunk)
+            check(lib().gab_wfa_run(st._h, at(b.pat, 0), at(b.pat_off, lo), at(b.pat_len, lo), at(b.txt, 0), at(b.txt_off, lo), at(b.txt_len, lo),
+                                    C.c_int64(hi - lo), at(ops, 0), at(self.off, lo), at(ln, lo), at(sc, lo)))
+        try:
+            sec = host_queue((n + chunk - 1) // chunk, lambda: AffineWavefronts(device=self.dev_index), run, lambda st: st.close())
+        finally:
+            unpin(pinned)
+        dl = self.ops_len.cpu().numpy()
+        assert np.array_equal(sc, self.score.cpu().numpy()) and np.array_equal(ln, dl), "host-pointer path and device path disagree"
+        dev_ops = self.ops.cpu().numpy()
+        for i in range(0, n, max(1, n // 5000)):
+            o = int(self.off[i])
+            assert np.array_equal(ops[o:o + ln[i]], dev_ops[o:o + ln[i]]), f"cigar {i}: host-pointer path and device path disagree"
+        return {"ms": round(sec * 1e3, 3), "value": round(n / sec / 1e6, 3), "unit": self.unit, "chunk": chunk, "workers_per_gpu": HOST_WORKERS,
+                "note": "gab_wfa_run on page-locked host slabs, chunks pulled by worker threads (the C driver's ROI): the sequences over the "
+                        "bus + kernels + the CIGAR room back; scores, lengths and a sample of the CIGARs equal to the device path's"}
 
     def cpu_baseline(self, cores):
         from oracle import pyoracle

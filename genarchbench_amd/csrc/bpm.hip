@@ -838,8 +838,8 @@ extern "C" int gab_bpm_run(gab_bpm *h, const char *pat, const int64_t *pat_off, 
         pa = std::min(pa, pat_off[i]); ta = std::min(ta, txt_off[i]);
     }
     pa &= ~(int64_t)255; ta &= ~(int64_t)255;      // stage only the referenced window [min, max) of each slab
-    // one slab for both (the drivers' pair files: '>' and '<' lines interleaved): the window is staged once, not twice
-    const bool shared = pat == txt;
+    // one slab for both with overlapping windows (the drivers' pair files: '>' and '<' lines interleaved): staged once, not twice
+    const bool shared = pat == txt && std::max(pb, tb) - std::min(pa, ta) <= (pb - pa) + (tb - ta);
     if (shared) { pa = ta = std::min(pa, ta); pb = tb = std::max(pb, tb); }
     const size_t ppad = ((size_t)(pb - pa) + 3 + 255) & ~(size_t)255, tpad = shared ? 0 : ((size_t)(tb - ta) + 3 + 255) & ~(size_t)255;
     const size_t nn = (size_t)n;
