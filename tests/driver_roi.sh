@@ -27,6 +27,27 @@ try:
 except Exception:
     pass
 print(n)")   # the CPU quota of the box, not every visible hardware thread
+if [[ -n "$GAB_ROI_FMI" ]]; then     # fmi-large: 256 Mbp index + 10 M reads of 151 bp (several minutes: index build on the host)
+  python - <<'PY'
+import sys, os
+sys.path.insert(0, os.getcwd())
+from tools import gabgen, mkindex
+T = "/tmp/gab_roi"
+if not os.path.exists(f"{T}/fmi_reads.fq"):
+    ref = gabgen.fmi_ref(7, 256_000_000, 5)
+    mkindex.FmIndex(ref).write(f"{T}/fmi_ref", with_bns=True)
+    gabgen.fmi_write_fastq(f"{T}/fmi_reads.fq", gabgen.fmi_reads(8, ref, 10_000_000, 151, 151))
+PY
+  GAB_WORKERS_PER_GPU=3 GAB_GPUS=1 ./benchmarks/fmi/fmi $T/fmi_ref $T/fmi_reads.fq 512 19 1 > $T/fmi_out.txt 2> $T/fmi_err.txt
+  grep -E "Computing time|totalSmems" $T/fmi_out.txt | sed "s/^/fmi-large driver, 3 worker(s) per GPU: /"
+  echo "   md5 of the SMEM lines: $(tail -n +7 $T/fmi_out.txt | md5sum | cut -c1-12)"
+  if [[ -x oracle/_ref/fmi_ref ]]; then
+    OMP_PROC_BIND=true OMP_PLACES=cores oracle/_ref/fmi_ref $T/fmi_ref $T/fmi_reads.fq 512 19 $cores > $T/fmi_ref_out.txt 2> $T/fmi_ref_err.txt
+    grep -E "Computing time|totalSmems" $T/fmi_ref_out.txt | sed "s/^/fmi-large reference, $cores threads: /"
+    echo "   md5 of the SMEM lines: $(tail -n +7 $T/fmi_ref_out.txt | md5sum | cut -c1-12)"
+  fi
+  exit 0
+fi
 for w in ${@:-1 2 3}; do   # chain-large through the driver needs its fscanf parse of 85 M anchors (~20 s) per run
   export GAB_WORKERS_PER_GPU=$w GAB_GPUS=1
   ./benchmarks/bsw/main_bsw -pairs $T/bsw.txt -t 1 -b 512 2> $T/bsw_err_$w.txt | grep -E "Overall SW" | sed "s/^/bsw-large driver, $w worker(s) per GPU: /"
