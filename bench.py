@@ -1221,6 +1221,10 @@ def main():
             if not go[0]:
                 suite[name] = {"skipped": f"time budget of {SUITE_BUDGET_S:.0f} s reached (GAB_BENCH_BUDGET_S); run --workload {wname}"}
                 continue
+            if world > 1 and wname.startswith("fmi") and not os.environ.get("GAB_BENCH_SUITE_FMI"):
+                # every rank would build its own 256 Mbp index on the shared host cores (minutes with 8 ranks): not inside a scaling run
+                suite[name] = {"skipped": f"runs at --gpus 1 (the index is built per rank on the host); GAB_BENCH_SUITE_FMI=1 or --workload {wname}"}
+                continue
             SW = WORKLOADS[wname]
             t0 = time.time()
             try:
