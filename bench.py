@@ -1144,14 +1144,16 @@ def run_workload(W, items, steps, warmup, ctx, args, with_cpu=True, with_host=Tr
         # BASELINE.md 3.5 also asks for the fraction of the MEASURED copy bandwidth (6.29 TB/s, MI355X_MICROARCH.md)
         if out["roofline"].get("unit") == "GB/s" and out["roofline"].get("achieved") is not None:
             out["roofline"]["frac_of_measured_copy_6290"] = round(out["roofline"]["achieved"] / 6290.0, 6)
-        if with_host and hasattr(wl, "host_roi") and not args.no_host_roi:
+        if with_host and world == 1 and hasattr(wl, "host_roi") and not args.no_host_roi:
             # what a drop-in driver times: host pointers in, host pointers out (PCIe both ways), never `value`
             try:
                 out["extra"]["roi_incl_pcie"] = wl.host_roi()
             except Exception as e:      # the figure is informative; a failure must not lose the measured line
                 out["extra"]["roi_incl_pcie"] = {"error": str(e)[:300]}
             mark("host-pointer ROI done")
-        if with_cpu and not args.no_cpu_baseline:
+        if world > 1:
+            out["cpu_baseline"] = None                     # timed at N = 1 only (the other ranks would wait for rank 0's host cores)
+        if with_cpu and world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = wl.cpu_baseline(host_cores())
             mark("cpu baseline done")
             cb, v = out["cpu_baseline"], out["value"]
