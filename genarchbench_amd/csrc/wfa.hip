@@ -538,7 +538,10 @@ __device__ __forceinline__ void wave_sync() {
 template <int G>
 __device__ bool wfa_pair_static(OffB *pool, int pool_cap, const WfRow *__restrict__ rows, int nrows, const WfaPen pen,
                                 const uint8_t *P, int plen, const uint8_t *T, int tlen, char *ops_global, char *ops,
-                                int32_t *ops_len_out, int32_t *score_out, unsigned long long &work) {
+                                int32_t *ops_len_out, int32_t *score_out, unsigned long long &work, int r_start, int &resume_row) {
+    // r_start > 0: the pool already holds the wavefronts of rows 0 .. r_start - 1 (a smaller tier ran out of room there);
+    // resume_row > 0 on a false return: the same for the next tier (rows 0 .. resume_row - 1 are complete in `pool`)
+    resume_row = 0;
     const int lane = threadIdx.x & (G - 1);
     const int ak = tlen - plen;
     if (pool_cap < 1 || nrows < 1) return false;
@@ -561,9 +564,9 @@ __device__ bool wfa_pair_static(OffB *pool, int pool_cap, const WfRow *__restric
     // Every wavefront is extended by the lane that computed it, before it is stored: a score step is one pass -- read the
     // sources, max, extend, store -- with one synchronisation, and the end test is a vote on the register of diagonal ak.
     const uint64_t group_mask = (G == 64 ? ~0ull : ((1ull << G) - 1)) << (threadIdx.x & 63 & ~(G - 1));
-    int r = 0;
+    int r = r_start > 0 ? r_start - 1 : 0;
     bool at_end = false, too_big = false;
-    if (lane == 0) {
+    if (r_start <= 0 && lane == 0) {
         const int o = extend(0, 0);
         pool[0] = OffB(o);
         at_end = ak == 0 && o >= tlen;
@@ -578,7 +581,7 @@ __device__ bool wfa_pair_static(OffB *pool, int pool_cap, const WfRow *__restric
         r++;
         if (r >= nrows) return false;
         const WfRow &n = rows[__builtin_amdgcn_readfirstlane(r)];
-        if (n.used_end > pool_cap) return false;
+        if (n.used_end > pool_cap) { resume_row = r; return false; }
         for (int k = n.lo + lane; k <= n.hi; k += G) {
             int best = (n.ms_lo <= k && k <= n.ms_hi) ? (int)pool[n.ms_m + (k - n.ms_lo)] + 1 : kNull;
             if (n.has_gap) {
@@ -654,11 +657,17 @@ __device__ bool wfa_pair_static(OffB *pool, int pool_cap, const WfRow *__restric
 }
 
 // dynamic LDS per group: [P: seqp bytes][T: seqt bytes][pool: pool_cap bytes]; the CIGAR is built over P/T
+// What a static tier leaves behind for a pair it ran out of room for: the row to resume at and the work done so far; the pool
+// bytes (rows 0 .. row - 1, the same layout in every static tier) sit in a slot of `save_pool`.  row = 0: start over.
+struct WfResume { int32_t row; uint32_t pad; unsigned long long work; };
+
 template <int G, bool CHAINED>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void wfa_lds_static(WfaIO io, WfaPen pen, const uint32_t *__restrict__ list, uint32_t count,
                                                      const uint32_t *__restrict__ count_ptr, int seqp, int seqt, int pool_cap,
                                                      uint32_t group_bytes, uint32_t *over_list, uint32_t *over_count, WfaCounters *ct,
-                                                     const WfRow *__restrict__ rows, int nrows) {
+                                                     const WfRow *__restrict__ rows, int nrows,
+                                                     const WfResume *__restrict__ in_hdr, const uint8_t *__restrict__ in_pool, uint32_t in_slots, uint32_t in_slot_bytes,
+                                                     WfResume *out_hdr, uint8_t *out_pool, uint32_t out_slots, uint32_t out_slot_bytes) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem_all[];
     constexpr int kGroups = 64 / G;
     const int grp = threadIdx.x / G, lane = threadIdx.x & (G - 1);
@@ -691,13 +700,41 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void
             *reinterpret_cast<uint32_t *>(T + i) = w;
             pad_byte = pad_byte || has_byte(w, 'X');
         }
+        // a pair the previous static tier ran out of room for continues where it stopped: its wavefronts come back from the slot
+        int r_start = 0;
+        if (CHAINED && in_hdr && b < in_slots) {
+            const WfResume hd = in_hdr[b];
+            if (hd.row > 0) {
+                r_start = hd.row;
+                const int bytes = rows[hd.row - 1].used_end;                 // (OffB = one byte per offset)
+                const uint32_t *src = reinterpret_cast<const uint32_t *>(in_pool + (size_t)b * in_slot_bytes);
+                for (int i = lane; i * 4 < bytes; i += G) reinterpret_cast<uint32_t *>(pool)[i] = src[i];
+                if (lane == 0) work = hd.work;
+            }
+        }
         const uint64_t gm = (G == 64 ? ~0ull : ((1ull << (G & 63)) - 1)) << (threadIdx.x & 63 & ~(G - 1));
         wave_sync();
+        int resume_row = 0;
         if (__ballot(pad_byte) & gm) ok = false;
         else
         ok = wfa_pair_static<G>(pool, pool_cap, rows, nrows, pen, P, plen, T, tlen, io.ops + io.ops_off[id], reinterpret_cast<char *>(P),
-                                io.ops_len + id, io.score + id, work);
-        if (!ok && lane == 0) over_list[atomicAdd(over_count, 1u)] = id;
+                                io.ops_len + id, io.score + id, work, r_start, resume_row);
+        if (!ok) {
+            uint32_t slot = 0;
+            if (lane == 0) { slot = atomicAdd(over_count, 1u); over_list[slot] = id; }
+            if (out_hdr) {
+                slot = __shfl(slot, (int)(threadIdx.x & 63 & ~(G - 1)));
+                unsigned long long gw = work;
+                for (int o = G / 2; o > 0; o >>= 1) gw += __shfl_xor(gw, o);
+                const bool keep = resume_row > 0 && slot < out_slots;
+                if (keep) {
+                    const int bytes = rows[resume_row - 1].used_end;
+                    uint32_t *dst = reinterpret_cast<uint32_t *>(out_pool + (size_t)slot * out_slot_bytes);
+                    for (int i = lane; i * 4 < bytes; i += G) dst[i] = reinterpret_cast<const uint32_t *>(pool)[i];
+                }
+                if (lane == 0) { WfResume hd; hd.row = keep ? resume_row : 0; hd.pad = 0; hd.work = keep ? gw : 0; out_hdr[slot] = hd; }
+            }
+        }
     }
     if (have && ok) work_all += work;
     wave_sync();
@@ -961,15 +998,27 @@ extern "C" int gab_wfa_run_device(gab_wfa *h, const char *pat, int64_t pat_bytes
         int static_pool2 = 2560;
         if (const char *e2 = getenv("GAB_WFA_POOL2")) static_pool2 = atoi(e2);
         const int pools[2] = {static_pool, static_pool2};
+        // the first launch leaves the wavefronts of the pairs it ran out of room for in slots of the scratch buffer and the second
+        // continues them (the pool layout is the table's in both): it does not repeat the ~40 score steps they had come
+        const bool two = pools[1] > pools[0];
+        const uint32_t slots = two ? (uint32_t)std::min<uint64_t>(cnt, std::max<uint64_t>(65536, cnt / 8)) : 0;
+        const size_t o_slots = ((size_t)sizeof(WfResume) * cnt + 255) & ~(size_t)255;
+        WfResume *d_hdr = nullptr; uint8_t *d_slots = nullptr;
+        if (two) {
+            if ((rc = h->scratch.reserve(o_slots + (size_t)slots * pools[0])) != GAB_OK) return rc;
+            d_hdr = (WfResume *)h->scratch.as<char>(); d_slots = (uint8_t *)h->scratch.as<char>() + o_slots;
+        }
         for (int k = 0; k < 2; k++) {
-            if (k == 1 && pools[1] <= pools[0]) break;
+            if (k == 1 && !two) break;
             const size_t per_group = (size_t)(seqp + seqt) + pools[k];
             const uint32_t per_wave = groups[0] == 8 ? 8 : 4;
             const uint32_t blocks = tier == 0 ? (cnt + per_wave - 1) / per_wave : next_grid(shares[std::min(tier, 3)], per_wave, 256);
             const uint32_t *cptr = tier == 0 ? nullptr : &d_ct->tier_over[tier - 1];
             auto kern = groups[0] == 8 ? (tier ? wfa_lds_static<8, true> : wfa_lds_static<8, false>) : (tier ? wfa_lds_static<16, true> : wfa_lds_static<16, false>);
             hipLaunchKernelGGL(kern, dim3(blocks), dim3(64), per_group * per_wave, s, io, h->pen, cur, cnt, cptr, seqp, seqt, pools[k],
-                               (uint32_t)per_group, nxt, &d_ct->tier_over[tier], d_ct, h->rows.as<WfRow>(), static_rows);
+                               (uint32_t)per_group, nxt, &d_ct->tier_over[tier], d_ct, h->rows.as<WfRow>(), static_rows,
+                               k == 1 ? (const WfResume *)d_hdr : nullptr, k == 1 ? (const uint8_t *)d_slots : nullptr, slots, (uint32_t)pools[0],
+                               k == 0 ? d_hdr : nullptr, k == 0 ? d_slots : nullptr, slots, (uint32_t)pools[0]);
             GAB_HIP(hipGetLastError());
             if (!ev2) { GAB_HIP(hipEventRecord(h->ev[2], s)); ev2 = true; }
             after_launch();
