@@ -662,7 +662,7 @@ __device__ bool wfa_pair_static(OffB *pool, int pool_cap, const WfRow *__restric
 struct WfResume { int32_t row; uint32_t pad; unsigned long long work; };
 
 template <int G, bool CHAINED>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void wfa_lds_static(WfaIO io, WfaPen pen, const uint32_t *__restrict__ list, uint32_t count,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(7, 7))) void wfa_lds_static(WfaIO io, WfaPen pen, const uint32_t *__restrict__ list, uint32_t count,
                                                      const uint32_t *__restrict__ count_ptr, int seqp, int seqt, int pool_cap,
                                                      uint32_t group_bytes, uint32_t *over_list, uint32_t *over_count, WfaCounters *ct,
                                                      const WfRow *__restrict__ rows, int nrows,
@@ -972,7 +972,7 @@ extern "C" int gab_wfa_run_device(gab_wfa *h, const char *pat, int64_t pat_bytes
     // complete mode: the first tier takes its directory from the penalties' table (wfa_pair_static) -- no directory in LDS
     const int static_rows = std::min(h->nrows, kOffBMax - 2 - h->h_ct->max_tlen);
     // LDS per pair of the first launch: 1568 B = 6272 B per wave of four = 24 waves per CU, six per SIMD (the kernel is
-    // compiled for that: 73 VGPRs, no scratch), i.e. ~1.2 K offsets behind two 151-bp strings = scores below 44 = 96 % of the
+    // compiled for seven: 65 VGPRs, no scratch; six would do), i.e. ~1.2 K offsets behind two 151-bp strings = scores below 44 = 96 % of the
     // pairs.  Measured: 1 520 offsets at 20 waves 382 M/s, 1 344 at 23 waves 391, 1 088-1 184 at 24 waves 405; the history a
     // pair needs steps with its score, so 1 216-1 312 offsets buy nothing over 1 184 and cost a wave.
     const int static_pool = tuned && byte_tier > 1 ? byte_tier : std::min(1568 - (seqp + seqt), 4080) & ~15;
