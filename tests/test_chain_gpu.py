@@ -42,6 +42,16 @@ def test_vs_oracle(eng, mode, seed, ncalls, gmode, nmin, nmax):
     assert ev_gpu == ev if mode == 1 else ev <= ev_gpu <= 2 * sum(min(i, 5000) for n in batch.hdr["n"] for i in range(int(n)))
 
 
+def test_walk_kernel_variant(eng, monkeypatch):
+    """GAB_CHAIN_KERNEL=walk: the per-anchor walk kernel kept for A/B runs gives the reference's result too"""
+    monkeypatch.setenv("GAB_CHAIN_KERNEL", "walk")
+    batch = gabgen.chain(39, 60, 1, 500, 9000)
+    ws, wp = pyoracle.chain(batch, 0)
+    s, p = eng.host_chain_kernel(batch, 0)
+    np.testing.assert_array_equal(s, ws)
+    np.testing.assert_array_equal(p, wp)
+
+
 @pytest.mark.parametrize("helpers", [3, 5, 7])
 @pytest.mark.parametrize("mode", [0, 1])
 def test_every_helper_count(eng, mode, helpers, monkeypatch):

@@ -80,6 +80,17 @@ def test_padding_characters_inside_the_strings(eng):
     same(eng.align(b), pyoracle.wfa(b))
 
 
+def test_directory_in_lds_variant(eng, monkeypatch):
+    """GAB_WFA_NO_STATIC=1: complete mode through the kernels that keep the directory in LDS (what adaptive mode always uses),
+    with one-byte and with int16 offsets"""
+    monkeypatch.setenv("GAB_WFA_NO_STATIC", "1")
+    for seed, n, mode, plen in ((61, 30000, 0, 151), (62, 5000, 1, 300)):
+        batch = gabgen.pairs(seed, n, mode, plen)
+        want = pyoracle.wfa(batch, want_cells=True)
+        same(eng.align(batch), want)
+        assert eng.last_stats()["work"] == want[4]
+
+
 def test_long_sequences_global_path(eng):
     """sequences beyond the LDS limit and scores beyond the LDS pools -> global-history kernel"""
     rng = np.random.default_rng(11)
