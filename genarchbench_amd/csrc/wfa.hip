@@ -613,11 +613,16 @@ __device__ bool wfa_pair_static(OffB *pool, int pool_cap, const WfRow *__restric
         auto valid_loc = [&](int kk, int oo) { return oo - kk > 0 && oo - kk <= plen && oo > 0 && oo <= tlen; };
         bool valid = valid_loc(k, offset);
         int v = offset - k, h = offset;
+        // the buffer (the strings' LDS, no longer needed) is filled with 'M' once, 16 bytes per lane and store: a run of matches
+        // -- most of the CIGAR -- then only moves the cursor
+        for (int i = 16 * lane; i < cap; i += 16 * G) *reinterpret_cast<uint4 *>(ops + i) = make_uint4(0x4d4d4d4du, 0x4d4d4d4du, 0x4d4d4d4du, 0x4d4d4d4du);
+        wave_sync();
         auto put = [&](char ch) { if (lane == 0 && pos >= 0) ops[pos] = ch; pos--; };
         auto put_run = [&](char ch, int cnt) {
             for (int i = lane; i < cnt && pos - i >= 0; i += G) ops[pos - i] = ch;
             pos -= cnt > 0 ? cnt : 0;
         };
+        auto skip_matches = [&](int cnt) { pos -= cnt > 0 ? cnt : 0; };
         auto in = [&](int lo, int hi, int kk) { return lo <= kk && kk <= hi; };
         while (v > 0 && h > 0 && s > 0) {
             if (!valid) {
@@ -635,7 +640,7 @@ __device__ bool wfa_pair_static(OffB *pool, int pool_cap, const WfRow *__restric
             const int ins_open = (type == 2 || !io_ok) ? kNull : (int)pool[w.mg_m + (k - 1 - w.mg_lo)] + 1;
             const int misms = (type != 0 || !mm_ok) ? kNull : (int)pool[w.ms_m + (k - w.ms_lo)] + 1;
             const int max_all = max(misms, max(max(ins_ext, ins_open), max(del_ext, del_open)));
-            if (type == 0) { put_run('M', offset - max_all); offset = max_all; }
+            if (type == 0) { skip_matches(offset - max_all); offset = max_all; }
             if (max_all == del_ext) { if (valid) put('D'); s -= e; r = w.r_ie; k++; type = 2; }
             else if (max_all == del_open) { if (valid) put('D'); s -= oe; r = w.r_mg; k++; type = 0; }
             else if (max_all == ins_ext) { if (valid) put('I'); s -= e; r = w.r_ie; k--; offset--; type = 1; }
@@ -643,7 +648,7 @@ __device__ bool wfa_pair_static(OffB *pool, int pool_cap, const WfRow *__restric
             else { if (valid) put('X'); s -= x; r = w.r_ms; offset--; }
             v = offset - k; h = offset;
         }
-        if (s == 0) put_run('M', offset);
+        if (s == 0) skip_matches(offset);
         else { put_run('D', v); put_run('I', h); }
     }
     // (writes in front of the buffer were dropped: a CIGAR longer than plen + tlen -- a sequence matching the other's padding
