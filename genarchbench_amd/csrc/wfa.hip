@@ -546,31 +546,51 @@ __device__ bool wfa_pair_static(OffB *pool, int pool_cap, const WfRow *__restric
     const int ak = tlen - plen;
     if (pool_cap < 1 || nrows < 1) return false;
     auto at = [&](int base, int lo, int hi, int k) { return (lo <= k && k <= hi) ? (int)pool[base + (k - lo)] : kNull; };
-    // affine_wavefronts_extend_mwavefront_compute on one diagonal (the padded strings: affine_wavefront_extend.c:51-83)
-    auto extend = [&](int o, int k) {
-        int v = o - k, h = o;
+    // affine_wavefronts_extend_mwavefront_compute (the padded strings: affine_wavefront_extend.c:51-83), sixteen bases at a time:
+    // the number of leading bases of P[v ..] and T[h ..] that match, 0 .. 16 (outside the strings 'X' meets 'Y': 0 -- the kernel
+    // keeps pairs that contain the other's padding byte out of this tier; the LDS copies carry kSeqPad bytes of padding)
+    auto match16 = [&](int v, int h) -> int {
+        if (!(v >= 0 && v <= plen && h >= 0 && h <= tlen)) return 0;
+        const uint64_t d8 = lds_ld8(P, v) ^ lds_ld8(T, h), e8 = lds_ld8(P, v + 8) ^ lds_ld8(T, h + 8);
+        if ((d8 | e8) == 0) return 16;
+        return d8 ? __builtin_ctzll(d8) >> 3 : 8 + (__builtin_ctzll(e8) >> 3);
+    };
+    const int wl = threadIdx.x & 63, gbase = wl & ~(G - 1);
+    const uint64_t group_mask = (G == 64 ? ~0ull : ((1ull << G) - 1)) << gbase;
+    // Extension of the diagonals of one pass (lane = diagonal k, offset o; `active` lanes only).  Every lane compares the first
+    // sixteen bases of its own diagonal; most stop there.  A diagonal that goes on -- usually the one the alignment follows,
+    // for ~50 bases -- used to keep its lane looping alone while the others waited; now the G lanes of the group take G
+    // consecutive 16-base chunks of it at once and a vote finds the first mismatch: one round per such diagonal.
+    auto extend_all = [&](int &o, int k, bool active) {
+        const int c0 = active ? match16(o - k, o) : 0;
+        o += c0; work += (unsigned)c0;
+        bool cont = active && c0 == 16;
         for (;;) {
-            if (v >= 0 && v <= plen && h >= 0 && h <= tlen) {
-                // sixteen bases per step; the LDS copies carry kSeqPad bytes of 'X' / 'Y' behind the strings
-                const uint64_t d8 = lds_ld8(P, v) ^ lds_ld8(T, h), e8 = lds_ld8(P, v + 8) ^ lds_ld8(T, h + 8);
-                if ((d8 | e8) == 0) { o += 16; v += 16; h += 16; work += 16; continue; }
-                const int c8 = d8 ? __builtin_ctzll(d8) >> 3 : 8 + (__builtin_ctzll(e8) >> 3);
-                o += c8; work += c8;
-            }
-            break;      // outside the strings 'X' meets 'Y' (the kernel keeps pairs that contain the other's padding byte out of this tier)
+            const uint64_t cm = __ballot(cont);
+            if (cm == 0) break;                                              // (wave-uniform: no group has a diagonal going on)
+            const uint64_t gm = cm & group_mask;
+            const int src = gm ? (int)__builtin_ctzll(gm) : wl;              // the group's first such lane
+            const int so = __shfl(o, src), sk = __shfl(k, src);
+            const int c = gm ? match16(so - sk + 16 * lane, so + 16 * lane) : 0;
+            const uint64_t fm = __ballot(c < 16) & group_mask;               // the first chunk that does not match through
+            const int jl = fm ? (int)__builtin_ctzll(fm) : gbase + G - 1;
+            const int cj = __shfl(c, jl);
+            const int total = fm ? 16 * (jl - gbase) + cj : 16 * G;
+            if (gm && wl == src) { o += total; work += (unsigned)total; cont = fm == 0; }
         }
-        return o;
     };
     // Every wavefront is extended by the lane that computed it, before it is stored: a score step is one pass -- read the
     // sources, max, extend, store -- with one synchronisation, and the end test is a vote on the register of diagonal ak.
-    const uint64_t group_mask = (G == 64 ? ~0ull : ((1ull << G) - 1)) << (threadIdx.x & 63 & ~(G - 1));
     int r = r_start > 0 ? r_start - 1 : 0;
     bool at_end = false, too_big = false;
-    if (r_start <= 0 && lane == 0) {
-        const int o = extend(0, 0);
-        pool[0] = OffB(o);
-        at_end = ak == 0 && o >= tlen;
-        too_big = o > kOffBSafe;
+    if (r_start <= 0) {
+        int o = 0;
+        extend_all(o, 0, lane == 0);
+        if (lane == 0) {
+            pool[0] = OffB(o);
+            at_end = ak == 0 && o >= tlen;
+            too_big = o > kOffBSafe;
+        }
     }
     for (;;) {
         // an offset beyond the byte's range (a pattern full of the text's padding byte can run past the end of the text):
@@ -582,19 +602,26 @@ __device__ bool wfa_pair_static(OffB *pool, int pool_cap, const WfRow *__restric
         if (r >= nrows) return false;
         const WfRow &n = rows[__builtin_amdgcn_readfirstlane(r)];
         if (n.used_end > pool_cap) { resume_row = r; return false; }
-        for (int k = n.lo + lane; k <= n.hi; k += G) {
-            int best = (n.ms_lo <= k && k <= n.ms_hi) ? (int)pool[n.ms_m + (k - n.ms_lo)] + 1 : kNull;
-            if (n.has_gap) {
-                const int ins = max(at(n.mg_m, n.mg_lo, n.mg_hi, k - 1), at(n.ie_i, n.ie_lo, n.ie_hi, k - 1)) + 1;
-                const int del = max(at(n.mg_m, n.mg_lo, n.mg_hi, k + 1), at(n.ie_d, n.ie_lo, n.ie_hi, k + 1));
-                pool[n.bI + (k - n.lo)] = OffB(ins);
-                pool[n.bD + (k - n.lo)] = OffB(del);
-                best = max(best, max(ins, del));
+        for (int k0 = n.lo; k0 <= n.hi; k0 += G) {                         // (n.lo, n.hi are wave-uniform: every lane takes every trip)
+            const int k = k0 + lane;
+            const bool active = k <= n.hi;
+            int best = kNull;
+            if (active) {
+                best = (n.ms_lo <= k && k <= n.ms_hi) ? (int)pool[n.ms_m + (k - n.ms_lo)] + 1 : kNull;
+                if (n.has_gap) {
+                    const int ins = max(at(n.mg_m, n.mg_lo, n.mg_hi, k - 1), at(n.ie_i, n.ie_lo, n.ie_hi, k - 1)) + 1;
+                    const int del = max(at(n.mg_m, n.mg_lo, n.mg_hi, k + 1), at(n.ie_d, n.ie_lo, n.ie_hi, k + 1));
+                    pool[n.bI + (k - n.lo)] = OffB(ins);
+                    pool[n.bD + (k - n.lo)] = OffB(del);
+                    best = max(best, max(ins, del));
+                }
             }
-            best = extend(best, k);
-            pool[n.bM + (k - n.lo)] = OffB(best);
-            at_end = at_end || (k == ak && best >= tlen);
-            too_big = too_big || best > kOffBSafe;
+            extend_all(best, k, active);
+            if (active) {
+                pool[n.bM + (k - n.lo)] = OffB(best);
+                at_end = at_end || (k == ak && best >= tlen);
+                too_big = too_big || best > kOffBSafe;
+            }
         }
         work += (lane == 0) ? (unsigned)(n.hi - n.lo + 1) : 0u;
     }
