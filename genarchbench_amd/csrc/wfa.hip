@@ -551,7 +551,11 @@ __device__ bool wfa_pair_static(OffB *pool, int pool_cap, const WfRow *__restric
     // keeps pairs that contain the other's padding byte out of this tier; the LDS copies carry kSeqPad bytes of padding)
     auto match16 = [&](int v, int h) -> int {
         if (!(v >= 0 && v <= plen && h >= 0 && h <= tlen)) return 0;
-        const uint64_t d8 = lds_ld8(P, v) ^ lds_ld8(T, h), e8 = lds_ld8(P, v + 8) ^ lds_ld8(T, h + 8);
+        // one 16-byte LDS read per string at ANY byte address (gfx950 reads LDS unaligned; aligned dwords + v_alignbyte cost
+        // three times the instructions)
+        uint4 a, b;
+        __builtin_memcpy(&a, P + v, 16); __builtin_memcpy(&b, T + h, 16);
+        const uint64_t d8 = ((uint64_t)(a.y ^ b.y) << 32) | (a.x ^ b.x), e8 = ((uint64_t)(a.w ^ b.w) << 32) | (a.z ^ b.z);
         if ((d8 | e8) == 0) return 16;
         return d8 ? __builtin_ctzll(d8) >> 3 : 8 + (__builtin_ctzll(e8) >> 3);
     };
