@@ -230,7 +230,9 @@ __device__ bool wfa_pair(WfStore<OffT, ADAPT> &st, const WfaPen pen, const uint8
                 for (;;) {
                     if (LDSSEQ && v >= 0 && v <= plen && h >= 0 && h <= tlen) {
                         // sixteen bases per step (the 'X' / 'Y' padding behind the strings never matches)
-                        const uint64_t d8 = lds_ld8(P, v) ^ lds_ld8(T, h), e8 = lds_ld8(P, v + 8) ^ lds_ld8(T, h + 8);
+                        uint4 qa, qb;                   // one unaligned 16-byte LDS read per string (see wfa_pair_static)
+                        __builtin_memcpy(&qa, P + v, 16); __builtin_memcpy(&qb, T + h, 16);
+                        const uint64_t d8 = ((uint64_t)(qa.y ^ qb.y) << 32) | (qa.x ^ qb.x), e8 = ((uint64_t)(qa.w ^ qb.w) << 32) | (qa.z ^ qb.z);
                         if ((d8 | e8) == 0) { o += 16; v += 16; h += 16; work += 16; continue; }
                         const int c8 = d8 ? __builtin_ctzll(d8) >> 3 : 8 + (__builtin_ctzll(e8) >> 3);
                         o += c8; work += c8;
