@@ -170,13 +170,19 @@ __device__ __forceinline__ uint64_t lds_ld8(const uint8_t *base, int byte_off) {
     return (uint64_t)__builtin_amdgcn_alignbyte(w2, w1, sh) << 32 | __builtin_amdgcn_alignbyte(w1, w0, sh);
 }
 __device__ __forceinline__ uint32_t glb_ld4(const char *p) { uint32_t w; __builtin_memcpy(&w, p, 4); return w; }
-// four bytes of a sequence at `pos`; bytes at or behind `len` read as `fill` (never loads past the dword of the last base)
-__device__ __forceinline__ uint32_t seq_ld4(const char *s, int pos, int len, uint32_t fill) {
-    if (pos + 4 <= len) return glb_ld4(s + pos);
-    uint32_t w = fill * 0x01010101u;
-    for (int b = 0; b < 4; b++)
-        if (pos + b < len) w = (w & ~(0xffu << (8 * b))) | (uint32_t)(uint8_t)s[pos + b] << (8 * b);
-    return w;
+// four bytes of a sequence at `pos` (a multiple of 4); bytes at or behind `len` read as `fill`.  Branch-free: the slab is
+// readable up to the next multiple of 4 (counted from the SLAB's start) behind the sequence, so the last dword is fetched
+// `d` bytes earlier when it would reach past that point (`end_lo` = the low two bits of the sequence's end offset in the
+// slab) and shifted; the bytes behind the end are replaced by a mask.  (The byte loop this used to take for the tail was
+// run by every wave.)
+__device__ __forceinline__ uint32_t seq_ld4(const char *s, int pos, int len, uint32_t fill, int end_lo) {
+    const int rem = len - pos;
+    const int avail = rem + ((4 - end_lo) & 3);               // bytes from pos to the end of the readable range
+    const int d = avail >= 4 ? 0 : 4 - avail;                 // 0 .. 3 (rem > 0 implies avail >= 1)
+    uint32_t w = rem > 0 ? glb_ld4(s + pos - d) : 0u;
+    w >>= 8 * d;
+    const uint32_t m = rem >= 4 ? 0xffffffffu : rem <= 0 ? 0u : (1u << (8 * rem)) - 1u;
+    return (w & m) | (fill * 0x01010101u & ~m);
 }
 
 // One pair, one wave.  LDSSEQ: P/T are LDS copies padded with kSeqPad bytes of 'X'/'Y';
@@ -495,8 +501,9 @@ __global__ __launch_bounds__(64) void wfa_lds(WfaIO io, WfaPen pen, const uint32
         const int plen = io.pat_len[id], tlen = io.txt_len[id];
         const char *gp = io.pat + io.pat_off[id], *gt = io.txt + io.txt_off[id];
         // four bytes per lane and step (the LDS copies are dword-aligned and have room to the next multiple of four)
-        for (int i = 4 * lane; i < plen + kSeqPad; i += 4 * G) *reinterpret_cast<uint32_t *>(P + i) = seq_ld4(gp, i, plen, (uint32_t)'X');
-        for (int i = 4 * lane; i < tlen + kSeqPad; i += 4 * G) *reinterpret_cast<uint32_t *>(T + i) = seq_ld4(gt, i, tlen, (uint32_t)'Y');
+        const int pend = (int)((io.pat_off[id] + plen) & 3), tend = (int)((io.txt_off[id] + tlen) & 3);
+        for (int i = 4 * lane; i < plen + kSeqPad; i += 4 * G) *reinterpret_cast<uint32_t *>(P + i) = seq_ld4(gp, i, plen, (uint32_t)'X', pend);
+        for (int i = 4 * lane; i < tlen + kSeqPad; i += 4 * G) *reinterpret_cast<uint32_t *>(T + i) = seq_ld4(gt, i, tlen, (uint32_t)'Y', tend);
         __syncthreads();
         WfStore<OffT, ADAPT> st;
         st.pool = pool; st.dir = dir; st.pool_cap = pool_cap; st.dir_cap = dir_cap; st.used = 0;
@@ -728,13 +735,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(7, 7))) void
         // does not look there, so such a pair (never a DNA read) goes to the general kernel.
         auto has_byte = [](uint32_t w, uint32_t c) { const uint32_t x = w ^ (c * 0x01010101u); return ((x - 0x01010101u) & ~x & 0x80808080u) != 0; };
         bool pad_byte = false;
+        const int pend = (int)((io.pat_off[id] + plen) & 3), tend = (int)((io.txt_off[id] + tlen) & 3);
         for (int i = 4 * lane; i < plen + kSeqPad; i += 4 * G) {
-            const uint32_t w = seq_ld4(gp, i, plen, (uint32_t)'X');
+            const uint32_t w = seq_ld4(gp, i, plen, (uint32_t)'X', pend);
             *reinterpret_cast<uint32_t *>(P + i) = w;
             pad_byte = pad_byte || has_byte(w, 'Y');
         }
         for (int i = 4 * lane; i < tlen + kSeqPad; i += 4 * G) {
-            const uint32_t w = seq_ld4(gt, i, tlen, (uint32_t)'Y');
+            const uint32_t w = seq_ld4(gt, i, tlen, (uint32_t)'Y', tend);
             *reinterpret_cast<uint32_t *>(T + i) = w;
             pad_byte = pad_byte || has_byte(w, 'X');
         }
