@@ -669,7 +669,7 @@ class WfaWorkload:
         ach = self.alg_bytes / (k * 1e-3) / 1e9
         return {"bound": "hbm", "achieved": round(ach, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(ach / HBM_PEAK_GBS, 6), "traffic": None,
-                "note": "plen+tlen+cigar+4 B per pair; the kernel is instruction-issue bound (80 % VALU busy at 43 % lane utilisation: four pairs per wave, lanes = diagonals)"}
+                "note": "plen+tlen+cigar+4 B per pair; the kernel is instruction-issue bound (83 % VALU busy at 45 % lane utilisation: four pairs per wave, lanes = diagonals)"}
 
     def host_roi(self, chunk=1 << 18):
         import ctypes as C
