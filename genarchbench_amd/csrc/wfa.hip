@@ -696,7 +696,12 @@ __device__ bool wfa_pair_static(OffB *pool, int pool_cap, const WfRow *__restric
     pos = max(pos, -1) + 1;
     const int nops = cap - pos;
     wave_sync();
-    for (int i = lane; i < nops; i += G) ops_global[i] = ops[pos + i];
+    // the CIGAR leaves the CU four bytes per lane and store (unaligned LDS read, unaligned global store), its last 0 .. 3 bytes singly
+    {
+        const int n4 = nops & ~3;
+        for (int i = 4 * lane; i < n4; i += 4 * G) { uint32_t w4; __builtin_memcpy(&w4, ops + pos + i, 4); __builtin_memcpy(ops_global + i, &w4, 4); }
+        if (lane < nops - n4) ops_global[n4 + lane] = ops[pos + n4 + lane];
+    }
     if (lane == 0) { *ops_len_out = nops; *score_out = score; }
     return true;
 }
