@@ -73,6 +73,16 @@ __device__ __forceinline__ int bpm_code(uint32_t ch, bool &clean) {
     return acgt ? (int)(x ^ (x >> 1)) : 4;
 }
 
+// bpm_code for the four bytes of a dword at once: the 2-bit codes as bytes (A0 C1 G2 T3), and whether all four are upper-case
+// A / C / G / T -- the codes select the expected letter from "ACGT" with one v_perm_b32 and one compare checks all four.
+// (A byte that is none of them yields some code 0 .. 3 and ok = false: the pair is re-done by the band kernel.)
+__device__ __forceinline__ uint32_t bpm_codes4(uint32_t w, bool &clean) {
+    const uint32_t x = (w >> 1) & 0x03030303u;                               // A0 C1 G3 T2
+    const uint32_t c4 = x ^ ((x >> 1) & 0x01010101u);                        // A0 C1 G2 T3
+    clean = clean && __builtin_amdgcn_perm(0u, 0x54474341u, c4) == w;       // selector byte k picks 'A' 'C' 'G' 'T'
+    return c4;
+}
+
 __device__ __forceinline__ uint32_t ld_u32(const char *p) { uint32_t w; __builtin_memcpy(&w, p, 4); return w; }
 // 16 bytes per lane and load: every lane streams its own sequence, and with 4-byte loads each 64-byte line was
 // re-fetched from HBM up to 16 times (profiles/r01_hbm_traffic.md: 8.7x the algorithmic bytes, HBM-bound)
@@ -230,10 +240,11 @@ __global__ __launch_bounds__(kBlock) void bpm_score(BpmIO io, const uint32_t *__
         int h0 = 0;
         for (; h0 + 16 <= m; h0 += 16) {
             const uint4 q = ld_u128(t + h0);
-            const uint32_t ws[4] = {q.x, q.y, q.z, q.w};
+            // (codes of four text bases at a time: bpm_code per base was 8 of the 54 instructions a base costs)
+            const uint32_t cs[4] = {bpm_codes4(q.x, clean), bpm_codes4(q.y, clean), bpm_codes4(q.z, clean), bpm_codes4(q.w, clean)};
 #pragma unroll
             for (int kk = 0; kk < 16; kk++) {
-                const int c = bpm_code((ws[kk >> 2] >> ((kk & 3) * 8)) & 0xffu, clean);
+                const int c = (int)((cs[kk >> 2] >> ((kk & 3) * 8)) & 3u);
                 uint32_t PH = 1, MH = 0;
 #pragma unroll
                 for (int b = 0; b < W; b++)
@@ -248,7 +259,7 @@ __global__ __launch_bounds__(kBlock) void bpm_score(BpmIO io, const uint32_t *__
                 uint32_t PH = 1, MH = 0;
 #pragma unroll
                 for (int b = 0; b < W; b++)
-                    bpm_step(peq[(b * 4 + c) * kBlock], b == W - 1 ? top_mask : 1ull << 63, P[b], M[b], PH, MH);
+                    bpm_step(peq[(b * 4 + (c & 3)) * kBlock], b == W - 1 ? top_mask : 1ull << 63, P[b], M[b], PH, MH);
                 score += (int)PH - (int)MH;
             }
         }
