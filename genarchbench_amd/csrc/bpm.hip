@@ -338,9 +338,19 @@ __global__ __launch_bounds__(64) void bpm_band(BpmIO io, const uint32_t *__restr
                 const int r0 = start(h + 1);
                 const int b0 = r0 >> 6, sh = r0 & 63;
                 uint64_t plo = P[0], phi = W > 1 ? P[W > 1 ? 1 : 0] : 0, mlo = M[0], mhi = W > 1 ? M[W > 1 ? 1 : 0] : 0;
+                // which 64-row word the band starts in is the same for the whole wave except in the few columns where the
+                // lanes cross a word boundary (their diagonals differ by a row or two): then the words are named by a scalar
+                // switch instead of being selected per lane (eight 64-bit selects per column)
+                const int b0u = __builtin_amdgcn_readfirstlane(b0);
+                if (W > 1 && __ballot(b0 != b0u) == 0) {
 #pragma unroll
-                for (int b = 1; b < W; b++)
-                    if (b0 == b) { plo = P[b]; mlo = M[b]; phi = b + 1 < W ? P[b + 1 < W ? b + 1 : b] : 0; mhi = b + 1 < W ? M[b + 1 < W ? b + 1 : b] : 0; }
+                    for (int b = 1; b < W; b++)
+                        if (b0u == b) { plo = P[b]; mlo = M[b]; phi = b + 1 < W ? P[b + 1 < W ? b + 1 : b] : 0; mhi = b + 1 < W ? M[b + 1 < W ? b + 1 : b] : 0; }
+                } else {
+#pragma unroll
+                    for (int b = 1; b < W; b++)
+                        if (b0 == b) { plo = P[b]; mlo = M[b]; phi = b + 1 < W ? P[b + 1 < W ? b + 1 : b] : 0; mhi = b + 1 < W ? M[b + 1 < W ? b + 1 : b] : 0; }
+                }
                 const uint32_t bm = (1u << kBandRows) - 1u;
                 const uint32_t pw = (uint32_t)((sh ? (plo >> sh) | (phi << (64 - sh)) : plo)) & bm;
                 const uint32_t mw = (uint32_t)((sh ? (mlo >> sh) | (mhi << (64 - sh)) : mlo)) & bm;
