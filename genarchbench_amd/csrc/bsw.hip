@@ -328,9 +328,6 @@ __device__ __forceinline__ uint32_t pk_mul_lo(uint32_t a, uint32_t b) {
 __device__ __forceinline__ uint32_t pk_max_i16(uint32_t a, uint32_t b) {
     uint32_t r; asm("v_pk_max_i16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r;
 }
-__device__ __forceinline__ uint32_t pk_sub_i16_k(uint32_t a, uint32_t k) {       // k: wave-uniform, stays in an SGPR
-    uint32_t r; asm("v_pk_sub_i16 %0, %1, %2" : "=v"(r) : "v"(a), "s"(k)); return r;
-}
 __device__ __forceinline__ uint32_t pk_subsat_u16_k(uint32_t a, uint32_t k) {    // max(half - k, 0), unsigned halves
     uint32_t r; asm("v_pk_sub_u16 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "s"(k)); return r;
 }
@@ -343,13 +340,19 @@ __device__ __forceinline__ uint32_t pk_max_i16_0(uint32_t a) {
 __device__ __forceinline__ uint32_t pk_min_u16_1(uint32_t a) {                    // min(half, 1) on both halves
     uint32_t r; asm("v_pk_min_u16 %0, %1, 1 op_sel_hi:[1,0]" : "=v"(r) : "v"(a)); return r;
 }
-// result.hi = max(a.hi, b.lo); result.lo = max(a.lo, b.lo)
-__device__ __forceinline__ uint32_t pk_max_i16_hi_from_lo(uint32_t a, uint32_t b) {
-    uint32_t r; asm("v_pk_max_i16 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(r) : "v"(a), "v"(b)); return r;
+// Non-packed 16-bit / 32-bit instructions of the 2-cycle class (profiles/r02_valu_issue.md), all operands in VGPRs.  On gfx9
+// a 16-bit VOP2 instruction reads the low halves of its sources and writes zero to the upper half of its destination.
+__device__ __forceinline__ uint32_t max_i16_lo(uint32_t a, uint32_t b) {
+    uint32_t r; asm("v_max_i16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r;
 }
-// result.lo = max(a.hi, b.lo); result.hi = max(a.hi, b.hi)
-__device__ __forceinline__ uint32_t pk_max_i16_lo_from_hi(uint32_t a, uint32_t b) {
-    uint32_t r; asm("v_pk_max_i16 %0, %1, %2 op_sel:[1,0]" : "=v"(r) : "v"(a), "v"(b)); return r;
+__device__ __forceinline__ uint32_t sub_u16_lo(uint32_t a, uint32_t b) {
+    uint32_t r; asm("v_sub_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r;
+}
+__device__ __forceinline__ uint32_t shr16(uint32_t a) {
+    uint32_t r; asm("v_lshrrev_b32 %0, 16, %1" : "=v"(r) : "v"(a)); return r;
+}
+__device__ __forceinline__ uint32_t add_u32_v(uint32_t a, uint32_t b) {
+    uint32_t r; asm("v_add_u32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r;
 }
 struct BswCellOut { int h, en, f; };
 __device__ __forceinline__ BswCellOut bsw_cell(int diag, int e, int f, uint32_t qc, uint32_t rlo, uint32_t rhi, int oe_del,
@@ -460,33 +463,40 @@ __global__ __launch_bounds__(64) void bsw_dp8(BswIO io, BswConst c, const BswRec
                 // between the two cells is scalar.  The loop is unrolled by two pairs so that the software pipeline
                 // (next pair's LDS words in flight while this pair is computed) needs no register copies.
                 const uint32_t k_oe_del = as_u32(pk_splat(oe_del)), k_e_del = as_u32(pk_splat(e_del));
-                const uint32_t k_oe_ins = as_u32(pk_splat(oe_ins)), k_e_ins = as_u32(pk_splat(e_ins));
-                const uint32_t k_bias = 0x00800080u, k_nib = 0x000f000fu, k_hi = 0xffff0000u;
-                uint32_t k_selz = 0x0c000c00u;                                   // per-lane copy: the third VOP3 source
-                asm volatile("" : "+v"(k_selz));
-                // carried between pairs: HB.hi = H of the previous column, FV.lo = F entering the pair (other halves unused)
-                uint32_t HB = (uint32_t)hleft << 16, FV = (uint32_t)f;
+                const uint32_t k_oe_ins = as_u32(pk_splat(oe_ins));
+                const uint32_t k_bias = 0x00800080u, k_nib = 0x000f000fu;
+                // per-lane copies of wave-uniform constants: the third VOP3 source of v_and_or_b32, and the operands of the
+                // 2-cycle instructions below (an SGPR or literal source makes them 4-cycle instructions, r02_valu_issue.md)
+                uint32_t k_selz = 0x0c000c00u, k_lo8 = 0x00ff00ffu, v_e_ins = (uint32_t)e_ins;
+                asm volatile("" : "+v"(k_selz), "+v"(k_lo8), "+v"(v_e_ins));
+                // carried between pairs, both in the LOW half of their register (high half zero):
+                // HB = H of the previous column, FV = F entering the pair
+                uint32_t HB = (uint32_t)hleft, FV = (uint32_t)f;
                 // M is clamped at 0 (unsigned saturating subtract): H, E' and F all take a max with a non-negative
                 // value, so the clamp changes none of them and lets E' / F-source use saturating subtracts too.
+                // The column-to-column carry chain (H[j] -> F -> H[j+1] -> F) uses one half per instruction anyway: it runs in
+                // the NON-packed 16-bit instructions (v_max_i16 / v_sub_u16 on the low halves, two shifts to bring the upper
+                // halves of ME and T down), which issue every 2.6 cycles at this occupancy instead of 4.2 (profiles/r02_valu_issue.md);
+                // so do the plain 32-bit add of the two packed halves (no carry: both < 256) and the byte mask.
 #define BSW_PAIR(V, QB, JJ, OUT)                                                                                \
     {                                                                                                             \
-        const uint32_t d2 = (V) & 0x00ff00ffu;                                   /* diag of both columns */      \
+        const uint32_t d2 = (V) & k_lo8;                                         /* diag of both columns */      \
         const uint32_t e2 = __builtin_amdgcn_perm(0u, (V), 0x0c030c01u);         /* E of both columns */         \
         const uint32_t sel = and_or_b32((QB) * 0x1001u, k_nib, k_selz);          /* code j -> byte 0, j+1 -> 2 */\
         const uint32_t sc2 = __builtin_amdgcn_perm(rhi, rlo, sel);               /* biased scores per half */    \
-        const uint32_t Mc = pk_subsat_u16_k(as_u32(as_u16x2(d2) + as_u16x2(sc2)), k_bias);                       \
+        const uint32_t Mc = pk_subsat_u16_k(add_u32_v(d2, sc2), k_bias);                                         \
         const uint32_t M = pk_mul_lo(Mc, pk_min_u16_1(d2));                      /* diag == 0 -> M = 0 */        \
         const uint32_t EN = pk_max_i16(pk_subsat_u16_k(M, k_oe_del), pk_subsat_u16_k(e2, k_e_del));              \
         const uint32_t T = pk_subsat_u16_k(M, k_oe_ins);                                                         \
         const uint32_t ME = pk_max_i16(M, e2);                                                                   \
-        const uint32_t HA = pk_max_i16(ME, FV);                                  /* lo = H[j]   */               \
-        const uint32_t FA = pk_max_i16(T, pk_sub_i16_k(FV, k_e_ins));            /* lo = F leaving column j */   \
+        const uint32_t HA = max_i16_lo(ME, FV);                                  /* H[j] */                      \
+        const uint32_t FA = max_i16_lo(T, sub_u16_lo(FV, v_e_ins));              /* F leaving column j */        \
         const uint32_t hprev = HB;                                                                               \
-        HB = pk_max_i16_hi_from_lo(ME, FA);                                      /* hi = H[j+1] */               \
-        FV = pk_max_i16_lo_from_hi(T, pk_sub_i16_k(FA, k_e_ins));                /* lo = F leaving column j+1 */ \
-        /* byte 0 = H[j-1] (hprev byte 2), byte 1 = E'[j], byte 2 = H[j] (HA byte 0), byte 3 = E'[j+1] */        \
-        (OUT) = (EN << 8) | __builtin_amdgcn_perm(HA, hprev, 0x0c040c02u);                                       \
-        const uint32_t pa = (HA << 16) | (uint32_t)(JJ), pb = and_or_b32(HB, k_hi, (uint32_t)((JJ) + 1));       \
+        HB = max_i16_lo(shr16(ME), FA);                                          /* H[j+1] */                    \
+        FV = max_i16_lo(shr16(T), sub_u16_lo(FA, v_e_ins));                      /* F leaving column j+1 */      \
+        /* byte 0 = H[j-1] (hprev), byte 1 = E'[j], byte 2 = H[j] (HA byte 0), byte 3 = E'[j+1] */               \
+        (OUT) = (EN << 8) | __builtin_amdgcn_perm(HA, hprev, 0x0c040c00u);                                       \
+        const uint32_t pa = (HA << 16) | (uint32_t)(JJ), pb = (HB << 16) | (uint32_t)((JJ) + 1);                 \
         rowpk = max(max(rowpk, pa), pb);                                                                         \
     }
                 for (; j + 3 < end; j += 4, cw += 128, qp += 128) {
@@ -500,7 +510,7 @@ __global__ __launch_bounds__(64) void bsw_dp8(BswIO io, BswConst c, const BswRec
                     BSW_PAIR(v0, q0, j, cw[0])
                     j += 2; v0 = v1; q0 = q1;
                 }
-                hleft = (int)(HB >> 16); f = (int)(FV & 0xffffu);
+                hleft = (int)HB; f = (int)FV;
 #undef BSW_PAIR
             }
             if (j < end) {                        // band ends on the lower half of a pair: its word is already in v0
