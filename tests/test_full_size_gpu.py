@@ -2,8 +2,8 @@
 builder-run only").
 
 `tests/full_parity.py` compares EVERY item of a large configuration with the oracle: the score of all 10 M bsw and bpm
-pairs and of all 10 M bitpal pairs in both of its modes, score + length + every CIGAR operation of all 1 M wfa pairs (complete and adaptive), score and parent of all
-85 M anchors of the 10 000 chain / fast-chain calls.  It runs here as ONE child process (a second GPU process beside the
+pairs and of all 10 M bitpal pairs in both of its modes, score + length + every CIGAR operation of all 1 M wfa pairs
+(complete and adaptive), score and parent of all 85 M anchors of the 10 000 chain / fast-chain calls.  It runs here as ONE child process (a second GPU process beside the
 test runner, inside the box's process guard) so that its 10 M-pair buffers are gone when it returns.  fmi-large (211 s of
 oracle time for its 77 M SMEM records, plus the 256 Mbp index build) stays in the stand-alone script
 (`python tests/full_parity.py`, last run kept in profiles/rNN_full_size_parity.md); its kernels are covered at reduced

@@ -9,8 +9,9 @@ rnd = sys.argv[1]
 src = os.path.join(root, "gpurun_out", rnd)
 which = sys.argv[2:] or sorted({f[len("bench_"):-len(".json")] for f in os.listdir(src) if f.startswith("bench_") and f.endswith(".json")})
 for w in which:
-    stats = glob.glob(os.path.join(src, f"prof_{w}", "**", "*kernel_stats.csv"), recursive=True)
-    trace = glob.glob(os.path.join(src, f"prof_{w}", "**", "*kernel_trace.csv"), recursive=True)
+    # gpurun merges every call's files into the same directory: take the NEWEST collection, not the first the glob finds
+    newest = lambda pat: sorted(glob.glob(os.path.join(src, f"prof_{w}", "**", pat), recursive=True), key=os.path.getmtime, reverse=True)
+    stats, trace = newest("*kernel_stats.csv"), newest("*kernel_trace.csv")
     if stats:
         shutil.copyfile(stats[0], os.path.join(root, "profiles", f"{rnd}_{w}_large_kernel_stats.csv"))
     if trace and w in ("bsw", "bpm"):
