@@ -337,6 +337,9 @@ __device__ __forceinline__ uint32_t and_or_b32(uint32_t a, uint32_t mask, uint32
 __device__ __forceinline__ uint32_t pk_max_i16_0(uint32_t a) {
     uint32_t r; asm("v_pk_max_i16 %0, %1, 0" : "=v"(r) : "v"(a)); return r;
 }
+__device__ __forceinline__ uint32_t pk_min_u16(uint32_t a, uint32_t b) {
+    uint32_t r; asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r;
+}
 __device__ __forceinline__ uint32_t pk_min_u16_1(uint32_t a) {                    // min(half, 1) on both halves
     uint32_t r; asm("v_pk_min_u16 %0, %1, 1 op_sel_hi:[1,0]" : "=v"(r) : "v"(a)); return r;
 }
@@ -366,8 +369,9 @@ __device__ __forceinline__ BswCellOut bsw_cell(int diag, int e, int f, uint32_t 
     return o;
 }
 
-// SYM: o_del + e_del == o_ins + e_ins (BWA-MEM's defaults): M - (o + e) is the same value for the E and the F source
-template <bool SYM>
+// SYM: o_del + e_del == o_ins + e_ins (BWA-MEM's defaults): M - (o + e) is the same value for the E and the F source.
+// MS1: no score above 1 (BWA-MEM's a = 1): for diag >= 1, M <= diag + 1 <= 2 diag, so "diag == 0 -> M = 0" is min(M, 2 diag).
+template <bool SYM, bool MS1>
 __global__ __launch_bounds__(64) void bsw_dp8(BswIO io, BswConst c, const BswRec *__restrict__ recs, int64_t kbeg,
                                               int64_t kend, int qcap, int32_t *__restrict__ score_out,
                                               gab_bsw_result *__restrict__ result_out, BswStats *st) {
@@ -487,7 +491,7 @@ __global__ __launch_bounds__(64) void bsw_dp8(BswIO io, BswConst c, const BswRec
         const uint32_t sel = and_or_b32((QB) * 0x1001u, k_nib, k_selz);          /* code j -> byte 0, j+1 -> 2 */\
         const uint32_t sc2 = __builtin_amdgcn_perm(rhi, rlo, sel);               /* biased scores per half */    \
         const uint32_t Mc = pk_subsat_u16_k(add_u32_v(d2, sc2), k_bias);                                         \
-        const uint32_t M = pk_mul_lo(Mc, pk_min_u16_1(d2));                      /* diag == 0 -> M = 0 */        \
+        const uint32_t M = MS1 ? pk_min_u16(Mc, add_u32_v(d2, d2)) : pk_mul_lo(Mc, pk_min_u16_1(d2));   /* diag == 0 -> M = 0 */ \
         const uint32_t Md = pk_subsat_u16_k(M, k_oe_del);                                                        \
         const uint32_t EN = pk_max_i16(Md, pk_subsat_u16_k(e2, k_e_del));                                        \
         const uint32_t T = SYM ? Md : pk_subsat_u16_k(M, k_oe_ins);                                              \
@@ -638,8 +642,10 @@ extern "C" int gab_bsw_create(const gab_bsw_params *p, int device, gab_bsw **out
     // the 256-base class needs more than the default 64 KiB of dynamic LDS
     if (hipFuncSetAttribute((const void *)bsw_dp<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
         hipFuncSetAttribute((const void *)bsw_dp<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
-        hipFuncSetAttribute((const void *)bsw_dp8<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64) != hipSuccess ||
-        hipFuncSetAttribute((const void *)bsw_dp8<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64) != hipSuccess) {
+        hipFuncSetAttribute((const void *)bsw_dp8<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64) != hipSuccess ||
+        hipFuncSetAttribute((const void *)bsw_dp8<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64) != hipSuccess ||
+        hipFuncSetAttribute((const void *)bsw_dp8<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64) != hipSuccess ||
+        hipFuncSetAttribute((const void *)bsw_dp8<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64) != hipSuccess) {
         gab_set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed"); delete h; return GAB_EDEVICE;
     }
     if (hipHostMalloc((void **)&h->h_qstart, sizeof(uint32_t) * (kQBuckets + 1)) != hipSuccess ||
@@ -744,7 +750,9 @@ extern "C" int gab_bsw_run_device(gab_bsw *h, const uint8_t *ref, int64_t ref_by
         if ((int64_t)h->h_stats->max_h0 + (int64_t)qcap * h->cst.max_sc <= 255 && h->cst.max_sc >= 0) {
             const size_t lds8 = sizeof(uint32_t) * 64 * ((size_t)(qcap + 2) / 2 + ((size_t)(qcap + 1) / 2 + 3) / 4 + 1);
             const bool sym = h->cst.o_del + h->cst.e_del == h->cst.o_ins + h->cst.e_ins;
-            hipLaunchKernelGGL(sym ? bsw_dp8<true> : bsw_dp8<false>, dim3(blocks), dim3(64), lds8, s, io, h->cst, d_recs, kb, ke, qcap,
+            const bool ms1 = h->cst.max_sc <= 1;
+            auto kern = sym ? (ms1 ? bsw_dp8<true, true> : bsw_dp8<true, false>) : (ms1 ? bsw_dp8<false, true> : bsw_dp8<false, false>);
+            hipLaunchKernelGGL(kern, dim3(blocks), dim3(64), lds8, s, io, h->cst, d_recs, kb, ke, qcap,
                                score_out, result_out, d_stats);
             continue;
         }
