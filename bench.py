@@ -192,18 +192,21 @@ class BswWorkload:
                 "dominant_kernel_timing": "HIP events around the DP launches of a step: one bsw_dp8 launch per query-length class, "
                                           "two in flight at a time (two streams), so rocprofv3's per-launch durations overlap; the matching "
                                           "figure is the first-start-to-last-end span (tools/profiling/kernel_span.py on "
-                                          "profiles/r01_bsw_large_kernel_trace.csv: 46.6-47.3 ms)",
-                # the bound that matters: integer VALU issue.  19.7 lane-instructions per DP cell is the PMC figure
-                # (SQ_INSTS_VALU x 64 / cells, profiles/r01_bsw_pmc.md).  Peak: MEASURED, profiles/r02_valu_issue.md
-                # (tools/microbench/valu_issue.hip): the packed 16-bit, SDWA, v_perm_b32, v_and_or_b32 and 32-bit max/min
-                # instructions this kernel is made of issue once per 4 cycles per SIMD whatever the occupancy (38.4-38.6 T
-                # lane-instr/s measured, 256 CUs x 4 SIMDs x 64 lanes x 2.4 GHz / 4 = 39.3 T); only v_add/sub/and/or/xor/
-                # lshr/mov, fp32 add/mul/fma and the NON-packed 16-bit integer / f16 ops reach one per 2 cycles, and only with
-                # >= 4 waves per SIMD (2.56 cycles at 2) -- the kernel runs at 1.85 waves per SIMD (LDS-capped).
-                "valu": {"lane_instr_per_cell": 19.7, "achieved_T_lane_instr_per_s":
-                         round(19.7 * self.cells / (k * 1e9), 2) if k else None, "peak_T_lane_instr_per_s": 39.3,
-                         "peak_source": "profiles/r02_valu_issue.md (measured issue rate of this kernel's instruction classes)",
-                         "frac": round(19.7 * self.cells / (k * 1e9) / 39.3, 3) if k else None}}
+                                          "profiles/r02_bsw_large_kernel_trace.csv)",
+                # the bound that matters: integer VALU issue.  19.9 lane-instructions per DP cell is the PMC figure of the
+                # end of r02 (SQ_INSTS_VALU x 64 / cells, profiles/r02_kernel_bounds.md).  Peak: MEASURED, profiles/r02_valu_issue.md
+                # (tools/microbench/valu_issue.hip): the packed 16-bit, v_perm_b32, v_and_or_b32, v_lshl_or_b32, v_max3 and
+                # 24-bit multiply instructions issue once per 4 cycles per SIMD whatever the occupancy (4.22 at the kernel's
+                # ~2 waves per SIMD; 256 CUs x 4 SIMDs x 64 lanes x 2.4 GHz / 4 = 39.3 T lane-instr/s), the non-packed 16-bit
+                # max / sub, 32-bit add / and / shift-right / mov ones once per 2.56-2.81 cycles at 2 waves per SIMD.  The loop
+                # is 33 instructions of the first and 29 of the second kind per four cells (disassembly), i.e. 3.5 cycles per
+                # instruction on average = 45 T lane-instr/s for this mix at this occupancy (LDS-capped).
+                "valu": {"lane_instr_per_cell": 19.9, "achieved_T_lane_instr_per_s":
+                         round(19.9 * self.cells / (k * 1e9), 2) if k else None, "peak_T_lane_instr_per_s": 45.0,
+                         "peak_source": "profiles/r02_valu_issue.md (measured issue cost of the kernel's instruction classes at 2 waves "
+                                        "per SIMD, weighted by the loop's mix: 33 x 4.22 + 29 x 2.6 cycles per 62 instructions)",
+                         "frac": round(19.9 * self.cells / (k * 1e9) / 45.0, 3) if k else None,
+                         "frac_if_every_instruction_cost_4_cycles": round(19.9 * self.cells / (k * 1e9) / 39.3, 3) if k else None}}
 
     def roofline(self):
         k = float(np.mean(self.kernel_ms))
