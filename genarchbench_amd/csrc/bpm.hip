@@ -53,6 +53,7 @@ struct BpmCounters {        // device-side, zeroed per run
     uint32_t wl2_count[8];  // pairs whose backtrace left the 64-row window (re-run with the full history)
     uint32_t wl1_count[8];  // pairs whose backtrace left the 8-row LDS band (re-run with the 64-row window)
     int32_t max_tlen[8];    // longest text per class (sizes the LDS band)
+    int32_t max_plen[8];    // longest pattern per class (selects the number of 32-bit words of the score kernel)
     int32_t bad, first_bad;
     unsigned long long steps;   // block steps executed by bpm_score (m * W summed)
     unsigned long long full_steps;
@@ -113,7 +114,7 @@ __device__ __forceinline__ uint32_t wave_class_add(uint32_t *counters, int cls, 
 __global__ __launch_bounds__(256) void bpm_count(BpmIO io, BpmCounters *ct) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     uint32_t mine[kClasses] = {0, 0, 0, 0, 0};
-    int mt[kClasses] = {0, 0, 0, 0, 0};
+    int mt[kClasses] = {0, 0, 0, 0, 0}, mp[kClasses] = {0, 0, 0, 0, 0};
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < io.n; i += stride) {
         const int n = io.pat_len[i], m = io.txt_len[i];
         const int64_t po = io.pat_off[i], to = io.txt_off[i];
@@ -126,26 +127,27 @@ __global__ __launch_bounds__(256) void bpm_count(BpmIO io, BpmCounters *ct) {
         }
         const int cls = bpm_class(n);
 #pragma unroll
-        for (int k = 0; k < kClasses; k++) { mine[k] += cls == k; mt[k] = (cls == k && m > mt[k]) ? m : mt[k]; }
+        for (int k = 0; k < kClasses; k++) { mine[k] += cls == k; mt[k] = (cls == k && m > mt[k]) ? m : mt[k]; mp[k] = (cls == k && n > mp[k]) ? n : mp[k]; }
     }
     // wave reductions, then one set of atomics per workgroup (they serialise in L2 on a handful of addresses)
-    __shared__ int s_mt[4][kClasses];
+    __shared__ int s_mt[4][kClasses], s_mp[4][kClasses];
     __shared__ uint32_t s_cnt[4][kClasses];
     const int wv = threadIdx.x >> 6;
 #pragma unroll
     for (int k = 0; k < kClasses; k++) {
-        int v = mt[k];
-        for (int o = 32; o > 0; o >>= 1) { const int u = __shfl_xor(v, o); v = u > v ? u : v; }
+        int v = mt[k], vp = mp[k];
+        for (int o = 32; o > 0; o >>= 1) { const int u = __shfl_xor(v, o); v = u > v ? u : v; const int up = __shfl_xor(vp, o); vp = up > vp ? up : vp; }
         uint32_t c = mine[k];
         for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
-        if ((threadIdx.x & 63) == 0) { s_mt[wv][k] = v; s_cnt[wv][k] = c; }
+        if ((threadIdx.x & 63) == 0) { s_mt[wv][k] = v; s_mp[wv][k] = vp; s_cnt[wv][k] = c; }
     }
     __syncthreads();
     if (threadIdx.x < kClasses) {
         const int k = threadIdx.x;
-        int v = 0; uint32_t c = 0;
-        for (int w2 = 0; w2 < 4; w2++) { v = s_mt[w2][k] > v ? s_mt[w2][k] : v; c += s_cnt[w2][k]; }
+        int v = 0, vp = 0; uint32_t c = 0;
+        for (int w2 = 0; w2 < 4; w2++) { v = s_mt[w2][k] > v ? s_mt[w2][k] : v; vp = s_mp[w2][k] > vp ? s_mp[w2][k] : vp; c += s_cnt[w2][k]; }
         if (v > 0) atomicMax(&ct->max_tlen[k], v);
+        if (vp > 0) atomicMax(&ct->max_plen[k], vp);
         if (c) atomicAdd(&ct->cls_count[k], c);
     }
 }
@@ -286,6 +288,106 @@ __global__ __launch_bounds__(kBlock) void bpm_score(BpmIO io, const uint32_t *__
     if (threadIdx.x == 0) {
         unsigned long long all = 0;
         for (int k = 0; k < kBlock / 64; k++) all += s_steps[k];
+        if (all) atomicAdd(&ct->steps, all);
+    }
+}
+
+// ---- score path in 32-bit words: D = ceil(plen / 32) in 1..8, the whole column as ONE D-word integer ----------------
+// BPM_ADVANCE_BLOCK chains 64-row blocks through its horizontal carries (edit_bpm.c:47-66); the vertical deltas it leaves are
+// those of the DP matrix, so a column advanced as one multi-word integer (Myers' recurrence with the carry of the addition
+// and the bits of the two shifts running through the words) holds the same Pv / Mv and the same distance.  Per 32-bit word:
+// or, and, add-with-carry, three v_bitop3_b32 (gfx950's three-input boolean: (sum ^ P) | Eq, M | ~(Xh | P), Mh | ~(Xv | Ph)),
+// two v_alignbit_b32, two and = 10 instructions, against ~16 per word of the block form as the compiler writes it (64-bit
+// shifts, compares and selects for the block carries), and a 151-base pattern is five words, not three blocks = six.
+// The distance moves with bit plen - 1 of Ph / Mh, which lies in one of the last two words (W = ceil(plen / 64), D >= 2W - 1).
+template <int D>
+__global__ __launch_bounds__(kBlock) void bpm_score32(BpmIO io, const uint32_t *__restrict__ perm, uint32_t kbeg,
+                                                      uint32_t kend, int32_t *__restrict__ score_out,
+                                                      uint32_t *__restrict__ worklist, uint32_t *wl_counter, BpmCounters *ct) {
+    constexpr int W = (D + 1) / 2;
+    __shared__ uint64_t peq_s[(4 * W + 1) * kBlock];
+    const uint32_t k = kbeg + blockIdx.x * kBlock + threadIdx.x;
+    unsigned long long steps = 0;
+    int64_t queue_id = -1;
+    if (k < kend) {
+        const uint32_t id = perm ? perm[k] : k;
+        const int n = io.pat_len[id], m = io.txt_len[id];
+        const char *p = io.pat + io.pat_off[id], *t = io.txt + io.txt_off[id];
+        uint64_t *peq = peq_s + threadIdx.x;
+        bool clean = bpm_build_peq<W>(peq, p, n);
+        uint32_t P[D], M[D];
+#pragma unroll
+        for (int d = 0; d < D; d++) { P[d] = ~0u; M[d] = 0; }
+        const int tb = n - 1;
+        const uint32_t top_in_last = (tb >> 5) == D - 1 ? ~0u : 0u;     // else word D - 2
+        const uint32_t tbit = (uint32_t)(tb & 31);
+        int score = n;
+        auto step = [&](int c) {
+            const uint64_t *e = peq + (size_t)c * kBlock;
+            uint32_t Eq[D], Xv[D], Ph[D], Mh[D];
+#pragma unroll
+            for (int b = 0; b < W; b++) {
+                const uint64_t q = e[(size_t)b * 4 * kBlock];
+                Eq[2 * b] = (uint32_t)q;
+                if (2 * b + 1 < D) Eq[2 * b + 1] = (uint32_t)(q >> 32);
+            }
+            uint32_t carry = 0;
+#pragma unroll
+            for (int d = 0; d < D; d++) {
+                Xv[d] = Eq[d] | M[d];
+                uint32_t co;
+                const uint32_t sum = __builtin_addc(Eq[d] & P[d], P[d], carry, &co);
+                carry = co;
+                const uint32_t Xh = __builtin_amdgcn_bitop3_b32(sum, P[d], Eq[d], (0xF0 ^ 0xCC) | 0xAA);       // (sum ^ P) | Eq
+                Ph[d] = __builtin_amdgcn_bitop3_b32(M[d], Xh, P[d], 0xF0 | (0xFF & ~(0xCC | 0xAA)));          // M | ~(Xh | P)
+                Mh[d] = P[d] & Xh;
+            }
+            {   // the distance follows the horizontal delta of row plen - 1
+                const uint32_t ph = D > 1 ? __builtin_amdgcn_bitop3_b32(top_in_last, Ph[D - 1], Ph[D > 1 ? D - 2 : 0], (0xF0 & 0xCC) | (0x0F & 0xAA)) : Ph[0];
+                const uint32_t mh = D > 1 ? __builtin_amdgcn_bitop3_b32(top_in_last, Mh[D - 1], Mh[D > 1 ? D - 2 : 0], (0xF0 & 0xCC) | (0x0F & 0xAA)) : Mh[0];
+                score += (int)((ph >> tbit) & 1u) - (int)((mh >> tbit) & 1u);
+            }
+#pragma unroll
+            for (int d = D - 1; d >= 0; d--) {
+                const uint32_t phs = d ? __builtin_amdgcn_alignbit(Ph[d], Ph[d - 1], 31) : (Ph[0] << 1) | 1u;
+                const uint32_t mhs = d ? __builtin_amdgcn_alignbit(Mh[d], Mh[d - 1], 31) : Mh[0] << 1;
+                P[d] = __builtin_amdgcn_bitop3_b32(mhs, Xv[d], phs, 0xF0 | (0xFF & ~(0xCC | 0xAA)));           // Mh | ~(Xv | Ph)
+                M[d] = phs & Xv[d];
+            }
+        };
+        int h0 = 0;
+        for (; h0 + 16 <= m; h0 += 16) {
+            const uint4 q = ld_u128(t + h0);
+            const uint32_t cs[4] = {bpm_codes4(q.x, clean), bpm_codes4(q.y, clean), bpm_codes4(q.z, clean), bpm_codes4(q.w, clean)};
+#pragma unroll
+            for (int kk = 0; kk < 16; kk++) step((int)((cs[kk >> 2] >> ((kk & 3) * 8)) & 3u));
+        }
+        for (; h0 < m; h0 += 4) {
+            uint32_t w = ld_u32(t + h0);
+            for (int kk = 0; kk < 4 && h0 + kk < m; kk++, w >>= 8) step(bpm_code(w & 0xffu, clean) & 3);
+        }
+        steps = (unsigned long long)m * W;
+        if (clean) score_out[id] = -score;
+        else queue_id = (int64_t)id;
+    }
+    {
+        // append the unclean pairs of this wave with one atomic
+        const unsigned long long q = __ballot(queue_id >= 0);
+        if (q) {
+            const int leader = __builtin_ctzll(q);
+            uint32_t base = 0;
+            if ((int)(threadIdx.x & 63) == leader) base = atomicAdd(wl_counter, (uint32_t)__popcll(q));
+            base = __shfl(base, leader);
+            if (queue_id >= 0) worklist[base + (uint32_t)__popcll(q & ((1ull << (threadIdx.x & 63)) - 1))] = (uint32_t)queue_id;
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) steps += __shfl_xor(steps, o);
+    __shared__ unsigned long long s_steps[kBlock / 64];
+    if ((threadIdx.x & 63) == 0) s_steps[threadIdx.x >> 6] = steps;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long all = 0;
+        for (int k2 = 0; k2 < kBlock / 64; k2++) all += s_steps[k2];
         if (all) atomicAdd(&ct->steps, all);
     }
 }
@@ -643,17 +745,23 @@ extern "C" void gab_bpm_destroy(gab_bpm *h) {
 
 template <int W>
 static void launch_score(hipStream_t s, const BpmIO &io, const uint32_t *perm, uint32_t kb, uint32_t ke, int32_t *score,
-                         uint32_t *wl, uint32_t *wl_counter, BpmCounters *ct) {
+                         uint32_t *wl, uint32_t *wl_counter, BpmCounters *ct, int max_plen) {
     if (ke <= kb) return;
-    hipLaunchKernelGGL(bpm_score<W>, dim3((ke - kb + kBlock - 1) / kBlock), dim3(kBlock), 0, s, io, perm, kb, ke, score, wl,
-                       wl_counter, ct);
+    static const bool blocks64 = getenv("GAB_BPM_SCORE64") != nullptr;       // the 64-row block form (kept under test)
+    const dim3 grid((ke - kb + kBlock - 1) / kBlock);
+    if (blocks64)
+        hipLaunchKernelGGL(bpm_score<W>, grid, dim3(kBlock), 0, s, io, perm, kb, ke, score, wl, wl_counter, ct);
+    else if (max_plen <= 32 * (2 * W - 1))                                    // the class's longest pattern fits 2W - 1 words
+        hipLaunchKernelGGL(bpm_score32<2 * W - 1>, grid, dim3(kBlock), 0, s, io, perm, kb, ke, score, wl, wl_counter, ct);
+    else
+        hipLaunchKernelGGL(bpm_score32<2 * W>, grid, dim3(kBlock), 0, s, io, perm, kb, ke, score, wl, wl_counter, ct);
 }
 // the score kernel of one slice on `s`, its band kernel on `sb` behind the event
 template <int W>
 static int launch_slice(hipStream_t s, hipStream_t sb, hipEvent_t scored, const BpmIO &io, const uint32_t *perm, uint32_t kb,
-                        uint32_t ke, int32_t *score, uint32_t *wl, uint32_t *wl_counter, int cols, uint32_t *wl1, BpmCounters *ct) {
+                        uint32_t ke, int32_t *score, uint32_t *wl, uint32_t *wl_counter, int cols, uint32_t *wl1, BpmCounters *ct, int max_plen) {
     if (ke <= kb) return GAB_OK;
-    launch_score<W>(s, io, perm, kb, ke, score, wl, wl_counter, ct);
+    launch_score<W>(s, io, perm, kb, ke, score, wl, wl_counter, ct, max_plen);
     GAB_HIP(hipEventRecord(scored, s));
     GAB_HIP(hipStreamWaitEvent(sb, scored, 0));
     const size_t lds = sizeof(uint64_t) * 64 * (4 * W + 1) + sizeof(uint16_t) * 64 * (size_t)cols;
@@ -736,10 +844,10 @@ extern "C" int gab_bpm_run_device(gab_bpm *h, const char *pat, int64_t pat_bytes
             const uint32_t ke = cstart[W] + std::min<uint32_t>(ccount[W], (uint32_t)(k + 1) * per);
             uint32_t *wl = d_wl + kb, *cnt = &d_ct->wl_slice[W][k], *wl1 = d_wl1 + cstart[W];
             switch (W) {
-                case 1: rc = launch_slice<1>(s, h->aux, h->scored[k], io, perm_arg, kb, ke, score_out, wl, cnt, cols, wl1, d_ct); break;
-                case 2: rc = launch_slice<2>(s, h->aux, h->scored[k], io, perm_arg, kb, ke, score_out, wl, cnt, cols, wl1, d_ct); break;
-                case 3: rc = launch_slice<3>(s, h->aux, h->scored[k], io, perm_arg, kb, ke, score_out, wl, cnt, cols, wl1, d_ct); break;
-                default: rc = launch_slice<4>(s, h->aux, h->scored[k], io, perm_arg, kb, ke, score_out, wl, cnt, cols, wl1, d_ct); break;
+                case 1: rc = launch_slice<1>(s, h->aux, h->scored[k], io, perm_arg, kb, ke, score_out, wl, cnt, cols, wl1, d_ct, h->h_ct->max_plen[1]); break;
+                case 2: rc = launch_slice<2>(s, h->aux, h->scored[k], io, perm_arg, kb, ke, score_out, wl, cnt, cols, wl1, d_ct, h->h_ct->max_plen[2]); break;
+                case 3: rc = launch_slice<3>(s, h->aux, h->scored[k], io, perm_arg, kb, ke, score_out, wl, cnt, cols, wl1, d_ct, h->h_ct->max_plen[3]); break;
+                default: rc = launch_slice<4>(s, h->aux, h->scored[k], io, perm_arg, kb, ke, score_out, wl, cnt, cols, wl1, d_ct, h->h_ct->max_plen[4]); break;
             }
             if (rc) return rc;
         }
