@@ -300,6 +300,38 @@ __global__ __launch_bounds__(kBlock) void bpm_score(BpmIO io, const uint32_t *__
 // two v_alignbit_b32, two and = 10 instructions, against ~16 per word of the block form as the compiler writes it (64-bit
 // shifts, compares and selects for the block carries), and a 151-base pattern is five words, not three blocks = six.
 // The distance moves with bit plen - 1 of Ph / Mh, which lies in one of the last two words (W = ceil(plen / 64), D >= 2W - 1).
+// One column of the D-word form (see bpm_score32): Eq words of the text base's code -> new P / M; Ph / Mh (before the shift)
+// are handed back for the distance.  `e` points at the lane's block-0 mask of the code; blocks are 4 masks apart.
+template <int D, int STRIDE>
+__device__ __forceinline__ void bpm_step32(const uint64_t *e, uint32_t (&P)[D], uint32_t (&M)[D], uint32_t (&Ph)[D], uint32_t (&Mh)[D]) {
+    constexpr int W = (D + 1) / 2;
+    uint32_t Eq[D], Xv[D];
+#pragma unroll
+    for (int b = 0; b < W; b++) {
+        const uint64_t q = e[(size_t)b * 4 * STRIDE];
+        Eq[2 * b] = (uint32_t)q;
+        if (2 * b + 1 < D) Eq[2 * b + 1] = (uint32_t)(q >> 32);
+    }
+    uint32_t carry = 0;
+#pragma unroll
+    for (int d = 0; d < D; d++) {
+        Xv[d] = Eq[d] | M[d];
+        uint32_t co;
+        const uint32_t sum = __builtin_addc(Eq[d] & P[d], P[d], carry, &co);
+        carry = co;
+        const uint32_t Xh = __builtin_amdgcn_bitop3_b32(sum, P[d], Eq[d], (0xF0 ^ 0xCC) | 0xAA);       // (sum ^ P) | Eq
+        Ph[d] = __builtin_amdgcn_bitop3_b32(M[d], Xh, P[d], 0xF0 | (0xFF & ~(0xCC | 0xAA)));          // M | ~(Xh | P)
+        Mh[d] = P[d] & Xh;
+    }
+#pragma unroll
+    for (int d = D - 1; d >= 0; d--) {
+        const uint32_t phs = d ? __builtin_amdgcn_alignbit(Ph[d], Ph[d - 1], 31) : (Ph[0] << 1) | 1u;
+        const uint32_t mhs = d ? __builtin_amdgcn_alignbit(Mh[d], Mh[d - 1], 31) : Mh[0] << 1;
+        P[d] = __builtin_amdgcn_bitop3_b32(mhs, Xv[d], phs, 0xF0 | (0xFF & ~(0xCC | 0xAA)));           // Mh | ~(Xv | Ph)
+        M[d] = phs & Xv[d];
+    }
+}
+
 template <int D>
 __global__ __launch_bounds__(kBlock) void bpm_score32(BpmIO io, const uint32_t *__restrict__ perm, uint32_t kbeg,
                                                       uint32_t kend, int32_t *__restrict__ score_out,
@@ -323,37 +355,12 @@ __global__ __launch_bounds__(kBlock) void bpm_score32(BpmIO io, const uint32_t *
         const uint32_t tbit = (uint32_t)(tb & 31);
         int score = n;
         auto step = [&](int c) {
-            const uint64_t *e = peq + (size_t)c * kBlock;
-            uint32_t Eq[D], Xv[D], Ph[D], Mh[D];
-#pragma unroll
-            for (int b = 0; b < W; b++) {
-                const uint64_t q = e[(size_t)b * 4 * kBlock];
-                Eq[2 * b] = (uint32_t)q;
-                if (2 * b + 1 < D) Eq[2 * b + 1] = (uint32_t)(q >> 32);
-            }
-            uint32_t carry = 0;
-#pragma unroll
-            for (int d = 0; d < D; d++) {
-                Xv[d] = Eq[d] | M[d];
-                uint32_t co;
-                const uint32_t sum = __builtin_addc(Eq[d] & P[d], P[d], carry, &co);
-                carry = co;
-                const uint32_t Xh = __builtin_amdgcn_bitop3_b32(sum, P[d], Eq[d], (0xF0 ^ 0xCC) | 0xAA);       // (sum ^ P) | Eq
-                Ph[d] = __builtin_amdgcn_bitop3_b32(M[d], Xh, P[d], 0xF0 | (0xFF & ~(0xCC | 0xAA)));          // M | ~(Xh | P)
-                Mh[d] = P[d] & Xh;
-            }
-            {   // the distance follows the horizontal delta of row plen - 1
-                const uint32_t ph = D > 1 ? __builtin_amdgcn_bitop3_b32(top_in_last, Ph[D - 1], Ph[D > 1 ? D - 2 : 0], (0xF0 & 0xCC) | (0x0F & 0xAA)) : Ph[0];
-                const uint32_t mh = D > 1 ? __builtin_amdgcn_bitop3_b32(top_in_last, Mh[D - 1], Mh[D > 1 ? D - 2 : 0], (0xF0 & 0xCC) | (0x0F & 0xAA)) : Mh[0];
-                score += (int)((ph >> tbit) & 1u) - (int)((mh >> tbit) & 1u);
-            }
-#pragma unroll
-            for (int d = D - 1; d >= 0; d--) {
-                const uint32_t phs = d ? __builtin_amdgcn_alignbit(Ph[d], Ph[d - 1], 31) : (Ph[0] << 1) | 1u;
-                const uint32_t mhs = d ? __builtin_amdgcn_alignbit(Mh[d], Mh[d - 1], 31) : Mh[0] << 1;
-                P[d] = __builtin_amdgcn_bitop3_b32(mhs, Xv[d], phs, 0xF0 | (0xFF & ~(0xCC | 0xAA)));           // Mh | ~(Xv | Ph)
-                M[d] = phs & Xv[d];
-            }
+            uint32_t Ph[D], Mh[D];
+            bpm_step32<D, kBlock>(peq + (size_t)c * kBlock, P, M, Ph, Mh);
+            // the distance follows the horizontal delta of row plen - 1
+            const uint32_t ph = D > 1 ? __builtin_amdgcn_bitop3_b32(top_in_last, Ph[D - 1], Ph[D > 1 ? D - 2 : 0], (0xF0 & 0xCC) | (0x0F & 0xAA)) : Ph[0];
+            const uint32_t mh = D > 1 ? __builtin_amdgcn_bitop3_b32(top_in_last, Mh[D - 1], Mh[D > 1 ? D - 2 : 0], (0xF0 & 0xCC) | (0x0F & 0xAA)) : Mh[0];
+            score += (int)((ph >> tbit) & 1u) - (int)((mh >> tbit) & 1u);
         };
         int h0 = 0;
         for (; h0 + 16 <= m; h0 += 16) {
@@ -399,13 +406,15 @@ __global__ __launch_bounds__(kBlock) void bpm_score32(BpmIO io, const uint32_t *
 // the backtrace cost LDS latency instead of HBM latency (the global-history kernels below spend ~20 ms of pure
 // latency on 1.4 M pairs).  A backtrace that drifts more than 3 rows off the diagonal is queued for bpm_win.
 // dynamic LDS: [ (4W+1) x 64 masks (u64) ][ (cols) x 64 u16 ]
-template <int W>
+template <int D>
 // The grid covers the whole slice (launched right behind the slice's score kernel, without a host round trip); the number
 // of queued pairs is read on the device and the workgroups behind it leave at once (a capped grid striding over the slots
-// was measured 3 % slower).
+// was measured 3 % slower).  The columns advance in the D-word form of bpm_score32 (D = 2W - 1 or 2W words for the class
+// W = ceil(plen / 64); the masks keep the 64-row layout, code-4 aliasing of edit_bpm.c included).
 __global__ __launch_bounds__(64) void bpm_band(BpmIO io, const uint32_t *__restrict__ list, const uint32_t *__restrict__ nslots_ptr, int cols,
                                                int32_t *__restrict__ score_out, uint32_t *__restrict__ miss_list,
                                                BpmCounters *ct) {
+    constexpr int W = (D + 1) / 2;
     extern __shared__ uint64_t band_smem[];
     const int lane = threadIdx.x;
     const uint32_t nslots = *nslots_ptr;
@@ -422,10 +431,9 @@ __global__ __launch_bounds__(64) void bpm_band(BpmIO io, const uint32_t *__restr
         bpm_build_peq<W, 64>(peq, p, n);
         const int cshift = (n - m) / 2;
         auto start = [&](int col) { int r = col + cshift - kBandRows / 2; r = r < 0 ? 0 : r; return r > 64 * W - kBandRows ? 64 * W - kBandRows : r; };
-        const uint64_t top_mask = (n & 63) ? 1ull << ((n & 63) - 1) : 1ull << 63;
-        uint64_t P[W], M[W];
+        uint32_t P[D], M[D];
 #pragma unroll
-        for (int b = 0; b < W; b++) { P[b] = ~0ull; M[b] = 0; }
+        for (int d = 0; d < D; d++) { P[d] = ~0u; M[d] = 0; }
         B[0] = (uint16_t)((1u << kBandRows) - 1u);                // column 0: Pv = 1..1, Mv = 0
         bool dummy = true;
         for (int h0 = 0; h0 < m; h0 += 4) {
@@ -433,29 +441,30 @@ __global__ __launch_bounds__(64) void bpm_band(BpmIO io, const uint32_t *__restr
             for (int kk = 0; kk < 4 && h0 + kk < m; kk++, w4 >>= 8) {
                 const int h = h0 + kk;
                 const int c = bpm_code(w4 & 0xffu, dummy);
-                uint32_t PH = 1, MH = 0;
-#pragma unroll
-                for (int b = 0; b < W; b++)
-                    bpm_step(peq[(b * 4 + c) * 64], b == W - 1 ? top_mask : 1ull << 63, P[b], M[b], PH, MH);
+                uint32_t Ph[D], Mh[D];
+                bpm_step32<D, 64>(peq + (size_t)c * 64, P, M, Ph, Mh);
+                // the 8 rows of the band from row r0 on: rows of the pattern end below 32 D (r0 <= plen - 4), a word past the
+                // last one reads as 0 (rows the walk never stands on)
                 const int r0 = start(h + 1);
-                const int b0 = r0 >> 6, sh = r0 & 63;
-                uint64_t plo = P[0], phi = W > 1 ? P[W > 1 ? 1 : 0] : 0, mlo = M[0], mhi = W > 1 ? M[W > 1 ? 1 : 0] : 0;
-                // which 64-row word the band starts in is the same for the whole wave except in the few columns where the
-                // lanes cross a word boundary (their diagonals differ by a row or two): then the words are named by a scalar
-                // switch instead of being selected per lane (eight 64-bit selects per column)
+                const int b0 = r0 >> 5;
+                const uint32_t sh = (uint32_t)(r0 & 31);
+                uint32_t plo = P[0], phi = D > 1 ? P[D > 1 ? 1 : 0] : 0, mlo = M[0], mhi = D > 1 ? M[D > 1 ? 1 : 0] : 0;
+                // which word the band starts in is the same for the whole wave except in the few columns where the lanes
+                // cross a word boundary (their diagonals differ by a row or two): then the words are named by a scalar switch
+                // instead of being selected per lane
                 const int b0u = __builtin_amdgcn_readfirstlane(b0);
-                if (W > 1 && __ballot(b0 != b0u) == 0) {
+                if (D > 1 && __ballot(b0 != b0u) == 0) {
 #pragma unroll
-                    for (int b = 1; b < W; b++)
-                        if (b0u == b) { plo = P[b]; mlo = M[b]; phi = b + 1 < W ? P[b + 1 < W ? b + 1 : b] : 0; mhi = b + 1 < W ? M[b + 1 < W ? b + 1 : b] : 0; }
+                    for (int b = 1; b < D; b++)
+                        if (b0u == b) { plo = P[b]; mlo = M[b]; phi = b + 1 < D ? P[b + 1 < D ? b + 1 : b] : 0; mhi = b + 1 < D ? M[b + 1 < D ? b + 1 : b] : 0; }
                 } else {
 #pragma unroll
-                    for (int b = 1; b < W; b++)
-                        if (b0 == b) { plo = P[b]; mlo = M[b]; phi = b + 1 < W ? P[b + 1 < W ? b + 1 : b] : 0; mhi = b + 1 < W ? M[b + 1 < W ? b + 1 : b] : 0; }
+                    for (int b = 1; b < D; b++)
+                        if (b0 == b) { plo = P[b]; mlo = M[b]; phi = b + 1 < D ? P[b + 1 < D ? b + 1 : b] : 0; mhi = b + 1 < D ? M[b + 1 < D ? b + 1 : b] : 0; }
                 }
                 const uint32_t bm = (1u << kBandRows) - 1u;
-                const uint32_t pw = (uint32_t)((sh ? (plo >> sh) | (phi << (64 - sh)) : plo)) & bm;
-                const uint32_t mw = (uint32_t)((sh ? (mlo >> sh) | (mhi << (64 - sh)) : mlo)) & bm;
+                const uint32_t pw = __builtin_amdgcn_alignbit(phi, plo, sh) & bm;     // ({hi, lo} >> sh): sh = 0 gives lo
+                const uint32_t mw = __builtin_amdgcn_alignbit(mhi, mlo, sh) & bm;
                 B[(h + 1) * 64] = (uint16_t)(pw | mw << kBandRows);
             }
         }
@@ -717,10 +726,11 @@ extern "C" int gab_bpm_create(int device, gab_bpm **out) {
         if (hipEventCreateWithFlags(&h->scored[k], hipEventDisableTiming) != hipSuccess) {
             gab_set_error("gab_bpm_create: event creation failed"); delete h; return GAB_EDEVICE;
         }
-    if (hipFuncSetAttribute((const void *)bpm_band<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
-        hipFuncSetAttribute((const void *)bpm_band<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
-        hipFuncSetAttribute((const void *)bpm_band<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
-        hipFuncSetAttribute((const void *)bpm_band<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+    bool attr_ok = true;
+    for (const void *f : {(const void *)bpm_band<1>, (const void *)bpm_band<2>, (const void *)bpm_band<3>, (const void *)bpm_band<4>,
+                          (const void *)bpm_band<5>, (const void *)bpm_band<6>, (const void *)bpm_band<7>, (const void *)bpm_band<8>})
+        attr_ok = attr_ok && hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+    if (!attr_ok) {
         gab_set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed"); delete h; return GAB_EDEVICE;
     }
     if (hipHostMalloc((void **)&h->h_ct, sizeof(BpmCounters)) != hipSuccess) {
@@ -765,7 +775,10 @@ static int launch_slice(hipStream_t s, hipStream_t sb, hipEvent_t scored, const 
     GAB_HIP(hipEventRecord(scored, s));
     GAB_HIP(hipStreamWaitEvent(sb, scored, 0));
     const size_t lds = sizeof(uint64_t) * 64 * (4 * W + 1) + sizeof(uint16_t) * 64 * (size_t)cols;
-    hipLaunchKernelGGL(bpm_band<W>, dim3((ke - kb + 63) / 64), dim3(64), lds, sb, io, wl, wl_counter, cols, score, wl1, ct);
+    if (max_plen <= 32 * (2 * W - 1))
+        hipLaunchKernelGGL(bpm_band<2 * W - 1>, dim3((ke - kb + 63) / 64), dim3(64), lds, sb, io, wl, wl_counter, cols, score, wl1, ct);
+    else
+        hipLaunchKernelGGL(bpm_band<2 * W>, dim3((ke - kb + 63) / 64), dim3(64), lds, sb, io, wl, wl_counter, cols, score, wl1, ct);
     return GAB_OK;
 }
 template <int W>
