@@ -757,7 +757,7 @@ template <int W>
 static void launch_score(hipStream_t s, const BpmIO &io, const uint32_t *perm, uint32_t kb, uint32_t ke, int32_t *score,
                          uint32_t *wl, uint32_t *wl_counter, BpmCounters *ct, int max_plen) {
     if (ke <= kb) return;
-    static const bool blocks64 = getenv("GAB_BPM_SCORE64") != nullptr;       // the 64-row block form (kept under test)
+    const bool blocks64 = getenv("GAB_BPM_SCORE64") != nullptr;              // the 64-row block form (kept under test)
     const dim3 grid((ke - kb + kBlock - 1) / kBlock);
     if (blocks64)
         hipLaunchKernelGGL(bpm_score<W>, grid, dim3(kBlock), 0, s, io, perm, kb, ke, score, wl, wl_counter, ct);

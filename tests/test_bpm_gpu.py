@@ -35,6 +35,23 @@ def test_vs_oracle(eng, seed, n, mode, plen):
     assert st["block_steps"] >= steps          # queued pairs are stepped twice (score pass + full pass)
 
 
+def test_block_form_score_kernel(eng, monkeypatch):
+    """GAB_BPM_SCORE64=1: the score pass through bpm_score<W>, the 64-row block form of BPM_ADVANCE_BLOCK (the default is the
+    D-word form, bpm_score32<D>); mode 1 of the generator mixes pattern lengths, i.e. odd and even word counts, in one batch"""
+    monkeypatch.setenv("GAB_BPM_SCORE64", "1")
+    for seed, n, mode, plen in ((57, 100000, 0, 151), (58, 40000, 1, 256)):
+        batch = gabgen.pairs(seed, n, mode, plen).swapped_longer_first()
+        np.testing.assert_array_equal(eng.benchmark_edit_bpm(batch), pyoracle.bpm(batch))
+
+
+@pytest.mark.parametrize("plen", [32, 33, 64, 65, 96, 97, 128, 129, 160, 161, 192, 193, 224, 225, 256])
+def test_word_count_boundaries(eng, plen):
+    """pattern lengths on both sides of every 32-row word boundary: the D-word kernels pick D = 2W - 1 or 2W by the longest
+    pattern of the class, and the distance bit moves between the last two words"""
+    batch = gabgen.pairs(600 + plen, 4000, 0, plen).swapped_longer_first()
+    np.testing.assert_array_equal(eng.benchmark_edit_bpm(batch), pyoracle.bpm(batch))
+
+
 def test_sliced_classes(eng):
     """classes of >= 2^18 pairs are scored in slices whose band kernels run on a second stream (device-side queue
     lengths): two populated classes, unclean pairs in every slice"""
