@@ -26,6 +26,7 @@
 // path is integer-VALU bound at about 16 k VALU per pair; its HBM traffic is the algorithmic
 // plen + tlen + 4 B per pair.  The full path adds 16 B x W x (tlen+1) of scratch per queued pair.
 #include "gab_internal.h"
+#include "gab_bitvec.h"
 #include <algorithm>
 #include <new>
 #include <vector>
@@ -299,37 +300,20 @@ __global__ __launch_bounds__(kBlock) void bpm_score(BpmIO io, const uint32_t *__
 // or, and, add-with-carry, three v_bitop3_b32 (gfx950's three-input boolean: (sum ^ P) | Eq, M | ~(Xh | P), Mh | ~(Xv | Ph)),
 // two v_alignbit_b32, two and = 10 instructions, against ~16 per word of the block form as the compiler writes it (64-bit
 // shifts, compares and selects for the block carries), and a 151-base pattern is five words, not three blocks = six.
-// The distance moves with bit plen - 1 of Ph / Mh, which lies in one of the last two words (W = ceil(plen / 64), D >= 2W - 1).
-// One column of the D-word form (see bpm_score32): Eq words of the text base's code -> new P / M; Ph / Mh (before the shift)
-// are handed back for the distance.  `e` points at the lane's block-0 mask of the code; blocks are 4 masks apart.
+// The distance is read off the last column: m + popcount(P & rows) - popcount(M & rows) (gab_bitvec.h); nothing per column.
+// One column of the D-word form (gab_bitvec.h): the Eq words of the text base's code from the lane's 64-row masks (`e`: block 0
+// of the code; blocks are 4 masks apart) -> new P / M.
 template <int D, int STRIDE>
-__device__ __forceinline__ void bpm_step32(const uint64_t *e, uint32_t (&P)[D], uint32_t (&M)[D], uint32_t (&Ph)[D], uint32_t (&Mh)[D]) {
+__device__ __forceinline__ void bpm_step32(const uint64_t *e, uint32_t (&P)[D], uint32_t (&M)[D]) {
     constexpr int W = (D + 1) / 2;
-    uint32_t Eq[D], Xv[D];
+    uint32_t Eq[D];
 #pragma unroll
     for (int b = 0; b < W; b++) {
         const uint64_t q = e[(size_t)b * 4 * STRIDE];
         Eq[2 * b] = (uint32_t)q;
         if (2 * b + 1 < D) Eq[2 * b + 1] = (uint32_t)(q >> 32);
     }
-    uint32_t carry = 0;
-#pragma unroll
-    for (int d = 0; d < D; d++) {
-        Xv[d] = Eq[d] | M[d];
-        uint32_t co;
-        const uint32_t sum = __builtin_addc(Eq[d] & P[d], P[d], carry, &co);
-        carry = co;
-        const uint32_t Xh = __builtin_amdgcn_bitop3_b32(sum, P[d], Eq[d], (0xF0 ^ 0xCC) | 0xAA);       // (sum ^ P) | Eq
-        Ph[d] = __builtin_amdgcn_bitop3_b32(M[d], Xh, P[d], 0xF0 | (0xFF & ~(0xCC | 0xAA)));          // M | ~(Xh | P)
-        Mh[d] = P[d] & Xh;
-    }
-#pragma unroll
-    for (int d = D - 1; d >= 0; d--) {
-        const uint32_t phs = d ? __builtin_amdgcn_alignbit(Ph[d], Ph[d - 1], 31) : (Ph[0] << 1) | 1u;
-        const uint32_t mhs = d ? __builtin_amdgcn_alignbit(Mh[d], Mh[d - 1], 31) : Mh[0] << 1;
-        P[d] = __builtin_amdgcn_bitop3_b32(mhs, Xv[d], phs, 0xF0 | (0xFF & ~(0xCC | 0xAA)));           // Mh | ~(Xv | Ph)
-        M[d] = phs & Xv[d];
-    }
+    gab_myers_step32<D>(Eq, P, M);
 }
 
 template <int D>
@@ -350,18 +334,7 @@ __global__ __launch_bounds__(kBlock) void bpm_score32(BpmIO io, const uint32_t *
         uint32_t P[D], M[D];
 #pragma unroll
         for (int d = 0; d < D; d++) { P[d] = ~0u; M[d] = 0; }
-        const int tb = n - 1;
-        const uint32_t top_in_last = (tb >> 5) == D - 1 ? ~0u : 0u;     // else word D - 2
-        const uint32_t tbit = (uint32_t)(tb & 31);
-        int score = n;
-        auto step = [&](int c) {
-            uint32_t Ph[D], Mh[D];
-            bpm_step32<D, kBlock>(peq + (size_t)c * kBlock, P, M, Ph, Mh);
-            // the distance follows the horizontal delta of row plen - 1
-            const uint32_t ph = D > 1 ? __builtin_amdgcn_bitop3_b32(top_in_last, Ph[D - 1], Ph[D > 1 ? D - 2 : 0], (0xF0 & 0xCC) | (0x0F & 0xAA)) : Ph[0];
-            const uint32_t mh = D > 1 ? __builtin_amdgcn_bitop3_b32(top_in_last, Mh[D - 1], Mh[D > 1 ? D - 2 : 0], (0xF0 & 0xCC) | (0x0F & 0xAA)) : Mh[0];
-            score += (int)((ph >> tbit) & 1u) - (int)((mh >> tbit) & 1u);
-        };
+        auto step = [&](int c) { bpm_step32<D, kBlock>(peq + (size_t)c * kBlock, P, M); };
         int h0 = 0;
         for (; h0 + 16 <= m; h0 += 16) {
             const uint4 q = ld_u128(t + h0);
@@ -374,7 +347,8 @@ __global__ __launch_bounds__(kBlock) void bpm_score32(BpmIO io, const uint32_t *
             for (int kk = 0; kk < 4 && h0 + kk < m; kk++, w >>= 8) step(bpm_code(w & 0xffu, clean) & 3);
         }
         steps = (unsigned long long)m * W;
-        if (clean) score_out[id] = -score;
+        // the distance from the vertical deltas of the last column: nothing is tracked per column
+        if (clean) score_out[id] = -gab_myers_distance32<D>(P, M, n, m);
         else queue_id = (int64_t)id;
     }
     {
@@ -441,8 +415,7 @@ __global__ __launch_bounds__(64) void bpm_band(BpmIO io, const uint32_t *__restr
             for (int kk = 0; kk < 4 && h0 + kk < m; kk++, w4 >>= 8) {
                 const int h = h0 + kk;
                 const int c = bpm_code(w4 & 0xffu, dummy);
-                uint32_t Ph[D], Mh[D];
-                bpm_step32<D, 64>(peq + (size_t)c * 64, P, M, Ph, Mh);
+                bpm_step32<D, 64>(peq + (size_t)c * 64, P, M);
                 // the 8 rows of the band from row r0 on: rows of the pattern end below 32 D (r0 <= plen - 4), a word past the
                 // last one reads as 0 (rows the walk never stands on)
                 const int r0 = start(h + 1);
