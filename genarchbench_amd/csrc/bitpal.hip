@@ -22,6 +22,7 @@
 // Roofline: plen + tlen + 4 algorithmic bytes per pair (the row string is really streamed once per 32-column chunk:
 // 3.1 x, profiles/r01_hbm_traffic.md) against 3.5 VALU per DP cell: integer-VALU bound, ~93 % of the issue rate.
 #include "gab_internal.h"
+#include "gab_bitvec.h"
 #include <algorithm>
 #include <new>
 #include <string.h>
@@ -231,6 +232,96 @@ __global__ __launch_bounds__(64) void bitpal_dp(BpIO io, const uint32_t *__restr
     if (lane == 0 && cells) atomicAdd(&ct->cells, cells);
 }
 
+// ---- -a bitpal-edit, bit-vector path: the score is minus the edit distance --------------------------------------------
+// benchmark_bitpal_m0_x1_g1 scores (match, mismatch, gap) = (0, -1, -1): the Needleman-Wunsch score is minus the Levenshtein
+// distance of the two strings as raw bytes.  For that one algorithm the column of the DP is Myers' bit-vector (gab_bitvec.h:
+// the column as ONE integer of D 32-bit words, ~60 VALU instructions per column of a 151-row pair) instead of 151 cells of
+// integer DP at 3.5 instructions each.  One pair per lane; the SHORTER string makes the rows (the distance is symmetric).
+// Raw-byte equality needs a match mask per byte value that occurs in the row string: slots for 'A' 'C' 'G' 'T' 'N' (upper case)
+// and a sixth, always empty, that every other byte of the COLUMN string selects (it equals no row byte); a row string with
+// any other byte, or longer than 32 D <= 256 rows, sends the pair to the integer DP through the id lists (bitpal_scatter's
+// job, done here for the rejects).  LDS: the lane's masks as [(slot * D + word)][lane] dwords, and a byte -> slot offset table.
+constexpr int kBvBlock = 256;
+constexpr int kBvSlots = 6;
+constexpr int kBvMaxRows = 256;
+
+__device__ __forceinline__ int bitpal_bv_slot(uint32_t ch) {
+    return ch == 'A' ? 0 : ch == 'C' ? 1 : ch == 'G' ? 2 : ch == 'T' ? 3 : ch == 'N' ? 4 : 5;
+}
+
+template <int D>
+__global__ __launch_bounds__(kBvBlock) void bitpal_edit_bv(BpIO io, uint32_t *cursors, uint32_t *__restrict__ list_lds,
+                                                           uint32_t *__restrict__ list_big, BpCounters *ct) {
+    __shared__ uint32_t eq_s[kBvSlots * D * kBvBlock];
+    __shared__ uint32_t lut[256];                            // byte -> first word of its slot (in units of kBvBlock dwords)
+    lut[threadIdx.x] = (uint32_t)(bitpal_bv_slot(threadIdx.x) * D * kBvBlock);
+    __syncthreads();
+    const int64_t i = (int64_t)blockIdx.x * kBvBlock + threadIdx.x;
+    bool reject = false, big = false;
+    unsigned long long cells = 0;
+    if (i < io.n) {
+        const int pl = io.pat_len[i], tl = io.txt_len[i];
+        const char *p = io.pat + io.pat_off[i], *t = io.txt + io.txt_off[i];
+        int nr, nc; const char *rs, *cs;
+        if (pl <= tl) { nr = pl; rs = p; nc = tl; cs = t; } else { nr = tl; rs = t; nc = pl; cs = p; }
+        if (nr > 32 * D || nr > kBvMaxRows) { reject = true; big = nr > kLdsRows; }
+        else if (nr == 0) io.score[i] = -nc;
+        else {
+            uint32_t *eq = eq_s + threadIdx.x;
+#pragma unroll
+            for (int k = 0; k < kBvSlots * D; k++) eq[k * kBvBlock] = 0;
+            const uint32_t other = (uint32_t)(5 * D * kBvBlock);
+            for (int j0 = 0; j0 < nr; j0 += 4) {             // (the slabs are readable to a multiple of four bytes)
+                uint32_t w; __builtin_memcpy(&w, rs + j0, 4);
+                for (int k = 0; k < 4 && j0 + k < nr; k++, w >>= 8) {
+                    const int j = j0 + k;
+                    const uint32_t off = lut[w & 0xffu];
+                    reject = reject || off == other;
+                    eq[off + (uint32_t)(j >> 5) * kBvBlock] |= 1u << (j & 31);
+                }
+            }
+            if (!reject) {
+                uint32_t P[D], M[D];
+#pragma unroll
+                for (int d = 0; d < D; d++) { P[d] = ~0u; M[d] = 0; }
+                auto step = [&](uint32_t byte) {
+                    const uint32_t *e = eq + lut[byte];
+                    uint32_t Eq[D];
+#pragma unroll
+                    for (int d = 0; d < D; d++) Eq[d] = e[d * kBvBlock];
+                    gab_myers_step32<D>(Eq, P, M);
+                };
+                int h0 = 0;
+                for (; h0 + 16 <= nc; h0 += 16) {
+                    uint4 q; __builtin_memcpy(&q, cs + h0, 16);
+                    const uint32_t ws[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+                    for (int kk = 0; kk < 16; kk++) step((ws[kk >> 2] >> ((kk & 3) * 8)) & 0xffu);
+                }
+                for (; h0 < nc; h0 += 4) {
+                    uint32_t w; __builtin_memcpy(&w, cs + h0, 4);
+                    for (int kk = 0; kk < 4 && h0 + kk < nc; kk++, w >>= 8) step(w & 0xffu);
+                }
+                io.score[i] = -gab_myers_distance32<D>(P, M, nr, nc);
+                cells = (unsigned long long)nc * (unsigned long long)nr;
+            } else big = false;
+        }
+    }
+    {   // the rejects' ids, in the lists the integer DP reads
+        const uint32_t s_lds = gab_wave_slot(&cursors[0], reject && !big), s_big = gab_wave_slot(&cursors[1], reject && big);
+        if (reject) { if (big) list_big[s_big] = (uint32_t)i; else list_lds[s_lds] = (uint32_t)i; }
+    }
+    for (int o = 32; o > 0; o >>= 1) cells += __shfl_xor(cells, o);
+    __shared__ unsigned long long s_cells[kBvBlock / 64];
+    if ((threadIdx.x & 63) == 0) s_cells[threadIdx.x >> 6] = cells;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long all = 0;
+        for (int k = 0; k < kBvBlock / 64; k++) all += s_cells[k];
+        if (all) atomicAdd(&ct->cells, all);
+    }
+}
+
 }  // namespace
 
 // =============================================================================== host side
@@ -311,11 +402,32 @@ extern "C" int gab_bitpal_run_device(gab_bitpal *h, const char *pat, int64_t pat
                       h->h_ct->first_bad - 1, GAB_BITPAL_MAX_LEN);
         return GAB_EINVAL;
     }
-    const uint32_t n_lds = h->h_ct->n_lds, n_big = h->h_ct->n_big;
-    if (n_big) hipLaunchKernelGGL(bitpal_scatter, dim3(grid), dim3(256), 0, s, io, d_ct->cursors, l_lds, l_big);
-    else l_lds = nullptr;
+    uint32_t n_lds = h->h_ct->n_lds, n_big = h->h_ct->n_big;
     const bool scored = h->sc.match != 0;
-    GAB_HIP(hipEventRecord(h->ev[1], s));
+    const bool bitvec = !scored && !getenv("GAB_BITPAL_NO_BV");   // -a bitpal-edit: Myers' bit-vector, the integer DP for its rejects
+    if (bitvec) {
+        GAB_HIP(hipEventRecord(h->ev[1], s));
+        const int rows = std::min(std::max(h->h_ct->max_rows_lds, 1), kBvMaxRows);
+        const dim3 bv_grid((unsigned)gab_ceil_div(n, kBvBlock));
+        switch ((rows + 31) / 32) {
+            case 1: hipLaunchKernelGGL(bitpal_edit_bv<1>, bv_grid, dim3(kBvBlock), 0, s, io, d_ct->cursors, l_lds, l_big, d_ct); break;
+            case 2: hipLaunchKernelGGL(bitpal_edit_bv<2>, bv_grid, dim3(kBvBlock), 0, s, io, d_ct->cursors, l_lds, l_big, d_ct); break;
+            case 3: hipLaunchKernelGGL(bitpal_edit_bv<3>, bv_grid, dim3(kBvBlock), 0, s, io, d_ct->cursors, l_lds, l_big, d_ct); break;
+            case 4: hipLaunchKernelGGL(bitpal_edit_bv<4>, bv_grid, dim3(kBvBlock), 0, s, io, d_ct->cursors, l_lds, l_big, d_ct); break;
+            case 5: hipLaunchKernelGGL(bitpal_edit_bv<5>, bv_grid, dim3(kBvBlock), 0, s, io, d_ct->cursors, l_lds, l_big, d_ct); break;
+            case 6: hipLaunchKernelGGL(bitpal_edit_bv<6>, bv_grid, dim3(kBvBlock), 0, s, io, d_ct->cursors, l_lds, l_big, d_ct); break;
+            case 7: hipLaunchKernelGGL(bitpal_edit_bv<7>, bv_grid, dim3(kBvBlock), 0, s, io, d_ct->cursors, l_lds, l_big, d_ct); break;
+            default: hipLaunchKernelGGL(bitpal_edit_bv<8>, bv_grid, dim3(kBvBlock), 0, s, io, d_ct->cursors, l_lds, l_big, d_ct); break;
+        }
+        GAB_HIP(hipGetLastError());
+        GAB_HIP(hipMemcpyAsync(h->h_ct, d_ct, sizeof(BpCounters), hipMemcpyDeviceToHost, s));
+        GAB_HIP(hipStreamSynchronize(s));
+        n_lds = h->h_ct->cursors[0]; n_big = h->h_ct->cursors[1];      // what is left for the integer DP
+    } else {
+        if (n_big) hipLaunchKernelGGL(bitpal_scatter, dim3(grid), dim3(256), 0, s, io, d_ct->cursors, l_lds, l_big);
+        else l_lds = nullptr;
+        GAB_HIP(hipEventRecord(h->ev[1], s));
+    }
     if (n_lds) {
         const size_t lds = (size_t)(h->h_ct->max_rows_lds + 1) * 64;
         auto kern = scored ? bitpal_dp<true, true> : bitpal_dp<true, false>;
