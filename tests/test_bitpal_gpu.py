@@ -56,6 +56,42 @@ def test_edge_lengths_and_bytes(eng):
     np.testing.assert_array_equal(eng.benchmark_bitpal(b), pyoracle.bitpal(b, eng.alg))
 
 
+def test_edit_bit_vector_path_and_its_rejects():
+    """-a bitpal-edit runs Myers' bit-vector (rows = the shorter string, masks for A C G T N) and hands the integer DP what it
+    cannot take: every row count from 1 to 300 (all word boundaries, beyond its 256 rows), bytes outside ACGTN in the row
+    string (reject) and in the column string only (no reject), lower case, accepted and rejected pairs side by side in a wave"""
+    from genarchbench_amd.bitpal import BitpalEngine
+    rng = np.random.default_rng(17)
+    alpha = np.frombuffer(b"ACGTN", np.uint8)
+    pats, txts = [], []
+    for ln in range(1, 301):
+        p = bytearray(rng.choice(alpha, ln).tobytes())
+        t = bytearray(p) + bytearray(rng.choice(alpha, int(rng.integers(0, 40))).tobytes())
+        for _ in range(1 + ln // 10):
+            t[int(rng.integers(0, len(t)))] = b"ACGT"[int(rng.integers(0, 4))]
+        kind = ln % 5
+        if kind == 1: t[int(rng.integers(0, len(t)))] = ord("x")            # column string only: stays on the bit-vector path
+        if kind == 2: p[int(rng.integers(0, len(p)))] = ord("a")            # row string: integer DP
+        if kind == 3: p, t = t, p                                          # the longer one first
+        pats.append(bytes(p)); txts.append(bytes(t))
+    b = gabgen.pairs_from_lists(pats * 8, txts * 8)
+    e = BitpalEngine(0)
+    np.testing.assert_array_equal(e.benchmark_bitpal(b), pyoracle.bitpal(b, 0))
+    assert e.last_stats()["cells"] == int((b.pat_len.astype(np.int64) * b.txt_len).sum())
+    e.close()
+
+
+def test_edit_through_the_integer_dp(monkeypatch):
+    """GAB_BITPAL_NO_BV=1: -a bitpal-edit through bitpal_dp<., false> alone (the kernel the bit-vector path's rejects take)"""
+    from genarchbench_amd.bitpal import BitpalEngine
+    monkeypatch.setenv("GAB_BITPAL_NO_BV", "1")
+    e = BitpalEngine(0)
+    for seed, n, mode, plen in ((48, 50000, 0, 151), (49, 10000, 1, 300)):
+        batch = gabgen.pairs(seed, n, mode, plen)
+        np.testing.assert_array_equal(e.benchmark_bitpal(batch), pyoracle.bitpal(batch, 0))
+    e.close()
+
+
 def test_long_pairs_global_path(eng):
     """row strings beyond the LDS column (2048 rows) -> int32 boundary column in global memory; mixed with short pairs"""
     rng = np.random.default_rng(8)
