@@ -601,6 +601,20 @@ class BitpalEditWorkload(BitpalWorkload):
     algorithm, alg_name = 0, "bitpal-edit"
     metric = "bpm (bitpal-edit) ROI M alignments/sec"
 
+    def extra(self, ms_per_step):
+        # -a bitpal-edit is minus the edit distance: it runs as Myers' bit-vector (bitpal_edit_bv<D>, gab_bitvec.h: ~60 VALU
+        # instructions per COLUMN of a 151-row pair), the integer DP (bitpal_dp, 3.5 per CELL) only takes its rejects
+        k = float(np.mean(self.kernel_ms))
+        return {"dp_cells_per_step": self.stats.get("cells"), "long_pairs": self.stats.get("long_pairs"),
+                "gcups_kernel": round(self.stats.get("cells", 0) / (k * 1e6), 1),
+                "dominant_kernel": "bitpal_edit_bv", "dominant_kernel_ms": k, "device_total_ms": float(np.mean(self.total_ms))}
+
+    def roofline(self):
+        r = super().roofline()
+        r["note"] = ("plen+tlen+4 B per pair vs ~60 VALU per text base and pair (Myers' bit-vector, five 32-bit words for 151 rows): "
+                     "VALU-issue bound")
+        return r
+
 
 # ------------------------------------------------------------------------------------- wfa
 class WfaWorkload:
