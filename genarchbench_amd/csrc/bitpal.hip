@@ -271,14 +271,23 @@ __global__ __launch_bounds__(kBvBlock) void bitpal_edit_bv(BpIO io, uint32_t *cu
 #pragma unroll
             for (int k = 0; k < kBvSlots * D; k++) eq[k * kBvBlock] = 0;
             const uint32_t other = (uint32_t)(5 * D * kBvBlock);
-            for (int j0 = 0; j0 < nr; j0 += 4) {             // (the slabs are readable to a multiple of four bytes)
+            auto row_byte = [&](int j, uint32_t byte) {
+                const uint32_t off = lut[byte];
+                reject = reject || off == other;
+                eq[off + (uint32_t)(j >> 5) * kBvBlock] |= 1u << (j & 31);
+            };
+            // sixteen bytes per load: every lane streams its own string, and with 4-byte loads each 64-byte line came from HBM
+            // up to sixteen times (19 GB fetched per 10 M pairs against 3 GB of strings)
+            int j0 = 0;
+            for (; j0 + 16 <= nr; j0 += 16) {
+                uint4 q; __builtin_memcpy(&q, rs + j0, 16);
+                const uint32_t ws[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+                for (int k = 0; k < 16; k++) row_byte(j0 + k, (ws[k >> 2] >> ((k & 3) * 8)) & 0xffu);
+            }
+            for (; j0 < nr; j0 += 4) {                       // (the slabs are readable to a multiple of four bytes)
                 uint32_t w; __builtin_memcpy(&w, rs + j0, 4);
-                for (int k = 0; k < 4 && j0 + k < nr; k++, w >>= 8) {
-                    const int j = j0 + k;
-                    const uint32_t off = lut[w & 0xffu];
-                    reject = reject || off == other;
-                    eq[off + (uint32_t)(j >> 5) * kBvBlock] |= 1u << (j & 31);
-                }
+                for (int k = 0; k < 4 && j0 + k < nr; k++, w >>= 8) row_byte(j0 + k, w & 0xffu);
             }
             if (!reject) {
                 uint32_t P[D], M[D];
