@@ -1080,6 +1080,8 @@ SUITE = [("chain-large", "chain", None, 5), ("fast-chain-large", "fast-chain", N
          ("wfa-large", "wfa", None, 5),
          ("bsw-small", "bsw", 100_000, 10), ("bpm-small", "bpm", 100_000, 10), ("wfa-small", "wfa", 100_000, 10),
          ("chain-small", "chain", 1000, 10), ("fast-chain-small", "fast-chain", 1000, 10),
+         # the bpm driver's BitPAl modes, same 10 M pairs as bpm-large
+         ("bitpal-edit-large", "bitpal-edit", None, 5), ("bitpal-scored-large", "bitpal", None, 3),
          ("fmi-large", "fmi", None, 3), ("fmi-large-wide-lists", "fmi-wide", None, 3)]
 SUITE_BUDGET_S = float(os.environ.get("GAB_BENCH_BUDGET_S", "400"))    # entries that would start after this are skipped (and say so)
 
