@@ -32,7 +32,7 @@ HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec 
 # counters in separate passes (tools/profiling/hbm_traffic.sh -> profiles/r01_hbm_traffic.json); `double_fetch`: the
 # kernel reads wide coalesced streams, for which gfx950's FETCH_SIZE reports half the bytes (MI355X_MICROARCH.md, HBM)
 TRAFFIC_KERNELS = {"bsw": (["bsw_dp8"], False), "chain": (["chain_block_kernel", "chain_facts_kernel"], False), "fast-chain": (["fastchain_kernel"], False),
-                   "bpm": (["bpm_score<3>"], False), "bitpal": (["bitpal_dp<true, true>"], False), "wfa": (["wfa_lds_static<16, false>"], False), "fmi": (["fmi_seed_kernel<true>"], False),
+                   "bpm": (["bpm_score32<", "bpm_score<"], False), "bitpal": (["bitpal_dp<true, true>"], False), "bitpal-edit": (["bitpal_edit_bv<"], False), "wfa": (["wfa_lds_static<16, false>"], False), "fmi": (["fmi_seed_kernel<true>"], False),
                    "fmi-sa": (["fmi_sa_kernel"], False), "parse-bsw": (["nl_count", "nl_fill", "bsw_meta", "bsw_codes", "len_offsets",
                                                                        "len_block_sums"], True)}
 
