@@ -480,7 +480,7 @@ class BpmWorkload:
     def extra(self, ms_per_step):
         return {"block_steps_per_step": self.stats.get("block_steps"), "full_path_pairs": self.stats.get("full_pairs"),
                 "g_block_steps_per_s": round(self.stats.get("block_steps", 0) / (ms_per_step * 1e6), 2),
-                "dominant_kernel": "bpm_score<3> (+ bpm_band<3> of the previous slice on a second stream)",
+                "dominant_kernel": "bpm_score32<5> (+ bpm_band<5> of the previous slice on a second stream)",
                 "dominant_kernel_ms": float(np.mean(self.kernel_ms)),
                 "device_total_ms": float(np.mean(self.total_ms))}
 
@@ -489,7 +489,7 @@ class BpmWorkload:
         ach = self.alg_bytes / (k * 1e-3) / 1e9
         return {"bound": "hbm", "achieved": round(ach, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(ach / HBM_PEAK_GBS, 6), "traffic": None,
-                "note": "score kernel: plen+tlen+4 B per pair vs ~16k integer VALU per pair (VALU bound)"}
+                "note": "score kernel: plen+tlen+4 B per pair vs ~9.4k integer VALU per pair (61 per text base: the column as five 32-bit words; VALU bound)"}
 
     def cpu_baseline(self, cores):
         from oracle import pyoracle
