@@ -285,8 +285,8 @@ __global__ __launch_bounds__(kBvBlock) void bitpal_edit_bv(BpIO io, uint32_t *cu
 #pragma unroll
                 for (int k = 0; k < 16; k++) row_byte(j0 + k, (ws[k >> 2] >> ((k & 3) * 8)) & 0xffu);
             }
-            for (; j0 < nr; j0 += 4) {                       // (the slabs are readable to a multiple of four bytes)
-                uint32_t w; __builtin_memcpy(&w, rs + j0, 4);
+            for (; j0 < nr; j0 += 4) {                       // the last dwords through seq_ld4: nothing is read behind the string's last dword
+                uint32_t w = seq_ld4(rs, j0, nr, 0u);
                 for (int k = 0; k < 4 && j0 + k < nr; k++, w >>= 8) row_byte(j0 + k, w & 0xffu);
             }
             if (!reject) {
@@ -308,7 +308,7 @@ __global__ __launch_bounds__(kBvBlock) void bitpal_edit_bv(BpIO io, uint32_t *cu
                     for (int kk = 0; kk < 16; kk++) step((ws[kk >> 2] >> ((kk & 3) * 8)) & 0xffu);
                 }
                 for (; h0 < nc; h0 += 4) {
-                    uint32_t w; __builtin_memcpy(&w, cs + h0, 4);
+                    uint32_t w = seq_ld4(cs, h0, nc, 0u);
                     for (int kk = 0; kk < 4 && h0 + kk < nc; kk++, w >>= 8) step(w & 0xffu);
                 }
                 io.score[i] = -gab_myers_distance32<D>(P, M, nr, nc);
