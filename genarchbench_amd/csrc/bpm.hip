@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256) void bpm_count(BpmIO io, BpmCounters *ct) {
         const int n = io.pat_len[i], m = io.txt_len[i];
         const int64_t po = io.pat_off[i], to = io.txt_off[i];
         const bool ok = n >= 1 && n <= GAB_BPM_MAX_PLEN && m >= 0 && m <= n && po >= 0 && to >= 0 &&
-                        ((po + n + 3) & ~3ll) <= io.pat_bytes && ((to + m + 3) & ~3ll) <= io.txt_bytes;
+                        po + n + 3 <= io.pat_bytes && to + m + 3 <= io.txt_bytes;          // (the kernels read dwords from the sequence's own start)
         if (!ok) {
             atomicAdd(&ct->bad, 1);
             atomicMin((unsigned int *)&ct->first_bad, (unsigned int)(i + 1 > 0x7fffffff ? 0x7fffffff : i + 1));
@@ -794,7 +794,7 @@ extern "C" int gab_bpm_run_device(gab_bpm *h, const char *pat, int64_t pat_bytes
     if (h->h_ct->bad) {
         gab_set_error("gab_bpm_run_device: %d pair(s) violate the limits (first: pair %d): need 1 <= pattern_length <= %d, "
                       "0 <= text_length <= pattern_length (apply the driver's longer-is-pattern swap), offsets inside "
-                      "the slabs (readable to a multiple of 4 bytes)", h->h_ct->bad, h->h_ct->first_bad - 1,
+                      "the slabs with 3 more readable bytes behind every sequence", h->h_ct->bad, h->h_ct->first_bad - 1,
                       GAB_BPM_MAX_PLEN);
         return GAB_EINVAL;
     }

@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256) void bsw_hist(BswIO io, uint32_t *hist, uint32
         int64_t ro = io.ref_off[i], qo = io.qry_off[i];
         bool ok = ql >= 1 && ql <= GAB_BSW_MAX_QLEN && tl >= 1 && tl <= GAB_BSW_MAX_TLEN && h >= 0 &&
                   h <= (1 << 29) && ro >= 0 && qo >= 0 &&
-                  ((ro + tl + 3) & ~3ll) <= io.ref_bytes && ((qo + ql + 3) & ~3ll) <= io.qry_bytes;
+                  ro + tl + 3 <= io.ref_bytes && qo + ql + 3 <= io.qry_bytes;     // (the kernels read dwords from the sequence's own start)
         if (!ok) {
             atomicAdd(&st->bad, 1);
             atomicMin((unsigned int *)&st->first_bad, (unsigned int)(i + 1 > 0x7fffffff ? 0x7fffffff : i + 1));
@@ -720,7 +720,7 @@ extern "C" int gab_bsw_run_device(gab_bsw *h, const uint8_t *ref, int64_t ref_by
     GAB_HIP(hipStreamSynchronize(s));   // launch geometry of the DP depends on the class sizes
     if (h->h_stats->bad) {
         gab_set_error("gab_bsw_run_device: %d pair(s) violate the limits (first: pair %d): need 1<=len2<=%d, "
-                      "1<=len1<=%d, 0<=h0, offsets inside the slabs (readable to a multiple of 4 bytes)",
+                      "1<=len1<=%d, 0<=h0, offsets inside the slabs with 3 more readable bytes behind every sequence",
                       h->h_stats->bad, h->h_stats->first_bad - 1, GAB_BSW_MAX_QLEN, GAB_BSW_MAX_TLEN);
         return GAB_EINVAL;
     }

@@ -99,8 +99,9 @@ int gab_bsw_run(gab_bsw *h, const uint8_t *ref, const int64_t *ref_off, const ui
 /* Device buffers.  Enqueues on `stream`, but synchronises it once mid-way (the launch geometry of the DP kernels needs
  * the sizes of the query-length classes on the host); the DP launches and the result stores that follow are asynchronous:
  * order later work against `stream` (or synchronise it) before reading score_out.  ref_bytes / qry_bytes = sizes of the two
- * sequence slabs (used for bounds validation of 4-byte reads: both slabs must be
- * readable up to a multiple of 4 bytes past the last base).  result_out may be NULL;
+ * sequence slabs, used for bounds validation: the kernels read a sequence four bytes at a time from its own (possibly
+ * unaligned) start, so every sequence must be followed by at least 3 more bytes INSIDE its slab (off + len + 3 <= bytes;
+ * their contents do not matter).  result_out may be NULL;
  * when given it receives all six result fields per pair. */
 int gab_bsw_run_device(gab_bsw *h, const uint8_t *ref, int64_t ref_bytes, const int64_t *ref_off,
                        const uint8_t *qry, int64_t qry_bytes, const int64_t *qry_off,
@@ -169,8 +170,9 @@ int gab_bpm_reserve(gab_bpm *h, int64_t max_pairs, int64_t max_seq_bytes);
 int gab_bpm_run(gab_bpm *h, const char *pat, const int64_t *pat_off, const int32_t *pat_len,
                 const char *txt, const int64_t *txt_off, const int32_t *txt_len, int64_t n,
                 int32_t *score_out);
-/* device buffers; pat_bytes / txt_bytes = slab sizes (each readable to a multiple of 4 bytes
- * past the last sequence).  Synchronises `stream` internally (the second kernel's launch
+/* device buffers; pat_bytes / txt_bytes = slab sizes: every sequence must be followed by at least 3 more bytes
+ * inside its slab (off + len + 3 <= bytes; the kernels read four bytes at a time from the sequence's own start).
+ * Synchronises `stream` internally (the second kernel's launch
  * geometry depends on the first one's queue length). */
 int gab_bpm_run_device(gab_bpm *h, const char *pat, int64_t pat_bytes, const int64_t *pat_off,
                        const int32_t *pat_len, const char *txt, int64_t txt_bytes,

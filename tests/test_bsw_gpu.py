@@ -109,3 +109,21 @@ def test_rejects_bad_input(sw):
         sw.getScores16(batch)
     empty = gabgen.bsw_from_arrays([], [], [])
     assert len(sw.getScores16(empty)) == 0
+    # device entry point: a sequence needs three more bytes behind it INSIDE its slab (the kernels read dwords from the sequence's
+    # own start): a slab that ends with the last base is refused, with three bytes of slack it is taken
+    import torch
+    ok = gabgen.bsw_from_arrays([A(0, 1, 2, 3, 0), A(1, 1, 2)], [A(0, 1, 2, 3, 0), A(1, 1, 2)], [5, 5])
+    want = pyoracle.bsw(ok)[:, 0]
+    total = int(ok.ref_off[-1] + ok.len1[-1])
+    dev = torch.device("cuda:0")
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    for slack, good in ((0, False), (2, False), (3, True)):
+        score = torch.full((ok.n,), -7, dtype=torch.int32, device=dev)
+        args = (t(ok.ref[:total + slack]), t(ok.ref_off), t(ok.qry), t(ok.qry_off), t(ok.len1), t(ok.len2), t(ok.h0), score, None)
+        if good:
+            sw.run_device(*args, stream=torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            np.testing.assert_array_equal(score.cpu().numpy(), want)
+        else:
+            with pytest.raises(GabError):
+                sw.run_device(*args, stream=torch.cuda.current_stream().cuda_stream)
