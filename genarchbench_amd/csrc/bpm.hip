@@ -317,11 +317,10 @@ __device__ __forceinline__ void bpm_step32(const uint64_t *e, uint32_t (&P)[D], 
 }
 
 template <int D>
-__global__ __launch_bounds__(kBlock) void bpm_score32(BpmIO io, const uint32_t *__restrict__ perm, uint32_t kbeg,
-                                                      uint32_t kend, int32_t *__restrict__ score_out,
-                                                      uint32_t *__restrict__ worklist, uint32_t *wl_counter, BpmCounters *ct) {
+__device__ __forceinline__ void bpm_score32_body(uint64_t *peq_s, BpmIO io, const uint32_t *__restrict__ perm, uint32_t kbeg,
+                                                 uint32_t kend, int32_t *__restrict__ score_out,
+                                                 uint32_t *__restrict__ worklist, uint32_t *wl_counter, BpmCounters *ct) {
     constexpr int W = (D + 1) / 2;
-    __shared__ uint64_t peq_s[(4 * W + 1) * kBlock];
     const uint32_t k = kbeg + blockIdx.x * kBlock + threadIdx.x;
     unsigned long long steps = 0;
     int64_t queue_id = -1;
@@ -371,6 +370,24 @@ __global__ __launch_bounds__(kBlock) void bpm_score32(BpmIO io, const uint32_t *
         for (int k2 = 0; k2 < kBlock / 64; k2++) all += s_steps[k2];
         if (all) atomicAdd(&ct->steps, all);
     }
+}
+
+// Up to six words the kernel needs 54 VGPRs when the compiler is told to fit six waves per SIMD (left alone it takes 114 for
+// the sixteen unrolled columns, four waves): 24 waves per CU, what the 26.6 KB of masks per workgroup allow (bpm-large +4 %).
+// Seven and eight words do not fit that budget and keep the uncapped form.
+template <int D>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6, 6)))
+void bpm_score32(BpmIO io, const uint32_t *__restrict__ perm, uint32_t kbeg, uint32_t kend, int32_t *__restrict__ score_out,
+                 uint32_t *__restrict__ worklist, uint32_t *wl_counter, BpmCounters *ct) {
+    __shared__ uint64_t peq_s[(4 * ((D + 1) / 2) + 1) * kBlock];
+    bpm_score32_body<D>(peq_s, io, perm, kbeg, kend, score_out, worklist, wl_counter, ct);
+}
+template <int D>
+__global__ __launch_bounds__(kBlock)
+void bpm_score32_wide(BpmIO io, const uint32_t *__restrict__ perm, uint32_t kbeg, uint32_t kend, int32_t *__restrict__ score_out,
+                      uint32_t *__restrict__ worklist, uint32_t *wl_counter, BpmCounters *ct) {
+    __shared__ uint64_t peq_s[(4 * ((D + 1) / 2) + 1) * kBlock];
+    bpm_score32_body<D>(peq_s, io, perm, kbeg, kend, score_out, worklist, wl_counter, ct);
 }
 
 // ---- LDS band path: 8 rows around the diagonal per column, history never leaves the CU ------------------------
@@ -734,10 +751,17 @@ static void launch_score(hipStream_t s, const BpmIO &io, const uint32_t *perm, u
     const dim3 grid((ke - kb + kBlock - 1) / kBlock);
     if (blocks64)
         hipLaunchKernelGGL(bpm_score<W>, grid, dim3(kBlock), 0, s, io, perm, kb, ke, score, wl, wl_counter, ct);
-    else if (max_plen <= 32 * (2 * W - 1))                                    // the class's longest pattern fits 2W - 1 words
-        hipLaunchKernelGGL(bpm_score32<2 * W - 1>, grid, dim3(kBlock), 0, s, io, perm, kb, ke, score, wl, wl_counter, ct);
-    else
-        hipLaunchKernelGGL(bpm_score32<2 * W>, grid, dim3(kBlock), 0, s, io, perm, kb, ke, score, wl, wl_counter, ct);
+    else if constexpr (W <= 3) {
+        if (max_plen <= 32 * (2 * W - 1))                                     // the class's longest pattern fits 2W - 1 words
+            hipLaunchKernelGGL(bpm_score32<2 * W - 1>, grid, dim3(kBlock), 0, s, io, perm, kb, ke, score, wl, wl_counter, ct);
+        else
+            hipLaunchKernelGGL(bpm_score32<2 * W>, grid, dim3(kBlock), 0, s, io, perm, kb, ke, score, wl, wl_counter, ct);
+    } else {
+        if (max_plen <= 32 * (2 * W - 1))
+            hipLaunchKernelGGL(bpm_score32_wide<2 * W - 1>, grid, dim3(kBlock), 0, s, io, perm, kb, ke, score, wl, wl_counter, ct);
+        else
+            hipLaunchKernelGGL(bpm_score32_wide<2 * W>, grid, dim3(kBlock), 0, s, io, perm, kb, ke, score, wl, wl_counter, ct);
+    }
 }
 // the score kernel of one slice on `s`, its band kernel on `sb` behind the event
 template <int W>
