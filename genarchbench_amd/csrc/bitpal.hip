@@ -301,6 +301,13 @@ __global__ __launch_bounds__(kBvBlock) void bitpal_edit_bv(BpIO io, uint32_t *cu
                     gab_myers_step32<D>(Eq, P, M);
                 };
                 int h0 = 0;
+                // thirty-two columns per trip, both 16-byte loads at once: a 64-byte line is visited twice instead of four times
+                for (; h0 + 32 <= nc; h0 += 32) {
+                    uint4 q, r; __builtin_memcpy(&q, cs + h0, 16); __builtin_memcpy(&r, cs + h0 + 16, 16);
+                    const uint32_t ws[8] = {q.x, q.y, q.z, q.w, r.x, r.y, r.z, r.w};
+#pragma unroll
+                    for (int kk = 0; kk < 32; kk++) step((ws[kk >> 2] >> ((kk & 3) * 8)) & 0xffu);
+                }
                 for (; h0 + 16 <= nc; h0 += 16) {
                     uint4 q; __builtin_memcpy(&q, cs + h0, 16);
                     const uint32_t ws[4] = {q.x, q.y, q.z, q.w};
