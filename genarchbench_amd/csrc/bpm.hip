@@ -435,36 +435,43 @@ __global__ __launch_bounds__(64) void bpm_band(BpmIO io, const uint32_t *__restr
         for (int d = 0; d < D; d++) { P[d] = ~0u; M[d] = 0; }
         B[0] = (uint16_t)((1u << kBandRows) - 1u);                // column 0: Pv = 1..1, Mv = 0
         bool dummy = true;
-        for (int h0 = 0; h0 < m; h0 += 4) {
-            uint32_t w4 = ld_u32(t + h0);
-            for (int kk = 0; kk < 4 && h0 + kk < m; kk++, w4 >>= 8) {
-                const int h = h0 + kk;
-                const int c = bpm_code(w4 & 0xffu, dummy);
-                bpm_step32<D, 64>(peq + (size_t)c * 64, P, M);
-                // the 8 rows of the band from row r0 on: rows of the pattern end below 32 D (r0 <= plen - 4), a word past the
-                // last one reads as 0 (rows the walk never stands on)
-                const int r0 = start(h + 1);
-                const int b0 = r0 >> 5;
-                const uint32_t sh = (uint32_t)(r0 & 31);
-                uint32_t plo = P[0], phi = D > 1 ? P[D > 1 ? 1 : 0] : 0, mlo = M[0], mhi = D > 1 ? M[D > 1 ? 1 : 0] : 0;
-                // which word the band starts in is the same for the whole wave except in the few columns where the lanes
-                // cross a word boundary (their diagonals differ by a row or two): then the words are named by a scalar switch
-                // instead of being selected per lane
-                const int b0u = __builtin_amdgcn_readfirstlane(b0);
-                if (D > 1 && __ballot(b0 != b0u) == 0) {
+        auto column = [&](int h, uint32_t byte) {
+            const int c = bpm_code(byte, dummy);
+            bpm_step32<D, 64>(peq + (size_t)c * 64, P, M);
+            // the 8 rows of the band from row r0 on: rows of the pattern end below 32 D (r0 <= plen - 4), a word past the
+            // last one reads as 0 (rows the walk never stands on)
+            const int r0 = start(h + 1);
+            const int b0 = r0 >> 5;
+            const uint32_t sh = (uint32_t)(r0 & 31);
+            uint32_t plo = P[0], phi = D > 1 ? P[D > 1 ? 1 : 0] : 0, mlo = M[0], mhi = D > 1 ? M[D > 1 ? 1 : 0] : 0;
+            // which word the band starts in is the same for the whole wave except in the few columns where the lanes
+            // cross a word boundary (their diagonals differ by a row or two): then the words are named by a scalar switch
+            // instead of being selected per lane
+            const int b0u = __builtin_amdgcn_readfirstlane(b0);
+            if (D > 1 && __ballot(b0 != b0u) == 0) {
 #pragma unroll
-                    for (int b = 1; b < D; b++)
-                        if (b0u == b) { plo = P[b]; mlo = M[b]; phi = b + 1 < D ? P[b + 1 < D ? b + 1 : b] : 0; mhi = b + 1 < D ? M[b + 1 < D ? b + 1 : b] : 0; }
-                } else {
+                for (int b = 1; b < D; b++)
+                    if (b0u == b) { plo = P[b]; mlo = M[b]; phi = b + 1 < D ? P[b + 1 < D ? b + 1 : b] : 0; mhi = b + 1 < D ? M[b + 1 < D ? b + 1 : b] : 0; }
+            } else {
 #pragma unroll
-                    for (int b = 1; b < D; b++)
-                        if (b0 == b) { plo = P[b]; mlo = M[b]; phi = b + 1 < D ? P[b + 1 < D ? b + 1 : b] : 0; mhi = b + 1 < D ? M[b + 1 < D ? b + 1 : b] : 0; }
-                }
-                const uint32_t bm = (1u << kBandRows) - 1u;
-                const uint32_t pw = __builtin_amdgcn_alignbit(phi, plo, sh) & bm;     // ({hi, lo} >> sh): sh = 0 gives lo
-                const uint32_t mw = __builtin_amdgcn_alignbit(mhi, mlo, sh) & bm;
-                B[(h + 1) * 64] = (uint16_t)(pw | mw << kBandRows);
+                for (int b = 1; b < D; b++)
+                    if (b0 == b) { plo = P[b]; mlo = M[b]; phi = b + 1 < D ? P[b + 1 < D ? b + 1 : b] : 0; mhi = b + 1 < D ? M[b + 1 < D ? b + 1 : b] : 0; }
             }
+            const uint32_t bm = (1u << kBandRows) - 1u;
+            const uint32_t pw = __builtin_amdgcn_alignbit(phi, plo, sh) & bm;     // ({hi, lo} >> sh): sh = 0 gives lo
+            const uint32_t mw = __builtin_amdgcn_alignbit(mhi, mlo, sh) & bm;
+            B[(h + 1) * 64] = (uint16_t)(pw | mw << kBandRows);
+        };
+        int h0 = 0;
+        for (; h0 + 16 <= m; h0 += 16) {                     // sixteen columns per load, as in the score kernel
+            const uint4 q = ld_u128(t + h0);
+            const uint32_t ws[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+            for (int kk = 0; kk < 16; kk++) column(h0 + kk, (ws[kk >> 2] >> ((kk & 3) * 8)) & 0xffu);
+        }
+        for (; h0 < m; h0 += 4) {
+            uint32_t w4 = ld_u32(t + h0);
+            for (int kk = 0; kk < 4 && h0 + kk < m; kk++, w4 >>= 8) column(h0 + kk, w4 & 0xffu);
         }
         steps = (unsigned long long)m * W;
         (void)cols;
