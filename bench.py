@@ -5,9 +5,17 @@
 
 A "step" is one pass of the hot path over one batch of synthetic input that is already
 resident in HBM (the reference's ROI likewise excludes file parsing).  The default
-workload is the one BASELINE.json's metric is quoted on: bsw-large, 10 M pairs per GPU
-(configs[1]).  Ranks shard the item-id range with no collective on the data path (weak
-scaling); rank 0 prints ONE JSON line.
+workload is the one BASELINE.json's metric is quoted on: bsw-large, 10 M pairs (configs[1]).
+Ranks shard the item-id range with no collective on the data path: with N > 1 the FIXED large
+input is split across the ranks (strong scaling, configs[4]; --scaling weak gives every rank a
+full-size input of its own).
+
+Output contract: the LAST line of stdout is ONE compact JSON object (< 4 KB: metric, value, unit,
+n_gpus, steps, warmup, ms_per_step, scaling, dtype, config, roofline, cpu_baseline, parity and a
+short `extra`).  Every other configuration of the suite is printed BEFORE it as a line of its own
+({"suite": "<name>", ...}) and the full detail of everything goes to bench_suite.json next to this
+file -- one grep-able timing line per run, as the reference's drivers print theirs
+(bsw/src/main_banded.cpp:411-426, chain/src/main.cpp:201).
 """
 import argparse
 import json
@@ -24,7 +32,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-ROUND = "r02"           # prefix of this round's evidence under profiles/
+ROUND = "r03"           # prefix of this round's evidence under profiles/
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
@@ -96,9 +104,10 @@ def unpin(arrays):
 
 
 def host_queue(nchunks, make_state, run_chunk, close_state, passes=3):
-    """-> best wall time (s) of `passes` timed passes after one untimed pass (device buffers get allocated there)"""
+    """-> MEAN wall time (s) of `passes` timed passes after one untimed pass (device buffers get allocated there), like
+    the headline metric (a mean over the timed steps)"""
     import threading
-    states = [make_state() for _ in range(HOST_WORKERS)]
+    states = [make_state() for _ in range(max(1, min(HOST_WORKERS, nchunks)))]
     err = []
 
     def one_pass():
@@ -124,13 +133,13 @@ def host_queue(nchunks, make_state, run_chunk, close_state, passes=3):
         return time.perf_counter() - t0
     try:
         one_pass()
-        best = min(one_pass() for _ in range(passes))
+        mean = sum(one_pass() for _ in range(passes)) / passes
     finally:
         for st in states:
             close_state(st)
     if err:
         raise err[0]
-    return best
+    return mean
 
 
 # ------------------------------------------------------------------------------------- bsw
@@ -142,14 +151,14 @@ class BswWorkload:
     default_items = 10_000_000
     seed = 2
 
-    def __init__(self, items, rank, dev):
+    def __init__(self, items, rank, dev, first=0, ids=None):
         import torch
         from tools import gabgen
         from genarchbench_amd.bsw import BandedPairWiseSW
         self.torch = torch
         self.items = items
         t0 = time.time()
-        self.batch = gabgen.bsw(self.seed, items, 0, first=rank * items)
+        self.batch = gabgen.bsw(self.seed, items, 0, first=first)
         log(f"[rank {rank}] generated {items} bsw pairs in {time.time() - t0:.1f}s")
         b = self.batch
         t = lambda a: torch.from_numpy(a).to(dev)
@@ -289,14 +298,16 @@ class ChainWorkload:
     ref_exe = "chain_ref"
     kernel = "chain_block_kernel"
 
-    def __init__(self, items, rank, dev):
+    def __init__(self, items, rank, dev, first=0, ids=None):
         import torch
         from tools import gabgen
         from genarchbench_amd.chain import ChainEngine
         self.torch = torch
         self.calls = items
         t0 = time.time()
-        self.batch = b = gabgen.chain(self.seed, items, 0, 50, 60000, first=rank * items)
+        # ids: this rank's calls of the fixed input under strong scaling (dealt longest first, genarchbench_amd/shard.py)
+        self.batch = b = (gabgen.chain(self.seed, items, 0, 50, 60000, first=first) if ids is None else
+                          gabgen.chain_ids(self.seed, ids, 0, 50, 60000))
         self.items = b.nanchors       # the metric counts seeds (anchors)
         log(f"[rank {rank}] generated {items} calls / {b.nanchors} anchors in {time.time() - t0:.1f}s")
         self.x = torch.from_numpy(b.x.view(np.int64)).to(dev)
@@ -436,13 +447,13 @@ class BpmWorkload:
     seed = 3
     plen = 151
 
-    def __init__(self, items, rank, dev):
+    def __init__(self, items, rank, dev, first=0, ids=None):
         import torch
         from tools import gabgen
         from genarchbench_amd.bpm import BpmEngine
         self.items = items
         t0 = time.time()
-        raw = gabgen.pairs(self.seed, items, 0, self.plen, first=rank * items)
+        raw = gabgen.pairs(self.seed, items, 0, self.plen, first=first)
         self.batch = b = raw.swapped_combined()      # the driver's longer-is-pattern swap
         log(f"[rank {rank}] generated {items} bpm pairs in {time.time() - t0:.1f}s")
         t = lambda a: torch.from_numpy(a).to(dev)
@@ -491,6 +502,42 @@ class BpmWorkload:
                 "frac": round(ach / HBM_PEAK_GBS, 6), "traffic": None,
                 "note": "score kernel: plen+tlen+4 B per pair vs ~9.4k integer VALU per pair (61 per text base: the column as five 32-bit words; VALU bound)"}
 
+    host_entry, host_reserve = "gab_bpm_run", "gab_bpm_reserve"
+
+    def _host_engine(self):
+        from genarchbench_amd.bpm import BpmEngine
+        return BpmEngine(device=self.dev_index)
+
+    def host_roi(self, chunk=1 << 20):
+        """the C driver's ROI (bpm/tools/align_benchmark.c:213-337 in the reference): host slabs in, scores out"""
+        import ctypes as C
+        from genarchbench_amd._lib import check, lib
+        b, n = self.batch, self.items
+        score = np.full(n, 12345, np.int32)
+        pinned = pin(b.pat, b.pat_off, b.pat_len, b.txt_off, b.txt_len, score)       # b.txt IS b.pat (one interleaved slab)
+        at = lambda a, i: C.c_void_p(a.ctypes.data + a.itemsize * i)
+        entry, reserve = self.host_entry, self.host_reserve
+        slab_bytes = int(b.pat.nbytes)
+
+        def make():
+            e = self._host_engine()
+            # buffers for the largest chunk + warm copy queues, outside the ROI (the drivers do the same)
+            check(getattr(lib(), reserve)(e._h, C.c_int64(min(n, chunk)), C.c_int64(min(slab_bytes, 2 * 160 * chunk))))
+            return e
+
+        def run(st, c):
+            lo, hi = c * chunk, min(n, (c + 1) * chunk)
+            check(getattr(lib(), entry)(st._h, at(b.pat, 0), at(b.pat_off, lo), at(b.pat_len, lo), at(b.txt, 0), at(b.txt_off, lo),
+                                         at(b.txt_len, lo), C.c_int64(hi - lo), at(score, lo)))
+        try:
+            sec = host_queue((n + chunk - 1) // chunk, make, run, lambda st: st.close())
+        finally:
+            unpin(pinned)
+        assert np.array_equal(score, self.score.cpu().numpy()), "host-pointer path and device path disagree"
+        return {"ms": round(sec * 1e3, 3), "value": round(n / sec / 1e6, 3), "unit": self.unit, "chunk": chunk, "workers_per_gpu": HOST_WORKERS,
+                "note": f"{entry} on page-locked host slabs, chunks pulled by worker threads (the C driver's ROI): the pair text over the "
+                        "bus (~310 B per pair) + kernels + the scores back; all scores equal to the device path's"}
+
     def cpu_baseline(self, cores):
         from oracle import pyoracle
         from tools import gabgen
@@ -524,23 +571,30 @@ class BitpalWorkload(BpmWorkload):
     metric = "bpm (bitpal-scored) ROI M alignments/sec"
     dtype = "i32"
 
-    def __init__(self, items, rank, dev):
+    def __init__(self, items, rank, dev, first=0, ids=None):
         import torch
         from tools import gabgen
         from genarchbench_amd.bitpal import BitpalEngine
         self.items = items
         t0 = time.time()
-        raw = gabgen.pairs(self.seed, items, 0, self.plen, first=rank * items)
+        raw = gabgen.pairs(self.seed, items, 0, self.plen, first=first)
         self.batch = b = raw.swapped_combined()
         log(f"[rank {rank}] generated {items} bpm pairs in {time.time() - t0:.1f}s")
         t = lambda a: torch.from_numpy(a).to(dev)
         slab = t(b.pat)
         self.d = [slab, t(b.pat_off), t(b.pat_len), slab, t(b.txt_off), t(b.txt_len)]
         self.score = torch.empty(items, dtype=torch.int32, device=dev)
-        self.eng = BitpalEngine(self.algorithm, device=dev.index or 0)
+        self.dev_index = dev.index or 0
+        self.eng = BitpalEngine(self.algorithm, device=self.dev_index)
         self.alg_bytes = int(b.pat_len.astype(np.int64).sum() + b.txt_len.astype(np.int64).sum() + 4 * items)
         self.kernel_ms, self.total_ms = [], []
         self.stats = {}
+
+    host_entry, host_reserve = "gab_bitpal_run", "gab_bitpal_reserve"
+
+    def _host_engine(self):
+        from genarchbench_amd.bitpal import BitpalEngine
+        return BitpalEngine(self.algorithm, device=self.dev_index)
 
     def check(self):
         from oracle import pyoracle
@@ -626,13 +680,13 @@ class WfaWorkload:
     seed = 4
     plen = 151
 
-    def __init__(self, items, rank, dev):
+    def __init__(self, items, rank, dev, first=0, ids=None):
         import torch
         from tools import gabgen
         from genarchbench_amd.wfa import AffineWavefronts, ops_layout
         self.items = items
         t0 = time.time()
-        self.batch = b = gabgen.pairs(self.seed, items, 0, self.plen, first=rank * items)
+        self.batch = b = gabgen.pairs(self.seed, items, 0, self.plen, first=first)
         log(f"[rank {rank}] generated {items} wfa pairs in {time.time() - t0:.1f}s")
         t = lambda a: torch.from_numpy(a).to(dev)
         self.off, total = ops_layout(b)
@@ -689,32 +743,56 @@ class WfaWorkload:
                 "note": "plen+tlen+cigar+4 B per pair; the kernel is instruction-issue bound (83 % VALU busy at 45 % lane utilisation: four pairs per wave, lanes = diagonals)"}
 
     def host_roi(self, chunk=1 << 18):
+        """the C driver's ROI (wfa/tools/align_benchmark.c:378-491 in the reference): pair text in, the alignments out -- as the
+        run-length CIGAR text the driver prints (gab_wfa_run_packed), not as pattern + text length bytes of operation room"""
         import ctypes as C
         from genarchbench_amd._lib import check, lib
         from genarchbench_amd.wfa import AffineWavefronts
         b, n = self.batch, self.items
-        total = int(self.off[-1] + b.pat_len[-1] + b.txt_len[-1]) if n else 0
-        ops = np.zeros(total + 16, np.uint8); ln = np.zeros(n, np.int32); sc = np.full(n, -1, np.int32)
-        pinned = pin(b.pat, b.txt, b.pat_off, b.txt_off, b.pat_len, b.txt_len, ops, self.off, ln, sc)
+        nchunks = (n + chunk - 1) // chunk
+        room = (b.pat_len.astype(np.int64) + b.txt_len.astype(np.int64))
+        beg = np.zeros(nchunks + 1, np.int64)                    # text room of chunk c: a quarter of its operation room
+        for c in range(nchunks):
+            beg[c + 1] = beg[c] + ((int(room[c * chunk:(c + 1) * chunk].sum()) // 4 + 4096 + 255) & ~255)
+        text = np.zeros(int(beg[-1]) + 16, np.uint8)
+        off = np.full(n, -1, np.int64); ln = np.full(n, -1, np.int32); sc = np.full(n, -1, np.int32)
+        used = np.zeros(nchunks, np.int64)
+        pinned = pin(b.pat, b.txt, b.pat_off, b.txt_off, b.pat_len, b.txt_len, text, off, ln, sc)
         at = lambda a, i: C.c_void_p(a.ctypes.data + a.itemsize * i)
+        stride = (int(room.max()) + 7) & ~7
+
+        def make():
+            e = AffineWavefronts(device=self.dev_index)
+            check(lib().gab_wfa_reserve(e._h, C.c_int64(min(n, chunk)), C.c_int64(int(b.pat.nbytes + b.txt.nbytes) // max(nchunks, 1) + (1 << 20)),
+                                        C.c_int64(stride * min(n, chunk) + int(np.diff(beg).max()) + 4096)))
+            return e
 
         def run(st, c):
             lo, hi = c * chunk, min(n, (c + 1) * chunk)
-            check(lib().gab_wfa_run(st._h, at(b.pat, 0), at(b.pat_off, lo), at(b.pat_len, lo), at(b.txt, 0), at(b.txt_off, lo), at(b.txt_len, lo),
-                                    C.c_int64(hi - lo), at(ops, 0), at(self.off, lo), at(ln, lo), at(sc, lo)))
+            need = C.c_int64(0)
+            check(lib().gab_wfa_run_packed(st._h, at(b.pat, 0), at(b.pat_off, lo), at(b.pat_len, lo), at(b.txt, 0), at(b.txt_off, lo), at(b.txt_len, lo),
+                                           C.c_int64(hi - lo), at(text, int(beg[c])), C.c_int64(int(beg[c + 1] - beg[c])), at(off, lo), at(ln, lo), at(sc, lo),
+                                           C.byref(need)))
+            used[c] = need.value
         try:
-            sec = host_queue((n + chunk - 1) // chunk, lambda: AffineWavefronts(device=self.dev_index), run, lambda st: st.close())
+            sec = host_queue(nchunks, make, run, lambda st: st.close())
         finally:
             unpin(pinned)
         dl = self.ops_len.cpu().numpy()
-        assert np.array_equal(sc, self.score.cpu().numpy()) and np.array_equal(ln, dl), "host-pointer path and device path disagree"
+        assert np.array_equal(sc, self.score.cpu().numpy()), "host-pointer path and device path disagree"
         dev_ops = self.ops.cpu().numpy()
-        for i in range(0, n, max(1, n // 5000)):
-            o = int(self.off[i])
-            assert np.array_equal(ops[o:o + ln[i]], dev_ops[o:o + ln[i]]), f"cigar {i}: host-pointer path and device path disagree"
+        for i in range(0, n, max(1, n // 5000)):                 # the text is the run-length form of the device path's operations
+            o = int(self.off[i]); ops = dev_ops[o:o + dl[i]]
+            cut = np.flatnonzero(np.diff(ops)) + 1
+            runs = np.diff(np.concatenate(([0], cut, [len(ops)])))
+            want = b"".join(b"%d%c" % (r, ops[k]) for r, k in zip(runs, np.concatenate(([0], cut)))) if len(ops) else b""
+            t0 = int(beg[i // chunk] + off[i])
+            assert text[t0:t0 + ln[i]].tobytes() == want, f"cigar {i}: host-pointer path and device path disagree"
         return {"ms": round(sec * 1e3, 3), "value": round(n / sec / 1e6, 3), "unit": self.unit, "chunk": chunk, "workers_per_gpu": HOST_WORKERS,
-                "note": "gab_wfa_run on page-locked host slabs, chunks pulled by worker threads (the C driver's ROI): the sequences over the "
-                        "bus + kernels + the CIGAR room back; scores, lengths and a sample of the CIGARs equal to the device path's"}
+                "bytes_in": int(b.pat.nbytes + b.txt.nbytes + 24 * n), "bytes_out": int(used.sum() + 16 * n),
+                "note": "gab_wfa_run_packed on page-locked host slabs, chunks pulled by worker threads (the C driver's ROI): the sequences over the "
+                        "bus + kernels + the printed CIGAR text back (run-length encoded on the device); all scores and a sample of the "
+                        "CIGARs equal to the device path's"}
 
     def cpu_baseline(self, cores):
         from oracle import pyoracle
@@ -755,23 +833,36 @@ class FmiWorkload:
     min_seed_len = 19
     wide_lists = False
 
-    def __init__(self, items, rank, dev):
+    def __init__(self, items, rank, dev, first=0, ids=None):
         import torch
         from tools import gabgen, mkindex
         from genarchbench_amd.fmi import FMI_search
         self.items = items
         t0 = time.time()
         key = (self.seed, self.ref_mbp)
+        world, dist = _CTX.get("world", 1), _CTX.get("dist")
         if key not in _FMI_INDEX_CACHE:                 # fmi, fmi (16-byte lists) and fmi-sa of one run share the index
-            ref = gabgen.fmi_ref(self.seed, self.ref_mbp * 1_000_000, 5)
-            log(f"[rank {rank}] generated the {self.ref_mbp} Mbp reference in {time.time() - t0:.1f}s")
-            t0 = time.time()
             _FMI_INDEX_CACHE.clear()
-            _FMI_INDEX_CACHE[key] = (ref, mkindex.FmIndex(ref))       # outside the ROI, like load_index in the reference
-            log(f"[rank {rank}] built the FM-index ({_FMI_INDEX_CACHE[key][1].ref_seq_len} rows, "
-                f"{len(_FMI_INDEX_CACHE[key][1].cp_occ) / 2**20:.0f} MiB of CP_OCC) in {time.time() - t0:.1f}s")
+            share = os.path.join(_CTX["share_dir"], f"fmi_{self.seed}_{self.ref_mbp}") if world > 1 else None
+            if world == 1 or rank == 0:
+                ref = gabgen.fmi_ref(self.seed, self.ref_mbp * 1_000_000, 5)
+                log(f"[rank {rank}] generated the {self.ref_mbp} Mbp reference in {time.time() - t0:.1f}s")
+                t0 = time.time()
+                index = mkindex.FmIndex(ref)                 # outside the ROI, like load_index in the reference
+                log(f"[rank {rank}] built the FM-index ({index.ref_seq_len} rows, {len(index.cp_occ) / 2**20:.0f} MiB of CP_OCC) "
+                    f"in {time.time() - t0:.1f}s")
+                if share:                                    # ONE index per node: the other ranks map rank 0's file, as the
+                    index.write(share)                       # reference's threads share one FMI_search (fmi/fmi.cpp:102-103)
+                    np.save(share + ".ref.npy", ref)
+            if world > 1:
+                dist.barrier()
+                if rank != 0:
+                    ref = np.load(share + ".ref.npy", mmap_mode="r")
+                    index = mkindex.IndexFile(share)
+                    log(f"[rank {rank}] mapped rank 0's index file ({index.ref_seq_len} rows)")
+            _FMI_INDEX_CACHE[key] = (ref, index)
         self.ref, self.index = _FMI_INDEX_CACHE[key]
-        self.reads = gabgen.fmi_reads(self.seed + 1, self.ref, items, self.readlen, self.readlen, first=rank * items)
+        self.reads = gabgen.fmi_reads(self.seed + 1, np.ascontiguousarray(self.ref), items, self.readlen, self.readlen, first=first)
         if self.wide_lists:
             os.environ["GAB_FMI_WIDE_LISTS"] = "1"      # read when the handle is made
         try:
@@ -779,6 +870,7 @@ class FmiWorkload:
                                   device=dev.index or 0)
         finally:
             os.environ.pop("GAB_FMI_WIDE_LISTS", None)
+        self.dev_index = dev.index or 0
         self.enc = torch.from_numpy(self.reads.enc).to(dev)
         self.len = torch.from_numpy(self.reads.len).to(dev)
         self.kernel_ms = []
@@ -842,6 +934,42 @@ class FmiWorkload:
                         "table fetch none); measured chip ceiling for random 64-B reads is 55 G rec/s = 3.5 TB/s "
                         "(profiles/r01_random_read_ceiling.md)"}
 
+    def host_roi(self, chunk=1 << 20):
+        """the C driver's ROI (fmi/fmi.cpp:189-362 in the reference): read codes in, sorted SMEM records out, into page-locked
+        arrays of the caller (gab_fmi_seed_into), one clone of the index handle per worker"""
+        import ctypes as C
+        from genarchbench_amd.fmi import SMEM_DTYPE
+        n = self.items
+        d_out, d_off, total = self.result
+        hip = C.CDLL("libamdhip64.so")
+        off = np.zeros(n + 1, np.int64)
+        assert hip.hipMemcpy(off.ctypes.data_as(C.c_void_p), C.c_void_p(d_off), C.c_size_t(8 * (n + 1)), C.c_int(2)) == 0
+        nchunks = (n + chunk - 1) // chunk
+        out = np.zeros(max(total, 1), SMEM_DTYPE)                    # chunk c writes at off[c * chunk]: the device path's layout
+        enc, ln = self.reads.enc, self.reads.len
+        pinned = pin(enc, ln, out)
+        counts = [0] * nchunks
+
+        def run(st, c):
+            lo, hi = c * chunk, min(n, (c + 1) * chunk)
+            counts[c] = st.seed_into(enc[lo:hi], ln[lo:hi], out[int(off[lo]):int(off[hi])], self.min_seed_len)
+        try:
+            sec = host_queue(nchunks, lambda: self.eng.clone(), run, lambda st: st.close())
+        finally:
+            unpin(pinned)
+        assert sum(counts) == total, "host-pointer path and device path disagree on the SMEM count"
+        dev = np.zeros(max(total, 1) * 40, np.uint8)
+        assert hip.hipMemcpy(dev.ctypes.data_as(C.c_void_p), C.c_void_p(d_out), C.c_size_t(total * 40), C.c_int(2)) == 0
+        dev = dev[:total * 40].view(SMEM_DTYPE)
+        for c in range(nchunks):                                     # a chunk numbers its reads from 0 (fmi.cpp:340-343 adds the offset)
+            lo, hi = int(off[c * chunk]), int(off[min(n, (c + 1) * chunk)])
+            out["rid"][lo:hi] += np.uint32(c * chunk)
+        assert all(np.array_equal(out[f][:total], dev[f]) for f in ("rid", "m", "n", "k", "l", "s")), "host-pointer path and device path disagree"
+        return {"ms": round(sec * 1e3, 3), "value": round(n / sec / 1e6, 3), "unit": self.unit, "chunk": chunk, "workers_per_gpu": HOST_WORKERS,
+                "note": "gab_fmi_seed_into on page-locked host arrays, chunks pulled by worker threads with clones of one index handle "
+                        f"(the C driver's ROI): {enc.nbytes / 1e9:.2f} GB of read codes in, {total * 40 / 1e9:.2f} GB of SMEM records out; "
+                        "every record equal to the device path's"}
+
     def cpu_baseline(self, cores):
         import ctypes as C
         from oracle import pyoracle
@@ -883,6 +1011,7 @@ class FmiWideWorkload(FmiWorkload):
 
 
 _FMI_INDEX_CACHE = {}
+_CTX = {}               # rank / world / dist / share_dir of this process (set in main)
 
 
 class FmiSaWorkload(FmiWorkload):
@@ -894,9 +1023,10 @@ class FmiSaWorkload(FmiWorkload):
     unit = "M coordinates/s"
     default_items = 10_000_000
     max_occ = 500                                   # BWA-MEM2's default max_occ
+    host_roi = None                                 # the reference driver has no ROI for this step (its call is commented out)
 
-    def __init__(self, items, rank, dev):
-        super().__init__(items, rank, dev)
+    def __init__(self, items, rank, dev, first=0, ids=None):
+        super().__init__(items, rank, dev, first=first)
         self.eng.set_sa(self.index.sa_ms_byte, self.index.sa_ls_word)
         self.d_smems, _, self.nsmem = self.eng.seed_device(self.enc, self.len, self.min_seed_len)
         self.coords = 0
@@ -985,10 +1115,11 @@ class ParseBswWorkload:
     default_items = 10_000_000        # pairs
     seed = 2
 
-    def __init__(self, items, rank, dev):
+    def __init__(self, items, rank, dev, first=0, ids=None):
         import torch
         from tools import gabgen
         from genarchbench_amd.parse import InputParser
+        assert first == 0, "parse-bsw parses one file: run it at --gpus 1"
         self.items = items
         t0 = time.time()
         with tempfile.TemporaryDirectory() as td:
@@ -1105,14 +1236,36 @@ def self_launch(args):
     raise SystemExit(subprocess.call(cmd, env=env))
 
 
+def plan_shard(W, items, ctx, scaling):
+    """-> (count, first, ids, total): what this rank processes.  `items` is the size of the FIXED input under strong scaling
+    (split across the ranks) and the per-rank size under weak scaling."""
+    from genarchbench_amd.shard import deal_longest_first, shard_range, shard_strong
+    rank, world = ctx["rank"], ctx["world"]
+    if world == 1:
+        return items, 0, None, items
+    if scaling == "weak":
+        first, count = shard_range(rank, world, items)
+        return count, first, None, items * world
+    if issubclass(W, ChainWorkload):
+        # calls differ in size by three orders of magnitude: longest first, each to the rank with the least work so far
+        # (what `omp for schedule(dynamic)` over the sorted calls does in effect, chain/src/host_kernel.cpp:98-105)
+        from tools import gabgen
+        ids = deal_longest_first(gabgen.chain_sizes(W.seed, items, 0, 50, 60000), world)[rank]
+        return len(ids), 0, ids, items
+    first, count = shard_strong(rank, world, items)
+    return count, first, None, items
+
+
 def run_workload(W, items, steps, warmup, ctx, args, with_cpu=True, with_host=True):
     """one workload, the bench contract's way: W untimed warm-up steps, K timed steps between barrier + synchronize on both
     sides, MAX over ranks.  Returns the result dict on rank 0 (None elsewhere)."""
     import torch
     rank, world, dev, dist = ctx["rank"], ctx["world"], ctx["dev"], ctx["dist"]
+    scaling = args.scaling if world > 1 else "weak"            # at N = 1 the two coincide; the line says "weak" as before
     tw = time.time()
     mark = lambda what: log(f"[rank {rank}] {W.name}: {what} (+{time.time() - tw:.1f} s)")     # progress, one line per phase
-    wl = W(items, rank, dev)
+    count, first, ids, total = plan_shard(W, items, ctx, scaling)
+    wl = W(count, rank, dev, first=first, ids=ids)
     mark("inputs resident")
     stream = torch.cuda.current_stream().cuda_stream
 
@@ -1134,39 +1287,57 @@ def run_workload(W, items, steps, warmup, ctx, args, with_cpu=True, with_host=Tr
     barrier()
     elapsed = time.perf_counter() - t0
     from genarchbench_amd.shard import aggregate
-    units = wl.units_per_step() if hasattr(wl, "units_per_step") else getattr(wl, "items", items)
+    units = wl.units_per_step() if hasattr(wl, "units_per_step") else getattr(wl, "items", count)
+    own_ms = elapsed / steps * 1e3
     elapsed, total_units = aggregate(elapsed, units, dist if world > 1 else None, ctx.get("agg_dev", dev))
 
     mark(f"{steps} timed steps done")
     verdict = None if args.no_check else wl.check()
     mark("parity check done")
+    per_rank = None
+    if world > 1:                                             # who was the slowest, and on how much work (informative)
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, {"rank": rank, "units": float(units), "ms_per_step": round(own_ms, 4),
+                                          "kernel_ms": round(float(np.mean(wl.kernel_ms)), 4) if getattr(wl, "kernel_ms", None) else None})
     out = None
     if rank == 0:
         ms = elapsed / steps * 1e3
         value = total_units / (ms * 1e-3) / 1e6       # units of all ranks / max-over-ranks time
         large = items == W.default_items
+        sharding = ("1 GPU" if world == 1 else
+                    f"strong: the fixed input of {total} items split across {world} ranks" +
+                    (", calls dealt longest first to the least-loaded rank" if ids is not None else ", contiguous id ranges") +
+                    ", no collective" if scaling == "strong" else
+                    f"weak: {world} x independent id ranges of {items} items, no collective")
+        if ctx.get("share"):
+            sharding += " -- TEST MODE: all ranks share GPU 0 (GAB_BENCH_SHARE_GPU=1), not an N-GPU measurement"
         out = {
             "metric": W.metric, "value": round(value, 4), "unit": W.unit, "n_gpus": world,
             "steps": steps, "warmup": warmup, "ms_per_step": round(ms, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": W.dtype,
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": W.dtype,
             "data": "synthetic (seeded generator tools/gen, SURVEY.md 8d distributions)",
             "config": {"workload": f"{W.name}-large" if large else f"{W.name}-{items}",
-                       "items_per_gpu": items, "sharding": f"{world} x independent id ranges, no collective" +
-                       (" -- TEST MODE: all ranks share GPU 0 (GAB_BENCH_SHARE_GPU=1), not an N-GPU measurement" if ctx.get("share") else "")},
+                       "total_items": total, "items_per_gpu": round(total / world, 1), "sharding": sharding,
+                       "value_is": "value_hbm_resident (inputs already in HBM when the timed region starts; the drop-in ROI "
+                                   "incl. PCIe is extra.value_roi_incl_pcie)"},
             "roofline": wl.roofline(), "extra": wl.extra(ms), "parity": verdict,
         }
+        out["extra"]["value_hbm_resident"] = out["value"]
+        if per_rank:
+            out["extra"]["per_rank"] = per_rank
         km = out["extra"].get("dominant_kernel_ms")
-        t, detail = pmc_traffic(W.name, large, km)
+        t, detail = pmc_traffic(W.name, large and world == 1, km)
         if t is not None:
             out["roofline"]["traffic"] = t                  # GB/s of real HBM traffic, comparable with `achieved`
             out["roofline"]["traffic_detail"] = detail
         # BASELINE.md 3.5 also asks for the fraction of the MEASURED copy bandwidth (6.29 TB/s, MI355X_MICROARCH.md)
         if out["roofline"].get("unit") == "GB/s" and out["roofline"].get("achieved") is not None:
             out["roofline"]["frac_of_measured_copy_6290"] = round(out["roofline"]["achieved"] / 6290.0, 6)
-        if with_host and world == 1 and hasattr(wl, "host_roi") and not args.no_host_roi:
-            # what a drop-in driver times: host pointers in, host pointers out (PCIe both ways), never `value`
+        if with_host and world == 1 and callable(getattr(wl, "host_roi", None)) and not args.no_host_roi:
+            # SURVEY.md 8d's ROI -- what a drop-in driver times: host pointers in, host pointers out (PCIe both ways); never `value`
             try:
                 out["extra"]["roi_incl_pcie"] = wl.host_roi()
+                out["extra"]["value_roi_incl_pcie"] = out["extra"]["roi_incl_pcie"].get("value")
             except Exception as e:      # the figure is informative; a failure must not lose the measured line
                 out["extra"]["roi_incl_pcie"] = {"error": str(e)[:300]}
             mark("host-pointer ROI done")
@@ -1174,13 +1345,92 @@ def run_workload(W, items, steps, warmup, ctx, args, with_cpu=True, with_host=Tr
             out["cpu_baseline"] = None                     # timed at N = 1 only (the other ranks would wait for rank 0's host cores)
         if with_cpu and world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = wl.cpu_baseline(host_cores())
+            out["cpu_baseline"]["host_threads_visible"] = os.cpu_count()      # `cores` of these were used (cgroup quota)
             mark("cpu baseline done")
             cb, v = out["cpu_baseline"], out["value"]
             if cb.get("value"):
                 out["extra"]["x_cpu_baseline"] = round(v / world / cb["value"], 2)      # one GPU vs the host's cores
+                if out["extra"].get("value_roi_incl_pcie"):
+                    out["extra"]["x_cpu_baseline_roi_incl_pcie"] = round(out["extra"]["value_roi_incl_pcie"] / cb["value"], 2)
     del wl
     torch.cuda.empty_cache()
     return out
+
+
+# ---- output: one compact headline as the LAST line of stdout, one line per suite entry before it ------------------------
+HEADLINE_LIMIT = 4096
+
+
+def _cut(text, n):
+    text = str(text)
+    return text if len(text) <= n else text[:n - 3] + "..."
+
+
+def compact(r, note_chars=160):
+    """the fields of a result the driver's record needs, bounded in size (the full dict goes to bench_suite.json)"""
+    keep = {k: r.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                  "vs_baseline", "dtype") if k in r}
+    keep["data"] = "synthetic"
+    cfg = r.get("config") or {}
+    keep["config"] = {"workload": cfg.get("workload"), "total_items": cfg.get("total_items"), "items_per_gpu": cfg.get("items_per_gpu"),
+                      "sharding": _cut(cfg.get("sharding", ""), 150), "value_is": "value_hbm_resident"}
+    rf = r.get("roofline") or {}
+    keep["roofline"] = {k: rf.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")}
+    cb = r.get("cpu_baseline")
+    keep["cpu_baseline"] = None if not cb else {"value": cb.get("value"), "unit": cb.get("unit"), "cores": cb.get("cores"),
+                                                "host_threads_visible": cb.get("host_threads_visible"), "kind": cb.get("kind"),
+                                                "sample": _cut(cb.get("sample", ""), note_chars)}
+    keep["parity"] = _cut(r.get("parity"), 120) if r.get("parity") is not None else None
+    ex = r.get("extra") or {}
+    keep["extra"] = {k: ex[k] for k in ("dominant_kernel", "dominant_kernel_ms", "value_hbm_resident", "value_roi_incl_pcie",
+                                        "x_cpu_baseline", "x_cpu_baseline_roi_incl_pcie", "gcups") if ex.get(k) is not None}
+    if isinstance(keep["extra"].get("dominant_kernel"), str):
+        keep["extra"]["dominant_kernel"] = _cut(keep["extra"]["dominant_kernel"], 60)
+    if isinstance(keep["extra"].get("dominant_kernel_ms"), float):
+        keep["extra"]["dominant_kernel_ms"] = round(keep["extra"]["dominant_kernel_ms"], 4)
+    return keep
+
+
+def headline(out, suite):
+    """the LAST stdout line: the compact headline + one [value, unit, roofline frac, value incl. PCIe, x CPU] row per suite entry"""
+    h = compact(out)
+    if suite:
+        rows = {}
+        for name, r in suite.items():
+            if "value" in r:
+                ex = r.get("extra") or {}
+                rows[name] = [r["value"], r.get("unit"), (r.get("roofline") or {}).get("frac"), ex.get("value_roi_incl_pcie"),
+                              ex.get("x_cpu_baseline")]
+            else:
+                rows[name] = _cut(r.get("skipped") or r.get("error") or "?", 60)
+        h["extra"]["suite"] = rows
+        h["extra"]["suite_columns"] = ["value_hbm_resident", "unit", "roofline.frac", "value_roi_incl_pcie", "x_cpu_baseline"]
+        h["extra"]["suite_detail"] = "bench_suite.json + the {\"suite\": ...} lines above"
+    line = json.dumps(h, separators=(",", ":"))
+    if len(line) >= HEADLINE_LIMIT:                      # never again an unparseable record: shed the optional parts
+        for k in ("suite_detail", "suite_columns", "suite"):
+            h["extra"].pop(k, None)
+            line = json.dumps(h, separators=(",", ":"))
+            if len(line) < HEADLINE_LIMIT:
+                break
+    assert len(line) < HEADLINE_LIMIT, "headline does not fit"
+    return line
+
+
+def emit(out, suite, path=None):
+    """suite lines first, then the headline as the very last thing on stdout; the full detail to bench_suite.json"""
+    for name, r in (suite or {}).items():
+        row = {"suite": name}
+        row.update(compact(r) if "value" in r else r)
+        print(json.dumps(row, separators=(",", ":")), flush=True)
+    path = path or os.environ.get("GAB_BENCH_SUITE_JSON") or os.path.join(ROOT, "bench_suite.json")
+    try:
+        with open(path, "w") as f:
+            json.dump({"headline": out, "suite": suite or {}}, f, indent=1)
+    except OSError as e:
+        log(f"could not write {path}: {e}")
+    sys.stdout.flush()
+    print(headline(out, suite), flush=True)
 
 
 def main():
@@ -1189,8 +1439,12 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS),
-                    help="one workload only (default: bsw-large as the headline + the suite in extra.suite)")
-    ap.add_argument("--items", type=int, default=0, help="items per GPU per step (default: the large config)")
+                    help="one workload only (default: bsw-large as the headline + the suite, one line each)")
+    ap.add_argument("--items", type=int, default=0,
+                    help="size of the input (default: the large config): the whole input under strong scaling, per GPU under weak scaling")
+    ap.add_argument("--scaling", choices=("strong", "weak"), default="strong",
+                    help="with --gpus N > 1: strong = ONE large input split across the N GPUs (default, BASELINE.json configs[4]); "
+                         "weak = every GPU gets a full-size input of its own")
     ap.add_argument("--no-suite", action="store_true", help="headline only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-roi", action="store_true")
@@ -1214,8 +1468,10 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: libgab_hip has no CPU fallback")
-    # GAB_BENCH_SHARE_GPU=1 (tests only): the N ranks all use GPU 0 and rendezvous over gloo -- the N > 1 code path (id-range
-    # sharding, barrier, MAX / SUM aggregation) with real engine handles on a one-GPU box.  The line says so.
+    if world > 1:                                  # the host's cores are shared by the ranks (generators, oracle checks)
+        os.environ["OMP_NUM_THREADS"] = str(max(1, host_cores() // world))
+    # GAB_BENCH_SHARE_GPU=1 (tests only): the N ranks all use GPU 0 and rendezvous over gloo -- the N > 1 code path (sharding,
+    # barrier, MAX / SUM aggregation) with real engine handles on a one-GPU box.  The line says so.
     share = world > 1 and os.environ.get("GAB_BENCH_SHARE_GPU") == "1"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -1228,51 +1484,57 @@ def main():
     dev = torch.device("cuda", local_rank if world > 1 and not share else 0)
     torch.cuda.set_device(dev)
     ctx = {"rank": rank, "world": world, "dev": dev, "dist": dist, "agg_dev": None if share else dev, "share": share}
+    share_dir = None
+    if world > 1:                                  # a directory all ranks of this node see (rank 0's FM-index file)
+        base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else tempfile.gettempdir()
+        share_dir = os.path.join(base, f"gab_bench_{os.environ.get('MASTER_PORT', '0')}_{os.getuid()}")
+        os.makedirs(share_dir, exist_ok=True)
+    _CTX.update(rank=rank, world=world, dist=dist, share_dir=share_dir)
     t_start = time.time()
 
-    W = WORKLOADS[args.workload or "bsw"]
-    out = run_workload(W, args.items or W.default_items, args.steps, args.warmup, ctx, args)
+    try:
+        W = WORKLOADS[args.workload or "bsw"]
+        out = run_workload(W, args.items or W.default_items, args.steps, args.warmup, ctx, args)
 
-    if args.workload is None and not args.items and not args.no_suite:
         suite = {}
-        for name, wname, items, steps in SUITE:
-            go = [time.time() - t_start < SUITE_BUDGET_S]
-            if world > 1:
-                dist.broadcast_object_list(go, src=0)           # every rank takes the same branch
-            if not go[0]:
-                suite[name] = {"skipped": f"time budget of {SUITE_BUDGET_S:.0f} s reached (GAB_BENCH_BUDGET_S); run --workload {wname}"}
-                continue
-            if world > 1 and wname.startswith("fmi") and not os.environ.get("GAB_BENCH_SUITE_FMI"):
-                # every rank would build its own 256 Mbp index on the shared host cores (minutes with 8 ranks): not inside a scaling run
-                suite[name] = {"skipped": f"runs at --gpus 1 (the index is built per rank on the host); GAB_BENCH_SUITE_FMI=1 or --workload {wname}"}
-                continue
-            SW = WORKLOADS[wname]
-            t0 = time.time()
-            try:
-                r = run_workload(SW, items or SW.default_items, min(steps, max(args.steps, 1)), 1, ctx, args,
-                                 with_host=items is None)
-            except Exception as e:
+        if args.workload is None and not args.items and not args.no_suite:
+            for name, wname, items, steps in SUITE:
+                go = [time.time() - t_start < SUITE_BUDGET_S]
                 if world > 1:
-                    raise
-                log(f"suite entry {name} failed: {e}")
-                suite[name] = {"error": str(e)[:300]}
-                continue
-            if r is not None:
-                keep = {k: r[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "dtype", "config", "roofline", "parity") if k in r}
-                keep["cpu_baseline"] = r.get("cpu_baseline")
-                keep["extra"] = r.get("extra")
-                keep["wall_s"] = round(time.time() - t0, 1)
-                suite[name] = keep
-                log(f"suite: {name}: {r['value']} {r['unit']} ({keep['wall_s']} s)")
-        if out is not None:
-            out["extra"]["suite"] = suite
-            out["extra"]["suite_note"] = ("one entry per configuration of BASELINE.json's metric besides the headline, same contract "
-                                          "(value = whole-job throughput with inputs resident in HBM, max over ranks)")
-    if rank == 0:
-        print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+                    dist.broadcast_object_list(go, src=0)           # every rank takes the same branch
+                if not go[0]:
+                    suite[name] = {"skipped": f"time budget of {SUITE_BUDGET_S:.0f} s reached (GAB_BENCH_BUDGET_S); run --workload {wname}"}
+                    continue
+                if world > 1 and items is not None:
+                    suite[name] = {"skipped": "small inputs run at --gpus 1 (they do not fill one GPU)"}
+                    continue
+                SW = WORKLOADS[wname]
+                t0 = time.time()
+                try:
+                    r = run_workload(SW, items or SW.default_items, min(steps, max(args.steps, 1)), 1, ctx, args,
+                                     with_host=items is None)
+                except Exception as e:
+                    if world > 1:
+                        raise
+                    log(f"suite entry {name} failed: {e}")
+                    suite[name] = {"error": str(e)[:300]}
+                    continue
+                if r is not None:
+                    r["wall_s"] = round(time.time() - t0, 1)
+                    suite[name] = r
+                    log(f"suite: {name}: {r['value']} {r['unit']} ({r['wall_s']} s)")
+        if rank == 0:
+            emit(out, suite)
+    finally:
+        if world > 1:
+            try:
+                dist.barrier()
+                dist.destroy_process_group()
+            except Exception:       # noqa: BLE001 -- a failed rank must not hide the first error behind a barrier time-out
+                pass
+            if rank == 0 and share_dir:
+                import shutil
+                shutil.rmtree(share_dir, ignore_errors=True)
 
 
 if __name__ == "__main__":

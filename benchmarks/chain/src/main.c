@@ -189,7 +189,7 @@ int main(int argc, char **argv) {
     }
     gab_pin(x, 8 * na); gab_pin(y, 8 * na); gab_pin(ctx.score, 4 * na); gab_pin(ctx.parent, 4 * na);
     gab_queue q;
-    gab_queue_open(&q, ngpus, gpu_init, run_chunk, gpu_fini, &ctx);
+    gab_queue_open(&q, ngpus, nchunks, gpu_init, run_chunk, gpu_fini, &ctx);
 
     /* ---- region of interest (main.cpp:111-193) ---- */
     const double t0 = gab_now();

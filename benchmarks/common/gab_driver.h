@@ -186,8 +186,12 @@ static void *gab_worker_main(void *p) {
 /* init/fini run outside the caller's timed region if the caller times only gab_queue_run */
 typedef struct { int ngpus, nworkers; gab_worker *w; pthread_mutex_t mu; int64_t cursor; } gab_queue;
 static inline int gab_workers_per_gpu(void) { return (int)gab_env_i64("GAB_WORKERS_PER_GPU", 3); }
-static inline void gab_queue_open(gab_queue *q, int ngpus, gab_gpu_init_fn init, gab_chunk_fn run, gab_gpu_fini_fn fini, void *ctx) {
+/* nchunks = the chunks gab_queue_run will be given: no more workers than that are started (every worker's init reserves
+ * device buffers for a whole chunk; with one chunk on one GPU two of the default three would hold theirs for nothing) */
+static inline void gab_queue_open(gab_queue *q, int ngpus, int64_t nchunks, gab_gpu_init_fn init, gab_chunk_fn run, gab_gpu_fini_fn fini, void *ctx) {
     q->ngpus = ngpus; q->nworkers = ngpus * gab_workers_per_gpu(); q->cursor = 0;
+    if (nchunks < 1) nchunks = 1;
+    if ((int64_t)q->nworkers > nchunks) q->nworkers = (int)nchunks;
     pthread_mutex_init(&q->mu, NULL);
     q->w = (gab_worker *)calloc((size_t)q->nworkers, sizeof(gab_worker));
     for (int k = 0; k < q->nworkers; k++) {

@@ -7,9 +7,13 @@
  * fmi/scripts/regression_small.sh:91,97-98).  <ref_prefix>.bwt.2bit.64 is BWA-MEM2's own index file; it is
  * loaded and replicated on every GPU before the ROI, as load_index precedes begin_computing in the reference.
  * The per-batch ROI body (getSMEMsAllPos -> re-seed -> bwtSeedStrategy -> sortSMEMs, fmi.cpp:288-348) becomes
- * gab_fmi_seed on chunks of reads ($GAB_CHUNK, default 2^20) pulled by $GAB_WORKERS_PER_GPU host threads per GPU
+ * gab_fmi_seed_into on chunks of reads ($GAB_CHUNK, default 2^20) pulled by $GAB_WORKERS_PER_GPU host threads per GPU
  * (default 3; the workers of a GPU share one copy of the index); batch_size and n_threads only shaped the CPU
  * scheduling and are accepted and ignored.
+ * Every worker collects its SMEMs in an array of its own sized like the reference's per-thread matchArray (20 records per
+ * read of its share, fmi.cpp:243,254-255) and, like it, takes more room when a chunk does not fit (:277-286) -- here the
+ * array is page-locked, so it is made with the handle before the ROI (the reference's malloc inside the ROI costs nothing
+ * until the pages are written; page-locking populates them) and the records arrive by DMA at the link rate.
  */
 #define GAB_ENERGY_STREAM stderr      /* where the reference prints "Energy consumption:" in this driver */
 #include "../common/gab_driver.h"
@@ -20,31 +24,47 @@
 typedef struct {
     const char *prefix; const uint8_t *enc; int32_t stride; const int32_t *len; int64_t n, chunk; int32_t msl;
     gab_smem **out; int64_t *nout;      /* per chunk */
+    char *own;                          /* per chunk: out[chunk] is a block of its own (gab_fmi_seed) rather than part of an arena */
     gab_fmi *owner[MAX_GPUS];           /* the handle that owns the index of each GPU; further workers clone it */
+    int64_t arena_records;              /* SMEM records of a worker's array */
 } fmi_ctx;
+typedef struct { gab_fmi *h; gab_smem *arena; int64_t cap, used; } fmi_worker;
 /* the index is loaded ONCE per GPU and shared by that GPU's workers, as the reference's threads share one FMI_search */
 static void *gpu_init(int worker, int gpu, void *vc) {
     (void)worker;
     fmi_ctx *c = (fmi_ctx *)vc;
-    gab_fmi *h = NULL;
-    if (gpu < MAX_GPUS && c->owner[gpu]) { GAB_DIE_IF(gab_fmi_clone(c->owner[gpu], &h), "gab_fmi_clone"); return h; }
-    GAB_DIE_IF(gab_fmi_load(gpu, c->prefix, &h), "gab_fmi_load");
-    if (gpu < MAX_GPUS) c->owner[gpu] = h;
-    return h;
+    fmi_worker *w = (fmi_worker *)calloc(1, sizeof(fmi_worker));
+    if (gpu < MAX_GPUS && c->owner[gpu]) GAB_DIE_IF(gab_fmi_clone(c->owner[gpu], &w->h), "gab_fmi_clone");
+    else {
+        GAB_DIE_IF(gab_fmi_load(gpu, c->prefix, &w->h), "gab_fmi_load");
+        if (gpu < MAX_GPUS) c->owner[gpu] = w->h;
+    }
+    w->cap = c->arena_records;
+    void *a = NULL;
+    if (gab_env_i64("GAB_NO_PIN", 0) || gab_host_alloc((size_t)w->cap * sizeof(gab_smem), &a) != 0) a = malloc((size_t)w->cap * sizeof(gab_smem));
+    if (!a) { fprintf(stderr, "ERROR: out of memory\n"); exit(EXIT_FAILURE); }
+    w->arena = (gab_smem *)a;
+    return w;
 }
 /* clones go first (workers are closed in index order and the owners are the first ngpus workers): defer the owners */
 static void gpu_fini(int worker, int gpu, void *vc, void *st) {
     (void)worker;
     fmi_ctx *c = (fmi_ctx *)vc;
-    if (gpu < MAX_GPUS && c->owner[gpu] == (gab_fmi *)st) return;       /* destroyed after the queue is closed */
-    gab_fmi_destroy((gab_fmi *)st);
+    fmi_worker *w = (fmi_worker *)st;           /* (the arenas hold the results: they are released after printing) */
+    if (!(gpu < MAX_GPUS && c->owner[gpu] == w->h)) gab_fmi_destroy(w->h);       /* the owners: after the queue is closed */
 }
 static void run_chunk(int worker, int gpu, int64_t chunk, void *vctx, void *st) {
     (void)gpu; (void)worker;
     fmi_ctx *c = (fmi_ctx *)vctx;
+    fmi_worker *w = (fmi_worker *)st;
     const int64_t b = chunk * c->chunk, e = b + c->chunk < c->n ? b + c->chunk : c->n;
-    GAB_DIE_IF(gab_fmi_seed((gab_fmi *)st, c->enc + b * c->stride, c->stride, c->len + b, e - b, c->msl, &c->out[chunk],
-                            &c->nout[chunk]), "gab_fmi_seed");
+    int rc = gab_fmi_seed_into(w->h, c->enc + b * c->stride, c->stride, c->len + b, e - b, c->msl, w->arena + w->used, w->cap - w->used,
+                               &c->nout[chunk]);
+    if (rc == 0) { c->out[chunk] = w->arena + w->used; w->used += c->nout[chunk]; }
+    else if (rc == GAB_ERANGE) {                 /* the array is full (the reference reallocs, fmi.cpp:277-286): a block for this chunk */
+        GAB_DIE_IF(gab_fmi_seed(w->h, c->enc + b * c->stride, c->stride, c->len + b, e - b, c->msl, &c->out[chunk], &c->nout[chunk]), "gab_fmi_seed");
+        c->own[chunk] = 1;
+    } else GAB_DIE_IF(rc, "gab_fmi_seed_into");
     for (int64_t i = 0; i < c->nout[chunk]; i++) c->out[chunk][i].rid += (uint32_t)b;      /* rid += batch offset, fmi.cpp:340-343 */
 }
 int main(int argc, char **argv) {
@@ -103,8 +123,16 @@ int main(int argc, char **argv) {
     const int64_t nchunks = (n + ctx.chunk - 1) / ctx.chunk;
     gab_pin(enc, (size_t)n * (size_t)max_rl); gab_pin(len, 4 * (size_t)n);
     ctx.out = (gab_smem **)calloc((size_t)nchunks, sizeof(gab_smem *)); ctx.nout = (int64_t *)calloc((size_t)nchunks, 8);
+    ctx.own = (char *)calloc((size_t)nchunks + 1, 1);
+    {   /* perThreadQuota * 20 (fmi.cpp:243,254): a worker's share of the reads, whole chunks, 20 records per read */
+        int64_t workers = (int64_t)ngpus * gab_workers_per_gpu();
+        if (workers > nchunks) workers = nchunks > 0 ? nchunks : 1;
+        const int64_t share = ((nchunks + workers - 1) / workers) * ctx.chunk;
+        ctx.arena_records = 20 * (share < n ? share : n) + 1024;
+        if (gab_env_i64("GAB_FMI_ARENA", 0)) ctx.arena_records = gab_env_i64("GAB_FMI_ARENA", 0);      /* tests: force the overflow path */
+    }
     gab_queue q;
-    gab_queue_open(&q, ngpus, gpu_init, run_chunk, gpu_fini, &ctx);       /* index load: before the ROI (fmi.cpp:102-105) */
+    gab_queue_open(&q, ngpus, nchunks, gpu_init, run_chunk, gpu_fini, &ctx);       /* index load: before the ROI (fmi.cpp:102-105) */
     const double tr1 = gab_now();
     printf("numReads = %ld, max_readlength = %d, min_readlength = %d\n", (long)n, max_rl, min_rl);
     printf("Running %d threads\n", atoi(argv[5]));
@@ -113,6 +141,9 @@ int main(int argc, char **argv) {
     gab_queue_run(&q, nchunks);
     gab_roi_end();
     const double t1 = gab_now();
+    fmi_worker **ws = (fmi_worker **)calloc((size_t)q.nworkers, sizeof(fmi_worker *));
+    const int nws = q.nworkers;
+    for (int k = 0; k < nws; k++) ws[k] = (fmi_worker *)q.w[k].state;
     gab_queue_close(&q);
     for (int g = 0; g < MAX_GPUS; g++) if (ctx.owner[g]) gab_fmi_destroy(ctx.owner[g]);
     gab_unpin(enc); gab_unpin(len);
@@ -129,7 +160,9 @@ int main(int argc, char **argv) {
             prevRid = (int64_t)s.rid;
             printf("[%u,%u]\n", s.m, s.n + 1);
         }
-    for (int64_t c = 0; c < nchunks; c++) gab_fmi_free(ctx.out[c]);
+    for (int64_t c = 0; c < nchunks; c++) if (ctx.own[c]) gab_fmi_free(ctx.out[c]);
+    for (int k = 0; k < nws; k++) { gab_host_free(ws[k]->arena); free(ws[k]); }
+    free(ws); free(ctx.own);
     free(ctx.out); free(ctx.nout); free(enc); free(seqs); free(soff); free(len);
     return 0;
 }

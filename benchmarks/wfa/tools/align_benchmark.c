@@ -7,14 +7,22 @@
  * harness sorts by id, wfa/scripts/regression_small.sh:94); stdout "Total.reads:", "Time.Benchmark:",
  * "Time.Alignment:" (align_benchmark.c:529-533).  --minimum-wavefront-length >= 0 selects the adaptive
  * reduction (align_benchmark.c:359-368), otherwise the complete mode.
- * The per-pair ROI call affine_wavefronts_align (align_benchmark.c:415-437) becomes gab_wfa_run on chunks.
+ * The per-pair ROI call affine_wavefronts_align (align_benchmark.c:415-437) becomes gab_wfa_run_packed on chunks: the driver
+ * only ever PRINTS the alignments, so the text edit_cigar_print would write is produced on the device and ~20 bytes per
+ * 151-bp pair come back instead of the 302 bytes of operation room (GAB_WFA_UNPACKED=1: gab_wfa_run + encoding on the host).
  */
 #include "../../common/gab_pairs.h"
 #include <getopt.h>
 #include <sys/time.h>
 
 #define CHUNK_PAIRS (1 << 18)   /* default chunk of the work queue; $GAB_CHUNK overrides it */
-typedef struct { const gab_pairs *p; int64_t chunk; gab_wfa_penalties pen; int min_wavefront_length, max_distance_threshold; char *ops; int64_t *ops_off; int32_t *ops_len, *score; int64_t max_seq_bytes, max_ops_bytes; } wfa_ctx;
+typedef struct {
+    const gab_pairs *p; int64_t chunk; gab_wfa_penalties pen; int min_wavefront_length, max_distance_threshold;
+    char *ops; int64_t *ops_off; int32_t *ops_len, *score; int64_t max_seq_bytes, max_ops_bytes;
+    /* packed mode: chunk c writes its CIGAR text into cig + cig_beg[c] (room cig_beg[c + 1] - cig_beg[c]); pair i's text is
+     * cig_base[its chunk] + ops_off[i], ops_len[i] bytes; a chunk whose text outgrew its room gets a block of its own */
+    int packed; char *cig; int64_t *cig_beg; char **cig_base;
+} wfa_ctx;
 static void *gpu_init(int worker, int gpu, void *vc) {
     (void)worker;
     wfa_ctx *c = (wfa_ctx *)vc; gab_wfa *h = NULL;
@@ -28,6 +36,20 @@ static void run_chunk(int worker, int gpu, int64_t chunk, void *vctx, void *st) 
     (void)gpu; (void)worker;
     wfa_ctx *c = (wfa_ctx *)vctx;
     const int64_t b = chunk * c->chunk, e = b + c->chunk < c->p->n ? b + c->chunk : c->p->n;
+    if (c->packed) {
+        int64_t need = 0;
+        c->cig_base[chunk] = c->cig + c->cig_beg[chunk];
+        int rc = gab_wfa_run_packed((gab_wfa *)st, c->p->slab, c->p->off1 + b, c->p->len1 + b, c->p->slab, c->p->off2 + b, c->p->len2 + b, e - b,
+                                    c->cig_base[chunk], c->cig_beg[chunk + 1] - c->cig_beg[chunk], c->ops_off + b, c->ops_len + b, c->score + b, &need);
+        if (rc == GAB_ERANGE) {          /* more text than a quarter of the operation room (very divergent pairs): a block of its own */
+            c->cig_base[chunk] = (char *)malloc((size_t)need + 1);
+            if (!c->cig_base[chunk]) { fprintf(stderr, "ERROR: out of memory\n"); exit(EXIT_FAILURE); }
+            rc = gab_wfa_run_packed((gab_wfa *)st, c->p->slab, c->p->off1 + b, c->p->len1 + b, c->p->slab, c->p->off2 + b, c->p->len2 + b, e - b,
+                                    c->cig_base[chunk], need, c->ops_off + b, c->ops_len + b, c->score + b, &need);
+        }
+        GAB_DIE_IF(rc, "gab_wfa_run_packed");
+        return;
+    }
     GAB_DIE_IF(gab_wfa_run((gab_wfa *)st, c->p->slab, c->p->off1 + b, c->p->len1 + b, c->p->slab, c->p->off2 + b, c->p->len2 + b,
                            e - b, c->ops, c->ops_off + b, c->ops_len + b, c->score + b), "gab_wfa_run");
 }
@@ -127,50 +149,67 @@ int main(int argc, char **argv) {
     gab_pairs_read(in, &p);
     fclose(in);
     ctx.p = &p;
+    ctx.packed = !gab_env_i64("GAB_WFA_UNPACKED", 0);
     ctx.ops_off = (int64_t *)malloc(8 * (size_t)p.n + 8);
     ctx.ops_len = (int32_t *)malloc(4 * (size_t)p.n + 4); ctx.score = (int32_t *)malloc(4 * (size_t)p.n + 4);
     int64_t tot = 0;
     for (int64_t i = 0; i < p.n; i++) { ctx.ops_off[i] = tot; tot += (int64_t)p.len1[i] + p.len2[i]; }
-    ctx.ops = (char *)malloc((size_t)tot + 16);
     const int ngpus = gab_pick_gpus(gpus);
     ctx.chunk = gab_env_i64("GAB_CHUNK", CHUNK_PAIRS);
+    const int64_t nchunks = (p.n + ctx.chunk - 1) / ctx.chunk;
+    ctx.cig_beg = (int64_t *)calloc((size_t)nchunks + 1, 8); ctx.cig_base = (char **)calloc((size_t)nchunks + 1, sizeof(char *));
     ctx.max_seq_bytes = ctx.max_ops_bytes = 0;       /* the widest chunk: what gpu_init reserves for */
-    for (int64_t b = 0; b < p.n; b += ctx.chunk) {
+    for (int64_t b = 0, k = 0; b < p.n; b += ctx.chunk, k++) {
         const int64_t e = b + ctx.chunk < p.n ? b + ctx.chunk : p.n;
         const int64_t lo = p.off1[b] < p.off2[b] ? p.off1[b] : p.off2[b];
         const int64_t h1 = p.off1[e - 1] + p.len1[e - 1], h2 = p.off2[e - 1] + p.len2[e - 1], hi = h1 > h2 ? h1 : h2;
-        const int64_t ops = ctx.ops_off[e - 1] + p.len1[e - 1] + p.len2[e - 1] - ctx.ops_off[b];
+        int64_t ops = ctx.ops_off[e - 1] + p.len1[e - 1] + p.len2[e - 1] - ctx.ops_off[b];
+        /* text room of the chunk: a quarter of its operation room (a 151-bp read pair at 2 % needs ~20 of its 302 bytes) */
+        ctx.cig_beg[k + 1] = ctx.cig_beg[k] + ((ops / 4 + 4096 + 255) & ~(int64_t)255);
+        if (ctx.packed) {                            /* on the device: fixed-stride operation room + the text */
+            int64_t stride = 0;
+            for (int64_t i = b; i < e; i++) if ((int64_t)p.len1[i] + p.len2[i] > stride) stride = (int64_t)p.len1[i] + p.len2[i];
+            ops = ((stride + 7) & ~(int64_t)7) * (e - b) + (ctx.cig_beg[k + 1] - ctx.cig_beg[k]);
+        }
         if (hi - lo + 512 > ctx.max_seq_bytes) ctx.max_seq_bytes = hi - lo + 512;
         if (ops + 512 > ctx.max_ops_bytes) ctx.max_ops_bytes = ops + 512;
     }
+    if (ctx.packed) { ctx.ops = NULL; ctx.cig = (char *)malloc((size_t)ctx.cig_beg[nchunks] + 16); }
+    else { ctx.cig = NULL; ctx.ops = (char *)malloc((size_t)tot + 16); }
+    if (!ctx.cig && !ctx.ops) { fprintf(stderr, "ERROR: out of memory\n"); exit(EXIT_FAILURE); }
     gab_pin(p.slab, p.used); gab_pin(p.off1, 8 * (size_t)p.n); gab_pin(p.off2, 8 * (size_t)p.n); gab_pin(p.len1, 4 * (size_t)p.n);
-    gab_pin(p.len2, 4 * (size_t)p.n); gab_pin(ctx.ops, (size_t)tot + 16); gab_pin(ctx.ops_off, 8 * (size_t)p.n);
+    gab_pin(p.len2, 4 * (size_t)p.n); gab_pin(ctx.ops_off, 8 * (size_t)p.n);
+    if (ctx.packed) gab_pin(ctx.cig, (size_t)ctx.cig_beg[nchunks] + 16); else gab_pin(ctx.ops, (size_t)tot + 16);
     gab_pin(ctx.ops_len, 4 * (size_t)p.n); gab_pin(ctx.score, 4 * (size_t)p.n);
     gab_queue q;
-    gab_queue_open(&q, ngpus, gpu_init, run_chunk, gpu_fini, &ctx);
+    gab_queue_open(&q, ngpus, nchunks, gpu_init, run_chunk, gpu_fini, &ctx);
     const double t0 = tv_now();                  /* ROI: align_benchmark.c:378-491 */
     gab_roi_begin_n(ngpus);
-    gab_queue_run(&q, (p.n + ctx.chunk - 1) / ctx.chunk);
+    gab_queue_run(&q, nchunks);
     gab_roi_end();
     const double t1 = tv_now();
     gab_queue_close(&q);
-    gab_unpin(p.slab); gab_unpin(p.off1); gab_unpin(p.off2); gab_unpin(p.len1); gab_unpin(p.len2); gab_unpin(ctx.ops);
+    gab_unpin(p.slab); gab_unpin(p.off1); gab_unpin(p.off2); gab_unpin(p.len1); gab_unpin(p.len2); gab_unpin(ctx.packed ? ctx.cig : ctx.ops);
     gab_unpin(ctx.ops_off); gab_unpin(ctx.ops_len); gab_unpin(ctx.score);
     if (out) {
         for (int64_t i = 0; i < p.n; i++) {
             fprintf(out, "id=%ld ", (long)i);
-            const char *o = ctx.ops + ctx.ops_off[i];
             const int n = ctx.ops_len[i];
             /* edit_cigar_print reads operations[begin] even when the CIGAR is empty; an empty pair prints nothing here */
-            for (int k = 0; k < n;) { int r = k; while (r < n && o[r] == o[k]) r++; fprintf(out, "%d%c", r - k, o[k]); k = r; }
+            if (ctx.packed) fwrite(ctx.cig_base[i / ctx.chunk] + ctx.ops_off[i], 1, (size_t)n, out);       /* already the printed text */
+            else {
+                const char *o = ctx.ops + ctx.ops_off[i];
+                for (int k = 0; k < n;) { int r = k; while (r < n && o[r] == o[k]) r++; fprintf(out, "%d%c", r - k, o[k]); k = r; }
+            }
             fprintf(out, "\n");
         }
         fclose(out);
     }
+    for (int64_t k = 0; k < nchunks; k++) if (ctx.packed && ctx.cig_base[k] && ctx.cig_base[k] != ctx.cig + ctx.cig_beg[k]) free(ctx.cig_base[k]);
     printf("Total.reads: %ld\n", (long)p.n);
     printf("Time.Benchmark: %f s\n", tv_now() - bench0);
     printf("Time.Alignment: %f s\n", t1 - t0);
-    free(ctx.ops); free(ctx.ops_off); free(ctx.ops_len); free(ctx.score);
+    free(ctx.ops); free(ctx.cig); free(ctx.cig_beg); free(ctx.cig_base); free(ctx.ops_off); free(ctx.ops_len); free(ctx.score);
     gab_pairs_free(&p);
     return 0;
 }

@@ -594,6 +594,19 @@ constexpr int kFcHelpers = 3;
 // where another kernel writes them while this one waits
 template <bool FED> struct AnchorPtr { using type = const uint64_t *__restrict__; };
 template <> struct AnchorPtr<true> { using type = const uint64_t *; };
+// ... and how they are READ.  In the fed variant the anchors were written by ANOTHER kernel that is still running
+// (chain_gather_kernel, relaxed agent-scope stores + the per-call facts word).  The wait orders the two only at workgroup
+// scope (an agent-scope acquire costs the whole L2 of the XCD, see chain_feed_wait), so the data accesses themselves must
+// be coherent at agent scope: every read of x / y in the fed kernels is a relaxed agent-scope atomic load (sc1 on gfx950: it
+// is served from the device's coherence point, never from a stale line of this XCD's L2 or this CU's L1), which pairs
+// with the gather kernel's write-through stores.  The plain variant keeps ordinary loads.
+template <bool FED> struct AnchorView {
+    const uint64_t *p;
+    __device__ __forceinline__ uint64_t operator[](int64_t i) const {
+        if (FED) return __hip_atomic_load(p + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return p[i];
+    }
+};
 constexpr int kGapTab = 2048;             // entries of the per-call gap-cost table (LDS, int32): bw + 2 of them are used
 template <int H, bool FED>
 __device__ __forceinline__ void fastchain_body(const ChainWork *__restrict__ work, typename AnchorPtr<FED>::type xs,
@@ -604,7 +617,7 @@ __device__ __forceinline__ void fastchain_body(const ChainWork *__restrict__ wor
     if (FED && chain_feed_wait(feed, &feed_word) == 0) return;
     const ChainWork w = work[blockIdx.x];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave index: uniform, say so
-    const uint64_t *X = xs + w.off, *Y = ys + w.off;
+    const AnchorView<FED> X{xs + w.off}, Y{ys + w.off};
     int32_t *S = score_out + w.off, *P = parent_out + w.off;
     const int64_t n = w.n;
     const int32_t mdx = w.max_dist_x, mdy = w.max_dist_y, bw = w.bw;
@@ -892,7 +905,8 @@ __device__ __forceinline__ int32_t chain_geometry_plain(uint32_t xa_lo, int32_t 
 // the reference's scan of ONE anchor, by one whole wave, everything from global memory (x, y input; score, parent of
 // the predecessors as stored so far; marks in the per-anchor global array with tag i + 1).  Same three parallel steps as
 // the exact path of chain_hw_kernel.  Returns (best, best_j absolute) in all lanes; `evals` counts the visited items.
-__device__ __forceinline__ void chain_exact_global(const uint64_t *X, const uint64_t *Y, const int32_t *S, const int32_t *P, int32_t *GM,
+template <class Anchors>
+__device__ __forceinline__ void chain_exact_global(const Anchors X, const Anchors Y, const int32_t *S, const int32_t *P, int32_t *GM,
                                                    int i, int st, int32_t mdx, int32_t mdy, int32_t bw, bool multi_seg, double avg_d,
                                                    int32_t &best_out, int32_t &bestj_out, unsigned long long &evals) {
     const int lane = threadIdx.x & 63;
@@ -992,7 +1006,7 @@ __device__ __forceinline__ void chain_block_body(const ChainWork *__restrict__ w
     if (FED && feed.dbg && threadIdx.x == 0) feed.dbg[3 * blockIdx.x + 1] = wall_clock64();
     const ChainWork w = work[blockIdx.x];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const uint64_t *X = xs + w.off, *Y = ys + w.off;
+    const AnchorView<FED> X{xs + w.off}, Y{ys + w.off};
     int32_t *S = score_out + w.off, *P = parent_out + w.off, *GM = gmarks_all + w.off;
     const int n = (int)w.n;                                  // < 2^31 (checked by the host)
     const int32_t mdx = w.max_dist_x, mdy = w.max_dist_y, bw = w.bw;
@@ -1621,7 +1635,12 @@ static int chain_run_fed(gab_chain *h, int mode, const uint64_t *x, const uint64
             (void)hipFree(d_dbg);
         }
     }
-    GAB_CHECK(((uint32_t *)h->h_evals)[4] == 0, "gab_chain_run: the DP kernel gave up waiting for its anchors");
+    if (((uint32_t *)h->h_evals)[4] != 0) {
+        // a wait gave up (seconds without its anchors: a stalled bus, a pre-empted gather kernel).  Every waiting workgroup
+        // has left, the grid has drained, nothing was lost but time: the caller takes the copy-engine path instead.
+        fprintf(stderr, "[gab_chain_run] note: the fed DP kernel gave up waiting for its anchors; re-running the batch through the copy engines\n");
+        return 2;
+    }
     h->have_stats = true;
     return GAB_OK;
 }
@@ -1652,7 +1671,7 @@ extern "C" int gab_chain_run(gab_chain *h, int mode, const uint64_t *x, const ui
     if (total >= big && (ncalls >= 1024 || getenv("GAB_CHAIN_FEED_MIN")) && ncalls < (1ll << 31) && !getenv("GAB_CHAIN_NO_OVERLAP")) {
         if (!getenv("GAB_CHAIN_NO_FEED") && !(getenv("GAB_CHAIN_KERNEL") && !strcmp(getenv("GAB_CHAIN_KERNEL"), "walk"))) {
             rc = chain_run_fed(h, mode, x, y, call_off, hdr, ncalls, total, score_out, parent_out, s);
-            if (rc != 1) return rc;               // 1: the arrays are not page-locked
+            if (rc != 1 && rc != 2) return rc;    // 1: the arrays are not page-locked; 2: the fed kernel gave up waiting
         }
         return chain_run_overlapped(h, mode, x, y, call_off, hdr, ncalls, total, score_out, parent_out, s);
     }

@@ -1101,6 +1101,49 @@ extern "C" int gab_fmi_seed(gab_fmi *h, const uint8_t *enc, int32_t stride, cons
 
 extern "C" void gab_fmi_free(gab_smem *p) { free(p); }
 
+// The reference's worker threads write their SMEMs into per-thread arrays allocated before the ROI (fmi/fmi.cpp:236-247)
+// and grow them when a batch does not fit (:277-286); this is the same contract with the caller's buffer, which may be
+// page-locked (gab_host_alloc / gab_host_register) so that the result comes back as one DMA at the full link rate.
+extern "C" int gab_fmi_seed_into(gab_fmi *h, const uint8_t *enc, int32_t stride, const int32_t *len, int64_t nreads,
+                                 int32_t min_seed_len, gab_smem *out, int64_t capacity, int64_t *nout) {
+    GAB_CHECK(h, "gab_fmi_seed_into: NULL handle");
+    GAB_CHECK(nout, "gab_fmi_seed_into: NULL output argument");
+    *nout = 0;
+    GAB_CHECK(capacity >= 0 && (out || capacity == 0), "gab_fmi_seed_into: NULL buffer with a capacity");
+    GAB_CHECK(nreads >= 0 && nreads < (1ll << 31), "gab_fmi_seed_into: nreads out of range");
+    if (nreads == 0) return GAB_OK;
+    GAB_CHECK(enc && len && stride > 0, "gab_fmi_seed_into: NULL buffer");
+    gab_device_guard g(h->device);
+    const size_t eb = (size_t)nreads * (size_t)stride;
+    const size_t o_len = (eb + 255) & ~(size_t)255;
+    int rc = h->io.reserve(o_len + 4 * (size_t)nreads);
+    if (rc) return rc;
+    hipStream_t s = nullptr;
+    if ((rc = h->hs.get(&s)) != GAB_OK) return rc;
+    char *b = h->io.as<char>();
+    {
+        std::lock_guard<std::mutex> gate(gab_h2d_mutex(h->device));
+        GAB_HIP(hipMemcpyAsync(b, enc, eb, hipMemcpyHostToDevice, s));
+        GAB_HIP(hipMemcpyAsync(b + o_len, len, 4 * (size_t)nreads, hipMemcpyHostToDevice, s));
+        GAB_HIP(hipStreamSynchronize(s));
+    }
+    const gab_smem *d_out = nullptr;
+    int64_t n = 0;
+    rc = gab_fmi_seed_device(h, (const uint8_t *)b, stride, (const int32_t *)(b + o_len), nreads, min_seed_len, &d_out,
+                             nullptr, &n, s);
+    if (rc) return rc;
+    *nout = n;
+    if (n > capacity) {
+        gab_set_error("gab_fmi_seed_into: %lld SMEMs do not fit the caller's %lld records", (long long)n, (long long)capacity);
+        return GAB_ERANGE;
+    }
+    if (n) {
+        GAB_HIP(hipMemcpyAsync(out, d_out, sizeof(gab_smem) * (size_t)n, hipMemcpyDeviceToHost, s));
+        GAB_HIP(hipStreamSynchronize(s));
+    }
+    return GAB_OK;
+}
+
 extern "C" int gab_fmi_last_stats(gab_fmi *h, int64_t *ext_calls, int64_t *nsmem, float *kernel_ms) {
     GAB_CHECK(h, "gab_fmi_last_stats: NULL handle");
     GAB_CHECK(h->have_stats, "gab_fmi_last_stats: no completed run on this handle");

@@ -3,6 +3,7 @@
 #include <string.h>
 #include <stdlib.h>
 #include <mutex>
+#include <unordered_set>
 
 static thread_local char g_err[512] = "";
 
@@ -38,11 +39,10 @@ int gab_check_device(int device) {
         return GAB_EDEVICE;
     }
     if (const char *e = getenv("GAB_HIP_SCHEDULE")) {          // experiment knob: spin | yield | blocking (before the context exists)
-        static bool done = false;
-        if (!done) {
-            done = true;
+        static std::once_flag once;                            // the drivers create their handles from several threads
+        std::call_once(once, [e] {
             (void)hipSetDeviceFlags(!strcmp(e, "spin") ? hipDeviceScheduleSpin : !strcmp(e, "yield") ? hipDeviceScheduleYield : hipDeviceScheduleBlockingSync);
-        }
+        });
     }
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
         gab_set_error("device %d is %s; this library is built for gfx950 only", device, prop.gcnArchName);
@@ -79,18 +79,33 @@ extern "C" int gab_device_copy_to_host(int device, void *dst, const void *d_src,
 // memory the runtime stages every copy through its own bounce buffer at a fraction of the link rate.  A caller that
 // allocates its slabs here (where the reference drivers call _mm_malloc / malloc before the region of interest) gets
 // direct DMA.  Any device may use the memory (hipHostMallocPortable).
+// What gab_host_alloc handed out: gab_host_free must not infer the allocator from the pointer's attributes -- memory from
+// malloc that is still registered (gab_host_register) also reports as page-locked host memory, and hipHostFree on it
+// fails, leaving it neither unregistered nor freed.
+static std::mutex g_host_mu;
+static std::unordered_set<void *> &gab_host_blocks() { static std::unordered_set<void *> s; return s; }
 extern "C" int gab_host_alloc(size_t bytes, void **out) {
     if (!out) { gab_set_error("gab_host_alloc: NULL argument"); return GAB_EINVAL; }
     *out = nullptr;
     if (gab_device_count() <= 0) { gab_set_error("no HIP device visible"); return GAB_ENODEV; }
     hipError_t e = hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocPortable);
     if (e != hipSuccess) { *out = nullptr; gab_set_error("hipHostMalloc(%zu) failed: %s", bytes, hipGetErrorString(e)); return GAB_ENOMEM; }
+    std::lock_guard<std::mutex> g(g_host_mu);
+    gab_host_blocks().insert(*out);
     return GAB_OK;
 }
+// p: from gab_host_alloc, or from malloc (the drivers' slab helper falls back to malloc when page-locked memory runs out);
+// malloc'ed memory that the caller registered is unregistered first
 extern "C" void gab_host_free(void *p) {
     if (!p) return;
-    if (gab_is_pinned(p)) (void)hipHostFree(p);
-    else free(p);                  // gab_slab_alloc of the drivers falls back to malloc when pinning fails
+    bool ours;
+    {
+        std::lock_guard<std::mutex> g(g_host_mu);
+        ours = gab_host_blocks().erase(p) != 0;
+    }
+    if (ours) { (void)hipHostFree(p); return; }
+    if (gab_is_pinned(p) && hipHostUnregister(p) != hipSuccess) (void)hipGetLastError();
+    free(p);
 }
 // page-lock memory the caller already owns (malloc, realloc, std::vector storage ...), in place
 extern "C" int gab_host_register(void *p, size_t bytes) {

@@ -766,10 +766,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(7, 7))) void
         const uint64_t gm = (G == 64 ? ~0ull : ((1ull << (G & 63)) - 1)) << (threadIdx.x & 63 & ~(G - 1));
         wave_sync();
         int resume_row = 0;
-        if (__ballot(pad_byte) & gm) ok = false;
-        else
-        ok = wfa_pair_static<G>(pool, pool_cap, rows, nrows, pen, P, plen, T, tlen, io.ops + io.ops_off[id], reinterpret_cast<char *>(P),
-                                io.ops_len + id, io.score + id, work, r_start, resume_row);
+        // wfa_pair_static fetches its rows by scalar loads: the row index must be the same in every group that is inside it
+        // together.  Groups of a chained launch can start at different rows (a resumed pair beside one that starts over: a
+        // slot index past in_slots, a pair sent on for its padding bytes or a too-large offset); such a wave runs its groups
+        // one after the other -- each alone in the call, so "the first active lane's row" is its own.
+        bool mixed = false;
+        if (CHAINED) mixed = __ballot(r_start != __builtin_amdgcn_readfirstlane(r_start)) != 0;
+        for (int turn = 0; turn < (mixed ? kGroups : 1); turn++) {
+            if (mixed && grp != turn) continue;
+            if (__ballot(pad_byte) & gm) ok = false;
+            else
+            ok = wfa_pair_static<G>(pool, pool_cap, rows, nrows, pen, P, plen, T, tlen, io.ops + io.ops_off[id], reinterpret_cast<char *>(P),
+                                    io.ops_len + id, io.score + id, work, r_start, resume_row);
+        }
         if (!ok) {
             uint32_t slot = 0;
             if (lane == 0) { slot = atomicAdd(over_count, 1u); over_list[slot] = id; }
@@ -832,6 +841,71 @@ bool wfa_lds_allow_big() {
     return true;
 }
 
+// ---- packed output (gab_wfa_run_packed): the CIGAR as the driver PRINTS it ----------------------------------------------
+// edit_cigar_print (wfa/gap_affine/edit_cigar.c:184-200) writes every run of equal operations as "%d%c".  One thread per
+// pair reads the pair's operations (eight bytes per load), sizes its text, gets its place in the output by a scan of the
+// workgroup and ONE atomic add per workgroup, and writes the text there: ~20 bytes per 151-bp pair instead of the 302 bytes
+// of operation room -- what goes back over the bus shrinks fifteen-fold.  (The layout in `out` is by workgroup arrival;
+// out_off / out_len say where each pair's text is.)
+__device__ __forceinline__ int wfa_dec_digits(uint32_t v) { return 1 + (v >= 10u) + (v >= 100u) + (v >= 1000u) + (v >= 10000u) + (v >= 100000u); }
+
+template <bool WRITE>
+__device__ __forceinline__ int wfa_rle_pass(const char *__restrict__ o, int nops, char *dst) {
+    int len = 0;
+    uint32_t last = 0, run = 0;
+    for (int k = 0; k < nops; k += 8) {
+        unsigned long long w;
+        __builtin_memcpy(&w, o + k, 8);                            // (unaligned; the room is readable 8 bytes past the last operation)
+        const int m = min(8, nops - k);
+        for (int j = 0; j < m; j++, w >>= 8) {
+            const uint32_t c = (uint32_t)(w & 0xff);
+            if (c != last && run) {
+                const int d = wfa_dec_digits(run);
+                if (WRITE) { uint32_t v = run; for (int q = d - 1; q >= 0; q--, v /= 10u) dst[len + q] = (char)('0' + v % 10u); dst[len + d] = (char)last; }
+                len += d + 1;
+                run = 0;
+            }
+            last = c; run++;
+        }
+    }
+    if (run) {
+        const int d = wfa_dec_digits(run);
+        if (WRITE) { uint32_t v = run; for (int q = d - 1; q >= 0; q--, v /= 10u) dst[len + q] = (char)('0' + v % 10u); dst[len + d] = (char)last; }
+        len += d + 1;
+    }
+    return len;
+}
+
+__global__ __launch_bounds__(256) void wfa_rle_pack(const char *__restrict__ ops, const int64_t *__restrict__ ops_off, const int32_t *__restrict__ ops_len,
+                                                    uint32_t n, char *__restrict__ out, unsigned long long cap, unsigned long long *cursor,
+                                                    int64_t *__restrict__ out_off, int32_t *__restrict__ out_len) {
+    __shared__ uint32_t s_wave[4];
+    __shared__ unsigned long long s_base;
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    const char *o = nullptr;
+    int nops = 0, len = 0;
+    if (i < n) { o = ops + ops_off[i]; nops = ops_len[i]; len = wfa_rle_pass<false>(o, nops, nullptr); }
+    // exclusive scan of `len` over the workgroup
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t incl = (uint32_t)len;
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(incl, d); if (lane >= d) incl += t; }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    uint32_t before = 0, total = 0;
+    for (int w = 0; w < 4; w++) { if (w < wave) before += s_wave[w]; total += s_wave[w]; }
+    if (threadIdx.x == 0) s_base = total ? atomicAdd(cursor, (unsigned long long)total) : 0ull;
+    __syncthreads();
+    if (i >= n) return;
+    const unsigned long long at = s_base + before + (incl - (uint32_t)len);
+    out_off[i] = (int64_t)at; out_len[i] = len;
+    if (at + (unsigned long long)len <= cap && len) wfa_rle_pass<true>(o, nops, out + at);       // (else: the host reports GAB_ERANGE)
+}
+
+__global__ __launch_bounds__(256) void wfa_fill_stride(int64_t *off, uint32_t n, int64_t stride) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < n) off[i] = (int64_t)i * stride;
+}
+
 }  // namespace
 
 // =============================================================================== host side
@@ -876,7 +950,8 @@ extern "C" int gab_wfa_create_reduced(const gab_wfa_penalties *p, int min_wavefr
     h->pen.min_len = min_wavefront_length; h->pen.max_dist = max_distance_threshold;
     for (int k = 0; k < 4; k++)
         if (hipEventCreate(&h->ev[k]) != hipSuccess) { gab_set_error("hipEventCreate failed"); delete h; return GAB_EDEVICE; }
-    if (hipHostMalloc((void **)&h->h_ct, sizeof(WfaCounters)) != hipSuccess ||
+    static_assert(sizeof(WfaCounters) <= 128, "the packed-output cursor sits at byte 128 of the pinned block");
+    if (hipHostMalloc((void **)&h->h_ct, 256) != hipSuccess ||
         !wfa_lds_allow_big()) {
         gab_set_error("gab_wfa_create: pinned allocation / LDS attribute failed"); delete h; return GAB_EDEVICE;
     }
@@ -1052,7 +1127,10 @@ extern "C" int gab_wfa_run_device(gab_wfa *h, const char *pat, int64_t pat_bytes
         // the first launch leaves the wavefronts of the pairs it ran out of room for in slots of the scratch buffer and the second
         // continues them (the pool layout is the table's in both): it does not repeat the ~40 score steps they had come
         const bool two = pools[1] > pools[0];
-        const uint32_t slots = two ? (uint32_t)std::min<uint64_t>(cnt, std::max<uint64_t>(65536, cnt / 8)) : 0;
+        // (a multiple of the pairs per wave, so that the boundary between resumed and restarted pairs falls between waves;
+        // the kernel copes with a mixed wave anyway.  GAB_WFA_SLOTS: tests force the boundary into a wave.)
+        uint32_t slots = two ? (uint32_t)std::min<uint64_t>(cnt, std::max<uint64_t>(65536, cnt / 8)) & ~7u : 0;
+        if (const char *e3 = getenv("GAB_WFA_SLOTS")) if (two) slots = (uint32_t)std::min<uint64_t>(cnt, (uint64_t)std::max(0, atoi(e3)));
         const size_t o_slots = ((size_t)sizeof(WfResume) * cnt + 255) & ~(size_t)255;
         WfResume *d_hdr = nullptr; uint8_t *d_slots = nullptr;
         if (two) {
@@ -1200,13 +1278,99 @@ extern "C" int gab_wfa_run(gab_wfa *h, const char *pat, const int64_t *pat_off, 
     return GAB_OK;
 }
 
+// The host-pointer entry point of a driver that PRINTS the alignments: same inputs as gab_wfa_run, the result as the
+// run-length text of edit_cigar_print.  The operations stay on the device (fixed-stride room in the handle's staging buffer).
+extern "C" int gab_wfa_run_packed(gab_wfa *h, const char *pat, const int64_t *pat_off, const int32_t *pat_len, const char *txt,
+                                  const int64_t *txt_off, const int32_t *txt_len, int64_t n, char *cigar_out, int64_t capacity,
+                                  int64_t *cigar_off_out, int32_t *cigar_len_out, int32_t *score_out, int64_t *cigar_bytes) {
+    GAB_CHECK(h, "gab_wfa_run_packed: NULL handle");
+    GAB_CHECK(n >= 0 && n < (1ll << 31), "gab_wfa_run_packed: n=%lld out of range", (long long)n);
+    if (cigar_bytes) *cigar_bytes = 0;
+    if (n == 0) return GAB_OK;
+    GAB_CHECK(pat && pat_off && pat_len && txt && txt_off && txt_len && cigar_off_out && cigar_len_out && score_out && capacity >= 0 &&
+              (cigar_out || capacity == 0), "gab_wfa_run_packed: NULL buffer");
+    gab_device_guard g(h->device);
+    int64_t pb = 0, tb = 0, pa = INT64_MAX, ta = INT64_MAX, stride = 0;
+    for (int64_t i = 0; i < n; i++) {
+        GAB_CHECK(pat_off[i] >= 0 && txt_off[i] >= 0 && pat_len[i] >= 0 && txt_len[i] >= 0,
+                  "gab_wfa_run_packed: negative offset/length at pair %lld", (long long)i);
+        pb = std::max(pb, pat_off[i] + pat_len[i]); tb = std::max(tb, txt_off[i] + txt_len[i]);
+        pa = std::min(pa, pat_off[i]); ta = std::min(ta, txt_off[i]);
+        stride = std::max<int64_t>(stride, (int64_t)pat_len[i] + txt_len[i]);
+    }
+    stride = (stride + 7) & ~(int64_t)7;
+    pa &= ~(int64_t)255; ta &= ~(int64_t)255;
+    const bool shared = pat == txt && std::max(pb, tb) - std::min(pa, ta) <= (pb - pa) + (tb - ta);
+    if (shared) { pa = ta = std::min(pa, ta); pb = tb = std::max(pb, tb); }
+    const size_t ppad = ((size_t)(pb - pa) + 3 + 255) & ~(size_t)255, tpad = shared ? 0 : ((size_t)(tb - ta) + 3 + 255) & ~(size_t)255;
+    const size_t nn = (size_t)n, opad = ((size_t)stride * nn + 16 + 255) & ~(size_t)255, cpad = ((size_t)capacity + 255) & ~(size_t)255;
+    size_t o = 0;
+    const size_t o_p = o; o += ppad;
+    const size_t o_t = o; o += tpad;
+    const size_t o_ops = o; o += opad;
+    const size_t o_txt = o; o += cpad;
+    const size_t o_po = o; o += 8 * nn;
+    const size_t o_to = o; o += 8 * nn;
+    const size_t o_oo = o; o += 8 * nn;
+    const size_t o_co = o; o += 8 * nn;
+    const size_t o_pl = o; o += 4 * nn;
+    const size_t o_tl = o; o += 4 * nn;
+    const size_t o_ol = o; o += 4 * nn;
+    const size_t o_cl = o; o += 4 * nn;
+    const size_t o_sc = o; o += 4 * nn;
+    const size_t o_cur = o; o += 256;
+    int rc = h->io.reserve(o);
+    if (rc) return rc;
+    char *b = h->io.as<char>();
+    hipStream_t s = nullptr;
+    if ((rc = h->hs.get(&s)) != GAB_OK) return rc;
+    {   // the copies of one chunk at a time per GPU (gab_core.hip: the workers of a GPU must not copy in lockstep)
+        std::lock_guard<std::mutex> gate(gab_h2d_mutex(h->device));
+        GAB_HIP(hipMemcpyAsync(b + o_p, pat + pa, (size_t)(pb - pa), hipMemcpyHostToDevice, s));
+        if (!shared) GAB_HIP(hipMemcpyAsync(b + o_t, txt + ta, (size_t)(tb - ta), hipMemcpyHostToDevice, s));
+        GAB_HIP(hipMemcpyAsync(b + o_po, pat_off, 8 * nn, hipMemcpyHostToDevice, s));
+        GAB_HIP(hipMemcpyAsync(b + o_to, txt_off, 8 * nn, hipMemcpyHostToDevice, s));
+        GAB_HIP(hipMemcpyAsync(b + o_pl, pat_len, 4 * nn, hipMemcpyHostToDevice, s));
+        GAB_HIP(hipMemcpyAsync(b + o_tl, txt_len, 4 * nn, hipMemcpyHostToDevice, s));
+        GAB_HIP(hipStreamSynchronize(s));
+    }
+    const unsigned grid = (unsigned)((nn + 255) / 256);
+    hipLaunchKernelGGL(wfa_fill_stride, dim3(grid), dim3(256), 0, s, (int64_t *)(b + o_oo), (uint32_t)n, stride);
+    GAB_HIP(hipGetLastError());
+    rc = gab_wfa_run_device(h, b + o_p - pa, pa + (int64_t)ppad, (const int64_t *)(b + o_po), (const int32_t *)(b + o_pl),
+                            (shared ? b + o_p : b + o_t) - ta, ta + (int64_t)(shared ? ppad : tpad), (const int64_t *)(b + o_to), (const int32_t *)(b + o_tl), n, b + o_ops,
+                            (const int64_t *)(b + o_oo), (int32_t *)(b + o_ol), (int32_t *)(b + o_sc), s);
+    if (rc) return rc;
+    GAB_HIP(hipMemsetAsync(b + o_cur, 0, 8, s));
+    hipLaunchKernelGGL(wfa_rle_pack, dim3(grid), dim3(256), 0, s, (const char *)(b + o_ops), (const int64_t *)(b + o_oo), (const int32_t *)(b + o_ol),
+                       (uint32_t)n, b + o_txt, (unsigned long long)capacity, (unsigned long long *)(b + o_cur), (int64_t *)(b + o_co), (int32_t *)(b + o_cl));
+    GAB_HIP(hipGetLastError());
+    unsigned long long *h_cur = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(h->h_ct) + 128);
+    GAB_HIP(hipMemcpyAsync(h_cur, b + o_cur, 8, hipMemcpyDeviceToHost, s));
+    GAB_HIP(hipMemcpyAsync(cigar_off_out, b + o_co, 8 * nn, hipMemcpyDeviceToHost, s));
+    GAB_HIP(hipMemcpyAsync(cigar_len_out, b + o_cl, 4 * nn, hipMemcpyDeviceToHost, s));
+    GAB_HIP(hipMemcpyAsync(score_out, b + o_sc, 4 * nn, hipMemcpyDeviceToHost, s));
+    GAB_HIP(hipStreamSynchronize(s));
+    const int64_t total = (int64_t)*h_cur;
+    if (cigar_bytes) *cigar_bytes = total;
+    if (total > capacity) {
+        gab_set_error("gab_wfa_run_packed: %lld bytes of CIGAR text do not fit the caller's %lld", (long long)total, (long long)capacity);
+        return GAB_ERANGE;
+    }
+    if (total) {
+        GAB_HIP(hipMemcpyAsync(cigar_out, b + o_txt, (size_t)total, hipMemcpyDeviceToHost, s));
+        GAB_HIP(hipStreamSynchronize(s));
+    }
+    return GAB_OK;
+}
+
 // see gab_bpm_reserve; max_ops_bytes = the room of the CIGAR operations (pattern + text length per pair)
 extern "C" int gab_wfa_reserve(gab_wfa *h, int64_t max_pairs, int64_t max_seq_bytes, int64_t max_ops_bytes) {
     GAB_CHECK(h, "gab_wfa_reserve: NULL handle");
     GAB_CHECK(max_pairs >= 0 && max_pairs < (1ll << 31) && max_seq_bytes >= 0 && max_ops_bytes >= 0, "gab_wfa_reserve: size out of range");
     gab_device_guard g(h->device);
     const size_t nn = (size_t)max_pairs;
-    int rc = h->io.reserve(std::max<size_t>(2 * (((size_t)max_seq_bytes + 3 + 511) & ~(size_t)255) + (((size_t)max_ops_bytes + 511) & ~(size_t)255) + 44 * nn + 1024,
+    int rc = h->io.reserve(std::max<size_t>(2 * (((size_t)max_seq_bytes + 3 + 511) & ~(size_t)255) + (((size_t)max_ops_bytes + 511) & ~(size_t)255) + 60 * nn + 2048,
                                             (size_t)4 << 20));
     if (rc) return rc;
     if ((rc = h->ws.reserve(kCountersBytes + kSlotsBytes + 3 * 4 * nn + 1024)) != GAB_OK) return rc;

@@ -44,6 +44,22 @@ class FMI_search:
         np.cumsum(np.bincount(arr["rid"], minlength=reads.n), out=off[1:])
         return arr, off
 
+    def clone(self):
+        """a second handle on the same GPU sharing this handle's index (gab_fmi_clone): one per host worker thread"""
+        other = FMI_search.__new__(FMI_search)
+        other._h = C.c_void_p()
+        check(lib().gab_fmi_clone(self._h, C.byref(other._h)))
+        return other
+
+    def seed_into(self, enc, length, out, min_seed_len=19):
+        """host arrays: enc [n, stride] uint8 (C-contiguous rows), length int32, out = the caller's SMEM_DTYPE array
+        (page-lock it for the full link rate) -> number of SMEMs written; GabError(GAB_ERANGE) when out is too small"""
+        n = C.c_int64(0)
+        rc = lib().gab_fmi_seed_into(self._h, _p(enc), C.c_int32(enc.shape[1]), _p(length), C.c_int64(enc.shape[0]),
+                                     C.c_int32(min_seed_len), _p(out), C.c_int64(len(out)), C.byref(n))
+        check(rc)
+        return n.value
+
     def seed_device(self, enc, length, min_seed_len=19, stream=0):
         """torch CUDA tensors enc [n, stride] uint8, length int32 -> (device ptr of gab_smem[], device ptr of
         read_off[], count); the pointers stay valid until the next call"""

@@ -49,6 +49,25 @@ class AffineWavefronts:
                                 _p(batch.txt_off), _p(batch.txt_len), C.c_int64(batch.n), _p(ops), _p(off), _p(ln), _p(sc)))
         return ops, off, ln, sc
 
+    def align_packed(self, batch, capacity=None):
+        """PairBatch -> (text uint8, text_off, text_len, score): per pair the run-length CIGAR text edit_cigar_print writes
+        (gab_wfa_run_packed).  capacity=None sizes the text buffer at a quarter of the operation room and retries once
+        with the exact size when the library says it does not fit (GAB_ERANGE)."""
+        from ._lib import GabError
+        cap = int(capacity) if capacity is not None else int(ops_layout(batch)[1] // 4 + 4096)
+        off = np.full(batch.n, -1, np.int64); ln = np.full(batch.n, -1, np.int32); sc = np.full(batch.n, -1, np.int32)
+        need = C.c_int64(0)
+        for _ in range(2):
+            text = np.zeros(cap + 16, np.uint8)
+            rc = lib().gab_wfa_run_packed(self._h, _p(batch.pat), _p(batch.pat_off), _p(batch.pat_len), _p(batch.txt), _p(batch.txt_off),
+                                          _p(batch.txt_len), C.c_int64(batch.n), _p(text), C.c_int64(cap), _p(off), _p(ln), _p(sc), C.byref(need))
+            if rc == -34 and capacity is None and need.value > cap:
+                cap = need.value
+                continue
+            check(rc)
+            return text[:need.value], off, ln, sc
+        raise GabError(-34, "gab_wfa_run_packed: text does not fit")
+
     def run_device(self, pat, pat_off, pat_len, txt, txt_off, txt_len, ops, ops_off, ops_len, score, stream=0):
         n = pat_len.numel()
         check(lib().gab_wfa_run_device(self._h, C.c_void_p(pat.data_ptr()), C.c_int64(pat.numel()),

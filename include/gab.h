@@ -36,6 +36,7 @@ extern "C" {
 #define GAB_ENOMEM (-12)   /* host or device allocation failed */
 #define GAB_EDEVICE (-5)   /* HIP runtime error                */
 #define GAB_ENODEV (-19)   /* no usable gfx950 device          */
+#define GAB_ERANGE (-34)   /* result larger than the caller's buffer (the needed size is returned) */
 
 /* ---- library ------------------------------------------------------------------- */
 const char *gab_version(void);
@@ -248,6 +249,18 @@ int gab_wfa_reserve(gab_wfa *h, int64_t max_pairs, int64_t max_seq_bytes, int64_
 int gab_wfa_run(gab_wfa *h, const char *pat, const int64_t *pat_off, const int32_t *pat_len,
                 const char *txt, const int64_t *txt_off, const int32_t *txt_len, int64_t n,
                 char *ops_out, const int64_t *ops_off, int32_t *ops_len_out, int32_t *score_out);
+/* The same call for a driver that PRINTS the alignments (wfa/tools/align_benchmark.c:499-504): the result is the text
+ * edit_cigar_print writes (wfa/gap_affine/edit_cigar.c:184-200) -- every run of equal operations as "%d%c", e.g. "70M1X80M" --
+ * encoded on the device, so that ~20 bytes per 151-bp pair cross the bus instead of pattern_length + text_length bytes of
+ * operation room.  Pair i's text is cigar_out[cigar_off_out[i] .. + cigar_len_out[i]) (no terminator; an empty CIGAR has
+ * length 0; the texts are packed without gaps but NOT in pair order).  *cigar_bytes = bytes of text produced; when that exceeds
+ * `capacity` no text is written and the call returns GAB_ERANGE (offsets, lengths and scores are valid): call again with
+ * *cigar_bytes of room.  2 * (pattern_length + text_length) per pair always suffices; a quarter of the operation room is
+ * ample for reads. */
+int gab_wfa_run_packed(gab_wfa *h, const char *pat, const int64_t *pat_off, const int32_t *pat_len,
+                       const char *txt, const int64_t *txt_off, const int32_t *txt_len, int64_t n,
+                       char *cigar_out, int64_t capacity, int64_t *cigar_off_out, int32_t *cigar_len_out,
+                       int32_t *score_out, int64_t *cigar_bytes);
 /* device buffers (sequence slabs readable to a multiple of 4 bytes past the last base);
  * synchronises `stream` internally between its passes */
 int gab_wfa_run_device(gab_wfa *h, const char *pat, int64_t pat_bytes, const int64_t *pat_off,
@@ -292,6 +305,13 @@ void gab_fmi_destroy(gab_fmi *h);
 int gab_fmi_seed(gab_fmi *h, const uint8_t *enc, int32_t stride, const int32_t *len, int64_t nreads,
                  int32_t min_seed_len, gab_smem **out, int64_t *nout);
 void gab_fmi_free(gab_smem *p);
+/* same, into the CALLER's array of `capacity` records -- how the reference's threads collect their SMEMs: per-thread arrays
+ * allocated before the region of interest and grown when a batch does not fit (fmi/fmi.cpp:236-247, 277-286).  Page-lock
+ * the array (gab_host_alloc / gab_host_register) and the result arrives as one DMA at the link rate instead of through
+ * the runtime's staging of pageable memory.  *nout = SMEMs found; when that exceeds `capacity` nothing is written and the
+ * call returns GAB_ERANGE: grow the array to *nout and call again. */
+int gab_fmi_seed_into(gab_fmi *h, const uint8_t *enc, int32_t stride, const int32_t *len, int64_t nreads,
+                      int32_t min_seed_len, gab_smem *out, int64_t capacity, int64_t *nout);
 /* device buffers; *d_out / *d_read_off (nreads + 1 offsets into d_out) point into memory owned by the
  * handle and stay valid until the next call on it.  Synchronises `stream` internally. */
 int gab_fmi_seed_device(gab_fmi *h, const uint8_t *d_enc, int32_t stride, const int32_t *d_len,

@@ -1,0 +1,79 @@
+"""The driver keeps only the tail of bench.py's stdout and parses its LAST line: that line must stay small and complete
+(round 2's 21.6 KB line came back as `parsed: null`).  Runs the formatter on the committed payload of a real default run."""
+import io
+import json
+import os
+import sys
+from contextlib import redirect_stdout
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import bench  # noqa: E402
+
+REQUIRED = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+            "dtype", "data", "config", "roofline", "cpu_baseline", "parity", "extra")
+
+
+def _payload():
+    """a real result: the r02 default run (headline with the whole suite nested in extra.suite, 21.6 KB)"""
+    out = json.load(open(os.path.join(ROOT, "profiles", "r02_bench_default.json")))
+    suite = out["extra"].pop("suite")
+    out["extra"].pop("suite_note", None)
+    out["extra"]["value_hbm_resident"] = out["value"]
+    out["extra"]["value_roi_incl_pcie"] = out["extra"]["roi_incl_pcie"]["value"]
+    out["cpu_baseline"]["host_threads_visible"] = 256
+    for r in suite.values():
+        if "value" in r:
+            r["extra"]["value_hbm_resident"] = r["value"]
+    return out, suite
+
+
+def test_headline_is_small_complete_json():
+    out, suite = _payload()
+    assert len(json.dumps(out)) + len(json.dumps(suite)) > 15000          # the payload really is the big one
+    line = bench.headline(out, suite)
+    assert "\n" not in line and len(line) < 4096
+    d = json.loads(line)
+    for k in REQUIRED:
+        assert k in d, k
+    assert d["metric"] == out["metric"] and d["value"] == out["value"] and d["ms_per_step"] == out["ms_per_step"]
+    assert d["config"]["workload"] == "bsw-large" and "model" not in d["config"]
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-5
+    cb = d["cpu_baseline"]
+    assert cb["kind"] in ("reference", "port") and cb["cores"] >= 1 and cb["value"] > 0 and cb["sample"] and cb["host_threads_visible"] == 256
+    assert d["extra"]["value_hbm_resident"] == d["value"] and d["extra"]["value_roi_incl_pcie"] > 0
+    # every suite entry is summarised in the headline
+    assert set(d["extra"]["suite"]) == set(suite)
+    assert d["extra"]["suite"]["chain-large"][0] == suite["chain-large"]["value"]
+
+
+def test_emit_prints_suite_lines_then_the_headline_last(tmp_path):
+    out, suite = _payload()
+    suite["skipped-one"] = {"skipped": "time budget"}
+    buf = io.StringIO()
+    path = tmp_path / "bench_suite.json"
+    with redirect_stdout(buf):
+        bench.emit(out, suite, path=str(path))
+    lines = buf.getvalue().splitlines()
+    assert len(lines) == len(suite) + 1
+    for l in lines:
+        assert len(l) < 4096
+        json.loads(l)
+    assert all("suite" in json.loads(l) and isinstance(json.loads(l)["suite"], str) for l in lines[:-1])
+    last = json.loads(lines[-1])
+    assert last["metric"] == out["metric"] and "roofline" in last and "cpu_baseline" in last
+    one = json.loads(lines[0])
+    assert one["suite"] == "chain-large" and one["roofline"]["frac"] > 0 and one["cpu_baseline"]["kind"] == "reference"
+    full = json.load(open(path))
+    assert full["headline"]["extra"]["valu"] and set(full["suite"]) == set(suite)       # nothing is lost, it just moved
+
+
+def test_headline_sheds_the_suite_rather_than_overflow():
+    out, suite = _payload()
+    big = {f"entry-{i}": dict(suite["chain-large"]) for i in range(200)}
+    line = bench.headline(out, big)
+    assert len(line) < 4096
+    d = json.loads(line)
+    assert "roofline" in d and "cpu_baseline" in d and "suite" not in d["extra"]

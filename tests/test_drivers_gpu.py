@@ -194,6 +194,42 @@ def test_fmi_chunks_fix_up_read_ids(inputs, tmp_path):
     assert nchunks == (1200 + 36) // 37 and sum(counts) == nchunks
 
 
+def test_fmi_driver_worker_arrays_fill_up(inputs, tmp_path):
+    """the workers collect their SMEMs in page-locked arrays of their own (the reference's per-thread matchArray,
+    fmi/fmi.cpp:243-255) and take a separate block for a chunk that no longer fits (:277-286): same output either way,
+    also from pageable arrays"""
+    exe = os.path.join(ROOT, "benchmarks", "fmi", "fmi")
+    args = [exe, f"{inputs}/fmi/broad", f"{inputs}/fmi/small/SRR7733443_1m_1.fastq", "512", "19", "1"]
+    want = open(f"{inputs}/fmi/small/out-reference.txt").read().splitlines()
+    for extra in ({"GAB_FMI_ARENA": "300"}, {"GAB_FMI_ARENA": "1"}, {"GAB_NO_PIN": "1"}):
+        r = subprocess.run(args, capture_output=True, text=True, timeout=300, env=dict(os.environ, GAB_CHUNK="100", **QUEUE_ENV, **extra))
+        assert r.returncode == 0, r.stderr[-500:]
+        assert r.stdout.splitlines()[6:] == want, extra
+
+
+def test_wfa_driver_packed_and_unpacked_output(inputs, tmp_path):
+    """the wfa driver gets the printed CIGAR text from the device (gab_wfa_run_packed); GAB_WFA_UNPACKED=1 takes the
+    operations (gab_wfa_run) and encodes on the host: same file, also when a chunk's text outgrows its room (very
+    divergent pairs: the chunk gets a block of its own)"""
+    import numpy as np
+    exe = os.path.join(ROOT, "benchmarks", "wfa", "bin", "align_benchmark")
+    rng = np.random.default_rng(5)
+    src = tmp_path / "divergent.txt"
+    with open(src, "wb") as f:
+        for i in range(3000):
+            n = int(rng.integers(20, 150))
+            p = rng.choice(np.frombuffer(b"ACGT", np.uint8), n).tobytes()
+            t = rng.choice(np.frombuffer(b"ACGT", np.uint8), n).tobytes() if i % 2 else p       # random text: a run per operation
+            f.write(b">" + p + b"\n<" + t + b"\n")
+    outs = []
+    for env in ({}, {"GAB_WFA_UNPACKED": "1"}, {"GAB_CHUNK": "64", **QUEUE_ENV}):
+        o = tmp_path / f"o{len(outs)}.txt"
+        r = subprocess.run([exe, "-i", str(src), "-o", str(o)], capture_output=True, text=True, timeout=300, env=dict(os.environ, **env))
+        assert r.returncode == 0, r.stderr[-500:]
+        outs.append(open(o).read())
+    assert outs[0] == outs[1] == outs[2] and outs[0].count("\n") == 3000
+
+
 def test_unpinned_and_piped_inputs(inputs, tmp_path):
     """GAB_NO_PIN=1 (pageable slabs) gives the same scores; a pipe instead of a file is refused by the seek the reference
     needs too, and GAB_GPU_PARSE on a pipe never reads an unknown size"""

@@ -146,6 +146,71 @@ def test_one_byte_history_limits(tmax, pen, red):
     e.close()
 
 
+@pytest.mark.parametrize("slots", [1001, 1002, 3, 0])
+def test_resumed_and_restarted_pairs_in_one_wave(monkeypatch, slots):
+    """the second static launch continues the pairs the first ran out of room for from the row they had reached -- for the
+    first `slots` of them; the others start over at row 0.  A slot count that is not a multiple of the four pairs of a
+    wave puts both kinds into ONE wave, whose row index is then no longer wave-uniform: the kernel runs
+    such a wave's groups one after the other.  High-divergence batch: most pairs leave the first tier."""
+    from genarchbench_amd.wfa import AffineWavefronts
+    monkeypatch.setenv("GAB_WFA_SLOTS", str(slots))
+    rng = np.random.default_rng(1000 + slots)
+    pats, txts = [], []
+    for _ in range(6000):
+        p, t = _mutated(rng, int(rng.integers(120, 152)), float(rng.choice([0.01, 0.08, 0.1, 0.12])))
+        pats.append(p); txts.append(t[:180])
+    b = gabgen.pairs_from_lists(pats, txts)
+    e = AffineWavefronts()
+    same(e.align(b), pyoracle.wfa(b))
+    assert e.last_stats()["requeued"] > max(slots, 1) + 8          # more pairs overflowed than there are slots
+    e.close()
+
+
+def _rle(ops):
+    out, k, n = bytearray(), 0, len(ops)
+    while k < n:
+        r = k
+        while r < n and ops[r] == ops[k]:
+            r += 1
+        out += b"%d%c" % (r - k, ops[k]); k = r
+    return bytes(out)
+
+
+@pytest.mark.parametrize("name", ["wfa_bench", "wfa_adv"])
+def test_packed_output_golden(eng, name):
+    """gab_wfa_run_packed returns the text edit_cigar_print writes: byte-identical to the reference's output lines"""
+    batch = gabgen.read_pairs_text(f"{GOLDEN}/{name}.in.txt")
+    want = [l.split(b" ", 1)[1] if b" " in l else b"" for l in open(f"{GOLDEN}/{name}.expected.txt", "rb").read().splitlines()]
+    text, off, ln, sc = eng.align_packed(batch)
+    got = [text[off[i]:off[i] + ln[i]].tobytes() for i in range(batch.n)]
+    assert got == want
+    assert int(ln.sum()) == len(text)                          # packed without gaps
+    np.testing.assert_array_equal(sc, pyoracle.wfa(batch)[3])
+
+
+def test_packed_output_vs_unpacked_and_capacity(eng):
+    """same alignments as gab_wfa_run, run-length encoded; a buffer that is too small is reported with the size that fits"""
+    from genarchbench_amd._lib import GabError
+    rng = np.random.default_rng(77)
+    pats, txts = [b"", b"A", b"", b"ACGT" * 300, b"A" * 1200], [b"", b"", b"ACG", b"ACGA" * 300, b"A" * 1000]     # empty CIGAR, pure I / D, runs >= 1000
+    for _ in range(5000):
+        p, t = _mutated(rng, int(rng.integers(1, 260)), float(rng.choice([0.0, 0.02, 0.1, 0.3])))
+        pats.append(p); txts.append(t)
+    b = gabgen.pairs_from_lists(pats, txts)
+    ops, ooff, oln, osc = eng.align(b)
+    text, off, ln, sc = eng.align_packed(b)
+    np.testing.assert_array_equal(sc, osc)
+    for i in range(b.n):
+        assert text[off[i]:off[i] + ln[i]].tobytes() == _rle(ops[ooff[i]:ooff[i] + oln[i]].tobytes()), i
+    assert ln[0] == 0 and ln[1] == 2 and ln[2] == 2                # "", "1D", "3I"
+    need = int(ln.sum())
+    with pytest.raises(GabError) as e:
+        eng.align_packed(b, capacity=need - 1)
+    assert e.value.code == -34
+    t2, off2, ln2, _ = eng.align_packed(b, capacity=need)      # exactly enough
+    assert len(t2) == need and np.array_equal(ln2, ln)
+
+
 def test_other_penalties():
     from genarchbench_amd.wfa import AffineWavefronts
     b = gabgen.pairs(67, 5000, 1, 120)

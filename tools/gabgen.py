@@ -13,8 +13,14 @@ _lib = None
 
 def build(force=False):
     so = os.path.join(_GEN_DIR, "libgabgen.so")
-    if force or not os.path.exists(so) or not os.path.exists(os.path.join(_GEN_DIR, "gabgen")):
-        subprocess.check_call(["make", "-C", _GEN_DIR, "-s"])
+    exe = os.path.join(_GEN_DIR, "gabgen")
+    srcs = [os.path.join(_GEN_DIR, f) for f in os.listdir(_GEN_DIR) if f.endswith((".c", ".h"))]
+    stale = not (os.path.exists(so) and os.path.exists(exe)) or any(os.path.getmtime(f) > os.path.getmtime(so) for f in srcs)
+    if force or stale:
+        import fcntl
+        with open(os.path.join(_GEN_DIR, ".build.lock"), "w") as lk:       # several ranks / test workers may get here at once
+            fcntl.flock(lk, fcntl.LOCK_EX)
+            subprocess.check_call(["make", "-C", _GEN_DIR, "-s"] + (["-B"] if force else []))
     return so
 
 
@@ -146,6 +152,25 @@ def chain(seed, ncalls, mode=0, nmin=50, nmax=60000, first=0):
     x = np.zeros(total, np.uint64); y = np.zeros(total, np.uint64)
     L.gab_gen_chain_fill(C.c_uint64(seed), C.c_int(mode), C.c_int64(nmin), C.c_int64(nmax), C.c_int64(first),
                          C.c_int64(ncalls), _p(hdr), _p(call_off), _p(x), _p(y))
+    return ChainBatch(hdr, call_off, x, y)
+
+
+def chain_sizes(seed, ncalls, mode=0, nmin=50, nmax=60000):
+    """anchor count of calls 0 .. ncalls-1 (headers only: cheap)"""
+    hdr = np.zeros(ncalls, CHAIN_HDR)
+    lib().gab_gen_chain_hdrs(C.c_uint64(seed), C.c_int(mode), C.c_int64(nmin), C.c_int64(nmax), C.c_int64(0), C.c_int64(ncalls), _p(hdr))
+    return hdr["n"].copy()
+
+
+def chain_ids(seed, ids, mode=0, nmin=50, nmax=60000):
+    """the calls with the given ids (any subset, any order) of the same seeded input chain(seed, N, ...) generates"""
+    L = lib()
+    ids = np.ascontiguousarray(ids, np.int64)
+    hdr = np.zeros(len(ids), CHAIN_HDR)
+    L.gab_gen_chain_ids(C.c_uint64(seed), C.c_int(mode), C.c_int64(nmin), C.c_int64(nmax), _p(ids), C.c_int64(len(ids)), _p(hdr))
+    call_off, total = _offsets(hdr["n"])
+    x = np.zeros(total, np.uint64); y = np.zeros(total, np.uint64)
+    L.gab_gen_chain_fill_ids(C.c_uint64(seed), C.c_int(mode), _p(ids), C.c_int64(len(ids)), _p(hdr), _p(call_off), _p(x), _p(y))
     return ChainBatch(hdr, call_off, x, y)
 
 

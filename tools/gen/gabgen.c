@@ -279,6 +279,26 @@ void gab_gen_chain_fill(uint64_t seed, int mode, int64_t nmin, int64_t nmax,
     }
 }
 
+/* the same for an arbitrary list of call ids (bench.py's strong-scaling deal hands a rank a scattered subset) */
+void gab_gen_chain_ids(uint64_t seed, int mode, int64_t nmin, int64_t nmax, const int64_t *ids, int64_t ncalls,
+                       gabgen_chain_hdr *hdr) {
+    for (int64_t c = 0; c < ncalls; c++) gab_gen_chain_hdrs(seed, mode, nmin, nmax, ids[c], 1, &hdr[c]);
+}
+void gab_gen_chain_fill_ids(uint64_t seed, int mode, const int64_t *ids, int64_t ncalls, gabgen_chain_hdr *hdr,
+                            const int64_t *call_off, uint64_t *x, uint64_t *y) {
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int64_t c = 0; c < ncalls; c++) {
+        int64_t n = hdr[c].n;
+        gen_anchor *a = (gen_anchor *)malloc(sizeof(gen_anchor) * (size_t)n);
+        float avg = chain_item(seed, mode, ids[c], n, a);
+        if (mode == 1 && ids[c] % 3 != 2) avg = (float)(int)(avg + 0.5f);
+        char buf[64]; snprintf(buf, sizeof buf, "%f", avg); avg = strtof(buf, 0);
+        hdr[c].avg_qspan = avg;
+        for (int64_t i = 0; i < n; i++) { x[call_off[c] + i] = a[i].x; y[call_off[c] + i] = a[i].y; }
+        free(a);
+    }
+}
+
 /* decimal text of v into p, returns the end (fprintf per anchor made the 85 M-anchor file take minutes) */
 static char *put_u64(char *p, uint64_t v) {
     char t[24]; int k = 0;

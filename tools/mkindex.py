@@ -68,3 +68,29 @@ class FmIndex:
             self.cp_occ = None; self.sa_ms_byte = None; self.sa_ls_word = None
 
     __del__ = close
+
+
+class IndexFile:
+    """the arrays of an index file <prefix>.bwt.2bit.64 as the reference writes it (FMI_search.cpp:163-164,252,275-276,296:
+    i64 reference_seq_len, i64 count[5], CP_OCC[(len >> 6) + 1], the sampled suffix array as (len >> 3) + 1 most-significant
+    bytes and as many low words, i64 sentinel_index), memory-mapped: same attributes as FmIndex.  bench.py's ranks share ONE
+    index built by rank 0 this way."""
+
+    def __init__(self, prefix):
+        path = prefix + ".bwt.2bit.64"
+        mm = np.memmap(path, np.uint8, "r")
+        head = np.frombuffer(mm[:48].tobytes(), np.int64)
+        self.ref_seq_len = int(head[0])
+        self.count = head[1:6].copy()
+        nocc = (self.ref_seq_len >> 6) + 1
+        nsa = (self.ref_seq_len >> 3) + 1
+        o = 48
+        self.cp_occ = mm[o:o + 64 * nocc]; o += 64 * nocc
+        self.sa_ms_byte = mm[o:o + nsa].view(np.int8); o += nsa
+        self.sa_ls_word = np.frombuffer(mm[o:o + 4 * nsa].tobytes(), np.uint32); o += 4 * nsa
+        self.sentinel_index = int(np.frombuffer(mm[o:o + 8].tobytes(), np.int64)[0])
+        assert o + 8 == len(mm), f"{path}: unexpected size"
+        self._mm = mm
+
+    def close(self):
+        self.cp_occ = self.sa_ms_byte = self.sa_ls_word = self._mm = None
