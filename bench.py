@@ -512,9 +512,10 @@ class BpmWorkload:
         """the C driver's ROI (bpm/tools/align_benchmark.c:213-337 in the reference): host slabs in, scores out"""
         import ctypes as C
         from genarchbench_amd._lib import check, lib
-        b, n = self.batch, self.items
+        n = self.items
+        b = self.batch.interleaved()       # the layout of the driver's slab (the pair file): pattern i, text i, pattern i + 1, ...
         score = np.full(n, 12345, np.int32)
-        pinned = pin(b.pat, b.pat_off, b.pat_len, b.txt_off, b.txt_len, score)       # b.txt IS b.pat (one interleaved slab)
+        pinned = pin(b.pat, b.pat_off, b.pat_len, b.txt_off, b.txt_len, score)       # b.txt IS b.pat
         at = lambda a, i: C.c_void_p(a.ctypes.data + a.itemsize * i)
         entry, reserve = self.host_entry, self.host_reserve
         slab_bytes = int(b.pat.nbytes)
@@ -748,7 +749,8 @@ class WfaWorkload:
         import ctypes as C
         from genarchbench_amd._lib import check, lib
         from genarchbench_amd.wfa import AffineWavefronts
-        b, n = self.batch, self.items
+        n = self.items
+        b = self.batch.interleaved()       # the layout of the driver's slab (the pair file): pattern i, text i, pattern i + 1, ...
         nchunks = (n + chunk - 1) // chunk
         room = (b.pat_len.astype(np.int64) + b.txt_len.astype(np.int64))
         beg = np.zeros(nchunks + 1, np.int64)                    # text room of chunk c: a quarter of its operation room
@@ -757,13 +759,13 @@ class WfaWorkload:
         text = np.zeros(int(beg[-1]) + 16, np.uint8)
         off = np.full(n, -1, np.int64); ln = np.full(n, -1, np.int32); sc = np.full(n, -1, np.int32)
         used = np.zeros(nchunks, np.int64)
-        pinned = pin(b.pat, b.txt, b.pat_off, b.txt_off, b.pat_len, b.txt_len, text, off, ln, sc)
+        pinned = pin(b.pat, b.pat_off, b.txt_off, b.pat_len, b.txt_len, text, off, ln, sc)
         at = lambda a, i: C.c_void_p(a.ctypes.data + a.itemsize * i)
         stride = (int(room.max()) + 7) & ~7
 
         def make():
             e = AffineWavefronts(device=self.dev_index)
-            check(lib().gab_wfa_reserve(e._h, C.c_int64(min(n, chunk)), C.c_int64(int(b.pat.nbytes + b.txt.nbytes) // max(nchunks, 1) + (1 << 20)),
+            check(lib().gab_wfa_reserve(e._h, C.c_int64(min(n, chunk)), C.c_int64(int(b.pat.nbytes) // max(nchunks, 1) + (1 << 20)),
                                         C.c_int64(stride * min(n, chunk) + int(np.diff(beg).max()) + 4096)))
             return e
 
@@ -789,7 +791,7 @@ class WfaWorkload:
             t0 = int(beg[i // chunk] + off[i])
             assert text[t0:t0 + ln[i]].tobytes() == want, f"cigar {i}: host-pointer path and device path disagree"
         return {"ms": round(sec * 1e3, 3), "value": round(n / sec / 1e6, 3), "unit": self.unit, "chunk": chunk, "workers_per_gpu": HOST_WORKERS,
-                "bytes_in": int(b.pat.nbytes + b.txt.nbytes + 24 * n), "bytes_out": int(used.sum() + 16 * n),
+                "bytes_in": int(b.pat.nbytes + 24 * n), "bytes_out": int(used.sum() + 16 * n),
                 "note": "gab_wfa_run_packed on page-locked host slabs, chunks pulled by worker threads (the C driver's ROI): the sequences over the "
                         "bus + kernels + the printed CIGAR text back (run-length encoded on the device); all scores and a sample of the "
                         "CIGARs equal to the device path's"}

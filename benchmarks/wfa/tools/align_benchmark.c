@@ -183,6 +183,7 @@ int main(int argc, char **argv) {
     gab_pin(ctx.ops_len, 4 * (size_t)p.n); gab_pin(ctx.score, 4 * (size_t)p.n);
     gab_queue q;
     gab_queue_open(&q, ngpus, nchunks, gpu_init, run_chunk, gpu_fini, &ctx);
+    for (int64_t rep = gab_env_i64("GAB_ROI_WARMUPS", 0); rep > 0; rep--) gab_queue_run(&q, nchunks);       /* diagnosis only: untimed passes before the ROI */
     const double t0 = tv_now();                  /* ROI: align_benchmark.c:378-491 */
     gab_roi_begin_n(ngpus);
     gab_queue_run(&q, nchunks);

@@ -1223,6 +1223,446 @@ void chain_block_kernel_lat(const ChainWork *__restrict__ work, typename AnchorP
     chain_block_body<H, FED>(work, xs, ys, score_out, parent_out, gmarks_all, evals_out, feed);
 }
 
+// ---- chain: the LATENCY form of the block kernel ("fast") --------------------------------------------------------------------
+// chain_block_kernel is built for throughput: six calls per CU, four waves per call.  Alone on the chip a call still takes
+// 0.26 us per anchor with it (60 000 anchors: 16 ms -- the floor under a 1 000-call batch and under every shard of a
+// strong-scaling run), and knock-outs (profiles/r03_chain_latency.md) show where that goes: 0.15 us is the
+// sequential window-start search (one ballot round per ANCHOR, repeated by every helper wave), 0.09 us the far fold riding
+// on the same wave; the main wave's own 128 predecessor steps per block are not the critical path, they only make it longer.
+// Here a call gets sixteen waves with one job each:
+//   * SEARCH wave: the window starts of a whole block at once.  All 64 anchors scan the candidates j = st, st + 1, ...
+//     together (x[j] is wave-uniform: one v_readlane per candidate) and count their leading passes -- the exact first index
+//     at which anchor a's `while` would stop if it started at the block's entry value; since the pointer only moves forward the
+//     sequential result is the running maximum of those (and of i - max_iter), PROVIDED that an anchor whose own stop lies
+//     before its predecessor's also stops AT the predecessor's -- true whenever x ascends, verified per block by one gather,
+//     and a block that fails it (unsorted x) takes the reference's anchor-by-anchor loop.  ~80 candidates per block instead of
+//     64 dependent ballot rounds.
+//   * WORKER waves (14): everything about a pair (anchor, predecessor) that involves no score of the current or the previous
+//     block.  Eight of them leave the geometry of the 64 + 63 near / in-block pairs in LDS, G[pred][anchor] =
+//     (oc - gc) << 7 | code (INT_MIN when the pair is filtered; code 1 .. 64 = the previous block's anchors, 65 + b = anchor b
+//     of the block itself) plus a bit per unfiltered pair; all of them fold the far predecessors (final scores) in units of 16.
+//   * MAIN wave: one key per anchor, score << 7 | code of its best predecessor so far (initially q_span << 7 | 127; the far
+//     maximum enters with code 0): a step is key = max(key, G + (score of the predecessor << 7)) -- v_readlane, v_add, v_max.
+//     The larger code wins a tie, i.e. the NEWER predecessor, as the reference's scan from i - 1 downwards with a strict >
+//     does; a predecessor that merely equals q_span loses to the initial key's code 127, as `sc > max_f` demands.
+//   * max_skip: the certificate of chain_block_body -- at most 25 unfiltered predecessors newer than the argmax -- is
+//     checked AFTER the block from the bit masks (popcounts) instead of a counter in every step; a block in which any anchor
+//     misses it is done again by the legacy code (per-anchor check, exact re-scan through chain_exact_global): on the suite's
+//     inputs that is no block at all, on the adversarial ones a few per cent.
+// Needs: the call's facts (one segment id, 32-bit-exact x, gap table: chain_facts_kernel), 0 <= avg_qspan <= 4096 and at
+// most 65 793 anchors, so that a score (<= 255 n) fits the 24 bits above the code; other calls take the legacy code inside
+// the same kernel.  LDS: 64 KB of G (two blocks in flight) + ~32 KB: one call per CU.
+constexpr int kFastW = 14;                // worker waves
+constexpr int kFastMaxN = 65000;
+constexpr int32_t kFastSane = (1 << 24) - (1 << 15);     // scores the keys can hold with a block's growth to spare (255 * kFastMaxN is below it)
+constexpr size_t kFastDynLds = 2 * 2 * 16 * 64 * 16;     // G[buf][near | block][pred / 4][anchor][4]
+
+// MODE = GAB_CHAIN: as described above.  MODE = GAB_FASTCHAIN: the same machinery for fast-chain's rules (fastchain_body) --
+// truncated 32-bit coordinates with wrap-around, fp32-floor gap cost from the call's table, `x[i] - x[st] > max_dist_x` as the
+// window test, no max_skip (so no certificate).  The legacy code of the block takes over where the keys cannot express the
+// reference: blocks in which some anchor has a window of <= 6 predecessors (the double-precision gap cost of the AVX code's
+// scalar tail), a pair whose |dr - dq| wrapped to INT_MIN, scores that left the 24 bits (only reachable through such wraps).
+template <int MODE>
+__global__ __launch_bounds__(64 * (2 + kFastW))
+void chain_fast_kernel(const ChainWork *__restrict__ work, const uint64_t *__restrict__ xs, const uint64_t *__restrict__ ys, int32_t *score_out,
+                       int32_t *parent_out, int32_t *gmarks_all, unsigned long long *evals_out) {
+    constexpr int NW = kFastW;
+    constexpr bool FC = MODE == GAB_FASTCHAIN;
+    extern __shared__ __attribute__((aligned(16))) uint8_t fast_lds[];
+    int4 *G4 = reinterpret_cast<int4 *>(fast_lds);                                    // [buf][kind][16][64]
+    __shared__ int32_t part_best[2][NW][64], part_j[2][NW][64], part_ok[2][NW][64], part_st[3][64];
+    __shared__ uint16_t okh[2][8][64];                                                // unfiltered-pair bits, 16 pairs per G unit
+    __shared__ int32_t weird[2];                                                      // fast-chain: a G pair wrapped (see above)
+    __shared__ int32_t gap_tab[kGapTab];
+    const ChainWork w = work[blockIdx.x];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const AnchorView<false> X{xs + w.off}, Y{ys + w.off};
+    int32_t *S = score_out + w.off, *P = parent_out + w.off, *GM = FC ? nullptr : gmarks_all + w.off;
+    const int n = (int)w.n;
+    const int32_t mdx = w.max_dist_x, mdy = w.max_dist_y, bw = w.bw;
+    const uint64_t mdx64 = (uint64_t)(int64_t)mdx;
+    const double avg_d = (double)w.avg_qspan;
+    const float k32 = (float)(0.01 * (double)w.avg_qspan);
+    const bool multi_seg = w.n_segs > 1;
+    const bool plain = !FC && (w.pad & 1) != 0;              // chain: chain_facts_kernel's verdict
+    const bool use_tab = FC ? (bw >= 0 && bw <= kGapTab - 2) : plain;
+    const int32_t mq = mdy < mdx ? mdy : mdx;
+    const uint32_t dq_lim = mq < 0 ? 0u : (uint32_t)mq;
+    const bool fast = use_tab && n <= kFastMaxN && w.avg_qspan >= 0.f && w.avg_qspan <= 4096.f && (!FC || dq_lim <= (1u << 20));
+    const int nblocks = (n + 63) / 64;
+    const int NEG = (int)0x80000000;
+    if (use_tab) {
+        for (int d = threadIdx.x; d <= bw + 1; d += 64 * (2 + NW)) {
+            if (FC) {
+                const int32_t dv = d <= bw ? d : NEG;
+                gap_tab[d] = (int32_t)floorf(__fmul_rn((float)dv, k32)) + (15 - (__clz((int)((uint32_t)dv | 1u)) >> 1));
+            } else gap_tab[d] = chain_gap_cost(d, avg_d);
+        }
+    }
+    if (threadIdx.x < 2) weird[threadIdx.x] = 0;
+
+    // ---- the score-independent part of a pair (anchor in this lane, predecessor in lane `src` of pv): oc - gc, and whether
+    // the pair passes the filters.  TAG: chain -- the call's facts hold (plain arithmetic + gap table); fast-chain -- the block
+    // needs the arithmetic gap cost (narrow windows, no table)
+    struct Pred { uint64_t x; uint32_t y; int32_t sid; };
+    struct Anchor { uint64_t x; int32_t q, qs, sid; bool wide; };
+    auto pair = [&](auto tag, const Anchor &A, const Pred &pv, int src, bool &ok, bool &wrapped) -> int32_t {
+        constexpr bool TAG = decltype(tag)::value;
+        const uint32_t xj_lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)pv.x, src);
+        const uint32_t yj = (uint32_t)__builtin_amdgcn_readlane((int)pv.y, src);
+        wrapped = false;
+        if constexpr (FC) {                                  // fastchain_body's score_pred with sj = 0
+            const int32_t ddr = (int32_t)((uint32_t)A.x - xj_lo);
+            const int32_t ddq = (int32_t)((uint32_t)A.q - yj);
+            const int32_t diff = (int32_t)((uint32_t)ddr - (uint32_t)ddq);
+            const int32_t dd = max(diff, (int32_t)(0u - (uint32_t)diff));
+            ok = !(dd > bw || ddr == 0 || (uint32_t)ddq - 1u >= dq_lim);
+            wrapped = dd < 0;
+            const int32_t oc = min(min(ddr, ddq), A.qs);
+            int32_t gc;
+            if constexpr (TAG) {
+                const int32_t lgh = 15 - (__clz((int)((uint32_t)dd | 1u)) >> 1);
+                gc = (int32_t)floorf(__fmul_rn((float)dd, k32)) + lgh;
+                const int32_t gd = (int32_t)__dmul_rn(__dmul_rn((double)dd, .01), avg_d) + lgh;
+                gc = A.wide ? gc : gd;
+            } else gc = gap_tab[min((uint32_t)dd, (uint32_t)bw + 1u)];
+            return (int32_t)((uint32_t)oc - (uint32_t)gc);
+        } else if constexpr (TAG) return chain_geometry_plain((uint32_t)A.x, A.q, A.qs, xj_lo, yj, mdy, dq_lim, bw, multi_seg, gap_tab, ok);
+        else {
+            const uint64_t xj = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(pv.x >> 32), src) << 32) | xj_lo;
+            return chain_geometry(A.x, A.q, A.qs, A.sid, xj, yj, __builtin_amdgcn_readlane(pv.sid, src), mdx, mdy, bw, multi_seg, avg_d, ok);
+        }
+    };
+    auto load_pred = [&](int i, bool valid) {
+        Pred pv = {0, 0, 0};
+        if (valid) { pv.x = X[i]; const uint64_t yy = Y[i]; pv.y = (uint32_t)yy; pv.sid = (int32_t)(yy >> 48 & 0xff); }
+        return pv;
+    };
+    auto anchor_of = [&](uint64_t xa, uint64_t ya, bool wide) { return Anchor{xa, (int32_t)ya, (int32_t)(ya >> 32 & 0xff), (int32_t)(ya >> 48 & 0xff), wide}; };
+    // the window test of the start search: chain host_kernel.cpp:56-57, fast-chain host_kernel.cpp:200-207 (unsigned difference)
+    auto beyond = [&](uint64_t xi, uint64_t xj) { return FC ? (xi - xj) > mdx64 : xi > xj + mdx64; };
+
+    // ---- the search wave's state: st = the pointer after the last anchor searched; XS = x[sb + lane], sb a multiple of 64
+    int st = 0, sb = 0;
+    uint64_t XS = (wave == 1 && lane < n) ? X[lane] : 0;
+    uint64_t XSn = (wave == 1 && 64 + lane < n) ? X[64 + lane] : 0;   // the chunk behind XS, requested when XS was taken
+    uint64_t sxa = XS;                                                  // x of the anchors of the next block to search, requested a block early
+    // the reference's loop, anchor by anchor: the fall-back of search_block
+    auto search_block_seq = [&](int kb, uint64_t xa) {
+        const int i0 = kb * 64;
+        const int nb = n - i0 < 64 ? n - i0 : 64;
+        int st_a = 0;
+        for (int a = 0; a < nb; a++) {
+            const int i = i0 + a;
+            const uint64_t xi = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(xa >> 32), a) << 32) |
+                                (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)xa, a);
+            for (;;) {
+                const int cand = sb + lane;
+                const bool pass = cand < st || (cand < i && beyond(xi, XS));
+                const unsigned long long m = __ballot(pass);
+                if (m == ~0ull) { sb += 64; st = sb; XS = (sb + lane < n) ? X[sb + lane] : 0; continue; }
+                st = sb + __builtin_ctzll(~m);
+                break;
+            }
+            if (i - st > kMaxIter) st = i - kMaxIter;
+            if (st - sb >= 64) { sb = st & ~63; XS = (sb + lane < n) ? X[sb + lane] : 0; }
+            if (lane == a) st_a = st;
+        }
+        return st_a;
+    };
+    auto search_block = [&](int kb) {
+        const int i0 = kb * 64;
+        const int nb = n - i0 < 64 ? n - i0 : 64;
+        const bool mine = lane < nb;
+        const int ia = i0 + lane;
+        const uint64_t xa = mine ? sxa : 0;
+        sxa = ia + 64 < n ? X[ia + 64] : 0;
+#ifdef GAB_KO_SEARCH
+        { part_st[kb % 3][lane] = ia > 200 ? ia - 200 : 0; return; }
+#endif
+        const int S0 = st, sb0 = sb;
+        const uint64_t XS0 = XS;
+        // leading passes of every anchor over the candidates S0, S0 + 1, ... (all of an anchor's candidates are below its own index)
+        bool alive = mine;
+        int cnt = 0;
+        int j = S0;
+        const int jend = i0 + nb;
+        while (j < jend && __ballot(alive)) {
+            if ((j & ~63) != sb) {
+                const bool next = (j & ~63) == sb + 64;
+                sb = j & ~63;
+                XS = next ? XSn : (sb + lane < n) ? X[sb + lane] : 0;
+                XSn = (sb + 64 + lane < n) ? X[sb + 64 + lane] : 0;
+            }
+            const int lim = sb + 64 < jend ? sb + 64 : jend;
+            const uint32_t xlo = (uint32_t)XS, xhi = (uint32_t)(XS >> 32);
+            auto step = [&](int jj) {
+                const uint64_t xj = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)xhi, jj - sb) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)xlo, jj - sb);
+                const bool pass = (jj < ia) & beyond(xa, xj);
+                alive = alive & pass;
+                cnt += alive ? 1 : 0;
+            };
+            for (; j + 4 <= lim; j += 4) { step(j); step(j + 1); step(j + 2); step(j + 3); if (!__ballot(alive)) break; }
+            if (j + 4 > lim) for (; j < lim; j++) step(j);
+        }
+        const int g = S0 + cnt;
+        const int c = mine ? max(g, ia - kMaxIter) : NEG;
+        const int M = max(S0, wave_incl_max(c));
+        const int Mprev = lane == 0 ? S0 : wave_shr1(M, S0);
+        // an anchor that would stop BEFORE the pointer it inherits must stop AT it (true when x ascends)
+        bool bad = false;
+        if (mine && g < Mprev) bad = Mprev < ia && beyond(xa, X[Mprev]);
+        int st_a = M;
+        if (__ballot(bad)) {                                  // unsorted x: the reference's own loop from the block's entry state
+            st = S0; sb = sb0; XS = XS0;
+            st_a = search_block_seq(kb, xa);
+            XSn = (sb + 64 + lane < n) ? X[sb + 64 + lane] : 0;
+        } else {
+            st = __builtin_amdgcn_readlane(M, nb - 1);
+        }
+        part_st[kb % 3][lane] = st_a;
+    };
+    if (wave == 1 && nblocks > 0) search_block(0);
+    __syncthreads();
+
+    int32_t pbest = 0;                                       // main: scores of the previous block
+    uint64_t mnx = (wave == 0 && lane < n) ? X[lane] : 0, mny = (wave == 0 && lane < n) ? Y[lane] : 0, mpx = 0, mpy = 0;    // ... its anchors, a block early
+    bool sane = true;
+    unsigned long long evals = 0;
+    // workers: the block's own x / y arrive one phase early (they are input, not results) and stay one phase longer as the
+    // previous block's: no wait for memory at the top of a phase except for the far predecessors' scores
+    uint64_t nxa = (wave >= 2 && lane < n) ? X[lane] : 0, nya = (wave >= 2 && lane < n) ? Y[lane] : 0, pxa = 0, pya = 0;
+
+    for (int t = -1; t < nblocks; t++) {
+        const int par = (t + 1) & 1;                         // slot of block t + 1 in the two-deep LDS arrays; block t lives in par ^ 1
+        if (wave == 1) {
+            if (t + 2 < nblocks) search_block(t + 2);        // two blocks ahead of the main wave, one ahead of the workers
+        } else if (wave >= 2) {
+            // ------------------------------------------------ workers: block t + 1
+            const int kb = t + 1, wk = wave - 2;
+            if (kb < nblocks) {
+                const int i0 = kb * 64;
+                const int nb = n - i0 < 64 ? n - i0 : 64;
+                const bool mine = lane < nb;
+                const uint64_t xa = nxa, ya = nya;
+                {
+                    const bool more = i0 + 64 + lane < n;
+                    nxa = more ? X[i0 + 64 + lane] : 0; nya = more ? Y[i0 + 64 + lane] : 0;
+                }
+                const int st_a = part_st[kb % 3][lane];
+                const int st_rel = st_a - i0;
+                const int st_lo = __builtin_amdgcn_readfirstlane(st_a);
+                const bool wide_a = !((lane - 1) - st_rel <= 5);
+                const bool arith = FC && (__ballot(mine && !wide_a) != 0 || !use_tab);     // fast-chain: this block takes the arithmetic gap cost
+                const Anchor A = anchor_of(xa, ya, wide_a);
+                // the first far unit's predecessors are requested before the G unit is computed
+                int fu = (wk - 8 + NW) % NW;
+                auto far_load = [&](int fu_, Pred &pv, int32_t &vs) {
+                    const int jl = i0 - 65 - 16 * fu_ - lane;
+                    pv = Pred{0, 0, 0}; vs = 0;
+                    if (lane < 16 && jl >= st_lo) {
+                        pv = load_pred(jl, true);
+                        vs = __hip_atomic_load(&S[jl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                };
+                Pred fpv; int32_t fvs;
+                far_load(fu, fpv, fvs);
+#ifdef GAB_KO_G
+                if (false) {
+#else
+                if (fast && !arith && wk < 8) {
+#endif
+                    // G of 16 predecessors: units 0..3 the previous block's anchors, 4..7 the block's own
+                    const bool nearu = wk < 4;
+                    const int p0 = (wk & 3) * 16;
+                    const Pred pv = nearu ? Pred{pxa, (uint32_t)pya, (int32_t)(pya >> 48 & 0xff)} : Pred{xa, (uint32_t)ya, A.sid};
+                    uint32_t bits = 0;
+                    bool any_wrapped = false;
+                    int4 *dst = G4 + ((size_t)(par * 2 + (nearu ? 0 : 1)) * 16 + (p0 >> 2)) * 64 + lane;
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; g4++) {
+                        int32_t gv[4];
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            const int p = p0 + 4 * g4 + k;
+                            bool ok, wr;
+                            const int32_t v = FC ? pair(std::false_type{}, A, pv, p, ok, wr) : pair(std::true_type{}, A, pv, p, ok, wr);
+                            const int jrel = nearu ? p - 64 : p;
+                            ok = ok & mine & (jrel >= st_rel) & (nearu ? kb > 0 : lane > p);
+                            any_wrapped |= ok & wr;
+                            const int code = nearu ? p + 1 : 65 + p;
+                            gv[k] = ok ? (int32_t)(((uint32_t)v << 7) | (uint32_t)code) : NEG;
+                            bits |= ok ? (1u << (4 * g4 + k)) : 0u;
+                        }
+                        dst[(size_t)g4 * 64] = make_int4(gv[0], gv[1], gv[2], gv[3]);
+                    }
+                    okh[par][wk][lane] = (uint16_t)bits;
+                    if (FC && __ballot(any_wrapped) && lane == 0) weird[par] = 1;
+                }
+                int32_t best = NEG, best_j = -1, nok = 0;
+                // far predecessors j <= i0 - 65 (final since block t - 1) in units of 16, dealt round-robin starting with the
+                // workers that have no G unit
+#ifdef GAB_KO_FAR
+                for (; false; fu += NW) {
+#else
+                for (; i0 - 65 - 16 * fu >= st_lo; fu += NW) {
+#endif
+                    const int jb = i0 - 65 - 16 * fu;
+                    const Pred pv = fpv;
+                    const int32_t vs = fvs;
+                    if (i0 - 65 - 16 * (fu + NW) >= st_lo) far_load(fu + NW, fpv, fvs);      // the next unit's, under this one's arithmetic
+                    const int cnt = jb - st_lo + 1 < 16 ? jb - st_lo + 1 : 16;
+                    const int jrel0 = jb - i0;
+                    auto far_unit = [&](auto tag) {
+                        auto step = [&](int l) {
+                            bool ok, wr;
+                            int32_t sc = (int32_t)((uint32_t)pair(tag, A, pv, l, ok, wr) + (uint32_t)__builtin_amdgcn_readlane(vs, l));
+                            asm volatile("" : "+v"(sc));
+                            const int jrel = jrel0 - l;
+                            const bool okk = ok & mine & (jrel >= st_rel);
+                            if (!FC) nok += okk ? 1 : 0;
+                            const bool up = okk & (sc > best);
+                            best = up ? sc : best; best_j = up ? jrel : best_j;
+                        };
+                        int l = 0;
+                        for (; l + 3 < cnt; l += 4) { step(l); step(l + 1); step(l + 2); step(l + 3); }
+                        for (; l < cnt; l++) step(l);
+                    };
+                    if (FC ? arith : plain) far_unit(std::true_type{}); else far_unit(std::false_type{});
+                }
+                part_best[par][wk][lane] = best; part_j[par][wk][lane] = best_j; part_ok[par][wk][lane] = nok;
+                pxa = xa; pya = ya;
+            }
+        } else if (t >= 0) {
+            // ------------------------------------------------ main wave: block t
+            const int i0 = t * 64;
+            const int nb = n - i0 < 64 ? n - i0 : 64;
+            const bool mine = lane < nb;
+            const int st_rel = part_st[t % 3][lane] - i0;
+            if (mine) evals += (unsigned long long)(lane - st_rel);
+            constexpr int kNoJ = (int)0x80000000;
+            const uint64_t xa64 = mnx, ya64 = mny;
+            {
+                const bool more = i0 + 64 + lane < n;
+                mnx = more ? X[i0 + 64 + lane] : 0; mny = more ? Y[i0 + 64 + lane] : 0;
+            }
+            const int32_t qsa = mine ? (int32_t)(ya64 >> 32 & 0xff) : 0;
+            const bool wide_a = !((lane - 1) - st_rel <= 5);
+            const bool arith = FC && (__ballot(mine && !wide_a) != 0 || !use_tab);
+            // the workers' far maxima: units interleave, so the larger j wins a tie; thr0 = the score to reach, j0 = argmax
+            // (relative to i0) or none; chain: all far unfiltered ones count as risk
+            int32_t thr0 = qsa + 1, j0 = kNoJ, risk0 = 0;
+#pragma unroll
+            for (int hh = 0; hh < NW; hh++) {
+                const int32_t b2 = part_best[par ^ 1][hh][lane], j2 = part_j[par ^ 1][hh][lane];
+                if (!FC) risk0 += part_ok[par ^ 1][hh][lane];
+                if (b2 >= thr0 && !(j0 != kNoJ && b2 == thr0 && j2 < j0)) { thr0 = b2; j0 = j2; }
+            }
+            // scores the keys cannot hold: only ever produced by fast-chain's wrapped arithmetic; the call stays with the legacy code then
+            sane = sane && __ballot(mine && ((uint32_t)pbest >= (uint32_t)kFastSane || (j0 != kNoJ && (uint32_t)thr0 >= (uint32_t)kFastSane))) == 0;
+            int32_t best = 0, best_jrel = kNoJ;
+            bool redo = !fast || arith || !sane || (FC && weird[par ^ 1] != 0);
+#ifdef GAB_KO_MAIN
+            if (false) {
+#else
+            if (!redo) {
+#endif
+                const int32_t initkey = (qsa << 7) | 127;
+                int32_t key = j0 != kNoJ ? max(initkey, thr0 << 7) : initkey;
+                const int4 *gn = G4 + ((size_t)((par ^ 1) * 2 + 0) * 16) * 64 + lane;
+                const int4 *gb = G4 + ((size_t)((par ^ 1) * 2 + 1) * 16) * 64 + lane;
+                const int32_t pkey = pbest << 7;
+#pragma unroll
+                for (int g4 = 0; g4 < 16; g4++) {            // the previous block: no dependence between the steps
+                    const int4 g = gn[(size_t)g4 * 64];
+                    key = max(key, g.x + __builtin_amdgcn_readlane(pkey, 4 * g4));
+                    key = max(key, g.y + __builtin_amdgcn_readlane(pkey, 4 * g4 + 1));
+                    key = max(key, g.z + __builtin_amdgcn_readlane(pkey, 4 * g4 + 2));
+                    key = max(key, g.w + __builtin_amdgcn_readlane(pkey, 4 * g4 + 3));
+                }
+#pragma unroll
+                for (int g4 = 0; g4 < 16; g4++) {            // the block itself: anchor b is final once 0 .. b - 1 are folded
+                    const int4 g = gb[(size_t)g4 * 64];
+                    key = max(key, g.x + (__builtin_amdgcn_readlane(key, 4 * g4) & ~127));
+                    key = max(key, g.y + (__builtin_amdgcn_readlane(key, 4 * g4 + 1) & ~127));
+                    key = max(key, g.z + (__builtin_amdgcn_readlane(key, 4 * g4 + 2) & ~127));
+                    if (g4 < 15) key = max(key, g.w + (__builtin_amdgcn_readlane(key, 4 * g4 + 3) & ~127));
+                }
+                const bool none = key == initkey;
+                const int code = key & 127;
+                best = key >> 7;
+                best_jrel = none ? kNoJ : code ? code - 65 : j0;
+                if (!FC) {
+                    // the certificate: unfiltered pairs newer than the argmax -- pair numbers code .. 126 (pair c = code - 1 is the
+                    // argmax); for a far argmax all of them plus every far one
+                    int32_t risk = code ? 0 : risk0;
+#pragma unroll
+                    for (int wd = 0; wd < 4; wd++) {
+                        const uint32_t bits = (uint32_t)okh[par ^ 1][2 * wd][lane] | ((uint32_t)okh[par ^ 1][2 * wd + 1][lane] << 16);
+                        const uint32_t m = code <= 32 * wd ? ~0u : code >= 32 * wd + 32 ? 0u : (~0u << (code - 32 * wd));
+                        risk += __popc(bits & m);
+                    }
+                    redo = __ballot(mine && !none && risk > kMaxSkip) != 0;
+                }
+            }
+            if (redo) {
+                // the legacy block: geometry in this wave; chain: the certificate per anchor, the reference's own scan on a miss
+                const Pred cur = {xa64, (uint32_t)ya64, (int32_t)(ya64 >> 48 & 0xff)}, prev = {mpx, (uint32_t)mpy, (int32_t)(mpy >> 48 & 0xff)};
+                const Anchor A = anchor_of(xa64, ya64, wide_a);
+                const int pnb = t > 0 ? 64 : 0;
+                int32_t thr = thr0, best_j = j0, risk = risk0;
+                auto fold = [&](int32_t sc, bool ok, int jrel) {
+                    asm volatile("" : "+v"(sc));
+                    const bool up = ok & (sc >= thr);
+                    risk = up ? 0 : risk + (ok ? 1 : 0);
+                    thr = up ? sc : thr; best_j = up ? jrel : best_j;
+                };
+                auto score_of = [&](int b) { return __builtin_amdgcn_readlane(thr, b) - (__builtin_amdgcn_readlane(best_j, b) == kNoJ ? 1 : 0); };
+                auto near_fold = [&](auto tag) {
+                    for (int l = 0; l < pnb; l++) {                      // oldest first: a newer predecessor wins a tie (>=)
+                        bool ok, wr;
+                        const int32_t sc = (int32_t)((uint32_t)pair(tag, A, prev, l, ok, wr) + (uint32_t)__builtin_amdgcn_readlane(pbest, l));
+                        fold(sc, ok & mine & (l - 64 >= st_rel), l - 64);
+                    }
+                };
+                if (FC ? arith : plain) near_fold(std::true_type{}); else near_fold(std::false_type{});
+                auto finalize = [&](int b) {
+                    if constexpr (!FC) {
+                        const int rb = __builtin_amdgcn_readlane(risk, b);
+                        if (rb > kMaxSkip && __builtin_amdgcn_readlane(best_j, b) != kNoJ) {
+                            if (mine && lane < b) { S[i0 + lane] = thr - (best_j == kNoJ ? 1 : 0); P[i0 + lane] = best_j == kNoJ ? -1 : i0 + best_j; }
+                            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                            int32_t eb, ej;
+                            chain_exact_global(X, Y, S, P, GM, i0 + b, i0 + __builtin_amdgcn_readlane(st_rel, b), mdx, mdy, bw, multi_seg, avg_d, eb, ej, evals);
+                            if (lane == b) { thr = ej >= 0 ? eb : eb + 1; best_j = ej >= 0 ? ej - i0 : kNoJ; risk = 0; }
+                        }
+                    }
+                };
+                auto block_fold = [&](auto tag) {
+                    for (int b = 0; b < nb; b++) {
+                        finalize(b);
+                        if (b + 1 < nb) {
+                            bool ok, wr;
+                            const int32_t gg = pair(tag, A, cur, b, ok, wr);
+                            fold((int32_t)((uint32_t)gg + (uint32_t)score_of(b)), ok & mine & (lane > b) & (b >= st_rel), b);
+                        }
+                    }
+                };
+                if (FC ? arith : plain) block_fold(std::true_type{}); else block_fold(std::false_type{});
+                best = thr - (best_j == kNoJ ? 1 : 0);
+                best_jrel = best_j;
+            }
+            if (mine) { S[i0 + lane] = best; P[i0 + lane] = best_jrel == kNoJ ? -1 : i0 + best_jrel; }
+            pbest = best;
+            mpx = xa64; mpy = ya64;
+            if (FC && lane == 0) weird[par ^ 1] = 0;          // (the workers set the other slot in this phase)
+        }
+        __syncthreads();
+    }
+    for (int o = 32; o > 0; o >>= 1) evals += __shfl_xor(evals, o);
+    if (lane == 0 && evals) atomicAdd(evals_out, evals);
+}
+
 }  // namespace
 
 // =============================================================================== host side
@@ -1235,6 +1675,8 @@ struct gab_chain {
     hipEvent_t ev[2] = {nullptr, nullptr};
     // the host-pointer entry point of big batches: two more streams and the events that order its copies and kernels
     hipStream_t xs[2] = {nullptr, nullptr};
+    hipStream_t fs = nullptr;                // the latency-form launch of the longest calls runs beside the throughput launch of the rest
+    hipEvent_t fe[2] = {nullptr, nullptr};
     hipEvent_t xe[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     unsigned long long *h_evals = nullptr;   // pinned: evals, (spare), abort word of the fed path
     uint8_t *h_started = nullptr;            // pinned: one byte per workgroup of chain_gather_kernel
@@ -1266,6 +1708,8 @@ extern "C" void gab_chain_destroy(gab_chain *h) {
     h->work.release(); h->io.release(); h->hs.release(); h->gmarks.release();
     for (int k = 0; k < 2; k++) if (h->ev[k]) (void)hipEventDestroy(h->ev[k]);
     for (int k = 0; k < 2; k++) if (h->xs[k]) (void)hipStreamDestroy(h->xs[k]);
+    if (h->fs) (void)hipStreamDestroy(h->fs);
+    for (int k = 0; k < 2; k++) if (h->fe[k]) (void)hipEventDestroy(h->fe[k]);
     for (int k = 0; k < 5; k++) if (h->xe[k]) (void)hipEventDestroy(h->xe[k]);
     if (h->h_evals) (void)hipHostFree(h->h_evals);
     if (h->h_started) (void)hipHostFree(h->h_started);
@@ -1373,6 +1817,51 @@ extern "C" int gab_chain_run_device(gab_chain *h, int mode, const uint64_t *d_x,
         GAB_HIP(hipMemsetAsync(d_gm, 0, sizeof(int32_t) * (size_t)total, s));      // vector::resize zero-fills targets
     }
     GAB_HIP(hipEventRecord(h->ev[0], s));
+    // The longest calls (the list is sorted) go to the latency form (chain_fast_kernel: one call per CU, sixteen waves), the
+    // rest to the throughput form, side by side on two streams -- when the batch would otherwise wait for its longest call:
+    // the throughput form takes ~0.30 us per anchor of a call however empty the chip is and does ~2.85 G anchors/s over all
+    // calls; a batch whose longest call needs more than 0.75 of the batch's throughput time hands every call above a third of
+    // that time's worth of anchors to the latency form (chain-large on one GPU: none; an eighth of it: every call above ~3 700
+    // anchors; the 1 000-call input: above ~2 900).  GAB_CHAIN_FAST_MIN / GAB_CHAIN_FAST_CALLS pin the choice (tests, A/B runs).
+    size_t nfast = 0;
+    if (!(mode == GAB_CHAIN && getenv("GAB_CHAIN_KERNEL") && !strcmp(getenv("GAB_CHAIN_KERNEL"), "walk")) && !getenv("GAB_CHAIN_HELPERS")) {
+        int64_t min_n = 0, max_calls = 0;
+        const double est_tp = (double)total / 2.85e9, lat_max = 0.30e-6 * (double)wk[0].n;
+        if (lat_max >= 0.75 * est_tp) { min_n = std::max<int64_t>(1024, total / 2850); max_calls = (int64_t)nw; }
+        if (getenv("GAB_CHAIN_FAST_MIN")) min_n = atoll(getenv("GAB_CHAIN_FAST_MIN"));
+        if (getenv("GAB_CHAIN_FAST_CALLS")) max_calls = atoll(getenv("GAB_CHAIN_FAST_CALLS"));
+        if (getenv("GAB_CHAIN_FAST_MIN") && !getenv("GAB_CHAIN_FAST_CALLS")) max_calls = (int64_t)nw;
+        while (nfast < nw && (int64_t)nfast < max_calls && wk[nfast].n >= min_n) nfast++;
+    }
+    if (nfast) {
+        if (!h->fs) {
+            if (hipStreamCreateWithFlags(&h->fs, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&h->fe[0], hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&h->fe[1], hipEventDisableTiming) != hipSuccess ||
+                hipFuncSetAttribute((const void *)chain_fast_kernel<GAB_CHAIN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFastDynLds) != hipSuccess ||
+                hipFuncSetAttribute((const void *)chain_fast_kernel<GAB_FASTCHAIN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFastDynLds) != hipSuccess) {
+                gab_set_error("gab_chain: stream / event / LDS attribute of the latency-form kernel failed"); return GAB_EDEVICE;
+            }
+        }
+        const ChainFeed nofeed{nullptr, nullptr, nullptr, nullptr, nullptr};
+        if (mode == GAB_CHAIN) hipLaunchKernelGGL(chain_facts_kernel, dim3((unsigned)nw), dim3(256), 0, s, d_work, d_x, d_y);
+        GAB_HIP(hipEventRecord(h->fe[0], s));
+        GAB_HIP(hipStreamWaitEvent(h->fs, h->fe[0], 0));
+        if (mode == GAB_CHAIN)
+            hipLaunchKernelGGL(chain_fast_kernel<GAB_CHAIN>, dim3((unsigned)nfast), dim3(64 * (2 + kFastW)), kFastDynLds, h->fs, d_work, d_x, d_y, d_score, d_parent, d_gm, d_ev);
+        else
+            hipLaunchKernelGGL(chain_fast_kernel<GAB_FASTCHAIN>, dim3((unsigned)nfast), dim3(64 * (2 + kFastW)), kFastDynLds, h->fs, d_work, d_x, d_y, d_score, d_parent, d_gm, d_ev);
+        GAB_HIP(hipGetLastError());
+        GAB_HIP(hipEventRecord(h->fe[1], h->fs));
+        if (nw > nfast) {
+            if (mode == GAB_CHAIN)
+                hipLaunchKernelGGL((chain_block_kernel<kCbHelpers, false>), dim3((unsigned)(nw - nfast)), dim3(64 * (1 + kCbHelpers)), 0, s, d_work + nfast, d_x, d_y,
+                                   d_score, d_parent, d_gm, d_ev, nofeed);
+            else
+                hipLaunchKernelGGL((fastchain_kernel<kFcHelpers, false>), dim3((unsigned)(nw - nfast)), dim3(64 * (1 + kFcHelpers)), 0, s, d_work + nfast, d_x, d_y,
+                                   d_score, d_parent, d_ev, nofeed);
+        }
+        GAB_HIP(hipStreamWaitEvent(s, h->fe[1], 0));
+    } else
     chain_launch(mode, chain_helpers_for(total, wk.empty() ? 0 : wk[0].n), s, d_work, (unsigned)nw, d_x, d_y, d_score, d_parent, d_gm, d_ev);
     GAB_HIP(hipGetLastError());
     GAB_HIP(hipEventRecord(h->ev[1], s));

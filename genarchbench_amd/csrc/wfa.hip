@@ -1318,6 +1318,7 @@ extern "C" int gab_wfa_run_packed(gab_wfa *h, const char *pat, const int64_t *pa
     const size_t o_ol = o; o += 4 * nn;
     const size_t o_cl = o; o += 4 * nn;
     const size_t o_sc = o; o += 4 * nn;
+    o = (o + 255) & ~(size_t)255;                  // (a 64-bit atomic lives here)
     const size_t o_cur = o; o += 256;
     int rc = h->io.reserve(o);
     if (rc) return rc;
@@ -1379,7 +1380,17 @@ extern "C" int gab_wfa_reserve(gab_wfa *h, int64_t max_pairs, int64_t max_seq_by
     GAB_HIP(hipMemsetAsync(h->io.p, 0, h->io.cap, s));
     GAB_HIP(hipMemsetAsync(h->ws.p, 0, h->ws.cap, s));
     GAB_HIP(hipStreamSynchronize(s));
-    return gab_warm_copy_engines(s, h->io.p);
+    if ((rc = gab_warm_copy_engines(s, h->io.p)) != GAB_OK) return rc;
+    // ... and one tiny batch through the whole path: the first launch of a kernel pays for loading the code object and for
+    // the runtime's per-kernel bookkeeping (milliseconds, once per process and handle) -- not inside the caller's ROI
+    static const char seq[] = "ACGTTGCAACGTACGTTGCATGCAACGTACGT" "ACGTTGCAACCTACGTTGCATGAACGTACGTA";
+    const int64_t po[4] = {0, 0, 32, 32}, to[4] = {32, 0, 0, 32};
+    const int32_t pl[4] = {32, 32, 33, 5}, tl[4] = {33, 32, 32, 7};
+    char text[256]; int64_t coff[4], bytes = 0; int32_t clen[4], sc[4];
+    const bool had = h->have_stats;
+    rc = gab_wfa_run_packed(h, seq, po, pl, seq, to, tl, 4, text, (int64_t)sizeof text, coff, clen, sc, &bytes);
+    h->have_stats = had;
+    return rc;
 }
 
 extern "C" int gab_wfa_last_stats(gab_wfa *h, int64_t *work, int64_t *requeued, float *first_pass_ms, float *total_ms) {

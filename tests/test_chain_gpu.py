@@ -9,6 +9,18 @@ from tests.util import GOLDEN, read_chain_output
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=["default-split", "latency-form-for-all", "throughput-form-for-all"])
+def kernel_choice(request, monkeypatch):
+    """chain: the longest calls of a batch (>= 4096 anchors) run in the latency form (chain_fast_kernel: geometry prepared by the
+    helper waves, key-max fold, certificate by popcount), the rest in the throughput form.  Every test of this file runs with
+    the default split (by the batch-shape rule of gab_chain_run_device), with EVERY call in the latency form and with none -- chain and fast-chain alike."""
+    if request.param == "latency-form-for-all":
+        monkeypatch.setenv("GAB_CHAIN_FAST_MIN", "1"); monkeypatch.setenv("GAB_CHAIN_FAST_CALLS", "1000000000")
+    elif request.param == "throughput-form-for-all":
+        monkeypatch.setenv("GAB_CHAIN_FAST_CALLS", "0")
+    return request.param
+
+
 @pytest.fixture(scope="module")
 def eng():
     from genarchbench_amd.chain import ChainEngine

@@ -248,6 +248,19 @@ class PairBatch:
         tl = np.where(swap, self.pat_len, self.txt_len).astype(np.int32)
         return PairBatch(slab, po, pl, slab, to, tl)
 
+    def interleaved(self, gap=2):
+        """the same pairs in ONE slab laid out like the drivers' input file: pattern i, text i, pattern i + 1, ... with
+        `gap` bytes between sequences (the file's "\\n<" / "\\n>"); the window of a chunk of pairs is then contiguous"""
+        L = lib()
+        n = self.n
+        po = np.empty(n, np.int64); to = np.empty(n, np.int64)
+        args = [_p(self.pat), _p(self.pat_off), _p(self.pat_len), _p(self.txt), _p(self.txt_off), _p(self.txt_len), C.c_int64(n), C.c_int(gap)]
+        L.gab_gen_interleave.restype = C.c_int64
+        total = L.gab_gen_interleave(*args, None, _p(po), _p(to))
+        slab = np.zeros(total + 16, np.uint8)
+        L.gab_gen_interleave(*args, _p(slab), _p(po), _p(to))
+        return PairBatch(slab, po, self.pat_len, slab, to, self.txt_len)
+
     def write_text(self, path):
         with open(path, "wb") as f:
             for i in range(self.n):

@@ -299,6 +299,25 @@ void gab_gen_chain_fill_ids(uint64_t seed, int mode, const int64_t *ids, int64_t
     }
 }
 
+/* the pairs of a batch laid out as the drivers' input file has them: pattern i directly followed by text i (plus `gap`
+ * bytes where the file has "\n<" resp. "\n>"); out_poff / out_toff receive the new offsets.  Returns the bytes used. */
+int64_t gab_gen_interleave(const uint8_t *pat, const int64_t *pat_off, const int32_t *pat_len, const uint8_t *txt,
+                           const int64_t *txt_off, const int32_t *txt_len, int64_t n, int gap, uint8_t *out,
+                           int64_t *out_poff, int64_t *out_toff) {
+    int64_t at = gap;
+    for (int64_t i = 0; i < n; i++) {
+        out_poff[i] = at; at += pat_len[i] + gap;
+        out_toff[i] = at; at += txt_len[i] + gap;
+    }
+    if (!out) return at;
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; i++) {
+        memcpy(out + out_poff[i], pat + pat_off[i], (size_t)pat_len[i]);
+        memcpy(out + out_toff[i], txt + txt_off[i], (size_t)txt_len[i]);
+    }
+    return at;
+}
+
 /* decimal text of v into p, returns the end (fprintf per anchor made the 85 M-anchor file take minutes) */
 static char *put_u64(char *p, uint64_t v) {
     char t[24]; int k = 0;
