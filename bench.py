@@ -1243,6 +1243,9 @@ def plan_shard(W, items, ctx, scaling):
     (split across the ranks) and the per-rank size under weak scaling."""
     from genarchbench_amd.shard import deal_longest_first, shard_range, shard_strong
     rank, world = ctx["rank"], ctx["world"]
+    if ctx.get("emulate"):                                     # --shard R/N: rank R's share of an N-GPU strong-scaling run, on this one GPU
+        rank, world = ctx["emulate"]
+        scaling = "strong"
     if world == 1:
         return items, 0, None, items
     if scaling == "weak":
@@ -1306,7 +1309,10 @@ def run_workload(W, items, steps, warmup, ctx, args, with_cpu=True, with_host=Tr
         ms = elapsed / steps * 1e3
         value = total_units / (ms * 1e-3) / 1e6       # units of all ranks / max-over-ranks time
         large = items == W.default_items
-        sharding = ("1 GPU" if world == 1 else
+        if ctx.get("emulate"):
+            out_shard = "rank %d's share of a %d-GPU strong-scaling run (--shard), processed on ONE GPU: %d of %d items" % (
+                ctx["emulate"][0], ctx["emulate"][1], count if ids is None else len(ids), items)
+        sharding = (out_shard if ctx.get("emulate") else "1 GPU" if world == 1 else
                     f"strong: the fixed input of {total} items split across {world} ranks" +
                     (", calls dealt longest first to the least-loaded rank" if ids is not None else ", contiguous id ranges") +
                     ", no collective" if scaling == "strong" else
@@ -1328,7 +1334,7 @@ def run_workload(W, items, steps, warmup, ctx, args, with_cpu=True, with_host=Tr
         if per_rank:
             out["extra"]["per_rank"] = per_rank
         km = out["extra"].get("dominant_kernel_ms")
-        t, detail = pmc_traffic(W.name, large and world == 1, km)
+        t, detail = pmc_traffic(W.name, large and world == 1 and not ctx.get("emulate"), km)
         if t is not None:
             out["roofline"]["traffic"] = t                  # GB/s of real HBM traffic, comparable with `achieved`
             out["roofline"]["traffic_detail"] = detail
@@ -1447,6 +1453,9 @@ def main():
     ap.add_argument("--scaling", choices=("strong", "weak"), default="strong",
                     help="with --gpus N > 1: strong = ONE large input split across the N GPUs (default, BASELINE.json configs[4]); "
                          "weak = every GPU gets a full-size input of its own")
+    ap.add_argument("--shard", default=None, metavar="R/N",
+                    help="(one GPU) process only rank R's share of an N-GPU strong-scaling run: what that rank would spend; "
+                         "T / max over R of these times is the N-GPU figure the sharding can reach")
     ap.add_argument("--no-suite", action="store_true", help="headline only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-roi", action="store_true")
@@ -1486,6 +1495,12 @@ def main():
     dev = torch.device("cuda", local_rank if world > 1 and not share else 0)
     torch.cuda.set_device(dev)
     ctx = {"rank": rank, "world": world, "dev": dev, "dist": dist, "agg_dev": None if share else dev, "share": share}
+    if args.shard:
+        if world != 1:
+            raise SystemExit("bench.py: --shard emulates one rank of an N-GPU run on ONE GPU (use it with --gpus 1)")
+        r_, n_ = (int(v) for v in args.shard.split("/"))
+        assert 0 <= r_ < n_
+        ctx["emulate"] = (r_, n_)
     share_dir = None
     if world > 1:                                  # a directory all ranks of this node see (rank 0's FM-index file)
         base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else tempfile.gettempdir()
@@ -1499,7 +1514,7 @@ def main():
         out = run_workload(W, args.items or W.default_items, args.steps, args.warmup, ctx, args)
 
         suite = {}
-        if args.workload is None and not args.items and not args.no_suite:
+        if args.workload is None and not args.items and not args.no_suite and not args.shard:
             for name, wname, items, steps in SUITE:
                 go = [time.time() - t_start < SUITE_BUDGET_S]
                 if world > 1:

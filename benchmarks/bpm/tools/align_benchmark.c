@@ -154,7 +154,7 @@ int main(int argc, char **argv) {
         if (hi - lo + 512 > ctx.max_seq_bytes) ctx.max_seq_bytes = hi - lo + 512;
     }
     gab_pin(p.slab, p.used); gab_pin(ctx.poff, 8 * (size_t)p.n); gab_pin(ctx.toff, 8 * (size_t)p.n);
-    gab_pin(ctx.plen, 4 * (size_t)p.n); gab_pin(ctx.tlen, 4 * (size_t)p.n); gab_pin(ctx.score, 4 * (size_t)p.n);
+    gab_pin(ctx.plen, 4 * (size_t)p.n); gab_pin(ctx.tlen, 4 * (size_t)p.n); gab_pin_out(ctx.score, 4 * (size_t)p.n);
     gab_queue q;
     gab_queue_open(&q, ngpus, (p.n + ctx.chunk - 1) / ctx.chunk, gpu_init, run_chunk, gpu_fini, &ctx);
     const double t0 = gab_now();                 /* ROI: align_benchmark.c:213-337 */

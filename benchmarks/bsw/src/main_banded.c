@@ -193,7 +193,7 @@ int main(int argc, char *argv[]) {
     /* the slabs the ROI reads and writes are page-locked where the reference _mm_malloc's its own (main_banded.cpp:260-264) */
     gab_pin(ref, refUsed + 8); gab_pin(qry, qryUsed + 8);
     gab_pin(ref_off, 8 * (size_t)n); gab_pin(qry_off, 8 * (size_t)n);
-    gab_pin(len1, 4 * (size_t)n); gab_pin(len2, 4 * (size_t)n); gab_pin(h0, 4 * (size_t)n); gab_pin(score, 4 * (size_t)n);
+    gab_pin(len1, 4 * (size_t)n); gab_pin(len2, 4 * (size_t)n); gab_pin(h0, 4 * (size_t)n); gab_pin_out(score, 4 * (size_t)n);
     gab_queue q;
     gab_queue_open(&q, ngpus, (n + ctx.chunk - 1) / ctx.chunk, gpu_init, run_chunk, gpu_fini, &ctx);     /* like `new BandedPairWiseSW` per thread: before the ROI */
     ctx.busy = (double *)calloc((size_t)q.nworkers, sizeof(double));

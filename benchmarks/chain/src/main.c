@@ -187,7 +187,7 @@ int main(int argc, char **argv) {
         if (a > ctx.max_chunk_anchors) ctx.max_chunk_anchors = a;
         if (e - b > ctx.max_chunk_calls) ctx.max_chunk_calls = e - b;
     }
-    gab_pin(x, 8 * na); gab_pin(y, 8 * na); gab_pin(ctx.score, 4 * na); gab_pin(ctx.parent, 4 * na);
+    gab_pin(x, 8 * na); gab_pin(y, 8 * na); gab_pin_out(ctx.score, 4 * na); gab_pin_out(ctx.parent, 4 * na);
     gab_queue q;
     gab_queue_open(&q, ngpus, nchunks, gpu_init, run_chunk, gpu_fini, &ctx);
 

@@ -160,6 +160,20 @@ static inline void gab_pin(const void *p, size_t bytes) {
     if (gab_env_i64("GAB_NO_PIN", 0)) return;
     if (gab_host_register((void *)p, bytes) != 0) fprintf(stderr, "note: could not page-lock %zu bytes (%s); copies will be staged\n", bytes, gab_last_error());
 }
+/* the same for a slab the ROI WRITES (scores, CIGAR text ...): fresh malloc'ed memory has no pages behind it yet, and the first
+ * device-to-host copy into such a buffer was measured at ~10 ms for 5 MB (wfa driver, once per process) against 0.1 ms for the
+ * next one -- the pages are touched here, before the ROI, as calloc would (that alone changes nothing: see below) */
+static inline void gab_pin_out(void *p, size_t bytes) {
+    memset(p, 0, bytes);
+    gab_pin(p, bytes);
+    /* ... and the first device-to-host copy of more than a few MB into a freshly page-locked region costs ~10 ms, once
+     * (wfa driver: 10.8 ms for the first 5.3 MB of CIGAR text, 0.1 ms for every later chunk; ROI 16.1 -> 9.2 ms with this):
+     * one copy of up to 16 MB from the first GPU, before the ROI.  GAB_NO_OUT_WARM=1 to compare. */
+    if (gab_env_i64("GAB_NO_OUT_WARM", 0) || gab_env_i64("GAB_NO_PIN", 0)) return;
+    void *d = NULL;
+    const size_t wb = bytes < ((size_t)16 << 20) ? bytes : ((size_t)16 << 20);
+    if (wb && gab_device_alloc(0, wb, &d) == 0) { (void)gab_device_copy_to_host(0, p, d, wb); gab_device_free(0, d); }
+}
 static inline void gab_unpin(const void *p) { if (!gab_env_i64("GAB_NO_PIN", 0)) gab_host_unregister((void *)p); }
 
 /* ---- per-GPU work queue ---------------------------------------------------------------------- */

@@ -179,8 +179,8 @@ int main(int argc, char **argv) {
     if (!ctx.cig && !ctx.ops) { fprintf(stderr, "ERROR: out of memory\n"); exit(EXIT_FAILURE); }
     gab_pin(p.slab, p.used); gab_pin(p.off1, 8 * (size_t)p.n); gab_pin(p.off2, 8 * (size_t)p.n); gab_pin(p.len1, 4 * (size_t)p.n);
     gab_pin(p.len2, 4 * (size_t)p.n); gab_pin(ctx.ops_off, 8 * (size_t)p.n);
-    if (ctx.packed) gab_pin(ctx.cig, (size_t)ctx.cig_beg[nchunks] + 16); else gab_pin(ctx.ops, (size_t)tot + 16);
-    gab_pin(ctx.ops_len, 4 * (size_t)p.n); gab_pin(ctx.score, 4 * (size_t)p.n);
+    if (ctx.packed) gab_pin_out(ctx.cig, (size_t)ctx.cig_beg[nchunks] + 16); else gab_pin_out(ctx.ops, (size_t)tot + 16);
+    gab_pin_out(ctx.ops_len, 4 * (size_t)p.n); gab_pin_out(ctx.score, 4 * (size_t)p.n);
     gab_queue q;
     gab_queue_open(&q, ngpus, nchunks, gpu_init, run_chunk, gpu_fini, &ctx);
     for (int64_t rep = gab_env_i64("GAB_ROI_WARMUPS", 0); rep > 0; rep--) gab_queue_run(&q, nchunks);       /* diagnosis only: untimed passes before the ROI */

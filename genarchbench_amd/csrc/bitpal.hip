@@ -534,7 +534,7 @@ extern "C" int gab_bitpal_reserve(gab_bitpal *h, int64_t max_pairs, int64_t max_
     GAB_HIP(hipMemsetAsync(h->io.p, 0, h->io.cap, s));
     GAB_HIP(hipMemsetAsync(h->ws.p, 0, h->ws.cap, s));
     GAB_HIP(hipStreamSynchronize(s));
-    return gab_warm_copy_engines(s, h->io.p);
+    return gab_warm_copy_engines(s, h->io.p, h->io.cap);
 }
 
 extern "C" int gab_bitpal_last_stats(gab_bitpal *h, int64_t *cells, int64_t *long_pairs, float *kernel_ms, float *total_ms) {

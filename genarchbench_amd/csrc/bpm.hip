@@ -1053,7 +1053,7 @@ extern "C" int gab_bpm_reserve(gab_bpm *h, int64_t max_pairs, int64_t max_seq_by
     GAB_HIP(hipMemsetAsync(h->io.p, 0, h->io.cap, s));
     GAB_HIP(hipMemsetAsync(h->ws.p, 0, h->ws.cap, s));
     GAB_HIP(hipStreamSynchronize(s));
-    return gab_warm_copy_engines(s, h->io.p);
+    return gab_warm_copy_engines(s, h->io.p, h->io.cap);
 }
 
 extern "C" int gab_bpm_last_stats(gab_bpm *h, int64_t *block_steps, int64_t *full_pairs, float *score_kernel_ms,

@@ -23,6 +23,7 @@
 // ~7.4 k cells per ~210 input bytes); HBM traffic is the algorithmic minimum
 // len1 + len2 + 12 B per pair plus the 4-byte permutation entry.
 #include "gab_internal.h"
+#include <atomic>
 #include <algorithm>
 #include <new>
 #include <string.h>
@@ -56,7 +57,8 @@ struct BswIO {
     const uint8_t *qry; const int64_t *qry_off;
     const int32_t *len1, *len2, *h0;
     int64_t ref_bytes, qry_bytes, n;
-};
+    int64_t ref_lo, qry_lo;        // lowest readable offset of the two slabs (0 for a caller's device slabs; the staged window's
+};                                 // start when gab_bsw_run has copied only the part of the host slabs it expects the pairs to use)
 
 // (query length, reference length / 8, h0 / 32): lanes of a wave then run the same number of rows AND start with bands of
 // similar width (row -1 is non-zero up to column ~h0, and the band stays ~2 x score wide until it reaches w)
@@ -83,11 +85,12 @@ __global__ __launch_bounds__(256) void bsw_hist(BswIO io, uint32_t *hist, uint32
         int ql = io.len2[i], tl = io.len1[i], h = io.h0[i];
         int64_t ro = io.ref_off[i], qo = io.qry_off[i];
         bool ok = ql >= 1 && ql <= GAB_BSW_MAX_QLEN && tl >= 1 && tl <= GAB_BSW_MAX_TLEN && h >= 0 &&
-                  h <= (1 << 29) && ro >= 0 && qo >= 0 &&
+                  h <= (1 << 29) && ro >= io.ref_lo && qo >= io.qry_lo &&
                   ro + tl + 3 <= io.ref_bytes && qo + ql + 3 <= io.qry_bytes;     // (the kernels read dwords from the sequence's own start)
         if (!ok) {
             atomicAdd(&st->bad, 1);
             atomicMin((unsigned int *)&st->first_bad, (unsigned int)(i + 1 > 0x7fffffff ? 0x7fffffff : i + 1));
+            rank[i] = ~0u;                 // (the scatter pass is already queued behind this one: it must not place this pair)
             continue;
         }
         mh = h > mh ? h : mh;
@@ -145,7 +148,7 @@ __global__ __launch_bounds__(256) void bsw_scatter(BswIO io, const uint32_t *__r
     int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (; i < io.n; i += stride) {
         int ql = io.len2[i], tl = io.len1[i];
-        if (ql < 1 || ql > GAB_BSW_MAX_QLEN || tl < 1 || tl > GAB_BSW_MAX_TLEN) continue;
+        if (rank[i] == ~0u) continue;      // failed bsw_hist's validation (the host returns GAB_EINVAL after this pass)
         BswRec r;
         r.ref_off = io.ref_off[i]; r.qry_off = io.qry_off[i]; r.len1 = tl; r.len2 = ql; r.h0 = io.h0[i]; r.id = (uint32_t)i;
         recs[start[bsw_key(ql, tl, r.h0)] + rank[i]] = r;
@@ -671,10 +674,20 @@ extern "C" void gab_bsw_destroy(gab_bsw *h) {
     delete h;
 }
 
+static int bsw_run_device_impl(gab_bsw *h, const uint8_t *ref, int64_t ref_bytes, const int64_t *ref_off,
+                               const uint8_t *qry, int64_t qry_bytes, const int64_t *qry_off,
+                               const int32_t *len1, const int32_t *len2, const int32_t *h0, int64_t n,
+                               int32_t *score_out, gab_bsw_result *result_out, void *stream_, int64_t ref_lo, int64_t qry_lo);
 extern "C" int gab_bsw_run_device(gab_bsw *h, const uint8_t *ref, int64_t ref_bytes, const int64_t *ref_off,
                                   const uint8_t *qry, int64_t qry_bytes, const int64_t *qry_off,
                                   const int32_t *len1, const int32_t *len2, const int32_t *h0, int64_t n,
                                   int32_t *score_out, gab_bsw_result *result_out, void *stream_) {
+    return bsw_run_device_impl(h, ref, ref_bytes, ref_off, qry, qry_bytes, qry_off, len1, len2, h0, n, score_out, result_out, stream_, 0, 0);
+}
+static int bsw_run_device_impl(gab_bsw *h, const uint8_t *ref, int64_t ref_bytes, const int64_t *ref_off,
+                               const uint8_t *qry, int64_t qry_bytes, const int64_t *qry_off,
+                               const int32_t *len1, const int32_t *len2, const int32_t *h0, int64_t n,
+                               int32_t *score_out, gab_bsw_result *result_out, void *stream_, int64_t ref_lo, int64_t qry_lo) {
     GAB_CHECK(h, "gab_bsw_run_device: NULL handle");
     GAB_CHECK(n >= 0 && n < (1ll << 31), "gab_bsw_run_device: n=%lld out of range", (long long)n);
     h->have_stats = false;
@@ -701,7 +714,7 @@ extern "C" int gab_bsw_run_device(gab_bsw *h, const uint8_t *ref, int64_t ref_by
     BswRec *d_recs = (BswRec *)(base + o_recs);             // the pairs' records in bucket order
     uint32_t *d_rank = (uint32_t *)(base + o_rank);
 
-    BswIO io{ref, ref_off, qry, qry_off, len1, len2, h0, ref_bytes, qry_bytes, n};
+    BswIO io{ref, ref_off, qry, qry_off, len1, len2, h0, ref_bytes, qry_bytes, n, ref_lo, qry_lo};
     GAB_HIP(hipEventRecord(h->ev[0], s));
     GAB_HIP(hipMemsetAsync(base, 0, o_recs, s));
     {
@@ -789,14 +802,31 @@ extern "C" int gab_bsw_run(gab_bsw *h, const uint8_t *ref, const int64_t *ref_of
     auto now = [] { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; };
     const double t_0 = now();
     // extent of the two slabs actually referenced: only [min, max) is staged, so a driver can hand a window
-    // of a big input (absolute offsets) to each GPU without re-basing its offset arrays
+    // of a big input (absolute offsets) to each GPU without re-basing its offset arrays.  A scan of all n offsets here is
+    // ~1 ms per million pairs of serial host work inside the caller's ROI, and the device validates every pair against the
+    // staged window anyway (bsw_hist): the window is first taken from 66 pairs spread over the batch -- exact whenever the
+    // sequences lie in pair order, as loadPairs lays them out (main_banded.cpp:164-206) -- and only a batch the device
+    // rejects for it is scanned in full and staged again.
     int64_t rb = 0, qb = 0, ra = INT64_MAX, qa = INT64_MAX;
-    for (int64_t i = 0; i < n; i++) {
-        GAB_CHECK(ref_off[i] >= 0 && qry_off[i] >= 0 && len1[i] >= 0 && len2[i] >= 0,
-                  "gab_bsw_run: negative offset/length at pair %lld", (long long)i);
+    auto take = [&](int64_t i) {
         int64_t r = ref_off[i] + len1[i], q = qry_off[i] + len2[i];
         rb = r > rb ? r : rb; qb = q > qb ? q : qb;
         ra = ref_off[i] < ra ? ref_off[i] : ra; qa = qry_off[i] < qa ? qry_off[i] : qa;
+        return ref_off[i] >= 0 && qry_off[i] >= 0 && len1[i] >= 0 && len2[i] >= 0;
+    };
+    static std::atomic<bool> out_of_order{false};      // a batch of this process was rejected for its sampled window: scan from now on
+    bool sampled = n > 4096 && !out_of_order.load(std::memory_order_relaxed) && !getenv("GAB_BSW_FULL_SCAN");
+    if (sampled) {
+        bool ok = take(0);
+        ok = take(n - 1) && ok;
+        for (int k = 1; k <= 64; k++) ok = take((n - 1) * k / 65) && ok;
+        // (a window the sample makes absurd -- negative fields, or more than 64 KB per pair -- is not worth a copy: scan)
+        if (!ok || rb - ra > 65536 * n || qb - qa > 65536 * n) sampled = false;
+    }
+    if (!sampled) {
+        rb = qb = 0; ra = qa = INT64_MAX;
+        for (int64_t i = 0; i < n; i++)
+            GAB_CHECK(take(i), "gab_bsw_run: negative offset/length at pair %lld", (long long)i);
     }
     ra &= ~(int64_t)255; qa &= ~(int64_t)255;          // keep the device alignment of the slab origin
     const size_t rpad = ((size_t)(rb - ra) + 3 + 255) & ~(size_t)255, qpad = ((size_t)(qb - qa) + 3 + 255) & ~(size_t)255;
@@ -830,10 +860,15 @@ extern "C" int gab_bsw_run(gab_bsw *h, const uint8_t *ref, const int64_t *ref_of
     double t_2 = 0;
     if (trace) { GAB_HIP(hipStreamSynchronize(s)); t_2 = now(); }
     // virtual slab origins: device address of byte 0 of the caller's slabs
-    rc = gab_bsw_run_device(h, (const uint8_t *)(b + o_ref) - ra, ra + (int64_t)rpad, (const int64_t *)(b + o_roff),
-                            (const uint8_t *)(b + o_qry) - qa, qa + (int64_t)qpad, (const int64_t *)(b + o_qoff),
-                            (const int32_t *)(b + o_l1), (const int32_t *)(b + o_l2), (const int32_t *)(b + o_h0),
-                            n, (int32_t *)(b + o_sc), nullptr, s);
+    rc = bsw_run_device_impl(h, (const uint8_t *)(b + o_ref) - ra, ra + (int64_t)rpad, (const int64_t *)(b + o_roff),
+                             (const uint8_t *)(b + o_qry) - qa, qa + (int64_t)qpad, (const int64_t *)(b + o_qoff),
+                             (const int32_t *)(b + o_l1), (const int32_t *)(b + o_l2), (const int32_t *)(b + o_h0),
+                             n, (int32_t *)(b + o_sc), nullptr, s, ra, qa);
+    if (rc == GAB_EINVAL && sampled) {
+        // a pair outside the sampled window (sequences not in pair order) -- or a really invalid one: the full scan tells
+        out_of_order.store(true, std::memory_order_relaxed);
+        return gab_bsw_run(h, ref, ref_off, qry, qry_off, len1, len2, h0, n, score_out);
+    }
     if (rc) return rc;
     double t_3 = 0;
     if (trace) { GAB_HIP(hipStreamSynchronize(s)); t_3 = now(); }
@@ -864,7 +899,7 @@ extern "C" int gab_bsw_reserve(gab_bsw *h, int64_t max_pairs, int64_t max_ref_by
     GAB_HIP(hipMemsetAsync(h->io.p, 0, h->io.cap, s));
     GAB_HIP(hipMemsetAsync(h->ws.p, 0, h->ws.cap, s));
     GAB_HIP(hipStreamSynchronize(s));
-    return gab_warm_copy_engines(s, h->io.p);
+    return gab_warm_copy_engines(s, h->io.p, h->io.cap);
 }
 
 extern "C" int gab_bsw_last_stats(gab_bsw *h, int64_t *cells, float *kernel_ms, float *total_ms) {

@@ -887,6 +887,20 @@ __device__ __forceinline__ int32_t chain_gap_cost(int32_t dd, double avg_d) {
     const int32_t gap = (int32_t)__dmul_rn(__dmul_rn((double)dd, .01), avg_d) + lgh;
     return gap - (gap >> 31);
 }
+// the part of chain_geometry_plain before the table: the overlap term and the table index.  Callers that evaluate several
+// pairs in a row take the indices of all of them first and read the table afterwards, so that the LDS reads are in flight
+// together (left to the compiler every step waits for its own ds_read_b32).  MSEG: the call has n_segs > 1 (dr > max_dist_y rule)
+template <bool MSEG>
+__device__ __forceinline__ int32_t chain_geometry_plain_pre(uint32_t xa_lo, int32_t qa, int32_t q_span, uint32_t xj_lo, uint32_t yj, int32_t mdy,
+                                                            uint32_t dq_lim, int32_t bw, uint32_t &idx, bool &ok) {
+    const int32_t dr = (int32_t)(xa_lo - xj_lo);
+    const int32_t dq = qa - (int32_t)yj;
+    const int32_t diff = (int32_t)((uint32_t)dr - (uint32_t)dq);
+    const int32_t dd = max(diff, (int32_t)(0u - (uint32_t)diff));
+    ok = !(dr == 0 || (uint32_t)dq - 1u >= dq_lim || dd > bw || (MSEG && dr > mdy));
+    idx = min((uint32_t)dd, (uint32_t)bw + 1u);
+    return min(min(dq, dr), q_span);
+}
 __device__ __forceinline__ int32_t chain_geometry_plain(uint32_t xa_lo, int32_t qa, int32_t q_span, uint32_t xj_lo, uint32_t yj, int32_t mdy,
                                                         uint32_t dq_lim, int32_t bw, bool multi_seg, const int32_t *gap_tab, bool &ok) {
     const int32_t dr = (int32_t)(xa_lo - xj_lo);
@@ -1093,25 +1107,54 @@ __device__ __forceinline__ void chain_block_body(const ChainWork *__restrict__ w
                     const int cnt = jb - st_lo + 1 < 64 ? jb - st_lo + 1 : 64;
                     const int jrel0 = jb - i0;
                     // (four steps per trip by hand: the evaluations are independent, only the running maximum is a chain)
+                    auto fold_far = [&](int32_t sc, bool ok, int l) {         // descending j: strict > keeps the newest of equal scores
+                        // every lane evaluates every predecessor and the result is SELECTED: left to itself the compiler
+                        // branches around the arithmetic of filtered lanes (exec-mask juggling and four branches per
+                        // step cost more issue slots than they save)
+                        asm volatile("" : "+v"(sc));
+                        const int jrel = jrel0 - l;
+                        const bool okk = ok & mine & (jrel >= st_rel);
+                        nok += okk ? 1 : 0;
+                        const bool up = okk & (sc > best);
+                        best = up ? sc : best; best_j = up ? jrel : best_j;
+                    };
                     auto far_chunk = [&](auto tag) {
-                        auto step = [&](int l) {             // descending j: strict > keeps the newest of equal scores
+                        auto step = [&](int l) {
                             bool ok;
-                            int32_t sc = geom(tag, xa, qa, qsa, sida, pv, l, ok) + __builtin_amdgcn_readlane(vs, l);
-                            // every lane evaluates every predecessor and the result is SELECTED: left to itself the compiler
-                            // branches around the arithmetic of filtered lanes (exec-mask juggling and four branches per
-                            // step cost more issue slots than they save)
-                            asm volatile("" : "+v"(sc));
-                            const int jrel = jrel0 - l;
-                            const bool okk = ok & mine & (jrel >= st_rel);
-                            nok += okk ? 1 : 0;
-                            const bool up = okk & (sc > best);
-                            best = up ? sc : best; best_j = up ? jrel : best_j;
+                            fold_far(geom(tag, xa, qa, qsa, sida, pv, l, ok) + __builtin_amdgcn_readlane(vs, l), ok, l);
                         };
                         int l = 0;
                         for (; l + 3 < cnt; l += 4) { step(l); step(l + 1); step(l + 2); step(l + 3); }
                         for (; l < cnt; l++) step(l);
                     };
-                    if (plain) far_chunk(std::true_type{}); else far_chunk(std::false_type{});
+                    // plain calls: four pairs per trip with their four gap-table reads in flight together (chain_geometry_plain_pre);
+                    // MSEG (n_segs > 1: the dr > max_dist_y rule) is a compile-time tag, most calls have one segment
+                    auto far_chunk_tab = [&](auto mseg_tag) {
+                        constexpr bool MSEG = decltype(mseg_tag)::value;
+                        auto pre = [&](int l, uint32_t &idx, bool &ok) -> int32_t {
+                            const uint32_t xj_lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)pv.x, l);
+                            const uint32_t yj = (uint32_t)__builtin_amdgcn_readlane((int)pv.y, l);
+                            return chain_geometry_plain_pre<MSEG>((uint32_t)xa, qa, qsa, xj_lo, yj, mdy, dq_lim, bw, idx, ok);
+                        };
+                        int l = 0;
+                        for (; l + 3 < cnt; l += 4) {
+                            uint32_t i0_, i1_, i2_, i3_; bool o0, o1, o2, o3;
+                            const int32_t c0 = pre(l, i0_, o0), c1 = pre(l + 1, i1_, o1), c2 = pre(l + 2, i2_, o2), c3 = pre(l + 3, i3_, o3);
+                            const int32_t g0 = gap_tab[i0_], g1 = gap_tab[i1_], g2 = gap_tab[i2_], g3 = gap_tab[i3_];
+                            fold_far(c0 - g0 + __builtin_amdgcn_readlane(vs, l), o0, l);
+                            fold_far(c1 - g1 + __builtin_amdgcn_readlane(vs, l + 1), o1, l + 1);
+                            fold_far(c2 - g2 + __builtin_amdgcn_readlane(vs, l + 2), o2, l + 2);
+                            fold_far(c3 - g3 + __builtin_amdgcn_readlane(vs, l + 3), o3, l + 3);
+                        }
+                        for (; l < cnt; l++) {
+                            uint32_t ix; bool o;
+                            const int32_t c = pre(l, ix, o);
+                            fold_far(c - gap_tab[ix] + __builtin_amdgcn_readlane(vs, l), o, l);
+                        }
+                    };
+                    if (!plain) far_chunk(std::false_type{});
+                    else if (multi_seg) far_chunk_tab(std::true_type{});
+                    else far_chunk_tab(std::false_type{});
                 }
                 part_best[par][wave - 1][lane] = best; part_j[par][wave - 1][lane] = best_j; part_ok[par][wave - 1][lane] = nok;
                 if (wave == 1) part_st[par][lane] = st_rel;
@@ -1333,6 +1376,23 @@ void chain_fast_kernel(const ChainWork *__restrict__ work, const uint64_t *__res
             return chain_geometry(A.x, A.q, A.qs, A.sid, xj, yj, __builtin_amdgcn_readlane(pv.sid, src), mdx, mdy, bw, multi_seg, avg_d, ok);
         }
     };
+    // the table variants in two halves (see chain_geometry_plain_pre): overlap term + table index now, gap_tab[idx] by the caller
+    auto pair_pre = [&](auto mseg_tag, const Anchor &A, const Pred &pv, int src, uint32_t &idx, bool &ok, bool &wrapped) -> int32_t {
+        constexpr bool MSEG = decltype(mseg_tag)::value;
+        const uint32_t xj_lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)pv.x, src);
+        const uint32_t yj = (uint32_t)__builtin_amdgcn_readlane((int)pv.y, src);
+        wrapped = false;
+        if constexpr (FC) {
+            const int32_t ddr = (int32_t)((uint32_t)A.x - xj_lo);
+            const int32_t ddq = (int32_t)((uint32_t)A.q - yj);
+            const int32_t diff = (int32_t)((uint32_t)ddr - (uint32_t)ddq);
+            const int32_t dd = max(diff, (int32_t)(0u - (uint32_t)diff));
+            ok = !(dd > bw || ddr == 0 || (uint32_t)ddq - 1u >= dq_lim);
+            wrapped = dd < 0;
+            idx = min((uint32_t)dd, (uint32_t)bw + 1u);
+            return min(min(ddr, ddq), A.qs);
+        } else return chain_geometry_plain_pre<MSEG>((uint32_t)A.x, A.q, A.qs, xj_lo, yj, mdy, dq_lim, bw, idx, ok);
+    };
     auto load_pred = [&](int i, bool valid) {
         Pred pv = {0, 0, 0};
         if (valid) { pv.x = X[i]; const uint64_t yy = Y[i]; pv.y = (uint32_t)yy; pv.sid = (int32_t)(yy >> 48 & 0xff); }
@@ -1479,23 +1539,32 @@ void chain_fast_kernel(const ChainWork *__restrict__ work, const uint64_t *__res
                     uint32_t bits = 0;
                     bool any_wrapped = false;
                     int4 *dst = G4 + ((size_t)(par * 2 + (nearu ? 0 : 1)) * 16 + (p0 >> 2)) * 64 + lane;
+                    auto g_unit = [&](auto mseg_tag) {
 #pragma unroll
-                    for (int g4 = 0; g4 < 4; g4++) {
-                        int32_t gv[4];
+                        for (int g4 = 0; g4 < 4; g4++) {
+                            int32_t oc[4], gv[4]; uint32_t ix[4]; bool okv[4];
 #pragma unroll
-                        for (int k = 0; k < 4; k++) {
-                            const int p = p0 + 4 * g4 + k;
-                            bool ok, wr;
-                            const int32_t v = FC ? pair(std::false_type{}, A, pv, p, ok, wr) : pair(std::true_type{}, A, pv, p, ok, wr);
-                            const int jrel = nearu ? p - 64 : p;
-                            ok = ok & mine & (jrel >= st_rel) & (nearu ? kb > 0 : lane > p);
-                            any_wrapped |= ok & wr;
-                            const int code = nearu ? p + 1 : 65 + p;
-                            gv[k] = ok ? (int32_t)(((uint32_t)v << 7) | (uint32_t)code) : NEG;
-                            bits |= ok ? (1u << (4 * g4 + k)) : 0u;
+                            for (int k = 0; k < 4; k++) {                 // four pairs, then their four table reads together
+                                bool wr;
+                                oc[k] = pair_pre(mseg_tag, A, pv, p0 + 4 * g4 + k, ix[k], okv[k], wr);
+                                any_wrapped |= okv[k] & wr;
+                            }
+#pragma unroll
+                            for (int k = 0; k < 4; k++) gv[k] = gap_tab[ix[k]];
+#pragma unroll
+                            for (int k = 0; k < 4; k++) {
+                                const int p = p0 + 4 * g4 + k;
+                                const int jrel = nearu ? p - 64 : p;
+                                const bool ok = okv[k] & mine & (jrel >= st_rel) & (nearu ? kb > 0 : lane > p);
+                                const int code = nearu ? p + 1 : 65 + p;
+                                const uint32_t v = (uint32_t)oc[k] - (uint32_t)gv[k];
+                                gv[k] = ok ? (int32_t)((v << 7) | (uint32_t)code) : NEG;
+                                bits |= ok ? (1u << (4 * g4 + k)) : 0u;
+                            }
+                            dst[(size_t)g4 * 64] = make_int4(gv[0], gv[1], gv[2], gv[3]);
                         }
-                        dst[(size_t)g4 * 64] = make_int4(gv[0], gv[1], gv[2], gv[3]);
-                    }
+                    };
+                    if (!FC && multi_seg) g_unit(std::true_type{}); else g_unit(std::false_type{});
                     okh[par][wk][lane] = (uint16_t)bits;
                     if (FC && __ballot(any_wrapped) && lane == 0) weird[par] = 1;
                 }
@@ -1513,22 +1582,43 @@ void chain_fast_kernel(const ChainWork *__restrict__ work, const uint64_t *__res
                     if (i0 - 65 - 16 * (fu + NW) >= st_lo) far_load(fu + NW, fpv, fvs);      // the next unit's, under this one's arithmetic
                     const int cnt = jb - st_lo + 1 < 16 ? jb - st_lo + 1 : 16;
                     const int jrel0 = jb - i0;
-                    auto far_unit = [&](auto tag) {
-                        auto step = [&](int l) {
-                            bool ok, wr;
-                            int32_t sc = (int32_t)((uint32_t)pair(tag, A, pv, l, ok, wr) + (uint32_t)__builtin_amdgcn_readlane(vs, l));
-                            asm volatile("" : "+v"(sc));
-                            const int jrel = jrel0 - l;
-                            const bool okk = ok & mine & (jrel >= st_rel);
-                            if (!FC) nok += okk ? 1 : 0;
-                            const bool up = okk & (sc > best);
-                            best = up ? sc : best; best_j = up ? jrel : best_j;
-                        };
-                        int l = 0;
-                        for (; l + 3 < cnt; l += 4) { step(l); step(l + 1); step(l + 2); step(l + 3); }
-                        for (; l < cnt; l++) step(l);
+                    auto fold_far = [&](int32_t sc, bool ok, int l) {
+                        asm volatile("" : "+v"(sc));
+                        const int jrel = jrel0 - l;
+                        const bool okk = ok & mine & (jrel >= st_rel);
+                        if (!FC) nok += okk ? 1 : 0;
+                        const bool up = okk & (sc > best);
+                        best = up ? sc : best; best_j = up ? jrel : best_j;
                     };
-                    if (FC ? arith : plain) far_unit(std::true_type{}); else far_unit(std::false_type{});
+                    auto far_unit = [&](auto tag) {                       // the arithmetic variants (generic chain calls, fast-chain's narrow blocks)
+                        for (int l = 0; l < cnt; l++) {
+                            bool ok, wr;
+                            fold_far((int32_t)((uint32_t)pair(tag, A, pv, l, ok, wr) + (uint32_t)__builtin_amdgcn_readlane(vs, l)), ok, l);
+                        }
+                    };
+                    // the table variants: four pairs per trip, their four table reads in flight together
+                    auto far_unit_tab = [&](auto mseg_tag) {
+                        auto pre = [&](int l, uint32_t &idx, bool &ok) -> int32_t { bool wr; return pair_pre(mseg_tag, A, pv, l, idx, ok, wr); };
+                        int l = 0;
+                        for (; l + 3 < cnt; l += 4) {
+                            uint32_t i0_, i1_, i2_, i3_; bool o0, o1, o2, o3;
+                            const int32_t c0 = pre(l, i0_, o0), c1 = pre(l + 1, i1_, o1), c2 = pre(l + 2, i2_, o2), c3 = pre(l + 3, i3_, o3);
+                            const int32_t g0 = gap_tab[i0_], g1 = gap_tab[i1_], g2 = gap_tab[i2_], g3 = gap_tab[i3_];
+                            fold_far((int32_t)((uint32_t)c0 - (uint32_t)g0 + (uint32_t)__builtin_amdgcn_readlane(vs, l)), o0, l);
+                            fold_far((int32_t)((uint32_t)c1 - (uint32_t)g1 + (uint32_t)__builtin_amdgcn_readlane(vs, l + 1)), o1, l + 1);
+                            fold_far((int32_t)((uint32_t)c2 - (uint32_t)g2 + (uint32_t)__builtin_amdgcn_readlane(vs, l + 2)), o2, l + 2);
+                            fold_far((int32_t)((uint32_t)c3 - (uint32_t)g3 + (uint32_t)__builtin_amdgcn_readlane(vs, l + 3)), o3, l + 3);
+                        }
+                        for (; l < cnt; l++) {
+                            uint32_t ix; bool o;
+                            const int32_t c = pre(l, ix, o);
+                            fold_far((int32_t)((uint32_t)c - (uint32_t)gap_tab[ix] + (uint32_t)__builtin_amdgcn_readlane(vs, l)), o, l);
+                        }
+                    };
+                    if (FC) { if (arith) far_unit(std::true_type{}); else far_unit_tab(std::false_type{}); }
+                    else if (!plain) far_unit(std::false_type{});
+                    else if (multi_seg) far_unit_tab(std::true_type{});
+                    else far_unit_tab(std::false_type{});
                 }
                 part_best[par][wk][lane] = best; part_j[par][wk][lane] = best_j; part_ok[par][wk][lane] = nok;
                 pxa = xa; pya = ya;
@@ -2191,7 +2281,7 @@ extern "C" int gab_chain_reserve(gab_chain *h, int64_t max_anchors, int64_t max_
     GAB_HIP(hipMemsetAsync(h->io.p, 0, h->io.cap, s));
     GAB_HIP(hipMemsetAsync(h->gmarks.p, 0, h->gmarks.cap, s));
     GAB_HIP(hipStreamSynchronize(s));
-    return gab_warm_copy_engines(s, h->io.p);
+    return gab_warm_copy_engines(s, h->io.p, h->io.cap);
 }
 
 extern "C" int gab_chain_last_stats(gab_chain *h, int64_t *evals, float *kernel_ms) {

@@ -2,6 +2,7 @@
 #include "gab_internal.h"
 #include <string.h>
 #include <stdlib.h>
+#include <algorithm>
 #include <mutex>
 #include <unordered_set>
 
@@ -139,8 +140,11 @@ std::mutex &gab_h2d_mutex(int device) { return g_h2d_mutex[device >= 0 && device
 // stream are created on first use; measured in the bsw driver: 13 ms instead of 4.3 for the first 240 MB in, 8 ms instead
 // of 0.1 for the first 4 MB out).  The *_reserve entry points pay that before the region of interest: 4 MB each way
 // between page-locked memory and the handle's staging buffer (at least 4 MB by then).
-int gab_warm_copy_engines(hipStream_t s, void *dev) {
-    const size_t bytes = (size_t)4 << 20;
+int gab_warm_copy_engines(hipStream_t s, void *dev, size_t dev_bytes) {
+    // (r03: a 4 MB copy does not warm everything -- the first device-to-host copy ABOVE a few MB on a process's streams was
+    // measured at 10.8 ms for 5.3 MB in the wfa driver's ROI, 0.1 ms for the next one: up to 32 MB each way here)
+    const size_t bytes = std::min<size_t>(dev_bytes, (size_t)32 << 20);
+    if (bytes == 0) return GAB_OK;
     void *pinned = nullptr;
     if (hipHostMalloc(&pinned, bytes, hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); return GAB_OK; }   // best effort
     memset(pinned, 0, bytes);
@@ -151,3 +155,4 @@ int gab_warm_copy_engines(hipStream_t s, void *dev) {
     if (e != hipSuccess) { gab_set_error("gab_warm_copy_engines: %s", hipGetErrorString(e)); return GAB_EDEVICE; }
     return GAB_OK;
 }
+

@@ -75,7 +75,7 @@ struct gab_host_stream {
 };
 
 std::mutex &gab_h2d_mutex(int device);      // see gab_core.hip: one H2D copy batch at a time per GPU
-int gab_warm_copy_engines(hipStream_t s, void *dev);      // gab_core.hip: first-use cost of a stream's copy queues, paid early
+int gab_warm_copy_engines(hipStream_t s, void *dev, size_t dev_bytes);      // gab_core.hip: first-use cost of a stream's copy queues, paid early
 int gab_check_device(int device);
 bool gab_is_pinned(const void *p);      // hipHostMalloc'ed / registered host memory (direct DMA) or pageable
 

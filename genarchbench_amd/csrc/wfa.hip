@@ -1189,6 +1189,9 @@ extern "C" int gab_wfa_run_device(gab_wfa *h, const char *pat, int64_t pat_bytes
             int64_t per_block = dir_cap * (h->adaptive ? 7 : 5) + pool_cap;
             int blocks = (int)std::min<int64_t>(c, std::max<int64_t>(1, (int64_t)(h->scratch_budget / 4) / per_block));
             blocks = std::min(blocks, 2048);
+            // what is already there (gab_wfa_reserve) is used as it is when it holds 64 workgroups' histories or more: an
+            // allocation here stalls every stream of the device for milliseconds (the workgroups stride over the pairs anyway)
+            if (const int64_t fit = (int64_t)(h->scratch.cap / ((size_t)per_block * 4)); fit >= 64) blocks = (int)std::min<int64_t>(blocks, fit);
             if ((size_t)per_block * 4 > h->scratch_budget) {
                 gab_set_error("gab_wfa_run_device: a pair needs more than %zu bytes of wavefront history", h->scratch_budget);
                 return GAB_ENOMEM;
@@ -1290,6 +1293,9 @@ extern "C" int gab_wfa_run_packed(gab_wfa *h, const char *pat, const int64_t *pa
     GAB_CHECK(pat && pat_off && pat_len && txt && txt_off && txt_len && cigar_off_out && cigar_len_out && score_out && capacity >= 0 &&
               (cigar_out || capacity == 0), "gab_wfa_run_packed: NULL buffer");
     gab_device_guard g(h->device);
+    const bool trace = getenv("GAB_WFA_TRACE") != nullptr;      // diagnosis: per-phase wall times of this call on stderr
+    auto now = [] { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; };
+    const double t_0 = now();
     int64_t pb = 0, tb = 0, pa = INT64_MAX, ta = INT64_MAX, stride = 0;
     for (int64_t i = 0; i < n; i++) {
         GAB_CHECK(pat_off[i] >= 0 && txt_off[i] >= 0 && pat_len[i] >= 0 && txt_len[i] >= 0,
@@ -1325,8 +1331,11 @@ extern "C" int gab_wfa_run_packed(gab_wfa *h, const char *pat, const int64_t *pa
     char *b = h->io.as<char>();
     hipStream_t s = nullptr;
     if ((rc = h->hs.get(&s)) != GAB_OK) return rc;
+    const double t_1 = now();
+    double t_gate = 0;
     {   // the copies of one chunk at a time per GPU (gab_core.hip: the workers of a GPU must not copy in lockstep)
         std::lock_guard<std::mutex> gate(gab_h2d_mutex(h->device));
+        t_gate = now();
         GAB_HIP(hipMemcpyAsync(b + o_p, pat + pa, (size_t)(pb - pa), hipMemcpyHostToDevice, s));
         if (!shared) GAB_HIP(hipMemcpyAsync(b + o_t, txt + ta, (size_t)(tb - ta), hipMemcpyHostToDevice, s));
         GAB_HIP(hipMemcpyAsync(b + o_po, pat_off, 8 * nn, hipMemcpyHostToDevice, s));
@@ -1335,6 +1344,7 @@ extern "C" int gab_wfa_run_packed(gab_wfa *h, const char *pat, const int64_t *pa
         GAB_HIP(hipMemcpyAsync(b + o_tl, txt_len, 4 * nn, hipMemcpyHostToDevice, s));
         GAB_HIP(hipStreamSynchronize(s));
     }
+    const double t_2 = now();
     const unsigned grid = (unsigned)((nn + 255) / 256);
     hipLaunchKernelGGL(wfa_fill_stride, dim3(grid), dim3(256), 0, s, (int64_t *)(b + o_oo), (uint32_t)n, stride);
     GAB_HIP(hipGetLastError());
@@ -1352,6 +1362,7 @@ extern "C" int gab_wfa_run_packed(gab_wfa *h, const char *pat, const int64_t *pa
     GAB_HIP(hipMemcpyAsync(cigar_len_out, b + o_cl, 4 * nn, hipMemcpyDeviceToHost, s));
     GAB_HIP(hipMemcpyAsync(score_out, b + o_sc, 4 * nn, hipMemcpyDeviceToHost, s));
     GAB_HIP(hipStreamSynchronize(s));
+    const double t_3 = now();
     const int64_t total = (int64_t)*h_cur;
     if (cigar_bytes) *cigar_bytes = total;
     if (total > capacity) {
@@ -1362,6 +1373,10 @@ extern "C" int gab_wfa_run_packed(gab_wfa *h, const char *pat, const int64_t *pa
         GAB_HIP(hipMemcpyAsync(cigar_out, b + o_txt, (size_t)total, hipMemcpyDeviceToHost, s));
         GAB_HIP(hipStreamSynchronize(s));
     }
+    if (trace)
+        fprintf(stderr, "[gab_wfa_run_packed %p] %lld pairs: host scan + buffers %.2f ms, wait for the copy gate %.2f ms, H2D of %.1f MB %.2f ms, "
+                        "kernels + small D2H %.2f ms, D2H of %.1f MB of text %.2f ms (t0 = %.2f)\n", (void *)h, (long long)n, t_1 - t_0, t_gate - t_1,
+                (double)((pb - pa) + 24 * n) / 1e6, t_2 - t_gate, t_3 - t_2, (double)total / 1e6, now() - t_3, t_0);
     return GAB_OK;
 }
 
@@ -1375,12 +1390,21 @@ extern "C" int gab_wfa_reserve(gab_wfa *h, int64_t max_pairs, int64_t max_seq_by
                                             (size_t)4 << 20));
     if (rc) return rc;
     if ((rc = h->ws.reserve(kCountersBytes + kSlotsBytes + 3 * 4 * nn + 1024)) != GAB_OK) return rc;
+    {   // the hand-over slots of the two static tiers (gab_wfa_run_device: headers of all pairs + a pool per slot): 80 MB for a
+        // chunk of 2^18 pairs, which the first call of a timed region must not have to allocate and map
+        const size_t slots = std::min<size_t>(nn, std::max<size_t>(65536, nn / 8));
+        // ... nor the first round of the global-history tier (4.3 MB per workgroup; the few pairs per chunk that outgrow the LDS
+        // tiers): 64 .. 256 workgroups' worth
+        const size_t global_tier = (size_t)(4096 * (h->adaptive ? 7 : 5) + (1 << 20)) * 4 * std::min<size_t>(256, std::max<size_t>(64, nn / 1024));
+        if ((rc = h->scratch.reserve(std::max(((sizeof(WfResume) * nn + 255) & ~(size_t)255) + slots * 1568, std::min(global_tier, h->scratch_budget)))) != GAB_OK) return rc;
+    }
     hipStream_t s = nullptr;
     if ((rc = h->hs.get(&s)) != GAB_OK) return rc;
     GAB_HIP(hipMemsetAsync(h->io.p, 0, h->io.cap, s));
     GAB_HIP(hipMemsetAsync(h->ws.p, 0, h->ws.cap, s));
+    GAB_HIP(hipMemsetAsync(h->scratch.p, 0, h->scratch.cap, s));
     GAB_HIP(hipStreamSynchronize(s));
-    if ((rc = gab_warm_copy_engines(s, h->io.p)) != GAB_OK) return rc;
+    if ((rc = gab_warm_copy_engines(s, h->io.p, h->io.cap)) != GAB_OK) return rc;
     // ... and one tiny batch through the whole path: the first launch of a kernel pays for loading the code object and for
     // the runtime's per-kernel bookkeeping (milliseconds, once per process and handle) -- not inside the caller's ROI
     static const char seq[] = "ACGTTGCAACGTACGTTGCATGCAACGTACGT" "ACGTTGCAACCTACGTTGCATGAACGTACGTA";

@@ -80,6 +80,52 @@ def main():
         ok &= line(f"{nm}-large", f"{len(cb.hdr)} calls, {cb.nanchors} anchors", "score and parent of every anchor",
                    np.array_equal(s, ws) and np.array_equal(p, wp), t1 - t0, t2 - t1)
         e.close(); del cb
+    for mode, nm in ((0, "chain"), (1, "fast-chain")):
+        if nm + "-shard" not in which:
+            continue
+        # one rank's share of chain-large under strong scaling on 8 GPUs (calls dealt longest first): a batch that waits for its
+        # longest call, so gab_chain_run_device hands most of it to the latency form (chain_fast_kernel) -- every anchor compared
+        from genarchbench_amd.chain import ChainEngine
+        from genarchbench_amd.shard import deal_longest_first
+        ids = deal_longest_first(gabgen.chain_sizes(5, 10000, 0, 50, 60000), 8)[0]
+        cb = gabgen.chain_ids(5, ids, 0, 50, 60000)
+        os.environ["GAB_CHAIN_NO_OVERLAP"] = "1"          # plain copies + gab_chain_run_device: the path bench.py's ranks take
+        try:
+            e = ChainEngine(device=0)
+            t0 = time.time(); s, p = e.host_chain_kernel(cb, mode); t1 = time.time()
+        finally:
+            os.environ.pop("GAB_CHAIN_NO_OVERLAP", None)
+        ws, wp = pyoracle.chain(cb, mode); t2 = time.time()
+        ok &= line(f"{nm}-large, shard 0 of 8 (latency form)", f"{len(cb.hdr)} calls, {cb.nanchors} anchors", "score and parent of every anchor",
+                   np.array_equal(s, ws) and np.array_equal(p, wp), t1 - t0, t2 - t1)
+        e.close(); del cb
+    if "fmi-mid" in which:
+        # fmi at a size that fits the driver-run test suite: 48 Mbp reference (96 M BWT rows, 92 MiB of CP_OCC --
+        # larger than the 32 MiB of L2; parity does not need the index to leave the Infinity Cache), 1.5 M reads of 151 bp,
+        # every field of every SMEM, with the 13-byte interval lists and with the 16-byte ones of >= 2^32-row indexes
+        import ctypes as C
+        from tools import mkindex
+        from genarchbench_amd.fmi import FMI_search
+        ref = gabgen.fmi_ref(16, 48_000_000, 5)
+        idx = mkindex.FmIndex(ref)
+        reads = gabgen.fmi_reads(17, ref, 1_500_000, 151, 151)
+        oidx = pyoracle.FmIndex()
+        cnt = (C.c_int64 * 5)(*[int(x) for x in idx.count])
+        pyoracle.lib().oracle_fmi_from_arrays(C.byref(oidx), C.c_int64(idx.ref_seq_len), cnt, idx.cp_occ.ctypes.data_as(C.c_void_p),
+                                              C.c_int64(idx.sentinel_index))
+        t1 = time.time(); w, woff = pyoracle.fmi(oidx, reads, 19); t2 = time.time()
+        for wide, nm in ((False, "fmi-large at 48 Mbp, 13-byte lists"), (True, "fmi-large at 48 Mbp, 16-byte lists")):
+            if wide:
+                os.environ["GAB_FMI_WIDE_LISTS"] = "1"
+            try:
+                e = FMI_search(arrays=(idx.ref_seq_len, idx.count, idx.cp_occ, idx.sentinel_index))
+            finally:
+                os.environ.pop("GAB_FMI_WIDE_LISTS", None)
+            t0 = time.time(); sm, off = e.seed(reads, 19); tg = time.time() - t0
+            same = np.array_equal(off, woff) and len(sm) == len(w) and all(np.array_equal(sm[f], w[f]) for f in ("rid", "m", "n", "k", "l", "s"))
+            ok &= line(nm, f"{reads.n} reads, {len(w)} SMEMs", "all six fields of every SMEM, per-read offsets", same, tg, t2 - t1)
+            e.close()
+        del ref, idx, reads, w
     if "fmi" in which:
         # fmi-large: all 10 M reads against the 256 Mbp index (bench.py checks the first 20 000 per run)
         import ctypes as C

@@ -101,6 +101,28 @@ def test_other_penalties():
         s.close()
 
 
+def test_host_window_from_a_sample_of_the_pairs(sw):
+    """gab_bsw_run stages only the window of the slabs a batch uses and takes that window from 66 pairs spread over the batch
+    (no serial scan of all offsets inside the ROI); the device checks every pair against it.  Sequences that do NOT lie in
+    pair order fall outside the sampled window: the call then scans all pairs and stages again -- same scores; an invalid
+    pair is still an error after that; batches in pair order keep working afterwards."""
+    from genarchbench_amd._lib import GabError
+    b = gabgen.bsw(21, 20000, 1)
+    want = pyoracle.bsw(b)[:, 0]
+    np.testing.assert_array_equal(sw.getScores16(b), want)                  # pair order: the sample is exact
+    rng = np.random.default_rng(3)
+    perm = rng.permutation(b.n)                                             # same slabs, pairs handed over in shuffled order,
+    sh = gabgen.BswBatch(b.ref, b.ref_off[perm].copy(), b.qry, b.qry_off[perm].copy(), b.len1[perm].copy(), b.len2[perm].copy(), b.h0[perm].copy())
+    lo, hi = 7000, 15000                                                    # ... and only a window of them: the extremes are inside
+    sub = gabgen.BswBatch(sh.ref, sh.ref_off[lo:hi], sh.qry, sh.qry_off[lo:hi], sh.len1[lo:hi], sh.len2[lo:hi], sh.h0[lo:hi])
+    np.testing.assert_array_equal(sw.getScores16(sub), want[perm][lo:hi])
+    bad = gabgen.BswBatch(b.ref, b.ref_off, b.qry, b.qry_off, b.len1, b.len2.copy(), b.h0)
+    bad.len2[12345] = 0
+    with pytest.raises(GabError):
+        sw.getScores16(bad)
+    np.testing.assert_array_equal(sw.getScores16(b), want)
+
+
 def test_rejects_bad_input(sw):
     from genarchbench_amd._lib import GabError
     A = lambda *x: np.array(x, np.uint8)

@@ -4,9 +4,9 @@
 # Run on the GPU box from the repository root; writes gpurun_out/traffic/<workload>_<counter>.txt and, at the end,
 # gpurun_out/traffic/${ROUND}_hbm_traffic.json (copy it to profiles/: bench.py reads roofline.traffic from there).
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-R=${ROUND:-r02}
+R=${ROUND:-r03}
 mkdir -p gpurun_out/traffic
-for w in ${WORKLOADS:-bsw chain fast-chain bpm wfa fmi fmi-sa parse-bsw}; do
+for w in ${WORKLOADS:-bsw chain fast-chain bpm bitpal bitpal-edit wfa fmi fmi-sa parse-bsw}; do
   for c in FETCH_SIZE WRITE_SIZE; do
     echo "== $w $c" >> gpurun_out/traffic/progress.log
     rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/traffic/${w}_$c -- python3 bench.py --workload $w --steps 1 --warmup 0 --no-cpu-baseline --no-host-roi --no-check > gpurun_out/traffic/${w}_$c.json 2> gpurun_out/traffic/${w}_$c.err || exit 1
