@@ -1296,20 +1296,30 @@ extern "C" int gab_wfa_run_packed(gab_wfa *h, const char *pat, const int64_t *pa
     const bool trace = getenv("GAB_WFA_TRACE") != nullptr;      // diagnosis: per-phase wall times of this call on stderr
     auto now = [] { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; };
     const double t_0 = now();
-    int64_t pb = 0, tb = 0, pa = INT64_MAX, ta = INT64_MAX, stride = 0;
+    int64_t pb = 0, tb = 0, pa = INT64_MAX, ta = INT64_MAX, stride = 0, room = 0;
     for (int64_t i = 0; i < n; i++) {
         GAB_CHECK(pat_off[i] >= 0 && txt_off[i] >= 0 && pat_len[i] >= 0 && txt_len[i] >= 0,
                   "gab_wfa_run_packed: negative offset/length at pair %lld", (long long)i);
         pb = std::max(pb, pat_off[i] + pat_len[i]); tb = std::max(tb, txt_off[i] + txt_len[i]);
         pa = std::min(pa, pat_off[i]); ta = std::min(ta, txt_off[i]);
         stride = std::max<int64_t>(stride, (int64_t)pat_len[i] + txt_len[i]);
+        room += (((int64_t)pat_len[i] + txt_len[i]) + 7) & ~(int64_t)7;
     }
     stride = (stride + 7) & ~(int64_t)7;
+    // operation room on the device: a fixed stride per pair (no offset array to build or copy) unless one long pair among
+    // short ones would make that more than twice the sum of the pairs' own rooms -- then exact offsets, built here
+    const bool fixed = stride * n <= 2 * room + (1 << 20);
+    std::vector<int64_t> exact;
+    if (!fixed) {
+        exact.resize((size_t)n);
+        int64_t at = 0;
+        for (int64_t i = 0; i < n; i++) { exact[(size_t)i] = at; at += (((int64_t)pat_len[i] + txt_len[i]) + 7) & ~(int64_t)7; }
+    }
     pa &= ~(int64_t)255; ta &= ~(int64_t)255;
     const bool shared = pat == txt && std::max(pb, tb) - std::min(pa, ta) <= (pb - pa) + (tb - ta);
     if (shared) { pa = ta = std::min(pa, ta); pb = tb = std::max(pb, tb); }
     const size_t ppad = ((size_t)(pb - pa) + 3 + 255) & ~(size_t)255, tpad = shared ? 0 : ((size_t)(tb - ta) + 3 + 255) & ~(size_t)255;
-    const size_t nn = (size_t)n, opad = ((size_t)stride * nn + 16 + 255) & ~(size_t)255, cpad = ((size_t)capacity + 255) & ~(size_t)255;
+    const size_t nn = (size_t)n, opad = ((size_t)(fixed ? stride * n : room) + 16 + 255) & ~(size_t)255, cpad = ((size_t)capacity + 255) & ~(size_t)255;
     size_t o = 0;
     const size_t o_p = o; o += ppad;
     const size_t o_t = o; o += tpad;
@@ -1342,11 +1352,12 @@ extern "C" int gab_wfa_run_packed(gab_wfa *h, const char *pat, const int64_t *pa
         GAB_HIP(hipMemcpyAsync(b + o_to, txt_off, 8 * nn, hipMemcpyHostToDevice, s));
         GAB_HIP(hipMemcpyAsync(b + o_pl, pat_len, 4 * nn, hipMemcpyHostToDevice, s));
         GAB_HIP(hipMemcpyAsync(b + o_tl, txt_len, 4 * nn, hipMemcpyHostToDevice, s));
+        if (!fixed) GAB_HIP(hipMemcpyAsync(b + o_oo, exact.data(), 8 * nn, hipMemcpyHostToDevice, s));
         GAB_HIP(hipStreamSynchronize(s));
     }
     const double t_2 = now();
     const unsigned grid = (unsigned)((nn + 255) / 256);
-    hipLaunchKernelGGL(wfa_fill_stride, dim3(grid), dim3(256), 0, s, (int64_t *)(b + o_oo), (uint32_t)n, stride);
+    if (fixed) hipLaunchKernelGGL(wfa_fill_stride, dim3(grid), dim3(256), 0, s, (int64_t *)(b + o_oo), (uint32_t)n, stride);
     GAB_HIP(hipGetLastError());
     rc = gab_wfa_run_device(h, b + o_p - pa, pa + (int64_t)ppad, (const int64_t *)(b + o_po), (const int32_t *)(b + o_pl),
                             (shared ? b + o_p : b + o_t) - ta, ta + (int64_t)(shared ? ppad : tpad), (const int64_t *)(b + o_to), (const int32_t *)(b + o_tl), n, b + o_ops,

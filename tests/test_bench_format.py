@@ -77,3 +77,21 @@ def test_headline_sheds_the_suite_rather_than_overflow():
     assert len(line) < 4096
     d = json.loads(line)
     assert "roofline" in d and "cpu_baseline" in d and "suite" not in d["extra"]
+
+
+def test_the_committed_default_run_of_this_round_is_a_parseable_record():
+    """profiles/r03_bench_default_stdout.txt = the stdout of `python bench.py` on the GPU box at the end of round 3, as the
+    driver reads it: suite lines first, the compact headline LAST"""
+    lines = open(os.path.join(ROOT, "profiles", "r03_bench_default_stdout.txt")).read().splitlines()
+    assert all(len(l) < 4096 for l in lines)
+    rows = [json.loads(l) for l in lines]
+    assert all("suite" in r and isinstance(r["suite"], str) for r in rows[:-1]) and len(rows) >= 12
+    last = rows[-1]
+    for k in REQUIRED:
+        assert k in last, k
+    assert last["config"]["workload"] == "bsw-large" and last["n_gpus"] == 1
+    assert last["roofline"]["traffic"] and last["cpu_baseline"]["kind"] == "reference" and last["parity"].startswith("bit-exact")
+    assert last["extra"]["value_roi_incl_pcie"] and set(last["extra"]["suite"]) >= {"chain-large", "fast-chain-large", "bpm-large", "wfa-large", "fmi-large"}
+    for r in rows[:-1]:
+        if "value" in r and r["suite"].endswith("-large"):
+            assert r["extra"].get("value_roi_incl_pcie"), r["suite"]          # SURVEY.md 8(d)'s ROI for every large workload

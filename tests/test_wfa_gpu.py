@@ -203,6 +203,14 @@ def test_packed_output_vs_unpacked_and_capacity(eng):
     for i in range(b.n):
         assert text[off[i]:off[i] + ln[i]].tobytes() == _rle(ops[ooff[i]:ooff[i] + oln[i]].tobytes()), i
     assert ln[0] == 0 and ln[1] == 2 and ln[2] == 2                # "", "1D", "3I"
+    # one long pair among short ones: the operation room on the device switches from a fixed stride to exact offsets
+    lp, lt = _mutated(rng, 30000, 0.01)
+    mixed = gabgen.pairs_from_lists(pats[:600] + [lp], txts[:600] + [lt])
+    mo, moff, mln, msc = eng.align(mixed)
+    mt, mtoff, mtln, mtsc = eng.align_packed(mixed)
+    np.testing.assert_array_equal(mtsc, msc)
+    for i in (0, 5, 599, 600):
+        assert mt[mtoff[i]:mtoff[i] + mtln[i]].tobytes() == _rle(mo[moff[i]:moff[i] + mln[i]].tobytes()), i
     need = int(ln.sum())
     with pytest.raises(GabError) as e:
         eng.align_packed(b, capacity=need - 1)
