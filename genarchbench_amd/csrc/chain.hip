@@ -1742,7 +1742,9 @@ void chain_fast_kernel(const ChainWork *__restrict__ work, const uint64_t *__res
                 best = thr - (best_j == kNoJ ? 1 : 0);
                 best_jrel = best_j;
             }
+#ifndef GAB_KO_STORE
             if (mine) { S[i0 + lane] = best; P[i0 + lane] = best_jrel == kNoJ ? -1 : i0 + best_jrel; }
+#endif
             pbest = best;
             mpx = xa64; mpy = ya64;
             if (FC && lane == 0) weird[par ^ 1] = 0;          // (the workers set the other slot in this phase)
