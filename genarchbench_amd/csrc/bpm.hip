@@ -861,7 +861,10 @@ extern "C" int gab_bpm_run_device(gab_bpm *h, const char *pat, int64_t pat_bytes
     GAB_HIP(hipStreamWaitEvent(h->aux, h->fork, 0));
     for (int W = 1; W <= kMaxRegW; W++) {
         if (!ccount[W]) continue;
-        const int nsl = ccount[W] >= (1u << 18) ? kSlices : 1;
+        // slices of ~600 k pairs (10 M pairs: sixteen): a launch of fewer pairs no longer fills the chip -- an eighth of bpm-large
+        // (one rank's share on 8 GPUs) cut into sixteen slices of 78 k pairs took 2.66 ms where 10 M take 5.4 (r03)
+        int nsl = (int)std::min<uint32_t>(kSlices, std::max<uint32_t>(1, ccount[W] / 600000));
+        if (const char *e = getenv("GAB_BPM_SLICES")) nsl = std::max(1, std::min(kSlices, atoi(e)));        // tuning runs
         const uint32_t per = ((ccount[W] + nsl - 1) / nsl + kBlock - 1) / kBlock * kBlock;
         const int cols = h->h_ct->max_tlen[W] + 1;
         for (int k = 0; k < nsl; k++) {

@@ -1912,14 +1912,15 @@ extern "C" int gab_chain_run_device(gab_chain *h, int mode, const uint64_t *d_x,
     // The longest calls (the list is sorted) go to the latency form (chain_fast_kernel: one call per CU, sixteen waves), the
     // rest to the throughput form, side by side on two streams -- when the batch would otherwise wait for its longest call:
     // the throughput form takes ~0.30 us per anchor of a call however empty the chip is and does ~2.85 G anchors/s over all
-    // calls; a batch whose longest call needs more than 0.75 of the batch's throughput time hands every call above a third of
-    // that time's worth of anchors to the latency form (chain-large on one GPU: none; an eighth of it: every call above ~3 700
-    // anchors; the 1 000-call input: above ~2 900).  GAB_CHAIN_FAST_MIN / GAB_CHAIN_FAST_CALLS pin the choice (tests, A/B runs).
+    // calls; a batch whose longest call needs more than 0.75 of the batch's throughput time hands every call of 512 anchors or
+    // more to the latency form (chain-large on one GPU: none; an eighth of it and the 1 000-call input: 99 % of their anchors --
+    // leaving the mid-size calls in the throughput form beside it cost the slowest call 1-2 %: its CU's SIMDs are shared).
+    // GAB_CHAIN_FAST_MIN / GAB_CHAIN_FAST_CALLS pin the choice (tests, A/B runs).
     size_t nfast = 0;
     if (!(mode == GAB_CHAIN && getenv("GAB_CHAIN_KERNEL") && !strcmp(getenv("GAB_CHAIN_KERNEL"), "walk")) && !getenv("GAB_CHAIN_HELPERS")) {
         int64_t min_n = 0, max_calls = 0;
         const double est_tp = (double)total / 2.85e9, lat_max = 0.30e-6 * (double)wk[0].n;
-        if (lat_max >= 0.75 * est_tp) { min_n = std::max<int64_t>(1024, total / 2850); max_calls = (int64_t)nw; }
+        if (lat_max >= 0.75 * est_tp) { min_n = 512; max_calls = (int64_t)nw; }
         if (getenv("GAB_CHAIN_FAST_MIN")) min_n = atoll(getenv("GAB_CHAIN_FAST_MIN"));
         if (getenv("GAB_CHAIN_FAST_CALLS")) max_calls = atoll(getenv("GAB_CHAIN_FAST_CALLS"));
         if (getenv("GAB_CHAIN_FAST_MIN") && !getenv("GAB_CHAIN_FAST_CALLS")) max_calls = (int64_t)nw;
