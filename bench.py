@@ -78,6 +78,27 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+class omp_threads:
+    """with omp_threads(n): OpenMP regions started from this thread use n threads (bench.py gives every rank of an N-GPU run
+    cores / N threads; a step only one rank performs while the others wait may take them all)"""
+
+    def __init__(self, n):
+        self.n = n
+
+    def __enter__(self):
+        import ctypes as C
+        try:
+            self.omp = C.CDLL("libgomp.so.1")
+            self.old = self.omp.omp_get_max_threads()
+            self.omp.omp_set_num_threads(int(self.n))
+        except OSError:
+            self.omp = None
+
+    def __exit__(self, *a):
+        if self.omp is not None:
+            self.omp.omp_set_num_threads(int(self.old))
+
+
 # ---- the host-pointer path: what a drop-in driver times (SURVEY.md 8d: "ROI on GPU includes H2D of packed inputs, kernels,
 # and D2H of results").  Same scheme as benchmarks/common/gab_driver.h: the item range is cut into chunks, WORKERS host
 # threads (each with its own engine handle = its own stream) pull chunk indices from a shared cursor and call the
@@ -850,7 +871,8 @@ class FmiWorkload:
                 ref = gabgen.fmi_ref(self.seed, self.ref_mbp * 1_000_000, 5)
                 log(f"[rank {rank}] generated the {self.ref_mbp} Mbp reference in {time.time() - t0:.1f}s")
                 t0 = time.time()
-                index = mkindex.FmIndex(ref)                 # outside the ROI, like load_index in the reference
+                with omp_threads(host_cores()):              # the other ranks wait at the barrier below: all host cores for the build
+                    index = mkindex.FmIndex(ref)             # outside the ROI, like load_index in the reference
                 log(f"[rank {rank}] built the FM-index ({index.ref_seq_len} rows, {len(index.cp_occ) / 2**20:.0f} MiB of CP_OCC) "
                     f"in {time.time() - t0:.1f}s")
                 if share:                                    # ONE index per node: the other ranks map rank 0's file, as the
