@@ -733,7 +733,33 @@ __device__ __forceinline__ void fastchain_body(const ChainWork *__restrict__ wor
                         for (; l + 3 < cnt; l += 4) { step(l); step(l + 1); step(l + 2); step(l + 3); }
                         for (; l < cnt; l++) step(l);
                     };
-                    if (any_narrow || !use_tab) far_chunk(std::true_type{}); else far_chunk(std::false_type{});
+                    // the table variant with the four gap-table reads of a trip in flight together (r03; left to the compiler every
+                    // step waited for its own ds_read_b32): filters, overlap term and table index first, then the four reads
+                    auto far_chunk_tab = [&]() {
+                        auto pre = [&](int l, uint32_t &idx, bool &ok) -> int32_t {
+                            const int32_t xj = __builtin_amdgcn_readlane(vx, l), yj = __builtin_amdgcn_readlane(vy, l);
+                            const int32_t ddr = (int32_t)((uint32_t)xa - (uint32_t)xj);
+                            const int32_t ddq = (int32_t)((uint32_t)ya - (uint32_t)yj);
+                            const int32_t diff = (int32_t)((uint32_t)ddr - (uint32_t)ddq);
+                            const int32_t dd = max(diff, (int32_t)(0u - (uint32_t)diff));
+                            ok = !(dd > bw || ddr == 0 || (uint32_t)ddq - 1u >= mq_u);
+                            idx = min((uint32_t)dd, (uint32_t)bw + 1u);
+                            return min(min(ddr, ddq), qsa);
+                        };
+                        auto fold = [&](int32_t oc, int32_t gc, bool ok, int l) {
+                            const int32_t sc = (int32_t)((uint32_t)__builtin_amdgcn_readlane(vs, l) + (uint32_t)oc - (uint32_t)gc);
+                            if (mine && ok && jrel0 - l >= st_rel && sc > best) { best = sc; best_j = jrel0 - l; }
+                        };
+                        int l = 0;
+                        for (; l + 3 < cnt; l += 4) {
+                            uint32_t i0_, i1_, i2_, i3_; bool o0, o1, o2, o3;
+                            const int32_t c0 = pre(l, i0_, o0), c1 = pre(l + 1, i1_, o1), c2 = pre(l + 2, i2_, o2), c3 = pre(l + 3, i3_, o3);
+                            const int32_t g0 = gap_tab[i0_], g1 = gap_tab[i1_], g2 = gap_tab[i2_], g3 = gap_tab[i3_];
+                            fold(c0, g0, o0, l); fold(c1, g1, o1, l + 1); fold(c2, g2, o2, l + 2); fold(c3, g3, o3, l + 3);
+                        }
+                        for (; l < cnt; l++) { uint32_t ix; bool o; const int32_t c = pre(l, ix, o); fold(c, gap_tab[ix], o, l); }
+                    };
+                    if (any_narrow || !use_tab) far_chunk(std::true_type{}); else far_chunk_tab();
                 }
                 part_best[par][wave - 1][lane] = best; part_j[par][wave - 1][lane] = best_j;
                 if (wave == 1) part_st[par][lane] = st_rel;
@@ -1200,7 +1226,34 @@ __device__ __forceinline__ void chain_block_body(const ChainWork *__restrict__ w
                 for (; l + 3 < pnb; l += 4) { step(l); step(l + 1); step(l + 2); step(l + 3); }
                 for (; l < pnb; l++) step(l);
             };
-            if (plain) near_fold(std::true_type{}); else near_fold(std::false_type{});
+            // plain calls: the same steps with the four gap-table reads of a trip in flight together (see the helpers' far_chunk_tab)
+            auto geom_pre = [&](auto mseg_tag, const Pred &pv, int src, uint32_t &idx, bool &ok) -> int32_t {
+                constexpr bool MSEG = decltype(mseg_tag)::value;
+                const uint32_t xj_lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)pv.x, src);
+                const uint32_t yj = (uint32_t)__builtin_amdgcn_readlane((int)pv.y, src);
+                return chain_geometry_plain_pre<MSEG>((uint32_t)xa, qa, qsa, xj_lo, yj, mdy, dq_lim, bw, idx, ok);
+            };
+            auto near_fold_tab = [&](auto mseg_tag) {
+                int l = 0;
+                for (; l + 3 < pnb; l += 4) {
+                    uint32_t i0_, i1_, i2_, i3_; bool o0, o1, o2, o3;
+                    const int32_t c0 = geom_pre(mseg_tag, prev, l, i0_, o0), c1 = geom_pre(mseg_tag, prev, l + 1, i1_, o1);
+                    const int32_t c2 = geom_pre(mseg_tag, prev, l + 2, i2_, o2), c3 = geom_pre(mseg_tag, prev, l + 3, i3_, o3);
+                    const int32_t g0 = gap_tab[i0_], g1 = gap_tab[i1_], g2 = gap_tab[i2_], g3 = gap_tab[i3_];
+                    fold(c0 - g0 + __builtin_amdgcn_readlane(pbest, l), o0 & mine & (l - 64 >= st_rel), l - 64);
+                    fold(c1 - g1 + __builtin_amdgcn_readlane(pbest, l + 1), o1 & mine & (l - 63 >= st_rel), l - 63);
+                    fold(c2 - g2 + __builtin_amdgcn_readlane(pbest, l + 2), o2 & mine & (l - 62 >= st_rel), l - 62);
+                    fold(c3 - g3 + __builtin_amdgcn_readlane(pbest, l + 3), o3 & mine & (l - 61 >= st_rel), l - 61);
+                }
+                for (; l < pnb; l++) {
+                    uint32_t ix; bool o;
+                    const int32_t c = geom_pre(mseg_tag, prev, l, ix, o);
+                    fold(c - gap_tab[ix] + __builtin_amdgcn_readlane(pbest, l), o & mine & (l - 64 >= st_rel), l - 64);
+                }
+            };
+            if (!plain) near_fold(std::false_type{});
+            else if (multi_seg) near_fold_tab(std::true_type{});
+            else near_fold_tab(std::false_type{});
             // predecessors inside the block: anchor b is final once 0 .. b-1 are folded; if its certificate fails it is
             // re-done exactly before its score is broadcast.  The geometry of (a, b) involves no score and is computed four
             // steps ahead, so the dependent part of a step is readlane(score, b) + add + compare + select.
@@ -1234,7 +1287,30 @@ __device__ __forceinline__ void chain_block_body(const ChainWork *__restrict__ w
                     if (b + 1 < nb) { bool o; const int32_t gg = g(b, o); fold(gg + score_of(b), o, b); }
                 }
             };
-            if (plain) block_fold(std::true_type{}); else block_fold(std::false_type{});
+            auto block_fold_tab = [&](auto mseg_tag) {
+                auto gp = [&](int b, uint32_t &idx, bool &ok) -> int32_t {
+                    const int32_t v = geom_pre(mseg_tag, cur, b, idx, ok);
+                    ok = ok & mine & (lane > b) & (b >= st_rel);
+                    return v;
+                };
+                int b = 0;
+                for (; b + 4 < nb; b += 4) {
+                    uint32_t i0_, i1_, i2_, i3_; bool o0, o1, o2, o3;
+                    const int32_t c0 = gp(b, i0_, o0), c1 = gp(b + 1, i1_, o1), c2 = gp(b + 2, i2_, o2), c3 = gp(b + 3, i3_, o3);
+                    const int32_t g0 = c0 - gap_tab[i0_], g1 = c1 - gap_tab[i1_], g2 = c2 - gap_tab[i2_], g3 = c3 - gap_tab[i3_];
+                    finalize(b);     fold(g0 + score_of(b), o0, b);
+                    finalize(b + 1); fold(g1 + score_of(b + 1), o1, b + 1);
+                    finalize(b + 2); fold(g2 + score_of(b + 2), o2, b + 2);
+                    finalize(b + 3); fold(g3 + score_of(b + 3), o3, b + 3);
+                }
+                for (; b < nb; b++) {
+                    finalize(b);
+                    if (b + 1 < nb) { uint32_t ix; bool o; const int32_t c = gp(b, ix, o); fold(c - gap_tab[ix] + score_of(b), o, b); }
+                }
+            };
+            if (!plain) block_fold(std::false_type{});
+            else if (multi_seg) block_fold_tab(std::true_type{});
+            else block_fold_tab(std::false_type{});
             const int32_t best = thr - (best_j == kNoJ ? 1 : 0);
             if (mine) {
                 const int32_t par_ = best_j == kNoJ ? -1 : i0 + best_j;
