@@ -1770,6 +1770,9 @@ void chain_fast_kernel(const ChainWork *__restrict__ work, const uint64_t *__res
                     }
                     redo = __ballot(mine && !none && risk > kMaxSkip) != 0;
                 }
+#ifdef GAB_KO_G
+                redo = false;                                  // (timing experiment: the G tables are garbage)
+#endif
             }
             if (redo) {
                 // the legacy block: geometry in this wave; chain: the certificate per anchor, the reference's own scan on a miss
