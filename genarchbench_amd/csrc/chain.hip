@@ -1155,6 +1155,15 @@ __device__ __forceinline__ void chain_block_body(const ChainWork *__restrict__ w
                     };
                     // plain calls: four pairs per trip with their four gap-table reads in flight together (chain_geometry_plain_pre);
                     // MSEG (n_segs > 1: the dr > max_dist_y rule) is a compile-time tag, most calls have one segment
+                    // a chunk whose oldest predecessor lies inside EVERY anchor's window needs no window test per pair (the pointer
+                    // never moves back: the last anchor's start is the largest)
+                    const bool inside = nb == 64 && jb - cnt + 1 >= i0 + __builtin_amdgcn_readlane(st_rel, 63);
+                    auto fold_far_in = [&](int32_t sc, bool ok, int l) {
+                        asm volatile("" : "+v"(sc));
+                        nok += ok ? 1 : 0;
+                        const bool up = ok & (sc > best);
+                        best = up ? sc : best; best_j = up ? jrel0 - l : best_j;
+                    };
                     auto far_chunk_tab = [&](auto mseg_tag) {
                         constexpr bool MSEG = decltype(mseg_tag)::value;
                         auto pre = [&](int l, uint32_t &idx, bool &ok) -> int32_t {
@@ -1163,6 +1172,17 @@ __device__ __forceinline__ void chain_block_body(const ChainWork *__restrict__ w
                             return chain_geometry_plain_pre<MSEG>((uint32_t)xa, qa, qsa, xj_lo, yj, mdy, dq_lim, bw, idx, ok);
                         };
                         int l = 0;
+                        if (inside) {
+                            for (; l + 3 < cnt; l += 4) {
+                                uint32_t i0_, i1_, i2_, i3_; bool o0, o1, o2, o3;
+                                const int32_t c0 = pre(l, i0_, o0), c1 = pre(l + 1, i1_, o1), c2 = pre(l + 2, i2_, o2), c3 = pre(l + 3, i3_, o3);
+                                const int32_t g0 = gap_tab[i0_], g1 = gap_tab[i1_], g2 = gap_tab[i2_], g3 = gap_tab[i3_];
+                                fold_far_in(c0 - g0 + __builtin_amdgcn_readlane(vs, l), o0, l);
+                                fold_far_in(c1 - g1 + __builtin_amdgcn_readlane(vs, l + 1), o1, l + 1);
+                                fold_far_in(c2 - g2 + __builtin_amdgcn_readlane(vs, l + 2), o2, l + 2);
+                                fold_far_in(c3 - g3 + __builtin_amdgcn_readlane(vs, l + 3), o3, l + 3);
+                            }
+                        }
                         for (; l + 3 < cnt; l += 4) {
                             uint32_t i0_, i1_, i2_, i3_; bool o0, o1, o2, o3;
                             const int32_t c0 = pre(l, i0_, o0), c1 = pre(l + 1, i1_, o1), c2 = pre(l + 2, i2_, o2), c3 = pre(l + 3, i3_, o3);
@@ -1233,8 +1253,24 @@ __device__ __forceinline__ void chain_block_body(const ChainWork *__restrict__ w
                 const uint32_t yj = (uint32_t)__builtin_amdgcn_readlane((int)pv.y, src);
                 return chain_geometry_plain_pre<MSEG>((uint32_t)xa, qa, qsa, xj_lo, yj, mdy, dq_lim, bw, idx, ok);
             };
+            // the near / in-block predecessors lie inside every anchor's window when the LAST anchor's does (the pointer never moves
+            // back): then the per-pair window tests go (most blocks: windows hold ~200 predecessors)
+            const int st_last = __builtin_amdgcn_readlane(st_rel, 63);
+            const bool near_in = nb == 64 && st_last <= -64, block_in = nb == 64 && st_last <= 0;
             auto near_fold_tab = [&](auto mseg_tag) {
                 int l = 0;
+                if (near_in) {
+                    for (; l + 3 < pnb; l += 4) {
+                        uint32_t i0_, i1_, i2_, i3_; bool o0, o1, o2, o3;
+                        const int32_t c0 = geom_pre(mseg_tag, prev, l, i0_, o0), c1 = geom_pre(mseg_tag, prev, l + 1, i1_, o1);
+                        const int32_t c2 = geom_pre(mseg_tag, prev, l + 2, i2_, o2), c3 = geom_pre(mseg_tag, prev, l + 3, i3_, o3);
+                        const int32_t g0 = gap_tab[i0_], g1 = gap_tab[i1_], g2 = gap_tab[i2_], g3 = gap_tab[i3_];
+                        fold(c0 - g0 + __builtin_amdgcn_readlane(pbest, l), o0, l - 64);
+                        fold(c1 - g1 + __builtin_amdgcn_readlane(pbest, l + 1), o1, l - 63);
+                        fold(c2 - g2 + __builtin_amdgcn_readlane(pbest, l + 2), o2, l - 62);
+                        fold(c3 - g3 + __builtin_amdgcn_readlane(pbest, l + 3), o3, l - 61);
+                    }
+                }
                 for (; l + 3 < pnb; l += 4) {
                     uint32_t i0_, i1_, i2_, i3_; bool o0, o1, o2, o3;
                     const int32_t c0 = geom_pre(mseg_tag, prev, l, i0_, o0), c1 = geom_pre(mseg_tag, prev, l + 1, i1_, o1);
@@ -1293,7 +1329,23 @@ __device__ __forceinline__ void chain_block_body(const ChainWork *__restrict__ w
                     ok = ok & mine & (lane > b) & (b >= st_rel);
                     return v;
                 };
+                auto gp_in = [&](int b, uint32_t &idx, bool &ok) -> int32_t {
+                    const int32_t v = geom_pre(mseg_tag, cur, b, idx, ok);
+                    ok = ok & (lane > b);
+                    return v;
+                };
                 int b = 0;
+                if (block_in) {
+                    for (; b + 4 < nb; b += 4) {
+                        uint32_t i0_, i1_, i2_, i3_; bool o0, o1, o2, o3;
+                        const int32_t c0 = gp_in(b, i0_, o0), c1 = gp_in(b + 1, i1_, o1), c2 = gp_in(b + 2, i2_, o2), c3 = gp_in(b + 3, i3_, o3);
+                        const int32_t g0 = c0 - gap_tab[i0_], g1 = c1 - gap_tab[i1_], g2 = c2 - gap_tab[i2_], g3 = c3 - gap_tab[i3_];
+                        finalize(b);     fold(g0 + score_of(b), o0, b);
+                        finalize(b + 1); fold(g1 + score_of(b + 1), o1, b + 1);
+                        finalize(b + 2); fold(g2 + score_of(b + 2), o2, b + 2);
+                        finalize(b + 3); fold(g3 + score_of(b + 3), o3, b + 3);
+                    }
+                }
                 for (; b + 4 < nb; b += 4) {
                     uint32_t i0_, i1_, i2_, i3_; bool o0, o1, o2, o3;
                     const int32_t c0 = gp(b, i0_, o0), c1 = gp(b + 1, i1_, o1), c2 = gp(b + 2, i2_, o2), c3 = gp(b + 3, i3_, o3);
@@ -1588,6 +1640,7 @@ void chain_fast_kernel(const ChainWork *__restrict__ work, const uint64_t *__res
                 const int st_a = part_st[kb % 3][lane];
                 const int st_rel = st_a - i0;
                 const int st_lo = __builtin_amdgcn_readfirstlane(st_a);
+                const int st_hi = __builtin_amdgcn_readlane(st_a, nb - 1);      // (the pointer never moves back: the last anchor's start is the largest)
                 const bool wide_a = !((lane - 1) - st_rel <= 5);
                 const bool arith = FC && (__ballot(mine && !wide_a) != 0 || !use_tab);     // fast-chain: this block takes the arithmetic gap cost
                 const Anchor A = anchor_of(xa, ya, wide_a);
@@ -1615,7 +1668,10 @@ void chain_fast_kernel(const ChainWork *__restrict__ work, const uint64_t *__res
                     uint32_t bits = 0;
                     bool any_wrapped = false;
                     int4 *dst = G4 + ((size_t)(par * 2 + (nearu ? 0 : 1)) * 16 + (p0 >> 2)) * 64 + lane;
-                    auto g_unit = [&](auto mseg_tag) {
+                    // (predecessors inside every anchor's window -- the last anchor's start is the largest -- need no window test)
+                    const bool g_in = nb == 64 && (nearu ? kb > 0 && st_hi <= i0 - 64 : st_hi <= i0);
+                    auto g_unit = [&](auto mseg_tag, auto in_tag) {
+                        constexpr bool IN = decltype(in_tag)::value;
 #pragma unroll
                         for (int g4 = 0; g4 < 4; g4++) {
                             int32_t oc[4], gv[4]; uint32_t ix[4]; bool okv[4];
@@ -1631,17 +1687,18 @@ void chain_fast_kernel(const ChainWork *__restrict__ work, const uint64_t *__res
                             for (int k = 0; k < 4; k++) {
                                 const int p = p0 + 4 * g4 + k;
                                 const int jrel = nearu ? p - 64 : p;
-                                const bool ok = okv[k] & mine & (jrel >= st_rel) & (nearu ? kb > 0 : lane > p);
+                                const bool ok = IN ? (okv[k] & (nearu || lane > p)) : (okv[k] & mine & (jrel >= st_rel) & (nearu ? kb > 0 : lane > p));
                                 const int code = nearu ? p + 1 : 65 + p;
                                 const uint32_t v = (uint32_t)oc[k] - (uint32_t)gv[k];
                                 gv[k] = ok ? (int32_t)((v << 7) | (uint32_t)code) : NEG;
-                                bits |= ok ? (1u << (4 * g4 + k)) : 0u;
+                                if (!FC) bits |= ok ? (1u << (4 * g4 + k)) : 0u;     // (the certificate's masks: chain only)
                             }
                             dst[(size_t)g4 * 64] = make_int4(gv[0], gv[1], gv[2], gv[3]);
                         }
                     };
-                    if (!FC && multi_seg) g_unit(std::true_type{}); else g_unit(std::false_type{});
-                    okh[par][wk][lane] = (uint16_t)bits;
+                    if (g_in) { if (!FC && multi_seg) g_unit(std::true_type{}, std::true_type{}); else g_unit(std::false_type{}, std::true_type{}); }
+                    else { if (!FC && multi_seg) g_unit(std::true_type{}, std::false_type{}); else g_unit(std::false_type{}, std::false_type{}); }
+                    if (!FC) okh[par][wk][lane] = (uint16_t)bits;
                     if (FC && __ballot(any_wrapped) && lane == 0) weird[par] = 1;
                 }
                 int32_t best = NEG, best_j = -1, nok = 0;
@@ -1658,6 +1715,9 @@ void chain_fast_kernel(const ChainWork *__restrict__ work, const uint64_t *__res
                     if (i0 - 65 - 16 * (fu + NW) >= st_lo) far_load(fu + NW, fpv, fvs);      // the next unit's, under this one's arithmetic
                     const int cnt = jb - st_lo + 1 < 16 ? jb - st_lo + 1 : 16;
                     const int jrel0 = jb - i0;
+                    // a unit whose oldest predecessor is inside EVERY anchor's window (all but the few units around the window starts)
+                    // needs no window test per pair
+                    const bool inside = jb - cnt + 1 >= st_hi && nb == 64;
                     auto fold_far = [&](int32_t sc, bool ok, int l) {
                         asm volatile("" : "+v"(sc));
                         const int jrel = jrel0 - l;
@@ -1665,6 +1725,12 @@ void chain_fast_kernel(const ChainWork *__restrict__ work, const uint64_t *__res
                         if (!FC) nok += okk ? 1 : 0;
                         const bool up = okk & (sc > best);
                         best = up ? sc : best; best_j = up ? jrel : best_j;
+                    };
+                    auto fold_far_in = [&](int32_t sc, bool ok, int l) {
+                        asm volatile("" : "+v"(sc));
+                        if (!FC) nok += ok ? 1 : 0;
+                        const bool up = ok & (sc > best);
+                        best = up ? sc : best; best_j = up ? jrel0 - l : best_j;
                     };
                     auto far_unit = [&](auto tag) {                       // the arithmetic variants (generic chain calls, fast-chain's narrow blocks)
                         for (int l = 0; l < cnt; l++) {
@@ -1676,6 +1742,17 @@ void chain_fast_kernel(const ChainWork *__restrict__ work, const uint64_t *__res
                     auto far_unit_tab = [&](auto mseg_tag) {
                         auto pre = [&](int l, uint32_t &idx, bool &ok) -> int32_t { bool wr; return pair_pre(mseg_tag, A, pv, l, idx, ok, wr); };
                         int l = 0;
+                        if (inside) {                         // (cnt == 16 then)
+                            for (; l + 3 < cnt; l += 4) {
+                                uint32_t i0_, i1_, i2_, i3_; bool o0, o1, o2, o3;
+                                const int32_t c0 = pre(l, i0_, o0), c1 = pre(l + 1, i1_, o1), c2 = pre(l + 2, i2_, o2), c3 = pre(l + 3, i3_, o3);
+                                const int32_t g0 = gap_tab[i0_], g1 = gap_tab[i1_], g2 = gap_tab[i2_], g3 = gap_tab[i3_];
+                                fold_far_in((int32_t)((uint32_t)c0 - (uint32_t)g0 + (uint32_t)__builtin_amdgcn_readlane(vs, l)), o0, l);
+                                fold_far_in((int32_t)((uint32_t)c1 - (uint32_t)g1 + (uint32_t)__builtin_amdgcn_readlane(vs, l + 1)), o1, l + 1);
+                                fold_far_in((int32_t)((uint32_t)c2 - (uint32_t)g2 + (uint32_t)__builtin_amdgcn_readlane(vs, l + 2)), o2, l + 2);
+                                fold_far_in((int32_t)((uint32_t)c3 - (uint32_t)g3 + (uint32_t)__builtin_amdgcn_readlane(vs, l + 3)), o3, l + 3);
+                            }
+                        }
                         for (; l + 3 < cnt; l += 4) {
                             uint32_t i0_, i1_, i2_, i3_; bool o0, o1, o2, o3;
                             const int32_t c0 = pre(l, i0_, o0), c1 = pre(l + 1, i1_, o1), c2 = pre(l + 2, i2_, o2), c3 = pre(l + 3, i3_, o3);
