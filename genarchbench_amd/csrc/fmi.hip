@@ -56,6 +56,7 @@ struct FmiCounters {
     int32_t max_per_read;
     int32_t bad, first_bad;
     int32_t next_read;             // work queue of the seeding kernel
+    int32_t n_ovf, pad;            // reads whose SMEMs overflowed the first-round slot
     unsigned long long wave_steps; // sum over waves of the steps of their longest-running lane (GAB_FMI_DEBUG)
     unsigned long long positions, spills, list_sum;   // seeding positions, those whose list outgrew LDS, sum of list lengths
 };
@@ -193,7 +194,7 @@ __global__ __launch_bounds__(64) void fmi_seed_kernel(FmiIdx ix, const uint8_t *
                                                       const int32_t *__restrict__ len_arr, int64_t first, int32_t nbatch,
                                                       int min_seed_len, PrevRec *prev, int prev_cap, OutRec *out_all, int cap,
                                                       int32_t *counts, FmiCounters *ct, int lds_entries, int64_t enc_bytes, int passes,
-                                                      int narrow_lists) {
+                                                      int narrow_lists, const int32_t *__restrict__ ids) {
     // dynamic LDS (LDSQ only): [ (stride + 7) / 8 words of read codes ][ lds_entries list entries ]  x 64 lanes; a list entry
     // is 16 bytes (k, l, s < 2^40, n < 256 packed), or -- narrow_lists, for indexes below 2^32 rows -- three dword planes
     // and a byte plane = 13 bytes, which is two more waves per CU at 12 entries
@@ -363,10 +364,10 @@ __global__ __launch_bounds__(64) void fmi_seed_kernel(FmiIdx ix, const uint8_t *
             const bool got = want && idx < nbatch;
             if (want && !got) state = ST_DONE;
             if (got) {
-                t = idx;
+                t = ids ? ids[idx] : idx;                      // ids: the second round over the reads that overflowed their slot
                 const int64_t r = first + t;
                 q = enc + r * (int64_t)stride; len = len_arr[r];
-                out = out_all + (int64_t)t * cap;
+                out = out_all + (int64_t)idx * cap;
                 x = 0; min_intv = 1; p2q0 = 0; p2q1 = 0; p2n = 0;
                 if (passes & 1) { nout = 0; pass = 1; state = ST_P1_NEXT; }
                 else { nout = counts[t]; pass = 3; state = ST_P3_START; }        // appends to what passes 1 and 2 found
@@ -560,11 +561,12 @@ __device__ __forceinline__ bool rec_less(const OutRec &a, const OutRec &b) {
     return a.k < b.k;
 }
 // sortSMEMs (:986-1022) per read: insertion sort inside the read's slot (a handful of records)
-__global__ __launch_bounds__(256) void fmi_sort_slots(OutRec *out_all, int cap, const int32_t *counts, int32_t nbatch) {
+__global__ __launch_bounds__(256) void fmi_sort_slots(OutRec *out_all, int cap, const int32_t *counts, int32_t nbatch,
+                                                      const int32_t *__restrict__ ids) {
     const int32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nbatch) return;
-    const int nout = counts[t];
-    if (nout > cap) return;                       // truncated slot: the batch is re-run with a bigger one
+    const int nout = counts[ids ? ids[t] : t];
+    if (nout > cap) return;                       // truncated slot: the read gets a second round with a bigger one
     OutRec *out = out_all + (int64_t)t * cap;
     for (int i = 1; i < nout; i++) {
         const OutRec key = out[i];
@@ -626,7 +628,29 @@ __global__ __launch_bounds__(256) void fmi_compact(const int32_t *counts, int32_
     if (t >= n) return;
     const int64_t off = block_off[blockIdx.x] + sh[threadIdx.x] - c;
     read_off[first + t] = off;
+    if (c > cap) return;                          // its records come from the second round (fmi_compact_overflowed)
     const OutRec *src = slots + (int64_t)t * cap;
+    for (int j = 0; j < c; j++) {
+        const OutRec o = src[j];
+        gab_smem g;
+        g.rid = (uint32_t)(first + t); g.m = o.m; g.n = o.n; g.pad = 0; g.k = o.k; g.l = o.l; g.s = o.s;
+        out[off + j] = g;
+    }
+}
+// The reads of a batch whose SMEMs did not fit the first-round slot (a handful of low-complexity reads among millions):
+// their numbers in batch order, for a second round of the seeding kernel over them alone with slots of the exact size.
+__global__ __launch_bounds__(256) void fmi_list_overflowed(const int32_t *counts, int32_t n, int cap, int32_t *ids, int32_t *n_ids) {
+    const int32_t t = blockIdx.x * 256 + threadIdx.x;
+    if (t < n && counts[t] > cap) ids[atomicAdd(n_ids, 1)] = t;
+}
+__global__ __launch_bounds__(256) void fmi_compact_overflowed(const int32_t *counts, const int32_t *ids, int32_t n_ids, const OutRec *slots,
+                                                              int cap, int64_t first, const int64_t *read_off, gab_smem *out) {
+    const int32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_ids) return;
+    const int32_t t = ids[i];
+    const int c = counts[t];
+    const int64_t off = read_off[first + t];
+    const OutRec *src = slots + (int64_t)i * cap;
     for (int j = 0; j < c; j++) {
         const OutRec o = src[j];
         gab_smem g;
@@ -759,6 +783,7 @@ struct gab_fmi {
     gab_devbuf ws;          // counters, counts, block sums
     gab_devbuf prev;        // prev[] scratch
     gab_devbuf slots;       // per-read output slots
+    gab_devbuf slots2, ovf; // second round: slots of the exact size for the reads that overflowed theirs, and their numbers
     gab_devbuf out;         // compacted SMEMs
     gab_devbuf roff;        // read_off (nreads + 1)
     gab_devbuf io;          // staging for the host entry point
@@ -767,7 +792,10 @@ struct gab_fmi {
     SaIdx sa_ix = {nullptr, nullptr};
     int64_t sa_lf_steps = 0; float sa_ms = 0; bool have_sa_stats = false;
     size_t scratch_budget = (size_t)6 << 30;   // bound of the two big scratch areas (per-lane spill lists, per-read output slots)
+    bool scratch_from_env = false;             // $GAB_FMI_SCRATCH_MB set: never look at the free memory for a bigger one
     int lds_entries_env = 0;                   // $GAB_FMI_LDS_ENTRIES / $GAB_FMI_WIDE_LISTS as they were when the handle was made
+    int64_t batch_max = 1 << 24;               // $GAB_FMI_BATCH: reads per launch of the seeding kernel
+    int waves_env = 0;                         // $GAB_FMI_WAVES: cap of the resident waves per CU of passes 1 + 2 (experiments)
     bool wide_env = false;                     // (tests and bench.py: force the list format of indexes with >= 2^32 rows)
     hipEvent_t ev[2] = {nullptr, nullptr};
     FmiCounters *h_ct = nullptr;
@@ -784,7 +812,9 @@ static int fmi_new_handle(int device, gab_fmi **out) {
     h->device = device;
     { const char *e = getenv("GAB_FMI_LDS_ENTRIES"); h->lds_entries_env = e ? atoi(e) : 0; }
     { const char *e = getenv("GAB_FMI_WIDE_LISTS"); h->wide_env = e && atoi(e) != 0; }
-    { const char *e = getenv("GAB_FMI_SCRATCH_MB"); if (e && atoll(e) > 0) h->scratch_budget = (size_t)atoll(e) << 20; }
+    { const char *e = getenv("GAB_FMI_WAVES"); h->waves_env = e ? atoi(e) : 0; }
+    { const char *e = getenv("GAB_FMI_BATCH"); if (e && atoll(e) >= 1024) h->batch_max = atoll(e); }
+    { const char *e = getenv("GAB_FMI_SCRATCH_MB"); if (e && atoll(e) > 0) { h->scratch_budget = (size_t)atoll(e) << 20; h->scratch_from_env = true; } }
     if (hipEventCreate(&h->ev[0]) != hipSuccess || hipEventCreate(&h->ev[1]) != hipSuccess ||
         hipHostMalloc((void **)&h->h_ct, sizeof(FmiCounters)) != hipSuccess) {
         gab_set_error("gab_fmi: event / pinned allocation failed"); delete h; return GAB_EDEVICE;
@@ -880,7 +910,7 @@ extern "C" int gab_fmi_clone(gab_fmi *src, gab_fmi **out) {
     gab_fmi *h = nullptr;
     int rc = fmi_new_handle(src->device, &h);
     if (rc) return rc;
-    h->ix = src->ix; h->sa_ix = src->sa_ix; h->scratch_budget = src->scratch_budget;
+    h->ix = src->ix; h->sa_ix = src->sa_ix; h->scratch_budget = src->scratch_budget; h->scratch_from_env = src->scratch_from_env; h->batch_max = src->batch_max; h->waves_env = src->waves_env;
     *out = h;
     return GAB_OK;
 }
@@ -888,7 +918,7 @@ extern "C" int gab_fmi_clone(gab_fmi *src, gab_fmi **out) {
 extern "C" void gab_fmi_destroy(gab_fmi *h) {
     if (!h) return;
     gab_device_guard g(h->device);
-    h->index.release(); h->kmer.release(); h->sa.release(); h->sa_ws.release(); h->sa_off.release(); h->sa_coords.release(); h->sa_io.release(); h->ws.release(); h->prev.release(); h->slots.release(); h->out.release(); h->roff.release();
+    h->index.release(); h->kmer.release(); h->sa.release(); h->sa_ws.release(); h->sa_off.release(); h->sa_coords.release(); h->sa_io.release(); h->ws.release(); h->prev.release(); h->slots.release(); h->slots2.release(); h->ovf.release(); h->out.release(); h->roff.release();
     h->io.release(); h->hs.release();
     for (int k = 0; k < 2; k++) if (h->ev[k]) (void)hipEventDestroy(h->ev[k]);
     if (h->h_ct) (void)hipHostFree(h->h_ct);
@@ -918,7 +948,20 @@ extern "C" int gab_fmi_seed_device(gab_fmi *h, const uint8_t *d_enc, int32_t str
     // The seeding kernel is a persistent grid of one-wave blocks sized to the occupancy; lanes pull reads from a
     // counter.  Scratch: a spill area for interval lists longer than the LDS part (stride entries x 32 B per LANE,
     // touched only by the rare long list) and the output slot per READ (cap x 32 B).
-    int cap = 48;
+    // A batch cannot end before its slowest read has (passes 1 + 2 of a read are one chain of dependent look-ups: ~750 wave steps
+    // on average, but ONE backward phase of a re-seeded position inside a repeat -- a 76-entry list over 75 columns -- is 5 700,
+    // ~25 ms), and while the last reads finish most lanes idle: 10 M reads in four batches spent 4 x ~22 ms of 322 ms there
+    // (profiles/r03_fmi_batches.md).  So the whole call is ONE batch whenever its slots (cap x 32 B per read) fit a third of
+    // the memory that is free right now, up to 32 GB; $GAB_FMI_SCRATCH_MB fixes the budget instead.
+    size_t budget = h->scratch_budget;
+    if (!h->scratch_from_env && (size_t)nreads * 48 * sizeof(OutRec) > budget) {
+        size_t fr = 0, tot = 0;
+        if (hipMemGetInfo(&fr, &tot) == hipSuccess) {
+            const size_t avail = (fr + h->slots.cap) / 3;
+            budget = std::max(budget, std::min<size_t>(avail, (size_t)32 << 30));
+        }
+    }
+    const int cap = 48;
     const int lds_entries_env = h->lds_entries_env;
     const bool ldsq = stride <= kLdsQMax;
     const int lds_entries = ldsq ? (lds_entries_env > 0 ? lds_entries_env : 12) : 0;
@@ -941,13 +984,14 @@ extern "C" int gab_fmi_seed_device(gab_fmi *h, const uint8_t *d_enc, int32_t str
         GAB_CHECK(waves_per_cu > 0, "gab_fmi_seed_device: the seeding kernel does not fit a CU (stride %d)", stride);
         // the per-lane spill area is stride x 32 B x 64 lanes per resident wave: long reads (no LDS lists: every list entry
         // lives there) run on fewer waves rather than on tens of GB of scratch
-        const int64_t fit = (int64_t)(h->scratch_budget / (sizeof(PrevRec) * (size_t)stride * 64)) / n_cu;
+        const int64_t fit = (int64_t)(budget / (sizeof(PrevRec) * (size_t)stride * 64)) / n_cu;
         if (fit < waves_per_cu) waves_per_cu = (int)std::max<int64_t>(fit, 1);
+        if (h->waves_env > 0 && h->waves_env < waves_per_cu) waves_per_cu = h->waves_env;
         if (fit < waves_per_cu_p3) waves_per_cu_p3 = (int)std::max<int64_t>(fit, 1);
     }
     const int64_t grid_waves = (int64_t)n_cu * std::max(waves_per_cu, waves_per_cu_p3);
-    int64_t B = (int64_t)std::min<size_t>((size_t)nreads, std::max<size_t>(1024, h->scratch_budget / (64 * sizeof(OutRec))));
-    B = std::min<int64_t>(B, 1 << 22);
+    int64_t B = (int64_t)std::min<size_t>((size_t)nreads, std::max<size_t>(1024, budget / (64 * sizeof(OutRec))));
+    B = std::min<int64_t>(B, h->batch_max);
     B = gab_ceil_div(nreads, gab_ceil_div(nreads, B));       // equal batches: no short last one
     const int64_t nb_blocks = gab_ceil_div(B, 256);
     const size_t o_counts = 256, o_bs = o_counts + 4 * (size_t)B + 64;
@@ -980,48 +1024,47 @@ extern "C" int gab_fmi_seed_device(gab_fmi *h, const uint8_t *d_enc, int32_t str
     int64_t total = 0;
     unsigned long long ext_total = 0, rec_total = 0;
     float kms = 0;
+    // one launch of the seeding kernel(s) over `count` reads of the batch at `first`: all of them (ids == nullptr, slot t for
+    // read t) or the listed ones (slot i for read ids[i])
+    auto seed = [&](int64_t first, int32_t nb, int32_t count, const int32_t *ids, OutRec *slots, int slot_cap, int *waves_dbg) -> int {
+        const int seed_blocks = (int)std::min<int64_t>((int64_t)n_cu * waves_per_cu, gab_ceil_div((int64_t)count, 64));
+        if (waves_dbg) *waves_dbg = seed_blocks;
+        GAB_HIP(hipMemsetAsync(&d_ct->next_read, 0, sizeof(int32_t), s));
+        if (ldsq) {
+            // passes 1 + 2 need the interval lists in LDS, which caps the occupancy; pass 3 needs only the read, so it
+            // runs as a second launch of the same kernel with no list area and twice the waves
+            hipLaunchKernelGGL(fmi_seed_kernel<true>, dim3(seed_blocks), dim3(64), lds_bytes, s, h->ix, d_enc, stride, d_len, first,
+                               count, min_seed_len, h->prev.as<PrevRec>(), (int)stride, slots, slot_cap, d_counts, d_ct,
+                               lds_entries, (int64_t)nreads * stride, 1, narrow_lists, ids);
+            GAB_HIP(hipMemsetAsync(&d_ct->next_read, 0, sizeof(int32_t), s));
+            const int p3_blocks = (int)std::min<int64_t>((int64_t)n_cu * waves_per_cu_p3, gab_ceil_div((int64_t)count, 64));
+            hipLaunchKernelGGL(fmi_seed_kernel<true>, dim3(p3_blocks), dim3(64), lds_bytes_p3, s, h->ix, d_enc, stride, d_len, first,
+                               count, min_seed_len, h->prev.as<PrevRec>(), (int)stride, slots, slot_cap, d_counts, d_ct,
+                               0, (int64_t)nreads * stride, 2, narrow_lists, ids);
+        } else
+            hipLaunchKernelGGL(fmi_seed_kernel<false>, dim3(seed_blocks), dim3(64), 0, s, h->ix, d_enc, stride, d_len, first, count,
+                               min_seed_len, h->prev.as<PrevRec>(), (int)stride, slots, slot_cap, d_counts, d_ct, 0,
+                               (int64_t)nreads * stride, 3, 0, ids);
+        hipLaunchKernelGGL(fmi_sort_slots, dim3((unsigned)gab_ceil_div((int64_t)count, 256)), dim3(256), 0, s, slots, slot_cap, d_counts, count, ids);
+        GAB_HIP(hipGetLastError());
+        (void)nb;
+        return GAB_OK;
+    };
     for (int64_t first = 0; first < nreads;) {
-        int32_t nb = (int32_t)std::min<int64_t>(B, nreads - first);
-        int blocks = (int)gab_ceil_div(nb, 256);
+        const int32_t nb = (int32_t)std::min<int64_t>(B, nreads - first);
+        const int blocks = (int)gab_ceil_div(nb, 256);
         int seed_blocks_dbg = 0;
-        for (;;) {                                        // at most two rounds: second with the exact slot size
-            rc = h->slots.reserve(sizeof(OutRec) * (size_t)cap * (size_t)nb);
-            if (rc) return rc;
-            h->h_ct->ext_calls = 0; h->h_ct->rec_reads = 0; h->h_ct->tab_reads = 0; h->h_ct->total = 0; h->h_ct->max_per_read = 0; h->h_ct->next_read = 0; h->h_ct->wave_steps = 0; h->h_ct->positions = h->h_ct->spills = h->h_ct->list_sum = 0;
-            GAB_HIP(hipMemcpyAsync(d_ct, h->h_ct, sizeof(FmiCounters), hipMemcpyHostToDevice, s));
-            GAB_HIP(hipEventRecord(h->ev[0], s));
-            const int seed_blocks = (int)std::min<int64_t>((int64_t)n_cu * waves_per_cu, gab_ceil_div((int64_t)nb, 64));
-            seed_blocks_dbg = seed_blocks;
-            if (ldsq) {
-                // passes 1 + 2 need the interval lists in LDS, which caps the occupancy; pass 3 needs only the read, so it
-                // runs as a second launch of the same kernel with no list area and twice the waves
-                hipLaunchKernelGGL(fmi_seed_kernel<true>, dim3(seed_blocks), dim3(64), lds_bytes, s, h->ix, d_enc, stride, d_len, first,
-                                   nb, min_seed_len, h->prev.as<PrevRec>(), (int)stride, h->slots.as<OutRec>(), cap, d_counts, d_ct,
-                                   lds_entries, (int64_t)nreads * stride, 1, narrow_lists);
-                GAB_HIP(hipMemsetAsync(&d_ct->next_read, 0, sizeof(int32_t), s));
-                const int p3_blocks = (int)std::min<int64_t>((int64_t)n_cu * waves_per_cu_p3, gab_ceil_div((int64_t)nb, 64));
-                hipLaunchKernelGGL(fmi_seed_kernel<true>, dim3(p3_blocks), dim3(64), lds_bytes_p3, s, h->ix, d_enc, stride, d_len, first,
-                                   nb, min_seed_len, h->prev.as<PrevRec>(), (int)stride, h->slots.as<OutRec>(), cap, d_counts, d_ct,
-                                   0, (int64_t)nreads * stride, 2, narrow_lists);
-            } else
-                hipLaunchKernelGGL(fmi_seed_kernel<false>, dim3(seed_blocks), dim3(64), 0, s, h->ix, d_enc, stride, d_len, first, nb,
-                                   min_seed_len, h->prev.as<PrevRec>(), (int)stride, h->slots.as<OutRec>(), cap, d_counts, d_ct, 0,
-                                   (int64_t)nreads * stride, 3, 0);
-            hipLaunchKernelGGL(fmi_sort_slots, dim3(blocks), dim3(256), 0, s, h->slots.as<OutRec>(), cap, d_counts, nb);
-            GAB_HIP(hipGetLastError());
-            GAB_HIP(hipEventRecord(h->ev[1], s));
-            GAB_HIP(hipMemcpyAsync(h->h_ct, d_ct, sizeof(FmiCounters), hipMemcpyDeviceToHost, s));
-            GAB_HIP(hipStreamSynchronize(s));
-            if (h->h_ct->max_per_read <= cap) break;
-            cap = h->h_ct->max_per_read + 8;              // some read overflowed its slot: redo the batch
-            // ... in smaller batches from here on if one repetitive read would otherwise multiply the slot buffer of millions
-            const size_t fitb = h->scratch_budget / (sizeof(OutRec) * (size_t)cap);
-            if ((size_t)nb > fitb && nb > 1024) {
-                B = (int64_t)std::max<size_t>(fitb, 1024);
-                nb = (int32_t)std::min<int64_t>(B, nreads - first);
-                blocks = (int)gab_ceil_div(nb, 256);
-            }
-        }
+        rc = h->slots.reserve(sizeof(OutRec) * (size_t)cap * (size_t)nb);
+        if (rc) return rc;
+        h->h_ct->ext_calls = 0; h->h_ct->rec_reads = 0; h->h_ct->tab_reads = 0; h->h_ct->total = 0; h->h_ct->max_per_read = 0; h->h_ct->next_read = 0; h->h_ct->n_ovf = 0; h->h_ct->wave_steps = 0; h->h_ct->positions = h->h_ct->spills = h->h_ct->list_sum = 0;
+        GAB_HIP(hipMemcpyAsync(d_ct, h->h_ct, sizeof(FmiCounters), hipMemcpyHostToDevice, s));
+        GAB_HIP(hipEventRecord(h->ev[0], s));
+        rc = seed(first, nb, nb, nullptr, h->slots.as<OutRec>(), cap, &seed_blocks_dbg);
+        if (rc) return rc;
+        GAB_HIP(hipEventRecord(h->ev[1], s));
+        GAB_HIP(hipMemcpyAsync(h->h_ct, d_ct, sizeof(FmiCounters), hipMemcpyDeviceToHost, s));
+        GAB_HIP(hipStreamSynchronize(s));
+        const int over_cap = h->h_ct->max_per_read > cap ? h->h_ct->max_per_read : 0;   // the counters of THIS round are the batch's
         float ms = 0;
         GAB_HIP(hipEventElapsedTime(&ms, h->ev[0], h->ev[1]));
         kms += ms;
@@ -1049,6 +1092,40 @@ extern "C" int gab_fmi_seed_device(gab_fmi *h, const uint8_t *d_enc, int32_t str
         hipLaunchKernelGGL(fmi_compact, dim3(blocks), dim3(256), 0, s, d_counts, nb, d_bs, h->slots.as<OutRec>(), cap, first,
                            h->roff.as<int64_t>(), h->out.as<gab_smem>());
         GAB_HIP(hipGetLastError());
+        if (over_cap) {
+            // Some reads found more SMEMs than a first-round slot holds (low-complexity reads; a handful among millions of
+            // real ones): they alone run again with slots of the size the worst of them needs, in as many rounds as the
+            // scratch budget asks for, and their records go to the places fmi_compact left open.  Everything the kernel
+            // counts (extensions, records) was complete after the first round; the second round's counts are dropped.
+            rc = h->ovf.reserve(4 * (size_t)nb + 64);
+            if (rc) return rc;
+            int32_t *d_ids = h->ovf.as<int32_t>();
+            hipLaunchKernelGGL(fmi_list_overflowed, dim3(blocks), dim3(256), 0, s, d_counts, nb, cap, d_ids, &d_ct->n_ovf);
+            GAB_HIP(hipGetLastError());
+            int32_t n_ovf = 0;
+            GAB_HIP(hipMemcpyAsync(&n_ovf, &d_ct->n_ovf, 4, hipMemcpyDeviceToHost, s));
+            GAB_HIP(hipStreamSynchronize(s));
+            const int64_t per_round = std::max<int64_t>(1, (int64_t)(budget / (sizeof(OutRec) * (size_t)over_cap)));
+            const int64_t round = std::min<int64_t>(n_ovf, per_round);
+            rc = h->slots2.reserve(sizeof(OutRec) * (size_t)over_cap * (size_t)round);
+            if (rc) return rc;
+            if (getenv("GAB_FMI_DEBUG"))
+                fprintf(stderr, "[gab_fmi] %d read(s) overflowed their %d-record slot (worst: %d records): second round in %lld part(s)\n",
+                        n_ovf, cap, over_cap, (long long)gab_ceil_div((int64_t)n_ovf, round));
+            GAB_HIP(hipEventRecord(h->ev[0], s));
+            for (int64_t i0 = 0; i0 < n_ovf; i0 += round) {
+                const int32_t cnt = (int32_t)std::min<int64_t>(round, n_ovf - i0);
+                rc = seed(first, nb, cnt, d_ids + i0, h->slots2.as<OutRec>(), over_cap, nullptr);
+                if (rc) return rc;
+                hipLaunchKernelGGL(fmi_compact_overflowed, dim3((unsigned)gab_ceil_div((int64_t)cnt, 256)), dim3(256), 0, s, d_counts, d_ids + i0,
+                                   cnt, h->slots2.as<OutRec>(), over_cap, first, h->roff.as<int64_t>(), h->out.as<gab_smem>());
+                GAB_HIP(hipGetLastError());
+            }
+            GAB_HIP(hipEventRecord(h->ev[1], s));
+            GAB_HIP(hipEventSynchronize(h->ev[1]));
+            GAB_HIP(hipEventElapsedTime(&ms, h->ev[0], h->ev[1]));
+            kms += ms;
+        }
         total += add;
         first += nb;
     }
