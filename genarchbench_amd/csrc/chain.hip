@@ -28,6 +28,7 @@
 #include "gab_internal.h"
 #include <algorithm>
 #include <new>
+#include <atomic>
 #include <vector>
 #include <chrono>
 #include <stdlib.h>
@@ -58,20 +59,23 @@ struct ChainFeed {
 };
 struct ChainChunk { int64_t hoff, doff; int32_t n, item; };   // up to kFeedChunk anchors of work item `item`: where they are, where they go
 constexpr int kFeedChunk = 2048;
-constexpr long kFeedSpinLimit = 4000000;      // x ~1 us of s_sleep: a wait gives up after seconds, so the grid always drains
+constexpr long kFeedSpinLimit = 600000;       // x ~7 us of s_sleep: a wait gives up after seconds, so the grid always drains
 
 // wait (thread 0, sleeping) until the anchors of this workgroup's call are in device memory; returns the facts word (0: gave up)
-__device__ __forceinline__ uint32_t chain_feed_wait(const ChainFeed &feed, uint32_t *s_word) {
+__device__ __forceinline__ uint32_t gab_xcc_id() { return (uint32_t)__builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xfu; }   // HW_REG_XCC_ID
+__device__ __forceinline__ uint32_t chain_feed_wait(const ChainFeed &feed, uint32_t item, uint32_t *s_word) {
     if (threadIdx.x == 0) {
         uint32_t f = 0;
         for (long spins = 0;; spins++) {
-            f = __hip_atomic_load(&feed.facts[blockIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            f = __hip_atomic_load(&feed.facts[item], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (f) break;
-            if (spins > kFeedSpinLimit || __hip_atomic_load(feed.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+            // (over a thousand workgroups wait at a time: a look at the ONE abort word per spin is a billion requests per second
+            // on one address, and a spin per microsecond is more than the anchors' arrival needs)
+            if (spins > kFeedSpinLimit || ((spins & 63) == 63 && __hip_atomic_load(feed.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
                 __hip_atomic_store(feed.abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 break;
             }
-            __builtin_amdgcn_s_sleep(32);
+            __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127);
         }
         *s_word = f;
     }
@@ -92,11 +96,20 @@ __global__ __launch_bounds__(256) void chain_gather_kernel(const ChainChunk *__r
                                                            uint64_t *__restrict__ dx, uint64_t *__restrict__ dy,
                                                            const ChainWork *__restrict__ work, const uint32_t *__restrict__ need,
                                                            uint32_t *done, unsigned long long *xlo, unsigned long long *xhi,
-                                                           uint32_t *mixed, uint32_t *facts, volatile uint8_t *started, int gap_tab_max) {
+                                                           uint32_t *mixed, uint32_t *facts, volatile uint8_t *started, int gap_tab_max,
+                                                           uint32_t *next_chunk, unsigned long long *pub_dbg) {
     __shared__ unsigned long long s_lo[4], s_hi[4];
     __shared__ uint32_t s_mx[4];
-    if (threadIdx.x == 0) started[blockIdx.x] = 1;            // (host memory: the host launches the DP once every workgroup is resident)
-    for (uint32_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
+    __shared__ uint32_t s_chunk;
+    if (threadIdx.x == 0) started[blockIdx.x] = (uint8_t)(1u + gab_xcc_id());   // (host memory: the host launches the DP once every workgroup is resident, and learns where they are)
+    // The chunks are handed out from ONE counter, in table order: workgroups read the bus at very different rates (a static
+    // stride had the fastest workgroups through their last chunk after 15 ms and the slowest after 24 -- the 300th-longest
+    // call, 19 % into the table, was complete after 16 ms instead of 5), and the DP's critical path is the longest calls.
+    for (;;) {
+        if (threadIdx.x == 0) s_chunk = atomicAdd(next_chunk, 1u);
+        __syncthreads();
+        const uint32_t c = s_chunk;
+        if (c >= nchunks) break;
         const ChainChunk ch = chunks[c];
         const ChainWork w = work[ch.item];
         const uint32_t sid0 = (uint32_t)(hy[w.hoff] >> 48 & 0xff);
@@ -142,6 +155,7 @@ __global__ __launch_bounds__(256) void chain_gather_kernel(const ChainChunk *__r
                 const unsigned long long lim = mq < 0 ? 0ull : (unsigned long long)mq;
                 const bool plain = w.n > 0 && !M && H - L + lim < 0x7fffffffull && w.bw >= 0 && w.bw <= gap_tab_max;   // = chain_facts_kernel
                 __hip_atomic_store(&facts[ch.item], 2u | (plain ? 1u : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (pub_dbg) pub_dbg[ch.item] = wall_clock64();
             }
         }
         __syncthreads();
@@ -603,7 +617,9 @@ template <> struct AnchorPtr<true> { using type = const uint64_t *; };
 template <bool FED> struct AnchorView {
     const uint64_t *p;
     __device__ __forceinline__ uint64_t operator[](int64_t i) const {
+#ifndef GAB_KO_FEDPLAIN
         if (FED) return __hip_atomic_load(p + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
         return p[i];
     }
 };
@@ -614,8 +630,9 @@ __device__ __forceinline__ void fastchain_body(const ChainWork *__restrict__ wor
                                                unsigned long long *evals_out, ChainFeed feed) {
     __shared__ int32_t part_best[2][H][64], part_j[2][H][64], part_st[2][64];
     __shared__ uint32_t feed_word;
-    if (FED && chain_feed_wait(feed, &feed_word) == 0) return;
-    const ChainWork w = work[blockIdx.x];
+    const uint32_t item = blockIdx.x;
+    if (FED && chain_feed_wait(feed, item, &feed_word) == 0) return;
+    const ChainWork w = work[item];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave index: uniform, say so
     const AnchorView<FED> X{xs + w.off}, Y{ys + w.off};
     int32_t *S = score_out + w.off, *P = parent_out + w.off;
@@ -827,7 +844,7 @@ __device__ __forceinline__ void fastchain_body(const ChainWork *__restrict__ wor
             if (mine) {
                 const int32_t par_ = have ? (int32_t)(i0 + best_j) : -1;
                 S[i0 + lane] = best; P[i0 + lane] = par_;
-                if (FED) { feed.host_score[w.hoff + i0 + lane] = best; feed.host_parent[w.hoff + i0 + lane] = par_; }
+                if (FED && feed.host_score) { feed.host_score[w.hoff + i0 + lane] = best; feed.host_parent[w.hoff + i0 + lane] = par_; }
             }
             pxa = xa; pya = ya; pbest = best; pnb = nb;
         }
@@ -1041,10 +1058,11 @@ __device__ __forceinline__ void chain_block_body(const ChainWork *__restrict__ w
     __shared__ int32_t part_best[2][H][64], part_j[2][H][64], part_ok[2][H][64], part_st[2][64];
     __shared__ uint32_t feed_word;
     uint32_t fed_facts = 0;
-    if (FED && feed.dbg && threadIdx.x == 0) feed.dbg[3 * blockIdx.x] = wall_clock64();
-    if (FED && (fed_facts = chain_feed_wait(feed, &feed_word)) == 0) return;
-    if (FED && feed.dbg && threadIdx.x == 0) feed.dbg[3 * blockIdx.x + 1] = wall_clock64();
-    const ChainWork w = work[blockIdx.x];
+    const uint32_t item = blockIdx.x;
+    if (FED && feed.dbg && threadIdx.x == 0) feed.dbg[3 * item] = wall_clock64() << 4 | gab_xcc_id();
+    if (FED && (fed_facts = chain_feed_wait(feed, item, &feed_word)) == 0) return;
+    if (FED && feed.dbg && threadIdx.x == 0) feed.dbg[3 * item + 1] = wall_clock64();
+    const ChainWork w = work[item];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const AnchorView<FED> X{xs + w.off}, Y{ys + w.off};
     int32_t *S = score_out + w.off, *P = parent_out + w.off, *GM = gmarks_all + w.off;
@@ -1367,7 +1385,7 @@ __device__ __forceinline__ void chain_block_body(const ChainWork *__restrict__ w
             if (mine) {
                 const int32_t par_ = best_j == kNoJ ? -1 : i0 + best_j;
                 S[i0 + lane] = best; P[i0 + lane] = par_;
-                if (FED) { feed.host_score[w.hoff + i0 + lane] = best; feed.host_parent[w.hoff + i0 + lane] = par_; }
+                if (FED && feed.host_score) { feed.host_score[w.hoff + i0 + lane] = best; feed.host_parent[w.hoff + i0 + lane] = par_; }
             }
             prev = cur; pbest = best; pnb = nb;
         }
@@ -1375,7 +1393,7 @@ __device__ __forceinline__ void chain_block_body(const ChainWork *__restrict__ w
     }
     for (int o = 32; o > 0; o >>= 1) evals += __shfl_xor(evals, o);
     if (lane == 0 && evals) atomicAdd(evals_out, evals);
-    if (FED && feed.dbg && threadIdx.x == 0) feed.dbg[3 * blockIdx.x + 2] = wall_clock64();
+    if (FED && feed.dbg && threadIdx.x == 0) feed.dbg[3 * item + 2] = wall_clock64();
 }
 
 // Throughput form (three helpers, big batches): six waves per SIMD = six calls per CU -- 80 VGPRs and 84 B of scratch instead
@@ -1923,6 +1941,9 @@ struct gab_chain {
     hipEvent_t ev[2] = {nullptr, nullptr};
     // the host-pointer entry point of big batches: two more streams and the events that order its copies and kernels
     hipStream_t xs[2] = {nullptr, nullptr};
+    hipStream_t gs = nullptr;                 // fed path: the gather's stream, confined to the CUs of one XCD
+    bool gs_tried = false;
+    int gs_blocks = 256;
     hipStream_t fs = nullptr;                // the latency-form launch of the longest calls runs beside the throughput launch of the rest
     hipEvent_t fe[2] = {nullptr, nullptr};
     hipEvent_t xe[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -1956,6 +1977,7 @@ extern "C" void gab_chain_destroy(gab_chain *h) {
     h->work.release(); h->io.release(); h->hs.release(); h->gmarks.release();
     for (int k = 0; k < 2; k++) if (h->ev[k]) (void)hipEventDestroy(h->ev[k]);
     for (int k = 0; k < 2; k++) if (h->xs[k]) (void)hipStreamDestroy(h->xs[k]);
+    if (h->gs) (void)hipStreamDestroy(h->gs);
     if (h->fs) (void)hipStreamDestroy(h->fs);
     for (int k = 0; k < 2; k++) if (h->fe[k]) (void)hipEventDestroy(h->fe[k]);
     for (int k = 0; k < 5; k++) if (h->xe[k]) (void)hipEventDestroy(h->xe[k]);
@@ -2266,9 +2288,34 @@ static int chain_run_fed(gab_chain *h, int mode, const uint64_t *x, const uint64
     }
     h->have_stats = false;
     if (!h->xs[0] && hipStreamCreateWithFlags(&h->xs[0], hipStreamNonBlocking) != hipSuccess) { gab_set_error("gab_chain_run: stream creation failed"); return GAB_EDEVICE; }
-    hipStream_t sG = h->xs[0];
-    constexpr int kGatherBlocks = 256;
-    if (!h->h_started && hipHostMalloc((void **)&h->h_started, kGatherBlocks + 64) != hipSuccess) { gab_set_error("gab_chain_run: pinned allocation failed"); return GAB_EDEVICE; }
+    // The gather kernel keeps megabytes of reads from HOST memory in flight, ~3 us each, and a CU's vector memory pipeline
+    // returns data in order: with a gather workgroup on every CU the DP ran at half of its speed until the last anchor had
+    // arrived (a 60 000-anchor call that was there at t = 0 was done after 33 ms, against 14 ms with the bus idle; 0.65-0.73 ms
+    // per 1000 anchors of a long call on every XCD against 0.33) -- overlapping the gather with the DP was worth 1.4 of 51 ms.
+    // The gather therefore runs on a stream confined to ONE CU per XCD (a CU-mask stream: mask bit b is CU b / 8 of XCD
+    // b % 8; 8 workgroups of 256 threads fill that CU and 64 of them keep the bus as busy as 256 did: 26.0 against 24.4 ms for
+    // 1.36 GB), and the DP has the other 248 CUs to itself: DP done after 35.7 ms instead of 51 (profiles/r03_chain_fed.md).
+    // $GAB_CHAIN_GATHER_MASK: "none" = the old form (256 workgroups anywhere), "N:M" = bits N .. N + M - 1 (experiments).
+    int gather_blocks = 256;
+    if (!h->gs && !h->gs_tried) {
+        h->gs_tried = true;
+        int ncu = 0;
+        (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, h->device);
+        const char *e = getenv("GAB_CHAIN_GATHER_MASK");
+        static std::atomic<int> next_cu{0};                  // every handle of the process its own CU (workers of one driver run side by side)
+        int b0 = 8 * (next_cu.fetch_add(1) % 32), nb = 8;
+        if (e && e[0] >= '0' && e[0] <= '9') { b0 = atoi(e); nb = strchr(e, ':') ? atoi(strchr(e, ':') + 1) : 8; }
+        if (!(e && !strcmp(e, "none")) && ncu == 256 && b0 >= 0 && nb > 0 && b0 + nb <= ncu) {
+            uint32_t mg[8] = {};
+            for (int b = b0; b < b0 + nb; b++) mg[b >> 5] |= 1u << (b & 31);
+            if (hipExtStreamCreateWithCUMask(&h->gs, 8, mg) != hipSuccess) { (void)hipGetLastError(); h->gs = nullptr; }
+            else h->gs_blocks = std::min(256, 8 * nb);        // 2048 threads per CU
+        }
+    }
+    if (h->gs) gather_blocks = h->gs_blocks;
+    if (const char *e = getenv("GAB_CHAIN_GATHER_BLOCKS")) { const int v = atoi(e); if (v >= 8 && v <= 256) gather_blocks = v; }
+    hipStream_t sG = h->gs ? h->gs : h->xs[0];
+    if (!h->h_started && hipHostMalloc((void **)&h->h_started, 256 + 64) != hipSuccess) { gab_set_error("gab_chain_run: pinned allocation failed"); return GAB_EDEVICE; }
     // work list, longest call first; on the device every call starts on a 128-byte line (16 anchors), so that no cache line is
     // shared between calls (see chain_feed_wait); and the chunk table
     std::vector<ChainWork> wk;
@@ -2321,14 +2368,16 @@ static int chain_run_fed(gab_chain *h, int mode, const uint64_t *x, const uint64
     GAB_HIP(hipMemcpyAsync(wb + o_need, need.data(), 4 * nw, hipMemcpyHostToDevice, sG));
     GAB_HIP(hipMemcpyAsync(wb + o_chunks, chunks.data(), sizeof(ChainChunk) * chunks.size(), hipMemcpyHostToDevice, sG));
     if (d_gm) GAB_HIP(hipMemsetAsync(d_gm, 0, sizeof(int32_t) * t, sG));            // vector::resize zero-fills targets
-    memset(h->h_started, 0, kGatherBlocks);
+    memset(h->h_started, 0, gather_blocks);
     void *d_started = nullptr;
     GAB_HIP(hipHostGetDevicePointer(&d_started, h->h_started, 0));
+    unsigned long long *d_pub = nullptr;
+    if (trace) { (void)hipMalloc((void **)&d_pub, 8 * nw); (void)hipMemsetAsync(d_pub, 0, 8 * nw, sG); }
     GAB_HIP(hipEventRecord(h->xe_fed, sG));                                         // tables and zeroed arrays are in place
-    hipLaunchKernelGGL(chain_gather_kernel, dim3(kGatherBlocks), dim3(256), 0, sG, (const ChainChunk *)(wb + o_chunks), (uint32_t)chunks.size(),
+    hipLaunchKernelGGL(chain_gather_kernel, dim3(gather_blocks), dim3(256), 0, sG, (const ChainChunk *)(wb + o_chunks), (uint32_t)chunks.size(),
                        (const uint64_t *)hx, (const uint64_t *)hy, dx, dy, (const ChainWork *)d_work, (const uint32_t *)(wb + o_need),
                        (uint32_t *)(wb + o_done), (unsigned long long *)(wb + o_xlo), (unsigned long long *)(wb + o_xhi),
-                       (uint32_t *)(wb + o_mixed), (uint32_t *)(wb + o_facts), (volatile uint8_t *)d_started, kGapTab - 2);
+                       (uint32_t *)(wb + o_mixed), (uint32_t *)(wb + o_facts), (volatile uint8_t *)d_started, kGapTab - 2, d_abort + 2, d_pub);
     GAB_HIP(hipGetLastError());
     if (trace) (void)hipEventRecord(tv[1], sG);
     // ---- wait until every gather workgroup is resident (they all start at once on an idle GPU: tens of microseconds);
@@ -2338,11 +2387,12 @@ static int chain_run_fed(gab_chain *h, int mode, const uint64_t *x, const uint64
         bool all = false;
         while (!all) {
             all = true;
-            for (int k = 0; k < kGatherBlocks; k++) if (!((volatile uint8_t *)h->h_started)[k]) { all = false; break; }
+            for (int k = 0; k < gather_blocks; k++) if (!((volatile uint8_t *)h->h_started)[k]) { all = false; break; }
             if (!all && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) break;
         }
         if (!all) GAB_HIP(hipStreamSynchronize(sG));
     }
+    if (getenv("GAB_CHAIN_FED_SERIAL")) GAB_HIP(hipStreamSynchronize(sG));        // experiments: the DP only after the last anchor
     // ---- the DP: one launch, its workgroups wait for their call
     GAB_HIP(hipStreamWaitEvent(sA, h->xe_fed, 0));
     const bool write_through = true;              // (measured: results by two copies at the end instead cost their 12 ms in full)
@@ -2359,18 +2409,39 @@ static int chain_run_fed(gab_chain *h, int mode, const uint64_t *x, const uint64
     GAB_HIP(hipStreamSynchronize(sA));            // (the host vectors must outlive their copies)
     if (trace) {
         float a = 0, c = 0;
-        (void)hipEventElapsedTime(&a, tv[0], tv[1]); (void)hipEventElapsedTime(&c, tv[0], tv[3]);
-        fprintf(stderr, "[gab_chain_run] fed: %zu calls in %zu chunks; all anchors on the device after %.1f ms, DP done after %.1f ms\n", nw, chunks.size(), a, c);
+        float d = 0;
+        (void)hipEventElapsedTime(&a, tv[0], tv[1]); (void)hipEventElapsedTime(&c, tv[0], tv[3]); (void)hipEventElapsedTime(&d, tv[2], tv[3]);
+        fprintf(stderr, "[gab_chain_run] fed: %zu calls in %zu chunks; all anchors on the device after %.1f ms, DP done after %.1f ms (the DP launch itself: %.1f ms)\n", nw, chunks.size(), a, c, d);
         for (auto &e : tv) (void)hipEventDestroy(e);
         if (d_dbg) {
-            std::vector<unsigned long long> dbg(3 * nw);
+            std::vector<unsigned long long> dbg(3 * nw), pub(nw);
             (void)hipMemcpy(dbg.data(), d_dbg, 24 * nw, hipMemcpyDeviceToHost);
+            if (d_pub) (void)hipMemcpy(pub.data(), d_pub, 8 * nw, hipMemcpyDeviceToHost);
             unsigned long long t0 = ~0ull;
+            std::vector<int> xcc(nw);
+            for (size_t k = 0; k < nw; k++) { xcc[k] = (int)(dbg[3 * k] & 15); dbg[3 * k] >>= 4; }
             for (size_t k = 0; k < nw; k++) t0 = std::min(t0, dbg[3 * k]);
             for (size_t k : {(size_t)0, (size_t)50, (size_t)300, (size_t)900, (size_t)1100, (size_t)1300, (size_t)1600, (size_t)2500, (size_t)5000, nw - 1})
-                if (k < nw) fprintf(stderr, "   item %zu (n = %lld): dispatched %.2f ms, anchors there %.2f ms, done %.2f ms\n", k, (long long)wk[k].n,
-                                    (dbg[3 * k] - t0) * 1e-5, (dbg[3 * k + 1] - t0) * 1e-5, (dbg[3 * k + 2] - t0) * 1e-5);
+                if (k < nw) fprintf(stderr, "   item %zu (n = %lld): dispatched %.2f ms, published by the gather %.2f ms, anchors there %.2f ms, done %.2f ms\n", k, (long long)wk[k].n,
+                                    (dbg[3 * k] - t0) * 1e-5, ((double)pub[k] - (double)t0) * 1e-5, (dbg[3 * k + 1] - t0) * 1e-5, (dbg[3 * k + 2] - t0) * 1e-5);
+            {
+                int hist[16] = {};
+                for (int k = 0; k < gather_blocks; k++) { const int v = ((volatile uint8_t *)h->h_started)[k]; if (v) hist[(v - 1) & 15]++; }
+                fprintf(stderr, "   gather workgroups per XCD: %d %d %d %d %d %d %d %d\n",
+                        hist[0], hist[1], hist[2], hist[3], hist[4], hist[5], hist[6], hist[7]);
+            }
+            for (int r = 0; r < 8; r++) {
+                double lat = 0, disp = 0; int nl = 0, nd = 0;
+                for (size_t k = 0; k < nw; k++) {
+                    if (xcc[k] != r) continue;
+                    if (k < 1000) { lat += (double)(dbg[3 * k + 2] - dbg[3 * k + 1]) * 1e-5 / ((double)wk[k].n * 1e-3); nl++; }
+                    else if (k >= 3000) { disp += (double)(dbg[3 * k] - t0) * 1e-5; nd++; }
+                }
+                fprintf(stderr, "   XCD %d: %.3f ms per 1000 anchors for its calls among the 1000 longest; items 3000.. dispatched after %.1f ms on average\n",
+                        r, nl ? lat / nl : 0., nd ? disp / nd : 0.);
+            }
             (void)hipFree(d_dbg);
+            if (d_pub) (void)hipFree(d_pub);
         }
     }
     if (((uint32_t *)h->h_evals)[4] != 0) {
