@@ -208,6 +208,7 @@ int main(int argc, char **argv) {
         fprintf(out, "EOR\n");
     }
     fprintf(stderr, "Time in kernel: %.2f sec\n", runtime);
+    if (gab_env_i64("GAB_ROI_PRECISE", 0)) fprintf(stderr, "[gab] region of interest: %.3f ms\n", runtime * 1e3);   /* (the reference prints two decimals of a second) */
     fclose(in); fclose(out);
     free(hdr); free(call_off); free(x); free(y); free(ctx.score); free(ctx.parent); free(ctx.chunk_beg);
     return 0;

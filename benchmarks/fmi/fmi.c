@@ -39,6 +39,7 @@ static void *gpu_init(int worker, int gpu, void *vc) {
         GAB_DIE_IF(gab_fmi_load(gpu, c->prefix, &w->h), "gab_fmi_load");
         if (gpu < MAX_GPUS) c->owner[gpu] = w->h;
     }
+    GAB_DIE_IF(gab_fmi_reserve(w->h, c->chunk < c->n ? c->chunk : c->n, c->stride), "gab_fmi_reserve");    /* buffers before the ROI */
     w->cap = c->arena_records;
     void *a = NULL;
     if (gab_env_i64("GAB_NO_PIN", 0) || gab_host_alloc((size_t)w->cap * sizeof(gab_smem), &a) != 0) a = malloc((size_t)w->cap * sizeof(gab_smem));

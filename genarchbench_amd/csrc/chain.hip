@@ -2040,6 +2040,19 @@ static ChainWork chain_work_of(const gab_chain_hdr &hd, int64_t off) {
     return w;
 }
 
+// stream, events and LDS attribute of the latency form (chain_fast_kernel); also made by gab_chain_reserve: a stream costs
+// ~8 ms the first time
+static int chain_fast_setup(gab_chain *h) {
+    if (h->fs) return GAB_OK;
+    if (hipStreamCreateWithFlags(&h->fs, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&h->fe[0], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->fe[1], hipEventDisableTiming) != hipSuccess ||
+        hipFuncSetAttribute((const void *)chain_fast_kernel<GAB_CHAIN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFastDynLds) != hipSuccess ||
+        hipFuncSetAttribute((const void *)chain_fast_kernel<GAB_FASTCHAIN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFastDynLds) != hipSuccess) {
+        gab_set_error("gab_chain: stream / event / LDS attribute of the latency-form kernel failed"); return GAB_EDEVICE;
+    }
+    return GAB_OK;
+}
+
 extern "C" int gab_chain_run_device(gab_chain *h, int mode, const uint64_t *d_x, const uint64_t *d_y,
                                     const int64_t *call_off, const gab_chain_hdr *hdr, int64_t ncalls,
                                     int32_t *d_score, int32_t *d_parent, void *stream_) {
@@ -2105,14 +2118,7 @@ extern "C" int gab_chain_run_device(gab_chain *h, int mode, const uint64_t *d_x,
         while (nfast < nw && (int64_t)nfast < max_calls && wk[nfast].n >= min_n) nfast++;
     }
     if (nfast) {
-        if (!h->fs) {
-            if (hipStreamCreateWithFlags(&h->fs, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&h->fe[0], hipEventDisableTiming) != hipSuccess ||
-                hipEventCreateWithFlags(&h->fe[1], hipEventDisableTiming) != hipSuccess ||
-                hipFuncSetAttribute((const void *)chain_fast_kernel<GAB_CHAIN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFastDynLds) != hipSuccess ||
-                hipFuncSetAttribute((const void *)chain_fast_kernel<GAB_FASTCHAIN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFastDynLds) != hipSuccess) {
-                gab_set_error("gab_chain: stream / event / LDS attribute of the latency-form kernel failed"); return GAB_EDEVICE;
-            }
-        }
+        if ((rc = chain_fast_setup(h)) != GAB_OK) return rc;
         const ChainFeed nofeed{nullptr, nullptr, nullptr, nullptr, nullptr};
         if (mode == GAB_CHAIN) hipLaunchKernelGGL(chain_facts_kernel, dim3((unsigned)nw), dim3(256), 0, s, d_work, d_x, d_y);
         GAB_HIP(hipEventRecord(h->fe[0], s));
@@ -2277,16 +2283,11 @@ static int chain_run_overlapped(gab_chain *h, int mode, const uint64_t *x, const
 // The DP kernel is launched only after every workgroup of the gather kernel has reported in (they are resident then and
 // cannot be locked out by waiting workgroups), and a wait gives up after seconds, so the grid drains in every case.
 // Returns GAB_EAGAIN-like 1 when the arrays are not device-accessible (the caller takes the copy-engine path).
-static int chain_run_fed(gab_chain *h, int mode, const uint64_t *x, const uint64_t *y, const int64_t *call_off,
-                         const gab_chain_hdr *hdr, int64_t ncalls, int64_t total, int32_t *score_out, int32_t *parent_out,
-                         hipStream_t sA) {
-    void *hx = nullptr, *hy = nullptr, *hs = nullptr, *hp = nullptr;
-    if (hipHostGetDevicePointer(&hx, (void *)x, 0) != hipSuccess || hipHostGetDevicePointer(&hy, (void *)y, 0) != hipSuccess ||
-        hipHostGetDevicePointer(&hs, (void *)score_out, 0) != hipSuccess || hipHostGetDevicePointer(&hp, (void *)parent_out, 0) != hipSuccess) {
-        (void)hipGetLastError();
-        return 1;
-    }
-    h->have_stats = false;
+// The streams and the page-locked flags of the fed path (chain_run_fed); also called by gab_chain_reserve, because making two
+// streams costs 17 ms the first time (hipStreamCreateWithFlags 8.0 ms, hipExtStreamCreateWithCUMask 8.9 ms in the C driver's
+// region of interest, which makes ONE call).
+static int chain_fed_setup(gab_chain *h, int *gather_blocks) {
+    *gather_blocks = 256;
     if (!h->xs[0] && hipStreamCreateWithFlags(&h->xs[0], hipStreamNonBlocking) != hipSuccess) { gab_set_error("gab_chain_run: stream creation failed"); return GAB_EDEVICE; }
     // The gather kernel keeps megabytes of reads from HOST memory in flight, ~3 us each, and a CU's vector memory pipeline
     // returns data in order: with a gather workgroup on every CU the DP ran at half of its speed until the last anchor had
@@ -2296,7 +2297,6 @@ static int chain_run_fed(gab_chain *h, int mode, const uint64_t *x, const uint64
     // b % 8; 8 workgroups of 256 threads fill that CU and 64 of them keep the bus as busy as 256 did: 26.0 against 24.4 ms for
     // 1.36 GB), and the DP has the other 248 CUs to itself: DP done after 35.7 ms instead of 51 (profiles/r03_chain_fed.md).
     // $GAB_CHAIN_GATHER_MASK: "none" = the old form (256 workgroups anywhere), "N:M" = bits N .. N + M - 1 (experiments).
-    int gather_blocks = 256;
     if (!h->gs && !h->gs_tried) {
         h->gs_tried = true;
         int ncu = 0;
@@ -2312,10 +2312,28 @@ static int chain_run_fed(gab_chain *h, int mode, const uint64_t *x, const uint64
             else h->gs_blocks = std::min(256, 8 * nb);        // 2048 threads per CU
         }
     }
-    if (h->gs) gather_blocks = h->gs_blocks;
-    if (const char *e = getenv("GAB_CHAIN_GATHER_BLOCKS")) { const int v = atoi(e); if (v >= 8 && v <= 256) gather_blocks = v; }
-    hipStream_t sG = h->gs ? h->gs : h->xs[0];
+    if (h->gs) *gather_blocks = h->gs_blocks;
+    if (const char *e = getenv("GAB_CHAIN_GATHER_BLOCKS")) { const int v = atoi(e); if (v >= 8 && v <= 256) *gather_blocks = v; }
     if (!h->h_started && hipHostMalloc((void **)&h->h_started, 256 + 64) != hipSuccess) { gab_set_error("gab_chain_run: pinned allocation failed"); return GAB_EDEVICE; }
+    return GAB_OK;
+}
+
+static int chain_run_fed(gab_chain *h, int mode, const uint64_t *x, const uint64_t *y, const int64_t *call_off,
+                         const gab_chain_hdr *hdr, int64_t ncalls, int64_t total, int32_t *score_out, int32_t *parent_out,
+                         hipStream_t sA) {
+    void *hx = nullptr, *hy = nullptr, *hs = nullptr, *hp = nullptr;
+    if (hipHostGetDevicePointer(&hx, (void *)x, 0) != hipSuccess || hipHostGetDevicePointer(&hy, (void *)y, 0) != hipSuccess ||
+        hipHostGetDevicePointer(&hs, (void *)score_out, 0) != hipSuccess || hipHostGetDevicePointer(&hp, (void *)parent_out, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        return 1;
+    }
+    h->have_stats = false;
+    int gather_blocks = 256;
+    {
+        const int rc0 = chain_fed_setup(h, &gather_blocks);
+        if (rc0) return rc0;
+    }
+    hipStream_t sG = h->gs ? h->gs : h->xs[0];
     // work list, longest call first; on the device every call starts on a 128-byte line (16 anchors), so that no cache line is
     // shared between calls (see chain_feed_wait); and the chunk table
     std::vector<ChainWork> wk;
@@ -2511,6 +2529,21 @@ extern "C" int gab_chain_reserve(gab_chain *h, int64_t max_anchors, int64_t max_
     GAB_HIP(hipMemsetAsync(h->io.p, 0, h->io.cap, s));
     GAB_HIP(hipMemsetAsync(h->gmarks.p, 0, h->gmarks.cap, s));
     GAB_HIP(hipStreamSynchronize(s));
+    {   // the fed path's streams, and its gather kernel once with nothing to do (the first launch of a kernel is 1.6 ms)
+        int blocks = 0;
+        if ((rc = chain_fast_setup(h)) != GAB_OK || (rc = chain_fed_setup(h, &blocks)) != GAB_OK) return rc;
+        hipStream_t sG = h->gs ? h->gs : h->xs[0];
+        memset(h->h_started, 0, 256 + 64);
+        void *d_started = nullptr;
+        GAB_HIP(hipHostGetDevicePointer(&d_started, h->h_started, 0));
+        GAB_HIP(hipMemsetAsync(h->work.p, 0, 256, sG));
+        hipLaunchKernelGGL(chain_gather_kernel, dim3(blocks), dim3(256), 0, sG, (const ChainChunk *)nullptr, 0u, (const uint64_t *)nullptr,
+                           (const uint64_t *)nullptr, (uint64_t *)nullptr, (uint64_t *)nullptr, (const ChainWork *)nullptr, (const uint32_t *)nullptr,
+                           (uint32_t *)nullptr, (unsigned long long *)nullptr, (unsigned long long *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr,
+                           (volatile uint8_t *)d_started, 0, h->work.as<uint32_t>(), (unsigned long long *)nullptr);
+        GAB_HIP(hipGetLastError());
+        GAB_HIP(hipStreamSynchronize(sG));
+    }
     return gab_warm_copy_engines(s, h->io.p, h->io.cap);
 }
 

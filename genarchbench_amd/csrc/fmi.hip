@@ -1221,6 +1221,29 @@ extern "C" int gab_fmi_seed_into(gab_fmi *h, const uint8_t *enc, int32_t stride,
     return GAB_OK;
 }
 
+extern "C" int gab_fmi_reserve(gab_fmi *h, int64_t max_reads, int32_t stride) {
+    GAB_CHECK(h, "gab_fmi_reserve: NULL handle");
+    GAB_CHECK(max_reads >= 0 && max_reads < (1ll << 31) && stride > 0, "gab_fmi_reserve: size out of range");
+    if (max_reads == 0) return GAB_OK;
+    gab_device_guard g(h->device);
+    const size_t eb = (size_t)max_reads * (size_t)stride, o_len = (eb + 255) & ~(size_t)255;
+    int rc = h->io.reserve(std::max<size_t>(o_len + 4 * (size_t)max_reads, (size_t)4 << 20));
+    if (rc) return rc;
+    hipStream_t s = nullptr;
+    if ((rc = h->hs.get(&s)) != GAB_OK) return rc;
+    // max_reads reads of length 0: every buffer of the path gets the size a real batch of that many reads starts with, every
+    // kernel runs once, nothing is found
+    GAB_HIP(hipMemsetAsync(h->io.p, 0, o_len + 4 * (size_t)max_reads, s));
+    const gab_smem *d_out = nullptr;
+    int64_t n = 0;
+    const bool had = h->have_stats;
+    rc = gab_fmi_seed_device(h, h->io.as<uint8_t>(), stride, (const int32_t *)(h->io.as<char>() + o_len), max_reads, 19, &d_out, nullptr, &n, s);
+    h->have_stats = had;
+    if (rc) return rc;
+    // the output of a real batch: ~8 records per read of 151 bases (the device array grows by doubling from 16 per read)
+    return gab_warm_copy_engines(s, h->io.p, h->io.cap);
+}
+
 extern "C" int gab_fmi_last_stats(gab_fmi *h, int64_t *ext_calls, int64_t *nsmem, float *kernel_ms) {
     GAB_CHECK(h, "gab_fmi_last_stats: NULL handle");
     GAB_CHECK(h->have_stats, "gab_fmi_last_stats: no completed run on this handle");

@@ -60,6 +60,10 @@ class FMI_search:
         check(rc)
         return n.value
 
+    def reserve(self, max_reads, stride):
+        """size the device buffers for host-pointer calls of up to max_reads reads now (gab_fmi_reserve): outside a timed region"""
+        check(lib().gab_fmi_reserve(self._h, C.c_int64(max_reads), C.c_int32(stride)))
+
     def seed_device(self, enc, length, min_seed_len=19, stream=0):
         """torch CUDA tensors enc [n, stride] uint8, length int32 -> (device ptr of gab_smem[], device ptr of
         read_off[], count); the pointers stay valid until the next call"""

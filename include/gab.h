@@ -312,6 +312,10 @@ void gab_fmi_free(gab_smem *p);
  * call returns GAB_ERANGE: grow the array to *nout and call again. */
 int gab_fmi_seed_into(gab_fmi *h, const uint8_t *enc, int32_t stride, const int32_t *len, int64_t nreads,
                       int32_t min_seed_len, gab_smem *out, int64_t capacity, int64_t *nout);
+/* optional: size the handle's device buffers now for host-pointer calls of up to max_reads reads of `stride` bases and push
+ * an empty batch of that size through the whole path (see gab_bsw_reserve): a driver that times ONE pass (fmi/fmi.cpp:236-362)
+ * would otherwise allocate gigabytes of slots and output inside its region of interest */
+int gab_fmi_reserve(gab_fmi *h, int64_t max_reads, int32_t stride);
 /* device buffers; *d_out / *d_read_off (nreads + 1 offsets into d_out) point into memory owned by the
  * handle and stay valid until the next call on it.  Synchronises `stream` internally. */
 int gab_fmi_seed_device(gab_fmi *h, const uint8_t *d_enc, int32_t stride, const int32_t *d_len,
