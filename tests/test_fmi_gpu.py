@@ -54,6 +54,37 @@ def test_vs_oracle(tmp_path, rseed, L, n, lo, hi, msl):
     f.close()
 
 
+def test_seed_into_the_callers_array(tmp_path):
+    """gab_fmi_seed_into (the reference's per-thread SMEM arrays, fmi.cpp:243-255,277-286) on a clone of the handle whose buffers
+    gab_fmi_reserve sized beforehand: the records of each chunk of reads land in the caller's array, chunk-local read numbers;
+    an array that is too small is refused with the number of records needed (GAB_ERANGE) and left to the caller"""
+    from genarchbench_amd.fmi import FMI_search, SMEM_DTYPE
+    from genarchbench_amd._lib import GabError
+    ref = gabgen.fmi_ref(21, 300_000, 10)
+    idx, prefix = build(ref, tmp_path)
+    reads = gabgen.fmi_reads(22, ref, 9000, 80, 151)
+    w, woff = pyoracle.fmi(pyoracle.fmi_load(prefix), reads, 19)
+    owner = FMI_search(prefix)
+    f = owner.clone()
+    f.reserve(4000, reads.enc.shape[1])
+    out = np.zeros(len(w) + 16, SMEM_DTYPE)
+    used = 0
+    for lo in range(0, 9000, 4000):                         # 4000 + 4000 + 1000 reads
+        hi = min(9000, lo + 4000)
+        n = f.seed_into(reads.enc[lo:hi], reads.len[lo:hi], out[used:], 19)
+        assert n == woff[hi] - woff[lo]
+        out["rid"][used:used + n] += np.uint32(lo)          # the driver's fix-up (fmi.cpp:340-343)
+        used += n
+    assert used == len(w)
+    for fld in ("rid", "m", "n", "k", "l", "s"):
+        np.testing.assert_array_equal(out[fld][:used], w[fld], err_msg=fld)
+    small = np.zeros(10, SMEM_DTYPE)
+    with pytest.raises(GabError) as e:
+        f.seed_into(reads.enc[:4000], reads.len[:4000], small, 19)
+    assert e.value.code == -34 and not small["s"].any()
+    f.close(); owner.close()
+
+
 def test_repetitive_reads_overflow_slots(tmp_path):
     """a highly repetitive reference makes some reads produce more SMEMs than the first-pass slot holds"""
     from genarchbench_amd.fmi import FMI_search
