@@ -2406,7 +2406,7 @@ static int chain_run_fed(gab_chain *h, int mode, const uint64_t *x, const uint64
         while (!all) {
             all = true;
             for (int k = 0; k < gather_blocks; k++) if (!((volatile uint8_t *)h->h_started)[k]) { all = false; break; }
-            if (!all && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) break;
+            if (!all && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) break;     // (somebody else holds the gather's CUs)
         }
         if (!all) GAB_HIP(hipStreamSynchronize(sG));
     }
