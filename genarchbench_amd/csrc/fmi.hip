@@ -57,6 +57,8 @@ struct FmiCounters {
     int32_t bad, first_bad;
     int32_t next_read;             // work queue of the seeding kernel
     int32_t n_ovf, pad;            // reads whose SMEMs overflowed the first-round slot
+    int32_t wide_items, wide_cands, wide_queue, wide_pad;   // wide backward phases handed over (fmi_wide_kernel), the re-seeding candidates they find, its work queue
+    uint32_t wide_top, wide_pad2;  // entries used of the hand-over list area
     unsigned long long wave_steps; // sum over waves of the steps of their longest-running lane (GAB_FMI_DEBUG)
     unsigned long long positions, spills, list_sum;   // seeding positions, those whose list outgrew LDS, sum of list lengths
 };
@@ -170,6 +172,28 @@ __device__ __forceinline__ void extend(const FmiIdx &ix, int64_t k, int64_t l, i
     so = a == 0 ? ss[0] : a == 1 ? ss[1] : a == 2 ? ss[2] : ss[3];
     lo = a == 0 ? l0 : a == 1 ? l1 : a == 2 ? l2 : l3;
 }
+// ---- wide backward phases: handed over -----------------------------------------------------------------------------
+// The backward phase of a seeding position extends every entry of an interval list, column by column.  Most lists shrink to
+// one or two entries after their first column; the list of a position inside a repeat does not: 2.5 % of the phases of
+// fmi-large keep 16 entries or more for a column or longer, they are 9.4 % of all extensions, and the widest -- 76 entries
+// over 75 columns, 5 700 dependent steps for the one lane that owns the read -- are what a batch waits ~22 ms for while the
+// chip is idle (profiles/r03_fmi_batches.md).  The entries of a column are independent extensions.  So a lane whose column
+// leaves kWideMin survivors or more writes them to a hand-over area with the state of the phase (FmiWideItem) and goes on to
+// its next position; fmi_wide_kernel takes the items afterwards, a group of 16 lanes per item, sixteen entries per step.
+// A pass-1 phase emits re-seeding candidates (fmi.cpp:300-324): the wide kernel queues those (kind 1: x, min_intv) and a
+// second launch of it runs their forward phase (all lanes of the group in step) and their backward phase.
+struct FmiWideItem {            // 32 bytes
+    uint32_t t;                 // read of the batch
+    uint32_t jm;                // kind 0: column to do next + 1 | min_intv << 16 | pass 1 ? 1u << 31 : 0;  kind 1: x | min_intv << 16
+    uint32_t off, n;            // kind 0: the list = entries off .. off + n - 1 of the hand-over area, longest match first
+    uint32_t cur_m;             // kind 0: start of the match the list's entries stand for
+    uint32_t kind;              // 0 continuation, 1 re-seeding candidate, 2 void
+    uint32_t pad[2];
+};
+static_assert(sizeof(FmiWideItem) == 32, "FmiWideItem must be 32 bytes");
+constexpr int kWideMin = 24;
+struct FmiWide { FmiWideItem *items; uint4 *lists; int32_t items_cap; uint32_t lists_cap; int32_t min_entries; };
+
 // ---- the seeding kernel: one lane = one read at a time, as a state machine ------------------------------------
 // A straight transcription (one lane runs the three passes as nested loops) leaves ~13 % of the lanes active
 // (PMC, profiles/r01_fmi_pmc.md): neighbouring reads sit in different loops, so every look-up site executes with a
@@ -194,7 +218,7 @@ __global__ __launch_bounds__(64) void fmi_seed_kernel(FmiIdx ix, const uint8_t *
                                                       const int32_t *__restrict__ len_arr, int64_t first, int32_t nbatch,
                                                       int min_seed_len, PrevRec *prev, int prev_cap, OutRec *out_all, int cap,
                                                       int32_t *counts, FmiCounters *ct, int lds_entries, int64_t enc_bytes, int passes,
-                                                      int narrow_lists, const int32_t *__restrict__ ids) {
+                                                      int narrow_lists, const int32_t *__restrict__ ids, FmiWide wide) {
     // dynamic LDS (LDSQ only): [ (stride + 7) / 8 words of read codes ][ lds_entries list entries ]  x 64 lanes; a list entry
     // is 16 bytes (k, l, s < 2^40, n < 256 packed), or -- narrow_lists, for indexes below 2^32 rows -- three dword planes
     // and a byte plane = 13 bytes, which is two more waves per CU at 12 entries
@@ -518,7 +542,27 @@ __global__ __launch_bounds__(64) void fmi_seed_kernel(FmiIdx ix, const uint8_t *
             if (p >= nprev) {                                // column done
                 nprev = ncur; rev = false;
                 if (ncur == 0) state = ST_BWD_END;
-                else { cur_m = (uint32_t)j; j--; state = ST_BWD_COL; }
+                else {
+                    cur_m = (uint32_t)j; j--; state = ST_BWD_COL;
+                    if (LDSQ && wide.items && ncur >= wide.min_entries) {          // a wide phase: hand the rest of it over
+                        const int it = atomicAdd(&ct->wide_items, 1);
+                        const uint32_t off = atomicAdd(&ct->wide_top, (uint32_t)ncur);
+                        if (it < wide.items_cap) {
+                            FmiWideItem w;
+                            w.t = (uint32_t)t; w.jm = (uint32_t)(j + 1) | (uint32_t)min_intv << 16 | (pass == 1 ? 1u << 31 : 0u);
+                            w.off = off; w.n = (uint32_t)ncur; w.cur_m = cur_m; w.kind = 2; w.pad[0] = w.pad[1] = 0;
+                            if (off + (uint32_t)ncur <= wide.lists_cap && min_intv < 0x7fff) {
+                                for (int v = 0; v < ncur; v++) {
+                                    const PrevRec r = v < C ? lds_get(list_slot(v)) : prevp[(int64_t)v * pstride];
+                                    wide.lists[off + (uint32_t)v] = pack_iv(r.k, r.l, r.s, (uint32_t)r.n);
+                                }
+                                w.kind = 0;
+                                state = ST_POS_DONE;             // (next step) the phase is somebody else's now
+                            }
+                            wide.items[it] = w;
+                        }
+                    }
+                }
             }
         } else if (state == ST_P3_JUMP) {                    // D bases in one go
             sm_k = lo; sm_l = ko; sm_s = so; sm_n = x + D - 1;
@@ -546,6 +590,183 @@ __global__ __launch_bounds__(64) void fmi_seed_kernel(FmiIdx ix, const uint8_t *
         if (s64) atomicAdd(&ct->spills, s64);
         if (l64) atomicAdd(&ct->list_sum, l64);
         atomicAdd(&ct->wave_steps, steps);
+        if (c64) atomicAdd(&ct->ext_calls, c64);
+        if (r64) atomicAdd(&ct->rec_reads, r64);
+        if (t64) atomicAdd(&ct->tab_reads, t64);
+        if (tot) atomicAdd(&ct->total, tot);
+        if (mx) atomicMax(&ct->max_per_read, mx);
+    }
+}
+
+// ---- the wide phases: a group of 16 lanes per item, one entry per lane and step ------------------------------------
+// Same extensions, same order of decisions as the loop over prev[] of the reference (FMI_search.cpp:589-650):
+//     for p: if (first && so < min_intv && long enough) { emit; first = false; }
+//            else if (so >= min_intv && so != curr_s)   { keep; first = false; curr_s = (int)so; }
+// first is cleared by the first entry that emits or is kept, so only the FIRST entry with (so < min_intv && long enough) or
+// (so >= min_intv) can emit, and it does iff it is of the first kind; an entry is kept iff so >= min_intv and so differs
+// from (int64)(int)so of the previous entry with so >= min_intv (kept or not: a skipped one equals the value it was
+// compared with).  Both are ballots and lane shuffles over the sixteen entries of a step, carried from step to step.
+enum WideState : int { W_NEW, W_FWD, W_COL, W_ROUND, W_DONE };
+__device__ __forceinline__ void unpack_iv(const uint4 w, int64_t &k, int64_t &l, int64_t &s, int &n) {
+    k = (int64_t)((uint64_t)(w.w & 0xffu) << 32 | w.x); l = (int64_t)((uint64_t)((w.w >> 8) & 0xffu) << 32 | w.y);
+    s = (int64_t)((uint64_t)((w.w >> 16) & 0xffu) << 32 | w.z); n = (int)(w.w >> 24);
+}
+__global__ __launch_bounds__(64) void fmi_wide_kernel(FmiIdx ix, const uint8_t *__restrict__ enc, int32_t stride, const int32_t *__restrict__ len_arr,
+                                                      int64_t first, const FmiWideItem *__restrict__ items, const int32_t *__restrict__ n_items_dev,
+                                                      int32_t items_cap, const uint4 *__restrict__ lists_in, FmiWideItem *__restrict__ cands,
+                                                      int32_t *n_cands_dev, int32_t cands_cap, OutRec *__restrict__ out_all, int cap, int32_t *counts,
+                                                      FmiCounters *ct, int min_seed_len) {
+    // per group ONE list of LL entries: a step reads sixteen entries and then writes its survivors at ranks that are not above
+    // the first of them, so the column's list is compacted in place
+    extern __shared__ uint4 lst_all[];
+    const int LL = (stride + 15) & ~15;
+    const int lane = threadIdx.x, g = lane >> 4, gl = lane & 15, lead = g * 16;
+    const int split_len = (int)(min_seed_len * 1.5 + .499);
+    const int n_items = *n_items_dev < items_cap ? *n_items_dev : items_cap;
+    uint32_t calls = 0, recs = 0, tabs = 0, dummy = 0;
+    unsigned long long tot = 0;
+    int mx = 0;
+    // group-uniform state (every lane of the group holds the same values)
+    int st = W_NEW, t = 0, len = 0, j = 0, a = 4, a_next = 4, nprev = 0, ncur = 0, p0 = 0;
+    bool pass1 = false, first_phase = true, have_k = false;
+    uint32_t cur_m = 0;
+    int64_t min_intv = 1, last_so = 0;
+    const uint8_t *rbase = enc;
+    // forward phase of a candidate (all lanes of the group compute the same)
+    int x = 0, jf = 0, sm_n = 0;
+    int64_t sm_k = 0, sm_l = 0, sm_s = 0;
+
+    auto emit = [&](uint32_t m, uint32_t n, int64_t k, int64_t l, int64_t sv) {      // ONE lane of the group calls this
+        const int slot = atomicAdd(&counts[t], 1);
+        if (slot < cap) { OutRec o; o.m = m; o.n = n; o.k = k; o.l = l; o.s = sv; out_all[(int64_t)t * cap + slot] = o; }
+        tot++; mx = slot + 1 > mx ? slot + 1 : mx;
+        if (pass1 && cands && (int)(n + 1 - m) >= split_len && sv <= 10) {
+            const int ci = atomicAdd(n_cands_dev, 1);
+            if (ci < cands_cap) {
+                FmiWideItem c; c.t = (uint32_t)t; c.jm = ((n + 1 + m) >> 1) | (uint32_t)(sv + 1) << 16; c.off = c.n = c.cur_m = 0; c.kind = 1; c.pad[0] = c.pad[1] = 0;
+                cands[ci] = c;
+            }
+        }
+    };
+    auto fwd_push = [&]() { if (gl == 0) lst_all[g * LL + (nprev)] = pack_iv(sm_k, sm_l, sm_s, (uint32_t)sm_n); nprev++; };
+
+    while (__any(st != W_DONE)) {
+        __syncthreads();                                     // (one wave) the lists written in the last step are visible
+        if (st == W_NEW) {
+            int it = 0;
+            if (gl == 0) it = atomicAdd(&ct->wide_queue, 1);
+            it = __shfl(it, lead);
+            if (it >= n_items) st = W_DONE;
+            else {
+                const FmiWideItem w = items[it];
+                if (w.kind <= 1) {
+                    t = (int)w.t; len = len_arr[first + t];
+                    rbase = enc + (first + (int64_t)t) * (int64_t)stride;
+                    min_intv = (int64_t)((w.jm >> 16) & 0x7fffu);
+                    a_next = 4;
+                    if (w.kind == 0) {
+                        pass1 = (w.jm >> 31) != 0;
+                        j = (int)(w.jm & 0xffffu) - 1; cur_m = w.cur_m; nprev = (int)w.n;
+                        for (int v = gl; v < nprev; v += 16) lst_all[g * LL + (v)] = lists_in[w.off + (uint32_t)v];
+                        a = j >= 0 ? (int)rbase[j] : 4;
+                        st = W_COL;
+                    } else {                                 // getSMEMsOnePosOneThread :496-530 for the candidate
+                        pass1 = false;
+                        x = (int)(w.jm & 0xffffu);
+                        const int a0 = x < len ? (int)rbase[x] : 4;
+                        if (a0 <= 3) {
+                            sm_n = x; sm_k = ix.count[a0]; sm_l = ix.count[3 - a0]; sm_s = ix.count[a0 + 1] - ix.count[a0];
+                            nprev = 0; jf = x + 1;
+                            st = W_FWD;
+                        }
+                    }
+                }
+            }
+        }
+        if (st == W_COL) {                                   // backward loop :589-650, one column
+            const int ac = a > 3 ? 4 : a;
+            if (j >= 0 && ac <= 3) {
+                a = ac; ncur = 0; p0 = 0; first_phase = true; have_k = false;
+                a_next = j > 0 ? (int)rbase[j - 1] : 4;      // (used a column later)
+                st = W_ROUND;
+            } else {                                         // the read's start or an N: the longest entry is an SMEM
+                if (nprev != 0 && gl == 0) {
+                    int64_t k0, l0, s0; int n0;
+                    unpack_iv(lst_all[g * LL + (0)], k0, l0, s0, n0);
+                    if ((int)((int64_t)n0 - (int64_t)cur_m + 1) >= min_seed_len) emit(cur_m, (uint32_t)n0, k0, l0, s0);
+                }
+                st = W_NEW;
+            }
+        }
+        // ---- the extension: sixteen entries of the column, or the next base of a candidate's forward phase
+        bool need = false, fwd_end = false;
+        int64_t K = 0, L = 0, S = 0; int A = 0, n0 = 0;
+        if (st == W_ROUND) {
+            const int p = p0 + gl;
+            if (p < nprev) { unpack_iv(lst_all[g * LL + (p)], K, L, S, n0); A = a; need = true; }
+        } else if (st == W_FWD) {                            // forward loop :531-575
+            if (jf >= len) fwd_end = true;
+            else {
+                const int af = (int)rbase[jf];
+                if (af > 3) fwd_end = true; else { K = sm_l; L = sm_k; S = sm_s; A = 3 - af; need = true; }
+            }
+        }
+        int64_t ko = 0, lo = 0, so = 0;
+        if (need) {
+            if (st == W_ROUND || gl == 0) extend(ix, K, L, S, A, false, 0u, false, ko, lo, so, calls, recs, tabs);
+            else extend(ix, K, L, S, A, false, 0u, false, ko, lo, so, dummy, dummy, dummy);
+        }
+        // ---- consume
+        if (st == W_FWD) {
+            if (need) {
+                if (so != sm_s) fwd_push();
+                if (so < min_intv) fwd_end = true;
+                else { sm_k = lo; sm_l = ko; sm_s = so; sm_n = jf; jf++; }
+            }
+            if (fwd_end) {
+                if (sm_s >= min_intv) fwd_push();
+                if (nprev == 0) st = W_NEW;
+                else {
+                    // longest match first, as the backward columns want the list (prev[] is turned round in the reference too,
+                    // :577-587); lane 0 wrote the entries and the loop top's barrier has not come yet: it does the swaps as well
+                    if (gl == 0) for (int v = 0; v < nprev / 2; v++) { const uint4 tmp = lst_all[g * LL + v]; lst_all[g * LL + v] = lst_all[g * LL + nprev - 1 - v]; lst_all[g * LL + nprev - 1 - v] = tmp; }
+                    j = x - 1; cur_m = (uint32_t)x; a = j >= 0 ? (int)rbase[j] : 4; st = W_COL;
+                }
+            }
+        } else if (st == W_ROUND) {
+            const bool lenok = need && (int)((int64_t)n0 - (int64_t)cur_m + 1) >= min_seed_len;
+            const bool isE = need && so < min_intv && lenok, isK = need && so >= min_intv;
+            const uint32_t mE = (uint32_t)(__ballot(isE) >> lead) & 0xffffu, mK = (uint32_t)(__ballot(isK) >> lead) & 0xffffu;
+            if (first_phase && (mE | mK)) {
+                const int f = __builtin_ctz(mE | mK);
+                if ((mE >> f) & 1u) { if (gl == f) emit(cur_m, (uint32_t)n0, K, L, S); }
+                first_phase = false;
+            }
+            // the value an entry with so >= min_intv is compared with: (int64)(int)so of the one before it
+            const uint32_t below = mK & ((1u << gl) - 1u);
+            const int src = below ? 31 - __builtin_clz(below) : 0;
+            const int64_t so_prev = __shfl(so, lead + src);
+            const bool has_prev = below != 0 || have_k;
+            const int64_t cmp = below ? so_prev : last_so;
+            const bool keep = isK && (!has_prev || so != (int64_t)(int)cmp);
+            const uint32_t mKeep = (uint32_t)(__ballot(keep) >> lead) & 0xffffu;
+            if (keep) lst_all[g * LL + (ncur + __builtin_popcount(mKeep & ((1u << gl) - 1u)))] = pack_iv(ko, lo, so, (uint32_t)n0);
+            ncur += __builtin_popcount(mKeep);
+            if (mK) { const int hi = 31 - __builtin_clz(mK); last_so = __shfl(so, lead + hi); have_k = true; }
+            p0 += 16;
+            if (p0 >= nprev) {                               // column done
+                nprev = ncur;
+                if (ncur == 0) st = W_NEW;
+                else { cur_m = (uint32_t)j; j--; a = a_next; st = W_COL; }
+            }
+        }
+    }
+    unsigned long long c64 = calls, r64 = recs, t64 = tabs;
+    for (int o = 32; o > 0; o >>= 1) {
+        c64 += __shfl_xor(c64, o); r64 += __shfl_xor(r64, o); t64 += __shfl_xor(t64, o); tot += __shfl_xor(tot, o);
+        const int v = __shfl_xor(mx, o); mx = v > mx ? v : mx;
+    }
+    if (lane == 0) {
         if (c64) atomicAdd(&ct->ext_calls, c64);
         if (r64) atomicAdd(&ct->rec_reads, r64);
         if (t64) atomicAdd(&ct->tab_reads, t64);
@@ -784,6 +1005,8 @@ struct gab_fmi {
     gab_devbuf prev;        // prev[] scratch
     gab_devbuf slots;       // per-read output slots
     gab_devbuf slots2, ovf; // second round: slots of the exact size for the reads that overflowed theirs, and their numbers
+    gab_devbuf witems, wlists, wcands;   // wide backward phases handed over to fmi_wide_kernel: items, their lists, the candidates they find
+    int handover_env = 1;   // $GAB_FMI_WIDE=0: no hand-over (every phase stays with the lane that owns the read); > 1: the survivor count that makes a phase wide
     gab_devbuf out;         // compacted SMEMs
     gab_devbuf roff;        // read_off (nreads + 1)
     gab_devbuf io;          // staging for the host entry point
@@ -813,6 +1036,7 @@ static int fmi_new_handle(int device, gab_fmi **out) {
     { const char *e = getenv("GAB_FMI_LDS_ENTRIES"); h->lds_entries_env = e ? atoi(e) : 0; }
     { const char *e = getenv("GAB_FMI_WIDE_LISTS"); h->wide_env = e && atoi(e) != 0; }
     { const char *e = getenv("GAB_FMI_WAVES"); h->waves_env = e ? atoi(e) : 0; }
+    { const char *e = getenv("GAB_FMI_WIDE"); h->handover_env = e ? atoi(e) : 1; }
     { const char *e = getenv("GAB_FMI_BATCH"); if (e && atoll(e) >= 1024) h->batch_max = atoll(e); }
     { const char *e = getenv("GAB_FMI_SCRATCH_MB"); if (e && atoll(e) > 0) { h->scratch_budget = (size_t)atoll(e) << 20; h->scratch_from_env = true; } }
     if (hipEventCreate(&h->ev[0]) != hipSuccess || hipEventCreate(&h->ev[1]) != hipSuccess ||
@@ -910,7 +1134,7 @@ extern "C" int gab_fmi_clone(gab_fmi *src, gab_fmi **out) {
     gab_fmi *h = nullptr;
     int rc = fmi_new_handle(src->device, &h);
     if (rc) return rc;
-    h->ix = src->ix; h->sa_ix = src->sa_ix; h->scratch_budget = src->scratch_budget; h->scratch_from_env = src->scratch_from_env; h->batch_max = src->batch_max; h->waves_env = src->waves_env;
+    h->ix = src->ix; h->sa_ix = src->sa_ix; h->scratch_budget = src->scratch_budget; h->scratch_from_env = src->scratch_from_env; h->batch_max = src->batch_max; h->waves_env = src->waves_env; h->handover_env = src->handover_env;
     *out = h;
     return GAB_OK;
 }
@@ -918,7 +1142,7 @@ extern "C" int gab_fmi_clone(gab_fmi *src, gab_fmi **out) {
 extern "C" void gab_fmi_destroy(gab_fmi *h) {
     if (!h) return;
     gab_device_guard g(h->device);
-    h->index.release(); h->kmer.release(); h->sa.release(); h->sa_ws.release(); h->sa_off.release(); h->sa_coords.release(); h->sa_io.release(); h->ws.release(); h->prev.release(); h->slots.release(); h->slots2.release(); h->ovf.release(); h->out.release(); h->roff.release();
+    h->index.release(); h->kmer.release(); h->sa.release(); h->sa_ws.release(); h->sa_off.release(); h->sa_coords.release(); h->sa_io.release(); h->ws.release(); h->prev.release(); h->slots.release(); h->slots2.release(); h->ovf.release(); h->witems.release(); h->wlists.release(); h->wcands.release(); h->out.release(); h->roff.release();
     h->io.release(); h->hs.release();
     for (int k = 0; k < 2; k++) if (h->ev[k]) (void)hipEventDestroy(h->ev[k]);
     if (h->h_ct) (void)hipHostFree(h->h_ct);
@@ -971,7 +1195,8 @@ extern "C" int gab_fmi_seed_device(gab_fmi *h, const uint8_t *d_enc, int32_t str
     const size_t list_bytes = narrow_lists ? (((size_t)lds_entries * 64 * 13 + 15) & ~(size_t)15) : (size_t)lds_entries * 64 * 16;
     const size_t lds_bytes = ldsq ? (((size_t)(stride + 7) / 8 * 64 + 3) / 4) * 16 + list_bytes : 0;
     const size_t lds_bytes_p3 = ldsq ? (((size_t)(stride + 7) / 8 * 64 + 3) / 4 + 64) * 16 : 0;   // read + slack for nibbles_at
-    int waves_per_cu = 0, waves_per_cu_p3 = 0, n_cu = 0;
+    int waves_per_cu = 0, waves_per_cu_p3 = 0, n_cu = 0, wide_occ = 1;
+    const size_t wide_lds = (size_t)4 * (size_t)((stride + 15) & ~15) * sizeof(uint4);          // fmi_wide_kernel: four groups, a list each
     {
         hipDeviceProp_t prop;
         GAB_HIP(hipGetDeviceProperties(&prop, h->device));
@@ -980,6 +1205,8 @@ extern "C" int gab_fmi_seed_device(gab_fmi *h, const uint8_t *d_enc, int32_t str
             GAB_HIP(hipFuncSetAttribute((const void *)fmi_seed_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             GAB_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&waves_per_cu, fmi_seed_kernel<true>, 64, lds_bytes));
             GAB_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&waves_per_cu_p3, fmi_seed_kernel<true>, 64, lds_bytes_p3));
+            GAB_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&wide_occ, fmi_wide_kernel, 64, wide_lds));
+            if (wide_occ < 1) wide_occ = 1;
         } else GAB_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&waves_per_cu, fmi_seed_kernel<false>, 64, 0));
         GAB_CHECK(waves_per_cu > 0, "gab_fmi_seed_device: the seeding kernel does not fit a CU (stride %d)", stride);
         // the per-lane spill area is stride x 32 B x 64 lanes per resident wave: long reads (no LDS lists: every list entry
@@ -1033,18 +1260,40 @@ extern "C" int gab_fmi_seed_device(gab_fmi *h, const uint8_t *d_enc, int32_t str
         if (ldsq) {
             // passes 1 + 2 need the interval lists in LDS, which caps the occupancy; pass 3 needs only the read, so it
             // runs as a second launch of the same kernel with no list area and twice the waves
+            // wide backward phases leave the kernel as items (see FmiWideItem): the areas for a batch of `count` reads
+            FmiWide wide{nullptr, nullptr, 0, 0, 0};
+            const int32_t wcap = (int32_t)std::min<int64_t>((int64_t)count * 3 / 10 + 4096, 1 << 28);
+            if (!ids && h->handover_env) {
+                const uint32_t lcap = (uint32_t)std::min<int64_t>((int64_t)count * 12 + 65536, 0x7fffffffll);
+                int rcw = h->witems.reserve(sizeof(FmiWideItem) * (size_t)wcap);
+                if (!rcw) rcw = h->wcands.reserve(sizeof(FmiWideItem) * (size_t)wcap);
+                if (!rcw) rcw = h->wlists.reserve(sizeof(uint4) * (size_t)lcap);
+                if (rcw) return rcw;
+                wide = FmiWide{h->witems.as<FmiWideItem>(), h->wlists.as<uint4>(), wcap, lcap, h->handover_env > 1 ? h->handover_env : kWideMin};
+            }
             hipLaunchKernelGGL(fmi_seed_kernel<true>, dim3(seed_blocks), dim3(64), lds_bytes, s, h->ix, d_enc, stride, d_len, first,
                                count, min_seed_len, h->prev.as<PrevRec>(), (int)stride, slots, slot_cap, d_counts, d_ct,
-                               lds_entries, (int64_t)nreads * stride, 1, narrow_lists, ids);
+                               lds_entries, (int64_t)nreads * stride, 1, narrow_lists, ids, wide);
+            if (wide.items) {
+                // ... and are walked by groups of 16 lanes: the items, then the re-seeding candidates their pass-1 phases found
+                const int wblocks = n_cu * wide_occ;
+                hipLaunchKernelGGL(fmi_wide_kernel, dim3(wblocks), dim3(64), wide_lds, s, h->ix, d_enc, stride, d_len, first, (const FmiWideItem *)wide.items,
+                                   (const int32_t *)&d_ct->wide_items, wcap, (const uint4 *)wide.lists, h->wcands.as<FmiWideItem>(), &d_ct->wide_cands, wcap,
+                                   slots, slot_cap, d_counts, d_ct, min_seed_len);
+                GAB_HIP(hipMemsetAsync(&d_ct->wide_queue, 0, sizeof(int32_t), s));
+                hipLaunchKernelGGL(fmi_wide_kernel, dim3(wblocks), dim3(64), wide_lds, s, h->ix, d_enc, stride, d_len, first, (const FmiWideItem *)h->wcands.as<FmiWideItem>(),
+                                   (const int32_t *)&d_ct->wide_cands, wcap, (const uint4 *)wide.lists, (FmiWideItem *)nullptr, (int32_t *)nullptr, 0,
+                                   slots, slot_cap, d_counts, d_ct, min_seed_len);
+            }
             GAB_HIP(hipMemsetAsync(&d_ct->next_read, 0, sizeof(int32_t), s));
             const int p3_blocks = (int)std::min<int64_t>((int64_t)n_cu * waves_per_cu_p3, gab_ceil_div((int64_t)count, 64));
             hipLaunchKernelGGL(fmi_seed_kernel<true>, dim3(p3_blocks), dim3(64), lds_bytes_p3, s, h->ix, d_enc, stride, d_len, first,
                                count, min_seed_len, h->prev.as<PrevRec>(), (int)stride, slots, slot_cap, d_counts, d_ct,
-                               0, (int64_t)nreads * stride, 2, narrow_lists, ids);
+                               0, (int64_t)nreads * stride, 2, narrow_lists, ids, FmiWide{nullptr, nullptr, 0, 0, 0});
         } else
             hipLaunchKernelGGL(fmi_seed_kernel<false>, dim3(seed_blocks), dim3(64), 0, s, h->ix, d_enc, stride, d_len, first, count,
                                min_seed_len, h->prev.as<PrevRec>(), (int)stride, slots, slot_cap, d_counts, d_ct, 0,
-                               (int64_t)nreads * stride, 3, 0, ids);
+                               (int64_t)nreads * stride, 3, 0, ids, FmiWide{nullptr, nullptr, 0, 0, 0});
         hipLaunchKernelGGL(fmi_sort_slots, dim3((unsigned)gab_ceil_div((int64_t)count, 256)), dim3(256), 0, s, slots, slot_cap, d_counts, count, ids);
         GAB_HIP(hipGetLastError());
         (void)nb;
@@ -1056,7 +1305,7 @@ extern "C" int gab_fmi_seed_device(gab_fmi *h, const uint8_t *d_enc, int32_t str
         int seed_blocks_dbg = 0;
         rc = h->slots.reserve(sizeof(OutRec) * (size_t)cap * (size_t)nb);
         if (rc) return rc;
-        h->h_ct->ext_calls = 0; h->h_ct->rec_reads = 0; h->h_ct->tab_reads = 0; h->h_ct->total = 0; h->h_ct->max_per_read = 0; h->h_ct->next_read = 0; h->h_ct->n_ovf = 0; h->h_ct->wave_steps = 0; h->h_ct->positions = h->h_ct->spills = h->h_ct->list_sum = 0;
+        h->h_ct->ext_calls = 0; h->h_ct->rec_reads = 0; h->h_ct->tab_reads = 0; h->h_ct->total = 0; h->h_ct->max_per_read = 0; h->h_ct->next_read = 0; h->h_ct->n_ovf = 0; h->h_ct->wide_items = h->h_ct->wide_cands = h->h_ct->wide_queue = 0; h->h_ct->wide_top = 0; h->h_ct->wave_steps = 0; h->h_ct->positions = h->h_ct->spills = h->h_ct->list_sum = 0;
         GAB_HIP(hipMemcpyAsync(d_ct, h->h_ct, sizeof(FmiCounters), hipMemcpyHostToDevice, s));
         GAB_HIP(hipEventRecord(h->ev[0], s));
         rc = seed(first, nb, nb, nullptr, h->slots.as<OutRec>(), cap, &seed_blocks_dbg);
@@ -1074,6 +1323,9 @@ extern "C" int gab_fmi_seed_device(gab_fmi *h, const uint8_t *d_enc, int32_t str
                     nb, seed_blocks_dbg, waves_per_cu, ms, h->h_ct->ext_calls, h->h_ct->tab_reads, h->h_ct->wave_steps,
                     (double)(h->h_ct->ext_calls + h->h_ct->tab_reads) / (double)(h->h_ct->wave_steps ? h->h_ct->wave_steps : 1), h->h_ct->positions,
                     h->h_ct->spills, (double)h->h_ct->list_sum / (double)(h->h_ct->positions ? h->h_ct->positions : 1));
+        if (getenv("GAB_FMI_DEBUG") && h->h_ct->wide_items)
+            fprintf(stderr, "[gab_fmi]   %d wide backward phases handed over (%u list entries), %d re-seeding candidates from them\n",
+                    h->h_ct->wide_items, h->h_ct->wide_top, h->h_ct->wide_cands);
         const int64_t add = (int64_t)h->h_ct->total;
         if ((size_t)(total + add) > out_cap) {
             // grow, keeping what earlier batches wrote
