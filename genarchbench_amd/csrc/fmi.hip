@@ -546,8 +546,8 @@ __global__ __launch_bounds__(64) void fmi_seed_kernel(FmiIdx ix, const uint8_t *
                     cur_m = (uint32_t)j; j--; state = ST_BWD_COL;
                     if (LDSQ && wide.items && ncur >= wide.min_entries) {          // a wide phase: hand the rest of it over
                         const int it = atomicAdd(&ct->wide_items, 1);
-                        const uint32_t off = atomicAdd(&ct->wide_top, (uint32_t)ncur);
-                        if (it < wide.items_cap) {
+                        if (it < wide.items_cap) {           // (so the list cursor stays below items_cap x 256 entries: no wrap)
+                            const uint32_t off = atomicAdd(&ct->wide_top, (uint32_t)ncur);
                             FmiWideItem w;
                             w.t = (uint32_t)t; w.jm = (uint32_t)(j + 1) | (uint32_t)min_intv << 16 | (pass == 1 ? 1u << 31 : 0u);
                             w.off = off; w.n = (uint32_t)ncur; w.cur_m = cur_m; w.kind = 2; w.pad[0] = w.pad[1] = 0;
