@@ -960,14 +960,13 @@ class FmiWorkload:
 
     def host_roi(self, chunk=None):
         """the C driver's ROI (fmi/fmi.cpp:189-362 in the reference): read codes in, sorted SMEM records out, into page-locked
-        arrays of the caller (gab_fmi_seed_into), one clone of the index handle per worker; like benchmarks/fmi/fmi.c a chunk is a
-        worker's share of the reads, 2^20 .. 2^22 (every chunk is one batch of the seeding kernel and ends with that batch's
-        slowest reads on a mostly idle chip: few big chunks)"""
+        arrays of the caller (gab_fmi_seed_into), one clone of the index handle per worker; like benchmarks/fmi/fmi.c a chunk is
+        half a worker's share of the reads, 2^20 .. 2^22"""
         import ctypes as C
         from genarchbench_amd.fmi import SMEM_DTYPE
         n = self.items
         if chunk is None:
-            chunk = min(max(-(-n // max(1, HOST_WORKERS)), 1 << 20), 1 << 22)
+            chunk = min(max(-(-n // max(1, 2 * HOST_WORKERS)), 1 << 20), 1 << 22)
         d_out, d_off, total = self.result
         hip = C.CDLL("libamdhip64.so")
         off = np.zeros(n + 1, np.int64)

@@ -7,7 +7,7 @@
  * fmi/scripts/regression_small.sh:91,97-98).  <ref_prefix>.bwt.2bit.64 is BWA-MEM2's own index file; it is
  * loaded and replicated on every GPU before the ROI, as load_index precedes begin_computing in the reference.
  * The per-batch ROI body (getSMEMsAllPos -> re-seed -> bwtSeedStrategy -> sortSMEMs, fmi.cpp:288-348) becomes
- * gab_fmi_seed_into on chunks of reads ($GAB_CHUNK; default: a worker's share, 2^20 .. 2^22 reads) pulled by $GAB_WORKERS_PER_GPU host threads per GPU
+ * gab_fmi_seed_into on chunks of reads ($GAB_CHUNK; default: half a worker's share, 2^20 .. 2^22 reads) pulled by $GAB_WORKERS_PER_GPU host threads per GPU
  * (default 3; the workers of a GPU share one copy of the index); batch_size and n_threads only shaped the CPU
  * scheduling and are accepted and ignored.
  * Every worker collects its SMEMs in an array of its own sized like the reference's per-thread matchArray (20 records per
@@ -119,11 +119,11 @@ int main(int argc, char **argv) {
     const int ngpus = gab_pick_gpus(0);
     fmi_ctx ctx;
     memset(&ctx, 0, sizeof ctx);
-    {   /* A chunk is one batch of the seeding kernel, and a batch ends with ~20 ms in which its slowest reads run on a mostly idle
-         * chip: a worker's share in ONE chunk of up to 4 M reads rather than many of 2^20 (10 M reads, three
-         * workers: 324 -> 303 ms); $GAB_CHUNK pins the size. */
+    {   /* A chunk is one batch of the seeding kernels: two chunks per worker, 2^20 .. 2^22 reads each -- the copy-out of one runs
+         * under the kernels of the next, and a batch is the more efficient the bigger it is (10 M reads, three workers: ten chunks
+         * of 2^20 259 ms, six of 1.67 M 249 ms, three of 3.33 M 266 ms; profiles/r03_fmi_batches.md); $GAB_CHUNK pins the size. */
         const int64_t w = (int64_t)ngpus * gab_workers_per_gpu();
-        int64_t share = (n + w - 1) / (w > 0 ? w : 1);
+        int64_t share = (n + 2 * w - 1) / (2 * (w > 0 ? w : 1));
         if (share < CHUNK_READS) share = CHUNK_READS;
         if (share > 4 * CHUNK_READS) share = 4 * CHUNK_READS;
         ctx.chunk = gab_env_i64("GAB_CHUNK", share);
