@@ -1006,6 +1006,7 @@ struct gab_fmi {
     gab_devbuf slots;       // per-read output slots
     gab_devbuf slots2, ovf; // second round: slots of the exact size for the reads that overflowed theirs, and their numbers
     gab_devbuf witems, wlists, wcands;   // wide backward phases handed over to fmi_wide_kernel: items, their lists, the candidates they find
+    int wide_cap_env = 0;   // $GAB_FMI_WIDE_CAP: places of the hand-over item / candidate queues (tests: the queues run full)
     int handover_env = 1;   // $GAB_FMI_WIDE=0: no hand-over (every phase stays with the lane that owns the read); > 1: the survivor count that makes a phase wide
     gab_devbuf out;         // compacted SMEMs
     gab_devbuf roff;        // read_off (nreads + 1)
@@ -1037,6 +1038,7 @@ static int fmi_new_handle(int device, gab_fmi **out) {
     { const char *e = getenv("GAB_FMI_WIDE_LISTS"); h->wide_env = e && atoi(e) != 0; }
     { const char *e = getenv("GAB_FMI_WAVES"); h->waves_env = e ? atoi(e) : 0; }
     { const char *e = getenv("GAB_FMI_WIDE"); h->handover_env = e ? atoi(e) : 1; }
+    { const char *e = getenv("GAB_FMI_WIDE_CAP"); h->wide_cap_env = e ? atoi(e) : 0; }
     { const char *e = getenv("GAB_FMI_BATCH"); if (e && atoll(e) >= 1024) h->batch_max = atoll(e); }
     { const char *e = getenv("GAB_FMI_SCRATCH_MB"); if (e && atoll(e) > 0) { h->scratch_budget = (size_t)atoll(e) << 20; h->scratch_from_env = true; } }
     if (hipEventCreate(&h->ev[0]) != hipSuccess || hipEventCreate(&h->ev[1]) != hipSuccess ||
@@ -1134,7 +1136,7 @@ extern "C" int gab_fmi_clone(gab_fmi *src, gab_fmi **out) {
     gab_fmi *h = nullptr;
     int rc = fmi_new_handle(src->device, &h);
     if (rc) return rc;
-    h->ix = src->ix; h->sa_ix = src->sa_ix; h->scratch_budget = src->scratch_budget; h->scratch_from_env = src->scratch_from_env; h->batch_max = src->batch_max; h->waves_env = src->waves_env; h->handover_env = src->handover_env;
+    h->ix = src->ix; h->sa_ix = src->sa_ix; h->scratch_budget = src->scratch_budget; h->scratch_from_env = src->scratch_from_env; h->batch_max = src->batch_max; h->waves_env = src->waves_env; h->handover_env = src->handover_env; h->wide_cap_env = src->wide_cap_env;
     *out = h;
     return GAB_OK;
 }
@@ -1253,6 +1255,8 @@ extern "C" int gab_fmi_seed_device(gab_fmi *h, const uint8_t *d_enc, int32_t str
     float kms = 0;
     // one launch of the seeding kernel(s) over `count` reads of the batch at `first`: all of them (ids == nullptr, slot t for
     // read t) or the listed ones (slot i for read ids[i])
+    bool handover = h->handover_env != 0;                   // wide backward phases go to fmi_wide_kernel (off for the rest of a call whose candidates outgrew their queue)
+    auto wide_cap = [&](int64_t count) { return h->wide_cap_env > 0 ? (int32_t)h->wide_cap_env : (int32_t)std::min<int64_t>(count * 3 / 10 + 4096, 1 << 28); };
     auto seed = [&](int64_t first, int32_t nb, int32_t count, const int32_t *ids, OutRec *slots, int slot_cap, int *waves_dbg) -> int {
         const int seed_blocks = (int)std::min<int64_t>((int64_t)n_cu * waves_per_cu, gab_ceil_div((int64_t)count, 64));
         if (waves_dbg) *waves_dbg = seed_blocks;
@@ -1262,8 +1266,8 @@ extern "C" int gab_fmi_seed_device(gab_fmi *h, const uint8_t *d_enc, int32_t str
             // runs as a second launch of the same kernel with no list area and twice the waves
             // wide backward phases leave the kernel as items (see FmiWideItem): the areas for a batch of `count` reads
             FmiWide wide{nullptr, nullptr, 0, 0, 0};
-            const int32_t wcap = (int32_t)std::min<int64_t>((int64_t)count * 3 / 10 + 4096, 1 << 28);
-            if (!ids && h->handover_env) {
+            const int32_t wcap = wide_cap(count);
+            if (!ids && handover) {
                 const uint32_t lcap = (uint32_t)std::min<int64_t>((int64_t)count * 12 + 65536, 0x7fffffffll);
                 int rcw = h->witems.reserve(sizeof(FmiWideItem) * (size_t)wcap);
                 if (!rcw) rcw = h->wcands.reserve(sizeof(FmiWideItem) * (size_t)wcap);
@@ -1305,14 +1309,22 @@ extern "C" int gab_fmi_seed_device(gab_fmi *h, const uint8_t *d_enc, int32_t str
         int seed_blocks_dbg = 0;
         rc = h->slots.reserve(sizeof(OutRec) * (size_t)cap * (size_t)nb);
         if (rc) return rc;
-        h->h_ct->ext_calls = 0; h->h_ct->rec_reads = 0; h->h_ct->tab_reads = 0; h->h_ct->total = 0; h->h_ct->max_per_read = 0; h->h_ct->next_read = 0; h->h_ct->n_ovf = 0; h->h_ct->wide_items = h->h_ct->wide_cands = h->h_ct->wide_queue = 0; h->h_ct->wide_top = 0; h->h_ct->wave_steps = 0; h->h_ct->positions = h->h_ct->spills = h->h_ct->list_sum = 0;
-        GAB_HIP(hipMemcpyAsync(d_ct, h->h_ct, sizeof(FmiCounters), hipMemcpyHostToDevice, s));
-        GAB_HIP(hipEventRecord(h->ev[0], s));
-        rc = seed(first, nb, nb, nullptr, h->slots.as<OutRec>(), cap, &seed_blocks_dbg);
-        if (rc) return rc;
-        GAB_HIP(hipEventRecord(h->ev[1], s));
-        GAB_HIP(hipMemcpyAsync(h->h_ct, d_ct, sizeof(FmiCounters), hipMemcpyDeviceToHost, s));
-        GAB_HIP(hipStreamSynchronize(s));
+        for (;;) {                                            // twice only when the handed-over phases found more candidates than their queue holds
+            h->h_ct->ext_calls = 0; h->h_ct->rec_reads = 0; h->h_ct->tab_reads = 0; h->h_ct->total = 0; h->h_ct->max_per_read = 0; h->h_ct->next_read = 0; h->h_ct->n_ovf = 0; h->h_ct->wide_items = h->h_ct->wide_cands = h->h_ct->wide_queue = 0; h->h_ct->wide_top = 0; h->h_ct->wave_steps = 0; h->h_ct->positions = h->h_ct->spills = h->h_ct->list_sum = 0;
+            GAB_HIP(hipMemcpyAsync(d_ct, h->h_ct, sizeof(FmiCounters), hipMemcpyHostToDevice, s));
+            GAB_HIP(hipEventRecord(h->ev[0], s));
+            rc = seed(first, nb, nb, nullptr, h->slots.as<OutRec>(), cap, &seed_blocks_dbg);
+            if (rc) return rc;
+            GAB_HIP(hipEventRecord(h->ev[1], s));
+            GAB_HIP(hipMemcpyAsync(h->h_ct, d_ct, sizeof(FmiCounters), hipMemcpyDeviceToHost, s));
+            GAB_HIP(hipStreamSynchronize(s));
+            if (!handover || h->h_ct->wide_cands <= wide_cap(nb)) break;
+            // a candidate without a place is a re-seeding that did not happen: the batch again, every phase with its own lane
+            float lost = 0;
+            GAB_HIP(hipEventElapsedTime(&lost, h->ev[0], h->ev[1]));
+            kms += lost;
+            handover = false;
+        }
         const int over_cap = h->h_ct->max_per_read > cap ? h->h_ct->max_per_read : 0;   // the counters of THIS round are the batch's
         float ms = 0;
         GAB_HIP(hipEventElapsedTime(&ms, h->ev[0], h->ev[1]));

@@ -137,6 +137,36 @@ def test_repetitive_short_reads_spill_lists(tmp_path, monkeypatch, lds_entries):
     assert ext == calls
 
 
+@pytest.mark.parametrize("wide, cap", [("0", None), ("4", None), ("4", "8"), ("2", "3")])
+def test_wide_phases_handed_over(tmp_path, wide, cap):
+    """backward phases whose lists stay wide leave the seeding kernel for fmi_wide_kernel (16 lanes per phase): on a repetitive
+    reference with the threshold lowered to 4 / 2 survivors nearly every phase goes that way, pass-1 phases with their re-seeding
+    candidates included; with room for 8 / 3 items and candidates the queues run full -- items stay with their lanes, a
+    candidate without a place makes the library run the batch again without the hand-over; GAB_FMI_WIDE=0 is the kernel alone.
+    Same SMEMs and the same number of extensions in every variant."""
+    import subprocess, sys, os
+    rng = np.random.default_rng(31)
+    unit = rng.integers(0, 4, 41).astype(np.uint8)
+    ref = np.concatenate([np.tile(unit, 120), rng.integers(0, 4, 40000).astype(np.uint8), np.tile(unit, 60), rng.integers(0, 4, 20000).astype(np.uint8)])
+    idx, prefix = build(ref, tmp_path)
+    reads = gabgen.fmi_reads(32, ref, 5000, 100, 151)
+    w, woff, calls = pyoracle.fmi(pyoracle.fmi_load(prefix), reads, 19, want_calls=True)
+    code = ("import sys, numpy as np; sys.path.insert(0, %r); from tools import gabgen; from genarchbench_amd.fmi import FMI_search;"
+            "reads = gabgen.ReadBatch(np.load(%r), np.load(%r)); f = FMI_search(%r); sm, off = f.seed(reads, 19);"
+            "np.save(%r, sm); np.save(%r, off); print(f.last_stats()['ext_calls'])")
+    e, l = str(tmp_path / "enc.npy"), str(tmp_path / "len.npy")
+    np.save(e, reads.enc); np.save(l, reads.len)
+    so, oo = str(tmp_path / "sm.npy"), str(tmp_path / "off.npy")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GAB_FMI_WIDE=wide)
+    if cap:
+        env["GAB_FMI_WIDE_CAP"] = cap
+    r = subprocess.run([sys.executable, "-c", code % (root, e, l, prefix, so, oo)], capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    same((np.load(so), np.load(oo)), (w, woff))
+    assert int(r.stdout.split()[-1]) == calls
+
+
 def test_all_n_and_short_reads(tmp_path):
     from genarchbench_amd.fmi import FMI_search
     ref = gabgen.fmi_ref(5, 20000, 5)
