@@ -18,6 +18,9 @@
 // registers, and extensions that produce a pattern of at most eight bases are answered by an L2-resident
 // table of bi-intervals instead of the index.  What bounds the kernel is the rate of random index
 // look-ups (~55 G line fills/s on MI355X whatever the record size, profiles/r01_random_read_ceiling.md).
+// A call is ONE batch of that kernel when memory allows (a batch ends with its slowest chains alone on the chip), and the
+// backward phases whose interval lists stay wide -- those chains -- are handed over to fmi_wide_kernel, a group of 16 lanes
+// per phase (FmiWideItem); pass 3 is a second launch of the state machine without list LDS.
 //
 // Roofline: readlen + 40 B per SMEM of streaming traffic + 64 B per CP_OCC record actually fetched
 // (counted by the kernel, gab_fmi_last_records).
