@@ -48,3 +48,22 @@ def test_short_kernel_names():
     cp = _cp()
     assert cp.short("void (anonymous namespace)::chain_block_kernel<3, false>((anonymous namespace)::ChainWork const*, int*)") == "chain_block_kernel<3, false>"
     assert cp.short("__amd_rocclr_copyBuffer") == "__amd_rocclr_copyBuffer"
+
+
+def test_this_rounds_committed_set_passes_the_lock():
+    """every r03 workload whose kernel stats and bench line are committed under profiles/ is evidence for that bench line:
+    the kernels bench.py prices and those of profiles/r03_hbm_traffic.json appear in the stats, and average x launches per
+    step fits the line's ms_per_step"""
+    cp = _cp()
+    traffic = json.load(open(os.path.join(ROOT, "profiles", "r03_hbm_traffic.json")))
+    seen = 0
+    for w in ("bsw", "chain", "fast-chain", "bpm", "bitpal", "bitpal-edit", "wfa", "fmi", "fmi-sa", "parse-bsw"):
+        stats = os.path.join(ROOT, "profiles", f"r03_{w}_large_kernel_stats.csv")
+        bench_line = os.path.join(ROOT, "profiles", f"r03_{w}_large_bench.json")
+        if not (os.path.exists(stats) and os.path.exists(bench_line)):
+            continue
+        trace = os.path.join(ROOT, "profiles", f"r03_{w}_large_kernel_trace.csv")
+        line = json.loads(open(bench_line).read().strip().splitlines()[-1])
+        assert cp.check(w, stats, trace if os.path.exists(trace) else None, line, traffic) == [], w
+        seen += 1
+    assert seen >= 6
