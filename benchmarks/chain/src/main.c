@@ -4,8 +4,16 @@
  * /root/reference/benchmarks/chain/src/main.cpp and fast-chain/src/main.cpp (the two are byte-identical);
  * text I/O as chain/src/host_data_io.cpp:13-60.  The harness compares out.txt and greps "Time in kernel"
  * (chain/scripts/regression_small.sh:89,94).
- * The ROI call host_chain_kernel(calls, rets, numThreads) (main.cpp:154) becomes gab_chain_run over chunks
- * of calls pulled by $GAB_WORKERS_PER_GPU host threads per GPU (default 3; $GAB_CHUNK = anchors per chunk).  Built twice: -DGAB_CHAIN_MODE=0 (chain) and =1 (fast-chain).
+ * The ROI call host_chain_kernel(calls, rets, numThreads) (main.cpp:154) becomes
+ *   one GPU:   ONE gab_chain_run over all calls;
+ *   N GPUs:    one SHARE of the calls per GPU and one gab_chain_run per share.  Calls differ in size by three orders of
+ *              magnitude and a batch cannot finish before its longest call, so the calls are sorted by descending anchor count
+ *              and dealt, longest first, to the GPU with the least anchors so far (the reference's analogue is
+ *              `omp for schedule(dynamic)` over calls, chain/src/host_kernel.cpp:98-105).  Each share is gathered into page-locked
+ *              slabs of its own BEFORE the ROI (where the reference's reader builds its vectors, main.cpp:120-150) by a thread
+ *              bound to its GPU's NUMA node, so the card reads memory next to it; results are printed from the shares;
+ *   $GAB_CHUNK (anchors per chunk; tests): file-order chunks pulled by $GAB_WORKERS_PER_GPU host threads per GPU.
+ * Built twice: -DGAB_CHAIN_MODE=0 (chain) and =1 (fast-chain).
  * Extra flag: -g <gpus> (or $GAB_GPUS).  -t is accepted and ignored.
  */
 #define GAB_ENERGY_STREAM stderr      /* where the reference prints "Energy consumption:" in this driver */
@@ -24,7 +32,51 @@ typedef struct {
     int64_t ncalls;
     int64_t *chunk_beg;      /* chunk c = calls [chunk_beg[c], chunk_beg[c+1]) */
     int64_t max_chunk_anchors, max_chunk_calls;
+    struct chain_share *shares;      /* N-GPU mode: chunk g = share g */
 } chain_ctx;
+
+/* one GPU's share of the calls, in slabs of its own */
+typedef struct chain_share {
+    int gpu;                     /* device whose NUMA node the slabs were first touched on */
+    int64_t ncalls, na;
+    int64_t *call_id;            /* share-local call k is call call_id[k] of the file (ascending) */
+    int64_t *off;                /* first anchor of share-local call k in the share's slabs */
+    gab_chain_hdr *hdr;
+    uint64_t *x, *y;
+    int32_t *score, *parent;
+    const chain_ctx *src;
+} chain_share;
+
+/* gather a share (thread bound to the GPU's node: malloc + first touch put the pages there; then page-lock) */
+static void *share_build(void *p) {
+    chain_share *sh = (chain_share *)p;
+    const chain_ctx *c = sh->src;
+    (void)gab_bind_thread_to_gpu(sh->gpu);
+    const size_t na = (size_t)sh->na;
+    sh->x = (uint64_t *)malloc(8 * (na + 1)); sh->y = (uint64_t *)malloc(8 * (na + 1));
+    sh->score = (int32_t *)malloc(4 * (na + 1)); sh->parent = (int32_t *)malloc(4 * (na + 1));
+    if (!sh->x || !sh->y || !sh->score || !sh->parent) { fprintf(stderr, "ERROR: out of memory for a GPU's share\n"); exit(EXIT_FAILURE); }
+    for (int64_t k = 0; k < sh->ncalls; k++) {
+        const int64_t id = sh->call_id[k], n = c->hdr[id].n;
+        memcpy(sh->x + sh->off[k], c->x + c->call_off[id], 8 * (size_t)n);
+        memcpy(sh->y + sh->off[k], c->y + c->call_off[id], 8 * (size_t)n);
+    }
+    gab_pin(sh->x, 8 * na); gab_pin(sh->y, 8 * na);
+    gab_pin_out_on(sh->gpu, sh->score, 4 * na); gab_pin_out_on(sh->gpu, sh->parent, 4 * na);
+    return NULL;
+}
+static void run_share(int worker, int gpu, int64_t chunk, void *vctx, void *st) {
+    (void)gpu; (void)worker;
+    chain_share *sh = &((chain_ctx *)vctx)->shares[chunk];
+    if (sh->ncalls == 0) return;
+    GAB_DIE_IF(gab_chain_run((gab_chain *)st, GAB_CHAIN_MODE, sh->x, sh->y, sh->off, sh->hdr, sh->ncalls, sh->score, sh->parent), "gab_chain_run");
+}
+static int by_n_desc(const void *a, const void *b, void *hdr_) {
+    const gab_chain_hdr *hdr = (const gab_chain_hdr *)hdr_;
+    const int64_t ia = *(const int64_t *)a, ib = *(const int64_t *)b;
+    if (hdr[ia].n != hdr[ib].n) return hdr[ia].n > hdr[ib].n ? -1 : 1;
+    return ia < ib ? -1 : ia > ib;              /* (stable: equal calls keep the file's order) */
+}
 
 static void *gpu_init(int worker, int gpu, void *vctx) {
     (void)worker;
@@ -160,12 +212,84 @@ int main(int argc, char **argv) {
 
     chain_ctx ctx;
     ctx.x = x; ctx.y = y; ctx.call_off = call_off; ctx.hdr = hdr; ctx.ncalls = (int64_t)ncalls;
-    ctx.score = (int32_t *)malloc(4 * (na + 1)); ctx.parent = (int32_t *)malloc(4 * (na + 1));
     const int ngpus = gab_pick_gpus(gpus);
-    /* chunks of ~equal anchor count ($GAB_CHUNK anchors each when set); with one GPU everything is one call by default
-     * (a chunk takes as long as the walk of its longest call, so fewer, larger chunks are better for this kernel) */
+    ctx.shares = NULL;
+    if (ngpus > 1 && gab_env_i64("GAB_CHUNK", 0) == 0 && ncalls > 0) {
+        /* ---- N GPUs: one share per GPU, calls dealt longest first to the least-loaded GPU ---- */
+        int64_t *order = (int64_t *)malloc(8 * ncalls), *load = (int64_t *)calloc((size_t)ngpus, 8);
+        int *owner = (int *)malloc(sizeof(int) * ncalls);
+        int64_t *local = (int64_t *)malloc(8 * ncalls);       /* index of a call inside its share */
+        for (size_t c = 0; c < ncalls; c++) order[c] = (int64_t)c;
+        qsort_r(order, ncalls, 8, by_n_desc, hdr);
+        chain_share *sh = (chain_share *)calloc((size_t)ngpus, sizeof(chain_share));
+        for (size_t k = 0; k < ncalls; k++) {
+            int g = 0;
+            for (int j = 1; j < ngpus; j++) if (load[j] < load[g]) g = j;
+            owner[order[k]] = g; load[g] += hdr[order[k]].n; sh[g].ncalls++;
+        }
+        int64_t max_a = 0, max_c = 0;
+        for (int g = 0; g < ngpus; g++) {
+            sh[g].gpu = gab_phys_gpu(g); sh[g].src = &ctx;
+            sh[g].call_id = (int64_t *)malloc(8 * (size_t)(sh[g].ncalls + 1)); sh[g].off = (int64_t *)malloc(8 * (size_t)(sh[g].ncalls + 1));
+            sh[g].hdr = (gab_chain_hdr *)malloc(sizeof(gab_chain_hdr) * (size_t)(sh[g].ncalls + 1));
+            sh[g].ncalls = 0; sh[g].na = 0;
+        }
+        for (size_t c = 0; c < ncalls; c++) {                  /* inside a share the calls keep the file's order */
+            chain_share *s = &sh[owner[c]];
+            local[c] = s->ncalls;
+            s->call_id[s->ncalls] = (int64_t)c; s->off[s->ncalls] = s->na; s->hdr[s->ncalls] = hdr[c];
+            s->ncalls++; s->na += hdr[c].n;
+        }
+        for (int g = 0; g < ngpus; g++) { if (sh[g].na > max_a) max_a = sh[g].na; if (sh[g].ncalls > max_c) max_c = sh[g].ncalls; }
+        {
+            pthread_t *th = (pthread_t *)calloc((size_t)ngpus, sizeof(pthread_t));
+            for (int g = 0; g < ngpus; g++) pthread_create(&th[g], NULL, share_build, &sh[g]);
+            for (int g = 0; g < ngpus; g++) pthread_join(th[g], NULL);
+            free(th);
+        }
+        ctx.shares = sh; ctx.max_chunk_anchors = max_a; ctx.max_chunk_calls = max_c;
+        if (getenv("GAB_QUEUE_REPORT")) {
+            fprintf(stderr, "chain shares (calls/anchors/longest):");
+            for (int g = 0; g < ngpus; g++) {
+                int64_t mx = 0;
+                for (int64_t k = 0; k < sh[g].ncalls; k++) if (sh[g].hdr[k].n > mx) mx = sh[g].hdr[k].n;
+                fprintf(stderr, " %ld/%ld/%ld", (long)sh[g].ncalls, (long)sh[g].na, (long)mx);
+            }
+            fprintf(stderr, "\n");
+        }
+        gab_queue q;
+        gab_queue_open(&q, ngpus, ngpus, gpu_init, run_share, gpu_fini, &ctx);
+        /* ---- region of interest (main.cpp:111-193): one gab_chain_run per GPU ---- */
+        const double t0 = gab_now();
+        gab_roi_begin_n(ngpus);
+        gab_queue_run(&q, ngpus);
+        gab_roi_end();
+        const double runtime = gab_now() - t0;
+        gab_queue_close(&q);
+        /* print_return (host_data_io.cpp:53-60), from the shares */
+        for (size_t c = 0; c < ncalls; c++) {
+            const chain_share *s = &sh[owner[c]];
+            const int64_t o = s->off[local[c]];
+            fprintf(out, "%lld\n", (long long)hdr[c].n);
+            for (int64_t i = 0; i < hdr[c].n; i++) fprintf(out, "%d\t%d\n", s->score[o + i], s->parent[o + i]);
+            fprintf(out, "EOR\n");
+        }
+        fprintf(stderr, "Time in kernel: %.2f sec\n", runtime);
+        if (gab_env_i64("GAB_ROI_PRECISE", 0)) fprintf(stderr, "[gab] region of interest: %.3f ms\n", runtime * 1e3);
+        for (int g = 0; g < ngpus; g++) {
+            gab_unpin(sh[g].x); gab_unpin(sh[g].y); gab_unpin(sh[g].score); gab_unpin(sh[g].parent);
+            free(sh[g].x); free(sh[g].y); free(sh[g].score); free(sh[g].parent); free(sh[g].call_id); free(sh[g].off); free(sh[g].hdr);
+        }
+        free(sh); free(order); free(load); free(owner); free(local);
+        fclose(in); fclose(out);
+        free(hdr); free(call_off); free(x); free(y);
+        return 0;
+    }
+    ctx.score = (int32_t *)malloc(4 * (na + 1)); ctx.parent = (int32_t *)malloc(4 * (na + 1));
+    /* one GPU: everything is ONE call (a chunk takes as long as its longest call, so fewer, larger chunks are better for
+     * this kernel); $GAB_CHUNK anchors per chunk when set: file-order chunks of ~equal anchor count */
     const int64_t chunk_anchors = gab_env_i64("GAB_CHUNK", 0);
-    int64_t nchunks_want = chunk_anchors > 0 ? (int64_t)(na / (size_t)chunk_anchors) + 1 : (ngpus == 1 ? 1 : 8 * ngpus);
+    int64_t nchunks_want = chunk_anchors > 0 ? (int64_t)(na / (size_t)chunk_anchors) + 1 : 1;
     if (nchunks_want > (int64_t)ncalls) nchunks_want = ncalls > 0 ? (int64_t)ncalls : 1;
     ctx.chunk_beg = (int64_t *)malloc(8 * (size_t)(nchunks_want + 2));
     int64_t nchunks = 0;
@@ -187,7 +311,7 @@ int main(int argc, char **argv) {
         if (a > ctx.max_chunk_anchors) ctx.max_chunk_anchors = a;
         if (e - b > ctx.max_chunk_calls) ctx.max_chunk_calls = e - b;
     }
-    gab_pin(x, 8 * na); gab_pin(y, 8 * na); gab_pin_out(ctx.score, 4 * na); gab_pin_out(ctx.parent, 4 * na);
+    gab_pin(x, 8 * na); gab_pin(y, 8 * na); gab_pin_out(ctx.score, 4 * na); gab_pin_out(ctx.parent, 4 * na);      /* (warm copy from the first GPU picked) */
     gab_queue q;
     gab_queue_open(&q, ngpus, nchunks, gpu_init, run_chunk, gpu_fini, &ctx);
 

@@ -23,6 +23,11 @@
  */
 #ifndef GAB_DRIVER_H
 #define GAB_DRIVER_H
+#ifndef _GNU_SOURCE
+#define _GNU_SOURCE             /* cpu_set_t, pthread_setaffinity_np (host placement below) */
+#endif
+#include <sched.h>
+#include <ctype.h>
 #include <dlfcn.h>
 #include <pthread.h>
 #include <stdint.h>
@@ -142,14 +147,89 @@ static inline void gab_roi_end(void) {
 #endif
 }
 
-/* number of GPUs to use: explicit flag value if > 0, else $GAB_GPUS, else 1; clamped to what is visible */
+/* number of GPUs to use: explicit flag value if > 0, else $GAB_GPUS, else 1; clamped to what is visible.
+ * GAB_GPU_OVERSUBSCRIBE=1 (tests on a one-GPU box): no clamp, logical GPU g is device g % visible -- the N-GPU code paths of
+ * the drivers (shares, per-GPU parsing, placement) then run with several logical GPUs on one card. */
 static inline int gab_pick_gpus(int flag) {
     int want = flag;
     if (want <= 0) { const char *e = getenv("GAB_GPUS"); want = e ? atoi(e) : 1; }
     if (want <= 0) want = 1;
     int have = gab_device_count();
     if (have <= 0) { fprintf(stderr, "ERROR: no MI355X visible (%s); this driver has no CPU path\n", gab_last_error()); exit(EXIT_FAILURE); }
+    if (gab_env_i64("GAB_GPU_OVERSUBSCRIBE", 0)) return want < 64 ? want : 64;
     return want < have ? want : have;
+}
+/* the device behind logical GPU g (g itself unless GAB_GPU_OVERSUBSCRIBE) */
+static inline int gab_phys_gpu(int g) {
+    const int have = gab_device_count();
+    return have > 0 ? g % have : g;
+}
+
+/* ---- host placement ---------------------------------------------------------------------------
+ * The reference pins its threads (OMP_PROC_BIND=true OMP_PLACES=cores, bsw/scripts/regression_small.sh:52).  Here a GPU's
+ * worker threads -- they stage its chunks, and with page-locked slabs the card reads host memory directly -- run on the cores
+ * of the NUMA node the card hangs off: PCI bus id (gab_device_pci_bus_id) -> /sys/bus/pci/devices/<id>/numa_node ->
+ * /sys/devices/system/node/node<N>/cpulist -> pthread_setaffinity_np, intersected with the mask the process was given
+ * (cgroup cpusets); slabs made by such a thread are first-touched on that node.  GAB_NO_BIND=1 leaves the threads alone;
+ * GAB_SYSFS_ROOT prefixes the two sysfs paths (tests point it at a made-up tree). */
+static inline int gab_parse_cpulist(const char *s, cpu_set_t *set) {      /* "0-15,128-143\n" -> set; returns the number of CPUs */
+    CPU_ZERO(set);
+    int n = 0;
+    while (*s) {
+        while (*s == ',' || isspace((unsigned char)*s)) s++;
+        if (!isdigit((unsigned char)*s)) break;
+        char *e;
+        long a = strtol(s, &e, 10), b = a;
+        if (*e == '-') b = strtol(e + 1, &e, 10);
+        if (b < a) return -1;
+        for (long c = a; c <= b; c++) if (c >= 0 && c < CPU_SETSIZE) { if (!CPU_ISSET((int)c, set)) n++; CPU_SET((int)c, set); }
+        s = e;
+    }
+    return n;
+}
+static inline int gab_read_small_file(const char *path, char *buf, size_t cap) {
+    FILE *f = fopen(path, "r");
+    if (!f) return -1;
+    const size_t n = fread(buf, 1, cap - 1, f);
+    fclose(f);
+    buf[n] = 0;
+    return (int)n;
+}
+/* NUMA node of a PCI device ("0000:c1:00.0", any case), or -1 (no such file, or the kernel says -1: one node / unknown) */
+static inline int gab_numa_node_of_pci(const char *busid) {
+    const char *root = getenv("GAB_SYSFS_ROOT");
+    char id[64], path[512], txt[64];
+    size_t k = 0;
+    for (; busid[k] && k + 1 < sizeof id; k++) id[k] = (char)tolower((unsigned char)busid[k]);
+    id[k] = 0;
+    snprintf(path, sizeof path, "%s/sys/bus/pci/devices/%s/numa_node", root ? root : "", id);
+    if (gab_read_small_file(path, txt, sizeof txt) <= 0) return -1;
+    return atoi(txt);
+}
+static inline int gab_node_cpus(int node, cpu_set_t *set) {              /* CPUs of a node; returns their number or -1 */
+    const char *root = getenv("GAB_SYSFS_ROOT");
+    char path[512], txt[4096];
+    snprintf(path, sizeof path, "%s/sys/devices/system/node/node%d/cpulist", root ? root : "", node);
+    if (gab_read_small_file(path, txt, sizeof txt) <= 0) return -1;
+    return gab_parse_cpulist(txt, set);
+}
+/* NUMA node of device `dev`, or -1 */
+static inline int gab_gpu_numa_node(int dev) {
+    char id[64];
+    if (gab_device_pci_bus_id(dev, id, (int)sizeof id) != 0) return -1;
+    return gab_numa_node_of_pci(id);
+}
+/* bind the calling thread to the cores of `dev`'s node; returns the node, or -1 when nothing was changed */
+static inline int gab_bind_thread_to_gpu(int dev) {
+    if (gab_env_i64("GAB_NO_BIND", 0)) return -1;
+    const int node = gab_gpu_numa_node(dev);
+    cpu_set_t want, have;
+    if (node < 0 || gab_node_cpus(node, &want) <= 0) return -1;
+    if (pthread_getaffinity_np(pthread_self(), sizeof have, &have) != 0) return -1;
+    CPU_AND(&want, &want, &have);
+    if (CPU_COUNT(&want) == 0) return -1;                    /* the node's cores are not ours (cpuset): stay where we are */
+    if (pthread_setaffinity_np(pthread_self(), sizeof want, &want) != 0) return -1;
+    return node;
 }
 
 #define GAB_DIE_IF(rc, what) do { if ((rc) != 0) { fprintf(stderr, "ERROR: %s failed (%d): %s\n", what, (int)(rc), gab_last_error()); exit(EXIT_FAILURE); } } while (0)
@@ -163,17 +243,22 @@ static inline void gab_pin(const void *p, size_t bytes) {
 /* the same for a slab the ROI WRITES (scores, CIGAR text ...): fresh malloc'ed memory has no pages behind it yet, and the first
  * device-to-host copy into such a buffer was measured at ~10 ms for 5 MB (wfa driver, once per process) against 0.1 ms for the
  * next one -- the pages are touched here, before the ROI, as calloc would (that alone changes nothing: see below) */
-static inline void gab_pin_out(void *p, size_t bytes) {
+static inline void gab_pin_out_on(int dev, void *p, size_t bytes) {
     memset(p, 0, bytes);
     gab_pin(p, bytes);
     /* ... and the first device-to-host copy of more than a few MB into a freshly page-locked region costs ~10 ms, once
      * (wfa driver: 10.8 ms for the first 5.3 MB of CIGAR text, 0.1 ms for every later chunk; ROI 16.1 -> 9.2 ms with this):
-     * one copy of up to 16 MB from the first GPU, before the ROI.  GAB_NO_OUT_WARM=1 to compare. */
+     * one copy of up to 16 MB from `dev` -- a GPU the run uses (not device 0 whatever was picked) -- before the
+     * ROI.  GAB_NO_OUT_WARM=1 to compare. */
     if (gab_env_i64("GAB_NO_OUT_WARM", 0) || gab_env_i64("GAB_NO_PIN", 0)) return;
     void *d = NULL;
     const size_t wb = bytes < ((size_t)16 << 20) ? bytes : ((size_t)16 << 20);
-    if (wb && gab_device_alloc(0, wb, &d) == 0) { (void)gab_device_copy_to_host(0, p, d, wb); gab_device_free(0, d); }
+    if (wb && gab_device_alloc(dev, wb, &d) == 0) {
+        if (gab_device_copy_to_host(dev, p, d, wb) != 0) fprintf(stderr, "note: warm-up copy from GPU %d failed (%s)\n", dev, gab_last_error());
+        gab_device_free(dev, d);
+    } else if (wb) fprintf(stderr, "note: no warm-up copy from GPU %d (%s); the first copy-out inside the ROI pays ~10 ms\n", dev, gab_last_error());
 }
+static inline void gab_pin_out(void *p, size_t bytes) { gab_pin_out_on(gab_phys_gpu(0), p, bytes); }
 static inline void gab_unpin(const void *p) { if (!gab_env_i64("GAB_NO_PIN", 0)) gab_host_unregister((void *)p); }
 
 /* ---- per-GPU work queue ---------------------------------------------------------------------- */
@@ -184,9 +269,11 @@ typedef struct {
     int worker, gpu; int64_t nchunks; int64_t *cursor; pthread_mutex_t *mu;
     gab_gpu_init_fn init; gab_chunk_fn run; gab_gpu_fini_fn fini; void *ctx; void *state;
     int64_t done;       /* chunks this worker ran */
+    int node;           /* NUMA node the thread was bound to, or -1 */
 } gab_worker;
 static void *gab_worker_main(void *p) {
     gab_worker *w = (gab_worker *)p;
+    w->node = gab_bind_thread_to_gpu(w->gpu);               /* (a fresh thread per gab_queue_run: bound before it touches a chunk) */
     for (;;) {
         pthread_mutex_lock(w->mu);
         int64_t c = (*w->cursor)++;
@@ -210,7 +297,8 @@ static inline void gab_queue_open(gab_queue *q, int ngpus, int64_t nchunks, gab_
     q->w = (gab_worker *)calloc((size_t)q->nworkers, sizeof(gab_worker));
     for (int k = 0; k < q->nworkers; k++) {
         gab_worker *w = &q->w[k];
-        w->worker = k; w->gpu = k % ngpus; w->cursor = &q->cursor; w->mu = &q->mu;      /* worker k and k + ngpus share a GPU */
+        w->worker = k; w->gpu = gab_phys_gpu(k % ngpus); w->cursor = &q->cursor; w->mu = &q->mu;      /* worker k and k + ngpus share a GPU */
+        w->node = -1;
         w->init = init; w->run = run; w->fini = fini; w->ctx = ctx;
         w->state = init ? init(k, w->gpu, ctx) : NULL;
     }
@@ -224,6 +312,9 @@ static inline void gab_queue_run(gab_queue *q, int64_t nchunks) {
     if (getenv("GAB_QUEUE_REPORT")) {       /* one line for tests / tuning: how the chunks were spread */
         fprintf(stderr, "gab_queue: %ld chunks over %d workers on %d GPU(s):", (long)nchunks, q->nworkers, q->ngpus);
         for (int k = 0; k < q->nworkers; k++) fprintf(stderr, " %ld", (long)q->w[k].done);
+        fprintf(stderr, "\n");
+        fprintf(stderr, "gab_queue placement (worker:gpu@node):");
+        for (int k = 0; k < q->nworkers; k++) fprintf(stderr, " %d:%d@%d", k, q->w[k].gpu, q->w[k].node);
         fprintf(stderr, "\n");
     }
 }

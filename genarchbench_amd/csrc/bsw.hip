@@ -58,7 +58,9 @@ struct BswIO {
     const int32_t *len1, *len2, *h0;
     int64_t ref_bytes, qry_bytes, n;
     int64_t ref_lo, qry_lo;        // lowest readable offset of the two slabs (0 for a caller's device slabs; the staged window's
-};                                 // start when gab_bsw_run has copied only the part of the host slabs it expects the pairs to use)
+                                   // start when gab_bsw_run has copied only the part of the host slabs it expects the pairs to use)
+    int64_t ref_hi, qry_hi;        // end of the bytes that really hold the caller's data (= ref_bytes / qry_bytes for device slabs; the
+};                                 // end of what gab_bsw_run COPIED: its window is padded to 256 bytes, and the padding is not the caller's data)
 
 // (query length, reference length / 8, h0 / 32): lanes of a wave then run the same number of rows AND start with bands of
 // similar width (row -1 is non-zero up to column ~h0, and the band stays ~2 x score wide until it reaches w)
@@ -86,7 +88,8 @@ __global__ __launch_bounds__(256) void bsw_hist(BswIO io, uint32_t *hist, uint32
         int64_t ro = io.ref_off[i], qo = io.qry_off[i];
         bool ok = ql >= 1 && ql <= GAB_BSW_MAX_QLEN && tl >= 1 && tl <= GAB_BSW_MAX_TLEN && h >= 0 &&
                   h <= (1 << 29) && ro >= io.ref_lo && qo >= io.qry_lo &&
-                  ro + tl + 3 <= io.ref_bytes && qo + ql + 3 <= io.qry_bytes;     // (the kernels read dwords from the sequence's own start)
+                  ro + tl + 3 <= io.ref_bytes && qo + ql + 3 <= io.qry_bytes &&   // (the kernels read dwords from the sequence's own start)
+                  ro + tl <= io.ref_hi && qo + ql <= io.qry_hi;
         if (!ok) {
             atomicAdd(&st->bad, 1);
             atomicMin((unsigned int *)&st->first_bad, (unsigned int)(i + 1 > 0x7fffffff ? 0x7fffffff : i + 1));
@@ -606,6 +609,7 @@ struct gab_bsw {
     uint32_t *h_qstart = nullptr;   // pinned, kQBuckets + 1
     BswStats *h_stats = nullptr;    // pinned
     int64_t last_cells = 0;
+    bool out_of_order = false;      // gab_bsw_run: a batch's sequences did not lie in pair order (its sampled window was rejected by the device)
 };
 
 extern "C" int gab_bsw_create(const gab_bsw_params *p, int device, gab_bsw **out) {
@@ -677,17 +681,20 @@ extern "C" void gab_bsw_destroy(gab_bsw *h) {
 static int bsw_run_device_impl(gab_bsw *h, const uint8_t *ref, int64_t ref_bytes, const int64_t *ref_off,
                                const uint8_t *qry, int64_t qry_bytes, const int64_t *qry_off,
                                const int32_t *len1, const int32_t *len2, const int32_t *h0, int64_t n,
-                               int32_t *score_out, gab_bsw_result *result_out, void *stream_, int64_t ref_lo, int64_t qry_lo);
+                               int32_t *score_out, gab_bsw_result *result_out, void *stream_, int64_t ref_lo, int64_t qry_lo,
+                               int64_t ref_hi, int64_t qry_hi);
 extern "C" int gab_bsw_run_device(gab_bsw *h, const uint8_t *ref, int64_t ref_bytes, const int64_t *ref_off,
                                   const uint8_t *qry, int64_t qry_bytes, const int64_t *qry_off,
                                   const int32_t *len1, const int32_t *len2, const int32_t *h0, int64_t n,
                                   int32_t *score_out, gab_bsw_result *result_out, void *stream_) {
-    return bsw_run_device_impl(h, ref, ref_bytes, ref_off, qry, qry_bytes, qry_off, len1, len2, h0, n, score_out, result_out, stream_, 0, 0);
+    return bsw_run_device_impl(h, ref, ref_bytes, ref_off, qry, qry_bytes, qry_off, len1, len2, h0, n, score_out, result_out, stream_, 0, 0,
+                               ref_bytes, qry_bytes);
 }
 static int bsw_run_device_impl(gab_bsw *h, const uint8_t *ref, int64_t ref_bytes, const int64_t *ref_off,
                                const uint8_t *qry, int64_t qry_bytes, const int64_t *qry_off,
                                const int32_t *len1, const int32_t *len2, const int32_t *h0, int64_t n,
-                               int32_t *score_out, gab_bsw_result *result_out, void *stream_, int64_t ref_lo, int64_t qry_lo) {
+                               int32_t *score_out, gab_bsw_result *result_out, void *stream_, int64_t ref_lo, int64_t qry_lo,
+                               int64_t ref_hi, int64_t qry_hi) {
     GAB_CHECK(h, "gab_bsw_run_device: NULL handle");
     GAB_CHECK(n >= 0 && n < (1ll << 31), "gab_bsw_run_device: n=%lld out of range", (long long)n);
     h->have_stats = false;
@@ -714,7 +721,7 @@ static int bsw_run_device_impl(gab_bsw *h, const uint8_t *ref, int64_t ref_bytes
     BswRec *d_recs = (BswRec *)(base + o_recs);             // the pairs' records in bucket order
     uint32_t *d_rank = (uint32_t *)(base + o_rank);
 
-    BswIO io{ref, ref_off, qry, qry_off, len1, len2, h0, ref_bytes, qry_bytes, n, ref_lo, qry_lo};
+    BswIO io{ref, ref_off, qry, qry_off, len1, len2, h0, ref_bytes, qry_bytes, n, ref_lo, qry_lo, ref_hi, qry_hi};
     GAB_HIP(hipEventRecord(h->ev[0], s));
     GAB_HIP(hipMemsetAsync(base, 0, o_recs, s));
     {
@@ -814,8 +821,7 @@ extern "C" int gab_bsw_run(gab_bsw *h, const uint8_t *ref, const int64_t *ref_of
         ra = ref_off[i] < ra ? ref_off[i] : ra; qa = qry_off[i] < qa ? qry_off[i] : qa;
         return ref_off[i] >= 0 && qry_off[i] >= 0 && len1[i] >= 0 && len2[i] >= 0;
     };
-    static std::atomic<bool> out_of_order{false};      // a batch of this process was rejected for its sampled window: scan from now on
-    bool sampled = n > 4096 && !out_of_order.load(std::memory_order_relaxed) && !getenv("GAB_BSW_FULL_SCAN");
+    bool sampled = n > 4096 && !h->out_of_order && !getenv("GAB_BSW_FULL_SCAN");      // (a batch of this handle was rejected for its sampled window: scan from then on)
     if (sampled) {
         bool ok = take(0);
         ok = take(n - 1) && ok;
@@ -863,10 +869,10 @@ extern "C" int gab_bsw_run(gab_bsw *h, const uint8_t *ref, const int64_t *ref_of
     rc = bsw_run_device_impl(h, (const uint8_t *)(b + o_ref) - ra, ra + (int64_t)rpad, (const int64_t *)(b + o_roff),
                              (const uint8_t *)(b + o_qry) - qa, qa + (int64_t)qpad, (const int64_t *)(b + o_qoff),
                              (const int32_t *)(b + o_l1), (const int32_t *)(b + o_l2), (const int32_t *)(b + o_h0),
-                             n, (int32_t *)(b + o_sc), nullptr, s, ra, qa);
+                             n, (int32_t *)(b + o_sc), nullptr, s, ra, qa, rb, qb);      // (rb / qb: a pair that ends in the window's padding was not copied)
     if (rc == GAB_EINVAL && sampled) {
         // a pair outside the sampled window (sequences not in pair order) -- or a really invalid one: the full scan tells
-        out_of_order.store(true, std::memory_order_relaxed);
+        h->out_of_order = true;
         return gab_bsw_run(h, ref, ref_off, qry, qry_off, len1, len2, h0, n, score_out);
     }
     if (rc) return rc;

@@ -547,9 +547,14 @@ __global__ __launch_bounds__(64) void fmi_seed_kernel(FmiIdx ix, const uint8_t *
                 if (ncur == 0) state = ST_BWD_END;
                 else {
                     cur_m = (uint32_t)j; j--; state = ST_BWD_COL;
-                    if (LDSQ && wide.items && ncur >= wide.min_entries) {          // a wide phase: hand the rest of it over
+                    // a wide phase: hand the rest of it over.  Once the item queue is full the counter is left alone (a lane
+                    // that keeps its phase comes back here after every later wide column; on a large low-complexity batch those
+                    // increments could carry the int32 counter past 2^31, a negative `it` would pass the bound below and the wide kernel
+                    // would see a negative item count)
+                    if (LDSQ && wide.items && ncur >= wide.min_entries &&
+                        __hip_atomic_load(&ct->wide_items, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < wide.items_cap) {
                         const int it = atomicAdd(&ct->wide_items, 1);
-                        if (it < wide.items_cap) {           // (so the list cursor stays below items_cap x 256 entries: no wrap)
+                        if (it >= 0 && it < wide.items_cap) {           // (so the list cursor stays below items_cap x 256 entries: no wrap)
                             const uint32_t off = atomicAdd(&ct->wide_top, (uint32_t)ncur);
                             FmiWideItem w;
                             w.t = (uint32_t)t; w.jm = (uint32_t)(j + 1) | (uint32_t)min_intv << 16 | (pass == 1 ? 1u << 31 : 0u);
@@ -625,7 +630,7 @@ __global__ __launch_bounds__(64) void fmi_wide_kernel(FmiIdx ix, const uint8_t *
     const int LL = (stride + 15) & ~15;
     const int lane = threadIdx.x, g = lane >> 4, gl = lane & 15, lead = g * 16;
     const int split_len = (int)(min_seed_len * 1.5 + .499);
-    const int n_items = *n_items_dev < items_cap ? *n_items_dev : items_cap;
+    const int n_items = (uint32_t)*n_items_dev < (uint32_t)items_cap ? *n_items_dev : items_cap;      // (the counter as unsigned: never a negative count)
     uint32_t calls = 0, recs = 0, tabs = 0, dummy = 0;
     unsigned long long tot = 0;
     int mx = 0;

@@ -24,6 +24,18 @@ extern "C" int gab_device_count(void) {
     return n;
 }
 
+// PCI bus id of a device ("0000:c1:00.0"): the drivers look up the NUMA node of the card with it (host placement,
+// benchmarks/common/gab_driver.h)
+extern "C" int gab_device_pci_bus_id(int device, char *buf, int len) {
+    if (!buf || len < 16) { gab_set_error("gab_device_pci_bus_id: buffer of at least 16 bytes needed"); return GAB_EINVAL; }
+    buf[0] = 0;
+    const int n = gab_device_count();
+    if (n <= 0) { gab_set_error("no HIP device visible"); return GAB_ENODEV; }
+    if (device < 0 || device >= n) { gab_set_error("device %d out of range (0..%d)", device, n - 1); return GAB_EINVAL; }
+    GAB_HIP(hipDeviceGetPCIBusId(buf, len, device));
+    return GAB_OK;
+}
+
 int gab_check_device(int device) {
     int n = gab_device_count();
     if (n <= 0) {

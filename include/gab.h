@@ -42,6 +42,10 @@ extern "C" {
 const char *gab_version(void);
 const char *gab_last_error(void);
 int gab_device_count(void);
+/* PCI bus id ("0000:c1:00.0") of a device into buf (len >= 16): what the drivers need to find the NUMA node a card hangs
+ * off (/sys/bus/pci/devices/<id>/numa_node) and place its worker threads there, as the reference places its threads with
+ * OMP_PROC_BIND / OMP_PLACES (bsw/scripts/regression_small.sh:52) */
+int gab_device_pci_bus_id(int device, char *buf, int len);
 /* device memory for C callers that chain two *_device entry points (e.g. parser -> kernel) without a HIP toolchain */
 int gab_device_alloc(int device, size_t bytes, void **out);
 void gab_device_free(int device, void *p);

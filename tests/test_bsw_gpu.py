@@ -123,6 +123,32 @@ def test_host_window_from_a_sample_of_the_pairs(sw):
     np.testing.assert_array_equal(sw.getScores16(b), want)
 
 
+def test_host_window_pair_ending_in_the_padding_of_the_sampled_window():
+    """the sampled window is padded to 256 bytes on the device, and only the sampled extent is copied.  A pair
+    that was NOT sampled and ends less than 256 bytes past the sampled end used to pass the device's check against the padded
+    window and read staging bytes nobody had copied (here: what the batch before left there).  The device now checks against
+    the copied extent, so such a batch is scanned in full and staged again."""
+    from genarchbench_amd.bsw import BandedPairWiseSW
+    sw = BandedPairWiseSW(device=0)
+    try:
+        a = gabgen.bsw(77, 20000, 1)
+        np.testing.assert_array_equal(sw.getScores16(a), pyoracle.bsw(a)[:, 0])          # fills the staging buffer with other data
+        b = gabgen.bsw(22, 20000, 1)
+        want = pyoracle.bsw(b)[:, 0]
+        # the last two pairs handed over in swapped order: pair n - 1 (sampled) is now the one that lies first in the slabs,
+        # pair n - 2 (not sampled: (n - 1) * 64 // 65 != n - 2) ends behind the sampled end
+        n = b.n
+        assert (n - 1) * 64 // 65 != n - 2
+        idx = np.arange(n); idx[n - 2], idx[n - 1] = n - 1, n - 2
+        sw2 = gabgen.BswBatch(b.ref, b.ref_off[idx].copy(), b.qry, b.qry_off[idx].copy(), b.len1[idx].copy(), b.len2[idx].copy(), b.h0[idx].copy())
+        assert sw2.ref_off[n - 2] + sw2.len1[n - 2] > sw2.ref_off[n - 1] + sw2.len1[n - 1]
+        assert sw2.ref_off[n - 2] + sw2.len1[n - 2] - (sw2.ref_off[n - 1] + sw2.len1[n - 1]) < 256
+        np.testing.assert_array_equal(sw.getScores16(sw2), want[idx])
+        np.testing.assert_array_equal(sw.getScores16(b), want)
+    finally:
+        sw.close()
+
+
 def test_rejects_bad_input(sw):
     from genarchbench_amd._lib import GabError
     A = lambda *x: np.array(x, np.uint8)

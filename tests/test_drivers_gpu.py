@@ -162,6 +162,31 @@ def test_regression_small_many_chunks_three_workers(inputs, bench, chunk, tmp_pa
     assert "OK" in r.stdout and "FAILED" not in r.stdout, r.stdout
 
 
+@pytest.mark.parametrize("bench", ["chain", "fast-chain"])
+def test_chain_shares_two_logical_gpus(inputs, bench, tmp_path):
+    """N GPUs (here: two logical GPUs on one card, GAB_GPU_OVERSUBSCRIBE=1): the calls are dealt longest first to the least-loaded
+    GPU (chain/src/host_kernel.cpp:98-105 schedules calls dynamically), every GPU gets ONE gab_chain_run over its
+    share, and the output file is the golden one"""
+    env = dict(os.environ, GENARCH_BENCH_INPUTS_ROOT=inputs, GAB_GPUS="2", GAB_GPU_OVERSUBSCRIBE="1", clean="0", **QUEUE_ENV)
+    r = subprocess.run(["bash", os.path.join(ROOT, "benchmarks", bench, "scripts", "regression_small.sh")], cwd=tmp_path,
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "OK" in r.stdout and "FAILED" not in r.stdout, r.stdout
+    # the driver's own report: two shares, one call of the library per GPU, balanced within the longest call
+    exe = os.path.join(ROOT, "benchmarks", bench, "chain")
+    o = str(tmp_path / "o.txt")
+    d = subprocess.run([exe, "-i", f"{inputs}/chain/small/in-1k.txt", "-o", o, "-t", "1"], capture_output=True, text=True, timeout=300, env=env)
+    assert d.returncode == 0, d.stderr[-500:]
+    nchunks, nworkers, counts = _queue_report(d.stderr)
+    assert (nchunks, nworkers, counts) == (2, 2, [1, 1])
+    sh = [l for l in d.stderr.splitlines() if l.startswith("chain shares")][0].split(":")[1].split()
+    calls, anchors, longest = zip(*[tuple(int(v) for v in t.split("/")) for t in sh])
+    assert abs(anchors[0] - anchors[1]) <= max(longest) and min(calls) > 0
+    one = str(tmp_path / "one.txt")
+    r1 = subprocess.run([exe, "-i", f"{inputs}/chain/small/in-1k.txt", "-o", one, "-t", "1"], capture_output=True, text=True, timeout=300)
+    assert r1.returncode == 0 and open(o).read() == open(one).read()
+
+
 def test_queue_spreads_chunks_over_workers(inputs, tmp_path):
     """every chunk runs exactly once, on some worker; more than one worker takes part"""
     exe = os.path.join(ROOT, "benchmarks", "bsw", "main_bsw")
