@@ -26,6 +26,7 @@
 // evaluations per anchor: latency/VALU bound by construction; the window re-reads are served by
 // L1/L2, not HBM.
 #include "gab_internal.h"
+#include "chain_dev.h"
 #include <algorithm>
 #include <new>
 #include <atomic>
@@ -36,17 +37,6 @@
 #include <type_traits>
 
 namespace {
-
-constexpr int kMaxIter = 5000;
-constexpr int kMaxSkip = 25;
-constexpr int kMarkRing = 1024;           // LDS ring of mark tags for the newest anchors; older marks go to global memory
-
-struct ChainWork {                        // one call, device-side descriptor
-    int64_t off, n;                       // first anchor in the DEVICE arrays (x, y, score, parent, marks), number of anchors
-    float avg_qspan;
-    int32_t max_dist_x, max_dist_y, bw, n_segs, pad;
-    int64_t hoff;                         // first anchor in the caller's arrays (= off except in the fed path, which pads calls to lines)
-};
 
 // ---- the host-pointer path of big batches: the anchors come in by a KERNEL, longest call first -----------------------
 // (see chain_run_fed).  A call's workgroup waits until its anchors are there and writes its results through to the caller's
@@ -162,47 +152,6 @@ __global__ __launch_bounds__(256) void chain_gather_kernel(const ChainChunk *__r
     }
 }
 
-#define GAB_DPP(old, src, ctrl, rmask) __builtin_amdgcn_update_dpp((old), (src), (ctrl), (rmask), 0xf, false)
-
-// inclusive max-scan across the 64 lanes (lane order), identity INT_MIN
-__device__ __forceinline__ int wave_incl_max(int v) {
-    const int id = (int)0x80000000;
-    v = max(v, GAB_DPP(id, v, 0x111, 0xf));   // row_shr:1
-    v = max(v, GAB_DPP(id, v, 0x112, 0xf));   // row_shr:2
-    v = max(v, GAB_DPP(id, v, 0x114, 0xf));   // row_shr:4
-    v = max(v, GAB_DPP(id, v, 0x118, 0xf));   // row_shr:8
-    v = max(v, GAB_DPP(id, v, 0x142, 0xa));   // row_bcast:15 -> rows 1,3
-    v = max(v, GAB_DPP(id, v, 0x143, 0xc));   // row_bcast:31 -> rows 2,3
-    return v;
-}
-// inclusive add-scan / min-scan, same DPP network
-__device__ __forceinline__ int wave_incl_sum(int v) {
-    v += GAB_DPP(0, v, 0x111, 0xf);
-    v += GAB_DPP(0, v, 0x112, 0xf);
-    v += GAB_DPP(0, v, 0x114, 0xf);
-    v += GAB_DPP(0, v, 0x118, 0xf);
-    v += GAB_DPP(0, v, 0x142, 0xa);
-    v += GAB_DPP(0, v, 0x143, 0xc);
-    return v;
-}
-__device__ __forceinline__ int wave_incl_min(int v) {
-    const int id = 0x7fffffff;
-    v = min(v, GAB_DPP(id, v, 0x111, 0xf));
-    v = min(v, GAB_DPP(id, v, 0x112, 0xf));
-    v = min(v, GAB_DPP(id, v, 0x114, 0xf));
-    v = min(v, GAB_DPP(id, v, 0x118, 0xf));
-    v = min(v, GAB_DPP(id, v, 0x142, 0xa));
-    v = min(v, GAB_DPP(id, v, 0x143, 0xc));
-    return v;
-}
-__device__ __forceinline__ int wave_shr1(int v, int fill) { return GAB_DPP(fill, v, 0x138, 0xf); }
-__device__ __forceinline__ uint64_t wave_shr1_u64(uint64_t v) {
-    uint32_t lo = (uint32_t)wave_shr1((int)(uint32_t)v, 0), hi = (uint32_t)wave_shr1((int)(uint32_t)(v >> 32), 0);
-    return ((uint64_t)hi << 32) | lo;
-}
-
-__device__ __forceinline__ int ilog2_u32(uint32_t v) { return 31 - __clz((int)v); }
-
 constexpr int kRing = 1024;               // anchors whose score / parent are kept in the LDS ring
 constexpr int kRingSafe = kRing - 8;      // entries younger than this are read from the ring
 
@@ -238,31 +187,6 @@ constexpr int kChHelpers = GAB_CH_HELPERS;
 constexpr int kChBlock = GAB_CH_BLOCK;
 constexpr int kGeoDepth = GAB_CH_GEODEPTH;   // predecessors per anchor the helpers prepare (kGeoDepth / 256 super-chunks)
 constexpr int kGeoNone = (int)0x80000000;      // predecessor filtered out (or outside the window)
-
-__device__ __forceinline__ int32_t chain_geometry(uint64_t xi, int32_t qi, int32_t q_span, int32_t sidi, uint64_t xj, uint32_t yj,
-                                                  int32_t sidj, int32_t mdx, int32_t mdy, int32_t bw, bool multi_seg, double avg_d,
-                                                  bool &ok) {
-    const int64_t dr = (int64_t)(xi - xj);
-    const int32_t dq = qi - (int32_t)yj;
-    const bool same = sidi == sidj;
-    const int32_t dd = (int32_t)(dr > dq ? dr - dq : dq - dr);
-    const bool skip = (same && dr == 0) || dq <= 0 || (same && dq > mdy) || dq > mdx || (same && dd > bw) ||
-                      (multi_seg && same && dr > mdy);
-    ok = !skip;
-    const int32_t min_d = (int32_t)(dq < dr ? (int64_t)dq : dr);
-    int32_t v = min_d > q_span ? q_span : min_d;
-    const int32_t lg = dd ? ilog2_u32((uint32_t)dd) : 0;
-    const int32_t c_lin = (int32_t)__dmul_rn(__dmul_rn((double)dd, .01), avg_d);
-    int32_t gap;
-    if (!same) {
-        if (dr == 0) { ++v; gap = 0; }
-        else gap = c_lin < lg ? c_lin : lg;
-    } else gap = c_lin + (lg >> 1);
-    // (int)((double)gap_cost * 1.0f + .499): gap_cost is an integer, so the truncation gives gap_cost itself when it is
-    // >= 0 and gap_cost + 1 when it is negative (a negative avg_qspan makes it so): two integer operations, no fp64
-    v -= gap - (gap >> 31);
-    return v;
-}
 
 __global__ __launch_bounds__(64 * (1 + kChHelpers)) void chain_hw_kernel(const ChainWork *__restrict__ work,
                                                                          const uint64_t *__restrict__ xs,
@@ -623,7 +547,6 @@ template <bool FED> struct AnchorView {
         return p[i];
     }
 };
-constexpr int kGapTab = 2048;             // entries of the per-call gap-cost table (LDS, int32): bw + 2 of them are used
 template <int H, bool FED>
 __device__ __forceinline__ void fastchain_body(const ChainWork *__restrict__ work, typename AnchorPtr<FED>::type xs,
                                                typename AnchorPtr<FED>::type ys, int32_t *score_out, int32_t *parent_out,
@@ -925,11 +848,7 @@ __global__ __launch_bounds__(256) void chain_facts_kernel(ChainWork *work, const
 // The gap cost -- (int)(dd * .01 * avg_qspan) in fp64 (two conversions and two multiplications at the fp64 rate) + ilog2(dd) / 2,
 // rounded -- depends on dd alone, and a pair with dd > bw is filtered: gap_tab[dd] for dd = 0 .. bw (built per call by
 // chain_gap_cost below, in LDS), one ds_read instead of ten instructions.  Pairs with dd > bw read entry bw + 1 (never used).
-__device__ __forceinline__ int32_t chain_gap_cost(int32_t dd, double avg_d) {
-    const int32_t lgh = (31 - __clz((int)((uint32_t)dd | 1u))) >> 1;          // ilog2(dd) >> 1, ilog2(0) = 0
-    const int32_t gap = (int32_t)__dmul_rn(__dmul_rn((double)dd, .01), avg_d) + lgh;
-    return gap - (gap >> 31);
-}
+// (chain_gap_cost: chain_dev.h)
 // the part of chain_geometry_plain before the table: the overlap term and the table index.  Callers that evaluate several
 // pairs in a row take the indices of all of them first and read the table afterwards, so that the LDS reads are in flight
 // together (left to the compiler every step waits for its own ds_read_b32).  MSEG: the call has n_segs > 1 (dr > max_dist_y rule)
@@ -958,98 +877,6 @@ __device__ __forceinline__ int32_t chain_geometry_plain(uint32_t xa_lo, int32_t 
     return v - gap_tab[min((uint32_t)dd, (uint32_t)bw + 1u)];
 }
 
-
-// the reference's scan of ONE anchor, by one whole wave, everything from global memory (x, y input; score, parent of
-// the predecessors as stored so far; marks in the per-anchor global array with tag i + 1).  Same three parallel steps as
-// the exact path of chain_hw_kernel.  Returns (best, best_j absolute) in all lanes; `evals` counts the visited items.
-template <class Anchors>
-__device__ __forceinline__ void chain_exact_global(const Anchors X, const Anchors Y, const int32_t *S, const int32_t *P, int32_t *GM,
-                                                   int i, int st, int32_t mdx, int32_t mdy, int32_t bw, bool multi_seg, double avg_d,
-                                                   int32_t &best_out, int32_t &bestj_out, unsigned long long &evals) {
-    const int lane = threadIdx.x & 63;
-    const int NEG = (int)0x80000000;
-    const uint64_t xi = X[i], yi = Y[i];
-    const int32_t qi = (int32_t)yi, q_span = (int32_t)(yi >> 32 & 0xff), sidi = (int32_t)(yi >> 48 & 0xff);
-    int32_t best = q_span, best_j = -1;
-    int n_skip = 0;
-    bool broke = false;
-    for (int top = i - 1; top >= st && !broke;) {
-        const int j0 = 4 * ((top >> 2) - lane);
-        bool valid[4], ok[4];
-        int32_t sc[4], parj[4] = {-1, -1, -1, -1};
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int j = j0 + 3 - k;
-            valid[k] = j >= st && j <= top; ok[k] = false; sc[k] = 0;
-            if (valid[k]) {
-                const uint64_t xj = X[j], yy = Y[j];
-                const int32_t scj = __hip_atomic_load(&S[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                parj[k] = __hip_atomic_load(&P[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                bool okk;
-                const int32_t v = chain_geometry(xi, qi, q_span, sidi, xj, (uint32_t)yy, (int32_t)(yy >> 48 & 0xff), mdx, mdy, bw, multi_seg, avg_d, okk);
-                ok[k] = okk; sc[k] = v + scj;
-            }
-        }
-        // marks: targets[parent[j]] = i for every unfiltered item, then this group's own four
-#pragma unroll
-        for (int k = 0; k < 4; k++)
-            if (ok[k] && parj[k] >= 0 && parj[k] >= st) __hip_atomic_store(&GM[parj[k]], (int32_t)(i + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        bool hit[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int j = j0 + 3 - k;
-            hit[k] = ok[k] && __hip_atomic_load(&GM[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int32_t)(i + 1);
-        }
-        int lmax = NEG;
-#pragma unroll
-        for (int k = 0; k < 4; k++) lmax = ok[k] ? max(lmax, sc[k]) : lmax;
-        const int incl = wave_incl_max(lmax);
-        int run = max(wave_shr1(incl, NEG), best);
-        bool imp[4];
-        int d[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            imp[k] = ok[k] && sc[k] > run;
-            run = ok[k] ? max(run, sc[k]) : run;
-            d[k] = imp[k] ? -1 : (ok[k] && hit[k]) ? 1 : 0;
-        }
-        const int p0 = d[0], p1 = p0 + d[1], p2 = p1 + d[2], p3 = p2 + d[3];
-        const int E = wave_incl_sum(p3) - p3;
-        const int mloc = min(min(p0, p1), min(p2, p3));
-        const int inclmin = wave_incl_min(E + mloc);
-        int rmin = min(-n_skip, wave_shr1(inclmin, 0x7fffffff));
-        int cnt[4];
-        const int pk[4] = {p0, p1, p2, p3};
-        int kfirst = 4;
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            rmin = min(rmin, E + pk[k]);
-            cnt[k] = E + pk[k] - rmin;
-            if (d[k] == 1 && cnt[k] > kMaxSkip && kfirst == 4) kfirst = k;
-        }
-        const unsigned long long om = __ballot(kfirst < 4);
-        int fl = 64, fk = 4;
-        if (om) { fl = __builtin_ctzll(om); fk = __builtin_amdgcn_readlane(kfirst, fl); broke = true; }
-        else n_skip = __builtin_amdgcn_readlane(cnt[3], 63);
-        const int klim = lane < fl ? 4 : lane == fl ? fk : 0;
-        int lastk = -1, lsc = 0, lj = 0;
-#pragma unroll
-        for (int k = 0; k < 4; k++)
-            if (imp[k] && k < klim) { lastk = k; lsc = sc[k]; lj = j0 + 3 - k; }
-        const unsigned long long lm = __ballot(lastk >= 0);
-        if (lm) {
-            const int ll = 63 - __builtin_clzll(lm);
-            best = __builtin_amdgcn_readlane(lsc, ll);
-            best_j = __builtin_amdgcn_readlane(lj, ll);
-        }
-        const int vlim = lane < fl ? 4 : lane == fl ? fk + 1 : 0;
-#pragma unroll
-        for (int k = 0; k < 4; k++) evals += (valid[k] && k < vlim) ? 1 : 0;
-        top = 4 * ((top >> 2) - 63) - 1;
-    }
-    best_out = best; bestj_out = best_j;
-}
 
 template <int H, bool FED>
 __device__ __forceinline__ void chain_block_body(const ChainWork *__restrict__ work, typename AnchorPtr<FED>::type xs,
@@ -1454,8 +1281,10 @@ constexpr size_t kFastDynLds = 2 * 2 * 16 * 64 * 16;     // G[buf][near | block]
 template <int MODE>
 __global__ __launch_bounds__(64 * (2 + kFastW))
 void chain_fast_kernel(const ChainWork *__restrict__ work, const uint64_t *__restrict__ xs, const uint64_t *__restrict__ ys, int32_t *score_out,
-                       int32_t *parent_out, int32_t *gmarks_all, unsigned long long *evals_out) {
+                       int32_t *parent_out, int32_t *gmarks_all, unsigned long long *evals_out, const uint32_t *gate) {
     constexpr int NW = kFastW;
+    // gate: the launch behind the table form (chain_tab.hip) -- only the calls it handed back (bail word set) are run here
+    if (gate && __hip_atomic_load(&gate[blockIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;
     constexpr bool FC = MODE == GAB_FASTCHAIN;
     extern __shared__ __attribute__((aligned(16))) uint8_t fast_lds[];
     int4 *G4 = reinterpret_cast<int4 *>(fast_lds);                                    // [buf][kind][16][64]
@@ -1951,6 +1780,9 @@ struct gab_chain {
     uint8_t *h_started = nullptr;            // pinned: one byte per workgroup of chain_gather_kernel
     hipEvent_t xe_fed = nullptr;
     bool have_stats = false;
+    ChainTab tab;                            // the table form's buffers (chain_tab.hip)
+    hipStream_t ts = nullptr;                // ... and its stream: it runs beside the other two forms
+    hipEvent_t te[2] = {nullptr, nullptr};
 };
 
 extern "C" int gab_chain_create(int device, gab_chain **out) {
@@ -1974,7 +1806,9 @@ extern "C" int gab_chain_create(int device, gab_chain **out) {
 extern "C" void gab_chain_destroy(gab_chain *h) {
     if (!h) return;
     gab_device_guard g(h->device);
-    h->work.release(); h->io.release(); h->hs.release(); h->gmarks.release();
+    h->work.release(); h->io.release(); h->hs.release(); h->gmarks.release(); h->tab.release();
+    if (h->ts) (void)hipStreamDestroy(h->ts);
+    for (int k = 0; k < 2; k++) if (h->te[k]) (void)hipEventDestroy(h->te[k]);
     for (int k = 0; k < 2; k++) if (h->ev[k]) (void)hipEventDestroy(h->ev[k]);
     for (int k = 0; k < 2; k++) if (h->xs[k]) (void)hipStreamDestroy(h->xs[k]);
     if (h->gs) (void)hipStreamDestroy(h->gs);
@@ -2043,6 +1877,12 @@ static ChainWork chain_work_of(const gab_chain_hdr &hd, int64_t off) {
 // stream, events and LDS attribute of the latency form (chain_fast_kernel); also made by gab_chain_reserve: a stream costs
 // ~8 ms the first time
 static int chain_fast_setup(gab_chain *h) {
+    if (!h->ts) {
+        if (hipStreamCreateWithFlags(&h->ts, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&h->te[0], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&h->te[1], hipEventDisableTiming) != hipSuccess) { gab_set_error("gab_chain: stream / event of the table form failed"); return GAB_EDEVICE; }
+        const int rc = chain_tab_setup();
+        if (rc) return rc;
+    }
     if (h->fs) return GAB_OK;
     if (hipStreamCreateWithFlags(&h->fs, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&h->fe[0], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->fe[1], hipEventDisableTiming) != hipSuccess ||
@@ -2107,43 +1947,73 @@ extern "C" int gab_chain_run_device(gab_chain *h, int mode, const uint64_t *d_x,
     // more to the latency form (chain-large on one GPU: none; an eighth of it and the 1 000-call input: 99 % of their anchors --
     // leaving the mid-size calls in the throughput form beside it cost the slowest call 1-2 %: its CU's SIMDs are shared).
     // GAB_CHAIN_FAST_MIN / GAB_CHAIN_FAST_CALLS pin the choice (tests, A/B runs).
-    size_t nfast = 0;
-    if (!(mode == GAB_CHAIN && getenv("GAB_CHAIN_KERNEL") && !strcmp(getenv("GAB_CHAIN_KERNEL"), "walk")) && !getenv("GAB_CHAIN_HELPERS")) {
+    // r04 -- and the calls a batch would WAIT for go to the table form (chain_tab.hip: the geometry of every block on any CU,
+    // the call's own workgroup only folds): a 60 000-anchor call takes ~1 ms there instead of 5-10, at 2 bytes of HBM traffic per
+    // pair.  The list is sorted longest first: [0, ntab) table form, [ntab, ntab + nfast) latency form, the rest throughput
+    // form, side by side on three streams.  GAB_CHAIN_TAB_MIN pins the table form's smallest call, GAB_CHAIN_TAB=0 turns it off.
+    const bool legacy_only = (mode == GAB_CHAIN && getenv("GAB_CHAIN_KERNEL") && !strcmp(getenv("GAB_CHAIN_KERNEL"), "walk")) || getenv("GAB_CHAIN_HELPERS");
+    size_t ntab = 0, nfast = 0;
+    int64_t tab_anchors = 0;
+    if (!legacy_only && !(getenv("GAB_CHAIN_TAB") && !atoi(getenv("GAB_CHAIN_TAB")))) {
+        int64_t min_n = INT64_MAX;
+        const double est_tp = (double)total / 2.85e9, lat_max = 0.12e-6 * (double)wk[0].n;      // (latency form: ~0.08-0.16 us per anchor)
+        if (lat_max >= 0.5 * est_tp) min_n = 2048;
+        if (getenv("GAB_CHAIN_TAB_MIN")) min_n = atoll(getenv("GAB_CHAIN_TAB_MIN"));
+        while (ntab < nw && wk[ntab].n >= min_n) { tab_anchors += wk[ntab].n; ntab++; }
+    }
+    const size_t nrest = nw - ntab;
+    if (!legacy_only && nrest) {
         int64_t min_n = 0, max_calls = 0;
-        const double est_tp = (double)total / 2.85e9, lat_max = 0.30e-6 * (double)wk[0].n;
-        if (lat_max >= 0.75 * est_tp) { min_n = 512; max_calls = (int64_t)nw; }
+        const double est_tp = (double)(total - tab_anchors) / 2.85e9, lat_max = 0.30e-6 * (double)wk[ntab].n;
+        if (lat_max >= 0.75 * est_tp) { min_n = 512; max_calls = (int64_t)nrest; }
         if (getenv("GAB_CHAIN_FAST_MIN")) min_n = atoll(getenv("GAB_CHAIN_FAST_MIN"));
         if (getenv("GAB_CHAIN_FAST_CALLS")) max_calls = atoll(getenv("GAB_CHAIN_FAST_CALLS"));
-        if (getenv("GAB_CHAIN_FAST_MIN") && !getenv("GAB_CHAIN_FAST_CALLS")) max_calls = (int64_t)nw;
-        while (nfast < nw && (int64_t)nfast < max_calls && wk[nfast].n >= min_n) nfast++;
+        if (getenv("GAB_CHAIN_FAST_MIN") && !getenv("GAB_CHAIN_FAST_CALLS")) max_calls = (int64_t)nrest;
+        while (nfast < nrest && (int64_t)nfast < max_calls && wk[ntab + nfast].n >= min_n) nfast++;
     }
-    if (nfast) {
+    if (ntab || nfast) {
         if ((rc = chain_fast_setup(h)) != GAB_OK) return rc;
         const ChainFeed nofeed{nullptr, nullptr, nullptr, nullptr, nullptr};
         if (mode == GAB_CHAIN) hipLaunchKernelGGL(chain_facts_kernel, dim3((unsigned)nw), dim3(256), 0, s, d_work, d_x, d_y);
         GAB_HIP(hipEventRecord(h->fe[0], s));
-        GAB_HIP(hipStreamWaitEvent(h->fs, h->fe[0], 0));
-        if (mode == GAB_CHAIN)
-            hipLaunchKernelGGL(chain_fast_kernel<GAB_CHAIN>, dim3((unsigned)nfast), dim3(64 * (2 + kFastW)), kFastDynLds, h->fs, d_work, d_x, d_y, d_score, d_parent, d_gm, d_ev);
-        else
-            hipLaunchKernelGGL(chain_fast_kernel<GAB_FASTCHAIN>, dim3((unsigned)nfast), dim3(64 * (2 + kFastW)), kFastDynLds, h->fs, d_work, d_x, d_y, d_score, d_parent, d_gm, d_ev);
-        GAB_HIP(hipGetLastError());
-        GAB_HIP(hipEventRecord(h->fe[1], h->fs));
-        if (nw > nfast) {
+        if (ntab) {
+            // the table form and, behind it on the same stream, the latency form for the calls it hands back (bail word set)
+            GAB_HIP(hipStreamWaitEvent(h->ts, h->fe[0], 0));
+            uint32_t *d_bail = nullptr;
+            if ((rc = chain_tab_run(&h->tab, mode, h->ts, d_work, wk.data(), ntab, total, d_x, d_y, d_score, d_parent, d_gm, d_ev, &d_bail)) != GAB_OK) return rc;
             if (mode == GAB_CHAIN)
-                hipLaunchKernelGGL((chain_block_kernel<kCbHelpers, false>), dim3((unsigned)(nw - nfast)), dim3(64 * (1 + kCbHelpers)), 0, s, d_work + nfast, d_x, d_y,
+                hipLaunchKernelGGL(chain_fast_kernel<GAB_CHAIN>, dim3((unsigned)ntab), dim3(64 * (2 + kFastW)), kFastDynLds, h->ts, d_work, d_x, d_y, d_score, d_parent, d_gm, d_ev, (const uint32_t *)d_bail);
+            else
+                hipLaunchKernelGGL(chain_fast_kernel<GAB_FASTCHAIN>, dim3((unsigned)ntab), dim3(64 * (2 + kFastW)), kFastDynLds, h->ts, d_work, d_x, d_y, d_score, d_parent, d_gm, d_ev, (const uint32_t *)d_bail);
+            GAB_HIP(hipGetLastError());
+            GAB_HIP(hipEventRecord(h->te[1], h->ts));
+        }
+        if (nfast) {
+            GAB_HIP(hipStreamWaitEvent(h->fs, h->fe[0], 0));
+            if (mode == GAB_CHAIN)
+                hipLaunchKernelGGL(chain_fast_kernel<GAB_CHAIN>, dim3((unsigned)nfast), dim3(64 * (2 + kFastW)), kFastDynLds, h->fs, d_work + ntab, d_x, d_y, d_score, d_parent, d_gm, d_ev, (const uint32_t *)nullptr);
+            else
+                hipLaunchKernelGGL(chain_fast_kernel<GAB_FASTCHAIN>, dim3((unsigned)nfast), dim3(64 * (2 + kFastW)), kFastDynLds, h->fs, d_work + ntab, d_x, d_y, d_score, d_parent, d_gm, d_ev, (const uint32_t *)nullptr);
+            GAB_HIP(hipGetLastError());
+            GAB_HIP(hipEventRecord(h->fe[1], h->fs));
+        }
+        if (nrest > nfast) {
+            if (mode == GAB_CHAIN)
+                hipLaunchKernelGGL((chain_block_kernel<kCbHelpers, false>), dim3((unsigned)(nrest - nfast)), dim3(64 * (1 + kCbHelpers)), 0, s, d_work + ntab + nfast, d_x, d_y,
                                    d_score, d_parent, d_gm, d_ev, nofeed);
             else
-                hipLaunchKernelGGL((fastchain_kernel<kFcHelpers, false>), dim3((unsigned)(nw - nfast)), dim3(64 * (1 + kFcHelpers)), 0, s, d_work + nfast, d_x, d_y,
+                hipLaunchKernelGGL((fastchain_kernel<kFcHelpers, false>), dim3((unsigned)(nrest - nfast)), dim3(64 * (1 + kFcHelpers)), 0, s, d_work + ntab + nfast, d_x, d_y,
                                    d_score, d_parent, d_ev, nofeed);
         }
-        GAB_HIP(hipStreamWaitEvent(s, h->fe[1], 0));
+        if (nfast) GAB_HIP(hipStreamWaitEvent(s, h->fe[1], 0));
+        if (ntab) GAB_HIP(hipStreamWaitEvent(s, h->te[1], 0));
     } else
     chain_launch(mode, chain_helpers_for(total, wk.empty() ? 0 : wk[0].n), s, d_work, (unsigned)nw, d_x, d_y, d_score, d_parent, d_gm, d_ev);
     GAB_HIP(hipGetLastError());
     GAB_HIP(hipEventRecord(h->ev[1], s));
     GAB_HIP(hipMemcpyAsync(h->h_evals, d_ev, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
     GAB_HIP(hipStreamSynchronize(s));    // wk (host vector) must outlive the H2D copy
+    if (ntab && getenv("GAB_CHAIN_TRACE")) chain_tab_report(&h->tab, ntab);
     h->have_stats = true;
     return GAB_OK;
 }

@@ -9,15 +9,19 @@ from tests.util import GOLDEN, read_chain_output
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["default-split", "latency-form-for-all", "throughput-form-for-all"])
+@pytest.fixture(autouse=True, params=["default-split", "latency-form-for-all", "throughput-form-for-all", "table-form-for-all"])
 def kernel_choice(request, monkeypatch):
     """chain: the longest calls of a batch (>= 4096 anchors) run in the latency form (chain_fast_kernel: geometry prepared by the
     helper waves, key-max fold, certificate by popcount), the rest in the throughput form.  Every test of this file runs with
-    the default split (by the batch-shape rule of gab_chain_run_device), with EVERY call in the latency form and with none -- chain and fast-chain alike."""
+    the default split (by the batch-shape rule of gab_chain_run_device), with EVERY call in the latency form and with none -- chain and fast-chain alike.
+    r04: and with every call in the TABLE form (chain_tab.hip: geometry bytes by any CU, the call's workgroup only folds); calls it
+    cannot take (a byte does not hold their gap costs, x not ascending, a missed max_skip certificate) come back through the latency form."""
     if request.param == "latency-form-for-all":
-        monkeypatch.setenv("GAB_CHAIN_FAST_MIN", "1"); monkeypatch.setenv("GAB_CHAIN_FAST_CALLS", "1000000000")
+        monkeypatch.setenv("GAB_CHAIN_FAST_MIN", "1"); monkeypatch.setenv("GAB_CHAIN_FAST_CALLS", "1000000000"); monkeypatch.setenv("GAB_CHAIN_TAB", "0")
     elif request.param == "throughput-form-for-all":
-        monkeypatch.setenv("GAB_CHAIN_FAST_CALLS", "0")
+        monkeypatch.setenv("GAB_CHAIN_FAST_CALLS", "0"); monkeypatch.setenv("GAB_CHAIN_TAB", "0")
+    elif request.param == "table-form-for-all":
+        monkeypatch.setenv("GAB_CHAIN_TAB_MIN", "1")
     return request.param
 
 
