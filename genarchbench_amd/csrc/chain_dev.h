@@ -196,14 +196,7 @@ struct ChainTab {
     gab_devbuf table;      // the geometry tables: 1 KB per 16 predecessors x 64 anchors
     gab_devbuf dbg;        // GAB_CHAIN_TRACE only
     size_t table_budget = 0;   // bytes the table may take (0: decided at the first call)
-    hipStream_t s2 = nullptr;  // the fold runs beside the geometry
-    hipEvent_t ev[2] = {nullptr, nullptr};
-    void release() {
-        calls.release(); blocks.release(); gtab.release(); st.release(); table.release(); dbg.release();
-        if (s2) (void)hipStreamDestroy(s2);
-        s2 = nullptr;
-        for (auto &e : ev) { if (e) (void)hipEventDestroy(e); e = nullptr; }
-    }
+    void release() { calls.release(); blocks.release(); gtab.release(); st.release(); table.release(); dbg.release(); }
 };
 // Runs the first `nsplit` calls of the (device) work list `d_work` -- `h_work` is the same list on the host -- through the table
 // form on stream `s`: window starts, geometry tables, fold.  d_bail[k] != 0 afterwards (on the stream) means call k was NOT

@@ -63,6 +63,8 @@ struct TabBlock {
 struct TabCounters { unsigned long long groups_needed; uint32_t no_room, rescans; };      // rescans: anchors whose certificate missed and whose exact scan confirmed the result
 
 constexpr int kTabNone = (int)0x80000000;      // a filtered pair in the key form
+constexpr int kTabSoftNone = -(1 << 22);       // ... while keys are still being added up (ctab_fold's unit closure): four of them do not overflow,
+constexpr int kTabSoftLim = -(1 << 21);        //     and a sum with one of them stays below this (a real key's |G << 7 | code| < 2^15, three hops < 2^17)
 constexpr int kTabNegH = -(1 << 23);           // below every far value (scores >= 0, G >= -255)
 
 // ---- 1. per call: is it eligible, its gap table, its bias -----------------------------------------------------------------------
@@ -248,15 +250,12 @@ __device__ __forceinline__ uint32_t ctab_sad(uint32_t a, uint32_t b) { uint32_t 
 template <int MODE, bool MSEG>
 __global__ __launch_bounds__(256) void ctab_geo(const ChainWork *__restrict__ work, const TabCall *__restrict__ calls, const TabBlock *__restrict__ blocks,
                                                 uint32_t *bail, const int32_t *__restrict__ gtab, const int32_t *__restrict__ st_all,
-                                                const uint64_t *__restrict__ xs, const uint64_t *__restrict__ ys, uint4 *T8, uint32_t *geo_done) {
+                                                const uint64_t *__restrict__ xs, const uint64_t *__restrict__ ys, uint4 *T8) {
     constexpr bool FC = MODE == GAB_FASTCHAIN;
     __shared__ int32_t gap[kGapTab];
     const TabBlock tb = blocks[blockIdx.x];
     const int c = tb.call;
-    if (bail[c] || tb.ng == 0) {                             // (uniform) nothing to write: the block still counts as done
-        if (threadIdx.x == 0) __hip_atomic_fetch_add(&geo_done[c], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return;
-    }
+    if (bail[c] || tb.ng == 0) return;
     const ChainWork w = work[c];
     const TabCall tc = calls[c];
     for (int d = threadIdx.x; d <= w.bw + 1; d += 256) gap[d] = gtab[tc.gt_off + d];
@@ -308,26 +307,18 @@ __global__ __launch_bounds__(256) void ctab_geo(const ChainWork *__restrict__ wo
             bool ok = oc >= 1 && (uint32_t)dq <= dq_lim;
             if (MSEG) ok = ok && dr <= mdy;
             if (!inside) ok = ok && (uint32_t)(j0 + k - st_a) < wspan;
-            const int32_t cl = min(max(gv, 0), 255);
-            bad |= (ok && gv > 255) ? 1 : 0;
-            bad |= (ok && narrow && dd <= (uint32_t)bw && gv < 1) ? 1 : 0;
-            bytes[k] = ok ? (uint32_t)cl : 0u;
+            // (gv <= q_span + bias <= 255: ctab_prep admits a call only then; dd > bw gives a huge negative value)
+            if (FC && any_narrow) bad |= (ok && narrow && dd <= (uint32_t)bw && (gv < 1 || gv > 255)) ? 1 : 0;
+            bytes[k] = ok ? (uint32_t)max(gv, 0) : 0u;
         }
         uint4 o;
         o.x = bytes[0] | bytes[1] << 8 | bytes[2] << 16 | bytes[3] << 24;
         o.y = bytes[4] | bytes[5] << 8 | bytes[6] << 16 | bytes[7] << 24;
         o.z = bytes[8] | bytes[9] << 8 | bytes[10] << 16 | bytes[11] << 24;
         o.w = bytes[12] | bytes[13] << 8 | bytes[14] << 16 | bytes[15] << 24;
-        // write-through (device-scope) stores: the fold kernel runs BESIDE this one, on any XCD, and starts on a call as soon as
-        // the call's blocks are counted done below; the L2 of this XCD is not the reader's (see chain_gather_kernel in chain.hip)
-        unsigned long long *dst = reinterpret_cast<unsigned long long *>(&T8[(tb.grp + g) * 64 + lane]);
-        __hip_atomic_store(dst, (unsigned long long)o.x | (unsigned long long)o.y << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(dst + 1, (unsigned long long)o.z | (unsigned long long)o.w << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        T8[(tb.grp + g) * 64 + lane] = o;
     }
-    if (__ballot(bad != 0) && lane == 0) __hip_atomic_store(&bail[c], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // a byte does not hold this call after all: the other kernels take it
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");       // this wave's stores have completed (at the device's coherence point) ...
-    __syncthreads();                                             // ... and so have the other waves', before the block is counted
-    if (threadIdx.x == 0) __hip_atomic_fetch_add(&geo_done[c], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (FC && __ballot(bad != 0) && lane == 0) bail[c] = 1u;      // a byte does not hold this call after all: the other kernels take it
 }
 
 // ---- 6. the fold ---------------------------------------------------------------------------------------------------------------
@@ -336,16 +327,18 @@ __global__ __launch_bounds__(256) void ctab_geo(const ChainWork *__restrict__ wo
 // memory (3.4 us per block, 3.2 ms for one 60 000-anchor call; the table is complete before this kernel starts, so reading
 // ahead is free of any ordering concern).
 #ifndef GAB_TAB_W
-#define GAB_TAB_W 6
+#define GAB_TAB_W 12
 #endif
-constexpr int kTabW = GAB_TAB_W;          // worker waves (-DGAB_TAB_W=..: tuning builds)
+constexpr int kTabW = GAB_TAB_W;          // worker waves (-DGAB_TAB_W=..: tuning builds): four close the block's own rows, the others take the far groups and the previous block's rows
+constexpr int kTabFW = kTabW - 4;         // ... the far workers
+static_assert(kTabFW >= 2, "the table form needs at least two far workers");
 constexpr int kTabF = 4;                  // far groups per worker held in registers (deeper windows: loaded when needed)
 constexpr int kTabRing = 8192;            // scores (minus bias) of the newest anchors: the deepest window is 5000 + 2 blocks + padding
-constexpr long kTabSpinLimit = 1500000;   // x ~1.3 us of s_sleep
 #ifndef GAB_TAB_MAX_RESCANS
 #define GAB_TAB_MAX_RESCANS 64
 #endif
 constexpr int kTabMaxRescans = GAB_TAB_MAX_RESCANS;
+constexpr int kTabMaxPatch = 8;            // anchors of a call whose result max_skip really changed (see the resolver)
 #ifndef GAB_KO_CERT_FAR          // timing experiments (wrong results for calls whose certificate misses)
 #define GAB_KO_CERT_FAR 0
 #endif
@@ -358,10 +351,12 @@ constexpr int kTabMaxRescans = GAB_TAB_MAX_RESCANS;
 struct TabLds {
     int4 G4[2][2][16][64];                // [slot][previous block | block itself][row / 4][anchor]: keys of 4 rows
     int32_t ring[kTabRing + 16];          // (+ the first 16 entries again: sixteen consecutive scores never wrap)
-    int32_t part_best[2][kTabW][64], part_g[2][kTabW][64];
+    int32_t part_best[2][kTabFW][64], part_g[2][kTabFW][64];
     int32_t res_key[3][64], res_fg[3][64];
     uint16_t okh[4][8][64];               // chain: one bit per unfiltered near / in-block pair, 16 rows per unit
-    int32_t stop[2];
+    int32_t stop[2];                      // 1: the call goes back to chain.hip; 2: start again from block restart_blk (a new patch)
+    int32_t restart_blk, patch_n;
+    int32_t patch_blk[kTabMaxPatch], patch_lane[kTabMaxPatch], patch_score[kTabMaxPatch], patch_parent[kTabMaxPatch];
 };
 __device__ __forceinline__ uint32_t gab_tab_xcc_id() { return (uint32_t)__builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xfu; }   // HW_REG_XCC_ID
 __device__ __forceinline__ int ctab_nonzero_bytes(uint32_t w) {
@@ -372,34 +367,16 @@ template <int MODE>
 __global__ __launch_bounds__(64 * (2 + kTabW))
 void ctab_fold(const ChainWork *__restrict__ work, const TabCall *__restrict__ calls, const TabBlock *__restrict__ blocks, uint32_t *bail,
                const uint4 *__restrict__ T8, const int32_t *__restrict__ st_all, const uint64_t *__restrict__ xs, const uint64_t *__restrict__ ys,
-               int32_t *score_out, int32_t *parent_out, int32_t *gmarks_all, unsigned long long *evals_out, const uint32_t *geo_done,
+               int32_t *score_out, int32_t *parent_out, int32_t *gmarks_all, unsigned long long *evals_out,
                TabCounters *ct, unsigned long long *dbg) {
     constexpr bool FC = MODE == GAB_FASTCHAIN;
-    constexpr int NW = kTabW;
+    constexpr int NF = kTabFW;
     extern __shared__ __attribute__((aligned(16))) uint8_t tab_lds_raw[];
     TabLds &L = *reinterpret_cast<TabLds *>(tab_lds_raw);
     const int c = blockIdx.x;
     const ChainWork w = work[c];
     const TabCall tc = calls[c];
-    // This kernel runs beside ctab_geo (launched before it, on another stream): wait until every block of the call has been
-    // counted done.  The geometry's workgroups never wait for anything and fit on a CU beside a waiting workgroup of this kernel
-    // (4 waves, 8 KB of LDS), so the count always arrives; the wait still gives up after ~2 s -- the call is then handed back.
-    if (dbg && threadIdx.x == 0) dbg[32 + 3 * (size_t)c] = wall_clock64() << 4 | gab_tab_xcc_id();
-    if (threadIdx.x == 0) {
-        int ok = 1;
-        if (tc.ok) {
-            long spins = 0;
-            while (__hip_atomic_load(&geo_done[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (uint32_t)tc.nblk) {
-                if (++spins > kTabSpinLimit) { __hip_atomic_store(&bail[c], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); ok = 0; break; }
-                __builtin_amdgcn_s_sleep(127);
-            }
-        }
-        L.stop[0] = (ok && __hip_atomic_load(&bail[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) ? 0 : 1;
-    }
-    __syncthreads();
-    if (L.stop[0]) return;
-    __syncthreads();
-    if (dbg && threadIdx.x == 0) dbg[32 + 3 * (size_t)c + 1] = wall_clock64();
+    if (bail[c]) return;
     const TabBlock *B = blocks + tc.blk0;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint64_t *X = xs + w.off, *Y = ys + w.off;
@@ -408,6 +385,7 @@ void ctab_fold(const ChainWork *__restrict__ work, const TabCall *__restrict__ c
     int32_t *GM = FC ? nullptr : gmarks_all + w.off;
     const int n = (int)w.n, nblocks = tc.nblk, bias = tc.bias;
     if (threadIdx.x < 2) L.stop[threadIdx.x] = 0;
+    if (threadIdx.x == 0) { L.patch_n = 0; L.restart_blk = 0; }
 #if defined(GAB_TAB_PRIO_ALL)
     __builtin_amdgcn_s_setprio(3);
 #elif defined(GAB_TAB_PRIO)
@@ -426,26 +404,34 @@ void ctab_fold(const ChainWork *__restrict__ work, const TabCall *__restrict__ c
     struct Desc { long long grp; int jrow0, ng; };
     auto desc_of = [&](int kb) { Desc d{0, 0, 0}; if (kb < nblocks) { const TabBlock tb = B[kb]; d.grp = tb.grp; d.jrow0 = tb.jrow0; d.ng = tb.ng; } return d; };
     const int wk = wave - 2;
+    int min_blk = 0;                                         // blocks below this one are final (a restart does not touch them)
+    // a patched anchor: max_skip cut the reference's scan of it short of the plain maximum -- its score and parent are what the
+    // reference's own scan gave (chain_exact_global), nothing is folded into it, and what it passes on is that score
+    auto patched = [&](int blk) { bool pl = false; for (int q = 0; q < L.patch_n; q++) pl |= L.patch_blk[q] == blk && L.patch_lane[q] == lane; return pl; };
     // (requested ONE block ahead.  Two blocks ahead -- a second set of registers rotated every phase, 184 VGPRs instead of 128 --
     // was measured slower everywhere: one call 2.42 -> 2.92 ms, 256 calls 6.8 -> 8.1 ms)
     Desc d_cur = desc_of(0), d_nxt = desc_of(1);
     uint4 pg[2] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)}, pf[kTabF];
 #pragma unroll
     for (int q = 0; q < kTabF; q++) pf[q] = make_uint4(0, 0, 0, 0);
+    // worker wk < 4 closes rows 16 wk .. of the block itself (unit 4 + wk); the others (far worker fw = wk - 4) share the previous
+    // block's four units and the far groups
+    const int fw = wk - 4;
+    auto unit_of = [&](int q) { return wk < 4 ? (q == 0 ? 4 + wk : 8) : (fw + NF * q < 4 ? fw + NF * q : 8); };
     auto prefetch = [&](const Desc &d, int kb) {            // the bytes of block kb for this worker
         const int nfar = d.ng - (kb > 0 ? 8 : 4);
         const uint4 *T = T8 + d.grp * 64 + lane;
 #pragma unroll
         for (int q = 0; q < 2; q++) {
-            const int u = wk + NW * q;
+            const int u = unit_of(q);
             pg[q] = make_uint4(0, 0, 0, 0);
             if (u < 8 && !(u < 4 && kb == 0)) pg[q] = T[(size_t)(nfar + (kb > 0 ? u : u - 4)) * 64];
         }
 #pragma unroll
         for (int q = 0; q < kTabF; q++) {
-            const int fgi = wk + NW * q;
+            const int fgi = fw + NF * q;
             pf[q] = make_uint4(0, 0, 0, 0);
-            if (fgi < nfar) pf[q] = T[(size_t)fgi * 64];
+            if (fw >= 0 && fgi < nfar) pf[q] = T[(size_t)fgi * 64];
         }
     };
     if (wave >= 2 && nblocks > 0) prefetch(d_cur, 0);
@@ -460,7 +446,7 @@ void ctab_fold(const ChainWork *__restrict__ work, const TabCall *__restrict__ c
         const int par = (t + 1) & 1;                         // slot of block t + 1 in the two-deep arrays; block t lives in par ^ 1
         const unsigned long long t_in = dbg ? clock64() : 0;
         if (wave == 0) {
-            if (t >= 0 && t < nblocks) {
+            if (t >= min_blk && t < nblocks) {
                 // ------------------------------------------------ main wave: block t
                 const int i0 = t * 64;
                 const int nb = n - i0 < 64 ? n - i0 : 64;
@@ -470,7 +456,7 @@ void ctab_fold(const ChainWork *__restrict__ work, const TabCall *__restrict__ c
                 // the workers' far maxima: groups interleave, so the larger group (= the newer predecessors) wins a tie
                 int32_t fbest = kTabNegH, fg = -1;
 #pragma unroll
-                for (int hh = 0; hh < NW; hh++) {
+                for (int hh = 0; hh < NF; hh++) {
                     const int32_t b2 = L.part_best[par ^ 1][hh][lane], g2 = L.part_g[par ^ 1][hh][lane];
                     if (b2 > fbest || (b2 == fbest && g2 > fg)) { fbest = b2; fg = g2; }
                 }
@@ -489,34 +475,17 @@ void ctab_fold(const ChainWork *__restrict__ work, const TabCall *__restrict__ c
                         key = max(key, g.w + __builtin_amdgcn_readlane(pkey, 4 * g4 + 3));
                     }
                 }
-#ifndef GAB_TAB_NOSPLIT
-                // the block itself: anchor b is final once 0 .. b - 1 are folded.  The only true chain of the kernel; it runs on
-                // the score shifted past the code bits, sc7 = score << 7: readlane, add, max.  The key (which predecessor) rides
-                // beside it, off the chain: a filtered entry is INT_MIN, so its sum stays far below every key.
-                int32_t sc7 = key & ~127;
+                if (!FC && L.patch_n)
+                    for (int q = 0; q < L.patch_n; q++) if (L.patch_blk[q] == t && L.patch_lane[q] == lane) key = L.patch_score[q] << 7;
+                // the block itself, in units of four anchors closed by the workers (see there): the kernel's only chain of dependent
+                // steps is four readlanes (the unit's scores before the unit), four adds, two three-way maxima -- per FOUR anchors
 #pragma unroll
                 for (int g4 = 0; g4 < 16; g4++) {
                     const int4 g = gb[(size_t)g4 * 64];
-                    const int32_t gv[4] = {g.x, g.y, g.z, g.w};
-#pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        if (4 * g4 + k < 63) {
-                            const int32_t sb7 = __builtin_amdgcn_readlane(sc7, 4 * g4 + k);
-                            sc7 = max(sc7, (gv[k] & ~127) + sb7);        // (the mask does not wait for anything)
-                            key = max(key, gv[k] + sb7);                 // (score << 7) + (G << 7 | code)
-                        }
-                    }
+                    const int32_t x0 = __builtin_amdgcn_readlane(key, 4 * g4) & ~127, x1 = __builtin_amdgcn_readlane(key, 4 * g4 + 1) & ~127,
+                                  x2 = __builtin_amdgcn_readlane(key, 4 * g4 + 2) & ~127, x3 = __builtin_amdgcn_readlane(key, 4 * g4 + 3) & ~127;
+                    key = max(max(key, g.x + x0), max(g.y + x1, max(g.z + x2, g.w + x3)));
                 }
-#else
-#pragma unroll
-                for (int g4 = 0; g4 < 16; g4++) {            // the block itself: anchor b is final once 0 .. b - 1 are folded
-                    const int4 g = gb[(size_t)g4 * 64];
-                    key = max(key, g.x + (__builtin_amdgcn_readlane(key, 4 * g4) & ~127));
-                    key = max(key, g.y + (__builtin_amdgcn_readlane(key, 4 * g4 + 1) & ~127));
-                    key = max(key, g.z + (__builtin_amdgcn_readlane(key, 4 * g4 + 2) & ~127));
-                    if (g4 < 15) key = max(key, g.w + (__builtin_amdgcn_readlane(key, 4 * g4 + 3) & ~127));
-                }
-#endif
                 const int32_t best = key >> 7;
                 if (mine) {
                     S[i0 + lane] = best;
@@ -533,7 +502,7 @@ void ctab_fold(const ChainWork *__restrict__ work, const TabCall *__restrict__ c
 #ifdef GAB_KO_TAB_RES
             if (false) {
 #else
-            if (t >= 2) {
+            if (t - 2 >= min_blk) {
 #endif
                 const int r = t - 2;
                 const int i0 = r * 64;
@@ -547,7 +516,8 @@ void ctab_fold(const ChainWork *__restrict__ work, const TabCall *__restrict__ c
                 int32_t parent = -1;
                 if (!none && code >= 65) parent = i0 + code - 65;
                 else if (!none && code >= 1) parent = i0 - 64 + code - 1;
-                const bool far = mine && !none && code == 0;
+                const bool pl = !FC && L.patch_n && patched(r);
+                const bool far = mine && !none && code == 0 && !pl;
                 if (mine) evals += (unsigned long long)(i0 + lane - r_st);
                 int32_t risk = 0;
                 if (__ballot(far)) {
@@ -598,9 +568,10 @@ void ctab_fold(const ChainWork *__restrict__ work, const TabCall *__restrict__ c
                         risk += __popc(bits & m);
                     }
                 }
+                if (pl) for (int q = 0; q < L.patch_n; q++) if (L.patch_blk[q] == r && L.patch_lane[q] == lane) parent = L.patch_parent[q];
                 if (mine) P[i0 + lane] = parent;
                 if (!FC && !GAB_KO_CERT_NEAR) {
-                    unsigned long long miss = __ballot(mine && !none && risk > kMaxSkip);
+                    unsigned long long miss = __ballot(mine && !none && !pl && risk > kMaxSkip);
                     if (miss) {
                         // max_skip may have cut these anchors' scans short (the certificate of chain_hw_kernel does not hold): the
                         // reference's own scan decides, anchor by anchor in order, on the scores and parents stored so far.  It
@@ -621,14 +592,23 @@ void ctab_fold(const ChainWork *__restrict__ work, const TabCall *__restrict__ c
                             chain_exact_global(X, Y, S, P, GM, i0 + b, __builtin_amdgcn_readlane(r_st, b), w.max_dist_x, w.max_dist_y, w.bw, w.n_segs > 1,
                                                (double)w.avg_qspan, eb, ej, evals_exact);
                             if (eb != __builtin_amdgcn_readlane(best, b) || ej != __builtin_amdgcn_readlane(parent, b)) {
-                                if (lane == 0) { L.stop[t & 1] = 1; __hip_atomic_store(&bail[c], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+                                // max_skip did change this anchor's result, and younger anchors have used the other score: the anchor is
+                                // PATCHED (score and parent of the reference's scan; nothing is folded into it any more) and the call starts
+                                // again from this block -- everything before it is final.  More than kTabMaxPatch such anchors: chain.hip.
+                                if (lane == 0) {
+                                    const int pn = L.patch_n;
+                                    if (pn < kTabMaxPatch) {
+                                        L.patch_blk[pn] = r; L.patch_lane[pn] = b; L.patch_score[pn] = eb; L.patch_parent[pn] = ej;
+                                        L.patch_n = pn + 1; L.restart_blk = r; L.stop[t & 1] = 2;
+                                    } else { L.stop[t & 1] = 1; __hip_atomic_store(&bail[c], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+                                }
                                 break;
                             }
                         }
                     }
                 }
             }
-            if (t >= 1 && t - 1 < nblocks) {
+            if (t - 1 >= min_blk && t - 1 < nblocks) {
                 // request what block t - 1 needs: its descriptor, the far lanes' group, the window starts
                 const int r = t - 1;
                 const TabBlock tb = B[r];
@@ -654,14 +634,15 @@ void ctab_fold(const ChainWork *__restrict__ work, const TabCall *__restrict__ c
             // the keys of the 128 near / in-block rows: unit u = 16 rows; 0 .. 3 the previous block, 4 .. 7 the block itself
 #pragma unroll
             for (int q = 0; q < 2; q++) {
-                const int u = wk + NW * q;
+                const int u = unit_of(q);
 #ifdef GAB_KO_TAB_G
                 if (false) {
 #else
                 if (u < 8) {
 #endif
                     const bool nearu = u < 4;
-                    const uint32_t wd[4] = {cg[q].x, cg[q].y, cg[q].z, cg[q].w};
+                    const bool pl = !FC && L.patch_n && patched(kb);       // nothing is folded into a patched anchor
+                    const uint32_t wd[4] = {pl ? 0u : cg[q].x, pl ? 0u : cg[q].y, pl ? 0u : cg[q].z, pl ? 0u : cg[q].w};
                     uint32_t bits = 0;
                     int4 *dst = &L.G4[par][nearu ? 0 : 1][(u & 3) * 4][lane];
 #pragma unroll
@@ -672,8 +653,27 @@ void ctab_fold(const ChainWork *__restrict__ work, const TabCall *__restrict__ c
                             const int p = (u & 3) * 16 + 4 * q4 + k;
                             const int32_t bb = (int32_t)(wd[q4] >> (8 * k) & 0xffu);
                             const int code = nearu ? p + 1 : 65 + p;
-                            gv[k] = bb ? (int32_t)(((uint32_t)(bb - bias) << 7) | (uint32_t)code) : kTabNone;
+                            gv[k] = bb ? (int32_t)(((uint32_t)(bb - bias) << 7) | (uint32_t)code) : (nearu ? kTabNone : kTabSoftNone);
                             bits |= bb ? (1u << (4 * q4 + k)) : 0u;
+                        }
+                        if (!nearu) {
+                            // The block's own rows in units of four, CLOSED over the unit: W_k[a] = the best way from row p_k to anchor a
+                            // through later rows of the unit, as a key of a's direct predecessor (the code rides along; the hops inside
+                            // the unit add their score-only part).  None of this involves a score, so it is done here, ahead of time, and
+                            // the main wave's chain of dependent steps is one step per FOUR anchors: with x_k the scores of the unit's four
+                            // anchors before the unit, every anchor a takes max_k (x_k + W_k[a]) -- for a inside the unit too (rows not
+                            // older than a are filtered).  A filtered entry is kTabSoftNone here (sums of four stay in range and below
+                            // every real value) and INT_MIN in the table.
+                            const int pl = (u & 3) * 16 + 4 * q4;                      // lane of the unit's first anchor
+                            const int32_t s01 = __builtin_amdgcn_readlane(gv[0], pl + 1) & ~127, s02 = __builtin_amdgcn_readlane(gv[0], pl + 2) & ~127,
+                                          s03 = __builtin_amdgcn_readlane(gv[0], pl + 3) & ~127, s12 = __builtin_amdgcn_readlane(gv[1], pl + 2) & ~127,
+                                          s13 = __builtin_amdgcn_readlane(gv[1], pl + 3) & ~127, s23 = __builtin_amdgcn_readlane(gv[2], pl + 3) & ~127;
+                            const int32_t w3 = gv[3];
+                            const int32_t w2 = max(gv[2], s23 + w3);
+                            const int32_t w1 = max(max(gv[1], s12 + w2), s13 + w3);
+                            const int32_t w0 = max(max(gv[0], s01 + w1), max(s02 + w2, s03 + w3));
+                            gv[0] = w0 < kTabSoftLim ? kTabNone : w0; gv[1] = w1 < kTabSoftLim ? kTabNone : w1;
+                            gv[2] = w2 < kTabSoftLim ? kTabNone : w2; gv[3] = w3 < kTabSoftLim ? kTabNone : w3;
                         }
                         dst[(size_t)q4 * 64] = make_int4(gv[0], gv[1], gv[2], gv[3]);
                     }
@@ -703,14 +703,30 @@ void ctab_fold(const ChainWork *__restrict__ work, const TabCall *__restrict__ c
             };
 #ifndef GAB_KO_TAB_FAR
 #pragma unroll
-            for (int q = 0; q < kTabF; q++) { const int fgi = wk + NW * q; if (fgi < nfar) far_group(cf[q], fgi); }
-            for (int fgi = wk + NW * kTabF; fgi < nfar; fgi += NW) far_group(T8[(d.grp + fgi) * 64 + lane], fgi);      // deep windows
+            for (int q = 0; q < kTabF; q++) { const int fgi = fw + NF * q; if (fw >= 0 && fgi < nfar) far_group(cf[q], fgi); }
+            if (fw >= 0) for (int fgi = fw + NF * kTabF; fgi < nfar; fgi += NF) far_group(T8[(d.grp + fgi) * 64 + lane], fgi);      // deep windows
 #endif
-            L.part_best[par][wk][lane] = best; L.part_g[par][wk][lane] = bg;
+            if (fw >= 0) { L.part_best[par][fw][lane] = best; L.part_g[par][fw][lane] = bg; }
         }
         if (dbg) busy += clock64() - t_in;
         __syncthreads();
-        if (L.stop[t & 1]) { stopped = true; break; }
+        const int st_code = L.stop[t & 1];
+        if (st_code == 1) { stopped = true; break; }
+        if (st_code == 2) {
+            // start again from block R with the new patch: every wave brings its own state to "block R comes next"
+            const int R = L.restart_blk;
+            __syncthreads();                                 // (everybody has read the two words)
+            if (threadIdx.x == 0) L.stop[t & 1] = 0;
+            min_blk = R;
+            if (wave == 0) {
+                pbest = R > 0 ? L.ring[(R * 64 - 64 + lane) & (kTabRing - 1)] + bias : 0;
+                qs_next = R * 64 + lane < n ? (int32_t)(Y[R * 64 + lane] >> 32 & 0xff) : 0;
+            } else if (wave >= 2) {
+                d_cur = desc_of(R); d_nxt = desc_of(R + 1);
+                prefetch(d_cur, R);
+            }
+            t = R - 2;                                       // (the loop makes it R - 1: the workers take block R, the main wave follows)
+        }
     }
     if (dbg && c == 0 && lane == 0) { dbg[2 * wave] = busy; dbg[2 * wave + 1] = clock64() - t_all; }
     if (dbg && threadIdx.x == 0) dbg[32 + 3 * (size_t)c + 2] = wall_clock64();
@@ -796,8 +812,8 @@ int chain_tab_run(ChainTab *t, int mode, hipStream_t s, const ChainWork *d_work,
         any_mseg = any_mseg || h_work[k].n_segs > 1;
     }
     auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
-    const size_t o_bail = up(sizeof(TabCall) * nsplit), o_ct = o_bail + up(4 * nsplit), o_done = o_ct + 512;
-    if ((rc = t->calls.reserve(o_done + 4 * nsplit + 256)) != GAB_OK) return rc;
+    const size_t o_bail = up(sizeof(TabCall) * nsplit), o_ct = o_bail + up(4 * nsplit);
+    if ((rc = t->calls.reserve(o_ct + 512)) != GAB_OK) return rc;
     if ((rc = t->blocks.reserve(sizeof(TabBlock) * (size_t)nblocks + 256)) != GAB_OK) return rc;
     if ((rc = t->gtab.reserve(4 * (size_t)gt + 256)) != GAB_OK) return rc;
     if ((rc = t->st.reserve(4 * (size_t)total_anchors + 256)) != GAB_OK) return rc;
@@ -824,8 +840,7 @@ int chain_tab_run(ChainTab *t, int mode, hipStream_t s, const ChainWork *d_work,
     uint4 *d_T8 = t->table.as<uint4>();
     *d_bail = bail;
     GAB_HIP(hipMemcpyAsync(d_calls, hc.data(), sizeof(TabCall) * nsplit, hipMemcpyHostToDevice, s));      // (pageable: staged before the call returns)
-    uint32_t *d_done = (uint32_t *)(cb + o_done);                         // per call: blocks whose geometry is in the table
-    GAB_HIP(hipMemsetAsync(d_ct, 0, 512 + 4 * nsplit, s));
+    GAB_HIP(hipMemsetAsync(d_ct, 0, 512, s));
     unsigned long long *d_dbg = nullptr;       // GAB_CHAIN_TRACE: per-wave cycle counts of call 0's fold, then start / ready / end of every call's workgroup
     if (getenv("GAB_CHAIN_TRACE")) {
         if ((rc = t->dbg.reserve(8 * (32 + 3 * nsplit))) != GAB_OK) return rc;
@@ -841,35 +856,29 @@ int chain_tab_run(ChainTab *t, int mode, hipStream_t s, const ChainWork *d_work,
     else hipLaunchKernelGGL(ctab_st<GAB_FASTCHAIN>, dim3(g4), dim3(256), 0, s, d_work, d_calls, d_blocks, nblocks, d_x, d_st);
     hipLaunchKernelGGL(ctab_place, dim3(1), dim3(1024), 0, s, d_calls, bail, (int)nsplit, budget_groups, d_ct);
     hipLaunchKernelGGL(ctab_block_offsets, dim3(nc), dim3(256), 0, s, (const TabCall *)d_calls, (const uint32_t *)bail, d_blocks);
-    // Geometry (VALU-bound, any CU) and fold (one workgroup per call, bound by the latency of its chain of blocks) run BESIDE each
-    // other: the geometry on `s`, the fold on a second stream behind everything that precedes the geometry, and a call's workgroup
-    // waits (in the kernel) until the call's blocks are counted done -- the longest calls come first in both, so their folds, the
-    // critical path, start after microseconds instead of after the whole geometry.  The geometry is launched FIRST: should the two
-    // streams share a hardware queue, the kernels simply run one after the other.
-    bool beside = !getenv("GAB_CHAIN_TAB_SERIAL");
-    if (beside && !t->s2) {
-        if (hipStreamCreateWithFlags(&t->s2, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&t->ev[0], hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&t->ev[1], hipEventDisableTiming) != hipSuccess) { gab_set_error("gab_chain: stream / event creation failed"); return GAB_EDEVICE; }
-    }
+    // Geometry, then fold, on one stream.  Measured and dropped (r04): the fold BESIDE the geometry -- a second stream, the
+    // geometry's stores written through, a call's workgroup waiting in the kernel until its blocks were counted done.  The folds
+    // of the longest calls did start after microseconds, and the two kernels together took as long as one after the other (chain
+    // shard 0/8: 5.98 against 6.01 ms): a wave of the geometry sharing a SIMD with a fold's main wave stretches every step of its
+    // chain of dependent instructions (s_setprio changes nothing: the pipeline is not pre-empted), and the written-through
+    // stores cost the geometry a third of its speed.  Four chunks on four streams (events): the streams share hardware queues.
     hipStream_t sf = s;
-    if (beside) { GAB_HIP(hipEventRecord(t->ev[0], s)); GAB_HIP(hipStreamWaitEvent(t->s2, t->ev[0], 0)); sf = t->s2; }
     const unsigned nbk = (unsigned)nblocks;
     if (mode == GAB_FASTCHAIN)
         hipLaunchKernelGGL((ctab_geo<GAB_FASTCHAIN, false>), dim3(nbk), dim3(256), 0, s, d_work, (const TabCall *)d_calls, (const TabBlock *)d_blocks, bail,
-                           (const int32_t *)d_gtab, (const int32_t *)d_st, d_x, d_y, d_T8, d_done);
+                           (const int32_t *)d_gtab, (const int32_t *)d_st, d_x, d_y, d_T8);
     else if (any_mseg)
         hipLaunchKernelGGL((ctab_geo<GAB_CHAIN, true>), dim3(nbk), dim3(256), 0, s, d_work, (const TabCall *)d_calls, (const TabBlock *)d_blocks, bail,
-                           (const int32_t *)d_gtab, (const int32_t *)d_st, d_x, d_y, d_T8, d_done);
+                           (const int32_t *)d_gtab, (const int32_t *)d_st, d_x, d_y, d_T8);
     else
         hipLaunchKernelGGL((ctab_geo<GAB_CHAIN, false>), dim3(nbk), dim3(256), 0, s, d_work, (const TabCall *)d_calls, (const TabBlock *)d_blocks, bail,
-                           (const int32_t *)d_gtab, (const int32_t *)d_st, d_x, d_y, d_T8, d_done);
+                           (const int32_t *)d_gtab, (const int32_t *)d_st, d_x, d_y, d_T8);
     if (mode == GAB_CHAIN)
         hipLaunchKernelGGL(ctab_fold<GAB_CHAIN>, dim3(nc), dim3(64 * (2 + kTabW)), sizeof(TabLds), sf, d_work, (const TabCall *)d_calls, (const TabBlock *)d_blocks, bail,
-                           (const uint4 *)d_T8, (const int32_t *)d_st, d_x, d_y, d_score, d_parent, d_gm, d_evals, (const uint32_t *)d_done, d_ct, d_dbg);
+                           (const uint4 *)d_T8, (const int32_t *)d_st, d_x, d_y, d_score, d_parent, d_gm, d_evals, d_ct, d_dbg);
     else
         hipLaunchKernelGGL(ctab_fold<GAB_FASTCHAIN>, dim3(nc), dim3(64 * (2 + kTabW)), sizeof(TabLds), sf, d_work, (const TabCall *)d_calls, (const TabBlock *)d_blocks, bail,
-                           (const uint4 *)d_T8, (const int32_t *)d_st, d_x, d_y, d_score, d_parent, d_gm, d_evals, (const uint32_t *)d_done, d_ct, d_dbg);
-    if (beside) { GAB_HIP(hipEventRecord(t->ev[1], t->s2)); GAB_HIP(hipStreamWaitEvent(s, t->ev[1], 0)); }
+                           (const uint4 *)d_T8, (const int32_t *)d_st, d_x, d_y, d_score, d_parent, d_gm, d_evals, d_ct, d_dbg);
     GAB_HIP(hipGetLastError());
     return GAB_OK;
 }

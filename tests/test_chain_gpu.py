@@ -58,6 +58,33 @@ def test_vs_oracle(eng, mode, seed, ncalls, gmode, nmin, nmax):
     assert ev_gpu == ev if mode == 1 else ev <= ev_gpu <= 2 * sum(min(i, 5000) for n in batch.hdr["n"] for i in range(int(n)))
 
 
+def test_table_form_patches_and_hands_back(eng, monkeypatch, capfd, kernel_choice):
+    """chain, table form: an anchor whose max_skip certificate misses is scanned again the reference's way (chain_exact_global); when
+    that really gives another result the anchor is PATCHED and the call starts again from its block (seed 31 holds such a call:
+    anchor 1881 of a 3306-anchor call takes a predecessor 49 back instead of the plain maximum's); a call with more than eight such
+    anchors (the dense golden set, where chain and fast-chain differ in hundreds of lines) goes back to the kernels of chain.hip"""
+    if kernel_choice != "table-form-for-all":
+        pytest.skip("table form only")
+    monkeypatch.setenv("GAB_CHAIN_TRACE", "1")
+    batch = gabgen.chain(31, 200, 0, 50, 20000)
+    ws, wp = pyoracle.chain(batch, 0)
+    capfd.readouterr()
+    s, p = eng.host_chain_kernel(batch, 0)
+    err = capfd.readouterr().err
+    np.testing.assert_array_equal(s, ws)
+    np.testing.assert_array_equal(p, wp)
+    line = [l for l in err.splitlines() if "eligible" in l][-1]
+    assert " 0 handed back" in line and "exact re-scans" in line and int(line.split(";")[1].split()[0]) >= 1, line
+    dense = gabgen.read_chain_text(f"{GOLDEN}/chain_dense.in.txt")
+    ws, wp = read_chain_output(f"{GOLDEN}/chain_dense.chain.expected.txt")
+    s, p = eng.host_chain_kernel(dense, 0)
+    err = capfd.readouterr().err
+    np.testing.assert_array_equal(s, ws)
+    np.testing.assert_array_equal(p, wp)
+    line = [l for l in err.splitlines() if "eligible" in l][-1]
+    assert int(line.split("eligible,")[1].split()[0]) >= 1, line          # handed back: too many patches
+
+
 def test_walk_kernel_variant(eng, monkeypatch):
     """GAB_CHAIN_KERNEL=walk: the per-anchor walk kernel kept for A/B runs gives the reference's result too"""
     monkeypatch.setenv("GAB_CHAIN_KERNEL", "walk")
