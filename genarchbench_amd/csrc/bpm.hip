@@ -541,21 +541,27 @@ __device__ __forceinline__ uint64_t bpm_win_take(const uint64_t (&X)[W], int r0)
     return s ? (lo >> s) | (hi << (64 - s)) : lo;
 }
 template <int W>
-__global__ __launch_bounds__(kBlock) void bpm_win(BpmIO io, const uint32_t *__restrict__ list, uint32_t nslots,
+__global__ __launch_bounds__(kBlock) void bpm_win(BpmIO io, const uint32_t *__restrict__ list, const uint32_t *__restrict__ nslots_ptr,
                                                   ulonglong2 *__restrict__ hist, int per_slot,
                                                   int32_t *__restrict__ score_out, uint32_t *__restrict__ miss_list,
                                                   BpmCounters *ct) {
     __shared__ uint64_t peq_s[(4 * W + 1) * kBlock];
-    const uint32_t s = blockIdx.x * kBlock + threadIdx.x;
-    int64_t miss_id = -1;
+    // The number of listed pairs is read HERE (the list was filled by the band kernels in front of this launch: no host round
+    // trip to size the grid, r04); the grid is sized for the history room, every thread owns one history slot and takes
+    // list entries slot, slot + threads, ...
+    const uint32_t nslots = *nslots_ptr;
+    const uint32_t slot = blockIdx.x * kBlock + threadIdx.x;
     unsigned long long steps = 0;
+  for (uint32_t sbase = blockIdx.x * kBlock; sbase < nslots; sbase += gridDim.x * kBlock) {
+    const uint32_t s = sbase + threadIdx.x;
+    int64_t miss_id = -1;
     if (s < nslots) {
         const uint32_t id = list[s];
         const int n = io.pat_len[id], m = io.txt_len[id];
         const char *p = io.pat + io.pat_off[id], *t = io.txt + io.txt_off[id];
         uint64_t *peq = peq_s + threadIdx.x;
         bpm_build_peq<W>(peq, p, n);
-        ulonglong2 *H = hist + (int64_t)s * per_slot;           // record of column c: {Pv window, Mv window}
+        ulonglong2 *H = hist + (int64_t)slot * per_slot;        // record of column c: {Pv window, Mv window}
         const int cshift = (n - m) / 2;
         const uint64_t top_mask = (n & 63) ? 1ull << ((n & 63) - 1) : 1ull << 63;
         uint64_t P[W], M[W];
@@ -572,7 +578,7 @@ __global__ __launch_bounds__(kBlock) void bpm_win(BpmIO io, const uint32_t *__re
             const int r0 = bpm_win_start<W>(h + 1, cshift);
             H[h + 1] = make_ulonglong2(bpm_win_take<W>(P, r0), bpm_win_take<W>(M, r0));
         }
-        steps = (unsigned long long)m * W;
+        steps += (unsigned long long)m * W;
         // backtrace (edit_bpm.c:289-313) on the windows
         int ops = 0, v = n - 1, h = m - 1;
         bool miss = false;
@@ -596,6 +602,7 @@ __global__ __launch_bounds__(kBlock) void bpm_win(BpmIO io, const uint32_t *__re
             if (miss_id >= 0) miss_list[base + (uint32_t)__popcll(q & ((1ull << (threadIdx.x & 63)) - 1))] = (uint32_t)miss_id;
         }
     }
+  }
     for (int o = 32; o > 0; o >>= 1) steps += __shfl_xor(steps, o);
     if ((threadIdx.x & 63) == 0 && steps) atomicAdd(&ct->full_steps, steps);
 }
@@ -608,12 +615,15 @@ __global__ __launch_bounds__(kBlock) void bpm_win(BpmIO io, const uint32_t *__re
 //           stays inside its own few KB instead of striding across the whole scratch); masks in LDS.
 // REGW == 0: any W (<= 255), base = slot_base[s]; the 4W+1 masks sit in front of the history.
 template <int REGW>
-__global__ __launch_bounds__(kBlock) void bpm_full(BpmIO io, const uint32_t *__restrict__ list, uint32_t nslots,
+__global__ __launch_bounds__(kBlock) void bpm_full(BpmIO io, const uint32_t *__restrict__ list, uint32_t nslots_arg, const uint32_t *__restrict__ nslots_ptr,
                                                    uint64_t *__restrict__ hist, const int64_t *__restrict__ slot_base,
                                                    int32_t *__restrict__ score_out, BpmCounters *ct) {
     __shared__ uint64_t peq_s[(REGW ? 4 * REGW + 1 : 1) * kBlock];
-    const uint32_t s = blockIdx.x * kBlock + threadIdx.x;
-    if (s >= nslots) return;          // (no wave-level operation below needs the exited lanes)
+    // nslots_ptr (REGW > 0): the list's length is read here, the grid is sized for the history room and a thread takes the
+    // entries slot, slot + threads, ... with ITS history slot (see bpm_win)
+    const uint32_t nslots = nslots_ptr ? *nslots_ptr : nslots_arg;
+    const uint32_t slot = blockIdx.x * kBlock + threadIdx.x;
+  for (uint32_t s = slot; s < nslots; s += gridDim.x * kBlock) {
     const uint32_t id = list[s];
     const int n = io.pat_len[id], m = io.txt_len[id];
     const char *p = io.pat + io.pat_off[id], *t = io.txt + io.txt_off[id];
@@ -624,7 +634,7 @@ __global__ __launch_bounds__(kBlock) void bpm_full(BpmIO io, const uint32_t *__r
     int64_t pstride;
     bool dummy = true;
     if (REGW) {
-        H = hist + (int64_t)s * ((64 * REGW + 1) * REGW * 2);
+        H = hist + (int64_t)slot * ((64 * REGW + 1) * REGW * 2);
         peq = peq_s + threadIdx.x; pstride = kBlock;
         bpm_build_peq<(REGW ? REGW : 1)>(peq, p, n);
     } else {
@@ -683,6 +693,7 @@ __global__ __launch_bounds__(kBlock) void bpm_full(BpmIO io, const uint32_t *__r
     }
 #undef HP
 #undef HM
+  }
 }
 
 }  // namespace
@@ -796,7 +807,7 @@ static int launch_slice(hipStream_t s, hipStream_t sb, hipEvent_t scored, const 
 template <int W>
 static void launch_full(hipStream_t s, const BpmIO &io, const uint32_t *list, uint32_t nslots, uint64_t *hist,
                         const int64_t *slot_base, int32_t *score, BpmCounters *ct) {
-    hipLaunchKernelGGL(bpm_full<W>, dim3((nslots + kBlock - 1) / kBlock), dim3(kBlock), 0, s, io, list, nslots, hist,
+    hipLaunchKernelGGL(bpm_full<W>, dim3((nslots + kBlock - 1) / kBlock), dim3(kBlock), 0, s, io, list, nslots, (const uint32_t *)nullptr, hist,
                        slot_base, score, ct);
 }
 
@@ -863,7 +874,9 @@ extern "C" int gab_bpm_run_device(gab_bpm *h, const char *pat, int64_t pat_bytes
         if (!ccount[W]) continue;
         // slices of ~600 k pairs (10 M pairs: sixteen): a launch of fewer pairs no longer fills the chip -- an eighth of bpm-large
         // (one rank's share on 8 GPUs) cut into sixteen slices of 78 k pairs took 2.66 ms where 10 M take 5.4 (r03)
-        int nsl = (int)std::min<uint32_t>(kSlices, std::max<uint32_t>(1, ccount[W] / 600000));
+        // (r04: below ~2.4 M pairs ONE slice -- every band launch has a ~0.12 ms tail of its own that the next slice's score kernel
+        // does not hide at that size: 1.25 M pairs 1.12 -> 1.04 ms, 100 k pairs 0.39 ms with two slices against 0.27 with one)
+        int nsl = ccount[W] < 2400000 ? 1 : (int)std::min<uint32_t>(kSlices, ccount[W] / 600000);
         if (const char *e = getenv("GAB_BPM_SLICES")) nsl = std::max(1, std::min(kSlices, atoi(e)));        // tuning runs
         const uint32_t per = ((ccount[W] + nsl - 1) / nsl + kBlock - 1) / kBlock * kBlock;
         const int cols = h->h_ct->max_tlen[W] + 1;
@@ -885,65 +898,50 @@ extern "C" int gab_bpm_run_device(gab_bpm *h, const char *pat, int64_t pat_bytes
     GAB_HIP(hipStreamWaitEvent(s, h->join, 0));
     GAB_HIP(hipEventRecord(h->ev[2], s));
 
-    int64_t nfull = 0;
     {
-        GAB_HIP(hipGetLastError());
-        GAB_HIP(hipMemcpyAsync(h->h_ct, d_ct, sizeof(BpmCounters), hipMemcpyDeviceToHost, s));
-        GAB_HIP(hipStreamSynchronize(s));
-        for (int W = 1; W <= kMaxRegW; W++)
-            for (int k = 0; k < kSlices; k++) nfull += h->h_ct->wl_slice[W][k];
-        // stage 1: 64-row window in global memory for the pairs that left the band
-        uint32_t wcnt[kMaxRegW + 1];
-        for (int W = 1; W <= kMaxRegW; W++) wcnt[W] = h->h_ct->wl1_count[W];
+        // stage 1: 64-row window in global memory for the pairs that left the band; stage 2: complete columns for the pairs that
+        // left the window.  r04: both are launched without asking the device how many pairs they got (that was two host round
+        // trips per call -- 0.1 of the 0.29 ms of a 100 000-pair batch): a launch is sized for the history room the handle has and
+        // reads the length of its list itself; its threads take list entries in strides (bpm_win / bpm_full).
         for (int W = 1; W <= kMaxRegW; W++) {
-            const uint32_t cnt = wcnt[W];
-            if (!cnt) continue;
+            if (!ccount[W]) continue;
             const int per_slot = 64 * W + 1;                       // columns 0 .. tlen <= 64 W, 16 bytes each
             const size_t bytes_slot = (size_t)per_slot * 16;
-            uint32_t batch = (uint32_t)std::max<size_t>(kBlock, std::min<size_t>(cnt, h->scratch_budget / bytes_slot));
-            rc = h->scratch.reserve(bytes_slot * batch);
+            uint32_t slots = (uint32_t)std::max<size_t>(kBlock, std::min<size_t>({(size_t)ccount[W], h->scratch_budget / bytes_slot, (size_t)1 << 16}));
+            slots = (slots + kBlock - 1) / kBlock * kBlock;
+            rc = h->scratch.reserve(bytes_slot * slots);
             if (rc) return rc;
-            for (uint32_t b0 = 0; b0 < cnt; b0 += batch) {
-                const uint32_t nb = std::min(batch, cnt - b0);
-                const uint32_t *list = d_wl1 + cstart[W] + b0;
-                ulonglong2 *hist = h->scratch.as<ulonglong2>();
-                const dim3 g((nb + kBlock - 1) / kBlock), blk(kBlock);
-                switch (W) {
-                    case 1: hipLaunchKernelGGL(bpm_win<1>, g, blk, 0, s, io, list, nb, hist, per_slot, score_out, d_wl2 + cstart[W], d_ct); break;
-                    case 2: hipLaunchKernelGGL(bpm_win<2>, g, blk, 0, s, io, list, nb, hist, per_slot, score_out, d_wl2 + cstart[W], d_ct); break;
-                    case 3: hipLaunchKernelGGL(bpm_win<3>, g, blk, 0, s, io, list, nb, hist, per_slot, score_out, d_wl2 + cstart[W], d_ct); break;
-                    default: hipLaunchKernelGGL(bpm_win<4>, g, blk, 0, s, io, list, nb, hist, per_slot, score_out, d_wl2 + cstart[W], d_ct); break;
-                }
+            const uint32_t *list = d_wl1 + cstart[W];
+            ulonglong2 *hist = h->scratch.as<ulonglong2>();
+            const dim3 g(slots / kBlock), blk(kBlock);
+            switch (W) {
+                case 1: hipLaunchKernelGGL(bpm_win<1>, g, blk, 0, s, io, list, (const uint32_t *)&d_ct->wl1_count[1], hist, per_slot, score_out, d_wl2 + cstart[W], d_ct); break;
+                case 2: hipLaunchKernelGGL(bpm_win<2>, g, blk, 0, s, io, list, (const uint32_t *)&d_ct->wl1_count[2], hist, per_slot, score_out, d_wl2 + cstart[W], d_ct); break;
+                case 3: hipLaunchKernelGGL(bpm_win<3>, g, blk, 0, s, io, list, (const uint32_t *)&d_ct->wl1_count[3], hist, per_slot, score_out, d_wl2 + cstart[W], d_ct); break;
+                default: hipLaunchKernelGGL(bpm_win<4>, g, blk, 0, s, io, list, (const uint32_t *)&d_ct->wl1_count[4], hist, per_slot, score_out, d_wl2 + cstart[W], d_ct); break;
+            }
+        }
+        for (int W = 1; W <= kMaxRegW; W++) {
+            if (!ccount[W]) continue;
+            const size_t per_slot = (size_t)(64 * W + 1) * W * 16;
+            uint32_t slots = (uint32_t)std::max<size_t>(kBlock, std::min<size_t>({(size_t)ccount[W], h->scratch_budget / per_slot, (size_t)1 << 14}));
+            slots = (slots + kBlock - 1) / kBlock * kBlock;
+            rc = h->scratch.reserve(per_slot * slots);
+            if (rc) return rc;
+            const uint32_t *list = d_wl2 + cstart[W];
+            uint64_t *hist = h->scratch.as<uint64_t>();
+            const dim3 g(slots / kBlock), blk(kBlock);
+            switch (W) {
+                case 1: hipLaunchKernelGGL(bpm_full<1>, g, blk, 0, s, io, list, 0u, (const uint32_t *)&d_ct->wl2_count[1], hist, (const int64_t *)nullptr, score_out, d_ct); break;
+                case 2: hipLaunchKernelGGL(bpm_full<2>, g, blk, 0, s, io, list, 0u, (const uint32_t *)&d_ct->wl2_count[2], hist, (const int64_t *)nullptr, score_out, d_ct); break;
+                case 3: hipLaunchKernelGGL(bpm_full<3>, g, blk, 0, s, io, list, 0u, (const uint32_t *)&d_ct->wl2_count[3], hist, (const int64_t *)nullptr, score_out, d_ct); break;
+                default: hipLaunchKernelGGL(bpm_full<4>, g, blk, 0, s, io, list, 0u, (const uint32_t *)&d_ct->wl2_count[4], hist, (const int64_t *)nullptr, score_out, d_ct); break;
             }
         }
         GAB_HIP(hipGetLastError());
-        GAB_HIP(hipMemcpyAsync(h->h_ct, d_ct, sizeof(BpmCounters), hipMemcpyDeviceToHost, s));
-        GAB_HIP(hipStreamSynchronize(s));
-        for (int W = 1; W <= kMaxRegW; W++) {
-            const uint32_t cnt = h->h_ct->wl2_count[W];
-            if (!cnt) continue;
-            const size_t per_slot = (size_t)(64 * W + 1) * W * 16;
-            uint32_t batch = (uint32_t)std::max<size_t>(kBlock, std::min<size_t>(cnt, h->scratch_budget / per_slot));
-            batch = (batch + kBlock - 1) / kBlock * kBlock;
-            if (batch > cnt) batch = cnt;
-            rc = h->scratch.reserve(per_slot * batch);
-            if (rc) return rc;
-            for (uint32_t b0 = 0; b0 < cnt; b0 += batch) {
-                const uint32_t nb = std::min(batch, cnt - b0);
-                const uint32_t *list = d_wl2 + cstart[W] + b0;
-                uint64_t *hist = h->scratch.as<uint64_t>();
-                switch (W) {
-                    case 1: launch_full<1>(s, io, list, nb, hist, nullptr, score_out, d_ct); break;
-                    case 2: launch_full<2>(s, io, list, nb, hist, nullptr, score_out, d_ct); break;
-                    case 3: launch_full<3>(s, io, list, nb, hist, nullptr, score_out, d_ct); break;
-                    default: launch_full<4>(s, io, list, nb, hist, nullptr, score_out, d_ct); break;
-                }
-            }
-        }
         // W > 4: every pair takes the generic full path with per-slot extents
         const uint32_t cnt0 = ccount[0];
         if (cnt0) {
-            nfull += cnt0;
             std::vector<int32_t> pl(cnt0), tl(cnt0);
             // lengths of those pairs: gathered on the device into one buffer, one copy back (a long-read input puts EVERY
             // pair here; two 4-byte copies per pair were minutes of host latency at 10 M pairs)
@@ -982,7 +980,7 @@ extern "C" int gab_bpm_run_device(gab_bpm *h, const char *pat, int64_t pat_bytes
     GAB_HIP(hipGetLastError());
     GAB_HIP(hipMemcpyAsync(h->h_ct, d_ct, sizeof(BpmCounters), hipMemcpyDeviceToHost, s));
     GAB_HIP(hipEventRecord(h->ev[3], s));
-    h->last_full = nfull;
+    h->last_full = (int64_t)ccount[0];      // (+ the pairs the band kernels queued: added from the counters in gab_bpm_last_stats)
     h->have_stats = true;
     return GAB_OK;
 }
@@ -1066,7 +1064,12 @@ extern "C" int gab_bpm_last_stats(gab_bpm *h, int64_t *block_steps, int64_t *ful
     gab_device_guard g(h->device);
     GAB_HIP(hipEventSynchronize(h->ev[3]));
     if (block_steps) *block_steps = (int64_t)(h->h_ct->steps + h->h_ct->full_steps);
-    if (full_pairs) *full_pairs = h->last_full;
+    if (full_pairs) {
+        int64_t nfull = h->last_full;
+        for (int W = 1; W <= kMaxRegW; W++)
+            for (int k = 0; k < kSlices; k++) nfull += h->h_ct->wl_slice[W][k];
+        *full_pairs = nfull;
+    }
     if (score_kernel_ms) GAB_HIP(hipEventElapsedTime(score_kernel_ms, h->ev[1], h->ev[2]));
     if (total_ms) GAB_HIP(hipEventElapsedTime(total_ms, h->ev[0], h->ev[3]));
     return GAB_OK;

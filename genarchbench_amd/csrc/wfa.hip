@@ -805,10 +805,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(7, 7))) void
 
 // ---- global kernel: int32 history in a scratch slab, any length ------------------------------
 template <bool ADAPT>
-__global__ __launch_bounds__(64) void wfa_global(WfaIO io, WfaPen pen, const uint32_t *__restrict__ list, uint32_t count,
-                                                 int32_t *scratch, int64_t per_block, int dir_cap, int pool_cap,
+__global__ __launch_bounds__(64) void wfa_global(WfaIO io, WfaPen pen, const uint32_t *__restrict__ list, uint32_t count_arg,
+                                                 const uint32_t *__restrict__ count_ptr, int32_t *scratch, int64_t per_block, int dir_cap, int pool_cap,
                                                  uint32_t *over_list, WfaCounters *ct) {
     const int lane = threadIdx.x;
+    const uint32_t count = count_ptr ? *count_ptr : count_arg;      // count_ptr: what the last LDS tier left, read here (no host round trip)
     int32_t *mine = scratch + (int64_t)blockIdx.x * per_block;
     for (uint32_t b = blockIdx.x; b < count; b += gridDim.x) {
         const uint32_t id = list ? list[b] : b;
@@ -1170,12 +1171,31 @@ extern "C" int gab_wfa_run_device(gab_wfa *h, const char *pat, int64_t pat_bytes
         if (!ev2) { GAB_HIP(hipEventRecord(h->ev[2], s)); ev2 = true; }
         after_launch();
     }
+    // r04: what the last LDS tier leaves (almost never anything) goes to the global-history kernel WITHOUT asking the device how
+    // many pairs that is: one launch of a few workgroups that reads the count itself, with the history room the handle already
+    // has; the host looks at the counters once, at the end of the call, and only continues (a bigger pool) for pairs that
+    // overflowed even that.  One round trip of ~40 us less per call.
+    bool first_global_done = false;
+    if (tier && cnt) {
+        const int64_t pool_cap0 = 1 << 20, dir_cap0 = 4096;
+        const int64_t per_block0 = dir_cap0 * (h->adaptive ? 7 : 5) + pool_cap0;
+        int blocks0 = 16;
+        if (const int64_t fit = (int64_t)(h->scratch.cap / ((size_t)per_block0 * 4)); fit >= 1) blocks0 = (int)std::min<int64_t>(64, fit);
+        else if ((rc = h->scratch.reserve((size_t)per_block0 * 4 * blocks0)) != GAB_OK) return rc;
+        GAB_HIP(hipMemsetAsync(&d_ct->n_over, 0, 4, s));
+        hipLaunchKernelGGL(h->adaptive ? wfa_global<true> : wfa_global<false>, dim3(blocks0), dim3(64), 0, s, io, h->pen, cur, 0u, (const uint32_t *)&d_ct->tier_over[tier - 1],
+                           h->scratch.as<int32_t>(), per_block0, (int)dir_cap0, (int)pool_cap0, nxt, d_ct);
+        GAB_HIP(hipGetLastError());
+        first_global_done = true;
+    }
     if (tier) {
         hipLaunchKernelGGL(wfa_sum_work, dim3(1), dim3(kWorkSlots), 0, s, d_ct);
         GAB_HIP(hipMemcpyAsync(h->h_ct, d_ct, sizeof(WfaCounters), hipMemcpyDeviceToHost, s));
+        if (!ev2) { GAB_HIP(hipEventRecord(h->ev[2], s)); ev2 = true; }
         GAB_HIP(hipStreamSynchronize(s));
         for (int k = 0; k < tier; k++) requeued += h->h_ct->tier_over[k];
-        cnt = h->h_ct->tier_over[tier - 1];
+        cnt = first_global_done ? h->h_ct->n_over : h->h_ct->tier_over[tier - 1];
+        if (first_global_done) { requeued += cnt; std::swap(cur, nxt); }      // (what overflowed the first global pass sits in nxt)
     }
     if (!ev2) GAB_HIP(hipEventRecord(h->ev[2], s));
     // pass 3+: global history; first the LDS leftovers, then the long pairs; pool grows on overflow
@@ -1185,6 +1205,7 @@ extern "C" int gab_wfa_run_device(gab_wfa *h, const char *pat, int64_t pat_bytes
         uint32_t c = which == 0 ? cnt : n_big;
         int64_t pool_cap = 1 << 20;                       // int32 elements per block
         int64_t dir_cap = 4096;
+        if (which == 0 && first_global_done) { pool_cap *= 8; dir_cap *= 4; }      // (the first size has been tried)
         while (c) {
             int64_t per_block = dir_cap * (h->adaptive ? 7 : 5) + pool_cap;
             int blocks = (int)std::min<int64_t>(c, std::max<int64_t>(1, (int64_t)(h->scratch_budget / 4) / per_block));
@@ -1199,7 +1220,7 @@ extern "C" int gab_wfa_run_device(gab_wfa *h, const char *pat, int64_t pat_bytes
             rc = h->scratch.reserve((size_t)per_block * 4 * blocks);
             if (rc) return rc;
             GAB_HIP(hipMemsetAsync(&d_ct->n_over, 0, 4, s));
-            hipLaunchKernelGGL(h->adaptive ? wfa_global<true> : wfa_global<false>, dim3(blocks), dim3(64), 0, s, io, h->pen, list, c, h->scratch.as<int32_t>(),
+            hipLaunchKernelGGL(h->adaptive ? wfa_global<true> : wfa_global<false>, dim3(blocks), dim3(64), 0, s, io, h->pen, list, c, (const uint32_t *)nullptr, h->scratch.as<int32_t>(),
                                per_block, (int)dir_cap, (int)pool_cap, spill, d_ct);
             GAB_HIP(hipGetLastError());
             hipLaunchKernelGGL(wfa_sum_work, dim3(1), dim3(kWorkSlots), 0, s, d_ct);
@@ -1213,7 +1234,7 @@ extern "C" int gab_wfa_run_device(gab_wfa *h, const char *pat, int64_t pat_bytes
         }
     }
     GAB_HIP(hipEventRecord(h->ev[3], s));
-    GAB_HIP(hipStreamSynchronize(s));
+    if (!tier || n_big) GAB_HIP(hipStreamSynchronize(s));      // (with LDS tiers and no long pairs the counters have been read after the last kernel)
     h->last_requeued = requeued;
     h->have_stats = true;
     return GAB_OK;
