@@ -32,12 +32,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-ROUND = "r03"           # prefix of this round's evidence under profiles/
+ROUND = "r04"           # prefix of this round's evidence under profiles/
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
 # HBM traffic of the dominant kernel(s) of a workload's LARGE configuration, measured once per round with rocprofv3 PMC
-# counters in separate passes (tools/profiling/hbm_traffic.sh -> profiles/r01_hbm_traffic.json); `double_fetch`: the
+# counters in separate passes (tools/profiling/hbm_traffic.sh -> profiles/<ROUND>_hbm_traffic.json); `double_fetch`: the
 # kernel reads wide coalesced streams, for which gfx950's FETCH_SIZE reports half the bytes (MI355X_MICROARCH.md, HBM)
 TRAFFIC_KERNELS = {"bsw": (["bsw_dp8"], False), "chain": (["chain_block_kernel", "chain_facts_kernel"], False), "fast-chain": (["fastchain_kernel"], False),
                    "bpm": (["bpm_score32<", "bpm_score<"], False), "bitpal": (["bitpal_dp<true, true>"], False), "bitpal-edit": (["bitpal_edit_bv<"], False), "wfa": (["wfa_lds_static<16, false>"], False), "fmi": (["fmi_seed_kernel<true>"], False),
@@ -222,7 +222,7 @@ class BswWorkload:
                 "dominant_kernel_timing": "HIP events around the DP launches of a step: one bsw_dp8 launch per query-length class, "
                                           "two in flight at a time (two streams), so rocprofv3's per-launch durations overlap; the matching "
                                           "figure is the first-start-to-last-end span (tools/profiling/kernel_span.py on "
-                                          "profiles/r02_bsw_large_kernel_trace.csv)",
+                                          f"profiles/{ROUND}_bsw_large_kernel_trace.csv)",
                 # the bound that matters: integer VALU issue.  19.9 lane-instructions per DP cell is the PMC figure of the
                 # end of r02 (SQ_INSTS_VALU x 64 / cells, profiles/r02_kernel_bounds.md).  Peak: MEASURED, profiles/r02_valu_issue.md
                 # (tools/microbench/valu_issue.hip): the packed 16-bit, v_perm_b32, v_and_or_b32, v_lshl_or_b32, v_max3 and
@@ -233,7 +233,7 @@ class BswWorkload:
                 # instruction on average = 45 T lane-instr/s for this mix at this occupancy (LDS-capped).
                 "valu": {"lane_instr_per_cell": 19.9, "achieved_T_lane_instr_per_s":
                          round(19.9 * self.cells / (k * 1e9), 2) if k else None, "peak_T_lane_instr_per_s": 45.0,
-                         "peak_source": "profiles/r02_valu_issue.md (measured issue cost of the kernel's instruction classes at 2 waves "
+                         "peak_source": "measured in round 2, profiles/r02_valu_issue.md (issue cost of the kernel's instruction classes at 2 waves "
                                         "per SIMD, weighted by the loop's mix: 33 x 4.22 + 29 x 2.6 cycles per 62 instructions)",
                          "frac": round(19.9 * self.cells / (k * 1e9) / 45.0, 3) if k else None,
                          "frac_if_every_instruction_cost_4_cycles": round(19.9 * self.cells / (k * 1e9) / 39.3, 3) if k else None}}
@@ -1351,8 +1351,11 @@ def run_workload(W, items, steps, warmup, ctx, args, with_cpu=True, with_host=Tr
             "data": "synthetic (seeded generator tools/gen, SURVEY.md 8d distributions)",
             "config": {"workload": f"{W.name}-large" if large else f"{W.name}-{items}",
                        "total_items": total, "items_per_gpu": round(total / world, 1), "sharding": sharding,
-                       "value_is": "value_hbm_resident (inputs already in HBM when the timed region starts; the drop-in ROI "
-                                   "incl. PCIe is extra.value_roi_incl_pcie)"},
+                       # (the task's measurement rule: `value` = throughput with the inputs resident in HBM; the PCIe-inclusive
+                       # rate is reported beside it and is what the comparison with the CPU baseline uses)
+                       "value_is": "hbm_resident: inputs already in HBM when the timed region starts.  The drop-in ROI of SURVEY.md 8(d) -- "
+                                   "host pointers in and out, PCIe both ways -- is extra.value_roi_incl_pcie, and extra.x_cpu_baseline compares "
+                                   "THAT with the CPU baseline (whose ROI includes its marshalling); extra.x_cpu_baseline_hbm_resident is the kernel-only ratio"},
             "roofline": wl.roofline(), "extra": wl.extra(ms), "parity": verdict,
         }
         out["extra"]["value_hbm_resident"] = out["value"]
@@ -1380,14 +1383,30 @@ def run_workload(W, items, steps, warmup, ctx, args, with_cpu=True, with_host=Tr
             out["cpu_baseline"] = wl.cpu_baseline(host_cores())
             out["cpu_baseline"]["host_threads_visible"] = os.cpu_count()      # `cores` of these were used (cgroup quota)
             mark("cpu baseline done")
-            cb, v = out["cpu_baseline"], out["value"]
-            if cb.get("value"):
-                out["extra"]["x_cpu_baseline"] = round(v / world / cb["value"], 2)      # one GPU vs the host's cores
-                if out["extra"].get("value_roi_incl_pcie"):
-                    out["extra"]["x_cpu_baseline_roi_incl_pcie"] = round(out["extra"]["value_roi_incl_pcie"] / cb["value"], 2)
+            finish_cpu_ratios(out, world, os.cpu_count())
     del wl
     torch.cuda.empty_cache()
     return out
+
+
+def finish_cpu_ratios(out, world, host_threads):
+    """per-core figure, the quota in words, and the ratios GPU / CPU: like for like -- the CPU figure is the reference's
+    ROI, marshalling included, so the GPU figure beside it is the drop-in ROI including PCIe; the HBM-resident ratio is kept under
+    its own name"""
+    cb, v = out["cpu_baseline"], out["value"]
+    if not cb or not cb.get("value"):
+        return
+    cores = max(int(cb.get("cores") or 1), 1)
+    cb["per_core"] = round(cb["value"] / cores, 4)
+    if cores < (host_threads or cores):
+        cb["sample"] = f"{cores}-core cgroup quota of a {host_threads}-thread host; " + str(cb.get("sample", ""))
+    out["extra"]["x_cpu_baseline_hbm_resident"] = round(v / world / cb["value"], 2)
+    if out["extra"].get("value_roi_incl_pcie"):
+        out["extra"]["x_cpu_baseline"] = round(out["extra"]["value_roi_incl_pcie"] / cb["value"], 2)
+        out["extra"]["x_cpu_baseline_is"] = "value_roi_incl_pcie / cpu_baseline.value (one GPU incl. PCIe vs the reference on the host's cores)"
+        out["extra"]["cpu_cores_equivalent"] = round(out["extra"]["value_roi_incl_pcie"] / cb["per_core"], 1)
+    else:
+        out["extra"]["x_cpu_baseline"] = None      # no host-pointer ROI measured in this run: no like-for-like figure
 
 
 # ---- output: one compact headline as the LAST line of stdout, one line per suite entry before it ------------------------
@@ -1406,17 +1425,19 @@ def compact(r, note_chars=160):
     keep["data"] = "synthetic"
     cfg = r.get("config") or {}
     keep["config"] = {"workload": cfg.get("workload"), "total_items": cfg.get("total_items"), "items_per_gpu": cfg.get("items_per_gpu"),
-                      "sharding": _cut(cfg.get("sharding", ""), 150), "value_is": "value_hbm_resident"}
+                      "sharding": _cut(cfg.get("sharding", ""), 150), "value_is": "hbm_resident"}
     rf = r.get("roofline") or {}
     keep["roofline"] = {k: rf.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")}
     cb = r.get("cpu_baseline")
     keep["cpu_baseline"] = None if not cb else {"value": cb.get("value"), "unit": cb.get("unit"), "cores": cb.get("cores"),
-                                                "host_threads_visible": cb.get("host_threads_visible"), "kind": cb.get("kind"),
+                                                "per_core": cb.get("per_core"), "host_threads_visible": cb.get("host_threads_visible"), "kind": cb.get("kind"),
                                                 "sample": _cut(cb.get("sample", ""), note_chars)}
     keep["parity"] = _cut(r.get("parity"), 120) if r.get("parity") is not None else None
     ex = r.get("extra") or {}
     keep["extra"] = {k: ex[k] for k in ("dominant_kernel", "dominant_kernel_ms", "value_hbm_resident", "value_roi_incl_pcie",
-                                        "x_cpu_baseline", "x_cpu_baseline_roi_incl_pcie", "gcups") if ex.get(k) is not None}
+                                        "x_cpu_baseline", "x_cpu_baseline_hbm_resident", "cpu_cores_equivalent", "gcups") if ex.get(k) is not None}
+    if "x_cpu_baseline" in keep["extra"]:
+        keep["extra"]["x_cpu_baseline_is"] = "roi_incl_pcie / cpu_baseline"
     if isinstance(keep["extra"].get("dominant_kernel"), str):
         keep["extra"]["dominant_kernel"] = _cut(keep["extra"]["dominant_kernel"], 60)
     if isinstance(keep["extra"].get("dominant_kernel_ms"), float):
@@ -1437,7 +1458,7 @@ def headline(out, suite):
             else:
                 rows[name] = _cut(r.get("skipped") or r.get("error") or "?", 60)
         h["extra"]["suite"] = rows
-        h["extra"]["suite_columns"] = ["value_hbm_resident", "unit", "roofline.frac", "value_roi_incl_pcie", "x_cpu_baseline"]
+        h["extra"]["suite_columns"] = ["value_hbm_resident", "unit", "roofline.frac", "value_roi_incl_pcie", "x_cpu_baseline (roi_incl_pcie / cpu)"]
         h["extra"]["suite_detail"] = "bench_suite.json + the {\"suite\": ...} lines above"
     line = json.dumps(h, separators=(",", ":"))
     if len(line) >= HEADLINE_LIMIT:                      # never again an unparseable record: shed the optional parts

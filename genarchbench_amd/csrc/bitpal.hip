@@ -47,6 +47,7 @@ struct BpCounters {
     uint32_t cursors[2];                    // bitpal_scatter
     unsigned long long cells;
 };
+GAB_STATIC_ATOMIC64(BpCounters, cells);
 
 struct BpScore { int32_t match, mismatch, gap; };
 

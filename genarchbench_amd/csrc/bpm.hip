@@ -59,6 +59,7 @@ struct BpmCounters {        // device-side, zeroed per run
     unsigned long long steps;   // block steps executed by bpm_score (m * W summed)
     unsigned long long full_steps;
 };
+GAB_STATIC_ATOMIC64(BpmCounters, steps); GAB_STATIC_ATOMIC64(BpmCounters, full_steps);
 
 __device__ __forceinline__ int bpm_class(int n) {
     const int W = (n + 63) >> 6;

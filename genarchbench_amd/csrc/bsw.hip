@@ -51,6 +51,7 @@ struct BswStats {          // device-side, zeroed per run
     int32_t first_bad;     // smallest failing index + 1
     int32_t pad;
 };
+GAB_STATIC_ATOMIC64(BswStats, cells);
 
 struct BswIO {
     const uint8_t *ref; const int64_t *ref_off;

@@ -46,6 +46,7 @@ struct ChainFeed {
     int32_t *host_score, *host_parent;        // device addresses of the caller's result arrays
     uint32_t *abort;                          // set by a wait that gave up; every other wait then gives up too
     unsigned long long *dbg;                  // diagnosis (GAB_CHAIN_TRACE): per work item wall-clock ticks at start / ready / done
+    long spin_limit;                          // spins of a wait before it gives up (kFeedSpinLimit; tests: a few thousand)
 };
 struct ChainChunk { int64_t hoff, doff; int32_t n, item; };   // up to kFeedChunk anchors of work item `item`: where they are, where they go
 constexpr int kFeedChunk = 2048;
@@ -61,7 +62,7 @@ __device__ __forceinline__ uint32_t chain_feed_wait(const ChainFeed &feed, uint3
             if (f) break;
             // (over a thousand workgroups wait at a time: a look at the ONE abort word per spin is a billion requests per second
             // on one address, and a spin per microsecond is more than the anchors' arrival needs)
-            if (spins > kFeedSpinLimit || ((spins & 63) == 63 && __hip_atomic_load(feed.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+            if (spins > feed.spin_limit || ((spins & 63) == 63 && __hip_atomic_load(feed.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
                 __hip_atomic_store(feed.abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 break;
             }
@@ -87,7 +88,7 @@ __global__ __launch_bounds__(256) void chain_gather_kernel(const ChainChunk *__r
                                                            const ChainWork *__restrict__ work, const uint32_t *__restrict__ need,
                                                            uint32_t *done, unsigned long long *xlo, unsigned long long *xhi,
                                                            uint32_t *mixed, uint32_t *facts, volatile uint8_t *started, int gap_tab_max,
-                                                           uint32_t *next_chunk, unsigned long long *pub_dbg) {
+                                                           uint32_t *next_chunk, unsigned long long *pub_dbg, uint32_t never_publish) {
     __shared__ unsigned long long s_lo[4], s_hi[4];
     __shared__ uint32_t s_mx[4];
     __shared__ uint32_t s_chunk;
@@ -144,7 +145,8 @@ __global__ __launch_bounds__(256) void chain_gather_kernel(const ChainChunk *__r
                 const int32_t mq = w.max_dist_y < w.max_dist_x ? w.max_dist_y : w.max_dist_x;
                 const unsigned long long lim = mq < 0 ? 0ull : (unsigned long long)mq;
                 const bool plain = w.n > 0 && !M && H - L + lim < 0x7fffffffull && w.bw >= 0 && w.bw <= gap_tab_max;   // = chain_facts_kernel
-                __hip_atomic_store(&facts[ch.item], 2u | (plain ? 1u : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // (never_publish: GAB_CHAIN_FEED_GIVEUP, a test hook -- one call's word stays 0, so that its workgroup's wait gives up)
+                if ((uint32_t)ch.item != never_publish) __hip_atomic_store(&facts[ch.item], 2u | (plain ? 1u : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (pub_dbg) pub_dbg[ch.item] = wall_clock64();
             }
         }
@@ -1846,7 +1848,7 @@ static int chain_helpers_for(int64_t total_anchors, int64_t longest_call) {
 // the kernels of one work list (already on the device) on `s`; nothing else (no memset, no synchronisation)
 static void chain_launch(int mode, int helpers, hipStream_t s, ChainWork *d_work, unsigned nw, const uint64_t *d_x, const uint64_t *d_y,
                          int32_t *d_score, int32_t *d_parent, int32_t *d_gm, unsigned long long *d_ev, const ChainFeed *feed_in = nullptr) {
-    const ChainFeed feed = feed_in ? *feed_in : ChainFeed{nullptr, nullptr, nullptr, nullptr, nullptr};
+    const ChainFeed feed = feed_in ? *feed_in : ChainFeed{nullptr, nullptr, nullptr, nullptr, nullptr, kFeedSpinLimit};
     if (nw == 0) return;
     if (mode == GAB_FASTCHAIN) {
         if (feed.facts) hipLaunchKernelGGL((fastchain_kernel<kFcHelpers, true>), dim3(nw), dim3(64 * (1 + kFcHelpers)), 0, s, d_work, d_x, d_y, d_score, d_parent, d_ev, feed);
@@ -1926,6 +1928,7 @@ extern "C" int gab_chain_run_device(gab_chain *h, int mode, const uint64_t *d_x,
     rc = h->work.reserve(o_ev + 16);
     if (rc) return rc;
     if (nw == 0) return GAB_OK;
+    GAB_CHECK_ATOMIC64(o_ev);
     ChainWork *d_work = h->work.as<ChainWork>();
     unsigned long long *d_ev = (unsigned long long *)(h->work.as<char>() + o_ev);
     // pageable -> device copy of the small work list completes before the call returns to the
@@ -1973,7 +1976,7 @@ extern "C" int gab_chain_run_device(gab_chain *h, int mode, const uint64_t *d_x,
     }
     if (ntab || nfast) {
         if ((rc = chain_fast_setup(h)) != GAB_OK) return rc;
-        const ChainFeed nofeed{nullptr, nullptr, nullptr, nullptr, nullptr};
+        const ChainFeed nofeed{nullptr, nullptr, nullptr, nullptr, nullptr, kFeedSpinLimit};
         if (mode == GAB_CHAIN) hipLaunchKernelGGL(chain_facts_kernel, dim3((unsigned)nw), dim3(256), 0, s, d_work, d_x, d_y);
         GAB_HIP(hipEventRecord(h->fe[0], s));
         if (ntab) {
@@ -2179,7 +2182,14 @@ static int chain_fed_setup(gab_chain *h, int *gather_blocks) {
             uint32_t mg[8] = {};
             for (int b = b0; b < b0 + nb; b++) mg[b >> 5] |= 1u << (b & 31);
             if (hipExtStreamCreateWithCUMask(&h->gs, 8, mg) != hipSuccess) { (void)hipGetLastError(); h->gs = nullptr; }
-            else h->gs_blocks = std::min(256, 8 * nb);        // 2048 threads per CU
+            else {
+                // workgroups that are RESIDENT together on one of the mask's CUs: the DP is launched once all of them have reported
+                // in, so a count the CUs cannot hold at once would cost every call the 20 ms wait below (the compiler's
+                // register count decides, not the 2048 threads a CU can hold)
+                int per_cu = 0;
+                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, chain_gather_kernel, 256, 0) != hipSuccess || per_cu < 1) { (void)hipGetLastError(); per_cu = 1; }
+                h->gs_blocks = std::min(256, std::min(8, per_cu) * nb);
+            }
         }
     }
     if (h->gs) *gather_blocks = h->gs_blocks;
@@ -2233,6 +2243,7 @@ static int chain_run_fed(gab_chain *h, int mode, const uint64_t *x, const uint64
     auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
     const size_t o_ev = up(sizeof(ChainWork) * nw), o_facts = o_ev + 256, o_done = o_facts + up(4 * nw), o_need = o_done + up(4 * nw),
                  o_mixed = o_need + up(4 * nw), o_xlo = o_mixed + up(4 * nw), o_xhi = o_xlo + up(8 * nw), o_chunks = o_xhi + up(8 * nw);
+    GAB_CHECK_ATOMIC64(o_ev); GAB_CHECK_ATOMIC64(o_xlo); GAB_CHECK_ATOMIC64(o_xhi);      // the evals counter, atomicMin / atomicMax per call
     if ((rc = h->work.reserve(o_chunks + sizeof(ChainChunk) * chunks.size())) != GAB_OK) return rc;
     char *wb = h->work.as<char>();
     ChainWork *d_work = (ChainWork *)wb;
@@ -2244,6 +2255,10 @@ static int chain_run_fed(gab_chain *h, int mode, const uint64_t *x, const uint64
         d_gm = h->gmarks.as<int32_t>();
     }
     const bool trace = getenv("GAB_CHAIN_TRACE") != nullptr;
+    // GAB_CHAIN_FEED_GIVEUP=1 (test hook): the gather kernel never publishes the facts word of the first (longest)
+    // call and a wait gives up after ~20 ms instead of seconds -- the branch nobody runs otherwise: the waiting workgroup sets
+    // the abort word, every other wait follows, the grid drains and gab_chain_run re-runs the batch through the copy engines
+    const bool giveup_test = getenv("GAB_CHAIN_FEED_GIVEUP") != nullptr;
     hipEvent_t tv[4] = {};
     if (trace) for (auto &e : tv) (void)hipEventCreate(&e);
     // ---- gather stream
@@ -2265,7 +2280,8 @@ static int chain_run_fed(gab_chain *h, int mode, const uint64_t *x, const uint64
     hipLaunchKernelGGL(chain_gather_kernel, dim3(gather_blocks), dim3(256), 0, sG, (const ChainChunk *)(wb + o_chunks), (uint32_t)chunks.size(),
                        (const uint64_t *)hx, (const uint64_t *)hy, dx, dy, (const ChainWork *)d_work, (const uint32_t *)(wb + o_need),
                        (uint32_t *)(wb + o_done), (unsigned long long *)(wb + o_xlo), (unsigned long long *)(wb + o_xhi),
-                       (uint32_t *)(wb + o_mixed), (uint32_t *)(wb + o_facts), (volatile uint8_t *)d_started, kGapTab - 2, d_abort + 2, d_pub);
+                       (uint32_t *)(wb + o_mixed), (uint32_t *)(wb + o_facts), (volatile uint8_t *)d_started, kGapTab - 2, d_abort + 2, d_pub,
+                       giveup_test ? 0u : ~0u);
     GAB_HIP(hipGetLastError());
     if (trace) (void)hipEventRecord(tv[1], sG);
     // ---- wait until every gather workgroup is resident (they all start at once on an idle GPU: tens of microseconds);
@@ -2278,7 +2294,10 @@ static int chain_run_fed(gab_chain *h, int mode, const uint64_t *x, const uint64
             for (int k = 0; k < gather_blocks; k++) if (!((volatile uint8_t *)h->h_started)[k]) { all = false; break; }
             if (!all && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) break;     // (somebody else holds the gather's CUs)
         }
-        if (!all) GAB_HIP(hipStreamSynchronize(sG));
+        if (!all) {
+            if (trace) fprintf(stderr, "[gab_chain_run] fed: not every gather workgroup was resident after 20 ms (somebody else holds its CUs?); the gather runs to its end before the DP starts\n");
+            GAB_HIP(hipStreamSynchronize(sG));
+        }
     }
     if (getenv("GAB_CHAIN_FED_SERIAL")) GAB_HIP(hipStreamSynchronize(sG));        // experiments: the DP only after the last anchor
     // ---- the DP: one launch, its workgroups wait for their call
@@ -2286,7 +2305,8 @@ static int chain_run_fed(gab_chain *h, int mode, const uint64_t *x, const uint64
     const bool write_through = true;              // (measured: results by two copies at the end instead cost their 12 ms in full)
     unsigned long long *d_dbg = nullptr;
     if (trace && mode == GAB_CHAIN) { (void)hipMalloc((void **)&d_dbg, 24 * nw); (void)hipMemsetAsync(d_dbg, 0, 24 * nw, sA); }
-    ChainFeed feed{(uint32_t *)(wb + o_facts), write_through ? (int32_t *)hs : nullptr, write_through ? (int32_t *)hp : nullptr, d_abort, d_dbg};
+    ChainFeed feed{(uint32_t *)(wb + o_facts), write_through ? (int32_t *)hs : nullptr, write_through ? (int32_t *)hp : nullptr, d_abort, d_dbg,
+                   giveup_test ? 3000 : kFeedSpinLimit};
     if (trace) (void)hipEventRecord(tv[2], sA);
     chain_launch(mode, 3, sA, d_work, (unsigned)nw, dx, dy, ds, dp, d_gm, d_ev, &feed);
     GAB_HIP(hipGetLastError());
@@ -2410,7 +2430,7 @@ extern "C" int gab_chain_reserve(gab_chain *h, int64_t max_anchors, int64_t max_
         hipLaunchKernelGGL(chain_gather_kernel, dim3(blocks), dim3(256), 0, sG, (const ChainChunk *)nullptr, 0u, (const uint64_t *)nullptr,
                            (const uint64_t *)nullptr, (uint64_t *)nullptr, (uint64_t *)nullptr, (const ChainWork *)nullptr, (const uint32_t *)nullptr,
                            (uint32_t *)nullptr, (unsigned long long *)nullptr, (unsigned long long *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr,
-                           (volatile uint8_t *)d_started, 0, h->work.as<uint32_t>(), (unsigned long long *)nullptr);
+                           (volatile uint8_t *)d_started, 0, h->work.as<uint32_t>(), (unsigned long long *)nullptr, ~0u);
         GAB_HIP(hipGetLastError());
         GAB_HIP(hipStreamSynchronize(sG));
     }

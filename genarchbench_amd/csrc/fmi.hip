@@ -65,6 +65,8 @@ struct FmiCounters {
     unsigned long long wave_steps; // sum over waves of the steps of their longest-running lane (GAB_FMI_DEBUG)
     unsigned long long positions, spills, list_sum;   // seeding positions, those whose list outgrew LDS, sum of list lengths
 };
+GAB_STATIC_ATOMIC64(FmiCounters, ext_calls); GAB_STATIC_ATOMIC64(FmiCounters, rec_reads); GAB_STATIC_ATOMIC64(FmiCounters, tab_reads); GAB_STATIC_ATOMIC64(FmiCounters, total);
+GAB_STATIC_ATOMIC64(FmiCounters, wave_steps); GAB_STATIC_ATOMIC64(FmiCounters, positions); GAB_STATIC_ATOMIC64(FmiCounters, spills); GAB_STATIC_ATOMIC64(FmiCounters, list_sum);
 
 __device__ __forceinline__ void load_rec(const CpOcc *p, int64_t (&cnt)[4], uint64_t (&bits)[4]) {
     const ulonglong2 *q = reinterpret_cast<const ulonglong2 *>(p);

@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stddef.h>
 #include <mutex>
 #include "../../include/gab.h"
 
@@ -80,6 +81,12 @@ int gab_check_device(int device);
 bool gab_is_pinned(const void *p);      // hipHostMalloc'ed / registered host memory (direct DMA) or pageable
 
 static inline int64_t gab_ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// 64-bit device atomics need 8-byte-aligned addresses: an unaligned one faults (r03: the cursor of gab_wfa_run_packed sat behind
+// an odd number of 4-byte arrays and the process aborted).  Scratch layouts computed at run time pass the offsets of such
+// words through GAB_CHECK_ATOMIC64; counter structs state it for their members with GAB_STATIC_ATOMIC64.
+#define GAB_CHECK_ATOMIC64(off) GAB_CHECK((((size_t)(off)) & 7) == 0, "internal error: a 64-bit atomic at offset %zu of a scratch layout (not a multiple of 8)", (size_t)(off))
+#define GAB_STATIC_ATOMIC64(type, member) static_assert(offsetof(type, member) % 8 == 0 && alignof(type) >= 8, "64-bit atomics need 8-byte alignment: " #type "::" #member)
 
 // Wave-aggregated "slot = (*counter)++" for the lanes with `active` set: one atomic per wave instead of one per lane
 // (10 M lanes incrementing one address take milliseconds), and consecutive lanes get consecutive slots, so a list filled

@@ -60,6 +60,7 @@ struct WfaCounters {
     unsigned long long work;          // wavefront cells computed + bases extended
     uint32_t tier_over[8];            // pairs queued by LDS tier k = the count tier k + 1 reads ON THE DEVICE (no host round trip)
 };
+GAB_STATIC_ATOMIC64(WfaCounters, work);
 
 // One-byte offsets for the first LDS tier: value + 10 in a byte (null = -10 -> 0), good for offsets up to 245.  An offset
 // never exceeds tlen + (number of score steps taken): extension stops at the padding and every later step adds at most 1.
@@ -1357,6 +1358,7 @@ extern "C" int gab_wfa_run_packed(gab_wfa *h, const char *pat, const int64_t *pa
     const size_t o_sc = o; o += 4 * nn;
     o = (o + 255) & ~(size_t)255;                  // (a 64-bit atomic lives here)
     const size_t o_cur = o; o += 256;
+    GAB_CHECK_ATOMIC64(o_cur);                       // wfa_rle_pack's 64-bit cursor
     int rc = h->io.reserve(o);
     if (rc) return rc;
     char *b = h->io.as<char>();

@@ -44,9 +44,25 @@ def test_headline_is_small_complete_json():
     cb = d["cpu_baseline"]
     assert cb["kind"] in ("reference", "port") and cb["cores"] >= 1 and cb["value"] > 0 and cb["sample"] and cb["host_threads_visible"] == 256
     assert d["extra"]["value_hbm_resident"] == d["value"] and d["extra"]["value_roi_incl_pcie"] > 0
+    # r04: `value` stays the HBM-resident figure (the task's measurement rule), and says so; the comparison with the CPU
+    # baseline is like for like -- the drop-in ROI including PCIe against the reference's ROI
+    assert d["config"]["value_is"] == "hbm_resident"
     # every suite entry is summarised in the headline
     assert set(d["extra"]["suite"]) == set(suite)
     assert d["extra"]["suite"]["chain-large"][0] == suite["chain-large"]["value"]
+
+
+def test_x_cpu_baseline_is_like_for_like():
+    """extra.x_cpu_baseline = ROI incl. PCIe / CPU baseline; the HBM-resident ratio has its own name; per-core figure and the
+    quota are stated (bench.finish_cpu_ratios is what run_one() calls on a fresh result)"""
+    out = {"value": 220.0, "extra": {"value_roi_incl_pcie": 170.0}, "cpu_baseline": {"value": 7.75, "cores": 16, "sample": "first 4000000 pairs", "kind": "reference"}}
+    bench.finish_cpu_ratios(out, world=1, host_threads=256)
+    assert out["extra"]["x_cpu_baseline"] == round(170.0 / 7.75, 2) and out["extra"]["x_cpu_baseline_hbm_resident"] == round(220.0 / 7.75, 2)
+    assert out["cpu_baseline"]["per_core"] == round(7.75 / 16, 4) and out["cpu_baseline"]["sample"].startswith("16-core cgroup quota of a 256-thread host")
+    assert abs(out["extra"]["cpu_cores_equivalent"] - 170.0 / (7.75 / 16)) < 0.2
+    out2 = {"value": 220.0, "extra": {}, "cpu_baseline": {"value": 7.75, "cores": 16, "sample": "s", "kind": "reference"}}
+    bench.finish_cpu_ratios(out2, world=1, host_threads=16)
+    assert out2["extra"]["x_cpu_baseline"] is None and out2["extra"]["x_cpu_baseline_hbm_resident"] > 0       # no host ROI measured: no like-for-like figure
 
 
 def test_emit_prints_suite_lines_then_the_headline_last(tmp_path):

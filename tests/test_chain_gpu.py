@@ -130,6 +130,26 @@ def test_big_batch_host_paths(eng, mode, pinned, monkeypatch):
 
 
 @pytest.mark.parametrize("mode", [0, 1])
+def test_fed_path_gives_up_and_the_copy_engines_take_over(eng, mode, monkeypatch, capfd, kernel_choice):
+    """the branch nobody runs: a workgroup of the fed DP kernel whose anchors never arrive -- here: the gather kernel
+    is told not to publish the longest call's word (GAB_CHAIN_FEED_GIVEUP) and the wait is shortened to ~20 ms -- gives up, sets the
+    abort word, every other wait follows, the grid drains, and gab_chain_run runs the batch again through the copy engines
+    (chain_run_overlapped): the reference's result, and the note once"""
+    if kernel_choice != "default-split":
+        pytest.skip("one kernel choice is enough for the host path")
+    monkeypatch.setenv("GAB_CHAIN_FEED_MIN", "1000")
+    monkeypatch.setenv("GAB_CHAIN_FEED_GIVEUP", "1")
+    batch = gabgen.chain(37, 300, 0, 1, 20000)
+    ws, wp = pyoracle.chain(batch, mode)
+    capfd.readouterr()
+    s, p = eng.host_chain_kernel(batch, mode, pinned=True)
+    err = capfd.readouterr().err
+    np.testing.assert_array_equal(s, ws)
+    np.testing.assert_array_equal(p, wp)
+    assert err.count("gave up waiting for its anchors") == 1, err[-500:]
+
+
+@pytest.mark.parametrize("mode", [0, 1])
 def test_gap_cost_table_limits(eng, mode):
     """the block kernels read the gap cost of a pair from a per-call table of bw + 2 entries when 0 <= bw <= 2046 and
     compute it otherwise: band widths on both sides of the limit, 0 and 1, with diagonal differences from 0 to beyond bw,
