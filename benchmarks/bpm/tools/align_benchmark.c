@@ -63,6 +63,37 @@ static void timer_print_like(FILE *f, double sec) {
     else if (ns > 1e6) fprintf(f, "%7.2f ms/call {min%.2fms,Max%.2fms})\n", sec * 1e3, sec * 1e3, sec * 1e3);
     else fprintf(f, "%7.2f us/call {min%.2fus,Max%.2fus})\n", sec * 1e6, sec * 1e6, sec * 1e6);
 }
+/* ---- GAB_GPU_PARSE: the file cut in front of '>' lines, every GPU indexes its piece and scores its pairs ------------------------ */
+typedef struct {
+    int dev, ok; int64_t first;
+    gab_parser *ps; gab_pairs_packed pk; gab_bpm *h; gab_bitpal *hb; int32_t *d_score;
+} bgp_part;
+typedef struct { int ng, bitpal; const char *whole; size_t cut[65]; bgp_part part[64]; int32_t *score; } bgp_ctx;
+static void bgp_parse(int g, void *v) {
+    bgp_ctx *G = (bgp_ctx *)v;
+    bgp_part *p = &G->part[g];
+    p->dev = gab_phys_gpu(g);
+    if (gab_parser_create(p->dev, &p->ps) != 0) return;
+    if (gab_pairs_parse(p->ps, G->whole + G->cut[g], (int64_t)(G->cut[g + 1] - G->cut[g]), 1, &p->pk, NULL) != 0) return;
+    if (G->bitpal >= 0) { if (gab_bitpal_create(G->bitpal, p->dev, &p->hb) != 0) return; }
+    else if (gab_bpm_create(p->dev, &p->h) != 0) return;
+    if (gab_device_alloc(p->dev, 4 * (size_t)p->pk.n + 4, (void **)&p->d_score) != 0) return;
+    p->ok = 1;
+}
+static void bgp_run(int g, void *v) {
+    bgp_ctx *G = (bgp_ctx *)v;
+    bgp_part *p = &G->part[g];
+    const gab_pairs_packed *pk = &p->pk;
+    if (pk->n == 0) return;
+    if (G->bitpal >= 0)
+        GAB_DIE_IF(gab_bitpal_run_device(p->hb, pk->d_text, pk->text_bytes, pk->d_pat_off, pk->d_pat_len, pk->d_text, pk->text_bytes,
+                                         pk->d_txt_off, pk->d_txt_len, pk->n, p->d_score, NULL), "gab_bitpal_run_device");
+    else
+        GAB_DIE_IF(gab_bpm_run_device(p->h, pk->d_text, pk->text_bytes, pk->d_pat_off, pk->d_pat_len, pk->d_text, pk->text_bytes, pk->d_txt_off,
+                                      pk->d_txt_len, pk->n, p->d_score, NULL), "gab_bpm_run_device");
+    GAB_DIE_IF(gab_device_copy_to_host(p->dev, G->score + p->first, p->d_score, 4 * (size_t)pk->n), "gab_device_copy_to_host");
+}
+
 int main(int argc, char **argv) {
     const char *algo = NULL, *input = NULL, *output = NULL;
     int threads = 1, gpus = 0, c;
@@ -93,41 +124,48 @@ int main(int argc, char **argv) {
     FILE *in = fopen(input, "r");
     if (!in) { fprintf(stderr, "Input file '%s' couldn't be opened\n", input); exit(1); }
     FILE *out = output ? fopen(output, "w") : NULL;
-    /* GAB_GPU_PARSE=1 (one GPU): the file is read in one piece and indexed ON the GPU (gab_pairs_parse with the swap rule,
-     * SURVEY.md 8f row f1); the sequences are used in place in the device copy of the text. */
+    /* GAB_GPU_PARSE=1: the file is read in one piece, cut in front of '>' lines into one piece per GPU, and every GPU indexes ITS
+     * piece (gab_pairs_parse with the swap rule); the sequences are used in place in that GPU's copy of the text. */
     const int64_t fsz = gab_regular_file_size(in);      /* -1 for pipes: they take the getline path */
-    if (getenv("GAB_GPU_PARSE") && atoi(getenv("GAB_GPU_PARSE")) && fsz >= 0 && gab_pick_gpus(gpus) == 1) {
+    if (getenv("GAB_GPU_PARSE") && atoi(getenv("GAB_GPU_PARSE")) && fsz >= 0) {
+        const int ng = gab_pick_gpus(gpus);
         char *whole = (char *)malloc((size_t)fsz + 1);
-        gab_parser *ps = NULL; gab_pairs_packed pk;
-        if (whole && fread(whole, 1, (size_t)fsz, in) == (size_t)fsz && gab_parser_create(0, &ps) == 0 &&
-            gab_pairs_parse(ps, whole, fsz, 1, &pk, NULL) == 0) {
+        bgp_ctx G;
+        memset(&G, 0, sizeof G);
+        G.ng = ng; G.whole = whole; G.bitpal = bitpal;
+        int ok = whole && fread(whole, 1, (size_t)fsz, in) == (size_t)fsz && gab_cut_at_marker(whole, (size_t)fsz, ng, ">", 0, G.cut) == 0;
+        if (ok) {
+            gab_run_parts(ng, bgp_parse, &G);
+            for (int g = 0; g < ng; g++) ok = ok && G.part[g].ok;
+        }
+        if (ok) {
             free(whole); fclose(in);
-            gab_bpm *h = NULL; gab_bitpal *hb = NULL;
-            if (bitpal >= 0) GAB_DIE_IF(gab_bitpal_create(bitpal, 0, &hb), "gab_bitpal_create");
-            else GAB_DIE_IF(gab_bpm_create(0, &h), "gab_bpm_create");
-            int32_t *d_score = NULL, *sc = (int32_t *)malloc(4 * (size_t)pk.n + 4);
-            GAB_DIE_IF(gab_device_alloc(0, 4 * (size_t)pk.n + 4, (void **)&d_score), "gab_device_alloc");
+            int64_t n = 0;
+            for (int g = 0; g < ng; g++) { G.part[g].first = n; n += G.part[g].pk.n; }
+            G.score = (int32_t *)malloc(4 * (size_t)n + 4);
+            gab_pin_out_on(gab_phys_gpu(0), G.score, 4 * (size_t)n + 4);
             const double t0g = gab_now();
-            gab_roi_begin();
-            if (bitpal >= 0)
-                GAB_DIE_IF(gab_bitpal_run_device(hb, pk.d_text, pk.text_bytes, pk.d_pat_off, pk.d_pat_len, pk.d_text, pk.text_bytes,
-                                                 pk.d_txt_off, pk.d_txt_len, pk.n, d_score, NULL), "gab_bitpal_run_device");
-            else
-                GAB_DIE_IF(gab_bpm_run_device(h, pk.d_text, pk.text_bytes, pk.d_pat_off, pk.d_pat_len, pk.d_text, pk.text_bytes, pk.d_txt_off,
-                                              pk.d_txt_len, pk.n, d_score, NULL), "gab_bpm_run_device");
-            GAB_DIE_IF(gab_device_copy_to_host(0, sc, d_score, 4 * (size_t)pk.n), "gab_device_copy_to_host");
+            gab_roi_begin_n(ng);
+            gab_run_parts(ng, bgp_run, &G);
             gab_roi_end();
             const double secg = gab_now() - t0g;
-            if (out) { for (int64_t i = 0; i < pk.n; i++) fprintf(out, "[%ld] score=%d\n", (long)i, sc[i]); fclose(out); }
+            gab_unpin(G.score);
+            if (out) { for (int64_t i = 0; i < n; i++) fprintf(out, "[%ld] score=%d\n", (long)i, G.score[i]); fclose(out); }
             fprintf(stderr, "[Benchmark] (input indexed on the GPU)\n");
-            fprintf(stderr, "=> Total.reads            %ld\n", (long)pk.n);
+            fprintf(stderr, "=> Total.reads            %ld\n", (long)n);
             fprintf(stderr, "=> Time.Benchmark      ");
             timer_print_like(stderr, secg);
-            gab_device_free(0, d_score); gab_bpm_destroy(h); gab_bitpal_destroy(hb); gab_parser_destroy(ps); free(sc);
+            if (getenv("GAB_QUEUE_REPORT")) {
+                fprintf(stderr, "gab GPU parse: %d piece(s), pairs per GPU:", ng);
+                for (int g = 0; g < ng; g++) fprintf(stderr, " %ld", (long)G.part[g].pk.n);
+                fprintf(stderr, "\n");
+            }
+            for (int g = 0; g < ng; g++) { bgp_part *q = &G.part[g]; gab_device_free(q->dev, q->d_score); gab_bpm_destroy(q->h); gab_bitpal_destroy(q->hb); gab_parser_destroy(q->ps); }
+            free(G.score);
             return 0;
         }
         fprintf(stderr, "GPU parser declined the file (%s); using the getline parser\n", gab_last_error());
-        if (ps) gab_parser_destroy(ps);
+        for (int g = 0; g < ng; g++) { bgp_part *q = &G.part[g]; if (q->d_score) gab_device_free(q->dev, q->d_score); gab_bpm_destroy(q->h); gab_bitpal_destroy(q->hb); if (q->ps) gab_parser_destroy(q->ps); }
         free(whole);
         fseek(in, 0L, SEEK_SET);
     }

@@ -13,10 +13,10 @@
  * the kernels of another).  -t and -b are accepted and ignored (they tune the CPU path only); -g / $GAB_GPUS selects the
  * number of GPUs.
  *
- * GAB_GPU_PARSE=1 (one GPU): the input file is read in one piece and parsed ON the GPU (gab_bsw_parse_pairs, SURVEY.md
- * 8f row f1) instead of line by line with fgets / sscanf; the packed buffers stay on the device and the ROI calls
- * gab_bsw_run_device.  Files the GPU parser does not accept (a line that hits one of the reference's buffer limits)
- * fall back to the line-by-line path below.
+ * GAB_GPU_PARSE=1: the input file is read in one piece, cut at pair boundaries into one piece per GPU, and every GPU parses
+ * ITS piece (gab_bsw_parse_pairs) instead of the host reading line by line with fgets / sscanf; the packed
+ * buffers stay on the GPU that parsed them and the ROI is one gab_bsw_run_device per GPU.  Files the GPU parser does not accept
+ * (a line that hits one of the reference's buffer limits) fall back to the line-by-line path below.
  */
 #include "../../common/gab_driver.h"
 #include <assert.h>
@@ -57,6 +57,33 @@ static void run_chunk(int worker, int gpu, int64_t chunk, void *vctx, void *st) 
     c->busy[worker] += gab_now() - t0;
 }
 
+/* ---- GAB_GPU_PARSE: the file cut at pair boundaries, every GPU parses its piece and runs the DP on it --- */
+typedef struct {
+    int dev, ok; int64_t first; double busy;
+    gab_parser *ps; gab_bsw_packed pk; gab_bsw *h; int32_t *d_score;
+} gpp_part;
+typedef struct { int ng; const char *whole; size_t cut[65]; gpp_part part[64]; gab_bsw_params prm; int32_t *score; } gpp_ctx;
+static void gpp_parse(int g, void *v) {
+    gpp_ctx *G = (gpp_ctx *)v;
+    gpp_part *p = &G->part[g];
+    p->dev = gab_phys_gpu(g);
+    if (gab_parser_create(p->dev, &p->ps) != 0) return;
+    if (gab_bsw_parse_pairs(p->ps, G->whole + G->cut[g], (int64_t)(G->cut[g + 1] - G->cut[g]), &p->pk, NULL) != 0) return;
+    if (gab_bsw_create(&G->prm, p->dev, &p->h) != 0) return;
+    if (gab_device_alloc(p->dev, 4 * (size_t)p->pk.n + 4, (void **)&p->d_score) != 0) return;
+    p->ok = 1;
+}
+static void gpp_run(int g, void *v) {
+    gpp_ctx *G = (gpp_ctx *)v;
+    gpp_part *p = &G->part[g];
+    if (p->pk.n == 0) return;
+    const double t0 = gab_now();
+    GAB_DIE_IF(gab_bsw_run_device(p->h, p->pk.d_ref, p->pk.ref_bytes, p->pk.d_ref_off, p->pk.d_qry, p->pk.qry_bytes, p->pk.d_qry_off, p->pk.d_len1,
+                                  p->pk.d_len2, p->pk.d_h0, p->pk.n, p->d_score, NULL, NULL), "gab_bsw_run_device");
+    GAB_DIE_IF(gab_device_copy_to_host(p->dev, G->score + p->first, p->d_score, 4 * (size_t)p->pk.n), "gab_device_copy_to_host");
+    p->busy = gab_now() - t0;
+}
+
 /* 5x5 matrix exactly as bwa_fill_scmat, main_banded.cpp:94-102 */
 static void fill_scmat(int a, int b, int ambig, int8_t mat[25]) {
     int k = 0;
@@ -92,45 +119,57 @@ int main(int argc, char *argv[]) {
 
     /* a pipe / process substitution has no size: only regular files take the whole-file GPU parser */
     const int64_t fsz = gab_regular_file_size(pairFile);
-    if (getenv("GAB_GPU_PARSE") && atoi(getenv("GAB_GPU_PARSE")) && fsz >= 0 && gab_pick_gpus(gpus) == 1) {
+    if (getenv("GAB_GPU_PARSE") && atoi(getenv("GAB_GPU_PARSE")) && fsz >= 0) {
         const double tR0 = gab_now();
+        const int ng = gab_pick_gpus(gpus);
         char *whole = (char *)malloc((size_t)fsz + 1);
-        gab_parser *ps = NULL; gab_bsw_packed pk;
-        if (whole && fread(whole, 1, (size_t)fsz, pairFile) == (size_t)fsz && gab_parser_create(0, &ps) == 0 &&
-            gab_bsw_parse_pairs(ps, whole, fsz, &pk, NULL) == 0) {
+        gpp_ctx G;
+        memset(&G, 0, sizeof G);
+        G.ng = ng; G.whole = whole;
+        G.prm.o_del = w_open; G.prm.e_del = w_extend; G.prm.o_ins = w_open; G.prm.e_ins = w_extend;
+        G.prm.zdrop = 100; G.prm.end_bonus = 5; G.prm.w = 100;
+        fill_scmat(w_match, w_mismatch, w_ambig, G.prm.mat);
+        int ok = whole && fread(whole, 1, (size_t)fsz, pairFile) == (size_t)fsz && gab_cut_by_lines(whole, (size_t)fsz, ng, 3, G.cut) == 0;
+        if (ok) {
+            gab_run_parts(ng, gpp_parse, &G);                    /* every GPU parses its piece and keeps it */
+            for (int g = 0; g < ng; g++) ok = ok && G.part[g].ok;
+        }
+        if (ok) {
             free(whole); fclose(pairFile);
+            int64_t n = 0, inb = 0;
+            for (int g = 0; g < ng; g++) { G.part[g].first = n; n += G.part[g].pk.n; inb += G.part[g].pk.ref_bytes + G.part[g].pk.qry_bytes; }
             const double readT = gab_now() - tR0;
-            printf("Number of input pairs: %ld\n", (long)pk.n);
-            printf("Allocating %.3f GB memory for input buffers...\n", (double)(pk.ref_bytes + pk.qry_bytes + 32 * pk.n) / (1024.0 * 1024 * 1024));
-            gab_bsw_params prm;
-            memset(&prm, 0, sizeof prm);
-            prm.o_del = w_open; prm.e_del = w_extend; prm.o_ins = w_open; prm.e_ins = w_extend;
-            prm.zdrop = 100; prm.end_bonus = 5; prm.w = 100;
-            fill_scmat(w_match, w_mismatch, w_ambig, prm.mat);
-            gab_bsw *h = NULL;
-            GAB_DIE_IF(gab_bsw_create(&prm, 0, &h), "gab_bsw_create");
-            int32_t *d_score = NULL, *sc = (int32_t *)malloc(4 * (size_t)pk.n + 4);
-            GAB_DIE_IF(gab_device_alloc(0, 4 * (size_t)pk.n + 4, (void **)&d_score), "gab_device_alloc");
+            printf("Number of input pairs: %ld\n", (long)n);
+            printf("Allocating %.3f GB memory for input buffers...\n", (double)(inb + 32 * n) / (1024.0 * 1024 * 1024));
+            G.score = (int32_t *)malloc(4 * (size_t)n + 4);
+            gab_pin_out_on(gab_phys_gpu(0), G.score, 4 * (size_t)n + 4);
             const double t0g = gab_now();
-            gab_roi_begin();
-            GAB_DIE_IF(gab_bsw_run_device(h, pk.d_ref, pk.ref_bytes, pk.d_ref_off, pk.d_qry, pk.qry_bytes, pk.d_qry_off, pk.d_len1,
-                                          pk.d_len2, pk.d_h0, pk.n, d_score, NULL, NULL), "gab_bsw_run_device");
-            GAB_DIE_IF(gab_device_copy_to_host(0, sc, d_score, 4 * (size_t)pk.n), "gab_device_copy_to_host");
+            gab_roi_begin_n(ng);
+            gab_run_parts(ng, gpp_run, &G);                      /* ROI: gab_bsw_run_device on every GPU's own pairs + the scores back */
             gab_roi_end();
             const double roiG = gab_now() - t0g;
-            printf("0] workTicks = %ld\n", (long)(roiG * 1e9));
-            printf("Executed HIP gfx950 code on 1 GPU(s) (input parsed on the GPU)...\n");
-            for (int64_t i = 0; i < pk.n; ++i) fprintf(stderr, "[%ld] score=%d\n", (long)i, sc[i]);
+            gab_unpin(G.score);
+            for (int g = 0; g < ng; g++) printf("%d] workTicks = %ld\n", g, (long)(G.part[g].busy * 1e9));
+            printf("Executed HIP gfx950 code on %d GPU(s) (input parsed on the GPU)...\n", ng);
+            for (int64_t i = 0; i < n; ++i) fprintf(stderr, "[%ld] score=%d\n", (long)i, G.score[i]);
             printf("Processor freq: %0.2lf MHz\n", 1000.0);
             printf("Read time = %0.2lf s\n", readT);
             printf("Overall SW cycles = %ld, %0.2lf s\n", (long)(roiG * 1e9), roiG);
-            printf("Total Pairs processed: %ld\n", (long)pk.n);
-            printf("avgTicks = %lf, maxTicks = %ld, load imbalance = %lf\n", roiG * 1e9, (long)(roiG * 1e9), 1.0);
-            gab_device_free(0, d_score); gab_bsw_destroy(h); gab_parser_destroy(ps); free(sc);
+            printf("Total Pairs processed: %ld\n", (long)n);
+            double sum = 0, mx = 0;
+            for (int g = 0; g < ng; g++) { sum += G.part[g].busy; if (G.part[g].busy > mx) mx = G.part[g].busy; }
+            printf("avgTicks = %lf, maxTicks = %ld, load imbalance = %lf\n", sum * 1e9 / ng, (long)(mx * 1e9), sum > 0 ? mx / (sum / ng) : 1.0);
+            if (getenv("GAB_QUEUE_REPORT")) {
+                fprintf(stderr, "gab GPU parse: %d piece(s), pairs per GPU:", ng);
+                for (int g = 0; g < ng; g++) fprintf(stderr, " %ld", (long)G.part[g].pk.n);
+                fprintf(stderr, "\n");
+            }
+            for (int g = 0; g < ng; g++) { gab_device_free(G.part[g].dev, G.part[g].d_score); gab_bsw_destroy(G.part[g].h); gab_parser_destroy(G.part[g].ps); }
+            free(G.score);
             return 0;
         }
         fprintf(stderr, "GPU parser declined the file (%s); using the line-by-line parser\n", gab_last_error());
-        if (ps) gab_parser_destroy(ps);
+        for (int g = 0; g < ng; g++) { if (G.part[g].d_score) gab_device_free(G.part[g].dev, G.part[g].d_score); if (G.part[g].h) gab_bsw_destroy(G.part[g].h); if (G.part[g].ps) gab_parser_destroy(G.part[g].ps); }
         free(whole);
         fseek(pairFile, 0L, SEEK_SET);
     }

@@ -14,7 +14,7 @@
  *              bound to its GPU's NUMA node, so the card reads memory next to it; results are printed from the shares;
  *   $GAB_CHUNK (anchors per chunk; tests): file-order chunks pulled by $GAB_WORKERS_PER_GPU host threads per GPU.
  * Built twice: -DGAB_CHAIN_MODE=0 (chain) and =1 (fast-chain).
- * Extra flag: -g <gpus> (or $GAB_GPUS).  -t is accepted and ignored.
+ * Extra flag: -g <gpus> (or $GAB_GPUS).  -t is accepted and ignored.  GAB_GPU_PARSE=1: see main().
  */
 #define GAB_ENERGY_STREAM stderr      /* where the reference prints "Energy consumption:" in this driver */
 #include "../../common/gab_driver.h"
@@ -102,6 +102,36 @@ static void run_chunk(int worker, int gpu, int64_t chunk, void *vctx, void *st) 
     free(off);
 }
 
+/* ---- GAB_GPU_PARSE: the file cut behind "EOR" lines, every GPU parses its piece and chains its calls ---------------------- */
+typedef struct {
+    int dev, ok;
+    gab_parser *ps; gab_chain_packed pk; gab_chain *h;
+    int32_t *d_score, *d_parent, *sc, *pa;
+} cgp_part;
+typedef struct { int ng; const char *whole; size_t cut[65]; cgp_part part[64]; } cgp_ctx;
+static void cgp_parse(int g, void *v) {
+    cgp_ctx *G = (cgp_ctx *)v;
+    cgp_part *p = &G->part[g];
+    p->dev = gab_phys_gpu(g);
+    if (gab_parser_create(p->dev, &p->ps) != 0) return;
+    if (gab_chain_parse(p->ps, G->whole + G->cut[g], (int64_t)(G->cut[g + 1] - G->cut[g]), &p->pk, NULL) != 0) return;
+    if (gab_chain_create(p->dev, &p->h) != 0) return;
+    const size_t t = (size_t)p->pk.total;
+    if (gab_device_alloc(p->dev, 4 * t + 4, (void **)&p->d_score) != 0 || gab_device_alloc(p->dev, 4 * t + 4, (void **)&p->d_parent) != 0) return;
+    p->sc = (int32_t *)malloc(4 * t + 4); p->pa = (int32_t *)malloc(4 * t + 4);
+    if (!p->sc || !p->pa) return;
+    gab_pin_out_on(p->dev, p->sc, 4 * t + 4); gab_pin_out_on(p->dev, p->pa, 4 * t + 4);
+    p->ok = 1;
+}
+static void cgp_run(int g, void *v) {
+    cgp_part *p = &((cgp_ctx *)v)->part[g];
+    if (p->pk.ncalls == 0) return;
+    GAB_DIE_IF(gab_chain_run_device(p->h, GAB_CHAIN_MODE, p->pk.d_x, p->pk.d_y, p->pk.call_off, p->pk.hdr, p->pk.ncalls, p->d_score, p->d_parent, NULL),
+               "gab_chain_run_device");
+    GAB_DIE_IF(gab_device_copy_to_host(p->dev, p->sc, p->d_score, 4 * (size_t)p->pk.total), "gab_device_copy_to_host");
+    GAB_DIE_IF(gab_device_copy_to_host(p->dev, p->pa, p->d_parent, 4 * (size_t)p->pk.total), "gab_device_copy_to_host");
+}
+
 static void help(void) {
     fprintf(stderr,
         "Usage: chain [OPTION]...\n"
@@ -144,44 +174,63 @@ int main(int argc, char **argv) {
     FILE *in = fopen(in_name, "r"), *out = fopen(out_name, "w");
     if (!in || !out) { fprintf(stderr, "ERROR: cannot open %s\n", !in ? in_name : out_name); exit(EXIT_FAILURE); }
 
-    /* GAB_GPU_PARSE=1 (one GPU): the file is read in one piece and parsed ON the GPU (gab_chain_parse);
-     * anchors stay on the device, the ROI calls gab_chain_run_device.  Files that are not in the one-record-per-line layout
-     * are declined and take the fscanf path below. */
+    /* GAB_GPU_PARSE=1: the file is read in one piece, cut behind "EOR" lines into one piece per GPU, and every GPU parses ITS piece
+     * (gab_chain_parse); the anchors stay on the GPU that parsed them, the ROI is one gab_chain_run_device per
+     * GPU.  Files that are not in the one-record-per-line layout are declined and take the fscanf path below. */
     const int64_t fsz = gab_regular_file_size(in);      /* -1 for pipes: they take the fscanf path */
-    if (getenv("GAB_GPU_PARSE") && atoi(getenv("GAB_GPU_PARSE")) && fsz >= 0 && gab_pick_gpus(gpus) == 1) {
+    if (getenv("GAB_GPU_PARSE") && atoi(getenv("GAB_GPU_PARSE")) && fsz >= 0) {
+        const int ng = gab_pick_gpus(gpus);
         char *whole = (char *)malloc((size_t)fsz + 1);
-        gab_parser *ps = NULL; gab_chain_packed pk;
-        if (whole && fread(whole, 1, (size_t)fsz, in) == (size_t)fsz && gab_parser_create(0, &ps) == 0 &&
-            gab_chain_parse(ps, whole, fsz, &pk, NULL) == 0) {
+        cgp_ctx G;
+        memset(&G, 0, sizeof G);
+        G.ng = ng; G.whole = whole;
+        int ok = whole && fread(whole, 1, (size_t)fsz, in) == (size_t)fsz && gab_cut_at_marker(whole, (size_t)fsz, ng, "EOR", 1, G.cut) == 0;
+        if (ok) {
+            gab_run_parts(ng, cgp_parse, &G);
+            for (int g = 0; g < ng; g++) ok = ok && G.part[g].ok;
+        }
+        if (ok) {
             free(whole);
             fprintf(stderr, "Running with threads: %d (input parsed on the GPU)\n", numThreads);
-            gab_chain *h = NULL;
-            GAB_DIE_IF(gab_chain_create(0, &h), "gab_chain_create");
-            int32_t *d_score = NULL, *d_parent = NULL;
-            GAB_DIE_IF(gab_device_alloc(0, 4 * (size_t)pk.total + 4, (void **)&d_score), "gab_device_alloc");
-            GAB_DIE_IF(gab_device_alloc(0, 4 * (size_t)pk.total + 4, (void **)&d_parent), "gab_device_alloc");
-            int32_t *sc = (int32_t *)malloc(4 * (size_t)pk.total + 4), *pa = (int32_t *)malloc(4 * (size_t)pk.total + 4);
             const double t0g = gab_now();
-            gab_roi_begin();
-            GAB_DIE_IF(gab_chain_run_device(h, GAB_CHAIN_MODE, pk.d_x, pk.d_y, pk.call_off, pk.hdr, pk.ncalls, d_score, d_parent, NULL),
-                       "gab_chain_run_device");
-            GAB_DIE_IF(gab_device_copy_to_host(0, sc, d_score, 4 * (size_t)pk.total), "gab_device_copy_to_host");
-            GAB_DIE_IF(gab_device_copy_to_host(0, pa, d_parent, 4 * (size_t)pk.total), "gab_device_copy_to_host");
+            gab_roi_begin_n(ng);
+            gab_run_parts(ng, cgp_run, &G);
             gab_roi_end();
             const double rt = gab_now() - t0g;
-            for (int64_t c2 = 0; c2 < pk.ncalls; c2++) {
-                fprintf(out, "%lld\n", (long long)pk.hdr[c2].n);
-                const int64_t o = pk.call_off[c2];
-                for (int64_t i = 0; i < pk.hdr[c2].n; i++) fprintf(out, "%d\t%d\n", sc[o + i], pa[o + i]);
-                fprintf(out, "EOR\n");
+            for (int g = 0; g < ng; g++) {
+                const cgp_part *p = &G.part[g];
+                for (int64_t c2 = 0; c2 < p->pk.ncalls; c2++) {
+                    fprintf(out, "%lld\n", (long long)p->pk.hdr[c2].n);
+                    const int64_t o = p->pk.call_off[c2];
+                    for (int64_t i = 0; i < p->pk.hdr[c2].n; i++) fprintf(out, "%d\t%d\n", p->sc[o + i], p->pa[o + i]);
+                    fprintf(out, "EOR\n");
+                }
             }
             fprintf(stderr, "Time in kernel: %.2f sec\n", rt);
+            if (gab_env_i64("GAB_ROI_PRECISE", 0)) fprintf(stderr, "[gab] region of interest: %.3f ms\n", rt * 1e3);
+            if (getenv("GAB_QUEUE_REPORT")) {
+                fprintf(stderr, "gab GPU parse: %d piece(s), calls per GPU:", ng);
+                for (int g = 0; g < ng; g++) fprintf(stderr, " %ld", (long)G.part[g].pk.ncalls);
+                fprintf(stderr, "\n");
+            }
             fclose(in); fclose(out);
-            gab_device_free(0, d_score); gab_device_free(0, d_parent); gab_chain_destroy(h); gab_parser_destroy(ps); free(sc); free(pa);
+            for (int g = 0; g < ng; g++) {
+                cgp_part *p = &G.part[g];
+                gab_unpin(p->sc); gab_unpin(p->pa);
+                gab_device_free(p->dev, p->d_score); gab_device_free(p->dev, p->d_parent); gab_chain_destroy(p->h); gab_parser_destroy(p->ps); free(p->sc); free(p->pa);
+            }
             return 0;
         }
         fprintf(stderr, "GPU parser declined the file (%s); using the fscanf parser\n", gab_last_error());
-        if (ps) gab_parser_destroy(ps);
+        for (int g = 0; g < ng; g++) {
+            cgp_part *p = &G.part[g];
+            if (p->d_score) gab_device_free(p->dev, p->d_score);
+            if (p->d_parent) gab_device_free(p->dev, p->d_parent);
+            if (p->h) gab_chain_destroy(p->h);
+            if (p->ps) gab_parser_destroy(p->ps);
+            if (p->sc) { gab_unpin(p->sc); free(p->sc); }
+            if (p->pa) { gab_unpin(p->pa); free(p->pa); }
+        }
         free(whole);
         fseek(in, 0L, SEEK_SET);
     }

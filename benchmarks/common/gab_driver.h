@@ -261,6 +261,66 @@ static inline void gab_pin_out_on(int dev, void *p, size_t bytes) {
 static inline void gab_pin_out(void *p, size_t bytes) { gab_pin_out_on(gab_phys_gpu(0), p, bytes); }
 static inline void gab_unpin(const void *p) { if (!gab_env_i64("GAB_NO_PIN", 0)) gab_host_unregister((void *)p); }
 
+/* ---- GAB_GPU_PARSE with N GPUs: the file cut at record boundaries, one piece per GPU --------------
+ * A GPU parses its own piece (gab_*_parse) and keeps what it parsed: a piece's data never leaves its GPU.  The cuts are found on
+ * the host.  cut[0] = 0, cut[parts] = n; returns 0, or -1 when the file cannot be cut that way (the caller reads line by line). */
+/* records of `lines` lines each, every line alike (bsw: h0 / reference / query): the host counts newlines, once */
+static inline int gab_cut_by_lines(const char *buf, size_t n, int parts, int lines, size_t *cut) {
+    if (parts == 1) { cut[0] = 0; cut[1] = n; return 0; }
+    size_t total = 0;
+    for (size_t i = 0; i < n; i++) total += buf[i] == '\n';
+    const size_t recs = total / (size_t)lines;
+    cut[0] = 0; cut[parts] = n;
+    size_t seen = 0, pos = 0;
+    for (int g = 1; g < parts; g++) {
+        const size_t want = recs * (size_t)g / (size_t)parts * (size_t)lines;      /* lines in front of piece g */
+        while (seen < want && pos < n) { const char *q = (const char *)memchr(buf + pos, '\n', n - pos); if (!q) return -1; pos = (size_t)(q - buf) + 1; seen++; }
+        cut[g] = pos;
+    }
+    /* what lies behind the last whole record (the reference ignores it: numPairs = lines / 3) stays in the last piece */
+    return 0;
+}
+/* records that END with a line starting with `tail` (chain: "EOR"), or START with a line starting with `head` (bpm / wfa: ">"):
+ * the cut nearest behind n * g / parts */
+static inline int gab_cut_at_marker(const char *buf, size_t n, int parts, const char *marker, int after_marker_line, size_t *cut) {
+    const size_t ml = strlen(marker);
+    cut[0] = 0; cut[parts] = n;
+    for (int g = 1; g < parts; g++) {
+        size_t pos = n * (size_t)g / (size_t)parts;
+        if (pos < cut[g - 1]) pos = cut[g - 1];
+        size_t found = n;
+        while (pos < n) {                                   /* the next line start at or behind pos whose line starts with the marker */
+            const char *q = pos == 0 ? buf - 1 : (const char *)memchr(buf + pos - 1, '\n', n - pos + 1);
+            if (!q) break;
+            const size_t ls = (size_t)(q - buf) + 1;          /* a line starts here */
+            if (ls + ml <= n && !memcmp(buf + ls, marker, ml)) { found = ls; break; }
+            pos = ls + 1;
+        }
+        if (found >= n) { cut[g] = n; continue; }
+        if (after_marker_line) {                             /* the piece ends behind the marker's line */
+            const char *e = (const char *)memchr(buf + found, '\n', n - found);
+            found = e ? (size_t)(e - buf) + 1 : n;
+        }
+        cut[g] = found;
+    }
+    return 0;
+}
+/* one thread per part, each bound to its GPU's NUMA node first; fn(part index, arg) */
+typedef struct { int part, gpu; void (*fn)(int, void *); void *arg; } gab_part_thread;
+static void *gab_part_main(void *p) {
+    gab_part_thread *t = (gab_part_thread *)p;
+    (void)gab_bind_thread_to_gpu(t->gpu);
+    t->fn(t->part, t->arg);
+    return NULL;
+}
+static inline void gab_run_parts(int parts, void (*fn)(int, void *), void *arg) {
+    pthread_t *th = (pthread_t *)calloc((size_t)parts, sizeof(pthread_t));
+    gab_part_thread *a = (gab_part_thread *)calloc((size_t)parts, sizeof(gab_part_thread));
+    for (int g = 0; g < parts; g++) { a[g].part = g; a[g].gpu = gab_phys_gpu(g); a[g].fn = fn; a[g].arg = arg; pthread_create(&th[g], NULL, gab_part_main, &a[g]); }
+    for (int g = 0; g < parts; g++) pthread_join(th[g], NULL);
+    free(th); free(a);
+}
+
 /* ---- per-GPU work queue ---------------------------------------------------------------------- */
 typedef void (*gab_chunk_fn)(int worker, int gpu, int64_t chunk, void *ctx, void *worker_state);
 typedef void *(*gab_gpu_init_fn)(int worker, int gpu, void *ctx);

@@ -54,6 +54,39 @@ static void run_chunk(int worker, int gpu, int64_t chunk, void *vctx, void *st) 
                            e - b, c->ops, c->ops_off + b, c->ops_len + b, c->score + b), "gab_wfa_run");
 }
 static double tv_now(void) { struct timeval tv; gettimeofday(&tv, NULL); return (double)tv.tv_sec + 1e-6 * (double)tv.tv_usec; }
+/* ---- GAB_GPU_PARSE: the file cut in front of '>' lines, every GPU indexes its piece and aligns its pairs ----------------------- */
+typedef struct {
+    int dev, ok;
+    gab_parser *ps; gab_pairs_packed pk; gab_wfa *h;
+    char *d_ops, *ops; int32_t *d_len, *d_score, *olen; int64_t *ooff;
+} wgp_part;
+typedef struct { int ng; const char *whole; size_t cut[65]; wgp_part part[64]; const wfa_ctx *wctx; } wgp_ctx;
+static void wgp_parse(int g, void *v) {
+    wgp_ctx *G = (wgp_ctx *)v;
+    wgp_part *p = &G->part[g];
+    p->dev = gab_phys_gpu(g);
+    if (gab_parser_create(p->dev, &p->ps) != 0) return;
+    if (gab_pairs_parse(p->ps, G->whole + G->cut[g], (int64_t)(G->cut[g + 1] - G->cut[g]), 0, &p->pk, NULL) != 0) return;
+    gab_wfa_penalties pen; pen.mismatch = G->wctx->pen.mismatch; pen.gap_opening = G->wctx->pen.gap_opening; pen.gap_extension = G->wctx->pen.gap_extension;
+    if (gab_wfa_create_reduced(&pen, G->wctx->min_wavefront_length, G->wctx->max_distance_threshold, p->dev, &p->h) != 0) return;
+    if (gab_device_alloc(p->dev, (size_t)p->pk.cap_bytes + 16, (void **)&p->d_ops) != 0 || gab_device_alloc(p->dev, 4 * (size_t)p->pk.n + 4, (void **)&p->d_len) != 0 ||
+        gab_device_alloc(p->dev, 4 * (size_t)p->pk.n + 4, (void **)&p->d_score) != 0) return;
+    p->ops = (char *)malloc((size_t)p->pk.cap_bytes + 16);
+    p->ooff = (int64_t *)malloc(8 * (size_t)p->pk.n + 8); p->olen = (int32_t *)malloc(4 * (size_t)p->pk.n + 4);
+    if (!p->ops || !p->ooff || !p->olen) return;
+    p->ok = 1;
+}
+static void wgp_run(int g, void *v) {
+    wgp_part *p = &((wgp_ctx *)v)->part[g];
+    const gab_pairs_packed *pk = &p->pk;
+    if (pk->n == 0) return;
+    GAB_DIE_IF(gab_wfa_run_device(p->h, pk->d_text, pk->text_bytes, pk->d_pat_off, pk->d_pat_len, pk->d_text, pk->text_bytes, pk->d_txt_off,
+                                  pk->d_txt_len, pk->n, p->d_ops, pk->d_cap_off, p->d_len, p->d_score, NULL), "gab_wfa_run_device");
+    GAB_DIE_IF(gab_device_copy_to_host(p->dev, p->ops, p->d_ops, (size_t)pk->cap_bytes), "gab_device_copy_to_host");
+    GAB_DIE_IF(gab_device_copy_to_host(p->dev, p->ooff, pk->d_cap_off, 8 * (size_t)pk->n), "gab_device_copy_to_host");
+    GAB_DIE_IF(gab_device_copy_to_host(p->dev, p->olen, p->d_len, 4 * (size_t)pk->n), "gab_device_copy_to_host");
+}
+
 int main(int argc, char **argv) {
     const char *input = NULL, *output = NULL;
     int threads = 1, gpus = 0, c;
@@ -96,52 +129,67 @@ int main(int argc, char **argv) {
     FILE *in = fopen(input, "r");
     if (!in) { fprintf(stderr, "Input file '%s' couldn't be opened\n", input); exit(1); }
     FILE *out = output ? fopen(output, "w") : NULL;
-    /* GAB_GPU_PARSE=1 (one GPU): the file is read in one piece and indexed ON the GPU (gab_pairs_parse, no swap; SURVEY.md
-     * 8f row f1); sequences are used in place in the device copy of the text, the CIGARs come back in one copy. */
+    /* GAB_GPU_PARSE=1: the file is read in one piece, cut in front of '>' lines into one piece per GPU, and every GPU indexes ITS
+     * piece (gab_pairs_parse, no swap); sequences are used in place in that GPU's copy of the text, the CIGARs
+     * of a piece come back in one copy. */
     const int64_t fsz = gab_regular_file_size(in);      /* -1 for pipes: they take the getline path */
-    if (getenv("GAB_GPU_PARSE") && atoi(getenv("GAB_GPU_PARSE")) && fsz >= 0 && gab_pick_gpus(gpus) == 1) {
+    if (getenv("GAB_GPU_PARSE") && atoi(getenv("GAB_GPU_PARSE")) && fsz >= 0) {
+        const int ng = gab_pick_gpus(gpus);
         char *whole = (char *)malloc((size_t)fsz + 1);
-        gab_parser *ps = NULL; gab_pairs_packed pk;
-        if (whole && fread(whole, 1, (size_t)fsz, in) == (size_t)fsz && gab_parser_create(0, &ps) == 0 &&
-            gab_pairs_parse(ps, whole, fsz, 0, &pk, NULL) == 0) {
+        wgp_ctx G;
+        memset(&G, 0, sizeof G);
+        G.ng = ng; G.whole = whole; G.wctx = &ctx;
+        int ok = whole && fread(whole, 1, (size_t)fsz, in) == (size_t)fsz && gab_cut_at_marker(whole, (size_t)fsz, ng, ">", 0, G.cut) == 0;
+        if (ok) {
+            gab_run_parts(ng, wgp_parse, &G);
+            for (int g = 0; g < ng; g++) ok = ok && G.part[g].ok;
+        }
+        if (ok) {
             free(whole); fclose(in);
-            gab_wfa_penalties pen; pen.mismatch = ctx.pen.mismatch; pen.gap_opening = ctx.pen.gap_opening; pen.gap_extension = ctx.pen.gap_extension;
-            gab_wfa *h = NULL;
-            GAB_DIE_IF(gab_wfa_create_reduced(&pen, ctx.min_wavefront_length, ctx.max_distance_threshold, 0, &h), "gab_wfa_create_reduced");
-            char *d_ops = NULL; int32_t *d_len = NULL, *d_score = NULL;
-            GAB_DIE_IF(gab_device_alloc(0, (size_t)pk.cap_bytes + 16, (void **)&d_ops), "gab_device_alloc");
-            GAB_DIE_IF(gab_device_alloc(0, 4 * (size_t)pk.n + 4, (void **)&d_len), "gab_device_alloc");
-            GAB_DIE_IF(gab_device_alloc(0, 4 * (size_t)pk.n + 4, (void **)&d_score), "gab_device_alloc");
-            char *ops = (char *)malloc((size_t)pk.cap_bytes + 16);
-            int64_t *ooff = (int64_t *)malloc(8 * (size_t)pk.n + 8); int32_t *olen = (int32_t *)malloc(4 * (size_t)pk.n + 4);
             const double t0g = tv_now();
-            gab_roi_begin();
-            GAB_DIE_IF(gab_wfa_run_device(h, pk.d_text, pk.text_bytes, pk.d_pat_off, pk.d_pat_len, pk.d_text, pk.text_bytes, pk.d_txt_off,
-                                          pk.d_txt_len, pk.n, d_ops, pk.d_cap_off, d_len, d_score, NULL), "gab_wfa_run_device");
-            GAB_DIE_IF(gab_device_copy_to_host(0, ops, d_ops, (size_t)pk.cap_bytes), "gab_device_copy_to_host");
-            GAB_DIE_IF(gab_device_copy_to_host(0, ooff, pk.d_cap_off, 8 * (size_t)pk.n), "gab_device_copy_to_host");
-            GAB_DIE_IF(gab_device_copy_to_host(0, olen, d_len, 4 * (size_t)pk.n), "gab_device_copy_to_host");
+            gab_roi_begin_n(ng);
+            gab_run_parts(ng, wgp_run, &G);
             gab_roi_end();
             const double t1g = tv_now();
-            if (out) {
-                for (int64_t i = 0; i < pk.n; i++) {
-                    fprintf(out, "id=%ld ", (long)i);
-                    const char *o = ops + ooff[i];
-                    const int n = olen[i];
-                    for (int k = 0; k < n;) { int r = k; while (r < n && o[r] == o[k]) r++; fprintf(out, "%d%c", r - k, o[k]); k = r; }
-                    fprintf(out, "\n");
-                }
-                fclose(out);
+            int64_t n = 0;
+            for (int g = 0; g < ng; g++) {
+                const wgp_part *q = &G.part[g];
+                if (out)
+                    for (int64_t i = 0; i < q->pk.n; i++) {
+                        fprintf(out, "id=%ld ", (long)(n + i));
+                        const char *o = q->ops + q->ooff[i];
+                        const int len = q->olen[i];
+                        for (int k = 0; k < len;) { int r = k; while (r < len && o[r] == o[k]) r++; fprintf(out, "%d%c", r - k, o[k]); k = r; }
+                        fprintf(out, "\n");
+                    }
+                n += q->pk.n;
             }
-            printf("Total.reads: %ld\n", (long)pk.n);
+            if (out) fclose(out);
+            printf("Total.reads: %ld\n", (long)n);
             printf("Time.Benchmark: %f s\n", tv_now() - bench0);
             printf("Time.Alignment: %f s (input indexed on the GPU)\n", t1g - t0g);
-            gab_device_free(0, d_ops); gab_device_free(0, d_len); gab_device_free(0, d_score);
-            gab_wfa_destroy(h); gab_parser_destroy(ps); free(ops); free(ooff); free(olen);
+            if (getenv("GAB_QUEUE_REPORT")) {
+                fprintf(stderr, "gab GPU parse: %d piece(s), pairs per GPU:", ng);
+                for (int g = 0; g < ng; g++) fprintf(stderr, " %ld", (long)G.part[g].pk.n);
+                fprintf(stderr, "\n");
+            }
+            for (int g = 0; g < ng; g++) {
+                wgp_part *q = &G.part[g];
+                gab_device_free(q->dev, q->d_ops); gab_device_free(q->dev, q->d_len); gab_device_free(q->dev, q->d_score);
+                gab_wfa_destroy(q->h); gab_parser_destroy(q->ps); free(q->ops); free(q->ooff); free(q->olen);
+            }
             return 0;
         }
         fprintf(stderr, "GPU parser declined the file (%s); using the getline parser\n", gab_last_error());
-        if (ps) gab_parser_destroy(ps);
+        for (int g = 0; g < ng; g++) {
+            wgp_part *q = &G.part[g];
+            if (q->d_ops) gab_device_free(q->dev, q->d_ops);
+            if (q->d_len) gab_device_free(q->dev, q->d_len);
+            if (q->d_score) gab_device_free(q->dev, q->d_score);
+            if (q->h) gab_wfa_destroy(q->h);
+            if (q->ps) gab_parser_destroy(q->ps);
+            free(q->ops); free(q->ooff); free(q->olen);
+        }
         free(whole);
         fseek(in, 0L, SEEK_SET);
     }

@@ -1958,9 +1958,16 @@ extern "C" int gab_chain_run_device(gab_chain *h, int mode, const uint64_t *d_x,
     size_t ntab = 0, nfast = 0;
     int64_t tab_anchors = 0;
     if (!legacy_only && !(getenv("GAB_CHAIN_TAB") && !atoi(getenv("GAB_CHAIN_TAB")))) {
+        // A batch whose longest call would outlast 0.75 of the batch's throughput time in the throughput form (0.30 us per anchor of
+        // a call, 2.85 G anchors/s over all calls: the latency-form rule below) hands its long calls to the table form: every call
+        // that would take a quarter of that time there, 2048 anchors at least.  Measured (r04, one rank's share of chain-large
+        // under 2 / 4 / 8-GPU strong scaling, smallest table call 2048 .. 35 000 anchors): the more calls in the table form the
+        // better down to ~2048 anchors -- 8 GPUs 4.97-5.12 ms, 4 GPUs 7.80-8.29 ms, 2 GPUs 15.2-15.6 ms (17.0 without) -- while
+        // chain-large on ONE GPU loses (27.8 -> 29.4 ms with the calls above 45 000 anchors there): the table form costs 2 bytes of
+        // HBM traffic per pair and ~25 % more instructions, and only pays where calls are waited for.
         int64_t min_n = INT64_MAX;
-        const double est_tp = (double)total / 2.85e9, lat_max = 0.12e-6 * (double)wk[0].n;      // (latency form: ~0.08-0.16 us per anchor)
-        if (lat_max >= 0.5 * est_tp) min_n = 2048;
+        const double est_tp = (double)total / 2.85e9, lat_max = 0.30e-6 * (double)wk[0].n;
+        if (lat_max >= 0.75 * est_tp) min_n = std::max<int64_t>(2048, (int64_t)(0.25 * est_tp / 0.30e-6));
         if (getenv("GAB_CHAIN_TAB_MIN")) min_n = atoll(getenv("GAB_CHAIN_TAB_MIN"));
         while (ntab < nw && wk[ntab].n >= min_n) { tab_anchors += wk[ntab].n; ntab++; }
     }
