@@ -311,7 +311,7 @@ int main(int argc, char **argv) {
         /* ---- region of interest (main.cpp:111-193): one gab_chain_run per GPU ---- */
         const double t0 = gab_now();
         gab_roi_begin_n(ngpus);
-        gab_queue_run(&q, ngpus);
+        gab_queue_run_each(&q, ngpus);                          /* share g on GPU g */
         gab_roi_end();
         const double runtime = gab_now() - t0;
         gab_queue_close(&q);

@@ -330,10 +330,15 @@ typedef struct {
     gab_gpu_init_fn init; gab_chunk_fn run; gab_gpu_fini_fn fini; void *ctx; void *state;
     int64_t done;       /* chunks this worker ran */
     int node;           /* NUMA node the thread was bound to, or -1 */
+    int64_t own_chunk;  /* >= 0: the one chunk this worker runs (gab_queue_run_each) instead of pulling from the cursor */
 } gab_worker;
 static void *gab_worker_main(void *p) {
     gab_worker *w = (gab_worker *)p;
     w->node = gab_bind_thread_to_gpu(w->gpu);               /* (a fresh thread per gab_queue_run: bound before it touches a chunk) */
+    if (w->own_chunk >= 0) {                                /* gab_queue_run_each: worker k's chunk is chunk k (a GPU's own share) */
+        if (w->own_chunk < w->nchunks) { w->run(w->worker, w->gpu, w->own_chunk, w->ctx, w->state); w->done++; }
+        return NULL;
+    }
     for (;;) {
         pthread_mutex_lock(w->mu);
         int64_t c = (*w->cursor)++;
@@ -358,7 +363,7 @@ static inline void gab_queue_open(gab_queue *q, int ngpus, int64_t nchunks, gab_
     for (int k = 0; k < q->nworkers; k++) {
         gab_worker *w = &q->w[k];
         w->worker = k; w->gpu = gab_phys_gpu(k % ngpus); w->cursor = &q->cursor; w->mu = &q->mu;      /* worker k and k + ngpus share a GPU */
-        w->node = -1;
+        w->node = -1; w->own_chunk = -1;
         w->init = init; w->run = run; w->fini = fini; w->ctx = ctx;
         w->state = init ? init(k, w->gpu, ctx) : NULL;
     }
@@ -377,6 +382,12 @@ static inline void gab_queue_run(gab_queue *q, int64_t nchunks) {
         for (int k = 0; k < q->nworkers; k++) fprintf(stderr, " %d:%d@%d", k, q->w[k].gpu, q->w[k].node);
         fprintf(stderr, "\n");
     }
+}
+/* chunk k by worker k -- the chunks are per-GPU shares (share g was laid out for GPU g: its slabs sit on that GPU's NUMA node) */
+static inline void gab_queue_run_each(gab_queue *q, int64_t nchunks) {
+    for (int k = 0; k < q->nworkers; k++) q->w[k].own_chunk = k;
+    gab_queue_run(q, nchunks);
+    for (int k = 0; k < q->nworkers; k++) q->w[k].own_chunk = -1;
 }
 static inline void gab_queue_close(gab_queue *q) {
     for (int k = 0; k < q->nworkers; k++) if (q->w[k].fini) q->w[k].fini(k, q->w[k].gpu, q->w[k].ctx, q->w[k].state);

@@ -187,6 +187,51 @@ def test_chain_shares_two_logical_gpus(inputs, bench, tmp_path):
     assert r1.returncode == 0 and open(o).read() == open(one).read()
 
 
+@pytest.mark.parametrize("bench", ["bsw", "chain", "fast-chain", "bpm", "wfa"])
+@pytest.mark.parametrize("ngpus", [2, 3])
+def test_gpu_parse_with_several_gpus(inputs, bench, ngpus, tmp_path):
+    """GAB_GPU_PARSE=1 with N GPUs (here N logical GPUs on one card, GAB_GPU_OVERSUBSCRIBE=1): the file is cut at record
+    boundaries on the host, every GPU parses ITS piece (gab_*_parse) and runs the kernel on it -- a piece's data never leaves its
+    GPU -- and the output is the one-GPU line-by-line driver's, byte for byte (bsw/src/main_banded.cpp:164-206 and
+    chain/src/host_data_io.cpp:13-51 are the readers this replaces)"""
+    env = dict(os.environ, GAB_GPU_PARSE="1", GAB_GPUS=str(ngpus), GAB_GPU_OVERSUBSCRIBE="1", GAB_QUEUE_REPORT="1")
+    a, b = str(tmp_path / "a.txt"), str(tmp_path / "b.txt")
+    if bench == "bsw":
+        exe = os.path.join(ROOT, "benchmarks", "bsw", "main_bsw")
+        args = [exe, "-pairs", f"{inputs}/bsw/small/bandedSWA_SRR7733443_100k_input.txt", "-t", "1", "-b", "512"]
+        ra = subprocess.run(args, capture_output=True, text=True, timeout=300)
+        rb = subprocess.run(args, capture_output=True, text=True, timeout=300, env=env)
+        assert ra.returncode == 0 and rb.returncode == 0, rb.stderr[-500:]
+        scores = lambda e: [l for l in e.splitlines() if "score=" in l]
+        assert scores(ra.stderr) == scores(rb.stderr) and len(scores(ra.stderr)) == 2048
+        assert f"on {ngpus} GPU(s) (input parsed on the GPU)" in rb.stdout and rb.stdout.count("] workTicks = ") == ngpus
+        report = rb.stderr
+    else:
+        if bench in ("chain", "fast-chain"):
+            exe = os.path.join(ROOT, "benchmarks", bench, "chain")
+            mk = lambda o: [exe, "-i", f"{inputs}/chain/small/in-1k.txt", "-o", o, "-t", "1"]
+        else:
+            exe = os.path.join(ROOT, "benchmarks", bench, "bin", "align_benchmark")
+            name = "BPM" if bench == "bpm" else "WFA"
+            inp = f"{inputs}/{bench}/small/{name}_SRR7733443_100k_input.txt"
+            mk = lambda o: [exe] + (["-a", "bpm-edit"] if bench == "bpm" else []) + ["-i", inp, "-o", o, "-t", "1"]
+        ra = subprocess.run(mk(a), capture_output=True, text=True, timeout=300)
+        rb = subprocess.run(mk(b), capture_output=True, text=True, timeout=300, env=env)
+        assert ra.returncode == 0 and rb.returncode == 0, rb.stderr[-500:]
+        assert "on the GPU" in rb.stderr + rb.stdout
+        key = (lambda l: int(l.split()[0][3:])) if bench == "wfa" else None
+        ta, tb = open(a).read(), open(b).read()
+        if bench == "wfa":
+            ta, tb = sorted(ta.splitlines(), key=key), sorted(tb.splitlines(), key=key)
+        elif bench == "bpm":
+            ta, tb = sorted(ta.splitlines()), sorted(tb.splitlines())
+        assert ta == tb and len(ta) > 0
+        report = rb.stderr
+    line = [l for l in report.splitlines() if l.startswith("gab GPU parse:")][0]
+    per = [int(v) for v in line.split(":")[2].split()]
+    assert len(per) == ngpus and all(v > 0 for v in per) and f"{ngpus} piece(s)" in line
+
+
 def test_queue_spreads_chunks_over_workers(inputs, tmp_path):
     """every chunk runs exactly once, on some worker; more than one worker takes part"""
     exe = os.path.join(ROOT, "benchmarks", "bsw", "main_bsw")
