@@ -112,6 +112,7 @@ __device__ __forceinline__ void backward_ext(const FmiIdx &ix, int64_t k, int64_
 // spread over the whole index and miss.  About a third of all extensions produce such short patterns.
 // Entry of pattern b0 b1 .. b(len-1): index (4^len - 4) / 3 + sum b_i << 2i; values with s == 0 are stored as zeros
 // (an empty interval only ever propagates s == 0, FMI_search.cpp:1040-1051).
+constexpr int kDefaultKmerDepth = 8;      // GAB_FMI_KMER_DEPTH: 0 .. 11 (tuning)
 __device__ __forceinline__ uint32_t kmer_level_off(int len) { return (0x55555555u & ((1u << (2 * len)) - 1u)) - 1u; }
 __device__ __forceinline__ uint4 pack_iv(int64_t k, int64_t l, int64_t s, uint32_t n) {
     uint4 w;
@@ -263,11 +264,23 @@ __global__ __launch_bounds__(64) void fmi_seed_kernel(FmiIdx ix, const uint8_t *
         const uint32_t w0 = lq[(start >> 3) * 64], w1 = lq[((start >> 3) + 1) * 64];   // w1 may be past the read: masked by callers
         return (uint32_t)(((uint64_t)w1 << 32 | w0) >> ((start & 7) * 4));
     };
-    // table index of the pattern of `plen` <= 8 bases starting at `start` (all of them A/C/G/T)
+    // ... sixteen of them (tables deeper than 8 bases, r04): three words
+    auto nibbles_at64 = [&](int start) -> uint64_t {
+        const uint32_t w0 = lq[(start >> 3) * 64], w1 = lq[((start >> 3) + 1) * 64], w2 = lq[((start >> 3) + 2) * 64];   // (w1 / w2 may be past the read: masked by callers; the LDS slack covers them)
+        const int sh = (start & 7) * 4;
+        const uint64_t lo = (uint64_t)w1 << 32 | w0, hi = (uint64_t)w2 << 32 | w1;
+        return sh ? (lo >> sh) | ((hi >> sh) << 32) : lo;
+    };
+    // table index of the pattern of `plen` <= kmer_depth bases starting at `start` (all of them A/C/G/T)
     auto kmer_index = [&](int start, int plen) -> uint32_t {
-        uint32_t v = nibbles_at(start) & 0x33333333u;
-        v = (v | v >> 2) & 0x0f0f0f0fu; v = (v | v >> 4) & 0x00ff00ffu; v = (v | v >> 8) & 0xffffu;
-        return kmer_level_off(plen) + (v & ((1u << (2 * plen)) - 1u));
+        if (D <= 8) {
+            uint32_t v = nibbles_at(start) & 0x33333333u;
+            v = (v | v >> 2) & 0x0f0f0f0fu; v = (v | v >> 4) & 0x00ff00ffu; v = (v | v >> 8) & 0xffffu;
+            return kmer_level_off(plen) + (v & ((1u << (2 * plen)) - 1u));
+        }
+        uint64_t v = nibbles_at64(start) & 0x3333333333333333ull;
+        v = (v | v >> 2) & 0x0f0f0f0f0f0f0f0full; v = (v | v >> 4) & 0x00ff00ff00ff00ffull; v = (v | v >> 8) & 0x0000ffff0000ffffull; v = (v | v >> 16) & 0xffffffffull;
+        return kmer_level_off(plen) + ((uint32_t)v & ((1u << (2 * plen)) - 1u));
     };
     // The interval lists of one seeding position (FMI_search.cpp:531-650: prev[] / curr[]).  Backward columns address
     // the list by v = 0, 1, ... (0 = longest match = the NEWEST forward entry), which makes the reference's reversal
@@ -480,7 +493,9 @@ __global__ __launch_bounds__(64) void fmi_seed_kernel(FmiIdx ix, const uint8_t *
                     state = ST_P3_STEP;
                     // the first D - 1 steps of the walk cannot emit (D < minSeedLen + 1) and only stop at an N or the
                     // read end: with D clean bases ahead their outcome is the table entry of q[x .. x+D-1]
-                    if (D > 1 && D < msl && x + D <= len && (nibbles_at(x) & 0x44444444u & (0xffffffffu >> (32 - 4 * D))) == 0u)
+                    if (D > 1 && D < msl && x + D <= len &&
+                        (D <= 8 ? (nibbles_at(x) & 0x44444444u & (0xffffffffu >> (32 - 4 * D))) == 0u
+                                : (nibbles_at64(x) & 0x4444444444444444ull & (~0ull >> (64 - 4 * D))) == 0ull))
                         state = ST_P3_JUMP;
                 } else x = next_x;
             }
@@ -1082,7 +1097,7 @@ extern "C" int gab_fmi_create(int device, int64_t ref_seq_len, const int64_t cou
     h->ix.kmer_tab = nullptr; h->ix.kmer_depth = 0;
     {   // short-pattern table, level by level (each level extends the previous one by one base to the left)
         const char *e = getenv("GAB_FMI_KMER_DEPTH");
-        const int depth = e ? std::max(0, std::min(8, atoi(e))) : 8;
+        const int depth = e ? std::max(0, std::min(11, atoi(e))) : kDefaultKmerDepth;
         if (depth > 0) {
             const size_t entries = ((((size_t)1 << (2 * (depth + 1))) - 4) / 3 + 3) & ~(size_t)3;
             rc = h->kmer.reserve(entries * sizeof(uint4));
