@@ -814,7 +814,9 @@ constexpr int kCbHelpers = 3;
 //           gap rule never applies) AND max(x) - min(x) < 2^31 (then every x[i] - x[j] of the call is exact in 32 bits).
 // Both hold for every call of the suite's inputs (one reference strand per call); calls that miss either use the generic
 // arithmetic.  Reads x and y once: 16 B per seed at HBM speed.
-__global__ __launch_bounds__(256) void chain_facts_kernel(ChainWork *work, const uint64_t *__restrict__ xs, const uint64_t *__restrict__ ys) {
+__global__ __launch_bounds__(256) void chain_facts_kernel(ChainWork *work, const uint64_t *__restrict__ xs, const uint64_t *__restrict__ ys,
+                                                          const uint32_t *gate = nullptr) {
+    if (gate && gate[blockIdx.x] == 0) return;      // (the launch behind the table form: only the calls it handed back)
     __shared__ unsigned long long s_lo[4], s_hi[4];
     __shared__ int s_mixed[4];
     ChainWork &w = work[blockIdx.x];
@@ -1862,7 +1864,7 @@ static void chain_launch(int mode, int helpers, hipStream_t s, ChainWork *d_work
             hipLaunchKernelGGL((chain_block_kernel<kCbHelpers, true>), dim3(nw), dim3(64 * (1 + kCbHelpers)), 0, s, d_work, d_x, d_y, d_score, d_parent, d_gm, d_ev, feed);
             return;
         }
-        hipLaunchKernelGGL(chain_facts_kernel, dim3(nw), dim3(256), 0, s, d_work, d_x, d_y);
+        hipLaunchKernelGGL(chain_facts_kernel, dim3(nw), dim3(256), 0, s, d_work, d_x, d_y, (const uint32_t *)nullptr);
         if (helpers == 7) hipLaunchKernelGGL((chain_block_kernel_lat<7, false>), dim3(nw), dim3(64 * 8), 0, s, d_work, d_x, d_y, d_score, d_parent, d_gm, d_ev, feed);
         else if (helpers == 5) hipLaunchKernelGGL((chain_block_kernel_lat<5, false>), dim3(nw), dim3(64 * 6), 0, s, d_work, d_x, d_y, d_score, d_parent, d_gm, d_ev, feed);
         else hipLaunchKernelGGL((chain_block_kernel<kCbHelpers, false>), dim3(nw), dim3(64 * (1 + kCbHelpers)), 0, s, d_work, d_x, d_y, d_score, d_parent, d_gm, d_ev, feed);
@@ -1984,13 +1986,15 @@ extern "C" int gab_chain_run_device(gab_chain *h, int mode, const uint64_t *d_x,
     if (ntab || nfast) {
         if ((rc = chain_fast_setup(h)) != GAB_OK) return rc;
         const ChainFeed nofeed{nullptr, nullptr, nullptr, nullptr, nullptr, kFeedSpinLimit};
-        if (mode == GAB_CHAIN) hipLaunchKernelGGL(chain_facts_kernel, dim3((unsigned)nw), dim3(256), 0, s, d_work, d_x, d_y);
+        // (the facts of the calls in the table form are only needed by the few it hands back: taken behind it, gated)
+        if (mode == GAB_CHAIN && nrest) hipLaunchKernelGGL(chain_facts_kernel, dim3((unsigned)nrest), dim3(256), 0, s, d_work + ntab, d_x, d_y, (const uint32_t *)nullptr);
         GAB_HIP(hipEventRecord(h->fe[0], s));
         if (ntab) {
             // the table form and, behind it on the same stream, the latency form for the calls it hands back (bail word set)
             GAB_HIP(hipStreamWaitEvent(h->ts, h->fe[0], 0));
             uint32_t *d_bail = nullptr;
             if ((rc = chain_tab_run(&h->tab, mode, h->ts, d_work, wk.data(), ntab, total, d_x, d_y, d_score, d_parent, d_gm, d_ev, &d_bail)) != GAB_OK) return rc;
+            if (mode == GAB_CHAIN) hipLaunchKernelGGL(chain_facts_kernel, dim3((unsigned)ntab), dim3(256), 0, h->ts, d_work, d_x, d_y, (const uint32_t *)d_bail);
             if (mode == GAB_CHAIN)
                 hipLaunchKernelGGL(chain_fast_kernel<GAB_CHAIN>, dim3((unsigned)ntab), dim3(64 * (2 + kFastW)), kFastDynLds, h->ts, d_work, d_x, d_y, d_score, d_parent, d_gm, d_ev, (const uint32_t *)d_bail);
             else
