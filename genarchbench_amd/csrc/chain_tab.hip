@@ -348,12 +348,23 @@ constexpr int kTabMaxPatch = 8;            // anchors of a call whose result max
 #ifndef GAB_KO_OKH
 #define GAB_KO_OKH 0
 #endif
+#ifndef GAB_KO_MAIN_NEAR      // (with GAB_KO_CERT_FAR = GAB_KO_CERT_NEAR = 1: the keys are garbage, nothing may act on them)
+#define GAB_KO_MAIN_NEAR 0
+#endif
+#ifndef GAB_KO_MAIN_BLOCK
+#define GAB_KO_MAIN_BLOCK 0
+#endif
+#ifndef GAB_KO_MAIN_MERGE
+#define GAB_KO_MAIN_MERGE 0
+#endif
+struct TabDesc { long long grp; int jrow0, ng; };       // what ctab_fold needs of a TabBlock
 struct TabLds {
     int4 G4[2][2][16][64];                // [slot][previous block | block itself][row / 4][anchor]: keys of 4 rows
     int32_t ring[kTabRing + 16];          // (+ the first 16 entries again: sixteen consecutive scores never wrap)
     int32_t part_best[2][kTabFW][64], part_g[2][kTabFW][64];
     int32_t res_key[3][64], res_fg[3][64];
     uint16_t okh[4][8][64];               // chain: one bit per unfiltered near / in-block pair, 16 rows per unit
+    TabDesc desc[256];                    // the descriptors of the blocks around the one in work (see ctab_fold)
     int32_t stop[2];                      // 1: the call goes back to chain.hip; 2: start again from block restart_blk (a new patch)
     int32_t restart_blk, patch_n;
     int32_t patch_blk[kTabMaxPatch], patch_lane[kTabMaxPatch], patch_score[kTabMaxPatch], patch_parent[kTabMaxPatch];
@@ -401,8 +412,19 @@ void ctab_fold(const ChainWork *__restrict__ work, const TabCall *__restrict__ c
     int n_rescans = 0;
     bool stopped = false;
     // workers: descriptor of the block they take next, and its bytes (their G units, their first kTabF far groups)
-    struct Desc { long long grp; int jrow0, ng; };
+    // Block descriptors come from an LDS ring of 256, refilled 64 at a time by the resolver wave: as scalar loads from memory
+    // (s_load, counted by lgkmcnt like every LDS operation) the next wait for ANY LDS read stalled on them -- a trip to L2 or HBM
+    // in every phase of every wave
+    using Desc = TabDesc;
+    // (chain only, and only its resolver, which uses its descriptor at once: +6 %.  The workers ask two phases ahead and keep their
+    // scalar loads, and the fast-chain instantiation has no ring at all: with it -- even unused by the workers -- one fast-chain call
+    // took 2.56 instead of 2.29 ms; the instantiations are scheduled differently by the compiler and nothing else explains it)
+    auto desc_ring = [&](int kb) { Desc d{0, 0, 0}; if (kb < nblocks) d = L.desc[kb & 255]; return d; };
     auto desc_of = [&](int kb) { Desc d{0, 0, 0}; if (kb < nblocks) { const TabBlock tb = B[kb]; d.grp = tb.grp; d.jrow0 = tb.jrow0; d.ng = tb.ng; } return d; };
+    if (!FC) {
+        for (int b = threadIdx.x; b < 192 && b < nblocks; b += 64 * (2 + kTabW)) { const TabBlock tb = B[b]; L.desc[b] = Desc{tb.grp, tb.jrow0, tb.ng}; }
+        __syncthreads();
+    }
     const int wk = wave - 2;
     int min_blk = 0;                                         // blocks below this one are final (a restart does not touch them)
     // a patched anchor: max_skip cut the reference's scan of it short of the plain maximum -- its score and parent are what the
@@ -456,7 +478,7 @@ void ctab_fold(const ChainWork *__restrict__ work, const TabCall *__restrict__ c
                 // the workers' far maxima: groups interleave, so the larger group (= the newer predecessors) wins a tie
                 int32_t fbest = kTabNegH, fg = -1;
 #pragma unroll
-                for (int hh = 0; hh < NF; hh++) {
+                for (int hh = 0; hh < (GAB_KO_MAIN_MERGE ? 1 : NF); hh++) {
                     const int32_t b2 = L.part_best[par ^ 1][hh][lane], g2 = L.part_g[par ^ 1][hh][lane];
                     if (b2 > fbest || (b2 == fbest && g2 > fg)) { fbest = b2; fg = g2; }
                 }
@@ -464,7 +486,7 @@ void ctab_fold(const ChainWork *__restrict__ work, const TabCall *__restrict__ c
                 int32_t key = fg >= 0 ? max(initkey, fbest << 7) : initkey;      // far: code 0 (loses a tie against anything newer)
                 const int4 *gn = &L.G4[par ^ 1][0][0][lane];
                 const int4 *gb = &L.G4[par ^ 1][1][0][lane];
-                if (t > 0) {
+                if (t > 0 && !GAB_KO_MAIN_NEAR) {
                     const int32_t pkey = pbest << 7;
 #pragma unroll
                     for (int g4 = 0; g4 < 16; g4++) {        // the previous block: no dependence between the steps
@@ -480,7 +502,7 @@ void ctab_fold(const ChainWork *__restrict__ work, const TabCall *__restrict__ c
                 // the block itself, in units of four anchors closed by the workers (see there): the kernel's only chain of dependent
                 // steps is four readlanes (the unit's scores before the unit), four adds, two three-way maxima -- per FOUR anchors
 #pragma unroll
-                for (int g4 = 0; g4 < 16; g4++) {
+                for (int g4 = 0; g4 < (GAB_KO_MAIN_BLOCK ? 0 : 16); g4++) {
                     const int4 g = gb[(size_t)g4 * 64];
                     const int32_t x0 = __builtin_amdgcn_readlane(key, 4 * g4) & ~127, x1 = __builtin_amdgcn_readlane(key, 4 * g4 + 1) & ~127,
                                   x2 = __builtin_amdgcn_readlane(key, 4 * g4 + 2) & ~127, x3 = __builtin_amdgcn_readlane(key, 4 * g4 + 3) & ~127;
@@ -611,13 +633,18 @@ void ctab_fold(const ChainWork *__restrict__ work, const TabCall *__restrict__ c
             if (t - 1 >= min_blk && t - 1 < nblocks) {
                 // request what block t - 1 needs: its descriptor, the far lanes' group, the window starts
                 const int r = t - 1;
-                const TabBlock tb = B[r];
-                r_desc.grp = tb.grp; r_desc.jrow0 = tb.jrow0; r_desc.ng = tb.ng;
+                Desc tb;
+                if (FC) tb = desc_of(r); else tb = desc_ring(r);
+                r_desc = tb;
                 const int32_t rk = L.res_key[r % 3][lane], fg = L.res_fg[r % 3][lane];
                 const bool mine = r * 64 + lane < n;
                 r_gw = make_uint4(0, 0, 0, 0);
                 if (mine && rk >= 0 && (rk & 127) == 0) r_gw = T8[(tb.grp + fg) * 64 + lane];
                 r_st = mine ? ST[r * 64 + lane] : 0;
+            }
+            if (!FC && t >= 0 && (t & 63) == 0) {            // the descriptors of blocks t + 128 .. t + 191 (their slots held t - 128 .. t - 65)
+                const int b = t + 128 + lane;
+                if (b < nblocks) { const TabBlock tb = B[b]; L.desc[b & 255] = Desc{tb.grp, tb.jrow0, tb.ng}; }
             }
         } else if (t + 1 < nblocks) {
             // ------------------------------------------------ workers: block t + 1 from the registers filled a phase ago
