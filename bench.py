@@ -1389,7 +1389,7 @@ def run_workload(W, items, steps, warmup, ctx, args, with_cpu=True, with_host=Tr
     return out
 
 
-def finish_cpu_ratios(out, world, host_threads):
+def finish_cpu_ratios(out, world, host_threads, quota=None):
     """per-core figure, the quota in words, and the ratios GPU / CPU: like for like -- the CPU figure is the reference's
     ROI, marshalling included, so the GPU figure beside it is the drop-in ROI including PCIe; the HBM-resident ratio is kept under
     its own name"""
@@ -1398,8 +1398,10 @@ def finish_cpu_ratios(out, world, host_threads):
         return
     cores = max(int(cb.get("cores") or 1), 1)
     cb["per_core"] = round(cb["value"] / cores, 4)
-    if cores < (host_threads or cores):
-        cb["sample"] = f"{cores}-core cgroup quota of a {host_threads}-thread host; " + str(cb.get("sample", ""))
+    quota = quota or host_cores()
+    if quota < (host_threads or quota):
+        used = "" if cores == quota else f", {cores} thread(s) of it used"
+        cb["sample"] = f"{quota}-core cgroup quota of a {host_threads}-thread host{used}; " + str(cb.get("sample", ""))
     out["extra"]["x_cpu_baseline_hbm_resident"] = round(v / world / cb["value"], 2)
     if out["extra"].get("value_roi_incl_pcie"):
         out["extra"]["x_cpu_baseline"] = round(out["extra"]["value_roi_incl_pcie"] / cb["value"], 2)

@@ -328,7 +328,13 @@ __device__ __forceinline__ void bpm_score32_body(uint64_t *peq_s, BpmIO io, cons
     if (k < kend) {
         const uint32_t id = perm ? perm[k] : k;
         const int n = io.pat_len[id], m = io.txt_len[id];
+#ifdef GAB_KO_BPM_LOCAL_TEXT      // measurement only (wrong results; bench inputs only, whose offsets ascend): every lane of a wave reads
+                                  // the strings of the wave's FIRST pair -- what a perfectly coalesced text layout could gain at most
+        const uint32_t id0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)id);
+        const char *p = io.pat + io.pat_off[id0], *t = io.txt + io.txt_off[id0];
+#else
         const char *p = io.pat + io.pat_off[id], *t = io.txt + io.txt_off[id];
+#endif
         uint64_t *peq = peq_s + threadIdx.x;
         bool clean = bpm_build_peq<W>(peq, p, n);
         uint32_t P[D], M[D];

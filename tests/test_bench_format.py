@@ -56,13 +56,17 @@ def test_x_cpu_baseline_is_like_for_like():
     """extra.x_cpu_baseline = ROI incl. PCIe / CPU baseline; the HBM-resident ratio has its own name; per-core figure and the
     quota are stated (bench.finish_cpu_ratios is what run_one() calls on a fresh result)"""
     out = {"value": 220.0, "extra": {"value_roi_incl_pcie": 170.0}, "cpu_baseline": {"value": 7.75, "cores": 16, "sample": "first 4000000 pairs", "kind": "reference"}}
-    bench.finish_cpu_ratios(out, world=1, host_threads=256)
+    bench.finish_cpu_ratios(out, world=1, host_threads=256, quota=16)
     assert out["extra"]["x_cpu_baseline"] == round(170.0 / 7.75, 2) and out["extra"]["x_cpu_baseline_hbm_resident"] == round(220.0 / 7.75, 2)
     assert out["cpu_baseline"]["per_core"] == round(7.75 / 16, 4) and out["cpu_baseline"]["sample"].startswith("16-core cgroup quota of a 256-thread host")
     assert abs(out["extra"]["cpu_cores_equivalent"] - 170.0 / (7.75 / 16)) < 0.2
     out2 = {"value": 220.0, "extra": {}, "cpu_baseline": {"value": 7.75, "cores": 16, "sample": "s", "kind": "reference"}}
-    bench.finish_cpu_ratios(out2, world=1, host_threads=16)
+    bench.finish_cpu_ratios(out2, world=1, host_threads=16, quota=16)
     assert out2["extra"]["x_cpu_baseline"] is None and out2["extra"]["x_cpu_baseline_hbm_resident"] > 0       # no host ROI measured: no like-for-like figure
+    # a one-thread baseline (the line readers) on the same box: the quota is the box's, the threads used are said beside it
+    out3 = {"value": 3.0, "extra": {}, "cpu_baseline": {"value": 0.36, "cores": 1, "sample": "s", "kind": "reference"}}
+    bench.finish_cpu_ratios(out3, world=1, host_threads=256, quota=16)
+    assert out3["cpu_baseline"]["sample"].startswith("16-core cgroup quota of a 256-thread host, 1 thread(s) of it used; ") and out3["cpu_baseline"]["per_core"] == 0.36
 
 
 def test_emit_prints_suite_lines_then_the_headline_last(tmp_path):
