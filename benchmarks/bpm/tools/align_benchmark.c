@@ -78,6 +78,7 @@ static void bgp_parse(int g, void *v) {
     if (G->bitpal >= 0) { if (gab_bitpal_create(G->bitpal, p->dev, &p->hb) != 0) return; }
     else if (gab_bpm_create(p->dev, &p->h) != 0) return;
     if (gab_device_alloc(p->dev, 4 * (size_t)p->pk.n + 4, (void **)&p->d_score) != 0) return;
+    if (G->bitpal >= 0 ? gab_bitpal_reserve(p->hb, p->pk.n, 0) != 0 : gab_bpm_reserve(p->h, p->pk.n, 0) != 0) return;   /* before the region of interest */
     p->ok = 1;
 }
 static void bgp_run(int g, void *v) {
@@ -127,7 +128,7 @@ int main(int argc, char **argv) {
     /* GAB_GPU_PARSE=1: the file is read in one piece, cut in front of '>' lines into one piece per GPU, and every GPU indexes ITS
      * piece (gab_pairs_parse with the swap rule); the sequences are used in place in that GPU's copy of the text. */
     const int64_t fsz = gab_regular_file_size(in);      /* -1 for pipes: they take the getline path */
-    if (getenv("GAB_GPU_PARSE") && atoi(getenv("GAB_GPU_PARSE")) && fsz >= 0) {
+    if (gab_gpu_parse_wanted(1) && fsz >= 0) {
         const int ng = gab_pick_gpus(gpus);
         char *whole = (char *)malloc((size_t)fsz + 1);
         bgp_ctx G;
@@ -164,7 +165,7 @@ int main(int argc, char **argv) {
             free(G.score);
             return 0;
         }
-        fprintf(stderr, "GPU parser declined the file (%s); using the getline parser\n", gab_last_error());
+        if (getenv("GAB_GPU_PARSE")) fprintf(stderr, "GPU parser declined the file (%s); using the getline parser\n", gab_last_error());      /* (asked for by name: say so; the default falls back silently) */
         for (int g = 0; g < ng; g++) { bgp_part *q = &G.part[g]; if (q->d_score) gab_device_free(q->dev, q->d_score); gab_bpm_destroy(q->h); gab_bitpal_destroy(q->hb); if (q->ps) gab_parser_destroy(q->ps); }
         free(whole);
         fseek(in, 0L, SEEK_SET);

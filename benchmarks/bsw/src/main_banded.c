@@ -13,7 +13,7 @@
  * the kernels of another).  -t and -b are accepted and ignored (they tune the CPU path only); -g / $GAB_GPUS selects the
  * number of GPUs.
  *
- * GAB_GPU_PARSE=1: the input file is read in one piece, cut at pair boundaries into one piece per GPU, and every GPU parses
+ * Default (GAB_GPU_PARSE=0 turns it off): the input file is read in one piece, cut at pair boundaries into one piece per GPU, and every GPU parses
  * ITS piece (gab_bsw_parse_pairs) instead of the host reading line by line with fgets / sscanf; the packed
  * buffers stay on the GPU that parsed them and the ROI is one gab_bsw_run_device per GPU.  Files the GPU parser does not accept
  * (a line that hits one of the reference's buffer limits) fall back to the line-by-line path below.
@@ -71,6 +71,7 @@ static void gpp_parse(int g, void *v) {
     if (gab_bsw_parse_pairs(p->ps, G->whole + G->cut[g], (int64_t)(G->cut[g + 1] - G->cut[g]), &p->pk, NULL) != 0) return;
     if (gab_bsw_create(&G->prm, p->dev, &p->h) != 0) return;
     if (gab_device_alloc(p->dev, 4 * (size_t)p->pk.n + 4, (void **)&p->d_score) != 0) return;
+    if (gab_bsw_reserve(p->h, p->pk.n, 0, 0) != 0) return;       /* work space, first launches: before the region of interest */
     p->ok = 1;
 }
 static void gpp_run(int g, void *v) {
@@ -119,7 +120,7 @@ int main(int argc, char *argv[]) {
 
     /* a pipe / process substitution has no size: only regular files take the whole-file GPU parser */
     const int64_t fsz = gab_regular_file_size(pairFile);
-    if (getenv("GAB_GPU_PARSE") && atoi(getenv("GAB_GPU_PARSE")) && fsz >= 0) {
+    if (gab_gpu_parse_wanted(1) && fsz >= 0) {
         const double tR0 = gab_now();
         const int ng = gab_pick_gpus(gpus);
         char *whole = (char *)malloc((size_t)fsz + 1);
@@ -168,7 +169,7 @@ int main(int argc, char *argv[]) {
             free(G.score);
             return 0;
         }
-        fprintf(stderr, "GPU parser declined the file (%s); using the line-by-line parser\n", gab_last_error());
+        if (getenv("GAB_GPU_PARSE")) fprintf(stderr, "GPU parser declined the file (%s); using the line-by-line parser\n", gab_last_error());      /* (asked for by name: say so; the default falls back silently) */
         for (int g = 0; g < ng; g++) { if (G.part[g].d_score) gab_device_free(G.part[g].dev, G.part[g].d_score); if (G.part[g].h) gab_bsw_destroy(G.part[g].h); if (G.part[g].ps) gab_parser_destroy(G.part[g].ps); }
         free(whole);
         fseek(pairFile, 0L, SEEK_SET);

@@ -121,6 +121,7 @@ static void cgp_parse(int g, void *v) {
     p->sc = (int32_t *)malloc(4 * t + 4); p->pa = (int32_t *)malloc(4 * t + 4);
     if (!p->sc || !p->pa) return;
     gab_pin_out_on(p->dev, p->sc, 4 * t + 4); gab_pin_out_on(p->dev, p->pa, 4 * t + 4);
+    if (gab_chain_reserve(p->h, p->pk.total, p->pk.ncalls) != 0) return;      /* work tables, streams, first launches: before the region of interest */
     p->ok = 1;
 }
 static void cgp_run(int g, void *v) {
@@ -178,7 +179,7 @@ int main(int argc, char **argv) {
      * (gab_chain_parse); the anchors stay on the GPU that parsed them, the ROI is one gab_chain_run_device per
      * GPU.  Files that are not in the one-record-per-line layout are declined and take the fscanf path below. */
     const int64_t fsz = gab_regular_file_size(in);      /* -1 for pipes: they take the fscanf path */
-    if (getenv("GAB_GPU_PARSE") && atoi(getenv("GAB_GPU_PARSE")) && fsz >= 0) {
+    if (gab_gpu_parse_wanted(0) && fsz >= 0) {
         const int ng = gab_pick_gpus(gpus);
         char *whole = (char *)malloc((size_t)fsz + 1);
         cgp_ctx G;
@@ -221,7 +222,7 @@ int main(int argc, char **argv) {
             }
             return 0;
         }
-        fprintf(stderr, "GPU parser declined the file (%s); using the fscanf parser\n", gab_last_error());
+        if (getenv("GAB_GPU_PARSE")) fprintf(stderr, "GPU parser declined the file (%s); using the fscanf parser\n", gab_last_error());      /* (asked for by name: say so; the default falls back silently) */
         for (int g = 0; g < ng; g++) {
             cgp_part *p = &G.part[g];
             if (p->d_score) gab_device_free(p->dev, p->d_score);

@@ -58,7 +58,7 @@ static double tv_now(void) { struct timeval tv; gettimeofday(&tv, NULL); return 
 typedef struct {
     int dev, ok;
     gab_parser *ps; gab_pairs_packed pk; gab_wfa *h;
-    char *d_ops, *ops; int32_t *d_len, *d_score, *olen; int64_t *ooff;
+    char *d_ops, *cig; int64_t cig_cap; int32_t *score, *olen; int64_t *ooff;
 } wgp_part;
 typedef struct { int ng; const char *whole; size_t cut[65]; wgp_part part[64]; const wfa_ctx *wctx; } wgp_ctx;
 static void wgp_parse(int g, void *v) {
@@ -69,22 +69,35 @@ static void wgp_parse(int g, void *v) {
     if (gab_pairs_parse(p->ps, G->whole + G->cut[g], (int64_t)(G->cut[g + 1] - G->cut[g]), 0, &p->pk, NULL) != 0) return;
     gab_wfa_penalties pen; pen.mismatch = G->wctx->pen.mismatch; pen.gap_opening = G->wctx->pen.gap_opening; pen.gap_extension = G->wctx->pen.gap_extension;
     if (gab_wfa_create_reduced(&pen, G->wctx->min_wavefront_length, G->wctx->max_distance_threshold, p->dev, &p->h) != 0) return;
-    if (gab_device_alloc(p->dev, (size_t)p->pk.cap_bytes + 16, (void **)&p->d_ops) != 0 || gab_device_alloc(p->dev, 4 * (size_t)p->pk.n + 4, (void **)&p->d_len) != 0 ||
-        gab_device_alloc(p->dev, 4 * (size_t)p->pk.n + 4, (void **)&p->d_score) != 0) return;
-    p->ops = (char *)malloc((size_t)p->pk.cap_bytes + 16);
-    p->ooff = (int64_t *)malloc(8 * (size_t)p->pk.n + 8); p->olen = (int32_t *)malloc(4 * (size_t)p->pk.n + 4);
-    if (!p->ops || !p->ooff || !p->olen) return;
+    const size_t n = (size_t)p->pk.n;
+    if (gab_device_alloc(p->dev, (size_t)p->pk.cap_bytes + 16, (void **)&p->d_ops) != 0) return;
+    /* the printed text of the piece: a quarter of its operation room (a 151-bp read pair at 2 % needs ~20 of its 302 bytes); page-locked
+     * like the index, and -- with the handle's buffers and first launches (gab_wfa_reserve) -- made before the region of interest */
+    p->cig_cap = ((int64_t)p->pk.cap_bytes / 4 + 4096 + 255) & ~(int64_t)255;
+    p->cig = (char *)malloc((size_t)p->cig_cap + 16);
+    p->ooff = (int64_t *)malloc(8 * n + 8); p->olen = (int32_t *)malloc(4 * n + 4); p->score = (int32_t *)malloc(4 * n + 4);
+    if (!p->cig || !p->ooff || !p->olen || !p->score) return;
+    gab_pin_out_on(p->dev, p->cig, (size_t)p->cig_cap + 16); gab_pin_out_on(p->dev, p->ooff, 8 * n + 8);
+    gab_pin_out_on(p->dev, p->olen, 4 * n + 4); gab_pin_out_on(p->dev, p->score, 4 * n + 4);
+    if (gab_wfa_reserve(p->h, p->pk.n, 0, p->cig_cap) != 0) return;
     p->ok = 1;
 }
 static void wgp_run(int g, void *v) {
     wgp_part *p = &((wgp_ctx *)v)->part[g];
     const gab_pairs_packed *pk = &p->pk;
     if (pk->n == 0) return;
-    GAB_DIE_IF(gab_wfa_run_device(p->h, pk->d_text, pk->text_bytes, pk->d_pat_off, pk->d_pat_len, pk->d_text, pk->text_bytes, pk->d_txt_off,
-                                  pk->d_txt_len, pk->n, p->d_ops, pk->d_cap_off, p->d_len, p->d_score, NULL), "gab_wfa_run_device");
-    GAB_DIE_IF(gab_device_copy_to_host(p->dev, p->ops, p->d_ops, (size_t)pk->cap_bytes), "gab_device_copy_to_host");
-    GAB_DIE_IF(gab_device_copy_to_host(p->dev, p->ooff, pk->d_cap_off, 8 * (size_t)pk->n), "gab_device_copy_to_host");
-    GAB_DIE_IF(gab_device_copy_to_host(p->dev, p->olen, p->d_len, 4 * (size_t)pk->n), "gab_device_copy_to_host");
+    int64_t need = 0;
+    int rc = gab_wfa_run_packed_device(p->h, pk->d_text, pk->text_bytes, pk->d_pat_off, pk->d_pat_len, pk->d_text, pk->text_bytes, pk->d_txt_off,
+                                       pk->d_txt_len, pk->n, p->d_ops, pk->d_cap_off, p->cig, p->cig_cap, p->ooff, p->olen, p->score, &need);
+    if (rc == GAB_ERANGE) {              /* more text than a quarter of the operation room (very divergent pairs): room for all of it */
+        gab_unpin(p->cig); free(p->cig);
+        p->cig_cap = need; p->cig = (char *)malloc((size_t)need + 16);
+        if (!p->cig) { fprintf(stderr, "ERROR: out of memory\n"); exit(EXIT_FAILURE); }
+        rc = gab_wfa_run_packed_device(p->h, pk->d_text, pk->text_bytes, pk->d_pat_off, pk->d_pat_len, pk->d_text, pk->text_bytes, pk->d_txt_off,
+                                       pk->d_txt_len, pk->n, p->d_ops, pk->d_cap_off, p->cig, p->cig_cap, p->ooff, p->olen, p->score, &need);
+        gab_pin(p->cig, (size_t)need + 16);         /* (so that the clean-up below unpins what it expects) */
+    }
+    GAB_DIE_IF(rc, "gab_wfa_run_packed_device");
 }
 
 int main(int argc, char **argv) {
@@ -133,7 +146,7 @@ int main(int argc, char **argv) {
      * piece (gab_pairs_parse, no swap); sequences are used in place in that GPU's copy of the text, the CIGARs
      * of a piece come back in one copy. */
     const int64_t fsz = gab_regular_file_size(in);      /* -1 for pipes: they take the getline path */
-    if (getenv("GAB_GPU_PARSE") && atoi(getenv("GAB_GPU_PARSE")) && fsz >= 0) {
+    if (gab_gpu_parse_wanted(1) && fsz >= 0) {
         const int ng = gab_pick_gpus(gpus);
         char *whole = (char *)malloc((size_t)fsz + 1);
         wgp_ctx G;
@@ -157,9 +170,7 @@ int main(int argc, char **argv) {
                 if (out)
                     for (int64_t i = 0; i < q->pk.n; i++) {
                         fprintf(out, "id=%ld ", (long)(n + i));
-                        const char *o = q->ops + q->ooff[i];
-                        const int len = q->olen[i];
-                        for (int k = 0; k < len;) { int r = k; while (r < len && o[r] == o[k]) r++; fprintf(out, "%d%c", r - k, o[k]); k = r; }
+                        fwrite(q->cig + q->ooff[i], 1, (size_t)q->olen[i], out);        /* already the printed text */
                         fprintf(out, "\n");
                     }
                 n += q->pk.n;
@@ -175,20 +186,24 @@ int main(int argc, char **argv) {
             }
             for (int g = 0; g < ng; g++) {
                 wgp_part *q = &G.part[g];
-                gab_device_free(q->dev, q->d_ops); gab_device_free(q->dev, q->d_len); gab_device_free(q->dev, q->d_score);
-                gab_wfa_destroy(q->h); gab_parser_destroy(q->ps); free(q->ops); free(q->ooff); free(q->olen);
+                gab_device_free(q->dev, q->d_ops);
+                gab_wfa_destroy(q->h); gab_parser_destroy(q->ps);
+                gab_unpin(q->cig); gab_unpin(q->ooff); gab_unpin(q->olen); gab_unpin(q->score);
+                free(q->cig); free(q->ooff); free(q->olen); free(q->score);
             }
             return 0;
         }
-        fprintf(stderr, "GPU parser declined the file (%s); using the getline parser\n", gab_last_error());
+        if (getenv("GAB_GPU_PARSE")) fprintf(stderr, "GPU parser declined the file (%s); using the getline parser\n", gab_last_error());      /* (asked for by name: say so; the default falls back silently) */
         for (int g = 0; g < ng; g++) {
             wgp_part *q = &G.part[g];
             if (q->d_ops) gab_device_free(q->dev, q->d_ops);
-            if (q->d_len) gab_device_free(q->dev, q->d_len);
-            if (q->d_score) gab_device_free(q->dev, q->d_score);
             if (q->h) gab_wfa_destroy(q->h);
             if (q->ps) gab_parser_destroy(q->ps);
-            free(q->ops); free(q->ooff); free(q->olen);
+            if (q->cig) gab_unpin(q->cig);
+            if (q->ooff) gab_unpin(q->ooff);
+            if (q->olen) gab_unpin(q->olen);
+            if (q->score) gab_unpin(q->score);
+            free(q->cig); free(q->ooff); free(q->olen); free(q->score);
         }
         free(whole);
         fseek(in, 0L, SEEK_SET);

@@ -1414,6 +1414,63 @@ extern "C" int gab_wfa_run_packed(gab_wfa *h, const char *pat, const int64_t *pa
     return GAB_OK;
 }
 
+// gab_wfa_run_packed for pairs that are ALREADY on the device (a driver whose read phase parsed the file there, SURVEY.md 8f row
+// f1): inputs as gab_wfa_run_device takes them, `ops` / `ops_off` = operation room on the device (scratch of the caller), the
+// result as gab_wfa_run_packed returns it -- the printed text and its index in HOST memory.  Nothing but that text, the offsets,
+// lengths and scores crosses the bus.
+extern "C" int gab_wfa_run_packed_device(gab_wfa *h, const char *pat, int64_t pat_bytes, const int64_t *pat_off, const int32_t *pat_len,
+                                         const char *txt, int64_t txt_bytes, const int64_t *txt_off, const int32_t *txt_len, int64_t n,
+                                         char *ops, const int64_t *ops_off, char *cigar_out, int64_t capacity, int64_t *cigar_off_out,
+                                         int32_t *cigar_len_out, int32_t *score_out, int64_t *cigar_bytes) {
+    GAB_CHECK(h, "gab_wfa_run_packed_device: NULL handle");
+    GAB_CHECK(n >= 0 && n < (1ll << 31), "gab_wfa_run_packed_device: n=%lld out of range", (long long)n);
+    if (cigar_bytes) *cigar_bytes = 0;
+    if (n == 0) return GAB_OK;
+    GAB_CHECK(pat && pat_off && pat_len && txt && txt_off && txt_len && ops && ops_off && cigar_off_out && cigar_len_out && score_out &&
+              capacity >= 0 && (cigar_out || capacity == 0), "gab_wfa_run_packed_device: NULL buffer");
+    gab_device_guard g(h->device);
+    const size_t nn = (size_t)n, cpad = ((size_t)capacity + 255) & ~(size_t)255;
+    size_t o = 0;
+    const size_t o_txt = o; o += cpad;
+    const size_t o_co = o; o += 8 * nn;
+    const size_t o_ol = o; o += 4 * nn;
+    const size_t o_cl = o; o += 4 * nn;
+    const size_t o_sc = o; o += 4 * nn;
+    o = (o + 255) & ~(size_t)255;                  // (a 64-bit atomic lives here)
+    const size_t o_cur = o; o += 256;
+    GAB_CHECK_ATOMIC64(o_cur);
+    int rc = h->io.reserve(o);
+    if (rc) return rc;
+    char *b = h->io.as<char>();
+    hipStream_t s = nullptr;
+    if ((rc = h->hs.get(&s)) != GAB_OK) return rc;
+    rc = gab_wfa_run_device(h, pat, pat_bytes, pat_off, pat_len, txt, txt_bytes, txt_off, txt_len, n, ops, ops_off, (int32_t *)(b + o_ol),
+                            (int32_t *)(b + o_sc), s);
+    if (rc) return rc;
+    const unsigned grid = (unsigned)((nn + 255) / 256);
+    GAB_HIP(hipMemsetAsync(b + o_cur, 0, 8, s));
+    hipLaunchKernelGGL(wfa_rle_pack, dim3(grid), dim3(256), 0, s, (const char *)ops, ops_off, (const int32_t *)(b + o_ol), (uint32_t)n, b + o_txt,
+                       (unsigned long long)capacity, (unsigned long long *)(b + o_cur), (int64_t *)(b + o_co), (int32_t *)(b + o_cl));
+    GAB_HIP(hipGetLastError());
+    unsigned long long *h_cur = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(h->h_ct) + 128);
+    GAB_HIP(hipMemcpyAsync(h_cur, b + o_cur, 8, hipMemcpyDeviceToHost, s));
+    GAB_HIP(hipMemcpyAsync(cigar_off_out, b + o_co, 8 * nn, hipMemcpyDeviceToHost, s));
+    GAB_HIP(hipMemcpyAsync(cigar_len_out, b + o_cl, 4 * nn, hipMemcpyDeviceToHost, s));
+    GAB_HIP(hipMemcpyAsync(score_out, b + o_sc, 4 * nn, hipMemcpyDeviceToHost, s));
+    GAB_HIP(hipStreamSynchronize(s));
+    const int64_t total = (int64_t)*h_cur;
+    if (cigar_bytes) *cigar_bytes = total;
+    if (total > capacity) {
+        gab_set_error("gab_wfa_run_packed_device: %lld bytes of CIGAR text do not fit the caller's %lld", (long long)total, (long long)capacity);
+        return GAB_ERANGE;
+    }
+    if (total) {
+        GAB_HIP(hipMemcpyAsync(cigar_out, b + o_txt, (size_t)total, hipMemcpyDeviceToHost, s));
+        GAB_HIP(hipStreamSynchronize(s));
+    }
+    return GAB_OK;
+}
+
 // see gab_bpm_reserve; max_ops_bytes = the room of the CIGAR operations (pattern + text length per pair)
 extern "C" int gab_wfa_reserve(gab_wfa *h, int64_t max_pairs, int64_t max_seq_bytes, int64_t max_ops_bytes) {
     GAB_CHECK(h, "gab_wfa_reserve: NULL handle");

@@ -77,6 +77,21 @@ class AffineWavefronts:
                                        C.c_void_p(ops.data_ptr()), C.c_void_p(ops_off.data_ptr()),
                                        C.c_void_p(ops_len.data_ptr()), C.c_void_p(score.data_ptr()), C.c_void_p(stream)))
 
+    def run_packed_device(self, pat, pat_off, pat_len, txt, txt_off, txt_len, ops, ops_off, capacity):
+        """device tensors in (as run_device; `ops` / `ops_off` = operation room on the device), the printed text out to host
+        arrays: (text uint8, text_off, text_len, score, bytes needed) -- gab_wfa_run_packed_device.  Raises GabError(-34) when
+        `capacity` bytes do not hold the text."""
+        n = pat_len.numel()
+        text = np.zeros(int(capacity) + 16, np.uint8)
+        off = np.full(n, -1, np.int64); ln = np.full(n, -1, np.int32); sc = np.full(n, -1, np.int32)
+        need = C.c_int64(0)
+        check(lib().gab_wfa_run_packed_device(self._h, C.c_void_p(pat.data_ptr()), C.c_int64(pat.numel()), C.c_void_p(pat_off.data_ptr()),
+                                              C.c_void_p(pat_len.data_ptr()), C.c_void_p(txt.data_ptr()), C.c_int64(txt.numel()),
+                                              C.c_void_p(txt_off.data_ptr()), C.c_void_p(txt_len.data_ptr()), C.c_int64(n),
+                                              C.c_void_p(ops.data_ptr()), C.c_void_p(ops_off.data_ptr()), _p(text), C.c_int64(int(capacity)),
+                                              _p(off), _p(ln), _p(sc), C.byref(need)))
+        return text[:need.value], off, ln, sc, need.value
+
     def last_stats(self):
         w = C.c_int64(0); r = C.c_int64(0); a = C.c_float(0); b = C.c_float(0)
         check(lib().gab_wfa_last_stats(self._h, C.byref(w), C.byref(r), C.byref(a), C.byref(b)))

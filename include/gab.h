@@ -265,6 +265,13 @@ int gab_wfa_run_packed(gab_wfa *h, const char *pat, const int64_t *pat_off, cons
                        const char *txt, const int64_t *txt_off, const int32_t *txt_len, int64_t n,
                        char *cigar_out, int64_t capacity, int64_t *cigar_off_out, int32_t *cigar_len_out,
                        int32_t *score_out, int64_t *cigar_bytes);
+/* The same for pairs that are already on the device (the read phase parsed the file there: gab_pairs_parse): DEVICE pointers in as
+ * for gab_wfa_run_device -- `ops` / `ops_off` is operation room on the device, pattern_length + text_length bytes per pair, scratch
+ * of the caller -- and the printed text, offsets, lengths and scores out to HOST memory as above (GAB_ERANGE likewise). */
+int gab_wfa_run_packed_device(gab_wfa *h, const char *pat, int64_t pat_bytes, const int64_t *pat_off, const int32_t *pat_len,
+                              const char *txt, int64_t txt_bytes, const int64_t *txt_off, const int32_t *txt_len, int64_t n,
+                              char *ops, const int64_t *ops_off, char *cigar_out, int64_t capacity, int64_t *cigar_off_out,
+                              int32_t *cigar_len_out, int32_t *score_out, int64_t *cigar_bytes);
 /* device buffers (sequence slabs readable to a multiple of 4 bytes past the last base);
  * synchronises `stream` internally between its passes */
 int gab_wfa_run_device(gab_wfa *h, const char *pat, int64_t pat_bytes, const int64_t *pat_off,

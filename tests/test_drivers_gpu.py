@@ -52,7 +52,7 @@ def test_bsw_driver_gpu_parse_mode(inputs, tmp_path):
     to the line-by-line mode, and a file the GPU parser declines falls back to it"""
     exe = os.path.join(ROOT, "benchmarks", "bsw", "main_bsw")
     inp = f"{inputs}/bsw/small/bandedSWA_SRR7733443_100k_input.txt"
-    a = subprocess.run([exe, "-pairs", inp, "-t", "1", "-b", "512"], capture_output=True, text=True, timeout=300)
+    a = subprocess.run([exe, "-pairs", inp, "-t", "1", "-b", "512"], capture_output=True, text=True, timeout=300, env=HOST_ENV)
     b = subprocess.run([exe, "-pairs", inp, "-t", "1", "-b", "512"], capture_output=True, text=True, timeout=300,
                        env=dict(os.environ, GAB_GPU_PARSE="1", GAB_GPUS="1"))
     assert a.returncode == 0 and b.returncode == 0, b.stderr[-500:]
@@ -72,7 +72,7 @@ def test_chain_driver_gpu_parse_mode(inputs, tmp_path, bench):
     exe = os.path.join(ROOT, "benchmarks", bench, "chain")
     inp = f"{inputs}/chain/small/in-1k.txt"
     a, b = str(tmp_path / "a.txt"), str(tmp_path / "b.txt")
-    ra = subprocess.run([exe, "-i", inp, "-o", a, "-t", "1"], capture_output=True, text=True, timeout=300)
+    ra = subprocess.run([exe, "-i", inp, "-o", a, "-t", "1"], capture_output=True, text=True, timeout=300, env=HOST_ENV)
     rb = subprocess.run([exe, "-i", inp, "-o", b, "-t", "1"], capture_output=True, text=True, timeout=300,
                         env=dict(os.environ, GAB_GPU_PARSE="1", GAB_GPUS="1"))
     assert ra.returncode == 0 and rb.returncode == 0, rb.stderr[-500:]
@@ -85,7 +85,7 @@ def test_bpm_driver_gpu_parse_mode(inputs, tmp_path):
     exe = os.path.join(ROOT, "benchmarks", "bpm", "bin", "align_benchmark")
     inp = f"{inputs}/bpm/small/BPM_SRR7733443_100k_input.txt"
     a, b = str(tmp_path / "a.txt"), str(tmp_path / "b.txt")
-    ra = subprocess.run([exe, "-a", "bpm-edit", "-i", inp, "-o", a, "-t", "1"], capture_output=True, text=True, timeout=300)
+    ra = subprocess.run([exe, "-a", "bpm-edit", "-i", inp, "-o", a, "-t", "1"], capture_output=True, text=True, timeout=300, env=HOST_ENV)
     rb = subprocess.run([exe, "-a", "bpm-edit", "-i", inp, "-o", b, "-t", "1"], capture_output=True, text=True, timeout=300,
                         env=dict(os.environ, GAB_GPU_PARSE="1", GAB_GPUS="1"))
     assert ra.returncode == 0 and rb.returncode == 0, rb.stderr[-500:]
@@ -100,7 +100,7 @@ def test_wfa_driver_gpu_parse_mode(inputs, tmp_path):
     if not os.path.exists(inp):
         inp = [os.path.join(f"{inputs}/wfa/small", f) for f in os.listdir(f"{inputs}/wfa/small") if "input" in f][0]
     a, b = str(tmp_path / "a.txt"), str(tmp_path / "b.txt")
-    ra = subprocess.run([exe, "-i", inp, "-o", a, "-t", "1"], capture_output=True, text=True, timeout=300)
+    ra = subprocess.run([exe, "-i", inp, "-o", a, "-t", "1"], capture_output=True, text=True, timeout=300, env=HOST_ENV)
     rb = subprocess.run([exe, "-i", inp, "-o", b, "-t", "1"], capture_output=True, text=True, timeout=300,
                         env=dict(os.environ, GAB_GPU_PARSE="1", GAB_GPUS="1"))
     assert ra.returncode == 0 and rb.returncode == 0, rb.stderr[-500:]
@@ -114,7 +114,7 @@ def test_wfa_driver_adaptive_flags(tmp_path):
     from tests.util import GOLDEN
     exe = os.path.join(ROOT, "benchmarks", "wfa", "bin", "align_benchmark")
     want = open(f"{GOLDEN}/wfa_adv.adaptive_5_3.expected.txt").read()
-    for env in ({}, {"GAB_GPU_PARSE": "1", "GAB_GPUS": "1"}):
+    for env in ({"GAB_GPU_PARSE": "0"}, {"GAB_GPU_PARSE": "1", "GAB_GPUS": "1"}):
         out = str(tmp_path / "o.txt")
         r = subprocess.run([exe, "-i", f"{GOLDEN}/wfa_adv.in.txt", "-o", out, "--minimum-wavefront-length", "5",
                             "--maximum-difference-distance", "3"], capture_output=True, text=True, timeout=300,
@@ -130,7 +130,7 @@ def test_bpm_driver_bitpal_algorithms(tmp_path, alg):
     from tests.util import GOLDEN
     exe = os.path.join(ROOT, "benchmarks", "bpm", "bin", "align_benchmark")
     want = open(f"{GOLDEN}/bpm_adv.{alg.replace('-', '_')}.expected.txt").read()
-    for env in ({}, {"GAB_GPU_PARSE": "1", "GAB_GPUS": "1"}):
+    for env in ({"GAB_GPU_PARSE": "0"}, {"GAB_GPU_PARSE": "1", "GAB_GPUS": "1"}):
         out = str(tmp_path / "o.txt")
         r = subprocess.run([exe, "-a", alg, "-i", f"{GOLDEN}/bpm_adv.in.txt", "-o", out], capture_output=True, text=True,
                            timeout=300, env=dict(os.environ, **env))
@@ -142,7 +142,10 @@ def test_bpm_driver_bitpal_algorithms(tmp_path, alg):
 # (benchmarks/common/gab_driver.h: chunks pulled from a shared cursor by GAB_WORKERS_PER_GPU threads per GPU, each with its
 # own handle; matches the reference's `omp for schedule(dynamic)` over batches, bsw/src/main_banded.cpp:338-350,
 # fmi/fmi.cpp:250-263 with the `rid += batch offset` fix-up of :340-343)
-QUEUE_ENV = {"GAB_WORKERS_PER_GPU": "3", "GAB_QUEUE_REPORT": "1"}
+# (GAB_GPU_PARSE=0: the chunk queue is the HOST-pointer path; since r04 the bsw / bpm / wfa drivers parse regular files on the GPU by
+# default and run ONE device call per GPU -- test_regression_small and the *_gpu_parse_mode tests cover that)
+HOST_ENV = dict(os.environ, GAB_GPU_PARSE="0")          # the line readers + the host-pointer entry points
+QUEUE_ENV = {"GAB_WORKERS_PER_GPU": "3", "GAB_QUEUE_REPORT": "1", "GAB_GPU_PARSE": "0"}
 
 
 def _queue_report(stderr):
@@ -199,7 +202,7 @@ def test_gpu_parse_with_several_gpus(inputs, bench, ngpus, tmp_path):
     if bench == "bsw":
         exe = os.path.join(ROOT, "benchmarks", "bsw", "main_bsw")
         args = [exe, "-pairs", f"{inputs}/bsw/small/bandedSWA_SRR7733443_100k_input.txt", "-t", "1", "-b", "512"]
-        ra = subprocess.run(args, capture_output=True, text=True, timeout=300)
+        ra = subprocess.run(args, capture_output=True, text=True, timeout=300, env=HOST_ENV)
         rb = subprocess.run(args, capture_output=True, text=True, timeout=300, env=env)
         assert ra.returncode == 0 and rb.returncode == 0, rb.stderr[-500:]
         scores = lambda e: [l for l in e.splitlines() if "score=" in l]
@@ -215,7 +218,7 @@ def test_gpu_parse_with_several_gpus(inputs, bench, ngpus, tmp_path):
             name = "BPM" if bench == "bpm" else "WFA"
             inp = f"{inputs}/{bench}/small/{name}_SRR7733443_100k_input.txt"
             mk = lambda o: [exe] + (["-a", "bpm-edit"] if bench == "bpm" else []) + ["-i", inp, "-o", o, "-t", "1"]
-        ra = subprocess.run(mk(a), capture_output=True, text=True, timeout=300)
+        ra = subprocess.run(mk(a), capture_output=True, text=True, timeout=300, env=HOST_ENV)
         rb = subprocess.run(mk(b), capture_output=True, text=True, timeout=300, env=env)
         assert ra.returncode == 0 and rb.returncode == 0, rb.stderr[-500:]
         assert "on the GPU" in rb.stderr + rb.stdout
@@ -237,7 +240,7 @@ def test_queue_spreads_chunks_over_workers(inputs, tmp_path):
     exe = os.path.join(ROOT, "benchmarks", "bsw", "main_bsw")
     inp = f"{inputs}/bsw/small/bandedSWA_SRR7733443_100k_input.txt"
     one = subprocess.run([exe, "-pairs", inp, "-t", "1", "-b", "512"], capture_output=True, text=True, timeout=300,
-                         env=dict(os.environ, GAB_WORKERS_PER_GPU="1"))
+                         env=dict(os.environ, GAB_WORKERS_PER_GPU="1", GAB_GPU_PARSE="0"))
     many = subprocess.run([exe, "-pairs", inp, "-t", "1", "-b", "512"], capture_output=True, text=True, timeout=300,
                           env=dict(os.environ, GAB_CHUNK="64", **QUEUE_ENV))
     assert one.returncode == 0 and many.returncode == 0, many.stderr[-500:]
@@ -292,12 +295,14 @@ def test_wfa_driver_packed_and_unpacked_output(inputs, tmp_path):
             t = rng.choice(np.frombuffer(b"ACGT", np.uint8), n).tobytes() if i % 2 else p       # random text: a run per operation
             f.write(b">" + p + b"\n<" + t + b"\n")
     outs = []
-    for env in ({}, {"GAB_WFA_UNPACKED": "1"}, {"GAB_CHUNK": "64", **QUEUE_ENV}):
+    # ({}: the default -- the file indexed on the GPU, gab_wfa_run_packed_device, with the same too-little-room retry)
+    for env in ({}, {"GAB_GPU_PARSE": "0"}, {"GAB_GPU_PARSE": "0", "GAB_WFA_UNPACKED": "1"}, {"GAB_CHUNK": "64", **QUEUE_ENV}):
         o = tmp_path / f"o{len(outs)}.txt"
         r = subprocess.run([exe, "-i", str(src), "-o", str(o)], capture_output=True, text=True, timeout=300, env=dict(os.environ, **env))
         assert r.returncode == 0, r.stderr[-500:]
         outs.append(open(o).read())
-    assert outs[0] == outs[1] == outs[2] and outs[0].count("\n") == 3000
+    key = lambda t: sorted(t.splitlines(), key=lambda l: int(l.split()[0][3:]))
+    assert key(outs[0]) == key(outs[1]) and outs[1] == outs[2] == outs[3] and outs[0].count("\n") == 3000
 
 
 def test_unpinned_and_piped_inputs(inputs, tmp_path):
@@ -307,7 +312,7 @@ def test_unpinned_and_piped_inputs(inputs, tmp_path):
     inp = f"{inputs}/bsw/small/bandedSWA_SRR7733443_100k_input.txt"
     a = subprocess.run([exe, "-pairs", inp, "-t", "1", "-b", "512"], capture_output=True, text=True, timeout=300)
     b = subprocess.run([exe, "-pairs", inp, "-t", "1", "-b", "512"], capture_output=True, text=True, timeout=300,
-                       env=dict(os.environ, GAB_NO_PIN="1"))
+                       env=dict(os.environ, GAB_NO_PIN="1", GAB_GPU_PARSE="0"))
     assert a.returncode == 0 and b.returncode == 0 and a.stderr == b.stderr
     for bench, args in [("bpm/bin/align_benchmark", ["-a", "bpm-edit", "-o", str(tmp_path / "o.txt")]),
                         ("wfa/bin/align_benchmark", ["-o", str(tmp_path / "o.txt")])]:
@@ -353,3 +358,20 @@ def test_perf_analysis_fifo_protocol(inputs, tmp_path):
     e = [l for l in r.stdout.splitlines() if l.startswith("Energy consumption:")]
     assert len(e) <= 1 and all(float(l.split()[2]) >= 0 for l in e)
     assert open(f"{inputs}/bsw/small/output-reference.file").read().splitlines() == [l for l in r.stderr.splitlines() if "score=" in l]
+
+
+def test_default_read_phase(inputs, tmp_path):
+    """r04: with GAB_GPU_PARSE unset the bsw, bpm and wfa drivers parse a regular file on the GPU and keep the pairs there (the
+    region of interest is kernels + results back); chain keeps its host reader (its host path overlaps the copy with the DP);
+    GAB_GPU_PARSE=0 turns the GPU parsers off everywhere"""
+    base = {k: v for k, v in os.environ.items() if k != "GAB_GPU_PARSE"}
+    runs = [("bsw", [os.path.join(ROOT, "benchmarks", "bsw", "main_bsw"), "-pairs", f"{inputs}/bsw/small/bandedSWA_SRR7733443_100k_input.txt", "-t", "1", "-b", "512"], True),
+            ("bpm", [os.path.join(ROOT, "benchmarks", "bpm", "bin", "align_benchmark"), "-a", "bpm-edit", "-i", f"{inputs}/bpm/small/BPM_SRR7733443_100k_input.txt", "-o", str(tmp_path / "b.txt")], True),
+            ("wfa", [os.path.join(ROOT, "benchmarks", "wfa", "bin", "align_benchmark"), "-i", f"{inputs}/wfa/small/WFA_SRR7733443_100k_input.txt", "-o", str(tmp_path / "w.txt")], True),
+            ("chain", [os.path.join(ROOT, "benchmarks", "chain", "chain"), "-i", f"{inputs}/chain/small/in-1k.txt", "-o", str(tmp_path / "c.txt"), "-t", "1"], False)]
+    for name, args, on_gpu in runs:
+        r = subprocess.run(args, capture_output=True, text=True, timeout=300, env=base)
+        assert r.returncode == 0, (name, r.stderr[-300:])
+        assert ("on the GPU" in r.stdout + r.stderr.split("score=")[0]) == on_gpu, name
+        r0 = subprocess.run(args, capture_output=True, text=True, timeout=300, env=dict(base, GAB_GPU_PARSE="0"))
+        assert r0.returncode == 0 and "on the GPU" not in r0.stdout + r0.stderr.split("score=")[0], name

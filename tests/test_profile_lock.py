@@ -4,6 +4,8 @@ import importlib.util
 import json
 import os
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -50,19 +52,20 @@ def test_short_kernel_names():
     assert cp.short("__amd_rocclr_copyBuffer") == "__amd_rocclr_copyBuffer"
 
 
-def test_this_rounds_committed_set_passes_the_lock():
-    """every r03 workload whose kernel stats and bench line are committed under profiles/ is evidence for that bench line:
-    the kernels bench.py prices and those of profiles/r03_hbm_traffic.json appear in the stats, and average x launches per
-    step fits the line's ms_per_step"""
+@pytest.mark.parametrize("rnd", ["r03", "r04"])
+def test_a_rounds_committed_set_passes_the_lock(rnd):
+    """every workload of the round whose kernel stats and bench line are committed under profiles/ is evidence for that bench
+    line: the kernels bench.py prices and those of profiles/<round>_hbm_traffic.json appear in the stats, and average x launches
+    per step fits the line's ms_per_step"""
     cp = _cp()
-    traffic = json.load(open(os.path.join(ROOT, "profiles", "r03_hbm_traffic.json")))
+    traffic = json.load(open(os.path.join(ROOT, "profiles", f"{rnd}_hbm_traffic.json")))
     seen = 0
     for w in ("bsw", "chain", "fast-chain", "bpm", "bitpal", "bitpal-edit", "wfa", "fmi", "fmi-sa", "parse-bsw"):
-        stats = os.path.join(ROOT, "profiles", f"r03_{w}_large_kernel_stats.csv")
-        bench_line = os.path.join(ROOT, "profiles", f"r03_{w}_large_bench.json")
+        stats = os.path.join(ROOT, "profiles", f"{rnd}_{w}_large_kernel_stats.csv")
+        bench_line = os.path.join(ROOT, "profiles", f"{rnd}_{w}_large_bench.json")
         if not (os.path.exists(stats) and os.path.exists(bench_line)):
             continue
-        trace = os.path.join(ROOT, "profiles", f"r03_{w}_large_kernel_trace.csv")
+        trace = os.path.join(ROOT, "profiles", f"{rnd}_{w}_large_kernel_trace.csv")
         line = json.loads(open(bench_line).read().strip().splitlines()[-1])
         assert cp.check(w, stats, trace if os.path.exists(trace) else None, line, traffic) == [], w
         seen += 1

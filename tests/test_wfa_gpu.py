@@ -287,3 +287,31 @@ def test_device_resident(eng):
                    ops, t(off), ln, sc, stream=torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     same((ops.cpu().numpy(), off, ln.cpu().numpy(), sc.cpu().numpy()), pyoracle.wfa(batch))
+
+
+def test_packed_output_from_device_resident_pairs(eng):
+    """gab_wfa_run_packed_device (the drivers' GPU-parse path): pairs already on the device, the printed text back to host arrays
+    -- the same text as gab_wfa_run_packed gives for host pointers, and the oracle's scores; too little room is GAB_ERANGE with the
+    size that fits"""
+    import torch
+    from genarchbench_amd._lib import GabError
+    from genarchbench_amd.wfa import ops_layout
+    batch = gabgen.pairs(69, 20000, 0, 151)
+    dev = torch.device("cuda:0")
+    t = lambda a: torch.from_numpy(a).to(dev)
+    off, total = ops_layout(batch)
+    ops = torch.zeros(total + 16, dtype=torch.uint8, device=dev)
+    args = (t(batch.pat), t(batch.pat_off), t(batch.pat_len), t(batch.txt), t(batch.txt_off), t(batch.txt_len), ops, t(off))
+    text, toff, tln, sc, need = eng.run_packed_device(*args, capacity=total // 4 + 4096)
+    wt, woff, wln, wsc = eng.align_packed(batch)
+    np.testing.assert_array_equal(sc, wsc)
+    np.testing.assert_array_equal(sc, pyoracle.wfa(batch)[3])
+    np.testing.assert_array_equal(tln, wln)
+    assert need == int(tln.sum()) == len(text)
+    for i in range(batch.n):
+        assert text[toff[i]:toff[i] + tln[i]].tobytes() == wt[woff[i]:woff[i] + wln[i]].tobytes(), i
+    with pytest.raises(GabError) as e:
+        eng.run_packed_device(*args, capacity=need - 1)
+    assert e.value.code == -34
+    t2, _, ln2, _, need2 = eng.run_packed_device(*args, capacity=need)       # exactly enough
+    assert need2 == need and np.array_equal(ln2, tln)

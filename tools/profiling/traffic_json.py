@@ -10,7 +10,8 @@ for path in sorted(glob.glob(os.path.join(d, "*_FETCH_SIZE"))):
     w = os.path.basename(path)[:-len("_FETCH_SIZE")]
     tab = collections.defaultdict(lambda: {"launches": 0, "fetch_gb_raw": 0.0, "write_gb": 0.0})
     for counter, key in (("FETCH_SIZE", "fetch_gb_raw"), ("WRITE_SIZE", "write_gb")):
-        for f in glob.glob(os.path.join(d, f"{w}_{counter}", "**", "*counter_collection.csv"), recursive=True):
+        # gpurun merges every call's files into the same directory: only the NEWEST collection counts (two would be summed)
+        for f in sorted(glob.glob(os.path.join(d, f"{w}_{counter}", "**", "*counter_collection.csv"), recursive=True), key=os.path.getmtime)[-1:]:
             for r in csv.DictReader(open(f)):
                 if r["Counter_Name"] != counter:
                     continue
