@@ -343,6 +343,7 @@ __global__ __launch_bounds__(kBvBlock) void bitpal_edit_bv(BpIO io, uint32_t *cu
 
 // =============================================================================== host side
 struct gab_bitpal {
+    gab_tuning tun = gab_tuning_loaded();      // experiment knobs, read when the handle is made
     gab_host_stream hs;     // private stream of the host-pointer entry point(s)
     int device = 0;
     BpScore sc;
@@ -421,7 +422,8 @@ extern "C" int gab_bitpal_run_device(gab_bitpal *h, const char *pat, int64_t pat
     }
     uint32_t n_lds = h->h_ct->n_lds, n_big = h->h_ct->n_big;
     const bool scored = h->sc.match != 0;
-    const bool bitvec = !scored && !getenv("GAB_BITPAL_NO_BV");   // -a bitpal-edit: Myers' bit-vector, the integer DP for its rejects
+    gab_tuning_refresh(&h->tun);
+    const bool bitvec = !scored && !h->tun.bitpal_no_bv;      // (GAB_BITPAL_NO_BV)   // -a bitpal-edit: Myers' bit-vector, the integer DP for its rejects
     if (bitvec) {
         GAB_HIP(hipEventRecord(h->ev[1], s));
         const int rows = std::min(std::max(h->h_ct->max_rows_lds, 1), kBvMaxRows);

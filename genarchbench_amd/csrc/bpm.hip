@@ -724,6 +724,7 @@ __global__ __launch_bounds__(256) void bpm_gather_lens(const uint32_t *__restric
 
 // =============================================================================== host side
 struct gab_bpm {
+    gab_tuning tun = gab_tuning_loaded();      // experiment knobs, read when the handle is made
     gab_host_stream hs;     // private stream of the host-pointer entry point(s)
     int device = 0;
     gab_devbuf ws;          // counters | perm | worklists
@@ -789,9 +790,8 @@ extern "C" void gab_bpm_destroy(gab_bpm *h) {
 
 template <int W>
 static void launch_score(hipStream_t s, const BpmIO &io, const uint32_t *perm, uint32_t kb, uint32_t ke, int32_t *score,
-                         uint32_t *wl, uint32_t *wl_counter, BpmCounters *ct, int max_plen) {
-    if (ke <= kb) return;
-    const bool blocks64 = getenv("GAB_BPM_SCORE64") != nullptr;              // the 64-row block form (kept under test)
+                         uint32_t *wl, uint32_t *wl_counter, BpmCounters *ct, int max_plen, bool blocks64) {
+    if (ke <= kb) return;      // (blocks64 = GAB_BPM_SCORE64: the 64-row block form, kept under test)
     const dim3 grid((ke - kb + kBlock - 1) / kBlock);
     if (blocks64)
         hipLaunchKernelGGL(bpm_score<W>, grid, dim3(kBlock), 0, s, io, perm, kb, ke, score, wl, wl_counter, ct);
@@ -810,9 +810,9 @@ static void launch_score(hipStream_t s, const BpmIO &io, const uint32_t *perm, u
 // the score kernel of one slice on `s`, its band kernel on `sb` behind the event
 template <int W>
 static int launch_slice(hipStream_t s, hipStream_t sb, hipEvent_t scored, const BpmIO &io, const uint32_t *perm, uint32_t kb,
-                        uint32_t ke, int32_t *score, uint32_t *wl, uint32_t *wl_counter, int cols, uint32_t *wl1, BpmCounters *ct, int max_plen) {
+                        uint32_t ke, int32_t *score, uint32_t *wl, uint32_t *wl_counter, int cols, uint32_t *wl1, BpmCounters *ct, int max_plen, bool blocks64) {
     if (ke <= kb) return GAB_OK;
-    launch_score<W>(s, io, perm, kb, ke, score, wl, wl_counter, ct, max_plen);
+    launch_score<W>(s, io, perm, kb, ke, score, wl, wl_counter, ct, max_plen, blocks64);
     GAB_HIP(hipEventRecord(scored, s));
     GAB_HIP(hipStreamWaitEvent(sb, scored, 0));
     const size_t lds = sizeof(uint64_t) * 64 * (4 * W + 1) + sizeof(uint16_t) * 64 * (size_t)cols;
@@ -838,6 +838,7 @@ extern "C" int gab_bpm_run_device(gab_bpm *h, const char *pat, int64_t pat_bytes
     if (n == 0) return GAB_OK;
     GAB_CHECK(pat && pat_off && pat_len && txt && txt_off && txt_len && score_out, "gab_bpm_run_device: NULL buffer");
     gab_device_guard g(h->device);
+    gab_tuning_refresh(&h->tun);
     hipStream_t s = (hipStream_t)stream_;
 
     const size_t o_perm = (sizeof(BpmCounters) + 255) & ~(size_t)255;
@@ -895,7 +896,7 @@ extern "C" int gab_bpm_run_device(gab_bpm *h, const char *pat, int64_t pat_bytes
         // (r04: below ~2.4 M pairs ONE slice -- every band launch has a ~0.12 ms tail of its own that the next slice's score kernel
         // does not hide at that size: 1.25 M pairs 1.12 -> 1.04 ms, 100 k pairs 0.39 ms with two slices against 0.27 with one)
         int nsl = ccount[W] < 2400000 ? 1 : (int)std::min<uint32_t>(kSlices, ccount[W] / 600000);
-        if (const char *e = getenv("GAB_BPM_SLICES")) nsl = std::max(1, std::min(kSlices, atoi(e)));        // tuning runs
+        if (h->tun.bpm_slices > 0) nsl = std::max(1, std::min(kSlices, h->tun.bpm_slices));        // GAB_BPM_SLICES: tuning runs
         const uint32_t per = ((ccount[W] + nsl - 1) / nsl + kBlock - 1) / kBlock * kBlock;
         const int cols = h->h_ct->max_tlen[W] + 1;
         for (int k = 0; k < nsl; k++) {
@@ -903,10 +904,10 @@ extern "C" int gab_bpm_run_device(gab_bpm *h, const char *pat, int64_t pat_bytes
             const uint32_t ke = cstart[W] + std::min<uint32_t>(ccount[W], (uint32_t)(k + 1) * per);
             uint32_t *wl = d_wl + kb, *cnt = &d_ct->wl_slice[W][k], *wl1 = d_wl1 + cstart[W];
             switch (W) {
-                case 1: rc = launch_slice<1>(s, h->aux, h->scored[k], io, perm_arg, kb, ke, score_out, wl, cnt, cols, wl1, d_ct, h->h_ct->max_plen[1]); break;
-                case 2: rc = launch_slice<2>(s, h->aux, h->scored[k], io, perm_arg, kb, ke, score_out, wl, cnt, cols, wl1, d_ct, h->h_ct->max_plen[2]); break;
-                case 3: rc = launch_slice<3>(s, h->aux, h->scored[k], io, perm_arg, kb, ke, score_out, wl, cnt, cols, wl1, d_ct, h->h_ct->max_plen[3]); break;
-                default: rc = launch_slice<4>(s, h->aux, h->scored[k], io, perm_arg, kb, ke, score_out, wl, cnt, cols, wl1, d_ct, h->h_ct->max_plen[4]); break;
+                case 1: rc = launch_slice<1>(s, h->aux, h->scored[k], io, perm_arg, kb, ke, score_out, wl, cnt, cols, wl1, d_ct, h->h_ct->max_plen[1], h->tun.bpm_score64); break;
+                case 2: rc = launch_slice<2>(s, h->aux, h->scored[k], io, perm_arg, kb, ke, score_out, wl, cnt, cols, wl1, d_ct, h->h_ct->max_plen[2], h->tun.bpm_score64); break;
+                case 3: rc = launch_slice<3>(s, h->aux, h->scored[k], io, perm_arg, kb, ke, score_out, wl, cnt, cols, wl1, d_ct, h->h_ct->max_plen[3], h->tun.bpm_score64); break;
+                default: rc = launch_slice<4>(s, h->aux, h->scored[k], io, perm_arg, kb, ke, score_out, wl, cnt, cols, wl1, d_ct, h->h_ct->max_plen[4], h->tun.bpm_score64); break;
             }
             if (rc) return rc;
         }

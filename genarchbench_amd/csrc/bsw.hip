@@ -594,6 +594,7 @@ __global__ __launch_bounds__(64) void bsw_dp8(BswIO io, BswConst c, const BswRec
 
 // =============================================================================== host side
 struct gab_bsw {
+    gab_tuning tun = gab_tuning_loaded();      // experiment knobs, read when the handle is made
     gab_host_stream hs;     // private stream of the host-pointer entry point(s)
     int device = 0;
     gab_bsw_params prm;
@@ -806,7 +807,8 @@ extern "C" int gab_bsw_run(gab_bsw *h, const uint8_t *ref, const int64_t *ref_of
     if (n == 0) return GAB_OK;
     GAB_CHECK(ref && ref_off && qry && qry_off && len1 && len2 && h0 && score_out, "gab_bsw_run: NULL buffer");
     gab_device_guard g(h->device);
-    const bool trace = getenv("GAB_BSW_TRACE") != nullptr;      // diagnosis: per-phase wall times of this call on stderr
+    gab_tuning_refresh(&h->tun);
+    const bool trace = h->tun.bsw_trace;      // GAB_BSW_TRACE, diagnosis: per-phase wall times of this call on stderr
     auto now = [] { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; };
     const double t_0 = now();
     // extent of the two slabs actually referenced: only [min, max) is staged, so a driver can hand a window
@@ -822,7 +824,7 @@ extern "C" int gab_bsw_run(gab_bsw *h, const uint8_t *ref, const int64_t *ref_of
         ra = ref_off[i] < ra ? ref_off[i] : ra; qa = qry_off[i] < qa ? qry_off[i] : qa;
         return ref_off[i] >= 0 && qry_off[i] >= 0 && len1[i] >= 0 && len2[i] >= 0;
     };
-    bool sampled = n > 4096 && !h->out_of_order && !getenv("GAB_BSW_FULL_SCAN");      // (a batch of this handle was rejected for its sampled window: scan from then on)
+    bool sampled = n > 4096 && !h->out_of_order && !h->tun.bsw_full_scan;      // (a batch of this handle was rejected for its sampled window: scan from then on)
     if (sampled) {
         bool ok = take(0);
         ok = take(n - 1) && ok;

@@ -1766,6 +1766,7 @@ void chain_fast_kernel(const ChainWork *__restrict__ work, const uint64_t *__res
 
 // =============================================================================== host side
 struct gab_chain {
+    gab_tuning tun = gab_tuning_loaded();      // experiment knobs, read when the handle is made
     gab_host_stream hs;     // private stream of the host-pointer entry point(s)
     int device = 0;
     gab_devbuf work;       // ChainWork[ncalls] + evals counter
@@ -1842,13 +1843,13 @@ static int chain_check_hdrs(const gab_chain_hdr *hdr, const int64_t *call_off, i
 // bound by that call's blocks, and those finish sooner with more hands: 1 000 calls / 8 M anchors, longest 60 000 --
 // chain 25.8 -> 21.7 -> 20.2 ms with 3 / 5 / 7 helpers, fast-chain 24.7 -> 21.4 -> 20.1 ms.  Seven are used when the batch,
 // at the seven-helper throughput (1.6 G anchors/s), would be done in 0.6 of the longest call's time (0.34 us per anchor).
-static int chain_helpers_for(int64_t total_anchors, int64_t longest_call) {
-    if (const char *e = getenv("GAB_CHAIN_HELPERS")) { const int v = atoi(e); if (v == 3 || v == 5 || v == 7) return v; }   // A/B runs
+static int chain_helpers_for(const gab_tuning &tun, int64_t total_anchors, int64_t longest_call) {
+    if (tun.chain_helpers == 3 || tun.chain_helpers == 5 || tun.chain_helpers == 7) return tun.chain_helpers;   // GAB_CHAIN_HELPERS: A/B runs
     return total_anchors <= 326 * longest_call ? 7 : 3;
 }
 
 // the kernels of one work list (already on the device) on `s`; nothing else (no memset, no synchronisation)
-static void chain_launch(int mode, int helpers, hipStream_t s, ChainWork *d_work, unsigned nw, const uint64_t *d_x, const uint64_t *d_y,
+static void chain_launch(const gab_tuning &tun, int mode, int helpers, hipStream_t s, ChainWork *d_work, unsigned nw, const uint64_t *d_x, const uint64_t *d_y,
                          int32_t *d_score, int32_t *d_parent, int32_t *d_gm, unsigned long long *d_ev, const ChainFeed *feed_in = nullptr) {
     const ChainFeed feed = feed_in ? *feed_in : ChainFeed{nullptr, nullptr, nullptr, nullptr, nullptr, kFeedSpinLimit};
     if (nw == 0) return;
@@ -1857,7 +1858,7 @@ static void chain_launch(int mode, int helpers, hipStream_t s, ChainWork *d_work
         else if (helpers == 7) hipLaunchKernelGGL((fastchain_kernel_lat<7, false>), dim3(nw), dim3(64 * 8), 0, s, d_work, d_x, d_y, d_score, d_parent, d_ev, feed);
         else if (helpers == 5) hipLaunchKernelGGL((fastchain_kernel_lat<5, false>), dim3(nw), dim3(64 * 6), 0, s, d_work, d_x, d_y, d_score, d_parent, d_ev, feed);
         else hipLaunchKernelGGL((fastchain_kernel<kFcHelpers, false>), dim3(nw), dim3(64 * (1 + kFcHelpers)), 0, s, d_work, d_x, d_y, d_score, d_parent, d_ev, feed);
-    } else if (getenv("GAB_CHAIN_KERNEL") && !strcmp(getenv("GAB_CHAIN_KERNEL"), "walk"))      // the per-anchor walk (A/B runs)
+    } else if (tun.chain_walk)      // GAB_CHAIN_KERNEL=walk: the per-anchor walk (A/B runs)
         hipLaunchKernelGGL(chain_hw_kernel, dim3(nw), dim3(64 * (1 + kChHelpers)), 0, s, d_work, d_x, d_y, d_score, d_parent, d_gm, d_ev);
     else {
         if (feed.facts) {
@@ -1911,6 +1912,7 @@ extern "C" int gab_chain_run_device(gab_chain *h, int mode, const uint64_t *d_x,
     if (rc) return rc;
     GAB_CHECK(total == 0 || (d_x && d_y && d_score && d_parent), "gab_chain_run_device: NULL buffer");
     gab_device_guard g(h->device);
+    gab_tuning_refresh(&h->tun);
     hipStream_t s = (hipStream_t)stream_;
 
     // longest call first: the sequential walk of the biggest call is the critical path
@@ -1956,10 +1958,10 @@ extern "C" int gab_chain_run_device(gab_chain *h, int mode, const uint64_t *d_x,
     // the call's own workgroup only folds): a 60 000-anchor call takes ~1 ms there instead of 5-10, at 2 bytes of HBM traffic per
     // pair.  The list is sorted longest first: [0, ntab) table form, [ntab, ntab + nfast) latency form, the rest throughput
     // form, side by side on three streams.  GAB_CHAIN_TAB_MIN pins the table form's smallest call, GAB_CHAIN_TAB=0 turns it off.
-    const bool legacy_only = (mode == GAB_CHAIN && getenv("GAB_CHAIN_KERNEL") && !strcmp(getenv("GAB_CHAIN_KERNEL"), "walk")) || getenv("GAB_CHAIN_HELPERS");
+    const bool legacy_only = (mode == GAB_CHAIN && h->tun.chain_walk) || h->tun.chain_helpers_set;
     size_t ntab = 0, nfast = 0;
     int64_t tab_anchors = 0;
-    if (!legacy_only && !(getenv("GAB_CHAIN_TAB") && !atoi(getenv("GAB_CHAIN_TAB")))) {
+    if (!legacy_only && h->tun.chain_tab != 0) {
         // A batch whose longest call would outlast 0.75 of the batch's throughput time in the throughput form (0.30 us per anchor of
         // a call, 2.85 G anchors/s over all calls: the latency-form rule below) hands its long calls to the table form: every call
         // that would take a quarter of that time there, 2048 anchors at least.  Measured (r04, one rank's share of chain-large
@@ -1970,7 +1972,7 @@ extern "C" int gab_chain_run_device(gab_chain *h, int mode, const uint64_t *d_x,
         int64_t min_n = INT64_MAX;
         const double est_tp = (double)total / 2.85e9, lat_max = 0.30e-6 * (double)wk[0].n;
         if (lat_max >= 0.75 * est_tp) min_n = std::max<int64_t>(2048, (int64_t)(0.25 * est_tp / 0.30e-6));
-        if (getenv("GAB_CHAIN_TAB_MIN")) min_n = atoll(getenv("GAB_CHAIN_TAB_MIN"));
+        if (h->tun.chain_tab_min >= 0) min_n = h->tun.chain_tab_min;      // GAB_CHAIN_TAB_MIN
         while (ntab < nw && wk[ntab].n >= min_n) { tab_anchors += wk[ntab].n; ntab++; }
     }
     const size_t nrest = nw - ntab;
@@ -1978,9 +1980,9 @@ extern "C" int gab_chain_run_device(gab_chain *h, int mode, const uint64_t *d_x,
         int64_t min_n = 0, max_calls = 0;
         const double est_tp = (double)(total - tab_anchors) / 2.85e9, lat_max = 0.30e-6 * (double)wk[ntab].n;
         if (lat_max >= 0.75 * est_tp) { min_n = 512; max_calls = (int64_t)nrest; }
-        if (getenv("GAB_CHAIN_FAST_MIN")) min_n = atoll(getenv("GAB_CHAIN_FAST_MIN"));
-        if (getenv("GAB_CHAIN_FAST_CALLS")) max_calls = atoll(getenv("GAB_CHAIN_FAST_CALLS"));
-        if (getenv("GAB_CHAIN_FAST_MIN") && !getenv("GAB_CHAIN_FAST_CALLS")) max_calls = (int64_t)nrest;
+        if (h->tun.chain_fast_min >= 0) min_n = h->tun.chain_fast_min;              // GAB_CHAIN_FAST_MIN
+        if (h->tun.chain_fast_calls >= 0) max_calls = h->tun.chain_fast_calls;      // GAB_CHAIN_FAST_CALLS
+        if (h->tun.chain_fast_min >= 0 && h->tun.chain_fast_calls < 0) max_calls = (int64_t)nrest;
         while (nfast < nrest && (int64_t)nfast < max_calls && wk[ntab + nfast].n >= min_n) nfast++;
     }
     if (ntab || nfast) {
@@ -1993,7 +1995,7 @@ extern "C" int gab_chain_run_device(gab_chain *h, int mode, const uint64_t *d_x,
             // the table form and, behind it on the same stream, the latency form for the calls it hands back (bail word set)
             GAB_HIP(hipStreamWaitEvent(h->ts, h->fe[0], 0));
             uint32_t *d_bail = nullptr;
-            if ((rc = chain_tab_run(&h->tab, mode, h->ts, d_work, wk.data(), ntab, total, d_x, d_y, d_score, d_parent, d_gm, d_ev, &d_bail)) != GAB_OK) return rc;
+            if ((rc = chain_tab_run(&h->tab, h->tun, mode, h->ts, d_work, wk.data(), ntab, total, d_x, d_y, d_score, d_parent, d_gm, d_ev, &d_bail)) != GAB_OK) return rc;
             if (mode == GAB_CHAIN) hipLaunchKernelGGL(chain_facts_kernel, dim3((unsigned)ntab), dim3(256), 0, h->ts, d_work, d_x, d_y, (const uint32_t *)d_bail);
             if (mode == GAB_CHAIN)
                 hipLaunchKernelGGL(chain_fast_kernel<GAB_CHAIN>, dim3((unsigned)ntab), dim3(64 * (2 + kFastW)), kFastDynLds, h->ts, d_work, d_x, d_y, d_score, d_parent, d_gm, d_ev, (const uint32_t *)d_bail);
@@ -2022,12 +2024,12 @@ extern "C" int gab_chain_run_device(gab_chain *h, int mode, const uint64_t *d_x,
         if (nfast) GAB_HIP(hipStreamWaitEvent(s, h->fe[1], 0));
         if (ntab) GAB_HIP(hipStreamWaitEvent(s, h->te[1], 0));
     } else
-    chain_launch(mode, chain_helpers_for(total, wk.empty() ? 0 : wk[0].n), s, d_work, (unsigned)nw, d_x, d_y, d_score, d_parent, d_gm, d_ev);
+    chain_launch(h->tun, mode, chain_helpers_for(h->tun, total, wk.empty() ? 0 : wk[0].n), s, d_work, (unsigned)nw, d_x, d_y, d_score, d_parent, d_gm, d_ev);
     GAB_HIP(hipGetLastError());
     GAB_HIP(hipEventRecord(h->ev[1], s));
     GAB_HIP(hipMemcpyAsync(h->h_evals, d_ev, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
     GAB_HIP(hipStreamSynchronize(s));    // wk (host vector) must outlive the H2D copy
-    if (ntab && getenv("GAB_CHAIN_TRACE")) chain_tab_report(&h->tab, ntab);
+    if (ntab && h->tun.chain_trace) chain_tab_report(&h->tab, ntab);
     h->have_stats = true;
     return GAB_OK;
 }
@@ -2055,7 +2057,7 @@ static int chain_run_overlapped(gab_chain *h, int mode, const uint64_t *x, const
     for (int k = 0; k < 5; k++)
         if (!h->xe[k] && hipEventCreateWithFlags(&h->xe[k], hipEventDisableTiming) != hipSuccess) { gab_set_error("gab_chain_run: event creation failed"); return GAB_EDEVICE; }
     hipStream_t sB1 = h->xs[0], sB2 = h->xs[1];
-    const bool trace = getenv("GAB_CHAIN_TRACE") != nullptr;                          // diagnosis: a time line of the three streams on stderr
+    const bool trace = h->tun.chain_trace;                          // GAB_CHAIN_TRACE, diagnosis: a time line of the three streams on stderr
     hipEvent_t tv[10] = {};
     if (trace) for (auto &e : tv) (void)hipEventCreate(&e);
     auto mark = [&](int k, hipStream_t st) { if (trace) (void)hipEventRecord(tv[k], st); };
@@ -2105,7 +2107,7 @@ static int chain_run_overlapped(gab_chain *h, int mode, const uint64_t *x, const
         GAB_HIP(hipMemcpyAsync(dy + w.off, y + w.off, 8 * (size_t)w.n, hipMemcpyHostToDevice, sA));
     }
     mark(1, sA);
-    chain_launch(mode, 3, sA, d_work[0], (unsigned)wk[0].size(), dx, dy, ds, dp, d_gm, d_ev);
+    chain_launch(h->tun, mode, 3, sA, d_work[0], (unsigned)wk[0].size(), dx, dy, ds, dp, d_gm, d_ev);
     mark(2, sA);
     GAB_HIP(hipEventRecord(h->xe[1], sA));                                             // A's results are final
     // ---- stream B1: first half
@@ -2114,7 +2116,7 @@ static int chain_run_overlapped(gab_chain *h, int mode, const uint64_t *x, const
     GAB_HIP(hipMemcpyAsync(dy, y, 8 * (size_t)mid, hipMemcpyHostToDevice, sB1));
     GAB_HIP(hipEventRecord(h->xe[2], sB1));                                            // first half is in
     mark(3, sB1);
-    chain_launch(mode, 3, sB1, d_work[1], (unsigned)wk[1].size(), dx, dy, ds, dp, d_gm, d_ev);
+    chain_launch(h->tun, mode, 3, sB1, d_work[1], (unsigned)wk[1].size(), dx, dy, ds, dp, d_gm, d_ev);
     mark(4, sB1);
     GAB_HIP(hipEventRecord(h->xe[4], sB1));                                            // B1's results are final
     // ---- stream B2: second half right behind the first
@@ -2122,7 +2124,7 @@ static int chain_run_overlapped(gab_chain *h, int mode, const uint64_t *x, const
     GAB_HIP(hipMemcpyAsync(dx + mid, x + mid, 8 * (t - (size_t)mid), hipMemcpyHostToDevice, sB2));
     GAB_HIP(hipMemcpyAsync(dy + mid, y + mid, 8 * (t - (size_t)mid), hipMemcpyHostToDevice, sB2));
     mark(5, sB2);
-    chain_launch(mode, 3, sB2, d_work[2], (unsigned)wk[2].size(), dx, dy, ds, dp, d_gm, d_ev);
+    chain_launch(h->tun, mode, 3, sB2, d_work[2], (unsigned)wk[2].size(), dx, dy, ds, dp, d_gm, d_ev);
     mark(6, sB2);
     GAB_HIP(hipGetLastError());
     // ---- results: each half once its own kernel and A's are done (a call of B2 may begin in the first half: its anchors
@@ -2185,7 +2187,7 @@ static int chain_fed_setup(gab_chain *h, int *gather_blocks) {
         h->gs_tried = true;
         int ncu = 0;
         (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, h->device);
-        const char *e = getenv("GAB_CHAIN_GATHER_MASK");
+        const char *e = h->tun.chain_gather_mask[0] ? h->tun.chain_gather_mask : nullptr;      // GAB_CHAIN_GATHER_MASK
         static std::atomic<int> next_cu{0};                  // every handle of the process its own CU (workers of one driver run side by side)
         int b0 = 8 * (next_cu.fetch_add(1) % 32), nb = 8;
         if (e && e[0] >= '0' && e[0] <= '9') { b0 = atoi(e); nb = strchr(e, ':') ? atoi(strchr(e, ':') + 1) : 8; }
@@ -2204,7 +2206,7 @@ static int chain_fed_setup(gab_chain *h, int *gather_blocks) {
         }
     }
     if (h->gs) *gather_blocks = h->gs_blocks;
-    if (const char *e = getenv("GAB_CHAIN_GATHER_BLOCKS")) { const int v = atoi(e); if (v >= 8 && v <= 256) *gather_blocks = v; }
+    if (h->tun.chain_gather_blocks >= 8 && h->tun.chain_gather_blocks <= 256) *gather_blocks = h->tun.chain_gather_blocks;      // GAB_CHAIN_GATHER_BLOCKS
     if (!h->h_started && hipHostMalloc((void **)&h->h_started, 256 + 64) != hipSuccess) { gab_set_error("gab_chain_run: pinned allocation failed"); return GAB_EDEVICE; }
     return GAB_OK;
 }
@@ -2265,11 +2267,11 @@ static int chain_run_fed(gab_chain *h, int mode, const uint64_t *x, const uint64
         if ((rc = h->gmarks.reserve(sizeof(int32_t) * t)) != GAB_OK) return rc;
         d_gm = h->gmarks.as<int32_t>();
     }
-    const bool trace = getenv("GAB_CHAIN_TRACE") != nullptr;
+    const bool trace = h->tun.chain_trace;
     // GAB_CHAIN_FEED_GIVEUP=1 (test hook): the gather kernel never publishes the facts word of the first (longest)
     // call and a wait gives up after ~20 ms instead of seconds -- the branch nobody runs otherwise: the waiting workgroup sets
     // the abort word, every other wait follows, the grid drains and gab_chain_run re-runs the batch through the copy engines
-    const bool giveup_test = getenv("GAB_CHAIN_FEED_GIVEUP") != nullptr;
+    const bool giveup_test = h->tun.chain_feed_giveup;      // GAB_CHAIN_FEED_GIVEUP
     hipEvent_t tv[4] = {};
     if (trace) for (auto &e : tv) (void)hipEventCreate(&e);
     // ---- gather stream
@@ -2310,7 +2312,7 @@ static int chain_run_fed(gab_chain *h, int mode, const uint64_t *x, const uint64
             GAB_HIP(hipStreamSynchronize(sG));
         }
     }
-    if (getenv("GAB_CHAIN_FED_SERIAL")) GAB_HIP(hipStreamSynchronize(sG));        // experiments: the DP only after the last anchor
+    if (h->tun.chain_fed_serial) GAB_HIP(hipStreamSynchronize(sG));        // experiments: the DP only after the last anchor
     // ---- the DP: one launch, its workgroups wait for their call
     GAB_HIP(hipStreamWaitEvent(sA, h->xe_fed, 0));
     const bool write_through = true;              // (measured: results by two copies at the end instead cost their 12 ms in full)
@@ -2319,7 +2321,7 @@ static int chain_run_fed(gab_chain *h, int mode, const uint64_t *x, const uint64
     ChainFeed feed{(uint32_t *)(wb + o_facts), write_through ? (int32_t *)hs : nullptr, write_through ? (int32_t *)hp : nullptr, d_abort, d_dbg,
                    giveup_test ? 3000 : kFeedSpinLimit};
     if (trace) (void)hipEventRecord(tv[2], sA);
-    chain_launch(mode, 3, sA, d_work, (unsigned)nw, dx, dy, ds, dp, d_gm, d_ev, &feed);
+    chain_launch(h->tun, mode, 3, sA, d_work, (unsigned)nw, dx, dy, ds, dp, d_gm, d_ev, &feed);
     GAB_HIP(hipGetLastError());
     if (trace) (void)hipEventRecord(tv[3], sA);
     GAB_HIP(hipEventRecord(h->ev[1], sA));
@@ -2395,9 +2397,10 @@ extern "C" int gab_chain_run(gab_chain *h, int mode, const uint64_t *x, const ui
     hipStream_t s = nullptr;
     if ((rc = h->hs.get(&s)) != GAB_OK) return rc;
     // (GAB_CHAIN_FEED_MIN: tests push small batches through the big-batch paths)
-    const int64_t big = getenv("GAB_CHAIN_FEED_MIN") ? atoll(getenv("GAB_CHAIN_FEED_MIN")) : ((int64_t)8 << 20);
-    if (total >= big && (ncalls >= 1024 || getenv("GAB_CHAIN_FEED_MIN")) && ncalls < (1ll << 31) && !getenv("GAB_CHAIN_NO_OVERLAP")) {
-        if (!getenv("GAB_CHAIN_NO_FEED") && !(getenv("GAB_CHAIN_KERNEL") && !strcmp(getenv("GAB_CHAIN_KERNEL"), "walk"))) {
+    gab_tuning_refresh(&h->tun);
+    const int64_t big = h->tun.chain_feed_min >= 0 ? h->tun.chain_feed_min : ((int64_t)8 << 20);      // GAB_CHAIN_FEED_MIN
+    if (total >= big && (ncalls >= 1024 || h->tun.chain_feed_min >= 0) && ncalls < (1ll << 31) && !h->tun.chain_no_overlap) {
+        if (!h->tun.chain_no_feed && !h->tun.chain_walk) {
             rc = chain_run_fed(h, mode, x, y, call_off, hdr, ncalls, total, score_out, parent_out, s);
             if (rc != 1 && rc != 2) return rc;    // 1: the arrays are not page-locked; 2: the fed kernel gave up waiting
         }

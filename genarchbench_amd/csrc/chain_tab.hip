@@ -819,7 +819,7 @@ void chain_tab_report(ChainTab *t, size_t nsplit) {
     }
 }
 
-int chain_tab_run(ChainTab *t, int mode, hipStream_t s, const ChainWork *d_work, const ChainWork *h_work, size_t nsplit, int64_t total_anchors,
+int chain_tab_run(ChainTab *t, const gab_tuning &tun, int mode, hipStream_t s, const ChainWork *d_work, const ChainWork *h_work, size_t nsplit, int64_t total_anchors,
                   const uint64_t *d_x, const uint64_t *d_y, int32_t *d_score, int32_t *d_parent, int32_t *d_gm, unsigned long long *d_evals, uint32_t **d_bail) {
     int rc = chain_tab_setup();
     if (rc) return rc;
@@ -851,7 +851,7 @@ int chain_tab_run(ChainTab *t, int mode, hipStream_t s, const ChainWork *d_work,
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = (size_t)8 << 30; }
         size_t budget = std::min<size_t>(free_b / 2, (size_t)96 << 30);
-        if (const char *e = getenv("GAB_CHAIN_TAB_MB")) { const long long v = atoll(e); if (v > 0) budget = (size_t)v << 20; }
+        if (tun.chain_tab_mb > 0) budget = (size_t)tun.chain_tab_mb << 20;      // GAB_CHAIN_TAB_MB
         t->table_budget = budget;
     }
     const size_t est = std::max<size_t>((size_t)nblocks * 27 * 1024, (size_t)1 << 20);
@@ -869,7 +869,7 @@ int chain_tab_run(ChainTab *t, int mode, hipStream_t s, const ChainWork *d_work,
     GAB_HIP(hipMemcpyAsync(d_calls, hc.data(), sizeof(TabCall) * nsplit, hipMemcpyHostToDevice, s));      // (pageable: staged before the call returns)
     GAB_HIP(hipMemsetAsync(d_ct, 0, 512, s));
     unsigned long long *d_dbg = nullptr;       // GAB_CHAIN_TRACE: per-wave cycle counts of call 0's fold, then start / ready / end of every call's workgroup
-    if (getenv("GAB_CHAIN_TRACE")) {
+    if (tun.chain_trace) {
         if ((rc = t->dbg.reserve(8 * (32 + 3 * nsplit))) != GAB_OK) return rc;
         d_dbg = t->dbg.as<unsigned long long>();
         GAB_HIP(hipMemsetAsync(d_dbg, 0, 8 * (32 + 3 * nsplit), s));

@@ -1021,6 +1021,7 @@ __global__ __launch_bounds__(64) void fmi_sa_kernel(FmiIdx ix, SaIdx sa, const g
 
 // =============================================================================== host side
 struct gab_fmi {
+    gab_tuning tun = gab_tuning_loaded();      // experiment knobs, read when the handle is made (an fmi handle never re-reads them)
     gab_host_stream hs;     // private stream of the host-pointer entry point(s)
     int device = 0;
     FmiIdx ix;
@@ -1059,13 +1060,11 @@ static int fmi_new_handle(int device, gab_fmi **out) {
     gab_fmi *h = new (std::nothrow) gab_fmi();
     if (!h) { gab_set_error("out of host memory"); return GAB_ENOMEM; }
     h->device = device;
-    { const char *e = getenv("GAB_FMI_LDS_ENTRIES"); h->lds_entries_env = e ? atoi(e) : 0; }
-    { const char *e = getenv("GAB_FMI_WIDE_LISTS"); h->wide_env = e && atoi(e) != 0; }
-    { const char *e = getenv("GAB_FMI_WAVES"); h->waves_env = e ? atoi(e) : 0; }
-    { const char *e = getenv("GAB_FMI_WIDE"); h->handover_env = e ? atoi(e) : 1; }
-    { const char *e = getenv("GAB_FMI_WIDE_CAP"); h->wide_cap_env = e ? atoi(e) : 0; }
-    { const char *e = getenv("GAB_FMI_BATCH"); if (e && atoll(e) >= 1024) h->batch_max = atoll(e); }
-    { const char *e = getenv("GAB_FMI_SCRATCH_MB"); if (e && atoll(e) > 0) { h->scratch_budget = (size_t)atoll(e) << 20; h->scratch_from_env = true; } }
+    const gab_tuning &t = h->tun;
+    h->lds_entries_env = t.fmi_lds_entries; h->wide_env = t.fmi_wide_lists; h->waves_env = t.fmi_waves;
+    h->handover_env = t.fmi_wide; h->wide_cap_env = t.fmi_wide_cap;
+    if (t.fmi_batch >= 1024) h->batch_max = t.fmi_batch;
+    if (t.fmi_scratch_mb > 0) { h->scratch_budget = (size_t)t.fmi_scratch_mb << 20; h->scratch_from_env = true; }
     if (hipEventCreate(&h->ev[0]) != hipSuccess || hipEventCreate(&h->ev[1]) != hipSuccess ||
         hipHostMalloc((void **)&h->h_ct, sizeof(FmiCounters)) != hipSuccess) {
         gab_set_error("gab_fmi: event / pinned allocation failed"); delete h; return GAB_EDEVICE;
@@ -1096,8 +1095,7 @@ extern "C" int gab_fmi_create(int device, int64_t ref_seq_len, const int64_t cou
     h->ix.ref_seq_len = ref_seq_len;
     h->ix.kmer_tab = nullptr; h->ix.kmer_depth = 0;
     {   // short-pattern table, level by level (each level extends the previous one by one base to the left)
-        const char *e = getenv("GAB_FMI_KMER_DEPTH");
-        const int depth = e ? std::max(0, std::min(11, atoi(e))) : kDefaultKmerDepth;
+        const int depth = h->tun.fmi_kmer_depth >= 0 ? std::min(11, h->tun.fmi_kmer_depth) : kDefaultKmerDepth;      // GAB_FMI_KMER_DEPTH
         if (depth > 0) {
             const size_t entries = ((((size_t)1 << (2 * (depth + 1))) - 4) / 3 + 3) & ~(size_t)3;
             rc = h->kmer.reserve(entries * sizeof(uint4));
@@ -1355,12 +1353,12 @@ extern "C" int gab_fmi_seed_device(gab_fmi *h, const uint8_t *d_enc, int32_t str
         GAB_HIP(hipEventElapsedTime(&ms, h->ev[0], h->ev[1]));
         kms += ms;
         ext_total += h->h_ct->ext_calls + h->h_ct->tab_reads; rec_total += h->h_ct->rec_reads;
-        if (getenv("GAB_FMI_DEBUG"))
+        if (h->tun.fmi_debug)
             fprintf(stderr, "[gab_fmi] batch of %d reads: %d waves (%d per CU), %.3f ms, %llu index extensions + %llu table look-ups, %llu wave steps -> %.1f extensions per step; %llu positions, %llu spilled, mean list %.2f\n",
                     nb, seed_blocks_dbg, waves_per_cu, ms, h->h_ct->ext_calls, h->h_ct->tab_reads, h->h_ct->wave_steps,
                     (double)(h->h_ct->ext_calls + h->h_ct->tab_reads) / (double)(h->h_ct->wave_steps ? h->h_ct->wave_steps : 1), h->h_ct->positions,
                     h->h_ct->spills, (double)h->h_ct->list_sum / (double)(h->h_ct->positions ? h->h_ct->positions : 1));
-        if (getenv("GAB_FMI_DEBUG") && h->h_ct->wide_items)
+        if (h->tun.fmi_debug && h->h_ct->wide_items)
             fprintf(stderr, "[gab_fmi]   %d wide backward phases handed over (%u list entries), %d re-seeding candidates from them\n",
                     h->h_ct->wide_items, h->h_ct->wide_top, h->h_ct->wide_cands);
         const int64_t add = (int64_t)h->h_ct->total;
@@ -1398,7 +1396,7 @@ extern "C" int gab_fmi_seed_device(gab_fmi *h, const uint8_t *d_enc, int32_t str
             const int64_t round = std::min<int64_t>(n_ovf, per_round);
             rc = h->slots2.reserve(sizeof(OutRec) * (size_t)over_cap * (size_t)round);
             if (rc) return rc;
-            if (getenv("GAB_FMI_DEBUG"))
+            if (h->tun.fmi_debug)
                 fprintf(stderr, "[gab_fmi] %d read(s) overflowed their %d-record slot (worst: %d records): second round in %lld part(s)\n",
                         n_ovf, cap, over_cap, (long long)gab_ceil_div((int64_t)n_ovf, round));
             GAB_HIP(hipEventRecord(h->ev[0], s));

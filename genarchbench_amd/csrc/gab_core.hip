@@ -64,6 +64,36 @@ int gab_check_device(int device) {
     return GAB_OK;
 }
 
+// ---- the experiment knobs (gab_internal.h: gab_tuning) -- the one place of the library that reads them -------------------------
+bool gab_tuning_live() { const char *e = getenv("GAB_TUNING_LIVE"); return e && *e && atoi(e) != 0; }
+void gab_tuning_load(gab_tuning *t) {
+    *t = gab_tuning();
+    auto on = [](const char *name) { return getenv(name) != nullptr; };
+    auto num = [](const char *name, long long unset) { const char *e = getenv(name); return e ? atoll(e) : unset; };
+    t->bsw_trace = on("GAB_BSW_TRACE"); t->bsw_full_scan = on("GAB_BSW_FULL_SCAN");
+    t->bpm_score64 = on("GAB_BPM_SCORE64"); t->bitpal_no_bv = on("GAB_BITPAL_NO_BV"); t->bpm_slices = (int)num("GAB_BPM_SLICES", 0);
+    if (const char *e = getenv("GAB_WFA_TUNE")) {
+        t->wfa_tuned = true;
+        const int k = sscanf(e, "%d,%d,%d,%d,%d,%d,%d", &t->wfa_tune[0], &t->wfa_tune[1], &t->wfa_tune[2], &t->wfa_tune[3], &t->wfa_tune[4], &t->wfa_tune[5], &t->wfa_tune[6]);
+        t->wfa_tune_fields = k > 0 ? k : 0;
+    }
+    t->wfa_no_static = on("GAB_WFA_NO_STATIC"); t->wfa_trace = on("GAB_WFA_TRACE");
+    t->wfa_pool2 = (int)num("GAB_WFA_POOL2", -1); t->wfa_slots = (int)num("GAB_WFA_SLOTS", -1);
+    if (const char *e = getenv("GAB_CHAIN_HELPERS")) { t->chain_helpers_set = true; t->chain_helpers = atoi(e); }
+    { const char *e = getenv("GAB_CHAIN_KERNEL"); t->chain_walk = e && !strcmp(e, "walk"); }
+    t->chain_trace = on("GAB_CHAIN_TRACE"); t->chain_feed_giveup = on("GAB_CHAIN_FEED_GIVEUP"); t->chain_fed_serial = on("GAB_CHAIN_FED_SERIAL");
+    t->chain_no_overlap = on("GAB_CHAIN_NO_OVERLAP"); t->chain_no_feed = on("GAB_CHAIN_NO_FEED");
+    if (const char *e = getenv("GAB_CHAIN_TAB")) t->chain_tab = atoi(e) != 0;
+    t->chain_tab_min = num("GAB_CHAIN_TAB_MIN", -1); t->chain_fast_min = num("GAB_CHAIN_FAST_MIN", -1); t->chain_fast_calls = num("GAB_CHAIN_FAST_CALLS", -1);
+    t->chain_feed_min = num("GAB_CHAIN_FEED_MIN", -1); t->chain_tab_mb = num("GAB_CHAIN_TAB_MB", -1);
+    if (const char *e = getenv("GAB_CHAIN_GATHER_MASK")) { strncpy(t->chain_gather_mask, e, sizeof t->chain_gather_mask - 1); t->chain_gather_mask[sizeof t->chain_gather_mask - 1] = 0; }
+    t->chain_gather_blocks = (int)num("GAB_CHAIN_GATHER_BLOCKS", 0);
+    t->fmi_lds_entries = (int)num("GAB_FMI_LDS_ENTRIES", 0); t->fmi_waves = (int)num("GAB_FMI_WAVES", 0); t->fmi_wide = (int)num("GAB_FMI_WIDE", 1);
+    t->fmi_wide_cap = (int)num("GAB_FMI_WIDE_CAP", 0); t->fmi_kmer_depth = (int)num("GAB_FMI_KMER_DEPTH", -1);
+    t->fmi_wide_lists = num("GAB_FMI_WIDE_LISTS", 0) != 0; t->fmi_debug = on("GAB_FMI_DEBUG");
+    t->fmi_batch = num("GAB_FMI_BATCH", 0); t->fmi_scratch_mb = num("GAB_FMI_SCRATCH_MB", 0);
+}
+
 // ---- plain device-memory helpers for C callers that keep data on the GPU between two entry points ----------------
 extern "C" int gab_device_alloc(int device, size_t bytes, void **out) {
     if (!out) { gab_set_error("gab_device_alloc: NULL argument"); return GAB_EINVAL; }

@@ -82,6 +82,40 @@ bool gab_is_pinned(const void *p);      // hipHostMalloc'ed / registered host me
 
 static inline int64_t gab_ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// ---- experiment knobs and test hooks -------------------------------------------------------------------------------
+// Every GAB_* environment switch the entry points honour lives in this ONE struct; gab_tuning_load (gab_core.hip) is the only
+// place that reads them, ONCE per handle, when the handle is created.  A shipping call reads no environment variable but
+// $GAB_TUNING_LIVE: set (tests/conftest.py does), the handle's copy is read again at every call, so a test can flip a switch
+// between two calls of one handle; a driver never does.  INTEGRATION.md lists what each switch is for.
+struct gab_tuning {
+    // bsw
+    bool bsw_trace = false, bsw_full_scan = false;
+    // bpm / bitpal
+    bool bpm_score64 = false, bitpal_no_bv = false;
+    int bpm_slices = 0;                              // 0 = by batch size
+    // wfa
+    bool wfa_tuned = false, wfa_no_static = false, wfa_trace = false;
+    int wfa_tune[7] = {0, 0, 0, 0, 0, 0, 0};         // GAB_WFA_TUNE, as many fields as it gave
+    int wfa_tune_fields = 0;
+    int wfa_pool2 = -1, wfa_slots = -1;              // -1 = unset
+    // chain / fast-chain
+    int chain_helpers = 0;                           // 3 / 5 / 7, 0 = unset
+    bool chain_helpers_set = false, chain_walk = false, chain_trace = false, chain_feed_giveup = false, chain_fed_serial = false;
+    bool chain_no_overlap = false, chain_no_feed = false;
+    int chain_tab = -1;                              // GAB_CHAIN_TAB: -1 unset, 0 off, 1 on
+    long long chain_tab_min = -1, chain_fast_min = -1, chain_fast_calls = -1, chain_feed_min = -1, chain_tab_mb = -1;   // -1 = unset
+    char chain_gather_mask[32] = "";                 // "" unset, "none", "N:M"
+    int chain_gather_blocks = 0;
+    // fmi
+    int fmi_lds_entries = 0, fmi_waves = 0, fmi_wide = 1, fmi_wide_cap = 0, fmi_kmer_depth = -1;      // (depth: -1 = unset)
+    bool fmi_wide_lists = false, fmi_debug = false;
+    long long fmi_batch = 0, fmi_scratch_mb = 0;
+};
+void gab_tuning_load(gab_tuning *t);
+bool gab_tuning_live();                             // $GAB_TUNING_LIVE
+inline void gab_tuning_refresh(gab_tuning *t) { if (gab_tuning_live()) gab_tuning_load(t); }
+inline gab_tuning gab_tuning_loaded() { gab_tuning t; gab_tuning_load(&t); return t; }     // (the handles' member initialiser)
+
 // 64-bit device atomics need 8-byte-aligned addresses: an unaligned one faults (r03: the cursor of gab_wfa_run_packed sat behind
 // an odd number of 4-byte arrays and the process aborted).  Scratch layouts computed at run time pass the offsets of such
 // words through GAB_CHECK_ATOMIC64; counter structs state it for their members with GAB_STATIC_ATOMIC64.

@@ -912,6 +912,7 @@ __global__ __launch_bounds__(256) void wfa_fill_stride(int64_t *off, uint32_t n,
 
 // =============================================================================== host side
 struct gab_wfa {
+    gab_tuning tun = gab_tuning_loaded();      // experiment knobs, read when the handle is made
     gab_host_stream hs;     // private stream of the host-pointer entry point(s)
     int device = 0;
     WfaPen pen;
@@ -1040,6 +1041,7 @@ extern "C" int gab_wfa_run_device(gab_wfa *h, const char *pat, int64_t pat_bytes
     GAB_CHECK(pat && pat_off && pat_len && txt && txt_off && txt_len && ops_out && ops_off && ops_len_out && score_out,
               "gab_wfa_run_device: NULL buffer");
     gab_device_guard g(h->device);
+    gab_tuning_refresh(&h->tun);
     hipStream_t s = (hipStream_t)stream_;
     const size_t o_l0 = kCountersBytes + kSlotsBytes, o_l1 = o_l0 + 4 * (size_t)n, o_l2 = o_l1 + 4 * (size_t)n;
     int rc = h->ws.reserve(o_l2 + 4 * (size_t)n);
@@ -1081,8 +1083,11 @@ extern "C" int gab_wfa_run_device(gab_wfa *h, const char *pat, int64_t pat_bytes
     int dir_caps[3] = {48, 128, 640};
     int groups[3] = {16, 64, 64};
     int byte_tier = 1;
-    const bool tuned = getenv("GAB_WFA_TUNE") != nullptr;
-    if (tuned) sscanf(getenv("GAB_WFA_TUNE"), "%d,%d,%d,%d,%d,%d,%d", &pool_bytes[0], &dir_caps[0], &pool_bytes[1], &dir_caps[1], &groups[0], &groups[1], &byte_tier);   // tuning runs only
+    const bool tuned = h->tun.wfa_tuned;                    // GAB_WFA_TUNE: tuning runs only
+    if (tuned) {
+        int *dst[7] = {&pool_bytes[0], &dir_caps[0], &pool_bytes[1], &dir_caps[1], &groups[0], &groups[1], &byte_tier};
+        for (int k = 0; k < h->tun.wfa_tune_fields && k < 7; k++) *dst[k] = h->tun.wfa_tune[k];
+    }
     // First tier with one-byte offsets (OffB) when no offset can leave the byte's range: text length + one per score step.
     // Its LDS is budgeted per pair: 2496 B = 10 032 B per wave of four pairs = 16 waves per CU, the measured optimum (the
     // next allocation step down, 14 waves, costs 9 %; 18-20 waves with a smaller history re-queue too many pairs).  In
@@ -1104,7 +1109,7 @@ extern "C" int gab_wfa_run_device(gab_wfa *h, const char *pat, int64_t pat_bytes
     // pairs.  Measured: 1 520 offsets at 20 waves 382 M/s, 1 344 at 23 waves 391, 1 088-1 184 at 24 waves 405; the history a
     // pair needs steps with its score, so 1 216-1 312 offsets buy nothing over 1 184 and cost a wave.
     const int static_pool = tuned && byte_tier > 1 ? byte_tier : std::min(1568 - (seqp + seqt), 4080) & ~15;
-    const bool use_static = !h->adaptive && byte_tier != 0 && !getenv("GAB_WFA_NO_STATIC") && (groups[0] == 16 || groups[0] == 8) && static_rows >= 16 && static_pool >= 1024;
+    const bool use_static = !h->adaptive && byte_tier != 0 && !h->tun.wfa_no_static && (groups[0] == 16 || groups[0] == 8) && static_rows >= 16 && static_pool >= 1024;
     // The tiers are launched back to back: tier k + 1 reads the number of pairs tier k left ON THE DEVICE and is sized by an
     // estimate (its waves stride over whatever there is), so the host looks at the counters once, after the last LDS tier
     // (three round trips of ~30 us less per call: 0.56 -> 0.46 ms per 100 k pairs, 2.65 -> 2.55 ms per 1 M).
@@ -1124,7 +1129,7 @@ extern "C" int gab_wfa_run_device(gab_wfa *h, const char *pat, int64_t pat_bytes
         // two launches: the small pool takes 96 % of the 151-bp pairs at 24 waves per CU, a 2.5 KB pool the scores up to ~64 of
         // the rest (measured: 2048-2560 B best, 4080 B 4 % slower)
         int static_pool2 = 2560;
-        if (const char *e2 = getenv("GAB_WFA_POOL2")) static_pool2 = atoi(e2);
+        if (h->tun.wfa_pool2 >= 0) static_pool2 = h->tun.wfa_pool2;      // GAB_WFA_POOL2
         const int pools[2] = {static_pool, static_pool2};
         // the first launch leaves the wavefronts of the pairs it ran out of room for in slots of the scratch buffer and the second
         // continues them (the pool layout is the table's in both): it does not repeat the ~40 score steps they had come
@@ -1132,7 +1137,7 @@ extern "C" int gab_wfa_run_device(gab_wfa *h, const char *pat, int64_t pat_bytes
         // (a multiple of the pairs per wave, so that the boundary between resumed and restarted pairs falls between waves;
         // the kernel copes with a mixed wave anyway.  GAB_WFA_SLOTS: tests force the boundary into a wave.)
         uint32_t slots = two ? (uint32_t)std::min<uint64_t>(cnt, std::max<uint64_t>(65536, cnt / 8)) & ~7u : 0;
-        if (const char *e3 = getenv("GAB_WFA_SLOTS")) if (two) slots = (uint32_t)std::min<uint64_t>(cnt, (uint64_t)std::max(0, atoi(e3)));
+        if (h->tun.wfa_slots >= 0 && two) slots = (uint32_t)std::min<uint64_t>(cnt, (uint64_t)h->tun.wfa_slots);      // GAB_WFA_SLOTS
         const size_t o_slots = ((size_t)sizeof(WfResume) * cnt + 255) & ~(size_t)255;
         WfResume *d_hdr = nullptr; uint8_t *d_slots = nullptr;
         if (two) {
@@ -1315,7 +1320,8 @@ extern "C" int gab_wfa_run_packed(gab_wfa *h, const char *pat, const int64_t *pa
     GAB_CHECK(pat && pat_off && pat_len && txt && txt_off && txt_len && cigar_off_out && cigar_len_out && score_out && capacity >= 0 &&
               (cigar_out || capacity == 0), "gab_wfa_run_packed: NULL buffer");
     gab_device_guard g(h->device);
-    const bool trace = getenv("GAB_WFA_TRACE") != nullptr;      // diagnosis: per-phase wall times of this call on stderr
+    gab_tuning_refresh(&h->tun);
+    const bool trace = h->tun.wfa_trace;      // GAB_WFA_TRACE, diagnosis: per-phase wall times of this call on stderr
     auto now = [] { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; };
     const double t_0 = now();
     int64_t pb = 0, tb = 0, pa = INT64_MAX, ta = INT64_MAX, stride = 0, room = 0;

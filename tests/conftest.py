@@ -19,6 +19,9 @@ def _cpu_quota():
 
 # the GPU box shows every hardware thread of the host but grants a CPU quota: keep OpenMP (generators, oracle) inside it
 os.environ.setdefault("OMP_NUM_THREADS", str(_cpu_quota()))
+# the library reads its experiment knobs (GAB_* switches) once per handle; the tests flip them between calls of one handle
+# (gab_internal.h: gab_tuning) -- test_bsw_gpu.py::test_knobs_are_read_when_the_handle_is_made covers the shipping behaviour
+os.environ.setdefault("GAB_TUNING_LIVE", "1")
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 

@@ -175,3 +175,26 @@ def test_rejects_bad_input(sw):
         else:
             with pytest.raises(GabError):
                 sw.run_device(*args, stream=torch.cuda.current_stream().cuda_stream)
+
+
+def test_knobs_are_read_when_the_handle_is_made(monkeypatch, capfd):
+    """the GAB_* experiment switches are read ONCE per handle (gab_internal.h: gab_tuning): a switch set after the
+    handle exists changes nothing -- unless GAB_TUNING_LIVE is set, as the test suite does for its own handles"""
+    from genarchbench_amd.bsw import BandedPairWiseSW
+    b = gabgen.bsw(5, 300)
+    monkeypatch.delenv("GAB_TUNING_LIVE", raising=False)
+    monkeypatch.delenv("GAB_BSW_TRACE", raising=False)
+    e = BandedPairWiseSW()
+    monkeypatch.setenv("GAB_BSW_TRACE", "1")                    # after the handle was made: not seen
+    want = e.getScores16(b)
+    assert "[gab_bsw_run" not in capfd.readouterr().err
+    e2 = BandedPairWiseSW()                                     # a handle made now has it
+    np.testing.assert_array_equal(e2.getScores16(b), want)
+    assert "[gab_bsw_run" in capfd.readouterr().err
+    monkeypatch.setenv("GAB_TUNING_LIVE", "1")                  # the tests' mode: every call reads the switches again
+    np.testing.assert_array_equal(e.getScores16(b), want)
+    assert "[gab_bsw_run" in capfd.readouterr().err
+    monkeypatch.delenv("GAB_BSW_TRACE")
+    np.testing.assert_array_equal(e.getScores16(b), want)
+    assert "[gab_bsw_run" not in capfd.readouterr().err
+    e.close(); e2.close()
