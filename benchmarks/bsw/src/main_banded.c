@@ -81,8 +81,10 @@ static void gpp_run(int g, void *v) {
     const double t0 = gab_now();
     GAB_DIE_IF(gab_bsw_run_device(p->h, p->pk.d_ref, p->pk.ref_bytes, p->pk.d_ref_off, p->pk.d_qry, p->pk.qry_bytes, p->pk.d_qry_off, p->pk.d_len1,
                                   p->pk.d_len2, p->pk.d_h0, p->pk.n, p->d_score, NULL, NULL), "gab_bsw_run_device");
+    const double t1 = gab_now();
     GAB_DIE_IF(gab_device_copy_to_host(p->dev, G->score + p->first, p->d_score, 4 * (size_t)p->pk.n), "gab_device_copy_to_host");
     p->busy = gab_now() - t0;
+    if (getenv("GAB_BSW_TRACE")) fprintf(stdout, "[gpu %d] launches returned after %.2f ms, scores on the host after %.2f ms\n", g, (t1 - t0) * 1e3, p->busy * 1e3);
 }
 
 /* 5x5 matrix exactly as bwa_fill_scmat, main_banded.cpp:94-102 */

@@ -247,6 +247,72 @@ __device__ __forceinline__ uint32_t ctab_sad(uint32_t a, uint32_t b) { uint32_t 
 //   oc = min(dr, dq, q_span), unfiltered iff dr != 0, 1 <= dq <= min(max_dist_x, max_dist_y), dd <= bw (chain, n_segs > 1: and
 //   dr <= max_dist_y).  With x ascending dr >= 0 inside a window, so "dr != 0 and dq >= 1" is "oc >= 1" (q_span >= 1: checked
 //   per call); gtab[min(dd, bw + 1)] = gc - bias, and a huge value at bw + 1, so dd > bw clamps to the byte 0 by itself.
+// The sixteen rows of one group for the wave's 64 anchors -> the group's 1 KB.  INSIDE: every row lies in every anchor's window
+// (no window test per pair); NARROW (fast-chain): some anchor of the block takes the scalar tail's double-precision gap cost.
+// Both are wave-uniform and decided ONCE per group by the caller: as run-time flags inside the unrolled rows the compiler turned
+// them into a branch per row -- 32 basic blocks that nothing could be scheduled across (fast-chain: see the rows below).
+template <bool FC, bool MSEG, bool INSIDE, bool NARROW>
+__device__ __forceinline__ uint4 ctab_geo_rows(uint32_t px, uint32_t py, uint32_t xa, int32_t qa, int32_t qs, const int32_t *gap, int32_t bw,
+                                               uint32_t dq_lim, int32_t mdy, int j0, int st_a, uint32_t wspan, bool narrow, double avg_d, int bias,
+                                               int &bad, bool inside_rt) {
+    uint32_t bytes[16];
+    if (NARROW || !FC) {                // row by row: the rare form of fast-chain (the first blocks of a call), and chain
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const uint32_t xj = (uint32_t)__builtin_amdgcn_readlane((int)px, k), yj = (uint32_t)__builtin_amdgcn_readlane((int)py, k);
+            const int32_t dr = (int32_t)(xa - xj), dq = (int32_t)((uint32_t)qa - yj);
+            const uint32_t dd = ctab_sad((uint32_t)dr, (uint32_t)dq);
+            const uint32_t idx = min(dd, (uint32_t)bw + 1u);
+            const int32_t oc = min(min(dr, dq), qs);
+            int32_t gv = oc - gap[idx];
+            if (NARROW) {
+                const int32_t lgh = 15 - (__clz((int)(dd | 1u)) >> 1);
+                const int32_t gd = (int32_t)__dmul_rn(__dmul_rn((double)(int32_t)dd, .01), avg_d) + lgh;
+                gv = (narrow && dd <= (uint32_t)bw) ? oc - gd + bias : gv;
+            }
+            bool ok = oc >= 1 && (uint32_t)dq <= dq_lim;
+            if (MSEG) ok = ok && dr <= mdy;
+            if (!INSIDE && !inside_rt) ok = ok && (uint32_t)(j0 + k - st_a) < wspan;       // (inside_rt: chain decides per group at run time)
+            if (NARROW) bad |= (ok && narrow && dd <= (uint32_t)bw && (gv < 1 || gv > 255)) ? 1 : 0;
+            bytes[k] = ok ? (uint32_t)max(gv, 0) : 0u;
+        }
+    } else {
+        // fast-chain, eight rows at a time: first everything that does not need the gap cost -- and the eight table reads, issued
+        // together and UNCONDITIONALLY (left alone the compiler sinks each read behind its pair's filters: a divergent branch and a wait
+        // for LDS per row) -- then the eight bytes.  Measured (rank 0's share of chain-large on 8 GPUs, two runs each): fast-chain
+        // 4.59 / 4.62 -> 4.42 / 4.31 ms, the 1 000-call input 4.32 / 4.56 -> 4.11 / 4.08 ms; chain 4.77 / 4.94 -> 5.19 / 4.92 ms -- its
+        // filters reject whole rows more often (77 % of the lanes active against 91 %) and the branch skips them: chain keeps the rows
+        // one by one.  (gv <= q_span + bias <= 255: ctab_prep admits a call only then; dd > bw reads the
+        // huge entry bw + 1 and clamps to 0.)
+#pragma unroll
+        for (int h = 0; h < 16; h += 8) {
+            int32_t oc[8], gc[8];
+            bool ok[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const uint32_t xj = (uint32_t)__builtin_amdgcn_readlane((int)px, h + k), yj = (uint32_t)__builtin_amdgcn_readlane((int)py, h + k);
+                const int32_t dr = (int32_t)(xa - xj), dq = (int32_t)((uint32_t)qa - yj);
+                const uint32_t dd = ctab_sad((uint32_t)dr, (uint32_t)dq);
+                oc[k] = min(min(dr, dq), qs);
+                gc[k] = gap[min(dd, (uint32_t)bw + 1u)];
+                ok[k] = oc[k] >= 1 && (uint32_t)dq <= dq_lim;
+                if (MSEG) ok[k] = ok[k] && dr <= mdy;
+                if (!INSIDE) ok[k] = ok[k] && (uint32_t)(j0 + h + k - st_a) < wspan;
+            }
+            // (the eight values are "used" here, all at once: no read can be moved behind its pair's filters, and one wait serves all)
+            asm volatile("" : "+v"(gc[0]), "+v"(gc[1]), "+v"(gc[2]), "+v"(gc[3]), "+v"(gc[4]), "+v"(gc[5]), "+v"(gc[6]), "+v"(gc[7]));
+#pragma unroll
+            for (int k = 0; k < 8; k++) bytes[h + k] = ok[k] ? (uint32_t)max(oc[k] - gc[k], 0) : 0u;
+        }
+    }
+    uint4 o;
+    o.x = bytes[0] | bytes[1] << 8 | bytes[2] << 16 | bytes[3] << 24;
+    o.y = bytes[4] | bytes[5] << 8 | bytes[6] << 16 | bytes[7] << 24;
+    o.z = bytes[8] | bytes[9] << 8 | bytes[10] << 16 | bytes[11] << 24;
+    o.w = bytes[12] | bytes[13] << 8 | bytes[14] << 16 | bytes[15] << 24;
+    return o;
+}
+
 template <int MODE, bool MSEG>
 __global__ __launch_bounds__(256) void ctab_geo(const ChainWork *__restrict__ work, const TabCall *__restrict__ calls, const TabBlock *__restrict__ blocks,
                                                 uint32_t *bail, const int32_t *__restrict__ gtab, const int32_t *__restrict__ st_all,
@@ -290,32 +356,12 @@ __global__ __launch_bounds__(256) void ctab_geo(const ChainWork *__restrict__ wo
         // (rows before the call or behind its last anchor keep x = y = 0: whatever they give is masked by the window test --
         // a group that holds such rows is never `inside`)
         const bool inside = nb == 64 && j0 >= st_hi && j0 >= 0 && j0 + 15 < i0;
-        uint32_t bytes[16];
-#pragma unroll
-        for (int k = 0; k < 16; k++) {
-            const uint32_t xj = (uint32_t)__builtin_amdgcn_readlane((int)px, k), yj = (uint32_t)__builtin_amdgcn_readlane((int)py, k);
-            const int32_t dr = (int32_t)(xa - xj), dq = (int32_t)((uint32_t)qa - yj);
-            const uint32_t dd = ctab_sad((uint32_t)dr, (uint32_t)dq);
-            const uint32_t idx = min(dd, (uint32_t)bw + 1u);
-            const int32_t oc = min(min(dr, dq), qs);
-            int32_t gv = oc - gap[idx];
-            if (FC && any_narrow) {
-                const int32_t lgh = 15 - (__clz((int)(dd | 1u)) >> 1);
-                const int32_t gd = (int32_t)__dmul_rn(__dmul_rn((double)(int32_t)dd, .01), avg_d) + lgh;
-                gv = (narrow && dd <= (uint32_t)bw) ? oc - gd + tc.bias : gv;
-            }
-            bool ok = oc >= 1 && (uint32_t)dq <= dq_lim;
-            if (MSEG) ok = ok && dr <= mdy;
-            if (!inside) ok = ok && (uint32_t)(j0 + k - st_a) < wspan;
-            // (gv <= q_span + bias <= 255: ctab_prep admits a call only then; dd > bw gives a huge negative value)
-            if (FC && any_narrow) bad |= (ok && narrow && dd <= (uint32_t)bw && (gv < 1 || gv > 255)) ? 1 : 0;
-            bytes[k] = ok ? (uint32_t)max(gv, 0) : 0u;
-        }
         uint4 o;
-        o.x = bytes[0] | bytes[1] << 8 | bytes[2] << 16 | bytes[3] << 24;
-        o.y = bytes[4] | bytes[5] << 8 | bytes[6] << 16 | bytes[7] << 24;
-        o.z = bytes[8] | bytes[9] << 8 | bytes[10] << 16 | bytes[11] << 24;
-        o.w = bytes[12] | bytes[13] << 8 | bytes[14] << 16 | bytes[15] << 24;
+#define GAB_GEO_ROWS(INSIDE, NARROW, RT) ctab_geo_rows<FC, MSEG, INSIDE, NARROW>(px, py, xa, qa, qs, gap, bw, dq_lim, mdy, j0, st_a, wspan, narrow, avg_d, tc.bias, bad, RT)
+        if (!FC) o = GAB_GEO_ROWS(false, false, inside);            // chain: one copy of the rows (two measured slower: the instruction cache)
+        else if (any_narrow) o = inside ? GAB_GEO_ROWS(true, true, false) : GAB_GEO_ROWS(false, true, false);
+        else o = inside ? GAB_GEO_ROWS(true, false, false) : GAB_GEO_ROWS(false, false, false);
+#undef GAB_GEO_ROWS
         T8[(tb.grp + g) * 64 + lane] = o;
     }
     if (FC && __ballot(bad != 0) && lane == 0) bail[c] = 1u;      // a byte does not hold this call after all: the other kernels take it

@@ -113,7 +113,10 @@ extern "C" int gab_device_copy_to_host(int device, void *dst, const void *d_src,
     if (bytes == 0) return GAB_OK;
     if (!dst || !d_src) { gab_set_error("gab_device_copy_to_host: NULL argument"); return GAB_EINVAL; }
     gab_device_guard g(device);
-    GAB_HIP(hipMemcpy(dst, d_src, bytes, hipMemcpyDeviceToHost));
+    // (asynchronous copy + wait: the synchronous call moved the 40 MB of bsw-large's scores into page-locked memory in ~9 ms,
+    // a tenth of the link's rate -- the drivers' GPU-parse paths end their region of interest with this copy)
+    GAB_HIP(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, nullptr));
+    GAB_HIP(hipStreamSynchronize(nullptr));
     return GAB_OK;
 }
 

@@ -85,6 +85,28 @@ def test_table_form_patches_and_hands_back(eng, monkeypatch, capfd, kernel_choic
     assert int(line.split("eligible,")[1].split()[0]) >= 1, line          # handed back: too many patches
 
 
+@pytest.mark.parametrize("mode", [0, 1])
+def test_table_too_small_for_the_batch(mode, monkeypatch, capfd, kernel_choice):
+    """GAB_CHAIN_TAB_MB=2: the table holds 2 048 groups of 16 rows -- a few short calls; the calls that find no room (the list is
+    sorted longest first: the long ones take what there is) keep the kernels of chain.hip, and the batch is the oracle's"""
+    if kernel_choice != "table-form-for-all":
+        pytest.skip("table form only")
+    from genarchbench_amd.chain import ChainEngine
+    monkeypatch.setenv("GAB_CHAIN_TAB_MB", "2")
+    monkeypatch.setenv("GAB_CHAIN_TRACE", "1")
+    e = ChainEngine()                                           # (the budget is fixed at a handle's first table-form call)
+    batch = gabgen.chain(35, 120, 0, 50, 6000)
+    ws, wp = pyoracle.chain(batch, mode)
+    capfd.readouterr()
+    s, p = e.host_chain_kernel(batch, mode)
+    err = capfd.readouterr().err
+    e.close()
+    np.testing.assert_array_equal(s, ws)
+    np.testing.assert_array_equal(p, wp)
+    line = [l for l in err.splitlines() if "eligible" in l][-1]
+    assert int(line.split("eligible,")[1].split()[0]) >= 1, line          # handed back: no room
+
+
 def test_walk_kernel_variant(eng, monkeypatch):
     """GAB_CHAIN_KERNEL=walk: the per-anchor walk kernel kept for A/B runs gives the reference's result too"""
     monkeypatch.setenv("GAB_CHAIN_KERNEL", "walk")

@@ -13,12 +13,13 @@ d, w = sys.argv[1], sys.argv[2]
 acc = collections.defaultdict(lambda: collections.defaultdict(float))
 dur = collections.defaultdict(float)
 for p in (0, 1):
-    for f in glob.glob(os.path.join(d, f"{w}_p{p}", "**", "*counter_collection.csv"), recursive=True):
+    # (gpurun merges every call's files into the same directory: the NEWEST collection only)
+    for f in sorted(glob.glob(os.path.join(d, f"{w}_p{p}", "**", "*counter_collection.csv"), recursive=True), key=os.path.getmtime)[-1:]:
         for r in csv.DictReader(open(f)):
             k = re.sub(r"\(.*$", "", r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "")).strip()
             acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
     if p == 0:
-        for f in glob.glob(os.path.join(d, f"{w}_p{p}", "**", "*kernel_trace.csv"), recursive=True):
+        for f in sorted(glob.glob(os.path.join(d, f"{w}_p{p}", "**", "*kernel_trace.csv"), recursive=True), key=os.path.getmtime)[-1:]:
             for r in csv.DictReader(open(f)):
                 k = re.sub(r"\(.*$", "", r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "")).strip()
                 dur[k] += (float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) * 1e-6

@@ -4,9 +4,11 @@
 # capabilities of the hardware to collect", r01's pmcg3.log), so the list is split into passes of FOUR counters, each its
 # own run of the workload; --pmc is only ever combined with --kernel-trace.
 # ITEMS=1000 TAG=_1000 WORKLOADS="chain fast-chain" ...: another input size (--items), results under <workload><TAG>_p<pass>
+# SHARD=0/8 TAG=_shard ...: one rank's share of an N-GPU strong-scaling run (--shard)
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/valu
 EXTRA=""; if [ -n "$ITEMS" ]; then EXTRA="--items $ITEMS"; fi
+if [ -n "$SHARD" ]; then EXTRA="$EXTRA --shard $SHARD"; fi
 PASSES=("SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY" "SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_SALU SQ_INSTS_LDS")
 for w in ${WORKLOADS:-bsw chain fast-chain bpm wfa fmi fmi-sa parse-bsw}; do
   p=0
