@@ -385,6 +385,9 @@ constexpr int kTabRing = 8192;            // scores (minus bias) of the newest a
 #endif
 constexpr int kTabMaxRescans = GAB_TAB_MAX_RESCANS;
 constexpr int kTabMaxPatch = 8;            // anchors of a call whose result max_skip really changed (see the resolver)
+#ifndef GAB_TAB_NEAR_LDS
+#define GAB_TAB_NEAR_LDS 1
+#endif
 #ifndef GAB_KO_CERT_FAR          // timing experiments (wrong results for calls whose certificate misses)
 #define GAB_KO_CERT_FAR 0
 #endif
@@ -411,6 +414,7 @@ struct TabLds {
     int32_t res_key[3][64], res_fg[3][64];
     uint16_t okh[4][8][64];               // chain: one bit per unfiltered near / in-block pair, 16 rows per unit
     TabDesc desc[256];                    // the descriptors of the blocks around the one in work (see ctab_fold)
+    int32_t pk[64];                       // main wave only: the previous block's scores << 7 (read back as broadcasts, four per load)
     int32_t stop[2];                      // 1: the call goes back to chain.hip; 2: start again from block restart_blk (a new patch)
     int32_t restart_blk, patch_n;
     int32_t patch_blk[kTabMaxPatch], patch_lane[kTabMaxPatch], patch_score[kTabMaxPatch], patch_parent[kTabMaxPatch];
@@ -443,6 +447,7 @@ void ctab_fold(const ChainWork *__restrict__ work, const TabCall *__restrict__ c
     const int n = (int)w.n, nblocks = tc.nblk, bias = tc.bias;
     if (threadIdx.x < 2) L.stop[threadIdx.x] = 0;
     if (threadIdx.x == 0) { L.patch_n = 0; L.restart_blk = 0; }
+    if (dbg && threadIdx.x == 0) dbg[32 + 3 * (size_t)c] = (wall_clock64() << 4) | gab_tab_xcc_id();      // GAB_CHAIN_TRACE: when (and on which XCD) the call's workgroup started
 #if defined(GAB_TAB_PRIO_ALL)
     __builtin_amdgcn_s_setprio(3);
 #elif defined(GAB_TAB_PRIO)
@@ -533,6 +538,16 @@ void ctab_fold(const ChainWork *__restrict__ work, const TabCall *__restrict__ c
                 const int4 *gn = &L.G4[par ^ 1][0][0][lane];
                 const int4 *gb = &L.G4[par ^ 1][1][0][lane];
                 if (t > 0 && !GAB_KO_MAIN_NEAR) {
+#if GAB_TAB_NEAR_LDS
+                    // (the previous block's scores come back from LDS as broadcasts, four per 16-byte read, instead of 64 v_readlane:
+                    // the main wave is the phase's critical path, 93 % busy -- GAB_CHAIN_TRACE)
+                    const int4 *pk4 = reinterpret_cast<const int4 *>(L.pk);
+#pragma unroll
+                    for (int g4 = 0; g4 < 16; g4++) {        // the previous block: no dependence between the steps
+                        const int4 g = gn[(size_t)g4 * 64], pv = pk4[g4];
+                        key = max(max(key, g.x + pv.x), max(g.y + pv.y, max(g.z + pv.z, g.w + pv.w)));
+                    }
+#else
                     const int32_t pkey = pbest << 7;
 #pragma unroll
                     for (int g4 = 0; g4 < 16; g4++) {        // the previous block: no dependence between the steps
@@ -542,6 +557,7 @@ void ctab_fold(const ChainWork *__restrict__ work, const TabCall *__restrict__ c
                         key = max(key, g.z + __builtin_amdgcn_readlane(pkey, 4 * g4 + 2));
                         key = max(key, g.w + __builtin_amdgcn_readlane(pkey, 4 * g4 + 3));
                     }
+#endif
                 }
                 if (!FC && L.patch_n)
                     for (int q = 0; q < L.patch_n; q++) if (L.patch_blk[q] == t && L.patch_lane[q] == lane) key = L.patch_score[q] << 7;
@@ -564,6 +580,9 @@ void ctab_fold(const ChainWork *__restrict__ work, const TabCall *__restrict__ c
                 L.res_key[t % 3][lane] = (!mine || key == initkey) ? -1 : key;     // -1: no predecessor improved on q_span
                 L.res_fg[t % 3][lane] = fg;
                 pbest = best;
+#if GAB_TAB_NEAR_LDS
+                L.pk[lane] = best << 7;
+#endif
             }
         } else if (wave == 1) {
             // ------------------------------------------------ resolver: parents (chain: and the certificate), two blocks behind
@@ -793,6 +812,9 @@ void ctab_fold(const ChainWork *__restrict__ work, const TabCall *__restrict__ c
             min_blk = R;
             if (wave == 0) {
                 pbest = R > 0 ? L.ring[(R * 64 - 64 + lane) & (kTabRing - 1)] + bias : 0;
+#if GAB_TAB_NEAR_LDS
+                L.pk[lane] = pbest << 7;
+#endif
                 qs_next = R * 64 + lane < n ? (int32_t)(Y[R * 64 + lane] >> 32 & 0xff) : 0;
             } else if (wave >= 2) {
                 d_cur = desc_of(R); d_nxt = desc_of(R + 1);
@@ -857,6 +879,15 @@ void chain_tab_report(ChainTab *t, size_t nsplit) {
         fprintf(stderr, "[gab_chain table form] fold workgroups per XCD:");
         for (int x = 0; x < 8; x++) fprintf(stderr, " %d", per_xcc[x]);
         fprintf(stderr, "\n");
+        {   // the calls that ended last
+            std::vector<size_t> ord;
+            for (size_t k = 0; k < nsplit; k++) if (dbg[32 + 3 * k] && dbg[32 + 3 * k + 2]) ord.push_back(k);
+            std::sort(ord.begin(), ord.end(), [&](size_t a, size_t b) { return dbg[32 + 3 * a + 2] > dbg[32 + 3 * b + 2]; });
+            for (size_t q = 0; q < ord.size() && q < 6; q++) {
+                const size_t k = ord[q];
+                fprintf(stderr, "   ended last: call %zu (%d blocks): started %.3f ms, done %.3f ms\n", k, hc[k].nblk, ((dbg[32 + 3 * k] >> 4) - t0) * 1e-5, (dbg[32 + 3 * k + 2] - t0) * 1e-5);
+            }
+        }
         for (size_t k = 0; k < nsplit; k = k < 8 ? k + 1 : k * 2) {
             if (!dbg[32 + 3 * k]) continue;
             fprintf(stderr, "   call %zu (%d blocks, XCD %d): started %.3f ms, geometry there %.3f ms, done %.3f ms\n", k, hc[k].nblk, (int)(dbg[32 + 3 * k] & 15),
