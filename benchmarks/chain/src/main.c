@@ -127,10 +127,9 @@ static void cgp_parse(int g, void *v) {
 static void cgp_run(int g, void *v) {
     cgp_part *p = &((cgp_ctx *)v)->part[g];
     if (p->pk.ncalls == 0) return;
-    GAB_DIE_IF(gab_chain_run_device(p->h, GAB_CHAIN_MODE, p->pk.d_x, p->pk.d_y, p->pk.call_off, p->pk.hdr, p->pk.ncalls, p->d_score, p->d_parent, NULL),
-               "gab_chain_run_device");
-    GAB_DIE_IF(gab_device_copy_to_host(p->dev, p->sc, p->d_score, 4 * (size_t)p->pk.total), "gab_device_copy_to_host");
-    GAB_DIE_IF(gab_device_copy_to_host(p->dev, p->pa, p->d_parent, 4 * (size_t)p->pk.total), "gab_device_copy_to_host");
+    /* (the results reach the page-locked host arrays WHILE the DP runs: its kernel writes every block through) */
+    GAB_DIE_IF(gab_chain_run_device_through(p->h, GAB_CHAIN_MODE, p->pk.d_x, p->pk.d_y, p->pk.call_off, p->pk.hdr, p->pk.ncalls, p->d_score, p->d_parent,
+                                            p->sc, p->pa, NULL), "gab_chain_run_device_through");
 }
 
 static void help(void) {

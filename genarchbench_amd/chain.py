@@ -49,6 +49,26 @@ class ChainEngine:
                                          C.c_void_p(score.data_ptr()), C.c_void_p(parent.data_ptr()),
                                          C.c_void_p(stream)))
 
+    def run_device_through(self, mode, x, y, call_off, hdr, score, parent, pinned=True, stream=0):
+        """run_device + the results in host arrays as well (gab_chain_run_device_through): returns (score, parent) numpy arrays;
+        pinned: page-lock them for the call, so that the DP kernel writes them through while it runs"""
+        n = int(score.numel())
+        hs = np.full(n, -777, np.int32); hp = np.full(n, -777, np.int32)
+        locked = []
+        if pinned:
+            for a in (hs, hp):
+                if a.nbytes:
+                    check(lib().gab_host_register(C.c_void_p(a.ctypes.data), C.c_size_t(a.nbytes)))
+                    locked.append(a)
+        try:
+            check(lib().gab_chain_run_device_through(self._h, C.c_int(mode), C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr()),
+                                                     _p(call_off), _p(hdr), C.c_int64(len(hdr)), C.c_void_p(score.data_ptr()),
+                                                     C.c_void_p(parent.data_ptr()), _p(hs), _p(hp), C.c_void_p(stream)))
+        finally:
+            for a in locked:
+                lib().gab_host_unregister(C.c_void_p(a.ctypes.data))
+        return hs, hp
+
     def last_stats(self):
         ev = C.c_int64(0); ms = C.c_float(0)
         check(lib().gab_chain_last_stats(self._h, C.byref(ev), C.byref(ms)))

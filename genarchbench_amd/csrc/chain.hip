@@ -549,7 +549,7 @@ template <bool FED> struct AnchorView {
         return p[i];
     }
 };
-template <int H, bool FED>
+template <int H, bool FED, bool THROUGH = FED>      // THROUGH: every block of 64 results is also written to feed.host_score / host_parent
 __device__ __forceinline__ void fastchain_body(const ChainWork *__restrict__ work, typename AnchorPtr<FED>::type xs,
                                                typename AnchorPtr<FED>::type ys, int32_t *score_out, int32_t *parent_out,
                                                unsigned long long *evals_out, ChainFeed feed) {
@@ -769,7 +769,7 @@ __device__ __forceinline__ void fastchain_body(const ChainWork *__restrict__ wor
             if (mine) {
                 const int32_t par_ = have ? (int32_t)(i0 + best_j) : -1;
                 S[i0 + lane] = best; P[i0 + lane] = par_;
-                if (FED && feed.host_score) { feed.host_score[w.hoff + i0 + lane] = best; feed.host_parent[w.hoff + i0 + lane] = par_; }
+                if (THROUGH && feed.host_score) { feed.host_score[w.hoff + i0 + lane] = best; feed.host_parent[w.hoff + i0 + lane] = par_; }
             }
             pxa = xa; pya = ya; pbest = best; pnb = nb;
         }
@@ -780,11 +780,11 @@ __device__ __forceinline__ void fastchain_body(const ChainWork *__restrict__ wor
 }
 
 // throughput form (three helpers): seven waves per SIMD, +3.7 %; latency form: no register cap (see chain_block_kernel)
-template <int H, bool FED>
+template <int H, bool FED, bool THROUGH = FED>
 __global__ __launch_bounds__(64 * (1 + H)) __attribute__((amdgpu_waves_per_eu(7, 7)))
 void fastchain_kernel(const ChainWork *__restrict__ work, typename AnchorPtr<FED>::type xs, typename AnchorPtr<FED>::type ys, int32_t *score_out,
                       int32_t *parent_out, unsigned long long *evals_out, ChainFeed feed) {
-    fastchain_body<H, FED>(work, xs, ys, score_out, parent_out, evals_out, feed);
+    fastchain_body<H, FED, THROUGH>(work, xs, ys, score_out, parent_out, evals_out, feed);
 }
 template <int H, bool FED>
 __global__ __launch_bounds__(64 * (1 + H))
@@ -882,7 +882,7 @@ __device__ __forceinline__ int32_t chain_geometry_plain(uint32_t xa_lo, int32_t 
 }
 
 
-template <int H, bool FED>
+template <int H, bool FED, bool THROUGH = FED>
 __device__ __forceinline__ void chain_block_body(const ChainWork *__restrict__ work, typename AnchorPtr<FED>::type xs,
                                                  typename AnchorPtr<FED>::type ys, int32_t *score_out, int32_t *parent_out,
                                                  int32_t *gmarks_all, unsigned long long *evals_out, ChainFeed feed) {
@@ -1216,7 +1216,7 @@ __device__ __forceinline__ void chain_block_body(const ChainWork *__restrict__ w
             if (mine) {
                 const int32_t par_ = best_j == kNoJ ? -1 : i0 + best_j;
                 S[i0 + lane] = best; P[i0 + lane] = par_;
-                if (FED && feed.host_score) { feed.host_score[w.hoff + i0 + lane] = best; feed.host_parent[w.hoff + i0 + lane] = par_; }
+                if (THROUGH && feed.host_score) { feed.host_score[w.hoff + i0 + lane] = best; feed.host_parent[w.hoff + i0 + lane] = par_; }
             }
             prev = cur; pbest = best; pnb = nb;
         }
@@ -1230,11 +1230,11 @@ __device__ __forceinline__ void chain_block_body(const ChainWork *__restrict__ w
 // Throughput form (three helpers, big batches): six waves per SIMD = six calls per CU -- 80 VGPRs and 84 B of scratch instead
 // of 99 and none; the kernel is bound by resident calls x per-call latency and a sixth call per CU is worth +5 %.
 // Latency form (batches bound by their longest call): no register cap, the spills would lengthen the critical path (3-5 %).
-template <int H, bool FED>
+template <int H, bool FED, bool THROUGH = FED>
 __global__ __launch_bounds__(64 * (1 + H)) __attribute__((amdgpu_waves_per_eu(6, 6)))
 void chain_block_kernel(const ChainWork *__restrict__ work, typename AnchorPtr<FED>::type xs, typename AnchorPtr<FED>::type ys, int32_t *score_out,
                         int32_t *parent_out, int32_t *gmarks_all, unsigned long long *evals_out, ChainFeed feed) {
-    chain_block_body<H, FED>(work, xs, ys, score_out, parent_out, gmarks_all, evals_out, feed);
+    chain_block_body<H, FED, THROUGH>(work, xs, ys, score_out, parent_out, gmarks_all, evals_out, feed);
 }
 template <int H, bool FED>
 __global__ __launch_bounds__(64 * (1 + H))
@@ -1857,6 +1857,7 @@ static void chain_launch(const gab_tuning &tun, int mode, int helpers, hipStream
         if (feed.facts) hipLaunchKernelGGL((fastchain_kernel<kFcHelpers, true>), dim3(nw), dim3(64 * (1 + kFcHelpers)), 0, s, d_work, d_x, d_y, d_score, d_parent, d_ev, feed);
         else if (helpers == 7) hipLaunchKernelGGL((fastchain_kernel_lat<7, false>), dim3(nw), dim3(64 * 8), 0, s, d_work, d_x, d_y, d_score, d_parent, d_ev, feed);
         else if (helpers == 5) hipLaunchKernelGGL((fastchain_kernel_lat<5, false>), dim3(nw), dim3(64 * 6), 0, s, d_work, d_x, d_y, d_score, d_parent, d_ev, feed);
+        else if (feed.host_score) hipLaunchKernelGGL((fastchain_kernel<kFcHelpers, false, true>), dim3(nw), dim3(64 * (1 + kFcHelpers)), 0, s, d_work, d_x, d_y, d_score, d_parent, d_ev, feed);
         else hipLaunchKernelGGL((fastchain_kernel<kFcHelpers, false>), dim3(nw), dim3(64 * (1 + kFcHelpers)), 0, s, d_work, d_x, d_y, d_score, d_parent, d_ev, feed);
     } else if (tun.chain_walk)      // GAB_CHAIN_KERNEL=walk: the per-anchor walk (A/B runs)
         hipLaunchKernelGGL(chain_hw_kernel, dim3(nw), dim3(64 * (1 + kChHelpers)), 0, s, d_work, d_x, d_y, d_score, d_parent, d_gm, d_ev);
@@ -1868,6 +1869,7 @@ static void chain_launch(const gab_tuning &tun, int mode, int helpers, hipStream
         hipLaunchKernelGGL(chain_facts_kernel, dim3(nw), dim3(256), 0, s, d_work, d_x, d_y, (const uint32_t *)nullptr);
         if (helpers == 7) hipLaunchKernelGGL((chain_block_kernel_lat<7, false>), dim3(nw), dim3(64 * 8), 0, s, d_work, d_x, d_y, d_score, d_parent, d_gm, d_ev, feed);
         else if (helpers == 5) hipLaunchKernelGGL((chain_block_kernel_lat<5, false>), dim3(nw), dim3(64 * 6), 0, s, d_work, d_x, d_y, d_score, d_parent, d_gm, d_ev, feed);
+        else if (feed.host_score) hipLaunchKernelGGL((chain_block_kernel<kCbHelpers, false, true>), dim3(nw), dim3(64 * (1 + kCbHelpers)), 0, s, d_work, d_x, d_y, d_score, d_parent, d_gm, d_ev, feed);
         else hipLaunchKernelGGL((chain_block_kernel<kCbHelpers, false>), dim3(nw), dim3(64 * (1 + kCbHelpers)), 0, s, d_work, d_x, d_y, d_score, d_parent, d_gm, d_ev, feed);
     }
 }
@@ -1898,9 +1900,27 @@ static int chain_fast_setup(gab_chain *h) {
     return GAB_OK;
 }
 
+static int chain_run_device_impl(gab_chain *h, int mode, const uint64_t *d_x, const uint64_t *d_y, const int64_t *call_off, const gab_chain_hdr *hdr,
+                                 int64_t ncalls, int32_t *d_score, int32_t *d_parent, void *stream_, int32_t *host_score, int32_t *host_parent);
 extern "C" int gab_chain_run_device(gab_chain *h, int mode, const uint64_t *d_x, const uint64_t *d_y,
                                     const int64_t *call_off, const gab_chain_hdr *hdr, int64_t ncalls,
                                     int32_t *d_score, int32_t *d_parent, void *stream_) {
+    return chain_run_device_impl(h, mode, d_x, d_y, call_off, hdr, ncalls, d_score, d_parent, stream_, nullptr, nullptr);
+}
+// gab_chain_run_device for a caller that wants the results in HOST memory as well (a driver whose read phase parsed the file on
+// the GPU): the device arrays are filled as always -- the DP reads its predecessors' scores from them -- and the results also land
+// in host_score / host_parent by the time the call returns.  When the whole batch runs in the throughput form and the host arrays
+// are page-locked, every block of 64 results is written through to them by the DP kernel itself (the stores of the fed path,
+// `THROUGH`): 0.68 GB of chain-large cross the bus UNDER the 28 ms of the DP instead of in 12 ms behind it; otherwise the two
+// arrays are copied when the kernels are done.
+extern "C" int gab_chain_run_device_through(gab_chain *h, int mode, const uint64_t *d_x, const uint64_t *d_y, const int64_t *call_off,
+                                            const gab_chain_hdr *hdr, int64_t ncalls, int32_t *d_score, int32_t *d_parent,
+                                            int32_t *host_score, int32_t *host_parent, void *stream_) {
+    GAB_CHECK(host_score && host_parent, "gab_chain_run_device_through: NULL host buffer");
+    return chain_run_device_impl(h, mode, d_x, d_y, call_off, hdr, ncalls, d_score, d_parent, stream_, host_score, host_parent);
+}
+static int chain_run_device_impl(gab_chain *h, int mode, const uint64_t *d_x, const uint64_t *d_y, const int64_t *call_off, const gab_chain_hdr *hdr,
+                                 int64_t ncalls, int32_t *d_score, int32_t *d_parent, void *stream_, int32_t *host_score, int32_t *host_parent) {
     GAB_CHECK(h, "gab_chain_run_device: NULL handle");
     GAB_CHECK(mode == GAB_CHAIN || mode == GAB_FASTCHAIN, "gab_chain_run_device: unknown mode %d", mode);
     GAB_CHECK(ncalls >= 0 && ncalls < (1ll << 31), "gab_chain_run_device: ncalls out of range");
@@ -1961,6 +1981,7 @@ extern "C" int gab_chain_run_device(gab_chain *h, int mode, const uint64_t *d_x,
     const bool legacy_only = (mode == GAB_CHAIN && h->tun.chain_walk) || h->tun.chain_helpers_set;
     size_t ntab = 0, nfast = 0;
     int64_t tab_anchors = 0;
+    bool written_through = false;          // gab_chain_run_device_through: the DP kernel itself fills the host arrays
     if (!legacy_only && h->tun.chain_tab != 0) {
         // A batch whose longest call would outlast 0.75 of the batch's throughput time in the throughput form (0.30 us per anchor of
         // a call, 2.85 G anchors/s over all calls: the latency-form rule below) hands its long calls to the table form: every call
@@ -2023,11 +2044,24 @@ extern "C" int gab_chain_run_device(gab_chain *h, int mode, const uint64_t *d_x,
         }
         if (nfast) GAB_HIP(hipStreamWaitEvent(s, h->fe[1], 0));
         if (ntab) GAB_HIP(hipStreamWaitEvent(s, h->te[1], 0));
-    } else
-    chain_launch(h->tun, mode, chain_helpers_for(h->tun, total, wk.empty() ? 0 : wk[0].n), s, d_work, (unsigned)nw, d_x, d_y, d_score, d_parent, d_gm, d_ev);
+    } else {
+        const int helpers = chain_helpers_for(h->tun, total, wk.empty() ? 0 : wk[0].n);
+        ChainFeed through{nullptr, nullptr, nullptr, nullptr, nullptr, kFeedSpinLimit};
+        void *hs = nullptr, *hp = nullptr;
+        if (host_score && helpers == 3 && !(mode == GAB_CHAIN && h->tun.chain_walk) &&
+            hipHostGetDevicePointer(&hs, host_score, 0) == hipSuccess && hipHostGetDevicePointer(&hp, host_parent, 0) == hipSuccess) {
+            through.host_score = (int32_t *)hs; through.host_parent = (int32_t *)hp;      // page-locked: the DP writes its results through
+            written_through = true;
+        } else (void)hipGetLastError();
+        chain_launch(h->tun, mode, helpers, s, d_work, (unsigned)nw, d_x, d_y, d_score, d_parent, d_gm, d_ev, written_through ? &through : nullptr);
+    }
     GAB_HIP(hipGetLastError());
     GAB_HIP(hipEventRecord(h->ev[1], s));
     GAB_HIP(hipMemcpyAsync(h->h_evals, d_ev, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    if (host_score && !written_through) {
+        GAB_HIP(hipMemcpyAsync(host_score, d_score, sizeof(int32_t) * (size_t)total, hipMemcpyDeviceToHost, s));
+        GAB_HIP(hipMemcpyAsync(host_parent, d_parent, sizeof(int32_t) * (size_t)total, hipMemcpyDeviceToHost, s));
+    }
     GAB_HIP(hipStreamSynchronize(s));    // wk (host vector) must outlive the H2D copy
     if (ntab && h->tun.chain_trace) chain_tab_report(&h->tab, ntab);
     h->have_stats = true;

@@ -149,6 +149,12 @@ int gab_chain_run(gab_chain *h, int mode, const uint64_t *x, const uint64_t *y, 
 int gab_chain_run_device(gab_chain *h, int mode, const uint64_t *d_x, const uint64_t *d_y,
                          const int64_t *call_off, const gab_chain_hdr *hdr, int64_t ncalls,
                          int32_t *d_score, int32_t *d_parent, void *stream);
+/* The same, with the results in HOST memory as well when the call returns (a driver whose read phase parsed the file on the GPU,
+ * gab_chain_parse): d_score / d_parent are filled as always, host_score / host_parent (page-locked for the fast way: the DP kernel
+ * then writes every block of results through to them while it runs; pageable or small batches: copied at the end) receive them too. */
+int gab_chain_run_device_through(gab_chain *h, int mode, const uint64_t *d_x, const uint64_t *d_y,
+                                 const int64_t *call_off, const gab_chain_hdr *hdr, int64_t ncalls,
+                                 int32_t *d_score, int32_t *d_parent, int32_t *host_score, int32_t *host_parent, void *stream);
 /* predecessor evaluations performed (chain: the whole window of an anchor resolved by the plain-maximum path, plus the
  * reference's own visits for the anchors that needed its max_skip scan; fast-chain: the windows) and kernel time (HIP
  * events) of the last run */

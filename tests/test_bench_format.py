@@ -6,6 +6,8 @@ import os
 import sys
 from contextlib import redirect_stdout
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
@@ -99,10 +101,11 @@ def test_headline_sheds_the_suite_rather_than_overflow():
     assert "roofline" in d and "cpu_baseline" in d and "suite" not in d["extra"]
 
 
-def test_the_committed_default_run_of_this_round_is_a_parseable_record():
-    """profiles/r03_bench_default_stdout.txt = the stdout of `python bench.py` on the GPU box at the end of round 3, as the
+@pytest.mark.parametrize("rnd", ["r03", "r04"])
+def test_the_committed_default_run_of_a_round_is_a_parseable_record(rnd):
+    """profiles/<round>_bench_default_stdout.txt = the stdout of `python bench.py` on the GPU box at the end of the round, as the
     driver reads it: suite lines first, the compact headline LAST"""
-    lines = open(os.path.join(ROOT, "profiles", "r03_bench_default_stdout.txt")).read().splitlines()
+    lines = open(os.path.join(ROOT, "profiles", f"{rnd}_bench_default_stdout.txt")).read().splitlines()
     assert all(len(l) < 4096 for l in lines)
     rows = [json.loads(l) for l in lines]
     assert all("suite" in r and isinstance(r["suite"], str) for r in rows[:-1]) and len(rows) >= 12
@@ -115,3 +118,7 @@ def test_the_committed_default_run_of_this_round_is_a_parseable_record():
     for r in rows[:-1]:
         if "value" in r and r["suite"].endswith("-large"):
             assert r["extra"].get("value_roi_incl_pcie"), r["suite"]          # SURVEY.md 8(d)'s ROI for every large workload
+    if rnd >= "r04":        # r04: the CPU comparison is like for like, the quota is said in words, `value` says what it is
+        assert last["config"]["value_is"] == "hbm_resident" and last["cpu_baseline"]["per_core"] > 0
+        assert "cgroup quota" in last["cpu_baseline"]["sample"] or last["cpu_baseline"]["cores"] == last["cpu_baseline"]["host_threads_visible"]
+        assert abs(last["extra"]["x_cpu_baseline"] - last["extra"]["value_roi_incl_pcie"] / last["cpu_baseline"]["value"]) < 0.05

@@ -172,6 +172,42 @@ def test_fed_path_gives_up_and_the_copy_engines_take_over(eng, mode, monkeypatch
 
 
 @pytest.mark.parametrize("mode", [0, 1])
+def test_fed_path_two_handles_on_one_gpu(mode, monkeypatch, kernel_choice):
+    """two handles of one GPU in the fed path AT ONCE (a driver's queue workers run side by side): each
+    has its own gather stream on its own CU per XCD, its own residency probe through host memory and its own facts words -- three
+    rounds of two concurrent calls on different batches, every result the oracle's"""
+    if kernel_choice != "default-split":
+        pytest.skip("one kernel choice is enough for the host path")
+    import threading
+    from genarchbench_amd.chain import ChainEngine
+    monkeypatch.setenv("GAB_CHAIN_FEED_MIN", "1000")
+    batches = [gabgen.chain(41, 400, 0, 1, 20000), gabgen.chain(42, 60, 1, 500, 12000)]
+    want = [pyoracle.chain(b, mode) for b in batches]
+    engines = [ChainEngine(), ChainEngine()]
+    errors = []
+
+    def work(k):
+        try:
+            for rnd in range(3):
+                b = batches[(k + rnd) % 2]
+                s, p = engines[k].host_chain_kernel(b, mode, pinned=True)
+                ws, wp = want[(k + rnd) % 2]
+                if not (np.array_equal(s, ws) and np.array_equal(p, wp)):
+                    errors.append((k, rnd))
+        except Exception as e:      # noqa: BLE001  (reported below, from the main thread)
+            errors.append((k, repr(e)))
+
+    th = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for e in engines:
+        e.close()
+    assert not errors, errors
+
+
+@pytest.mark.parametrize("mode", [0, 1])
 def test_gap_cost_table_limits(eng, mode):
     """the block kernels read the gap cost of a pair from a per-call table of bw + 2 entries when 0 <= bw <= 2046 and
     compute it otherwise: band widths on both sides of the limit, 0 and 1, with diagonal differences from 0 to beyond bw,
@@ -257,3 +293,23 @@ def test_device_resident(eng):
         ws, wp = pyoracle.chain(batch, mode)
         np.testing.assert_array_equal(sc.cpu().numpy(), ws)
         np.testing.assert_array_equal(pa.cpu().numpy(), wp)
+
+
+@pytest.mark.parametrize("pinned", [True, False])
+def test_device_resident_results_written_through_to_the_host(eng, pinned):
+    """gab_chain_run_device_through (the drivers' GPU-parse path): device arrays filled as always, and the same results in host arrays
+    when the call returns -- written through by the DP kernel itself when the batch runs in the throughput form and the host arrays
+    are page-locked (many equal calls: no call is waited for), copied at the end otherwise (pageable arrays; the other kernel forms of
+    the dispatch modes this file runs under)"""
+    import torch
+    dev = torch.device("cuda:0")
+    for batch in (gabgen.chain(43, 2500, 0, 600, 1500), gabgen.chain(44, 40, 0, 50, 9000)):
+        x = torch.from_numpy(batch.x.view(np.int64)).to(dev); y = torch.from_numpy(batch.y.view(np.int64)).to(dev)
+        sc = torch.zeros(batch.nanchors, dtype=torch.int32, device=dev); pa = torch.zeros_like(sc)
+        for mode in (0, 1):
+            hs, hp = eng.run_device_through(mode, x, y, batch.call_off, batch.hdr, sc, pa, pinned=pinned, stream=torch.cuda.current_stream().cuda_stream)
+            ws, wp = pyoracle.chain(batch, mode)
+            np.testing.assert_array_equal(hs, ws)
+            np.testing.assert_array_equal(hp, wp)
+            np.testing.assert_array_equal(sc.cpu().numpy(), ws)
+            np.testing.assert_array_equal(pa.cpu().numpy(), wp)
