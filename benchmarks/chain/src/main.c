@@ -178,7 +178,7 @@ int main(int argc, char **argv) {
      * (gab_chain_parse); the anchors stay on the GPU that parsed them, the ROI is one gab_chain_run_device per
      * GPU.  Files that are not in the one-record-per-line layout are declined and take the fscanf path below. */
     const int64_t fsz = gab_regular_file_size(in);      /* -1 for pipes: they take the fscanf path */
-    if (gab_gpu_parse_wanted(0) && fsz >= 0) {
+    if (gab_gpu_parse_wanted(1) && fsz >= 0) {
         const int ng = gab_pick_gpus(gpus);
         char *whole = (char *)malloc((size_t)fsz + 1);
         cgp_ctx G;

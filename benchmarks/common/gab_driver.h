@@ -261,11 +261,11 @@ static inline void gab_pin_out_on(int dev, void *p, size_t bytes) {
 static inline void gab_pin_out(void *p, size_t bytes) { gab_pin_out_on(gab_phys_gpu(0), p, bytes); }
 static inline void gab_unpin(const void *p) { if (!gab_env_i64("GAB_NO_PIN", 0)) gab_host_unregister((void *)p); }
 
-/* GAB_GPU_PARSE=1 / 0 turn the whole-file GPU parsers on / off; unset = the driver's default: on for bsw, bpm
- * and wfa (r04: the read phase leaves the pairs on the GPU, so the region of interest is kernels + results back -- bpm-large 61 ->
- * 7.8 ms, wfa-large 8.8 -> 4.1 ms, and the read phase itself is the parsers' GB/s instead of a getline loop), off for chain, whose
- * host path overlaps the anchors' copy with the DP (37 ms against 40 with 0.7 GB of results copied back behind the DP).  Pipes
- * always take the line readers. */
+/* GAB_GPU_PARSE=1 / 0 turn the whole-file GPU parsers on / off; unset = the driver's default: ON in all four
+ * drivers since r04 -- the read phase leaves the input on the GPU, so the region of interest is kernels + results back (bpm-large
+ * 61 -> 7.5 ms, wfa-large 8.6 -> 4.1 ms, bsw-large 60 -> 47 ms, chain-large 37.5 -> 29.5 ms: its DP kernel writes the results through
+ * to the page-locked output arrays while it runs), and the read phase itself is the parsers' GB/s instead of a getline / fscanf loop.
+ * Pipes, and files a parser declines, always take the line readers. */
 static inline int gab_gpu_parse_wanted(int dflt) { const char *e = getenv("GAB_GPU_PARSE"); return (e && *e) ? atoi(e) != 0 : dflt; }
 
 /* ---- GAB_GPU_PARSE with N GPUs: the file cut at record boundaries, one piece per GPU --------------

@@ -49,12 +49,12 @@ PY
   exit 0
 fi
 for w in ${@:-1 2 3}; do   # chain-large through the driver needs its fscanf parse of 85 M anchors (~20 s) per run
-  export GAB_WORKERS_PER_GPU=$w GAB_GPUS=1
+  export GAB_WORKERS_PER_GPU=$w GAB_GPUS=1 GAB_GPU_PARSE=0      # the host-pointer path: line readers, page-locked slabs, chunks x workers
   ./benchmarks/bsw/main_bsw -pairs $T/bsw.txt -t 1 -b 512 2> $T/bsw_err_$w.txt | grep -E "Overall SW" | sed "s/^/bsw-large driver, $w worker(s) per GPU: /"
   echo "   md5 of the scores: $(grep score= $T/bsw_err_$w.txt | md5sum | cut -c1-12)"
-  ./benchmarks/chain/chain -i $T/chain.txt -o $T/chain_out_$w.txt -t 1 2>&1 | grep "Time in kernel" | sed "s/^/chain-large driver, $w worker(s) per GPU: /"
+  ./benchmarks/chain/chain -i $T/chain.txt -o $T/chain_out_$w.txt -t 1 2>&1 | grep -E "Time in kernel|region of interest" | sed "s/^/chain-large driver, $w worker(s) per GPU: /"
   echo "   md5 of the output: $(md5sum $T/chain_out_$w.txt | cut -c1-12)"
-  ./benchmarks/fast-chain/chain -i $T/chain.txt -o $T/fchain_out_$w.txt -t 1 2>&1 | grep "Time in kernel" | sed "s/^/fast-chain-large driver, $w worker(s) per GPU: /"
+  ./benchmarks/fast-chain/chain -i $T/chain.txt -o $T/fchain_out_$w.txt -t 1 2>&1 | grep -E "Time in kernel|region of interest" | sed "s/^/fast-chain-large driver, $w worker(s) per GPU: /"
   ./benchmarks/bpm/bin/align_benchmark -a bpm-edit -i $T/bpm.txt -o $T/bpm_out_$w.txt -t 1 2>&1 | grep "Time.Benchmark" | tr -s " " | sed "s/^/bpm-large driver, $w worker(s) per GPU: /"
   echo "   md5 of the sorted output: $(sort -n -t "[" -k 2,2 $T/bpm_out_$w.txt | md5sum | cut -c1-12)"
   ./benchmarks/wfa/bin/align_benchmark -i $T/wfa.txt -o $T/wfa_out_$w.txt -t 1 2>&1 | grep "Time.Alignment" | sed "s/^/wfa-large driver, $w worker(s) per GPU: /"
@@ -66,9 +66,9 @@ if [[ -z "$GAB_ROI_NO_GPU_PARSE" ]]; then
   export GAB_WORKERS_PER_GPU=1 GAB_GPUS=1 GAB_GPU_PARSE=1
   ./benchmarks/bsw/main_bsw -pairs $T/bsw.txt -t 1 -b 512 2> $T/bsw_err_gp.txt | grep -E "Overall SW" | sed "s/^/bsw-large driver, GPU parse: /"
   echo "   md5 of the scores: $(grep score= $T/bsw_err_gp.txt | md5sum | cut -c1-12)"
-  ./benchmarks/chain/chain -i $T/chain.txt -o $T/chain_out_gp.txt -t 1 2>&1 | grep "Time in kernel" | sed "s/^/chain-large driver, GPU parse: /"
+  ./benchmarks/chain/chain -i $T/chain.txt -o $T/chain_out_gp.txt -t 1 2>&1 | grep -E "Time in kernel|region of interest" | sed "s/^/chain-large driver, GPU parse: /"
   echo "   md5 of the output: $(md5sum $T/chain_out_gp.txt | cut -c1-12)"
-  ./benchmarks/fast-chain/chain -i $T/chain.txt -o $T/fchain_out_gp.txt -t 1 2>&1 | grep "Time in kernel" | sed "s/^/fast-chain-large driver, GPU parse: /"
+  ./benchmarks/fast-chain/chain -i $T/chain.txt -o $T/fchain_out_gp.txt -t 1 2>&1 | grep -E "Time in kernel|region of interest" | sed "s/^/fast-chain-large driver, GPU parse: /"
   ./benchmarks/bpm/bin/align_benchmark -a bpm-edit -i $T/bpm.txt -o $T/bpm_out_gp.txt -t 1 2>&1 | grep "Time.Benchmark" | tr -s " " | sed "s/^/bpm-large driver, GPU parse: /"
   echo "   md5 of the sorted output: $(sort -n -t "[" -k 2,2 $T/bpm_out_gp.txt | md5sum | cut -c1-12)"
   ./benchmarks/wfa/bin/align_benchmark -i $T/wfa.txt -o $T/wfa_out_gp.txt -t 1 2>&1 | grep "Time.Alignment" | sed "s/^/wfa-large driver, GPU parse: /"

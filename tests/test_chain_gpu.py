@@ -186,10 +186,15 @@ def test_fed_path_two_handles_on_one_gpu(mode, monkeypatch, kernel_choice):
     engines = [ChainEngine(), ChainEngine()]
     errors = []
 
+    import dataclasses
+    # (every worker its own copies of the arrays, as a driver's workers have their own slabs: the binding page-locks the arrays of
+    # a call and unlocks them after it -- shared arrays would be unlocked under the other worker's running fetch kernel)
+    own = [[dataclasses.replace(b, x=b.x.copy(), y=b.y.copy()) for b in batches] for _ in range(2)]
+
     def work(k):
         try:
             for rnd in range(3):
-                b = batches[(k + rnd) % 2]
+                b = own[k][(k + rnd) % 2]
                 s, p = engines[k].host_chain_kernel(b, mode, pinned=True)
                 ws, wp = want[(k + rnd) % 2]
                 if not (np.array_equal(s, ws) and np.array_equal(p, wp)):

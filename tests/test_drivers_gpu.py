@@ -361,14 +361,14 @@ def test_perf_analysis_fifo_protocol(inputs, tmp_path):
 
 
 def test_default_read_phase(inputs, tmp_path):
-    """r04: with GAB_GPU_PARSE unset the bsw, bpm and wfa drivers parse a regular file on the GPU and keep the pairs there (the
-    region of interest is kernels + results back); chain keeps its host reader (its host path overlaps the copy with the DP);
+    """r04: with GAB_GPU_PARSE unset all the drivers parse a regular file on the GPU and keep the input there (the region of
+    interest is kernels + results back; chain's DP kernel writes its results through to the host arrays);
     GAB_GPU_PARSE=0 turns the GPU parsers off everywhere"""
     base = {k: v for k, v in os.environ.items() if k != "GAB_GPU_PARSE"}
     runs = [("bsw", [os.path.join(ROOT, "benchmarks", "bsw", "main_bsw"), "-pairs", f"{inputs}/bsw/small/bandedSWA_SRR7733443_100k_input.txt", "-t", "1", "-b", "512"], True),
             ("bpm", [os.path.join(ROOT, "benchmarks", "bpm", "bin", "align_benchmark"), "-a", "bpm-edit", "-i", f"{inputs}/bpm/small/BPM_SRR7733443_100k_input.txt", "-o", str(tmp_path / "b.txt")], True),
             ("wfa", [os.path.join(ROOT, "benchmarks", "wfa", "bin", "align_benchmark"), "-i", f"{inputs}/wfa/small/WFA_SRR7733443_100k_input.txt", "-o", str(tmp_path / "w.txt")], True),
-            ("chain", [os.path.join(ROOT, "benchmarks", "chain", "chain"), "-i", f"{inputs}/chain/small/in-1k.txt", "-o", str(tmp_path / "c.txt"), "-t", "1"], False)]
+            ("chain", [os.path.join(ROOT, "benchmarks", "chain", "chain"), "-i", f"{inputs}/chain/small/in-1k.txt", "-o", str(tmp_path / "c.txt"), "-t", "1"], True)]
     for name, args, on_gpu in runs:
         r = subprocess.run(args, capture_output=True, text=True, timeout=300, env=base)
         assert r.returncode == 0, (name, r.stderr[-300:])
