@@ -39,7 +39,7 @@ HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec 
 # HBM traffic of the dominant kernel(s) of a workload's LARGE configuration, measured once per round with rocprofv3 PMC
 # counters in separate passes (tools/profiling/hbm_traffic.sh -> profiles/<ROUND>_hbm_traffic.json); `double_fetch`: the
 # kernel reads wide coalesced streams, for which gfx950's FETCH_SIZE reports half the bytes (MI355X_MICROARCH.md, HBM)
-TRAFFIC_KERNELS = {"bsw": (["bsw_dp8"], False), "chain": (["chain_block_kernel", "chain_facts_kernel"], False), "fast-chain": (["fastchain_kernel"], False),
+TRAFFIC_KERNELS = {"bsw": (["bsw_dp8"], False), "chain": (["chain_block_kernel", "chain_facts_kernel"], False), "fast-chain": (["ctab_geo<1", "ctab_fold<1", "fastchain_kernel"], False),
                    "bpm": (["bpm_score32<", "bpm_score<"], False), "bitpal": (["bitpal_dp<true, true>"], False), "bitpal-edit": (["bitpal_edit_bv<"], False), "wfa": (["wfa_lds_static<16, false>"], False), "fmi": (["fmi_seed_kernel<true>"], False),
                    "fmi-sa": (["fmi_sa_kernel"], False), "parse-bsw": (["nl_count", "nl_fill", "bsw_meta", "bsw_codes", "len_offsets",
                                                                        "len_block_sums"], True)}
@@ -455,7 +455,9 @@ class FastChainWorkload(ChainWorkload):
     mode = 1
     metric = "fast-chain ROI M seeds/sec"
     dtype = "i32+f32"
-    kernel = "fastchain_kernel"
+    # r04: calls of >= 4 096 anchors run in the table form whatever the batch (chain_tab.hip: geometry + fold), the rest in
+    # fastchain_kernel beside them; the event-timed region covers all of them
+    kernel = "ctab_geo<1, false> + ctab_fold<1> (calls >= 4096 anchors), fastchain_kernel (the rest)"
 
 
 # ------------------------------------------------------------------------------------- bpm

@@ -121,7 +121,7 @@ static void cgp_parse(int g, void *v) {
     p->sc = (int32_t *)malloc(4 * t + 4); p->pa = (int32_t *)malloc(4 * t + 4);
     if (!p->sc || !p->pa) return;
     gab_pin_out_on(p->dev, p->sc, 4 * t + 4); gab_pin_out_on(p->dev, p->pa, 4 * t + 4);
-    if (gab_chain_reserve(p->h, p->pk.total, p->pk.ncalls) != 0) return;      /* work tables, streams, first launches: before the region of interest */
+    if (gab_chain_reserve_mode(p->h, GAB_CHAIN_MODE, p->pk.total, p->pk.ncalls) != 0) return;   /* work tables, streams, first launches, fast-chain's table: before the region of interest */
     p->ok = 1;
 }
 static void cgp_run(int g, void *v) {

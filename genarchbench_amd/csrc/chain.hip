@@ -1981,7 +1981,14 @@ static int chain_run_device_impl(gab_chain *h, int mode, const uint64_t *d_x, co
     const bool legacy_only = (mode == GAB_CHAIN && h->tun.chain_walk) || h->tun.chain_helpers_set;
     size_t ntab = 0, nfast = 0;
     int64_t tab_anchors = 0;
-    bool written_through = false;          // gab_chain_run_device_through: the DP kernel itself fills the host arrays
+    bool written_through = false;          // gab_chain_run_device_through: the DP kernels themselves fill the host arrays
+    int32_t *hs = nullptr, *hp = nullptr;  // ... device-visible addresses of the caller's page-locked arrays (nullptr: pageable, or not asked for)
+    if (host_score) {
+        void *a = nullptr, *b = nullptr;
+        if (hipHostGetDevicePointer(&a, host_score, 0) == hipSuccess && hipHostGetDevicePointer(&b, host_parent, 0) == hipSuccess) { hs = (int32_t *)a; hp = (int32_t *)b; }
+        else (void)hipGetLastError();
+    }
+    uint32_t *d_bail = nullptr;
     if (!legacy_only && h->tun.chain_tab != 0) {
         // A batch whose longest call would outlast 0.75 of the batch's throughput time in the throughput form (0.30 us per anchor of
         // a call, 2.85 G anchors/s over all calls: the latency-form rule below) hands its long calls to the table form: every call
@@ -1993,6 +2000,11 @@ static int chain_run_device_impl(gab_chain *h, int mode, const uint64_t *d_x, co
         int64_t min_n = INT64_MAX;
         const double est_tp = (double)total / 2.85e9, lat_max = 0.30e-6 * (double)wk[0].n;
         if (lat_max >= 0.75 * est_tp) min_n = std::max<int64_t>(2048, (int64_t)(0.25 * est_tp / 0.30e-6));
+        // fast-chain (no certificate, no exact re-scans; its geometry rows are batched): since the end of r04 the table form is also
+        // the FASTER form for calls of a few thousand anchors and more, whatever the batch -- all of fast-chain-large on one GPU with
+        // the calls of >= 40 000 / 25 000 / 12 500 / 4 096 / 2 048 / 512 / 1 anchors there: 27.87 / 27.09 / 26.15 / 25.88-25.95 / 26.16 / 26.48 /
+        // 26.65 ms against 27.65 without.  chain: 29.2 / 28.4 / 27.9 / 28.2 against 27.8 -- it keeps the rule above.
+        if (mode == GAB_FASTCHAIN) min_n = std::min<int64_t>(min_n, 4096);
         if (h->tun.chain_tab_min >= 0) min_n = h->tun.chain_tab_min;      // GAB_CHAIN_TAB_MIN
         while (ntab < nw && wk[ntab].n >= min_n) { tab_anchors += wk[ntab].n; ntab++; }
     }
@@ -2015,8 +2027,7 @@ static int chain_run_device_impl(gab_chain *h, int mode, const uint64_t *d_x, co
         if (ntab) {
             // the table form and, behind it on the same stream, the latency form for the calls it hands back (bail word set)
             GAB_HIP(hipStreamWaitEvent(h->ts, h->fe[0], 0));
-            uint32_t *d_bail = nullptr;
-            if ((rc = chain_tab_run(&h->tab, h->tun, mode, h->ts, d_work, wk.data(), ntab, total, d_x, d_y, d_score, d_parent, d_gm, d_ev, &d_bail)) != GAB_OK) return rc;
+            if ((rc = chain_tab_run(&h->tab, h->tun, mode, h->ts, d_work, wk.data(), ntab, total, d_x, d_y, d_score, d_parent, d_gm, d_ev, &d_bail, nfast == 0 ? hs : nullptr, nfast == 0 ? hp : nullptr)) != GAB_OK) return rc;
             if (mode == GAB_CHAIN) hipLaunchKernelGGL(chain_facts_kernel, dim3((unsigned)ntab), dim3(256), 0, h->ts, d_work, d_x, d_y, (const uint32_t *)d_bail);
             if (mode == GAB_CHAIN)
                 hipLaunchKernelGGL(chain_fast_kernel<GAB_CHAIN>, dim3((unsigned)ntab), dim3(64 * (2 + kFastW)), kFastDynLds, h->ts, d_work, d_x, d_y, d_score, d_parent, d_gm, d_ev, (const uint32_t *)d_bail);
@@ -2034,35 +2045,54 @@ static int chain_run_device_impl(gab_chain *h, int mode, const uint64_t *d_x, co
             GAB_HIP(hipGetLastError());
             GAB_HIP(hipEventRecord(h->fe[1], h->fs));
         }
+        // (gab_chain_run_device_through: the table form and the throughput form write their results through; the latency form does
+        // not, and neither do the calls the table form hands back -- then the arrays are copied at the end)
+        written_through = hs != nullptr && nfast == 0;
         if (nrest > nfast) {
-            if (mode == GAB_CHAIN)
-                hipLaunchKernelGGL((chain_block_kernel<kCbHelpers, false>), dim3((unsigned)(nrest - nfast)), dim3(64 * (1 + kCbHelpers)), 0, s, d_work + ntab + nfast, d_x, d_y,
-                                   d_score, d_parent, d_gm, d_ev, nofeed);
-            else
-                hipLaunchKernelGGL((fastchain_kernel<kFcHelpers, false>), dim3((unsigned)(nrest - nfast)), dim3(64 * (1 + kFcHelpers)), 0, s, d_work + ntab + nfast, d_x, d_y,
-                                   d_score, d_parent, d_ev, nofeed);
+            const ChainFeed through{nullptr, hs, hp, nullptr, nullptr, kFeedSpinLimit};
+            if (mode == GAB_CHAIN) {
+                if (written_through)
+                    hipLaunchKernelGGL((chain_block_kernel<kCbHelpers, false, true>), dim3((unsigned)(nrest - nfast)), dim3(64 * (1 + kCbHelpers)), 0, s, d_work + ntab + nfast, d_x, d_y,
+                                       d_score, d_parent, d_gm, d_ev, through);
+                else
+                    hipLaunchKernelGGL((chain_block_kernel<kCbHelpers, false>), dim3((unsigned)(nrest - nfast)), dim3(64 * (1 + kCbHelpers)), 0, s, d_work + ntab + nfast, d_x, d_y,
+                                       d_score, d_parent, d_gm, d_ev, nofeed);
+            } else {
+                if (written_through)
+                    hipLaunchKernelGGL((fastchain_kernel<kFcHelpers, false, true>), dim3((unsigned)(nrest - nfast)), dim3(64 * (1 + kFcHelpers)), 0, s, d_work + ntab + nfast, d_x, d_y,
+                                       d_score, d_parent, d_ev, through);
+                else
+                    hipLaunchKernelGGL((fastchain_kernel<kFcHelpers, false>), dim3((unsigned)(nrest - nfast)), dim3(64 * (1 + kFcHelpers)), 0, s, d_work + ntab + nfast, d_x, d_y,
+                                       d_score, d_parent, d_ev, nofeed);
+            }
         }
         if (nfast) GAB_HIP(hipStreamWaitEvent(s, h->fe[1], 0));
         if (ntab) GAB_HIP(hipStreamWaitEvent(s, h->te[1], 0));
     } else {
         const int helpers = chain_helpers_for(h->tun, total, wk.empty() ? 0 : wk[0].n);
         ChainFeed through{nullptr, nullptr, nullptr, nullptr, nullptr, kFeedSpinLimit};
-        void *hs = nullptr, *hp = nullptr;
-        if (host_score && helpers == 3 && !(mode == GAB_CHAIN && h->tun.chain_walk) &&
-            hipHostGetDevicePointer(&hs, host_score, 0) == hipSuccess && hipHostGetDevicePointer(&hp, host_parent, 0) == hipSuccess) {
-            through.host_score = (int32_t *)hs; through.host_parent = (int32_t *)hp;      // page-locked: the DP writes its results through
+        if (hs && helpers == 3 && !(mode == GAB_CHAIN && h->tun.chain_walk)) {
+            through.host_score = hs; through.host_parent = hp;      // page-locked: the DP writes its results through
             written_through = true;
-        } else (void)hipGetLastError();
+        }
         chain_launch(h->tun, mode, helpers, s, d_work, (unsigned)nw, d_x, d_y, d_score, d_parent, d_gm, d_ev, written_through ? &through : nullptr);
     }
     GAB_HIP(hipGetLastError());
     GAB_HIP(hipEventRecord(h->ev[1], s));
     GAB_HIP(hipMemcpyAsync(h->h_evals, d_ev, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    std::vector<uint32_t> h_bail;
+    if (written_through && ntab) { h_bail.resize(ntab); GAB_HIP(hipMemcpyAsync(h_bail.data(), d_bail, 4 * ntab, hipMemcpyDeviceToHost, s)); }
     if (host_score && !written_through) {
         GAB_HIP(hipMemcpyAsync(host_score, d_score, sizeof(int32_t) * (size_t)total, hipMemcpyDeviceToHost, s));
         GAB_HIP(hipMemcpyAsync(host_parent, d_parent, sizeof(int32_t) * (size_t)total, hipMemcpyDeviceToHost, s));
     }
     GAB_HIP(hipStreamSynchronize(s));    // wk (host vector) must outlive the H2D copy
+    if (written_through && ntab && std::any_of(h_bail.begin(), h_bail.end(), [](uint32_t b) { return b != 0; })) {
+        // a call the table form handed back ran in the latency form, which writes to the device arrays only: copy after all
+        GAB_HIP(hipMemcpyAsync(host_score, d_score, sizeof(int32_t) * (size_t)total, hipMemcpyDeviceToHost, s));
+        GAB_HIP(hipMemcpyAsync(host_parent, d_parent, sizeof(int32_t) * (size_t)total, hipMemcpyDeviceToHost, s));
+        GAB_HIP(hipStreamSynchronize(s));
+    }
     if (ntab && h->tun.chain_trace) chain_tab_report(&h->tab, ntab);
     h->have_stats = true;
     return GAB_OK;
@@ -2483,6 +2513,36 @@ extern "C" int gab_chain_reserve(gab_chain *h, int64_t max_anchors, int64_t max_
         GAB_HIP(hipStreamSynchronize(sG));
     }
     return gab_warm_copy_engines(s, h->io.p, h->io.cap);
+}
+
+// gab_chain_reserve + what the DEVICE entry points of `mode` need before a timed region: one small batch through
+// gab_chain_run_device (the first launch of every kernel of the forms the mode uses) and -- fast-chain, whose calls of a few
+// thousand anchors and more run in the table form whatever the batch -- the table for max_anchors anchors (36 GB for fast-chain-large:
+// an allocation of that size inside a driver's region of interest would cost more than the call).
+extern "C" int gab_chain_reserve_mode(gab_chain *h, int mode, int64_t max_anchors, int64_t max_calls) {
+    int rc = gab_chain_reserve(h, max_anchors, max_calls);
+    if (rc) return rc;
+    GAB_CHECK(mode == GAB_CHAIN || mode == GAB_FASTCHAIN, "gab_chain_reserve_mode: unknown mode %d", mode);
+    gab_device_guard g(h->device);
+    constexpr int kN = 6144;                                     // one call, long enough for the table form
+    std::vector<uint64_t> xy(2 * kN);
+    for (int i = 0; i < kN; i++) { xy[i] = 100 + 13ull * i; xy[kN + i] = (15ull << 32) | (uint64_t)(50 + 13 * i + (i % 7)); }
+    char *b = h->io.as<char>();                                  // (>= 4 MB: gab_chain_reserve)
+    uint64_t *d_x = (uint64_t *)b, *d_y = d_x + kN;
+    int32_t *d_s = (int32_t *)(d_y + kN), *d_p = d_s + kN;
+    hipStream_t s = nullptr;
+    if ((rc = h->hs.get(&s)) != GAB_OK) return rc;
+    GAB_HIP(hipMemcpyAsync(d_x, xy.data(), 16 * (size_t)kN, hipMemcpyHostToDevice, s));
+    GAB_HIP(hipStreamSynchronize(s));
+    gab_chain_hdr hd; memset(&hd, 0, sizeof hd);
+    hd.n = kN; hd.avg_qspan = 15.f; hd.max_dist_x = 5000; hd.max_dist_y = 5000; hd.bw = 500; hd.n_segs = 1;
+    const int64_t off = 0;
+    const bool had = h->have_stats;
+    rc = gab_chain_run_device(h, mode, d_x, d_y, &off, &hd, 1, d_s, d_p, s);
+    h->have_stats = had;
+    if (rc) return rc;
+    if (mode == GAB_FASTCHAIN && h->tun.chain_tab != 0) rc = chain_tab_prealloc(&h->tab, max_anchors, max_calls);
+    return rc;
 }
 
 extern "C" int gab_chain_last_stats(gab_chain *h, int64_t *evals, float *kernel_ms) {

@@ -202,6 +202,8 @@ struct ChainTab {
 // form on stream `s`: window starts, geometry tables, fold.  d_bail[k] != 0 afterwards (on the stream) means call k was NOT
 // computed (not eligible, no room in the table, certificate missed) and is the caller's to run through the other kernels.
 int chain_tab_run(ChainTab *t, const gab_tuning &tun, int mode, hipStream_t s, const ChainWork *d_work, const ChainWork *h_work, size_t nsplit, int64_t total_anchors,
-                  const uint64_t *d_x, const uint64_t *d_y, int32_t *d_score, int32_t *d_parent, int32_t *d_gm, unsigned long long *d_evals, uint32_t **d_bail);
+                  const uint64_t *d_x, const uint64_t *d_y, int32_t *d_score, int32_t *d_parent, int32_t *d_gm, unsigned long long *d_evals, uint32_t **d_bail,
+                  int32_t *host_score = nullptr, int32_t *host_parent = nullptr);      // (device-visible addresses of page-locked host arrays: results written through)
 void chain_tab_report(ChainTab *t, size_t nsplit);      // GAB_CHAIN_TRACE: what the last run did with its calls (after a synchronisation)
 int chain_tab_setup();      // function attributes (dynamic LDS), once
+int chain_tab_prealloc(ChainTab *t, int64_t max_anchors, int64_t max_calls);

@@ -429,7 +429,7 @@ __global__ __launch_bounds__(64 * (2 + kTabW))
 void ctab_fold(const ChainWork *__restrict__ work, const TabCall *__restrict__ calls, const TabBlock *__restrict__ blocks, uint32_t *bail,
                const uint4 *__restrict__ T8, const int32_t *__restrict__ st_all, const uint64_t *__restrict__ xs, const uint64_t *__restrict__ ys,
                int32_t *score_out, int32_t *parent_out, int32_t *gmarks_all, unsigned long long *evals_out,
-               TabCounters *ct, unsigned long long *dbg) {
+               TabCounters *ct, unsigned long long *dbg, int32_t *host_score, int32_t *host_parent) {
     constexpr bool FC = MODE == GAB_FASTCHAIN;
     constexpr int NF = kTabFW;
     extern __shared__ __attribute__((aligned(16))) uint8_t tab_lds_raw[];
@@ -573,6 +573,7 @@ void ctab_fold(const ChainWork *__restrict__ work, const TabCall *__restrict__ c
                 const int32_t best = key >> 7;
                 if (mine) {
                     S[i0 + lane] = best;
+                    if (host_score) host_score[w.hoff + i0 + lane] = best;       // gab_chain_run_device_through: written through to the caller's page-locked array
                     const int ri = (i0 + lane) & (kTabRing - 1);
                     L.ring[ri] = best - bias;
                     if (ri < 16) L.ring[kTabRing + ri] = best - bias;
@@ -656,7 +657,7 @@ void ctab_fold(const ChainWork *__restrict__ work, const TabCall *__restrict__ c
                     }
                 }
                 if (pl) for (int q = 0; q < L.patch_n; q++) if (L.patch_blk[q] == r && L.patch_lane[q] == lane) parent = L.patch_parent[q];
-                if (mine) P[i0 + lane] = parent;
+                if (mine) { P[i0 + lane] = parent; if (host_parent) host_parent[w.hoff + i0 + lane] = parent; }
                 if (!FC && !GAB_KO_CERT_NEAR) {
                     unsigned long long miss = __ballot(mine && !none && !pl && risk > kMaxSkip);
                     if (miss) {
@@ -836,6 +837,17 @@ void ctab_fold(const ChainWork *__restrict__ work, const TabCall *__restrict__ c
 }  // namespace
 
 // =============================================================================== host side
+// gab_chain_reserve_mode: the table for calls of up to max_anchors anchors in all, before a caller's timed region (the budget was
+// fixed by the handle's first table-form run; 27 KB per block of 64 anchors is what ~430 rows per block need)
+int chain_tab_prealloc(ChainTab *t, int64_t max_anchors, int64_t max_calls) {
+    if (t->table_budget == 0) return GAB_OK;
+    const size_t want = std::min<size_t>(t->table_budget, ((size_t)max_anchors / 64 + (size_t)max_calls) * 27 * 1024);
+    int rc = GAB_OK;
+    if (t->table.cap < want && (rc = t->table.reserve(want)) != GAB_OK) return rc;
+    if ((rc = t->st.reserve(4 * (size_t)max_anchors + 256)) != GAB_OK) return rc;
+    if ((rc = t->blocks.reserve(sizeof(TabBlock) * ((size_t)max_anchors / 64 + (size_t)max_calls) + 256)) != GAB_OK) return rc;
+    return t->calls.reserve((sizeof(TabCall) + 8) * (size_t)max_calls + 2048);
+}
 int chain_tab_setup() {
     static std::once_flag once;
     static int rc = GAB_OK;
@@ -897,7 +909,8 @@ void chain_tab_report(ChainTab *t, size_t nsplit) {
 }
 
 int chain_tab_run(ChainTab *t, const gab_tuning &tun, int mode, hipStream_t s, const ChainWork *d_work, const ChainWork *h_work, size_t nsplit, int64_t total_anchors,
-                  const uint64_t *d_x, const uint64_t *d_y, int32_t *d_score, int32_t *d_parent, int32_t *d_gm, unsigned long long *d_evals, uint32_t **d_bail) {
+                  const uint64_t *d_x, const uint64_t *d_y, int32_t *d_score, int32_t *d_parent, int32_t *d_gm, unsigned long long *d_evals, uint32_t **d_bail,
+                  int32_t *host_score, int32_t *host_parent) {
     int rc = chain_tab_setup();
     if (rc) return rc;
     // host side of the call table: blocks, gap-table offsets
@@ -979,10 +992,10 @@ int chain_tab_run(ChainTab *t, const gab_tuning &tun, int mode, hipStream_t s, c
                            (const int32_t *)d_gtab, (const int32_t *)d_st, d_x, d_y, d_T8);
     if (mode == GAB_CHAIN)
         hipLaunchKernelGGL(ctab_fold<GAB_CHAIN>, dim3(nc), dim3(64 * (2 + kTabW)), sizeof(TabLds), sf, d_work, (const TabCall *)d_calls, (const TabBlock *)d_blocks, bail,
-                           (const uint4 *)d_T8, (const int32_t *)d_st, d_x, d_y, d_score, d_parent, d_gm, d_evals, d_ct, d_dbg);
+                           (const uint4 *)d_T8, (const int32_t *)d_st, d_x, d_y, d_score, d_parent, d_gm, d_evals, d_ct, d_dbg, host_score, host_parent);
     else
         hipLaunchKernelGGL(ctab_fold<GAB_FASTCHAIN>, dim3(nc), dim3(64 * (2 + kTabW)), sizeof(TabLds), sf, d_work, (const TabCall *)d_calls, (const TabBlock *)d_blocks, bail,
-                           (const uint4 *)d_T8, (const int32_t *)d_st, d_x, d_y, d_score, d_parent, d_gm, d_evals, d_ct, d_dbg);
+                           (const uint4 *)d_T8, (const int32_t *)d_st, d_x, d_y, d_score, d_parent, d_gm, d_evals, d_ct, d_dbg, host_score, host_parent);
     GAB_HIP(hipGetLastError());
     return GAB_OK;
 }

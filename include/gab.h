@@ -141,6 +141,9 @@ int gab_chain_create(int device, gab_chain **out);
 void gab_chain_destroy(gab_chain *h);
 /* optional: size the handle's device buffers now for calls of up to max_anchors anchors in max_calls calls (see gab_bsw_reserve) */
 int gab_chain_reserve(gab_chain *h, int64_t max_anchors, int64_t max_calls);
+/* gab_chain_reserve + what gab_chain_run_device[_through] of `mode` needs before a timed region: the first launches of its kernels
+ * and, for GAB_FASTCHAIN (whose longer calls run in the table form, chain_tab.hip), the table for max_anchors anchors */
+int gab_chain_reserve_mode(gab_chain *h, int mode, int64_t max_anchors, int64_t max_calls);
 /* everything on the host */
 int gab_chain_run(gab_chain *h, int mode, const uint64_t *x, const uint64_t *y, const int64_t *call_off,
                   const gab_chain_hdr *hdr, int64_t ncalls, int32_t *score_out, int32_t *parent_out);
