@@ -251,12 +251,15 @@ __device__ __forceinline__ uint32_t ctab_sad(uint32_t a, uint32_t b) { uint32_t 
 // (no window test per pair); NARROW (fast-chain): some anchor of the block takes the scalar tail's double-precision gap cost.
 // Both are wave-uniform and decided ONCE per group by the caller: as run-time flags inside the unrolled rows the compiler turned
 // them into a branch per row -- 32 basic blocks that nothing could be scheduled across (fast-chain: see the rows below).
+#ifndef GAB_GEO_CHAIN_BATCHED      // experiment: chain's geometry rows eight at a time like fast-chain's
+#define GAB_GEO_CHAIN_BATCHED 0
+#endif
 template <bool FC, bool MSEG, bool INSIDE, bool NARROW>
 __device__ __forceinline__ uint4 ctab_geo_rows(uint32_t px, uint32_t py, uint32_t xa, int32_t qa, int32_t qs, const int32_t *gap, int32_t bw,
                                                uint32_t dq_lim, int32_t mdy, int j0, int st_a, uint32_t wspan, bool narrow, double avg_d, int bias,
                                                int &bad, bool inside_rt) {
     uint32_t bytes[16];
-    if (NARROW || !FC) {                // row by row: the rare form of fast-chain (the first blocks of a call), and chain
+    if (NARROW || (!FC && !GAB_GEO_CHAIN_BATCHED)) {                // row by row: the rare form of fast-chain (the first blocks of a call), and chain
 #pragma unroll
         for (int k = 0; k < 16; k++) {
             const uint32_t xj = (uint32_t)__builtin_amdgcn_readlane((int)px, k), yj = (uint32_t)__builtin_amdgcn_readlane((int)py, k);
@@ -280,7 +283,7 @@ __device__ __forceinline__ uint4 ctab_geo_rows(uint32_t px, uint32_t py, uint32_
         // fast-chain, eight rows at a time: first everything that does not need the gap cost -- and the eight table reads, issued
         // together and UNCONDITIONALLY (left alone the compiler sinks each read behind its pair's filters: a divergent branch and a wait
         // for LDS per row) -- then the eight bytes.  Measured (rank 0's share of chain-large on 8 GPUs, two runs each): fast-chain
-        // 4.59 / 4.62 -> 4.42 / 4.31 ms, the 1 000-call input 4.32 / 4.56 -> 4.11 / 4.08 ms; chain 4.77 / 4.94 -> 5.19 / 4.92 ms -- its
+        // 4.57 -> 4.26 ms, the 1 000-call input 4.28 -> 4.03 ms (three runs each); chain (-DGAB_GEO_CHAIN_BATCHED=1) 4.68-4.72 -> 4.72-4.76 ms -- its
         // filters reject whole rows more often (77 % of the lanes active against 91 %) and the branch skips them: chain keeps the rows
         // one by one.  (gv <= q_span + bias <= 255: ctab_prep admits a call only then; dd > bw reads the
         // huge entry bw + 1 and clamps to 0.)
@@ -358,7 +361,8 @@ __global__ __launch_bounds__(256) void ctab_geo(const ChainWork *__restrict__ wo
         const bool inside = nb == 64 && j0 >= st_hi && j0 >= 0 && j0 + 15 < i0;
         uint4 o;
 #define GAB_GEO_ROWS(INSIDE, NARROW, RT) ctab_geo_rows<FC, MSEG, INSIDE, NARROW>(px, py, xa, qa, qs, gap, bw, dq_lim, mdy, j0, st_a, wspan, narrow, avg_d, tc.bias, bad, RT)
-        if (!FC) o = GAB_GEO_ROWS(false, false, inside);            // chain: one copy of the rows (two measured slower: the instruction cache)
+        if (!FC && !GAB_GEO_CHAIN_BATCHED) o = GAB_GEO_ROWS(false, false, inside);            // chain: one copy of the rows, taken one by one (see ctab_geo_rows)
+        else if (!FC) o = inside ? GAB_GEO_ROWS(true, false, false) : GAB_GEO_ROWS(false, false, false);
         else if (any_narrow) o = inside ? GAB_GEO_ROWS(true, true, false) : GAB_GEO_ROWS(false, true, false);
         else o = inside ? GAB_GEO_ROWS(true, false, false) : GAB_GEO_ROWS(false, false, false);
 #undef GAB_GEO_ROWS
