@@ -196,15 +196,7 @@ struct ChainTab {
     gab_devbuf table;      // the geometry tables: 1 KB per 16 predecessors x 64 anchors
     gab_devbuf dbg;        // GAB_CHAIN_TRACE only
     size_t table_budget = 0;   // bytes the table may take (0: decided at the first call)
-    static constexpr int kMaxChunks = 8;
-    hipStream_t fold_stream = nullptr;              // big batches: the fold of chunk k runs here beside the geometry of chunk k + 1
-    hipEvent_t geo_done[kMaxChunks] = {}, fold_done = nullptr;
-    void release() {
-        calls.release(); blocks.release(); gtab.release(); st.release(); table.release(); dbg.release();
-        if (fold_stream) { (void)hipStreamDestroy(fold_stream); fold_stream = nullptr; }
-        for (int k = 0; k < kMaxChunks; k++) if (geo_done[k]) { (void)hipEventDestroy(geo_done[k]); geo_done[k] = nullptr; }
-        if (fold_done) { (void)hipEventDestroy(fold_done); fold_done = nullptr; }
-    }
+    void release() { calls.release(); blocks.release(); gtab.release(); st.release(); table.release(); dbg.release(); }
 };
 // Runs the first `nsplit` calls of the (device) work list `d_work` -- `h_work` is the same list on the host -- through the table
 // form on stream `s`: window starts, geometry tables, fold.  d_bail[k] != 0 afterwards (on the stream) means call k was NOT

@@ -319,10 +319,10 @@ __device__ __forceinline__ uint4 ctab_geo_rows(uint32_t px, uint32_t py, uint32_
 template <int MODE, bool MSEG>
 __global__ __launch_bounds__(256) void ctab_geo(const ChainWork *__restrict__ work, const TabCall *__restrict__ calls, const TabBlock *__restrict__ blocks,
                                                 uint32_t *bail, const int32_t *__restrict__ gtab, const int32_t *__restrict__ st_all,
-                                                const uint64_t *__restrict__ xs, const uint64_t *__restrict__ ys, uint4 *T8, unsigned first_block) {
+                                                const uint64_t *__restrict__ xs, const uint64_t *__restrict__ ys, uint4 *T8) {
     constexpr bool FC = MODE == GAB_FASTCHAIN;
     __shared__ int32_t gap[kGapTab];
-    const TabBlock tb = blocks[blockIdx.x + first_block];
+    const TabBlock tb = blocks[blockIdx.x];
     const int c = tb.call;
     if (bail[c] || tb.ng == 0) return;
     const ChainWork w = work[c];
@@ -388,7 +388,6 @@ constexpr int kTabRing = 8192;            // scores (minus bias) of the newest a
 #define GAB_TAB_MAX_RESCANS 64
 #endif
 constexpr int kTabMaxRescans = GAB_TAB_MAX_RESCANS;
-constexpr int64_t kTabChunkBlocks = 100000;     // a chunk of the pipelined form (chain_tab_run) holds at least this many blocks of 64 anchors
 constexpr int kTabMaxPatch = 8;            // anchors of a call whose result max_skip really changed (see the resolver)
 #ifndef GAB_TAB_NEAR_LDS
 #define GAB_TAB_NEAR_LDS 1
@@ -434,12 +433,12 @@ __global__ __launch_bounds__(64 * (2 + kTabW))
 void ctab_fold(const ChainWork *__restrict__ work, const TabCall *__restrict__ calls, const TabBlock *__restrict__ blocks, uint32_t *bail,
                const uint4 *__restrict__ T8, const int32_t *__restrict__ st_all, const uint64_t *__restrict__ xs, const uint64_t *__restrict__ ys,
                int32_t *score_out, int32_t *parent_out, int32_t *gmarks_all, unsigned long long *evals_out,
-               TabCounters *ct, unsigned long long *dbg, int32_t *host_score, int32_t *host_parent, int first_call) {
+               TabCounters *ct, unsigned long long *dbg, int32_t *host_score, int32_t *host_parent) {
     constexpr bool FC = MODE == GAB_FASTCHAIN;
     constexpr int NF = kTabFW;
     extern __shared__ __attribute__((aligned(16))) uint8_t tab_lds_raw[];
     TabLds &L = *reinterpret_cast<TabLds *>(tab_lds_raw);
-    const int c = blockIdx.x + first_call;
+    const int c = blockIdx.x;
     const ChainWork w = work[c];
     const TabCall tc = calls[c];
     if (bail[c]) return;
@@ -978,70 +977,29 @@ int chain_tab_run(ChainTab *t, const gab_tuning &tun, int mode, hipStream_t s, c
     else hipLaunchKernelGGL(ctab_st<GAB_FASTCHAIN>, dim3(g4), dim3(256), 0, s, d_work, d_calls, d_blocks, nblocks, d_x, d_st);
     hipLaunchKernelGGL(ctab_place, dim3(1), dim3(1024), 0, s, d_calls, bail, (int)nsplit, budget_groups, d_ct);
     hipLaunchKernelGGL(ctab_block_offsets, dim3(nc), dim3(256), 0, s, (const TabCall *)d_calls, (const uint32_t *)bail, d_blocks);
-    // Geometry, then fold.  In the LATENCY regime -- a batch that waits for its longest calls: a share of an 8-GPU run, the
-    // 1 000-call input -- on one stream, one launch each.  Measured and dropped there (r04): the fold BESIDE the geometry (a second
-    // stream, the geometry's stores written through, a call's workgroup waiting in the kernel until its blocks were counted
-    // done): the folds of the longest calls did start after microseconds, and the two kernels together took as long as one after
-    // the other (chain shard 0/8: 5.98 against 6.01 ms) -- a wave of the geometry sharing a SIMD with a fold's main wave stretches
-    // every step of its chain of dependent instructions (s_setprio changes nothing: the pipeline is not pre-empted).
-    // In the THROUGHPUT regime -- a big batch (all of fast-chain-large on one GPU: 1.2 M blocks) -- no call is waited for, the fold
-    // leaves two thirds of the chip's issue slots empty (24-37 % VALU busy: one workgroup per CU, most of its waves at the
-    // barrier) and the geometry is at the issue roofline: the calls (longest first) are cut into up to eight chunks of ~equal
-    // block counts and the fold of chunk k runs on a second stream BESIDE the geometry of chunk k + 1 (events between the two).
+    // Geometry, then fold, on one stream.  Measured and dropped (r04): the fold BESIDE the geometry -- a second stream, the
+    // geometry's stores written through, a call's workgroup waiting in the kernel until its blocks were counted done.  The folds
+    // of the longest calls did start after microseconds, and the two kernels together took as long as one after the other (chain
+    // shard 0/8: 5.98 against 6.01 ms): a wave of the geometry sharing a SIMD with a fold's main wave stretches every step of its
+    // chain of dependent instructions (s_setprio changes nothing: the pipeline is not pre-empted), and the written-through
+    // stores cost the geometry a third of its speed.  Four chunks on four streams (events): the streams share hardware queues.
+    hipStream_t sf = s;
     const unsigned nbk = (unsigned)nblocks;
-    int nchunks = (int)std::min<int64_t>(ChainTab::kMaxChunks, nblocks / kTabChunkBlocks);
-    if (tun.chain_tab_chunks >= 0) nchunks = std::min(tun.chain_tab_chunks, (int)ChainTab::kMaxChunks);      // GAB_CHAIN_TAB_CHUNKS
-    if (nchunks < 2 || nsplit < 2) nchunks = 1;
-    if (nchunks > 1 && !t->fold_stream) {
-        bool ok = hipStreamCreateWithFlags(&t->fold_stream, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&t->fold_done, hipEventDisableTiming) == hipSuccess;
-        for (int k = 0; ok && k < ChainTab::kMaxChunks; k++) ok = hipEventCreateWithFlags(&t->geo_done[k], hipEventDisableTiming) == hipSuccess;
-        if (!ok) { (void)hipGetLastError(); nchunks = 1; }
-    }
-    // chunk boundaries: calls [ccut[k], ccut[k + 1]) hold blocks [bcut[k], bcut[k + 1])
-    size_t ccut[ChainTab::kMaxChunks + 1]; int64_t bcut[ChainTab::kMaxChunks + 1];
-    ccut[0] = 0; bcut[0] = 0;
-    {
-        size_t c = 0;
-        for (int k = 1; k < nchunks; k++) {
-            const int64_t want = nblocks * k / nchunks;
-            while (c < nsplit && hc[c].blk0 < want) c++;
-            ccut[k] = c; bcut[k] = c < nsplit ? hc[c].blk0 : nblocks;
-        }
-        ccut[nchunks] = nsplit; bcut[nchunks] = nblocks;
-    }
-    for (int k = 0; k < nchunks; k++) {
-        const unsigned gb = (unsigned)(bcut[k + 1] - bcut[k]), fb = (unsigned)bcut[k], gc = (unsigned)(ccut[k + 1] - ccut[k]);
-        if (gb) {
-            if (mode == GAB_FASTCHAIN)
-                hipLaunchKernelGGL((ctab_geo<GAB_FASTCHAIN, false>), dim3(gb), dim3(256), 0, s, d_work, (const TabCall *)d_calls, (const TabBlock *)d_blocks, bail,
-                                   (const int32_t *)d_gtab, (const int32_t *)d_st, d_x, d_y, d_T8, fb);
-            else if (any_mseg)
-                hipLaunchKernelGGL((ctab_geo<GAB_CHAIN, true>), dim3(gb), dim3(256), 0, s, d_work, (const TabCall *)d_calls, (const TabBlock *)d_blocks, bail,
-                                   (const int32_t *)d_gtab, (const int32_t *)d_st, d_x, d_y, d_T8, fb);
-            else
-                hipLaunchKernelGGL((ctab_geo<GAB_CHAIN, false>), dim3(gb), dim3(256), 0, s, d_work, (const TabCall *)d_calls, (const TabBlock *)d_blocks, bail,
-                                   (const int32_t *)d_gtab, (const int32_t *)d_st, d_x, d_y, d_T8, fb);
-        }
-        hipStream_t sf = s;
-        if (nchunks > 1) {
-            GAB_HIP(hipEventRecord(t->geo_done[k], s));
-            GAB_HIP(hipStreamWaitEvent(t->fold_stream, t->geo_done[k], 0));
-            sf = t->fold_stream;
-        }
-        if (gc) {
-            if (mode == GAB_CHAIN)
-                hipLaunchKernelGGL(ctab_fold<GAB_CHAIN>, dim3(gc), dim3(64 * (2 + kTabW)), sizeof(TabLds), sf, d_work, (const TabCall *)d_calls, (const TabBlock *)d_blocks, bail,
-                                   (const uint4 *)d_T8, (const int32_t *)d_st, d_x, d_y, d_score, d_parent, d_gm, d_evals, d_ct, d_dbg, host_score, host_parent, (int)ccut[k]);
-            else
-                hipLaunchKernelGGL(ctab_fold<GAB_FASTCHAIN>, dim3(gc), dim3(64 * (2 + kTabW)), sizeof(TabLds), sf, d_work, (const TabCall *)d_calls, (const TabBlock *)d_blocks, bail,
-                                   (const uint4 *)d_T8, (const int32_t *)d_st, d_x, d_y, d_score, d_parent, d_gm, d_evals, d_ct, d_dbg, host_score, host_parent, (int)ccut[k]);
-        }
-    }
-    if (nchunks > 1) {           // the caller's stream continues behind the last fold
-        GAB_HIP(hipEventRecord(t->fold_done, t->fold_stream));
-        GAB_HIP(hipStreamWaitEvent(s, t->fold_done, 0));
-    }
-    (void)nbk;
+    if (mode == GAB_FASTCHAIN)
+        hipLaunchKernelGGL((ctab_geo<GAB_FASTCHAIN, false>), dim3(nbk), dim3(256), 0, s, d_work, (const TabCall *)d_calls, (const TabBlock *)d_blocks, bail,
+                           (const int32_t *)d_gtab, (const int32_t *)d_st, d_x, d_y, d_T8);
+    else if (any_mseg)
+        hipLaunchKernelGGL((ctab_geo<GAB_CHAIN, true>), dim3(nbk), dim3(256), 0, s, d_work, (const TabCall *)d_calls, (const TabBlock *)d_blocks, bail,
+                           (const int32_t *)d_gtab, (const int32_t *)d_st, d_x, d_y, d_T8);
+    else
+        hipLaunchKernelGGL((ctab_geo<GAB_CHAIN, false>), dim3(nbk), dim3(256), 0, s, d_work, (const TabCall *)d_calls, (const TabBlock *)d_blocks, bail,
+                           (const int32_t *)d_gtab, (const int32_t *)d_st, d_x, d_y, d_T8);
+    if (mode == GAB_CHAIN)
+        hipLaunchKernelGGL(ctab_fold<GAB_CHAIN>, dim3(nc), dim3(64 * (2 + kTabW)), sizeof(TabLds), sf, d_work, (const TabCall *)d_calls, (const TabBlock *)d_blocks, bail,
+                           (const uint4 *)d_T8, (const int32_t *)d_st, d_x, d_y, d_score, d_parent, d_gm, d_evals, d_ct, d_dbg, host_score, host_parent);
+    else
+        hipLaunchKernelGGL(ctab_fold<GAB_FASTCHAIN>, dim3(nc), dim3(64 * (2 + kTabW)), sizeof(TabLds), sf, d_work, (const TabCall *)d_calls, (const TabBlock *)d_blocks, bail,
+                           (const uint4 *)d_T8, (const int32_t *)d_st, d_x, d_y, d_score, d_parent, d_gm, d_evals, d_ct, d_dbg, host_score, host_parent);
     GAB_HIP(hipGetLastError());
     return GAB_OK;
 }

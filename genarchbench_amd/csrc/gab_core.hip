@@ -84,7 +84,6 @@ void gab_tuning_load(gab_tuning *t) {
     t->chain_trace = on("GAB_CHAIN_TRACE"); t->chain_feed_giveup = on("GAB_CHAIN_FEED_GIVEUP"); t->chain_fed_serial = on("GAB_CHAIN_FED_SERIAL");
     t->chain_no_overlap = on("GAB_CHAIN_NO_OVERLAP"); t->chain_no_feed = on("GAB_CHAIN_NO_FEED");
     if (const char *e = getenv("GAB_CHAIN_TAB")) t->chain_tab = atoi(e) != 0;
-    t->chain_tab_chunks = (int)num("GAB_CHAIN_TAB_CHUNKS", -1);
     t->chain_tab_min = num("GAB_CHAIN_TAB_MIN", -1); t->chain_fast_min = num("GAB_CHAIN_FAST_MIN", -1); t->chain_fast_calls = num("GAB_CHAIN_FAST_CALLS", -1);
     t->chain_feed_min = num("GAB_CHAIN_FEED_MIN", -1); t->chain_tab_mb = num("GAB_CHAIN_TAB_MB", -1);
     if (const char *e = getenv("GAB_CHAIN_GATHER_MASK")) { strncpy(t->chain_gather_mask, e, sizeof t->chain_gather_mask - 1); t->chain_gather_mask[sizeof t->chain_gather_mask - 1] = 0; }

@@ -103,7 +103,6 @@ struct gab_tuning {
     bool chain_helpers_set = false, chain_walk = false, chain_trace = false, chain_feed_giveup = false, chain_fed_serial = false;
     bool chain_no_overlap = false, chain_no_feed = false;
     int chain_tab = -1;                              // GAB_CHAIN_TAB: -1 unset, 0 off, 1 on
-    int chain_tab_chunks = -1;                       // GAB_CHAIN_TAB_CHUNKS: chunks of the pipelined table form (-1: by batch size; 1: none)
     long long chain_tab_min = -1, chain_fast_min = -1, chain_fast_calls = -1, chain_feed_min = -1, chain_tab_mb = -1;   // -1 = unset
     char chain_gather_mask[32] = "";                 // "" unset, "none", "N:M"
     int chain_gather_blocks = 0;
