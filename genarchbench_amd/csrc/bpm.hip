@@ -587,25 +587,59 @@ __global__ __launch_bounds__(kBlock) void bpm_win(BpmIO io, const uint32_t *__re
         for (int b = 0; b < W; b++) { P[b] = ~0ull; M[b] = 0; }
         H[0] = make_ulonglong2(~0ull, 0ull);
         bool dummy = true;
-        for (int h = 0; h < m; h++) {
-            const int c = bpm_code((uint8_t)t[h], dummy);
+        // r04: the handful of pairs that come here are the LAST thing a call waits for (0.3 ms behind the last band kernel of
+        // bpm-large, a quarter of the step of a 1.25 M-pair share), and what they waited for was memory latency: a byte load per
+        // column in front of every step, and two to four dependent loads per backtrace step.  The text now arrives sixteen bases
+        // per load, and the backtrace -- which visits the columns m, m - 1, ... in this order whatever path it takes, and the
+        // rows n - 1, n - 2, ... likewise -- keeps the next eight column records and the next dword of each string in
+        // registers, requested before they are needed.  bpm_win on bpm-large (~100 pairs): 0.306 -> 0.223 ms.
+        auto column = [&](int h, int c) {
             uint32_t PH = 1, MH = 0;
 #pragma unroll
             for (int b = 0; b < W; b++)
                 bpm_step(peq[(b * 4 + c) * kBlock], b == W - 1 ? top_mask : 1ull << 63, P[b], M[b], PH, MH);
             const int r0 = bpm_win_start<W>(h + 1, cshift);
             H[h + 1] = make_ulonglong2(bpm_win_take<W>(P, r0), bpm_win_take<W>(M, r0));
+        };
+        int hh = 0;
+        for (; hh + 16 <= m; hh += 16) {
+            const uint4 q = ld_u128(t + hh);
+            const uint32_t ws[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+            for (int k = 0; k < 16; k++) column(hh + k, bpm_code((ws[k >> 2] >> ((k & 3) * 8)) & 0xffu, dummy));
+        }
+        for (; hh < m; hh += 4) {
+            uint32_t w4 = ld_u32(t + hh);
+            for (int k = 0; k < 4 && hh + k < m; k++, w4 >>= 8) column(hh + k, bpm_code(w4 & 0xffu, dummy));
         }
         steps += (unsigned long long)m * W;
         // backtrace (edit_bpm.c:289-313) on the windows
         int ops = 0, v = n - 1, h = m - 1;
         bool miss = false;
+        constexpr int kAhead = 8;                     // R[k] = record of column h + 1 - k
+        ulonglong2 R[kAhead];
+#pragma unroll
+        for (int k = 0; k < kAhead; k++) R[k] = H[h + 1 - k > 0 ? h + 1 - k : 0];
+        // (the strings' dwords: bytes up to three behind a sequence are readable, and a dword in front of its first byte is
+        // never asked for: the index is clamped at 0)
+        uint32_t tw = h >= 0 ? ld_u32(t + (h & ~3)) : 0, tw_n = h >= 4 ? ld_u32(t + (h & ~3) - 4) : 0;
+        uint32_t pw = v >= 0 ? ld_u32(p + (v & ~3)) : 0, pw_n = v >= 4 ? ld_u32(p + (v & ~3) - 4) : 0;
+        auto step_h = [&]() {                         // h has just been decremented
+#pragma unroll
+            for (int k = 0; k + 1 < kAhead; k++) R[k] = R[k + 1];
+            const int col = h + 1 - (kAhead - 1);
+            R[kAhead - 1] = H[col > 0 ? col : 0];
+            if ((h & 3) == 3) { tw = tw_n; tw_n = h >= 4 ? ld_u32(t + (h & ~3) - 4) : 0; }
+        };
+        auto step_v = [&]() {                         // v has just been decremented
+            if ((v & 3) == 3) { pw = pw_n; pw_n = v >= 4 ? ld_u32(p + (v & ~3) - 4) : 0; }
+        };
         while (v >= 0 && h >= 0) {
             const int r1 = bpm_win_start<W>(h + 1, cshift), rh = bpm_win_start<W>(h, cshift);
             if (v < r1 || v >= r1 + 64 || v < rh || v >= rh + 64) { miss = true; break; }
-            if ((H[h + 1].x >> (v - r1)) & 1) { ops++; v--; }
-            else if ((H[h].y >> (v - rh)) & 1) { ops++; h--; }
-            else { ops += t[h] != p[v]; h--; v--; }
+            if ((R[0].x >> (v - r1)) & 1) { ops++; v--; step_v(); }
+            else if ((R[1].y >> (v - rh)) & 1) { ops++; h--; step_h(); }
+            else { ops += ((tw >> ((h & 3) * 8)) & 0xffu) != ((pw >> ((v & 3) * 8)) & 0xffu); h--; v--; step_h(); step_v(); }
         }
         if (miss) miss_id = (int64_t)id;
         else score_out[id] = -(ops + (h + 1) + (v + 1));
