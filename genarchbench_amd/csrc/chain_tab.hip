@@ -37,6 +37,7 @@
 #include "gab_internal.h"
 #include "chain_dev.h"
 #include <algorithm>
+#include <limits.h>
 #include <vector>
 #include <stdlib.h>
 #include <string.h>
@@ -389,6 +390,9 @@ constexpr int kTabRing = 8192;            // scores (minus bias) of the newest a
 #endif
 constexpr int kTabMaxRescans = GAB_TAB_MAX_RESCANS;
 constexpr int kTabMaxPatch = 8;            // anchors of a call whose result max_skip really changed (see the resolver)
+#ifndef GAB_TAB_MERGE_ATOMIC
+#define GAB_TAB_MERGE_ATOMIC 1
+#endif
 #ifndef GAB_TAB_NEAR_LDS
 #define GAB_TAB_NEAR_LDS 1
 #endif
@@ -415,6 +419,7 @@ struct TabLds {
     int4 G4[2][2][16][64];                // [slot][previous block | block itself][row / 4][anchor]: keys of 4 rows
     int32_t ring[kTabRing + 16];          // (+ the first 16 entries again: sixteen consecutive scores never wrap)
     int32_t part_best[2][kTabFW][64], part_g[2][kTabFW][64];
+    long long part64[2][64];              // GAB_TAB_MERGE_ATOMIC: the far workers' maxima merged by LDS atomics: (best << 32) | group
     int32_t res_key[3][64], res_fg[3][64];
     uint16_t okh[4][8][64];               // chain: one bit per unfiltered near / in-block pair, 16 rows per unit
     TabDesc desc[256];                    // the descriptors of the blocks around the one in work (see ctab_fold)
@@ -516,6 +521,7 @@ void ctab_fold(const ChainWork *__restrict__ work, const TabCall *__restrict__ c
     Desc r_desc{0, 0, 0};
     uint4 r_gw = make_uint4(0, 0, 0, 0);
     int32_t r_st = 0;
+    if (threadIdx.x < 128) (&L.part64[0][0])[threadIdx.x] = LLONG_MIN;
     __syncthreads();
 
     unsigned long long busy = 0, t_all = dbg ? clock64() : 0;      // (GAB_CHAIN_TRACE: cycles of every wave outside the barrier, call 0 only)
@@ -532,11 +538,19 @@ void ctab_fold(const ChainWork *__restrict__ work, const TabCall *__restrict__ c
                 qs_next = i0 + 64 + lane < n ? (int32_t)(Y[i0 + 64 + lane] >> 32 & 0xff) : 0;
                 // the workers' far maxima: groups interleave, so the larger group (= the newer predecessors) wins a tie
                 int32_t fbest = kTabNegH, fg = -1;
+#if GAB_TAB_MERGE_ATOMIC
+                {   // (merged by the workers themselves: one 64-bit LDS atomic max per worker and lane; the main wave reads ONE value)
+                    const long long pk = L.part64[par ^ 1][lane];
+                    L.part64[par ^ 1][lane] = LLONG_MIN;
+                    if (pk != LLONG_MIN) { fbest = (int32_t)(pk >> 32); fg = (int32_t)(uint32_t)pk; }
+                }
+#else
 #pragma unroll
                 for (int hh = 0; hh < (GAB_KO_MAIN_MERGE ? 1 : NF); hh++) {
                     const int32_t b2 = L.part_best[par ^ 1][hh][lane], g2 = L.part_g[par ^ 1][hh][lane];
                     if (b2 > fbest || (b2 == fbest && g2 > fg)) { fbest = b2; fg = g2; }
                 }
+#endif
                 const int32_t initkey = (qsa << 7) | 127;
                 int32_t key = fg >= 0 ? max(initkey, fbest << 7) : initkey;      // far: code 0 (loses a tie against anything newer)
                 const int4 *gn = &L.G4[par ^ 1][0][0][lane];
@@ -803,7 +817,11 @@ void ctab_fold(const ChainWork *__restrict__ work, const TabCall *__restrict__ c
             for (int q = 0; q < kTabF; q++) { const int fgi = fw + NF * q; if (fw >= 0 && fgi < nfar) far_group(cf[q], fgi); }
             if (fw >= 0) for (int fgi = fw + NF * kTabF; fgi < nfar; fgi += NF) far_group(T8[(d.grp + fgi) * 64 + lane], fgi);      // deep windows
 #endif
+#if GAB_TAB_MERGE_ATOMIC
+            if (fw >= 0 && bg >= 0) atomicMax(&L.part64[par][lane], (long long)(((unsigned long long)(uint32_t)best << 32) | (uint32_t)bg));
+#else
             if (fw >= 0) { L.part_best[par][fw][lane] = best; L.part_g[par][fw][lane] = bg; }
+#endif
         }
         if (dbg) busy += clock64() - t_in;
         __syncthreads();
@@ -825,6 +843,10 @@ void ctab_fold(const ChainWork *__restrict__ work, const TabCall *__restrict__ c
                 d_cur = desc_of(R); d_nxt = desc_of(R + 1);
                 prefetch(d_cur, R);
             }
+#if GAB_TAB_MERGE_ATOMIC
+            if (threadIdx.x < 128) (&L.part64[0][0])[threadIdx.x] = LLONG_MIN;      // what the abandoned phases left in the merge slots
+            __syncthreads();
+#endif
             t = R - 2;                                       // (the loop makes it R - 1: the workers take block R, the main wave follows)
         }
     }
