@@ -390,6 +390,9 @@ constexpr int kTabRing = 8192;            // scores (minus bias) of the newest a
 #endif
 constexpr int kTabMaxRescans = GAB_TAB_MAX_RESCANS;
 constexpr int kTabMaxPatch = 8;            // anchors of a call whose result max_skip really changed (see the resolver)
+#ifndef GAB_TAB_NEAR_HELP
+#define GAB_TAB_NEAR_HELP 1
+#endif
 #ifndef GAB_TAB_MERGE_ATOMIC
 #define GAB_TAB_MERGE_ATOMIC 1
 #endif
@@ -423,7 +426,8 @@ struct TabLds {
     int32_t res_key[3][64], res_fg[3][64];
     uint16_t okh[4][8][64];               // chain: one bit per unfiltered near / in-block pair, 16 rows per unit
     TabDesc desc[256];                    // the descriptors of the blocks around the one in work (see ctab_fold)
-    int32_t pk[64];                       // main wave only: the previous block's scores << 7 (read back as broadcasts, four per load)
+    int32_t near_key[64], near_cnt, near_pad[3];      // GAB_TAB_NEAR_HELP: the previous block's rows folded by the four unit workers (atomic max), and how many have
+    int32_t pk[64];                       // the main wave's (and its helpers'): the previous block's scores << 7 (read back as broadcasts, four per load)
     int32_t stop[2];                      // 1: the call goes back to chain.hip; 2: start again from block restart_blk (a new patch)
     int32_t restart_blk, patch_n;
     int32_t patch_blk[kTabMaxPatch], patch_lane[kTabMaxPatch], patch_score[kTabMaxPatch], patch_parent[kTabMaxPatch];
@@ -467,6 +471,7 @@ void ctab_fold(const ChainWork *__restrict__ work, const TabCall *__restrict__ c
 
     // what a wave keeps across the phases
     int32_t pbest = 0;                                       // main: the previous block's scores
+    int32_t near_target = 0;                                 // main: helpers' reports it has waited for so far (GAB_TAB_NEAR_HELP)
     int32_t qs_next = (wave == 0 && lane < n) ? (int32_t)(Y[lane] >> 32 & 0xff) : 0;       // ... the next block's q_span, a phase early
     unsigned long long evals = 0, evals_exact = 0;           // resolver (evals_exact: per-lane counts of the exact re-scans)
     int n_rescans = 0;
@@ -522,12 +527,34 @@ void ctab_fold(const ChainWork *__restrict__ work, const TabCall *__restrict__ c
     uint4 r_gw = make_uint4(0, 0, 0, 0);
     int32_t r_st = 0;
     if (threadIdx.x < 128) (&L.part64[0][0])[threadIdx.x] = LLONG_MIN;
+    if (threadIdx.x < 64) L.near_key[threadIdx.x] = kTabNone;
+    if (threadIdx.x == 0) L.near_cnt = 0;
     __syncthreads();
 
     unsigned long long busy = 0, t_all = dbg ? clock64() : 0;      // (GAB_CHAIN_TRACE: cycles of every wave outside the barrier, call 0 only)
     for (int t = -1; t <= nblocks + 1; t++) {
         const int par = (t + 1) & 1;                         // slot of block t + 1 in the two-deep arrays; block t lives in par ^ 1
         const unsigned long long t_in = dbg ? clock64() : 0;
+#if GAB_TAB_NEAR_HELP
+        // The previous block's 64 rows (keys of the rows + the scores the main wave left in `pk` at the end of the last phase) were a
+        // sixth of the main wave's phase, and the main wave is the phase's critical path: the four unit workers take sixteen rows
+        // each FIRST thing in the phase, merge by an LDS atomic max and count themselves done; the main wave waits for the count (a
+        // spin on an LDS word inside the phase: every wave of the workgroup is resident, and the helpers wait for nothing).
+        // fast-chain only: one call 2.13 -> 2.02 ms, a share of an 8-GPU run 4.21 -> 4.14 ms, all of fast-chain-large 24.95 -> 24.49 ms;
+        // chain's unit workers also build the certificate's bit masks and are not idle enough (shares 4.68 -> 4.74 ms with it).
+        if (FC && t >= min_blk && t < nblocks && t > 0 && wk >= 0 && wk < 4) {
+            const int4 *gnh = &L.G4[par ^ 1][0][4 * wk][lane];
+            const int4 *pkh = reinterpret_cast<const int4 *>(L.pk) + 4 * wk;
+            int32_t k16 = kTabNone;
+#pragma unroll
+            for (int g4 = 0; g4 < 4; g4++) {
+                const int4 g = gnh[(size_t)g4 * 64], pv = pkh[g4];
+                k16 = max(max(k16, g.x + pv.x), max(g.y + pv.y, max(g.z + pv.z, g.w + pv.w)));
+            }
+            atomicMax(&L.near_key[lane], k16);
+            if (lane == 0) atomicAdd(&L.near_cnt, 1);        // (behind the wave's atomic max: a wave's LDS operations execute in order)
+        }
+#endif
         if (wave == 0) {
             if (t >= min_blk && t < nblocks) {
                 // ------------------------------------------------ main wave: block t
@@ -555,7 +582,18 @@ void ctab_fold(const ChainWork *__restrict__ work, const TabCall *__restrict__ c
                 int32_t key = fg >= 0 ? max(initkey, fbest << 7) : initkey;      // far: code 0 (loses a tie against anything newer)
                 const int4 *gn = &L.G4[par ^ 1][0][0][lane];
                 const int4 *gb = &L.G4[par ^ 1][1][0][lane];
+#if GAB_TAB_NEAR_HELP
+                if (FC && t > 0) {
+                    near_target += 4;
+                    while (__hip_atomic_load(&L.near_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < near_target) __builtin_amdgcn_s_sleep(1);
+                    asm volatile("" ::: "memory");
+                    key = max(key, __hip_atomic_load(&L.near_key[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+                    L.near_key[lane] = kTabNone;
+                }
+                if (!FC && t > 0) {
+#else
                 if (t > 0 && !GAB_KO_MAIN_NEAR) {
+#endif
 #if GAB_TAB_NEAR_LDS
                     // (the previous block's scores come back from LDS as broadcasts, four per 16-byte read, instead of 64 v_readlane:
                     // the main wave is the phase's critical path, 93 % busy -- GAB_CHAIN_TRACE)
@@ -845,6 +883,9 @@ void ctab_fold(const ChainWork *__restrict__ work, const TabCall *__restrict__ c
             }
 #if GAB_TAB_MERGE_ATOMIC
             if (threadIdx.x < 128) (&L.part64[0][0])[threadIdx.x] = LLONG_MIN;      // what the abandoned phases left in the merge slots
+            if (threadIdx.x < 64) L.near_key[threadIdx.x] = kTabNone;
+            if (threadIdx.x == 0) L.near_cnt = 0;
+            near_target = 0;
             __syncthreads();
 #endif
             t = R - 2;                                       // (the loop makes it R - 1: the workers take block R, the main wave follows)
