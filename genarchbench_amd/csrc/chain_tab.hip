@@ -393,6 +393,12 @@ constexpr int kTabMaxPatch = 8;            // anchors of a call whose result max
 #ifndef GAB_TAB_NEAR_HELP
 #define GAB_TAB_NEAR_HELP 1
 #endif
+#ifndef GAB_TAB_NEAR_HELP_FC      // who folds the previous block's rows: 0 the main wave, 4 the unit workers, 8 the far workers
+#define GAB_TAB_NEAR_HELP_FC 4
+#endif
+#ifndef GAB_TAB_NEAR_HELP_CH
+#define GAB_TAB_NEAR_HELP_CH 0
+#endif
 #ifndef GAB_TAB_MERGE_ATOMIC
 #define GAB_TAB_MERGE_ATOMIC 1
 #endif
@@ -542,12 +548,16 @@ void ctab_fold(const ChainWork *__restrict__ work, const TabCall *__restrict__ c
         // spin on an LDS word inside the phase: every wave of the workgroup is resident, and the helpers wait for nothing).
         // fast-chain only: one call 2.13 -> 2.02 ms, a share of an 8-GPU run 4.21 -> 4.14 ms, all of fast-chain-large 24.95 -> 24.49 ms;
         // chain's unit workers also build the certificate's bit masks and are not idle enough (shares 4.68 -> 4.74 ms with it).
-        if (FC && t >= min_blk && t < nblocks && t > 0 && wk >= 0 && wk < 4) {
-            const int4 *gnh = &L.G4[par ^ 1][0][4 * wk][lane];
-            const int4 *pkh = reinterpret_cast<const int4 *>(L.pk) + 4 * wk;
+        // (kHelp = 4: the unit workers, sixteen rows each; 8: the far workers, eight rows each; 0: the main wave itself)
+        constexpr int kHelp = FC ? GAB_TAB_NEAR_HELP_FC : GAB_TAB_NEAR_HELP_CH;
+        const int hk = kHelp == 4 ? wk : wk - 4;                 // which helper this wave is
+        if (kHelp && t >= min_blk && t < nblocks && t > 0 && hk >= 0 && hk < kHelp) {
+            constexpr int kPer = 16 / (kHelp ? kHelp : 1);       // int4 words (of four rows) per helper
+            const int4 *gnh = &L.G4[par ^ 1][0][kPer * hk][lane];
+            const int4 *pkh = reinterpret_cast<const int4 *>(L.pk) + kPer * hk;
             int32_t k16 = kTabNone;
 #pragma unroll
-            for (int g4 = 0; g4 < 4; g4++) {
+            for (int g4 = 0; g4 < kPer; g4++) {
                 const int4 g = gnh[(size_t)g4 * 64], pv = pkh[g4];
                 k16 = max(max(k16, g.x + pv.x), max(g.y + pv.y, max(g.z + pv.z, g.w + pv.w)));
             }
@@ -583,14 +593,15 @@ void ctab_fold(const ChainWork *__restrict__ work, const TabCall *__restrict__ c
                 const int4 *gn = &L.G4[par ^ 1][0][0][lane];
                 const int4 *gb = &L.G4[par ^ 1][1][0][lane];
 #if GAB_TAB_NEAR_HELP
-                if (FC && t > 0) {
-                    near_target += 4;
+                constexpr int kHelpM = FC ? GAB_TAB_NEAR_HELP_FC : GAB_TAB_NEAR_HELP_CH;
+                if (kHelpM && t > 0) {
+                    near_target += kHelpM;
                     while (__hip_atomic_load(&L.near_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < near_target) __builtin_amdgcn_s_sleep(1);
                     asm volatile("" ::: "memory");
                     key = max(key, __hip_atomic_load(&L.near_key[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
                     L.near_key[lane] = kTabNone;
                 }
-                if (!FC && t > 0) {
+                if (!kHelpM && t > 0) {
 #else
                 if (t > 0 && !GAB_KO_MAIN_NEAR) {
 #endif
