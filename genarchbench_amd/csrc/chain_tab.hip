@@ -443,12 +443,13 @@ __device__ __forceinline__ int ctab_nonzero_bytes(uint32_t w) {
     return __popc((((w & 0x7f7f7f7fu) + 0x7f7f7f7fu) | w) & 0x80808080u);
 }
 
-template <int MODE>
+template <int MODE, bool TRACE>      // TRACE: GAB_CHAIN_TRACE's cycle counters and stamps (a variant of its own: they cost the loop eight scalar registers)
 __global__ __launch_bounds__(64 * (2 + kTabW))
 void ctab_fold(const ChainWork *__restrict__ work, const TabCall *__restrict__ calls, const TabBlock *__restrict__ blocks, uint32_t *bail,
                const uint4 *__restrict__ T8, const int32_t *__restrict__ st_all, const uint64_t *__restrict__ xs, const uint64_t *__restrict__ ys,
                int32_t *score_out, int32_t *parent_out, int32_t *gmarks_all, unsigned long long *evals_out,
-               TabCounters *ct, unsigned long long *dbg, int32_t *host_score, int32_t *host_parent) {
+               TabCounters *ct, unsigned long long *dbg_arg, int32_t *host_score, int32_t *host_parent) {
+    unsigned long long *const dbg = TRACE ? dbg_arg : nullptr;
     constexpr bool FC = MODE == GAB_FASTCHAIN;
     constexpr int NF = kTabFW;
     extern __shared__ __attribute__((aligned(16))) uint8_t tab_lds_raw[];
@@ -930,8 +931,10 @@ int chain_tab_setup() {
     static std::once_flag once;
     static int rc = GAB_OK;
     std::call_once(once, [] {
-        if (hipFuncSetAttribute((const void *)ctab_fold<GAB_CHAIN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(TabLds)) != hipSuccess ||
-            hipFuncSetAttribute((const void *)ctab_fold<GAB_FASTCHAIN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(TabLds)) != hipSuccess) {
+        if (hipFuncSetAttribute((const void *)ctab_fold<GAB_CHAIN, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(TabLds)) != hipSuccess ||
+            hipFuncSetAttribute((const void *)ctab_fold<GAB_FASTCHAIN, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(TabLds)) != hipSuccess ||
+            hipFuncSetAttribute((const void *)ctab_fold<GAB_CHAIN, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(TabLds)) != hipSuccess ||
+            hipFuncSetAttribute((const void *)ctab_fold<GAB_FASTCHAIN, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(TabLds)) != hipSuccess) {
             gab_set_error("chain table form: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed"); rc = GAB_EDEVICE;
         }
     });
@@ -1069,10 +1072,10 @@ int chain_tab_run(ChainTab *t, const gab_tuning &tun, int mode, hipStream_t s, c
         hipLaunchKernelGGL((ctab_geo<GAB_CHAIN, false>), dim3(nbk), dim3(256), 0, s, d_work, (const TabCall *)d_calls, (const TabBlock *)d_blocks, bail,
                            (const int32_t *)d_gtab, (const int32_t *)d_st, d_x, d_y, d_T8);
     if (mode == GAB_CHAIN)
-        hipLaunchKernelGGL(ctab_fold<GAB_CHAIN>, dim3(nc), dim3(64 * (2 + kTabW)), sizeof(TabLds), sf, d_work, (const TabCall *)d_calls, (const TabBlock *)d_blocks, bail,
+        hipLaunchKernelGGL((d_dbg ? ctab_fold<GAB_CHAIN, true> : ctab_fold<GAB_CHAIN, false>), dim3(nc), dim3(64 * (2 + kTabW)), sizeof(TabLds), sf, d_work, (const TabCall *)d_calls, (const TabBlock *)d_blocks, bail,
                            (const uint4 *)d_T8, (const int32_t *)d_st, d_x, d_y, d_score, d_parent, d_gm, d_evals, d_ct, d_dbg, host_score, host_parent);
     else
-        hipLaunchKernelGGL(ctab_fold<GAB_FASTCHAIN>, dim3(nc), dim3(64 * (2 + kTabW)), sizeof(TabLds), sf, d_work, (const TabCall *)d_calls, (const TabBlock *)d_blocks, bail,
+        hipLaunchKernelGGL((d_dbg ? ctab_fold<GAB_FASTCHAIN, true> : ctab_fold<GAB_FASTCHAIN, false>), dim3(nc), dim3(64 * (2 + kTabW)), sizeof(TabLds), sf, d_work, (const TabCall *)d_calls, (const TabBlock *)d_blocks, bail,
                            (const uint4 *)d_T8, (const int32_t *)d_st, d_x, d_y, d_score, d_parent, d_gm, d_evals, d_ct, d_dbg, host_score, host_parent);
     GAB_HIP(hipGetLastError());
     return GAB_OK;
