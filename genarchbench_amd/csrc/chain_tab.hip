@@ -378,8 +378,8 @@ __global__ __launch_bounds__(256) void ctab_geo(const ChainWork *__restrict__ wo
 // memory (3.4 us per block, 3.2 ms for one 60 000-anchor call; the table is complete before this kernel starts, so reading
 // ahead is free of any ordering concern).
 #ifndef GAB_TAB_W
-#define GAB_TAB_W 12
-#endif
+#define GAB_TAB_W 14      // (12 until the last day of r04: once the main wave had shed the merge and -- fast-chain -- the previous block's rows, the
+#endif                 //  far workers were the phase's longest waves: 14 = sixteen waves, the most a workgroup can hold; chain share 4.73 -> 4.58 ms)
 constexpr int kTabW = GAB_TAB_W;          // worker waves (-DGAB_TAB_W=..: tuning builds): four close the block's own rows, the others take the far groups and the previous block's rows
 constexpr int kTabFW = kTabW - 4;         // ... the far workers
 static_assert(kTabFW >= 2, "the table form needs at least two far workers");
