@@ -2004,7 +2004,14 @@ static int chain_run_device_impl(gab_chain *h, int mode, const uint64_t *d_x, co
         // the FASTER form for calls of a few thousand anchors and more, whatever the batch -- all of fast-chain-large on one GPU with
         // the calls of >= 40 000 / 25 000 / 12 500 / 4 096 / 2 048 / 512 / 1 anchors there: 27.87 / 27.09 / 26.15 / 25.88-25.95 / 26.16 / 26.48 /
         // 26.65 ms against 27.65 without.  chain: 29.2 / 28.4 / 27.9 / 28.2 against 27.8 -- it keeps the rule above.
-        if (mode == GAB_FASTCHAIN) min_n = std::min<int64_t>(min_n, 4096);
+        // (not when the results are also written through to host memory, gab_chain_run_device_through: the fold then produces 0.6 GB
+        // of results in its 10 ms and is held to the link's ~40 GB/s -- 16.5 ms -- while the throughput form spreads the same bytes
+        // over its 27 ms: the fast-chain driver's region of interest 32.3 ms against 29.8)
+        if (mode == GAB_FASTCHAIN && !hs) min_n = std::min<int64_t>(min_n, 4096);
+        // chain: with the fold of the end of the round (far maxima merged by LDS atomics, fourteen workers) its longest calls gain too, less:
+        // all of chain-large on one GPU with the calls of >= 30 000 / 20 000 / 16 000 / 12 500 / 8 192 / 6 000 anchors there: 27.86 / 26.99 /
+        // 26.83 / 27.01 / 27.23 / 27.13 ms against 27.82 without
+        else if (mode == GAB_CHAIN) min_n = std::min<int64_t>(min_n, 16000);
         if (h->tun.chain_tab_min >= 0) min_n = h->tun.chain_tab_min;      // GAB_CHAIN_TAB_MIN
         while (ntab < nw && wk[ntab].n >= min_n) { tab_anchors += wk[ntab].n; ntab++; }
     }
@@ -2541,7 +2548,7 @@ extern "C" int gab_chain_reserve_mode(gab_chain *h, int mode, int64_t max_anchor
     rc = gab_chain_run_device(h, mode, d_x, d_y, &off, &hd, 1, d_s, d_p, s);
     h->have_stats = had;
     if (rc) return rc;
-    if (mode == GAB_FASTCHAIN && h->tun.chain_tab != 0) rc = chain_tab_prealloc(&h->tab, max_anchors, max_calls);
+    if (h->tun.chain_tab != 0) rc = chain_tab_prealloc(&h->tab, max_anchors, max_calls);
     return rc;
 }
 
