@@ -39,7 +39,7 @@ HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec 
 # HBM traffic of the dominant kernel(s) of a workload's LARGE configuration, measured once per round with rocprofv3 PMC
 # counters in separate passes (tools/profiling/hbm_traffic.sh -> profiles/<ROUND>_hbm_traffic.json); `double_fetch`: the
 # kernel reads wide coalesced streams, for which gfx950's FETCH_SIZE reports half the bytes (MI355X_MICROARCH.md, HBM)
-TRAFFIC_KERNELS = {"bsw": (["bsw_dp8"], False), "chain": (["chain_block_kernel", "chain_facts_kernel"], False), "fast-chain": (["ctab_geo<1", "ctab_fold<1", "fastchain_kernel"], False),
+TRAFFIC_KERNELS = {"bsw": (["bsw_dp8"], False), "chain": (["chain_block_kernel", "chain_facts_kernel", "ctab_geo<0", "ctab_fold<0"], False), "fast-chain": (["ctab_geo<1", "ctab_fold<1", "fastchain_kernel"], False),
                    "bpm": (["bpm_score32<", "bpm_score<"], False), "bitpal": (["bitpal_dp<true, true>"], False), "bitpal-edit": (["bitpal_edit_bv<"], False), "wfa": (["wfa_lds_static<16, false>"], False), "fmi": (["fmi_seed_kernel<true>"], False),
                    "fmi-sa": (["fmi_sa_kernel"], False), "parse-bsw": (["nl_count", "nl_fill", "bsw_meta", "bsw_codes", "len_offsets",
                                                                        "len_block_sums"], True)}
@@ -317,7 +317,8 @@ class ChainWorkload:
     default_items = 10_000          # calls per GPU (chain-large: c_elegans 10k calls)
     seed = 5
     ref_exe = "chain_ref"
-    kernel = "chain_block_kernel"
+    # r04: calls of >= 16 000 anchors run in the table form (chain_tab.hip: geometry + fold), the rest in chain_block_kernel beside them
+    kernel = "chain_block_kernel (calls < 16000 anchors), ctab_geo<0, false> + ctab_fold<0> (the rest)"
 
     def __init__(self, items, rank, dev, first=0, ids=None):
         import torch
