@@ -37,6 +37,7 @@
 #include "gab_internal.h"
 #include "chain_dev.h"
 #include <algorithm>
+#include <type_traits>
 #include <limits.h>
 #include <vector>
 #include <stdlib.h>
@@ -539,6 +540,12 @@ void ctab_fold(const ChainWork *__restrict__ work, const TabCall *__restrict__ c
     __syncthreads();
 
     unsigned long long busy = 0, t_all = dbg ? clock64() : 0;      // (GAB_CHAIN_TRACE: cycles of every wave outside the barrier, call 0 only)
+    // The loop over the phases exists THREE times, once per role (a generic lambda instantiated for the main wave, the resolver and
+    // the workers): in one shared loop the values of every role were live for all sixteen waves and the chain instantiation
+    // spilled 106 scalar registers into VGPR lanes, reloaded by v_readlane on the main wave's critical path.  Every copy runs the
+    // same phases and the same barriers.
+    auto phases = [&](auto role_tag) {
+    constexpr int ROLE = decltype(role_tag)::value;          // 0 main wave, 1 resolver, 2 workers
     for (int t = -1; t <= nblocks + 1; t++) {
         const int par = (t + 1) & 1;                         // slot of block t + 1 in the two-deep arrays; block t lives in par ^ 1
         const unsigned long long t_in = dbg ? clock64() : 0;
@@ -552,7 +559,7 @@ void ctab_fold(const ChainWork *__restrict__ work, const TabCall *__restrict__ c
         // (kHelp = 4: the unit workers, sixteen rows each; 8: the far workers, eight rows each; 0: the main wave itself)
         constexpr int kHelp = FC ? GAB_TAB_NEAR_HELP_FC : GAB_TAB_NEAR_HELP_CH;
         const int hk = kHelp == 4 ? wk : wk - 4;                 // which helper this wave is
-        if (kHelp && t >= min_blk && t < nblocks && t > 0 && hk >= 0 && hk < kHelp) {
+        if (ROLE == 2 && kHelp && t >= min_blk && t < nblocks && t > 0 && hk >= 0 && hk < kHelp) {
             constexpr int kPer = 16 / (kHelp ? kHelp : 1);       // int4 words (of four rows) per helper
             const int4 *gnh = &L.G4[par ^ 1][0][kPer * hk][lane];
             const int4 *pkh = reinterpret_cast<const int4 *>(L.pk) + kPer * hk;
@@ -566,7 +573,7 @@ void ctab_fold(const ChainWork *__restrict__ work, const TabCall *__restrict__ c
             if (lane == 0) atomicAdd(&L.near_cnt, 1);        // (behind the wave's atomic max: a wave's LDS operations execute in order)
         }
 #endif
-        if (wave == 0) {
+        if constexpr (ROLE == 0) {
             if (t >= min_blk && t < nblocks) {
                 // ------------------------------------------------ main wave: block t
                 const int i0 = t * 64;
@@ -653,7 +660,7 @@ void ctab_fold(const ChainWork *__restrict__ work, const TabCall *__restrict__ c
                 L.pk[lane] = best << 7;
 #endif
             }
-        } else if (wave == 1) {
+        } else if constexpr (ROLE == 1) {
             // ------------------------------------------------ resolver: parents (chain: and the certificate), two blocks behind
 #ifdef GAB_KO_TAB_RES
             if (false) {
@@ -883,13 +890,13 @@ void ctab_fold(const ChainWork *__restrict__ work, const TabCall *__restrict__ c
             __syncthreads();                                 // (everybody has read the two words)
             if (threadIdx.x == 0) L.stop[t & 1] = 0;
             min_blk = R;
-            if (wave == 0) {
+            if constexpr (ROLE == 0) {
                 pbest = R > 0 ? L.ring[(R * 64 - 64 + lane) & (kTabRing - 1)] + bias : 0;
 #if GAB_TAB_NEAR_LDS
                 L.pk[lane] = pbest << 7;
 #endif
                 qs_next = R * 64 + lane < n ? (int32_t)(Y[R * 64 + lane] >> 32 & 0xff) : 0;
-            } else if (wave >= 2) {
+            } else if constexpr (ROLE == 2) {
                 d_cur = desc_of(R); d_nxt = desc_of(R + 1);
                 prefetch(d_cur, R);
             }
@@ -903,6 +910,10 @@ void ctab_fold(const ChainWork *__restrict__ work, const TabCall *__restrict__ c
             t = R - 2;                                       // (the loop makes it R - 1: the workers take block R, the main wave follows)
         }
     }
+    };
+    if (wave == 0) phases(std::integral_constant<int, 0>{});
+    else if (wave == 1) phases(std::integral_constant<int, 1>{});
+    else phases(std::integral_constant<int, 2>{});
     if (dbg && c == 0 && lane == 0) { dbg[2 * wave] = busy; dbg[2 * wave + 1] = clock64() - t_all; }
     if (dbg && threadIdx.x == 0) dbg[32 + 3 * (size_t)c + 2] = wall_clock64();
     if (wave == 1 && !stopped) {
