@@ -16,6 +16,26 @@ void gab_set_error(const char *fmt, ...) {
 }
 
 extern "C" const char *gab_version(void) { return "gab-hip 0.1 (gfx950)"; }
+
+// $GAB_ABORT_TRACE=1 (diagnosis): a SIGABRT anywhere in the process -- the HIP runtime's own abort(), a C++ exception nobody
+// caught -- prints the native call stack to stderr before the default action takes over.  Installed when the library is loaded.
+#include <execinfo.h>
+#include <signal.h>
+#include <unistd.h>
+namespace {
+void gab_abort_trace(int sig) {
+    void *frames[64];
+    const int n = backtrace(frames, 64);
+    static const char msg[] = "[gab] SIGABRT -- native stack:\n";
+    (void)!write(2, msg, sizeof msg - 1);
+    backtrace_symbols_fd(frames, n, 2);
+    signal(sig, SIG_DFL);
+    raise(sig);
+}
+struct GabAbortTraceInit {
+    GabAbortTraceInit() { const char *e = getenv("GAB_ABORT_TRACE"); if (e && *e && atoi(e)) signal(SIGABRT, gab_abort_trace); }
+} gab_abort_trace_init;
+}  // namespace
 extern "C" const char *gab_last_error(void) { return g_err; }
 
 extern "C" int gab_device_count(void) {

@@ -22,6 +22,9 @@ os.environ.setdefault("OMP_NUM_THREADS", str(_cpu_quota()))
 # the library reads its experiment knobs (GAB_* switches) once per handle; the tests flip them between calls of one handle
 # (gab_internal.h: gab_tuning) -- test_bsw_gpu.py::test_knobs_are_read_when_the_handle_is_made covers the shipping behaviour
 os.environ.setdefault("GAB_TUNING_LIVE", "1")
+# a SIGABRT inside the library or the HIP runtime prints its native call stack (gab_core.hip): one of ~10 full GPU runs of r04 ended in a
+# bare "Fatal Python error: Aborted" inside gab_fmi_seed that 24 repetitions of the fmi tests and three more full runs did not show again
+os.environ.setdefault("GAB_ABORT_TRACE", "1")
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
