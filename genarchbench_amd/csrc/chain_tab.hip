@@ -545,7 +545,9 @@ void ctab_fold(const ChainWork *__restrict__ work, const TabCall *__restrict__ c
     // spilled 106 scalar registers into VGPR lanes, reloaded by v_readlane on the main wave's critical path.  Every copy runs the
     // same phases and the same barriers.
     auto phases = [&](auto role_tag) {
-    constexpr int ROLE = decltype(role_tag)::value;          // 0 main wave, 1 resolver, 2 workers
+    constexpr int ROLE = decltype(role_tag)::value;          // 0 main wave, 1 resolver, 2 unit workers (wk < 4), 3 far workers
+    if (ROLE == 2) __builtin_assume(wk >= 0 && wk < 4);
+    if (ROLE == 3) __builtin_assume(wk >= 4);
     for (int t = -1; t <= nblocks + 1; t++) {
         const int par = (t + 1) & 1;                         // slot of block t + 1 in the two-deep arrays; block t lives in par ^ 1
         const unsigned long long t_in = dbg ? clock64() : 0;
@@ -559,7 +561,7 @@ void ctab_fold(const ChainWork *__restrict__ work, const TabCall *__restrict__ c
         // (kHelp = 4: the unit workers, sixteen rows each; 8: the far workers, eight rows each; 0: the main wave itself)
         constexpr int kHelp = FC ? GAB_TAB_NEAR_HELP_FC : GAB_TAB_NEAR_HELP_CH;
         const int hk = kHelp == 4 ? wk : wk - 4;                 // which helper this wave is
-        if (ROLE == 2 && kHelp && t >= min_blk && t < nblocks && t > 0 && hk >= 0 && hk < kHelp) {
+        if (ROLE >= 2 && kHelp && t >= min_blk && t < nblocks && t > 0 && hk >= 0 && hk < kHelp) {
             constexpr int kPer = 16 / (kHelp ? kHelp : 1);       // int4 words (of four rows) per helper
             const int4 *gnh = &L.G4[par ^ 1][0][kPer * hk][lane];
             const int4 *pkh = reinterpret_cast<const int4 *>(L.pk) + kPer * hk;
@@ -896,7 +898,7 @@ void ctab_fold(const ChainWork *__restrict__ work, const TabCall *__restrict__ c
                 L.pk[lane] = pbest << 7;
 #endif
                 qs_next = R * 64 + lane < n ? (int32_t)(Y[R * 64 + lane] >> 32 & 0xff) : 0;
-            } else if constexpr (ROLE == 2) {
+            } else if constexpr (ROLE >= 2) {
                 d_cur = desc_of(R); d_nxt = desc_of(R + 1);
                 prefetch(d_cur, R);
             }
@@ -913,7 +915,8 @@ void ctab_fold(const ChainWork *__restrict__ work, const TabCall *__restrict__ c
     };
     if (wave == 0) phases(std::integral_constant<int, 0>{});
     else if (wave == 1) phases(std::integral_constant<int, 1>{});
-    else phases(std::integral_constant<int, 2>{});
+    else if (wave < 6) phases(std::integral_constant<int, 2>{});
+    else phases(std::integral_constant<int, 3>{});
     if (dbg && c == 0 && lane == 0) { dbg[2 * wave] = busy; dbg[2 * wave + 1] = clock64() - t_all; }
     if (dbg && threadIdx.x == 0) dbg[32 + 3 * (size_t)c + 2] = wall_clock64();
     if (wave == 1 && !stopped) {
