@@ -547,7 +547,8 @@ void ctab_fold(const ChainWork *__restrict__ work, const TabCall *__restrict__ c
     auto phases = [&](auto role_tag) {
     constexpr int ROLE = decltype(role_tag)::value;          // 0 main wave, 1 resolver, 2 unit workers (wk < 4), 3 far workers
     if (ROLE == 2) __builtin_assume(wk >= 0 && wk < 4);
-    if (ROLE == 3) __builtin_assume(wk >= 4);
+    if (ROLE == 3) __builtin_assume(wk >= 4 && wk < 8);      // far workers that also expand a unit of the previous block
+    if (ROLE == 4) __builtin_assume(wk >= 8);                // far workers that only fold far groups
     for (int t = -1; t <= nblocks + 1; t++) {
         const int par = (t + 1) & 1;                         // slot of block t + 1 in the two-deep arrays; block t lives in par ^ 1
         const unsigned long long t_in = dbg ? clock64() : 0;
@@ -916,7 +917,8 @@ void ctab_fold(const ChainWork *__restrict__ work, const TabCall *__restrict__ c
     if (wave == 0) phases(std::integral_constant<int, 0>{});
     else if (wave == 1) phases(std::integral_constant<int, 1>{});
     else if (wave < 6) phases(std::integral_constant<int, 2>{});
-    else phases(std::integral_constant<int, 3>{});
+    else if (wave < 10) phases(std::integral_constant<int, 3>{});
+    else phases(std::integral_constant<int, 4>{});
     if (dbg && c == 0 && lane == 0) { dbg[2 * wave] = busy; dbg[2 * wave + 1] = clock64() - t_all; }
     if (dbg && threadIdx.x == 0) dbg[32 + 3 * (size_t)c + 2] = wall_clock64();
     if (wave == 1 && !stopped) {
