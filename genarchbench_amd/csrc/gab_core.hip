@@ -18,22 +18,33 @@ void gab_set_error(const char *fmt, ...) {
 extern "C" const char *gab_version(void) { return "gab-hip 0.1 (gfx950)"; }
 
 // $GAB_ABORT_TRACE=1 (diagnosis): a SIGABRT anywhere in the process -- the HIP runtime's own abort(), a C++ exception nobody
-// caught -- prints the native call stack to stderr before the default action takes over.  Installed when the library is loaded.
+// caught -- prints the native call stack to stderr before the default action takes over; $GAB_ABORT_TRACE=<path> appends it to
+// that file instead (a test runner that captures file descriptor 2 swallows the former).  Installed when the library is loaded.
 #include <execinfo.h>
+#include <fcntl.h>
 #include <signal.h>
 #include <unistd.h>
 namespace {
+char gab_abort_trace_path[512];
 void gab_abort_trace(int sig) {
     void *frames[64];
     const int n = backtrace(frames, 64);
     static const char msg[] = "[gab] SIGABRT -- native stack:\n";
-    (void)!write(2, msg, sizeof msg - 1);
-    backtrace_symbols_fd(frames, n, 2);
+    int fd = 2;
+    if (gab_abort_trace_path[0]) { const int f = open(gab_abort_trace_path, O_WRONLY | O_CREAT | O_APPEND, 0644); if (f >= 0) fd = f; }
+    (void)!write(fd, msg, sizeof msg - 1);
+    backtrace_symbols_fd(frames, n, fd);
     signal(sig, SIG_DFL);
     raise(sig);
 }
 struct GabAbortTraceInit {
-    GabAbortTraceInit() { const char *e = getenv("GAB_ABORT_TRACE"); if (e && *e && atoi(e)) signal(SIGABRT, gab_abort_trace); }
+    GabAbortTraceInit() {
+        const char *e = getenv("GAB_ABORT_TRACE");
+        if (!e || !*e || !strcmp(e, "0")) return;
+        if (e[0] == '/' || e[0] == '.') { strncpy(gab_abort_trace_path, e, sizeof gab_abort_trace_path - 1); }
+        void *warm[2]; (void)backtrace(warm, 2);             // (the first call loads libgcc: not inside a signal handler)
+        signal(SIGABRT, gab_abort_trace);
+    }
 } gab_abort_trace_init;
 }  // namespace
 extern "C" const char *gab_last_error(void) { return g_err; }

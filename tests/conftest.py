@@ -24,7 +24,8 @@ os.environ.setdefault("OMP_NUM_THREADS", str(_cpu_quota()))
 os.environ.setdefault("GAB_TUNING_LIVE", "1")
 # a SIGABRT inside the library or the HIP runtime prints its native call stack (gab_core.hip): one of ~10 full GPU runs of r04 ended in a
 # bare "Fatal Python error: Aborted" inside gab_fmi_seed that 24 repetitions of the fmi tests and three more full runs did not show again
-os.environ.setdefault("GAB_ABORT_TRACE", "1")
+os.environ.setdefault("GAB_ABORT_TRACE", os.path.join(ROOT, "gpurun_out", "abort_trace.log"))      # (a file: pytest captures fd 2)
+os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
