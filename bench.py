@@ -28,6 +28,10 @@ import time
 
 import numpy as np
 
+# before anything starts the HIP runtime: pageable arrays are staged, not pinned in place (genarchbench_amd/__init__.py says why;
+# nothing inside a timed region copies from pageable memory)
+os.environ.setdefault("GPU_PINNED_MIN_XFER_SIZE", "1000000")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -2012,7 +2012,8 @@ static int chain_run_device_impl(gab_chain *h, int mode, const uint64_t *d_x, co
         // all of chain-large on one GPU with the calls of >= 30 000 / 20 000 / 16 000 / 12 500 / 8 192 / 6 000 anchors there: 27.86 / 26.99 /
         // 26.83 / 27.01 / 27.23 / 27.13 ms against 27.82 without; and once the fold's loop existed per role: 16 000 / 10 000 / 6 000 / 4 096 /
         // 2 048 anchors 25.04 / 24.89 / 24.85 / 24.90 / 25.00 ms
-        // (written through, the same holds as for fast-chain: the chain driver's region of interest 31.8 ms with this rule, 28.2-28.9 without)
+        // (written through, the same holds as for fast-chain: the chain driver's region of interest 31.8 ms with the 8 192 rule, 31.2-32.2 ms
+        // with a 16 000 rule -- the faster fold of the end of the round makes the burst of results shorter still --, 29.0-29.1 ms without)
         else if (mode == GAB_CHAIN && !hs) min_n = std::min<int64_t>(min_n, 8192);
         if (h->tun.chain_tab_min >= 0) min_n = h->tun.chain_tab_min;      // GAB_CHAIN_TAB_MIN
         while (ntab < nw && wk[ntab].n >= min_n) { tab_anchors += wk[ntab].n; ntab++; }

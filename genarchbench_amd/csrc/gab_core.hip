@@ -23,6 +23,7 @@ extern "C" const char *gab_version(void) { return "gab-hip 0.1 (gfx950)"; }
 #include <execinfo.h>
 #include <fcntl.h>
 #include <signal.h>
+#include <sys/stat.h>
 #include <unistd.h>
 namespace {
 char gab_abort_trace_path[512];
@@ -34,6 +35,16 @@ void gab_abort_trace(int sig) {
     if (gab_abort_trace_path[0]) { const int f = open(gab_abort_trace_path, O_WRONLY | O_CREAT | O_APPEND, 0644); if (f >= 0) fd = f; }
     (void)!write(fd, msg, sizeof msg - 1);
     backtrace_symbols_fd(frames, n, fd);
+    // what the aborting code printed: under a test runner file descriptor 2 is a temporary FILE, lost with the process -- its tail
+    // goes into the trace (the HSA runtime names the faulting address and the reason there)
+    struct stat st;
+    if (fd != 2 && fstat(2, &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0) {
+        static char tail[2048];
+        const off_t from = st.st_size > (off_t)sizeof tail ? st.st_size - (off_t)sizeof tail : 0;
+        const ssize_t got = pread(2, tail, sizeof tail, from);
+        static const char hdr[] = "[gab] the end of what file descriptor 2 holds:\n";
+        if (got > 0) { (void)!write(fd, hdr, sizeof hdr - 1); (void)!write(fd, tail, (size_t)got); (void)!write(fd, "\n", 1); }
+    }
     signal(sig, SIG_DFL);
     raise(sig);
 }

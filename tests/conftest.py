@@ -26,6 +26,14 @@ os.environ.setdefault("GAB_TUNING_LIVE", "1")
 # bare "Fatal Python error: Aborted" inside gab_fmi_seed that 24 repetitions of the fmi tests and three more full runs did not show again
 os.environ.setdefault("GAB_ABORT_TRACE", os.path.join(ROOT, "gpurun_out", "abort_trace.log"))      # (a file: pytest captures fd 2)
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+# What those aborts were (the trace of the third: libhsa-runtime64's event thread -> abort, i.e. a GPU memory fault): by default
+# the HIP runtime PINS pageable host memory in place for copies of more than 1 MiB ("HSA Copy Using Pinned resource", rocblit.cpp) and
+# keeps the last few pins cached per queue.  A test process frees such an array and gets the next one of the same size at the SAME
+# address: the cached pin -- or a gab_host_register of the new array, which the driver layer merges with the registration it still
+# has for that address -- then refers to pages that are gone; if the kernel driver's re-validation runs in the window between the
+# unmap and the new mapping, the GPU mapping stays invalid and the next copy or written-through store faults.  Staging every
+# pageable copy (a very large minimum size for pinned transfers, MiB) leaves no such pins behind -- set before the runtime starts.
+os.environ.setdefault("GPU_PINNED_MIN_XFER_SIZE", "1000000")
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
