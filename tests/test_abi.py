@@ -50,3 +50,35 @@ def test_product_never_imports_oracle():
                     if re.search(r"pyoracle|liboracle|oracle/|oracle\.h", txt):
                         bad.append(os.path.join(dp, fn))
     assert not bad, bad
+
+
+def test_pageable_copies_are_staged_by_default():
+    """importing the package sets the HIP runtime's minimum size for pinned transfers (a default: the caller's value wins) before the
+    runtime starts -- pageable numpy arrays are then staged, not pinned in place (genarchbench_amd/__init__.py, DESIGN.md lesson 16)"""
+    import subprocess
+    import sys
+    code = "import os; os.environ.pop('GPU_PINNED_MIN_XFER_SIZE', None); import genarchbench_amd; print(os.environ['GPU_PINNED_MIN_XFER_SIZE'])"
+    assert subprocess.check_output([sys.executable, "-c", code], cwd=ROOT, text=True).strip() == "1000000"
+    code = "import os; os.environ['GPU_PINNED_MIN_XFER_SIZE'] = '64'; import genarchbench_amd; print(os.environ['GPU_PINNED_MIN_XFER_SIZE'])"
+    assert subprocess.check_output([sys.executable, "-c", code], cwd=ROOT, text=True).strip() == "64"
+
+
+def test_abort_trace_keeps_the_stack_and_the_end_of_a_captured_stderr(tmp_path):
+    """GAB_ABORT_TRACE=<file>: a SIGABRT anywhere in the process appends its native stack to the file and, when file descriptor 2 is
+    a regular file (a test runner's capture), the end of that file too -- the HSA runtime's fault message would otherwise die with
+    the process (gab_core.hip)"""
+    import signal
+    import subprocess
+    import sys
+    trace = tmp_path / "trace.log"
+    code = ("import os, ctypes, tempfile\n"
+            "f = tempfile.TemporaryFile(); os.dup2(f.fileno(), 2)\n"
+            "os.write(2, b'Memory access fault by GPU node-9 (a line written by the test)\\n')\n"
+            "import genarchbench_amd; genarchbench_amd.lib()\n"
+            "ctypes.CDLL(None).abort()\n")
+    env = dict(os.environ, GAB_ABORT_TRACE=str(trace))
+    p = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env)
+    assert p.returncode == -signal.SIGABRT
+    text = trace.read_text()
+    assert "[gab] SIGABRT -- native stack:" in text and "abort" in text
+    assert "Memory access fault by GPU node-9 (a line written by the test)" in text
