@@ -2,6 +2,7 @@
 // latency form, the host side; chain_tab.hip: the table form).  Everything here has internal linkage.
 #pragma once
 #include "gab_internal.h"
+#include <vector>
 
 struct ChainWork {                        // one call, device-side descriptor
     int64_t off, n;                       // first anchor in the DEVICE arrays (x, y, score, parent, marks), number of anchors
@@ -196,6 +197,8 @@ struct ChainTab {
     gab_devbuf table;      // the geometry tables: 1 KB per 16 predecessors x 64 anchors
     gab_devbuf dbg;        // GAB_CHAIN_TRACE only
     size_t table_budget = 0;   // bytes the table may take (0: decided at the first call)
+    std::vector<unsigned char> host_calls;   // the host side of `calls` for the copy: outlives chain_tab_run (the caller synchronises later,
+                                             // and a copy of more than 1 MiB from pageable memory is a DMA from the vector itself)
     void release() { calls.release(); blocks.release(); gtab.release(); st.release(); table.release(); dbg.release(); }
 };
 // Runs the first `nsplit` calls of the (device) work list `d_work` -- `h_work` is the same list on the host -- through the table

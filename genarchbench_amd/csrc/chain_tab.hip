@@ -1011,7 +1011,8 @@ int chain_tab_run(ChainTab *t, const gab_tuning &tun, int mode, hipStream_t s, c
     int rc = chain_tab_setup();
     if (rc) return rc;
     // host side of the call table: blocks, gap-table offsets
-    std::vector<TabCall> hc(nsplit);
+    t->host_calls.resize(sizeof(TabCall) * nsplit);
+    TabCall *const hc = reinterpret_cast<TabCall *>(t->host_calls.data());
     int64_t nblocks = 0, gt = 0;
     bool any_mseg = false;
     for (size_t k = 0; k < nsplit; k++) {
@@ -1053,7 +1054,7 @@ int chain_tab_run(ChainTab *t, const gab_tuning &tun, int mode, hipStream_t s, c
     int32_t *d_gtab = t->gtab.as<int32_t>(), *d_st = t->st.as<int32_t>();
     uint4 *d_T8 = t->table.as<uint4>();
     *d_bail = bail;
-    GAB_HIP(hipMemcpyAsync(d_calls, hc.data(), sizeof(TabCall) * nsplit, hipMemcpyHostToDevice, s));      // (pageable: staged before the call returns)
+    GAB_HIP(hipMemcpyAsync(d_calls, hc, sizeof(TabCall) * nsplit, hipMemcpyHostToDevice, s));      // (t->host_calls: alive until the handle's next run)
     GAB_HIP(hipMemsetAsync(d_ct, 0, 512, s));
     unsigned long long *d_dbg = nullptr;       // GAB_CHAIN_TRACE: per-wave cycle counts of call 0's fold, then start / ready / end of every call's workgroup
     if (tun.chain_trace) {
