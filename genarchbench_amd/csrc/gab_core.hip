@@ -1,4 +1,5 @@
 // libgab_hip.so -- library-level entry points (version, error reporting, device probing).
+#define GAB_NO_COPY_MACROS      // (this unit defines gab_memcpy / gab_memcpy_async on top of the runtime's calls)
 #include "gab_internal.h"
 #include <string.h>
 #include <stdlib.h>
@@ -157,7 +158,7 @@ extern "C" int gab_device_copy_to_host(int device, void *dst, const void *d_src,
     gab_device_guard g(device);
     // (asynchronous copy + wait: the synchronous call moved the 40 MB of bsw-large's scores into page-locked memory in ~9 ms,
     // a tenth of the link's rate -- the drivers' GPU-parse paths end their region of interest with this copy)
-    GAB_HIP(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, nullptr));
+    GAB_HIP(gab_memcpy_async(dst, d_src, bytes, hipMemcpyDeviceToHost, nullptr));
     GAB_HIP(hipStreamSynchronize(nullptr));
     return GAB_OK;
 }
@@ -243,3 +244,73 @@ int gab_warm_copy_engines(hipStream_t s, void *dev, size_t dev_bytes) {
     return GAB_OK;
 }
 
+// ---- pageable host memory through page-locked buffers of the library's own ($GAB_STAGE_PAGEABLE=1; gab_internal.h says why) -----
+namespace {
+constexpr size_t kBounceBytes = (size_t)8 << 20, kBounceMin = (size_t)1 << 20;
+struct GabBounce {
+    std::mutex mu;
+    void *buf[2] = {nullptr, nullptr};
+    hipEvent_t ev[2] = {nullptr, nullptr};       // the last transfer that used buf[k]
+    bool used[2] = {false, false};
+    bool ready() {
+        for (int k = 0; k < 2; k++) {
+            if (!buf[k] && hipHostMalloc(&buf[k], kBounceBytes, hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); buf[k] = nullptr; return false; }
+            if (!ev[k] && hipEventCreateWithFlags(&ev[k], hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); ev[k] = nullptr; return false; }
+        }
+        return true;
+    }
+};
+GabBounce g_bounce[64];
+bool gab_stage_pageable() {
+    static const bool on = [] { const char *e = getenv("GAB_STAGE_PAGEABLE"); return e && *e && strcmp(e, "0") != 0; }();
+    return on;
+}
+}  // namespace
+
+hipError_t gab_memcpy_async(void *dst, const void *src, size_t bytes, hipMemcpyKind kind, hipStream_t s) {
+    if (!gab_stage_pageable() || bytes <= kBounceMin || (kind != hipMemcpyHostToDevice && kind != hipMemcpyDeviceToHost))
+        return hipMemcpyAsync(dst, src, bytes, kind, s);
+    const bool h2d = kind == hipMemcpyHostToDevice;
+    if (gab_is_pinned(h2d ? src : dst)) return hipMemcpyAsync(dst, src, bytes, kind, s);
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { (void)hipGetLastError(); return hipMemcpyAsync(dst, src, bytes, kind, s); }
+    GabBounce &B = g_bounce[dev];
+    std::lock_guard<std::mutex> gate(B.mu);
+    if (!B.ready()) return hipMemcpyAsync(dst, src, bytes, kind, s);       // no page-locked memory left: the runtime's own way
+    hipError_t e = hipSuccess;
+    int k = 0, pk = -1;                 // pk: the chunk of a device-to-host copy still to be moved out of its buffer
+    size_t poff = 0, pn = 0;
+    for (size_t off = 0; off < bytes; k ^= 1) {
+        const size_t n = std::min(kBounceBytes, bytes - off);
+        if (B.used[k] && (e = hipEventSynchronize(B.ev[k])) != hipSuccess) return e;
+        if (h2d) {
+            memcpy(B.buf[k], (const char *)src + off, n);
+            if ((e = hipMemcpyAsync((char *)dst + off, B.buf[k], n, kind, s)) != hipSuccess) return e;
+        } else {
+            if ((e = hipMemcpyAsync(B.buf[k], (const char *)src + off, n, kind, s)) != hipSuccess) return e;
+        }
+        if ((e = hipEventRecord(B.ev[k], s)) != hipSuccess) return e;
+        B.used[k] = true;
+        if (!h2d) {
+            if (pk >= 0) {
+                if ((e = hipEventSynchronize(B.ev[pk])) != hipSuccess) return e;
+                memcpy((char *)dst + poff, B.buf[pk], pn);
+            }
+            pk = k; poff = off; pn = n;
+        }
+        off += n;
+    }
+    if (pk >= 0) {
+        if ((e = hipEventSynchronize(B.ev[pk])) != hipSuccess) return e;
+        memcpy((char *)dst + poff, B.buf[pk], pn);
+    }
+    return hipSuccess;
+}
+
+hipError_t gab_memcpy(void *dst, const void *src, size_t bytes, hipMemcpyKind kind) {
+    if (!gab_stage_pageable() || bytes <= kBounceMin || (kind != hipMemcpyHostToDevice && kind != hipMemcpyDeviceToHost) ||
+        gab_is_pinned(kind == hipMemcpyHostToDevice ? src : dst))
+        return hipMemcpy(dst, src, bytes, kind);
+    const hipError_t e = gab_memcpy_async(dst, src, bytes, kind, nullptr);
+    return e != hipSuccess ? e : hipStreamSynchronize(nullptr);
+}

@@ -135,3 +135,18 @@ __device__ __forceinline__ uint32_t gab_wave_slot(uint32_t *counter, bool active
     base = __shfl(base, leader);
     return base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
 }
+
+// ---- copies from / to PAGEABLE host memory ---------------------------------------------------------------------------------------
+// For copies of more than 1 MiB the HIP runtime pins pageable memory IN PLACE and keeps the pins cached; a caller that frees such a
+// buffer and gets the same address again can meet a pin whose pages are gone -- a GPU memory fault (lesson 16).
+// $GAB_STAGE_PAGEABLE=1 (read once per process): every copy of this library of more than 1 MiB from or to host memory that is
+// NOT page-locked goes through two page-locked 8 MiB buffers of the library's own instead (per GPU, shared by its handles), so
+// that nothing of the caller's is ever pinned.  Such a copy has consumed (host to device) or filled (device to host) the caller's
+// buffer when it returns.  Page-locked memory (gab_host_alloc, gab_host_register) and small copies take the runtime's call as is.
+// Every hipMemcpy / hipMemcpyAsync of the library's translation units is one of these (the macros below).
+hipError_t gab_memcpy_async(void *dst, const void *src, size_t bytes, hipMemcpyKind kind, hipStream_t s);
+hipError_t gab_memcpy(void *dst, const void *src, size_t bytes, hipMemcpyKind kind);
+#ifndef GAB_NO_COPY_MACROS
+#define hipMemcpyAsync gab_memcpy_async
+#define hipMemcpy gab_memcpy
+#endif
