@@ -82,3 +82,21 @@ def test_abort_trace_keeps_the_stack_and_the_end_of_a_captured_stderr(tmp_path):
     text = trace.read_text()
     assert "[gab] SIGABRT -- native stack:" in text and "abort" in text
     assert "Memory access fault by GPU node-9 (a line written by the test)" in text
+
+
+def test_every_copy_of_the_library_goes_through_its_wrappers():
+    """gab_internal.h turns hipMemcpy / hipMemcpyAsync of the library's translation units into gab_memcpy / gab_memcpy_async (pageable
+    memory staged by the library under GAB_STAGE_PAGEABLE=1); only gab_core.hip, which defines them, may opt out"""
+    import glob
+    csrc = os.path.join(ROOT, "genarchbench_amd", "csrc")
+    hdr = open(os.path.join(csrc, "gab_internal.h")).read()
+    assert "#define hipMemcpyAsync gab_memcpy_async" in hdr and "#define hipMemcpy gab_memcpy" in hdr
+    units = sorted(glob.glob(os.path.join(csrc, "*.hip")))
+    assert len(units) >= 8
+    for u in units:
+        src = open(u).read()
+        assert '#include "gab_internal.h"' in src or '#include "chain_dev.h"' in src, u
+        assert ("GAB_NO_COPY_MACROS" in src) == (os.path.basename(u) == "gab_core.hip"), u
+        assert not re.search(r"\bhipMemcpy(2D|3D|Peer|DtoH|HtoD)\w*\s*\(", src), f"{u}: a copy call the wrappers do not cover"
+    lib = genarchbench_amd.lib()
+    assert hasattr(lib, "gab_memcpy") and hasattr(lib, "gab_memcpy_async")
