@@ -1465,7 +1465,7 @@ extern "C" int gab_fmi_seed(gab_fmi *h, const uint8_t *enc, int32_t stride, cons
 
 extern "C" void gab_fmi_free(gab_smem *p) { free(p); }
 
-// The reference's worker threads write their SMEMs into per-thread arrays allocated before the ROI (fmi/fmi.cpp:236-247)
+// The reference's worker threads write their SMEMs into per-thread arrays allocated before the ROI (fmi/fmi.cpp:242, 253-257: sized by a per-thread quota, allocated at the start of the parallel region)
 // and grow them when a batch does not fit (:277-286); this is the same contract with the caller's buffer, which may be
 // page-locked (gab_host_alloc / gab_host_register) so that the result comes back as one DMA at the full link rate.
 extern "C" int gab_fmi_seed_into(gab_fmi *h, const uint8_t *enc, int32_t stride, const int32_t *len, int64_t nreads,

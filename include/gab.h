@@ -326,7 +326,7 @@ int gab_fmi_seed(gab_fmi *h, const uint8_t *enc, int32_t stride, const int32_t *
                  int32_t min_seed_len, gab_smem **out, int64_t *nout);
 void gab_fmi_free(gab_smem *p);
 /* same, into the CALLER's array of `capacity` records -- how the reference's threads collect their SMEMs: per-thread arrays
- * allocated before the region of interest and grown when a batch does not fit (fmi/fmi.cpp:236-247, 277-286).  Page-lock
+ * allocated before the region of interest and grown when a batch does not fit (fmi/fmi.cpp:242, 253-257, 277-286).  Page-lock
  * the array (gab_host_alloc / gab_host_register) and the result arrives as one DMA at the link rate instead of through
  * the runtime's staging of pageable memory.  *nout = SMEMs found; when that exceeds `capacity` nothing is written and the
  * call returns GAB_ERANGE: grow the array to *nout and call again. */
