@@ -1,4 +1,4 @@
-"""Host-side mirror of benchmark_bitpal_m0_x1_g1 / benchmark_bitpal_m1_x4_g2 (bpm/benchmark/benchmark_bitpal.c:30-55)
+"""Host-side mirror of benchmark_bitpal_m0_x1_g1 / benchmark_bitpal_m1_x4_g2 (bpm/benchmark/benchmark_bitpal.c:30-54)
 over the C ABI: the bpm driver's `-a bitpal-edit` / `-a bitpal-scored`."""
 import ctypes as C
 

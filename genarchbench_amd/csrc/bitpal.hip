@@ -1,7 +1,7 @@
 // bitpal -- global alignment scores of the bpm benchmark's BitPAl algorithms on gfx950.
 //
 // Semantics: benchmark_bitpal_m0_x1_g1 / benchmark_bitpal_m1_x4_g2,
-//   /root/reference/benchmarks/bpm/benchmark/benchmark_bitpal.c:30-55, selected by the driver's
+//   /root/reference/benchmarks/bpm/benchmark/benchmark_bitpal.c:30-54, selected by the driver's
 //   `-a bitpal-edit` / `-a bitpal-scored` (bpm/tools/align_benchmark.c:259-264, 330-338).  They call the generated
 //   bit-vector programs bpm/bitpal/bitpal.m0.x1.g1.c / bitpal.m1.x4.g2.c, whose result is the Needleman-Wunsch score
 //   of the two strings: global, linear gap cost, characters compared as raw bytes, with

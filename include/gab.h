@@ -202,7 +202,7 @@ int gab_bpm_last_stats(gab_bpm *h, int64_t *block_steps, int64_t *full_pairs,
  * Replaces  it->score = benchmark_bitpal_m0_x1_g1(&align_input)   (-a bitpal-edit)
  *           it->score = benchmark_bitpal_m1_x4_g2(&align_input)   (-a bitpal-scored)
  *                                                    bpm/tools/align_benchmark.c:259-264, 330-338
- *           (bpm/benchmark/benchmark_bitpal.c:30-55; generated kernels bpm/bitpal/bitpal.m0.x1.g1.c,
+ *           (bpm/benchmark/benchmark_bitpal.c:30-54; generated kernels bpm/bitpal/bitpal.m0.x1.g1.c,
  *            bpm/bitpal/bitpal.m1.x4.g2.c).
  * score_out[i] = the Needleman-Wunsch score of pair i: global, linear gaps, raw-byte comparison, with
  * (match, mismatch, gap) = (0, -1, -1) for GAB_BITPAL_EDIT and (+1, -4, -2) for GAB_BITPAL_SCORED --

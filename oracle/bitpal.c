@@ -2,7 +2,7 @@
  *
  * The bpm benchmark's BitPAl algorithms, as `align_benchmark -a bitpal-edit | bitpal-scored` computes the printed
  * score:  benchmark_bitpal_m0_x1_g1 / benchmark_bitpal_m1_x4_g2
- *   (/root/reference/benchmarks/bpm/benchmark/benchmark_bitpal.c:30-55), which run the generated bit-vector programs
+ *   (/root/reference/benchmarks/bpm/benchmark/benchmark_bitpal.c:30-54), which run the generated bit-vector programs
  *   bpm/bitpal/bitpal.m0.x1.g1.c:31-282 and bpm/bitpal/bitpal.m1.x4.g2.c.  Those programs encode, 63 columns per word,
  *   the row-to-row differences of the global alignment matrix with (match, mismatch, gap) = (0,-1,-1) resp. (+1,-4,-2)
  *   -- characters indexed as raw bytes (bitpal.m0.x1.g1.c:136-146), first row and column = multiples of the gap

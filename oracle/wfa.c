@@ -155,7 +155,7 @@ int oracle_wfa_one(const oracle_wfa_penalties *pen, const char *pattern, int ple
         while (v > 0 && h > 0 && s > 0) {
             if (!valid) {
                 valid = VALID(k, offset);
-                if (valid) {                      /* trailing gap, backtrace.c:47-63 */
+                if (valid) {                      /* trailing gap, affine_wavefront_backtrace.c:48-63 */
                     if (k < ak) for (int i = k; i < ak; i++) PUT('I');
                     else if (k > ak) for (int i = ak; i < k; i++) PUT('D');
                 }
