@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Every `path/file.ext:line[-line]` citation of the reference in the headers, the oracle, the library sources and the documents:
 does the file exist under the reference's benchmarks/ tree and does it have that many lines?  (Build container only: the reference
-is not on the GPU box.)    python tools/check_citations.py [/root/reference/benchmarks]"""
+is not on the GPU box.)    python tests/check_citations.py [/root/reference/benchmarks]"""
 import glob
 import os
 import re

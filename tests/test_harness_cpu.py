@@ -79,9 +79,9 @@ def test_invalid_inputs_root_is_an_error(tmp_path):
 @pytest.mark.skipif(not os.path.isdir("/root/reference/benchmarks"), reason="the reference is only in the build container")
 def test_reference_citations_resolve():
     """every `file:line` citation of the reference in include/gab.h, the oracle, the library sources, the drivers and the documents
-    names a file that exists there and lines it has (tools/check_citations.py)"""
+    names a file that exists there and lines it has (tests/check_citations.py)"""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    p = subprocess.run([sys.executable, os.path.join(root, "tools", "check_citations.py")], capture_output=True, text=True)
+    p = subprocess.run([sys.executable, os.path.join(root, "tests", "check_citations.py")], capture_output=True, text=True)
     assert p.returncode == 0, p.stdout[-2000:]
